@@ -1,0 +1,111 @@
+/* afx_device.h -- the thin C interface between the C host objects
+ * (csrc/host) and the HIP layer (csrc/hip).
+ *
+ * The host side is plain C99 and never sees a HIP type: device buffers are
+ * `void*`/`float*` device addresses, streams are opaque `void*`
+ * (a hipStream_t underneath).  Every function returns 0 on success and a
+ * negative status on failure; the text of the last failure is available from
+ * afxdev_last_error().  There is NO CPU fallback anywhere behind this
+ * interface: when no gfx950 device/runtime is usable the calls fail.
+ */
+#ifndef AFX_DEVICE_H
+#define AFX_DEVICE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes returned through the public *_new functions as well */
+#define AFX_OK 0
+#define AFX_ERR_NODEVICE (-2)  /* HIP runtime / device missing            */
+#define AFX_ERR_HIP (-3)       /* a HIP call or kernel launch failed      */
+#define AFX_ERR_UNSUPPORTED (-4) /* parameter combination not implemented */
+#define AFX_ERR_NOMEM (-5)
+#define AFX_ERR_ARG (-6)
+
+/* ---- runtime ---------------------------------------------------------- */
+int afxdev_ensure(void);              /* initialise HIP, select device      */
+const char *afxdev_last_error(void);
+void afxdev_set_error(const char *fmt, ...);
+int afxdev_device_count(void);
+int afxdev_set_device(int ordinal);   /* used by the multi-GPU launcher     */
+
+int afxdev_malloc(void **dptr, size_t bytes);
+void afxdev_free(void *dptr);
+int afxdev_memset(void *dptr, int value, size_t bytes, void *stream);
+int afxdev_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int afxdev_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int afxdev_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int afxdev_stream_create(void **stream);
+void afxdev_stream_destroy(void *stream);
+int afxdev_stream_sync(void *stream);
+
+/* grow-only scratch helper: (re)allocates *dptr when *capacity < bytes */
+int afxdev_reserve(void **dptr, size_t *capacity, size_t bytes);
+
+/* ---- kernels ---------------------------------------------------------- */
+
+/* what the STFT kernel stores per bin */
+enum {
+    AFX_SPEC_COMPLEX = 0, /* re, im                       */
+    AFX_SPEC_POWER = 1,   /* re^2+im^2                    */
+    AFX_SPEC_MAG = 2,     /* sqrt(re^2+im^2)              */
+    AFX_SPEC_SQUARE = 3,  /* (re+j im)^2 = re^2-im^2, 2 re im */
+    AFX_SPEC_POWER_NORM = 4, /* powf(re^2+im^2, normValue) */
+    AFX_SPEC_MAG_NORM = 5    /* powf(sqrt(re^2+im^2), normValue) */
+};
+
+typedef struct {
+    const float *x;        /* device, clip b starts at x + b*clipStride      */
+    long long clipStride;  /* in samples                                      */
+    int batch;             /* clips                                           */
+    int dataLength;        /* samples per clip                                */
+    int timeLength;        /* frames per clip                                 */
+    int radix2Exp;         /* fftLength = 1 << radix2Exp                      */
+    int hop;
+    const float *window;   /* device [fftLength]                              */
+    const float *twiddle;  /* device [fftLength/2] float2: (cos, -sin)(2*pi*m/fftLength)  */
+    int mode;              /* AFX_SPEC_*                                      */
+    float normValue;
+    int binLo;             /* first bin stored                                */
+    int binCount;          /* bins stored per frame (row pitch of the output) */
+    float *outRe;          /* device [batch*timeLength, binCount]             */
+    float *outIm;          /* device, modes COMPLEX/SQUARE only               */
+    float *energy;         /* optional device [batch*timeLength] (or NULL)    */
+    float *rms;
+    float *zcr;
+    /* centre zero padding used by the CQT octaves: frame i covers samples
+     * [i*hop - padLeft, i*hop - padLeft + fftLength) of the clip, reads
+     * outside [0,dataLength) give 0 */
+    int padLeft;
+} AfxStftArgs;
+
+/* generic framed FFT, any radix2Exp in 1..14 */
+int afxk_stft(const AfxStftArgs *a, void *stream);
+
+enum { AFX_MAP_NONE = 0, AFX_MAP_LOG10 = 1, AFX_MAP_CBRT = 2, AFX_MAP_POW = 3 };
+
+/* C[M,N] = post( pre(A)[M,K] * B[N,K]^T ), row-major, f32 MFMA.
+ * pre: AFX_MAP_NONE | LOG10 (log10f(max(a,1e-8))) | CBRT (powf(a,1/3))
+ * post: AFX_MAP_NONE | POW (powf(c, postArg))
+ * lda/ldc are row pitches in floats. */
+int afxk_gemm_nt(const float *A, long long lda, const float *B, int ldb,
+                 float *C, long long ldc, long long M, int N, int K,
+                 int pre, int post, float postArg, void *stream);
+
+/* "standard" cepstra post-pass (xxcc_algorithm.c:244-292): per frame, put
+ * ln(max(energy,1e-8)) in front of / in place of coefficient 0 and take the
+ * causal smoothing-derivative FIR (util_delta, util/flux_util.c:803-815) along
+ * the coefficient axis twice.
+ *   cc[rows, ccNum] -> coe/delta1/delta2 [rows, outLen], outLen = ccNum (+1 if append)
+ *   energyType: 0 replace, 1 append, 2 ignore */
+int afxk_xxcc_standard(const float *cc, const float *energy, long long rows, int ccNum,
+                       int energyType, int deltaLen, float *coe, float *delta1, float *delta2,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFX_DEVICE_H */

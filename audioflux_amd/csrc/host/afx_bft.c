@@ -1,0 +1,420 @@
+/* afx_bft.c -- the BFT object (C host side) behind include/bft_algorithm.h.
+ *
+ * Mirrors the parameter semantics of the reference object
+ * (src/bft_algorithm.c:87-626): defaults, range checks, status codes, the
+ * low/high frequency revision, getters and result-type switches.  What it does
+ * NOT mirror is the execution: instead of STFT -> [T,N] complex scratch ->
+ * crop -> square -> serial matmul on the CPU, a call uploads the clip(s),
+ * launches the framed-FFT kernel (spectrum values computed in its epilogue)
+ * and the MFMA filter-bank GEMM on this object's HIP stream, and downloads the
+ * [T,num] result.  There is no CPU compute path.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "afx_batch.h"
+#include "afx_device.h"
+#include "afx_host.h"
+#include "afx_objects.h"
+#include "bft_algorithm.h"
+
+/* largest [frames, F] spectrum scratch one launch may use; larger batches are
+ * processed in clip chunks (the fused kernel needs no such scratch) */
+static size_t scratch_budget_bytes(void) {
+    const char *s = getenv("AFX_SCRATCH_MB");
+    size_t mb = 2048;
+    if (s && atoi(s) > 0) mb = (size_t)atoi(s);
+    return mb << 20;
+}
+
+int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *lowFre,
+               float *highFre, int *binPerOctave, WindowType *windowType, int *slideLength,
+               SpectralFilterBankScaleType *filterScaleType,
+               SpectralFilterBankStyleType *filterStyleType,
+               SpectralFilterBankNormalType *filterNormalType, SpectralDataType *dataType,
+               int *isReassign, int *isTemporal) {
+    int r = 12, sr = 32000, bpo = 12, hop, fftLength;
+    float low = 0, high = 0;
+    int lowIndex = 0, highIndex = 0;
+    WindowType win = Window_Hann;
+    SpectralDataType dtype = SpectralData_Power;
+    SpectralFilterBankScaleType scale = SpectralFilterBankScale_Linear;
+    SpectralFilterBankStyleType style = SpectralFilterBankStyle_Slaney;
+    SpectralFilterBankNormalType normal = SpectralFilterBankNormal_None;
+
+    if (!bftObj) return -1;
+    *bftObj = NULL;
+
+    /* --- validation & defaults, in the reference's order (bft_algorithm.c:122-243) */
+    if (radix2Exp) {
+        r = radix2Exp;
+        if (r < 1 || r > 30) {
+            printf("radix2Exp is error!\n");
+            return -100;
+        }
+    }
+    fftLength = 1 << r;
+    if (samplate && *samplate > 0 && *samplate <= 196000) sr = *samplate;
+    if (dataType) dtype = *dataType;
+    if (filterScaleType) {
+        scale = *filterScaleType;
+        if ((int)scale > (int)SpectralFilterBankScale_Log) {
+            printf("scaleType is error!\n");
+            return 1;
+        }
+    }
+    if (filterStyleType) style = *filterStyleType;
+    if (filterNormalType) normal = *filterNormalType;
+
+    high = (float)(sr / 2.0);
+    if (lowFre && *lowFre >= 0 && *lowFre < sr / 2.0) low = *lowFre;
+    const int logLike =
+        (scale == SpectralFilterBankScale_Octave || scale == SpectralFilterBankScale_Log);
+    if (low == 0 && logLike) {
+        low = (float)(powf(2, (float)(-45 / 12.0)) * 440);
+        high = (float)(powf(2, (float)(38 / 12.0)) * 440);
+    }
+    if (highFre && *highFre > 0 && *highFre <= sr / 2.0) high = *highFre;
+    if (high < low) {
+        low = 0;
+        high = (float)(sr / 2.0);
+        if (logLike) {
+            low = (float)(powf(2, (float)(-45 / 12.0)) * 440);
+            high = (float)(powf(2, (float)(38 / 12.0)) * 440);
+        }
+    }
+    if (binPerOctave && *binPerOctave >= 4 && *binPerOctave <= 48) bpo = *binPerOctave;
+    if (windowType) win = *windowType;
+    hop = fftLength / 4;
+    if (slideLength && *slideLength > 0) hop = *slideLength;
+
+    if (scale == SpectralFilterBankScale_Linear) {
+        float det = sr / (float)fftLength;
+        afx_auditory_revise_linear(num, low, high, det, 1, &low, &high);
+        lowIndex = (int)roundf(low / det);
+        highIndex = (int)roundf(high / det);
+        if (high > sr / 2.0) {
+            printf("scale linear: lowFre and num is large, overflow error\n");
+            return -1;
+        }
+    } else if (scale == SpectralFilterBankScale_Octave) {
+        afx_auditory_revise_log(num, low, high, bpo, 1, &low, &high);
+        if (high > sr / 2.0) {
+            printf("scale log: lowFre and num is large, overflow error!\n");
+            return -1;
+        }
+    }
+    if (num < 2 || num > fftLength / 2 + 1) {
+        printf("num is error!\n");
+        return -1;
+    }
+    if (isReassign && *isReassign) {
+        /* time-frequency reassignment is a scatter pass outside this round's
+         * scope; refuse instead of computing something else */
+        afxdev_set_error("bftObj_new: isReassign=1 is not implemented by the MI355X backend");
+        return AFX_ERR_UNSUPPORTED;
+    }
+    if (r > 14) {
+        afxdev_set_error("bftObj_new: fftLength 2^%d exceeds the on-chip FFT limit 2^14", r);
+        return AFX_ERR_UNSUPPORTED;
+    }
+
+    int st = afxdev_ensure();
+    if (st != AFX_OK) return st;
+
+    BFTObj o = (BFTObj)calloc(1, sizeof(struct OpaqueBFT));
+    if (!o) return AFX_ERR_NOMEM;
+    o->fftLength = fftLength;
+    o->radix2Exp = r;
+    o->F = fftLength / 2 + 1;
+    o->num = num;
+    o->samplate = sr;
+    o->lowFre = low;
+    o->highFre = high;
+    o->lowIndex = lowIndex;
+    o->highIndex = highIndex;
+    o->binPerOctave = bpo;
+    o->windowType = win;
+    o->slideLength = hop;
+    o->dataType = dtype;
+    o->scale = scale;
+    o->style = style;
+    o->normal = normal;
+    o->normValue = 1;
+    o->isTemporal = isTemporal ? *isTemporal : 0;
+
+    /* --- host-side plan: window, band arrays, bank (bft_algorithm.c:278-389) */
+    float *hWindow = afx_window_fft(win, fftLength);
+    float *hTw = afx_twiddle_table(fftLength);
+    float *hBank = NULL;
+    o->freBandArr = (float *)calloc((size_t)num + 2, sizeof(float));
+    o->binBandArr = (int *)calloc((size_t)num + 2, sizeof(int));
+    if (!hWindow || !hTw || !o->freBandArr || !o->binBandArr) st = AFX_ERR_NOMEM;
+
+    if (st == AFX_OK) {
+        if (scale == SpectralFilterBankScale_Linear) {
+            float det = sr / (float)fftLength;
+            for (int i = lowIndex, j = 0; i <= highIndex && j < num + 2; i++, j++) {
+                o->freBandArr[j] = i * det;
+                o->binBandArr[j] = i;
+            }
+        } else {
+            hBank = (float *)calloc((size_t)num * o->F, sizeof(float));
+            if (!hBank) {
+                st = AFX_ERR_NOMEM;
+            } else {
+                afx_auditory_bank(num, fftLength, sr, scale, style, normal, low, high, bpo, hBank,
+                                  o->freBandArr, o->binBandArr);
+            }
+        }
+    }
+
+    /* --- device constants */
+    if (st == AFX_OK) st = afxdev_stream_create(&o->stream);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dWindow, sizeof(float) * fftLength);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTwiddle, sizeof(float) * fftLength);
+    if (st == AFX_OK) st = afxdev_h2d(o->dWindow, hWindow, sizeof(float) * fftLength, o->stream);
+    if (st == AFX_OK)
+        st = afxdev_h2d(o->dTwiddle, hTw, sizeof(float) * (fftLength / 2 > 0 ? fftLength : 2),
+                        o->stream);
+    if (st == AFX_OK && hBank) {
+        st = afxdev_malloc((void **)&o->dBank, sizeof(float) * (size_t)num * o->F);
+        if (st == AFX_OK)
+            st = afxdev_h2d(o->dBank, hBank, sizeof(float) * (size_t)num * o->F, o->stream);
+    }
+    if (st == AFX_OK) st = afx_bft_plan_fast(o, hWindow, hBank);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    free(hWindow);
+    free(hTw);
+    free(hBank);
+    if (st != AFX_OK) {
+        bftObj_free(o);
+        return st;
+    }
+    *bftObj = o;
+    return 0;
+}
+
+int bftObj_calTimeLength(BFTObj o, int dataLength) {
+    /* stftObj_calTimeLength without padding (src/stft_algorithm.c:225-262) */
+    if (!o || dataLength < o->fftLength) return 0;
+    return (dataLength - o->fftLength) / o->slideLength + 1;
+}
+
+float *bftObj_getFreBandArr(BFTObj o) { return o ? o->freBandArr : NULL; }
+int *bftObj_getBinBandArr(BFTObj o) { return o ? o->binBandArr : NULL; }
+
+void bftObj_setResultType(BFTObj o, int type) {
+    if (o) o->resultType = type;
+}
+
+void bftObj_setDataNormValue(BFTObj o, float normValue) {
+    if (o && normValue > 0) o->normValue = normValue;
+}
+
+/* spectrum mode + post-op for the current switches (bft_algorithm.c:457-529) */
+static void pick_modes(const struct OpaqueBFT *o, int *specMode, int *post) {
+    *post = AFX_MAP_NONE;
+    const int linear = (o->scale == SpectralFilterBankScale_Linear);
+    if (!o->resultType) {
+        *specMode = (o->dataType == SpectralData_Power) ? AFX_SPEC_SQUARE : AFX_SPEC_COMPLEX;
+    } else if (o->dataType == SpectralData_Mag) {
+        *specMode = AFX_SPEC_MAG;
+        if (o->normValue != 1) {
+            if (linear) {
+                *specMode = AFX_SPEC_MAG_NORM;
+            } else {
+                *post = AFX_MAP_POW;
+            }
+        }
+    } else {
+        /* any other dataType value falls through the reference's if/else-if as
+         * plain |S|^2 unless it equals Power with a norm exponent */
+        *specMode = AFX_SPEC_POWER;
+        if (o->dataType == SpectralData_Power && o->normValue != 1) *specMode = AFX_SPEC_POWER_NORM;
+    }
+}
+
+/* device-resident core: dData -> dRe (, dIm); dTemporal = 3 planes of frames or NULL */
+int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
+                       long long clipStride, float *dRe, float *dIm, float *dTemporal,
+                       void *stream) {
+    const int T = bftObj_calTimeLength(o, dataLength);
+    if (T <= 0 || batch <= 0) return AFX_OK;
+    int specMode, post;
+    pick_modes(o, &specMode, &post);
+    const int complexOut = !o->resultType;
+    const int linear = (o->scale == SpectralFilterBankScale_Linear);
+    const long long framesAll = (long long)batch * T;
+
+    AfxStftArgs a;
+    memset(&a, 0, sizeof(a));
+    a.clipStride = clipStride;
+    a.dataLength = dataLength;
+    a.timeLength = T;
+    a.radix2Exp = o->radix2Exp;
+    a.hop = o->slideLength;
+    a.window = o->dWindow;
+    a.twiddle = o->dTwiddle;
+    a.mode = specMode;
+    a.normValue = o->normValue;
+
+    if (linear) {
+        /* the "bank" is a bin slice: store straight into the result */
+        int count = o->highIndex - o->lowIndex + 1;
+        if (count > o->num) count = o->num;
+        if (count != o->num) {
+            afxdev_set_error("bft linear: %d bins for num=%d", count, o->num);
+            return AFX_ERR_ARG;
+        }
+        a.x = dData;
+        a.batch = batch;
+        a.binLo = o->lowIndex;
+        a.binCount = o->num;
+        a.outRe = dRe;
+        a.outIm = dIm;
+        if (dTemporal) {
+            a.energy = dTemporal;
+            a.rms = dTemporal + framesAll;
+            a.zcr = dTemporal + 2 * framesAll;
+        }
+        return afxk_stft(&a, stream);
+    }
+
+    /* fused register-resident kernel for the hot configurations */
+    if (!dTemporal) {
+        int used = 0;
+        int st = afx_bft_try_fast(o, dData, batch, dataLength, clipStride, dRe, dIm, stream, &used);
+        if (st != AFX_OK || used) return st;
+    }
+
+    /* generic path: spectrum scratch in HBM, chunked over clips */
+    const int planes = complexOut ? 2 : 1;
+    const size_t perClip = (size_t)T * o->F * sizeof(float) * planes;
+    long long chunk = (long long)(scratch_budget_bytes() / (perClip ? perClip : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    int st = afxdev_reserve((void **)&o->dSpec, &o->capSpec, perClip * (size_t)chunk);
+    if (st != AFX_OK) return st;
+
+    for (long long b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = (int)((batch - b0 < chunk) ? batch - b0 : chunk);
+        const long long frames = (long long)nb * T;
+        a.x = dData + b0 * clipStride;
+        a.batch = nb;
+        a.binLo = 0;
+        a.binCount = o->F;
+        a.outRe = o->dSpec;
+        a.outIm = complexOut ? o->dSpec + frames * o->F : NULL;
+        if (dTemporal) {
+            a.energy = dTemporal + b0 * T;
+            a.rms = dTemporal + framesAll + b0 * T;
+            a.zcr = dTemporal + 2 * framesAll + b0 * T;
+        }
+        st = afxk_stft(&a, stream);
+        if (st != AFX_OK) return st;
+        st = afxk_gemm_nt(a.outRe, o->F, o->dBank, o->F, dRe + b0 * T * o->num, o->num, frames,
+                          o->num, o->F, AFX_MAP_NONE, post, o->normValue, stream);
+        if (st != AFX_OK) return st;
+        if (complexOut) {
+            st = afxk_gemm_nt(a.outIm, o->F, o->dBank, o->F, dIm + b0 * T * o->num, o->num, frames,
+                              o->num, o->F, AFX_MAP_NONE, AFX_MAP_NONE, 1.f, stream);
+            if (st != AFX_OK) return st;
+        }
+    }
+    return AFX_OK;
+}
+
+int bftObj_bftBatchDevice(BFTObj o, const float *dData, int batch, int dataLength,
+                          long long clipStride, float *dReal, float *dImag, void *hipStream) {
+    if (!o || !dData || !dReal) return AFX_ERR_ARG;
+    if (!o->resultType && !dImag) return AFX_ERR_ARG;
+    return afx_bft_run_device(o, dData, batch, dataLength, clipStride, dReal, dImag, NULL,
+                              hipStream ? hipStream : o->stream);
+}
+
+int bftObj_bftBatch(BFTObj o, const float *dataArr, int batch, int dataLength, float *mRealArr3,
+                    float *mImageArr3) {
+    if (!o || !dataArr || dataLength <= 0 || batch <= 0 || !mRealArr3) return AFX_ERR_ARG;
+    const int T = bftObj_calTimeLength(o, dataLength);
+    if (T <= 0) return AFX_OK;
+    const int complexOut = !o->resultType;
+    if (complexOut && !mImageArr3) return AFX_ERR_ARG;
+    const long long frames = (long long)batch * T;
+    const size_t inBytes = sizeof(float) * (size_t)batch * dataLength;
+    const size_t outBytes = sizeof(float) * (size_t)frames * o->num;
+
+    int st = afxdev_reserve((void **)&o->dX, &o->capX, inBytes);
+    if (st == AFX_OK)
+        st = afxdev_reserve((void **)&o->dOut, &o->capOut, outBytes * (complexOut ? 2 : 1));
+    float *dTemporal = NULL;
+    if (st == AFX_OK && o->isTemporal) {
+        st = afxdev_reserve((void **)&o->dTemporal, &o->capTemporal,
+                            sizeof(float) * 3 * (size_t)frames);
+        dTemporal = o->dTemporal;
+    }
+    if (st == AFX_OK) st = afxdev_h2d(o->dX, dataArr, inBytes, o->stream);
+    float *dRe = o->dOut, *dIm = complexOut ? o->dOut + frames * o->num : NULL;
+    if (st == AFX_OK)
+        st = afx_bft_run_device(o, o->dX, batch, dataLength, dataLength, dRe, dIm, dTemporal,
+                                o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mRealArr3, dRe, outBytes, o->stream);
+    if (st == AFX_OK && complexOut) st = afxdev_d2h(mImageArr3, dIm, outBytes, o->stream);
+    if (st == AFX_OK && o->isTemporal) {
+        if (o->hTemporalCap < frames) {
+            free(o->hTemporal);
+            o->hTemporal = (float *)calloc(3 * (size_t)frames, sizeof(float));
+            o->hTemporalCap = o->hTemporal ? (int)frames : 0;
+            if (!o->hTemporal) st = AFX_ERR_NOMEM;
+        }
+        if (st == AFX_OK) {
+            /* keep the three planes contiguous at stride `frames` */
+            st = afxdev_d2h(o->hTemporal, dTemporal, sizeof(float) * 3 * (size_t)frames, o->stream);
+            o->hTemporalFrames = (int)frames;
+        }
+    }
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    o->lastTimeLength = T;
+    return st;
+}
+
+void bftObj_bft(BFTObj o, float *dataArr, int dataLength, float *mRealArr3, float *mImageArr3) {
+    if (!o) {
+        afxdev_set_error("bftObj_bft: NULL object");
+        return;
+    }
+    if (!dataArr || dataLength <= 0) return; /* stftObj_stft returns silently (stft_algorithm.c:267-269) */
+    int st = bftObj_bftBatch(o, dataArr, 1, dataLength, mRealArr3, mImageArr3);
+    if (st != AFX_OK) {
+        o->status = st;
+        fprintf(stderr, "[audioflux_mi355x] bftObj_bft failed (%d): %s\n", st, afxdev_last_error());
+    }
+}
+
+void bftObj_getTemporalData(BFTObj o, float **eArr, float **rArr, float **zArr) {
+    if (!o || !o->isTemporal || !o->hTemporal) return;
+    const int n = o->hTemporalFrames;
+    if (eArr) *eArr = o->hTemporal;
+    if (rArr) *rArr = o->hTemporal + n;
+    if (zArr) *zArr = o->hTemporal + 2 * n;
+}
+
+void bftObj_free(BFTObj o) {
+    if (!o) return;
+    if (o->stream) afxdev_stream_sync(o->stream);
+    afx_bft_free_fast(o);
+    afxdev_free(o->dWindow);
+    afxdev_free(o->dTwiddle);
+    afxdev_free(o->dBank);
+    afxdev_free(o->dX);
+    afxdev_free(o->dSpec);
+    afxdev_free(o->dOut);
+    afxdev_free(o->dTemporal);
+    afxdev_stream_destroy(o->stream);
+    free(o->freBandArr);
+    free(o->binBandArr);
+    free(o->hTemporal);
+    free(o);
+}

@@ -1,0 +1,50 @@
+/* afx_host.h -- declarations shared by the C host objects.  Setup-time work
+ * (windows, filter banks, DCT matrices, wavelet scales, CQT kernels) is done
+ * here on the host in float32 with the same operation order as the reference
+ * so that band edges / rounding decisions come out identical, then uploaded
+ * once per object.  All per-sample arithmetic runs in the HIP kernels.
+ */
+#ifndef AFX_HOST_H
+#define AFX_HOST_H
+
+#include <stddef.h>
+
+#include "flux_base.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ---- afx_window.c ------------------------------------------------------ */
+/* length-`length` window; periodic != 0 builds the length+1 symmetric window
+ * and drops its last sample.  Kaiser beta / Gauss alpha / Tukey alpha take the
+ * reference defaults (5, 2.5, 0.5).  Returns a malloc'ed array or NULL. */
+float *afx_window_create(WindowType type, int length, int periodic);
+/* the window an STFT of frame length `length` uses (periodic for the cosine
+ * family, symmetric for bartlett/triang/bartlett-hann/bohman) */
+float *afx_window_fft(WindowType type, int length);
+
+/* ---- afx_auditory.c ---------------------------------------------------- */
+/* fills bank[num*(fftLength/2+1)] (must be zeroed), fre[num], bin[num] */
+void afx_auditory_bank(int num, int fftLength, int samplate,
+                       SpectralFilterBankScaleType scale,
+                       SpectralFilterBankStyleType style,
+                       SpectralFilterBankNormalType normal,
+                       float lowFre, float highFre, int binPerOctave,
+                       float *bank, float *fre, int *bin);
+void afx_auditory_revise_linear(int num, float lowFre, float highFre, float detFre, int isEdge,
+                                float *lowOut, float *highOut);
+void afx_auditory_revise_log(int num, float lowFre, float highFre, int binPerOctave, int isEdge,
+                             float *lowOut, float *highOut);
+float afx_fre_to_log(float fre, float binPerOctave);
+float afx_log_to_fre(float value, float binPerOctave);
+
+/* ---- afx_util.c -------------------------------------------------------- */
+float *afx_linspace(float start, float stop, int length, int noStop);
+/* float2 table (cos, -sin)(2*pi*m/n), m < n/2, evaluated in double */
+float *afx_twiddle_table(int n);
+/* orthonormal DCT-II matrix rows 0..rows-1, D[c*num+n] */
+float *afx_dct2_matrix(int num, int rows);
+int afx_is_pow2(int v);
+
+#endif /* AFX_HOST_H */

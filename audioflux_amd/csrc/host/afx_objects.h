@@ -1,0 +1,74 @@
+/* afx_objects.h -- layouts of the opaque handles (library-internal). */
+#ifndef AFX_OBJECTS_H
+#define AFX_OBJECTS_H
+
+#include <stddef.h>
+
+#include "flux_base.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct AfxMelFusedPlan; /* afx_melfused.hip */
+
+struct OpaqueBFT {
+    /* plan */
+    int fftLength, radix2Exp, F, num;
+    int samplate;
+    float lowFre, highFre;
+    int lowIndex, highIndex; /* linear scale: first/last bin */
+    int binPerOctave;
+    WindowType windowType;
+    int slideLength;
+    SpectralDataType dataType;
+    SpectralFilterBankScaleType scale;
+    SpectralFilterBankStyleType style;
+    SpectralFilterBankNormalType normal;
+    int resultType;  /* 0 complex, 1 real */
+    float normValue; /* default 1 */
+    int isTemporal;
+    float *freBandArr; /* host, num+2 */
+    int *binBandArr;
+    /* device constants */
+    void *stream;
+    float *dWindow, *dTwiddle, *dBank;
+    struct AfxMelFusedPlan *fast; /* NULL when the fused kernel does not apply */
+    /* grow-only device scratch of the legacy host-pointer calls */
+    float *dX, *dSpec, *dOut, *dTemporal;
+    size_t capX, capSpec, capOut, capTemporal;
+    /* host copies for bftObj_getTemporalData */
+    float *hTemporal;
+    int hTemporalCap, hTemporalFrames;
+    int lastTimeLength;
+    int status; /* last failure of a void entry point */
+};
+
+struct OpaqueXXCC {
+    int num;
+    int timeLength;
+    void *stream;
+    float *dDct; /* device [num, num] orthonormal DCT-II */
+    float *dIn, *dOut;
+    size_t capIn, capOut;
+    int status;
+};
+
+/* fused-kernel hooks (afx_melfused.hip) */
+int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hBank);
+int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
+                     long long clipStride, float *dRe, float *dIm, void *stream, int *used);
+int afx_bft_try_fast_cc(struct OpaqueBFT *o, struct OpaqueXXCC *x, const float *dData, int batch,
+                        int dataLength, long long clipStride, int ccNum,
+                        CepstralRectifyType *rectifyType, float *dMel, float *dCc, void *stream,
+                        int *used);
+void afx_bft_free_fast(struct OpaqueBFT *o);
+
+int afx_bft_run_device(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
+                       long long clipStride, float *dRe, float *dIm, float *dTemporal,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFX_OBJECTS_H */

@@ -1,0 +1,54 @@
+/* afx_util.c -- small host helpers (linspace, twiddle and DCT tables). */
+#include <math.h>
+#include <stdlib.h>
+
+#include "afx_host.h"
+
+/* float32 linspace with the reference's accumulation arr[i] = start + i*step
+ * (src/vector/flux_vector.c:2145-2162); band edges depend on these bits */
+float *afx_linspace(float start, float stop, int length, int noStop) {
+    float *arr = (float *)calloc((size_t)(length > 0 ? length : 1), sizeof(float));
+    float step;
+    if (!arr) return NULL;
+    if (!noStop) {
+        step = (stop - start) / (length - 1 > 0 ? length - 1 : 1);
+    } else {
+        step = (stop - start) / length;
+    }
+    for (int i = 0; i < length; i++) arr[i] = start + i * step;
+    return arr;
+}
+
+/* (cos, -sin)(2 pi m / n) for m < n/2, interleaved.  The reference builds the
+ * same table with cosf/sinf (src/dsp/fft_algorithm.c:882-891); evaluating in
+ * double and rounding once is at least as accurate. */
+float *afx_twiddle_table(int n) {
+    int half = n / 2 > 0 ? n / 2 : 1;
+    float *t = (float *)malloc(sizeof(float) * 2 * (size_t)half);
+    if (!t) return NULL;
+    for (int m = 0; m < half; m++) {
+        double a = 2.0 * M_PI * (double)m / (double)n;
+        t[2 * m] = (float)cos(a);
+        t[2 * m + 1] = (float)(-sin(a));
+    }
+    return t;
+}
+
+/* orthonormal DCT-II: D[c][n] = s_c cos(pi (2n+1) c / (2 num)),
+ * s_0 = sqrt(1/num), s_c = sqrt(2/num).  Equals what the reference obtains
+ * through its FFT-based DCT (src/dsp/fft_algorithm.c:625-674) or its cosine
+ * matrix (src/dsp/dct_algorithm.c:170-181) with norm enabled. */
+float *afx_dct2_matrix(int num, int rows) {
+    float *d = (float *)malloc(sizeof(float) * (size_t)num * (size_t)rows);
+    if (!d) return NULL;
+    double s0 = sqrt(1.0 / num), s1 = sqrt(2.0 / num);
+    for (int c = 0; c < rows; c++) {
+        for (int n = 0; n < num; n++) {
+            double v = cos(M_PI * (2.0 * n + 1.0) * c / (2.0 * num));
+            d[(size_t)c * num + n] = (float)(v * (c == 0 ? s0 : s1));
+        }
+    }
+    return d;
+}
+
+int afx_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }

@@ -1,0 +1,58 @@
+/* afx_batch.h -- ADDITIVE entry points of libaudioflux_mi355x.so (not part of
+ * the reference API).  The reference interface is one clip per call through
+ * host pointers, which on a GPU is bounded by PCIe and launch latency; these
+ * calls expose the same transforms batched over clips and/or on buffers that
+ * already live in HBM.  Results are identical to looping the legacy call.
+ *
+ * Device pointers are plain `float*` HBM addresses (e.g. torch.Tensor.data_ptr())
+ * and `hipStream` is a hipStream_t passed as void* (NULL = the object's own
+ * stream).  Device variants are asynchronous on that stream; host variants
+ * return with the result in host memory.  All return 0 or a negative status
+ * (see afx_last_error()).
+ */
+#ifndef AFX_BATCH_H
+#define AFX_BATCH_H
+
+#include "bft_algorithm.h"
+#include "feature/xxcc_algorithm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 0 when a gfx950 device is usable; negative otherwise (no CPU fallback exists) */
+int afx_runtime_status(void);
+const char *afx_last_error(void);
+int afx_device_count(void);
+/* bind the calling thread / subsequently created objects to a device ordinal */
+int afx_set_device(int ordinal);
+/* "audioflux_mi355x <version> gfx950" */
+const char *afx_version(void);
+
+/* batch clips of dataLength samples, host pointers:
+ * dataArr[batch*dataLength] -> mRealArr3[batch*T*num] (+ mImageArr3 when the
+ * result type is complex).  Same as calling bftObj_bft per clip. */
+int bftObj_bftBatch(BFTObj bftObj, const float *dataArr, int batch, int dataLength,
+                    float *mRealArr3, float *mImageArr3);
+
+/* the same on HBM-resident buffers; clip b starts at dData + b*clipStride */
+int bftObj_bftBatchDevice(BFTObj bftObj, const float *dData, int batch, int dataLength,
+                          long long clipStride, float *dReal, float *dImag, void *hipStream);
+
+/* cepstral coefficients of rows frames on HBM-resident buffers:
+ * dIn[rows*num] -> dOut[rows*ccNum] */
+int xxccObj_xxccDevice(XXCCObj xxccObj, const float *dIn, long long rows, int ccNum,
+                       CepstralRectifyType *rectifyType, float *dOut, void *hipStream);
+
+/* the north-star path in one call: batched STFT -> filter bank -> cepstra.
+ * dMel (batch*T*num) may be NULL when only the cepstra are wanted;
+ * dCc is batch*T*ccNum.  bft must be in real result mode (type 1). */
+int afx_bftXxccBatchDevice(BFTObj bftObj, XXCCObj xxccObj, const float *dData, int batch,
+                           int dataLength, long long clipStride, int ccNum,
+                           CepstralRectifyType *rectifyType, float *dMel, float *dCc,
+                           void *hipStream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFX_BATCH_H */

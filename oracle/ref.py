@@ -1,0 +1,164 @@
+"""Raw ctypes driver of the compiled reference (oracle/_ref/libaudioflux_ref.so).
+
+TEST INFRASTRUCTURE.  Calls the reference's exported C functions with the same
+arguments the product library receives, so parity tests compare like with like.
+Signatures: /root/reference/src/{bft,cwt,cqt,cepstrogram}_algorithm.h and
+src/feature/xxcc_algorithm.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_PATH = os.path.join(_HERE, "_ref", "libaudioflux_ref.so")
+_lib = None
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+
+
+def available():
+    return os.path.exists(REF_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(REF_PATH)
+    return _lib
+
+
+def _pi(v):
+    return None if v is None else C.pointer(C.c_int(int(v)))
+
+
+def _pf(v):
+    return None if v is None else C.pointer(C.c_float(float(v)))
+
+
+def _f(a):
+    return a.ctypes.data_as(fp)
+
+
+class RefBFT:
+    def __init__(self, num, radix2_exp, samplate=None, low_fre=None, high_fre=None,
+                 bin_per_octave=None, window_type=None, slide_length=None, scale_type=None,
+                 style_type=None, normal_type=None, data_type=None, is_temporal=None):
+        L = lib()
+        self.L = L
+        self.num = num
+        self.obj = C.c_void_p(None)
+        L.bftObj_new.restype = C.c_int
+        L.bftObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, ip, fp, fp, ip, ip, ip,
+                                 ip, ip, ip, ip, ip, ip]
+        self.status = L.bftObj_new(C.byref(self.obj), num, radix2_exp, _pi(samplate), _pf(low_fre),
+                                   _pf(high_fre), _pi(bin_per_octave), _pi(window_type),
+                                   _pi(slide_length), _pi(scale_type), _pi(style_type),
+                                   _pi(normal_type), _pi(data_type), None, _pi(is_temporal))
+        L.bftObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
+        L.bftObj_bft.restype = None
+        L.bftObj_bft.argtypes = [C.c_void_p, fp, C.c_int, fp, fp]
+        L.bftObj_setResultType.argtypes = [C.c_void_p, C.c_int]
+        L.bftObj_setDataNormValue.argtypes = [C.c_void_p, C.c_float]
+        L.bftObj_getFreBandArr.restype = fp
+        L.bftObj_getFreBandArr.argtypes = [C.c_void_p]
+        L.bftObj_getBinBandArr.restype = ip
+        L.bftObj_getBinBandArr.argtypes = [C.c_void_p]
+        L.bftObj_getTemporalData.restype = None
+        L.bftObj_getTemporalData.argtypes = [C.c_void_p, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]
+        L.bftObj_free.argtypes = [C.c_void_p]
+        self.result_type = 0
+
+    def time_length(self, n):
+        return self.L.bftObj_calTimeLength(self.obj, n)
+
+    def set_result_type(self, t):
+        self.L.bftObj_setResultType(self.obj, t)
+        self.result_type = t
+
+    def set_norm(self, v):
+        self.L.bftObj_setDataNormValue(self.obj, v)
+
+    def fre_band(self):
+        return np.ctypeslib.as_array(self.L.bftObj_getFreBandArr(self.obj), (self.num,)).copy()
+
+    def bin_band(self):
+        return np.ctypeslib.as_array(self.L.bftObj_getBinBandArr(self.obj), (self.num,)).copy()
+
+    def bft(self, x):
+        """x[n] float32 -> (re[T,num], im[T,num])"""
+        x = np.ascontiguousarray(x, np.float32)
+        t = self.time_length(x.shape[0])
+        re = np.zeros((t, self.num), np.float32)
+        im = np.zeros((t, self.num), np.float32)
+        self.L.bftObj_bft(self.obj, _f(x), x.shape[0], _f(re), _f(im))
+        return re, im
+
+    def temporal(self, t):
+        e, r, z = fp(), fp(), fp()
+        self.L.bftObj_getTemporalData(self.obj, C.byref(e), C.byref(r), C.byref(z))
+        return tuple(np.ctypeslib.as_array(p, (t,)).copy() for p in (e, r, z))
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.bftObj_free(self.obj)
+            self.obj = C.c_void_p(None)
+
+
+class RefXXCC:
+    def __init__(self, num):
+        L = lib()
+        self.L = L
+        self.num = num
+        self.obj = C.c_void_p(None)
+        L.xxccObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        self.status = L.xxccObj_new(C.byref(self.obj), num)
+        L.xxccObj_setTimeLength.argtypes = [C.c_void_p, C.c_int]
+        L.xxccObj_setTimeLength.restype = None
+        L.xxccObj_xxcc.restype = None
+        L.xxccObj_xxcc.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
+        L.xxccObj_xxccStandard.restype = None
+        L.xxccObj_xxccStandard.argtypes = [C.c_void_p, fp, C.c_int, fp, ip, ip, ip, fp, fp, fp]
+        L.xxccObj_free.argtypes = [C.c_void_p]
+
+    def xxcc(self, m, cc_num=13, rectify=None):
+        """m[T,num] -> [T,cc_num]"""
+        m = np.ascontiguousarray(m, np.float32)
+        t = m.shape[0]
+        out = np.zeros((t, cc_num), np.float32)
+        self.L.xxccObj_setTimeLength(self.obj, t)
+        self.L.xxccObj_xxcc(self.obj, _f(m), cc_num, _pi(rectify), _f(out))
+        return out
+
+    def standard(self, m, energy, cc_num=13, delta_len=None, energy_type=None, rectify=None):
+        m = np.ascontiguousarray(m, np.float32)
+        energy = np.ascontiguousarray(energy, np.float32)
+        t = m.shape[0]
+        n_out = cc_num + (1 if energy_type == 1 else 0)
+        outs = [np.zeros((t, n_out), np.float32) for _ in range(3)]
+        self.L.xxccObj_setTimeLength(self.obj, t)
+        self.L.xxccObj_xxccStandard(self.obj, _f(m), cc_num, _f(energy), _pi(delta_len),
+                                    _pi(energy_type), _pi(rectify), _f(outs[0]), _f(outs[1]),
+                                    _f(outs[2]))
+        return outs
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.xxccObj_free(self.obj)
+            self.obj = C.c_void_p(None)
+
+
+def mel_mfcc(x_clips, num=128, radix2_exp=11, samplate=16000, hop=512, cc_num=13):
+    """reference mel (real power) + MFCC for each clip of x_clips[b,n]; the timed
+    region of BASELINE.md section 3.  Returns (mel[b,T,num], mfcc[b,T,cc])."""
+    bft = RefBFT(num, radix2_exp, samplate=samplate, low_fre=0.0, high_fre=samplate / 2.0,
+                 window_type=1, slide_length=hop, scale_type=2, style_type=0, normal_type=0,
+                 data_type=0)
+    bft.set_result_type(1)
+    cc = RefXXCC(num)
+    mels, ccs = [], []
+    for x in x_clips:
+        re, _ = bft.bft(x)
+        mels.append(re)
+        ccs.append(cc.xxcc(re, cc_num, 0))
+    return np.stack(mels), np.stack(ccs)

@@ -1,0 +1,253 @@
+"""numpy restatement of the reference algorithms on the hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Each function cites the reference
+file:line it follows.  Arithmetic is float64 unless a float32 decision (band
+edges) needs the reference's exact promotion; the restatement is pinned against
+the compiled reference (oracle.ref) and the golden fixtures by
+tests/test_oracle.py, where it must agree to ~1e-6 peak-relative -- the error
+floor of the reference's own float32 FFT.
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# windows -- src/dsp/flux_window.c:890-940 (window_calFFTWindow) and :281-865
+# --------------------------------------------------------------------------
+def _sym_window(kind, n):
+    """symmetric length-n window; every family is 'half formula + mirror'"""
+    i = np.arange(n, dtype=np.float64)
+    d = n - 1
+    if kind == "rect":
+        return np.ones(n)
+    if kind == "hann":  # :738-747
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * i / d)
+    elif kind == "hamm":  # :749-758
+        w = 0.54 - 0.46 * np.cos(2 * np.pi * i / d)
+    elif kind == "blackman":  # :761-770 (end samples forced to 0)
+        w = 0.42 - 0.5 * np.cos(2 * np.pi * i / d) + 0.08 * np.cos(4 * np.pi * i / d)
+        w[0] = w[-1] = 0.0
+    elif kind == "blackman_harris":  # :789-812
+        a = (0.35875, 0.48829, 0.14128, 0.01168)
+        w = a[0] - a[1] * np.cos(2 * np.pi * i / d) + a[2] * np.cos(4 * np.pi * i / d) - a[3] * np.cos(6 * np.pi * i / d)
+    elif kind == "blackman_nuttall":  # :814-837
+        a = (0.3635819, 0.4891775, 0.1365995, 0.0106411)
+        w = a[0] - a[1] * np.cos(2 * np.pi * i / d) + a[2] * np.cos(4 * np.pi * i / d) - a[3] * np.cos(6 * np.pi * i / d)
+    elif kind == "flattop":  # :839-865
+        a = (0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368)
+        w = (a[0] - a[1] * np.cos(2 * np.pi * i / d) + a[2] * np.cos(4 * np.pi * i / d)
+             - a[3] * np.cos(6 * np.pi * i / d) + a[4] * np.cos(8 * np.pi * i / d))
+    elif kind == "bartlett":  # :616-625
+        w = 2.0 * i / d
+    elif kind == "bartlett_hann":  # :628-637
+        w = 0.62 - 0.48 * np.abs(i / d - 0.5) + 0.38 * np.cos(2 * np.pi * (i / d - 0.5))
+        w[0] = w[-1] = 0.0
+    elif kind == "triang":  # :639-660
+        w = 2.0 * (i + (1.0 if n & 1 else 0.5)) / (n + (1 if n & 1 else 0))
+    elif kind == "bohman":  # :773-787
+        l = np.abs(-1.0 + i * (2.0 / d))
+        w = (1 - l) * np.cos(np.pi * l) + np.sin(np.pi * l) / np.pi
+        w[0] = w[-1] = 0.0
+    elif kind == "kaiser":  # :668-716, beta 5, I0 by 15-term series
+        def i0(a):
+            k = np.arange(1, 16)
+            terms = np.cumprod(np.broadcast_to((np.asarray(a)[..., None] / 2) / k, np.shape(a) + (15,)), axis=-1)
+            return 1 + np.sum(terms ** 2, axis=-1)
+        u = 2.0 * i / d - 1
+        w = i0(5.0 * np.sqrt(np.maximum(1 - u * u, 0))) / i0(np.array(5.0))
+    elif kind == "gauss":  # :718-736, alpha 2.5
+        half = (n + 1) // 2 if n & 1 else n // 2 + 1
+        det = 0.0 if n & 1 else 0.5
+        k = half - 1 - i
+        w = np.exp(-0.5 * (2 * 2.5 * (k - det) / (n - 1)) ** 2)
+    elif kind == "tukey":  # :573-614, alpha 0.5; not mirrored
+        a = 0.5
+        x = i / d
+        w = np.ones(n)
+        lo = x < a / 2
+        hi = ~(lo | ((x >= a / 2) & (x < 1 - a / 2)))
+        w[lo] = 0.5 * (1 + np.cos(2 * np.pi / a * (x[lo] - a / 2)))
+        w[hi] = 0.5 * (1 + np.cos(2 * np.pi / a * (x[hi] - 1 + a / 2)))
+        return w
+    else:
+        raise ValueError(kind)
+    half = (n + 1) // 2 if n & 1 else n // 2
+    if kind == "gauss":
+        half = (n + 1) // 2 if n & 1 else n // 2 + 1
+    w[half:] = w[: n - half][::-1]  # mirror (flux_window.c:293-295)
+    return w
+
+
+WINDOW_NAMES = ["rect", "hann", "hamm", "blackman", "kaiser", "bartlett", "triang", "flattop",
+                "gauss", "blackman_harris", "blackman_nuttall", "bartlett_hann", "bohman", "tukey"]
+_SYMMETRIC_ONLY = {"bartlett", "triang", "bartlett_hann", "bohman", "rect"}
+
+
+def fft_window(window_type, n):
+    """window_calFFTWindow: periodic (= symmetric n+1, last dropped) unless the
+    family is symmetric-only"""
+    kind = WINDOW_NAMES[int(window_type)]
+    if n == 1:
+        return np.ones(1)
+    if kind in _SYMMETRIC_ONLY:
+        return _sym_window(kind, n)
+    return _sym_window(kind, n + 1)[:n]
+
+
+# --------------------------------------------------------------------------
+# mel filter bank -- src/filterbank/auditory_filterBank.c:56-207, :594-677
+# (band edges), :435-500 (slaney), :373-426 (etsi).  float32 decisions kept.
+# --------------------------------------------------------------------------
+def _linspace32(start, stop, n):
+    start, stop = f32(start), f32(stop)
+    step = f32((stop - start) / f32(max(n - 1, 1)))
+    return (start + np.arange(n, dtype=f32) * step).astype(f32)  # flux_vector.c:2145-2162
+
+
+def hz_to_mel(f):
+    return f32(2595) * np.log10(f32(1) + np.asarray(f, f32) / f32(700), dtype=f32)  # :1051-1057
+
+
+def mel_to_hz(m):
+    return f32(700) * (np.power(f32(10), np.asarray(m, f32) / f32(2595), dtype=f32) - f32(1))  # :1059-1066
+
+
+def mel_bank(num, fft_length, samplate, low, high, style="slaney", normal="none"):
+    """returns (bank[num, F] float32, centre_hz[num], centre_bin[num])"""
+    F = fft_length // 2 + 1
+    edges = mel_to_hz(_linspace32(hz_to_mel(f32(low)), hz_to_mel(f32(high)), num + 2)).astype(f32)
+    bank = np.zeros((num, F), f32)
+    grid = _linspace32(0, f32(samplate) - f32(samplate) / f32(fft_length), fft_length)
+    if style == "slaney":
+        bins = np.array([int(np.argmax(grid > e)) for e in edges])  # first grid point > edge (:658-666)
+        width = (edges[1:] - edges[:-1]).astype(f32)
+        for i in range(num):
+            j = np.arange(bins[i], min(bins[i + 1], F))
+            bank[i, j] = (grid[j] - edges[i]) / width[i]
+            j = np.arange(bins[i + 1], min(bins[i + 2], F))
+            bank[i, j] = (edges[i + 2] - grid[j]) / width[i + 1]
+    else:  # etsi: triangles on bin indices
+        bins = np.round(f32(fft_length) * edges / f32(samplate)).astype(int)
+        for i in range(1, num + 1):
+            l, c, r = bins[i - 1], bins[i], bins[i + 1]
+            if c > l:
+                j = np.arange(l, c + 1)
+                bank[i - 1, j] = (j - l) / (c - l)
+            j = np.arange(c + 1, r + 1)
+            bank[i - 1, j] = (r - j) / (r - c)
+    if normal == "area":
+        bank = (bank / bank.astype(np.float64).sum(1, keepdims=True).astype(f32)).astype(f32)
+    elif normal == "bandwidth":
+        bank = (bank / ((edges[2:] - edges[:-2]) / f32(2))[:, None]).astype(f32)
+    return bank, edges[1:-1], bins[1:-1]
+
+
+# --------------------------------------------------------------------------
+# STFT / BFT -- src/stft_algorithm.c:696-803, src/bft_algorithm.c:397-540
+# --------------------------------------------------------------------------
+def frames_of(x, fft_length, hop):
+    t = (len(x) - fft_length) // hop + 1 if len(x) >= fft_length else 0  # stft_algorithm.c:225-262
+    idx = np.arange(fft_length)[None, :] + hop * np.arange(t)[:, None]
+    return np.asarray(x, np.float64)[idx]
+
+
+def stft(x, fft_length, hop, window_type=1):
+    """[T, F] complex128: rfft of x[i*hop : i*hop+N] * w (stft_algorithm.c:708-712 +
+    the crop to N/2+1 bins, flux_complex.c:254-286)"""
+    w = fft_window(window_type, fft_length)
+    return np.fft.rfft(frames_of(x, fft_length, hop) * w[None, :], axis=1)
+
+
+def bft(x, bank, fft_length, hop, window_type=1, data_type="power", result_type=1, norm_value=1.0):
+    """bftObj_bft with a filter bank (bft_algorithm.c:456-529).
+    result_type 1 -> real [T,num]; 0 -> complex [T,num]"""
+    S = stft(x, fft_length, hop, window_type)
+    B = bank.astype(np.float64)
+    if result_type == 0:
+        if data_type == "power":
+            S = S * S  # :459-468 (S^2, not |S|^2)
+        return S @ B.T  # __mcdot1, flux_complex.c:53-87
+    P = np.abs(S) ** 2  # __mcsquare
+    if data_type == "mag":
+        P = np.sqrt(P)
+    elif norm_value != 1:
+        P = P ** norm_value
+    out = P @ B.T  # __mdot1, flux_vector.c:55-86 (double accumulate)
+    if data_type == "mag" and norm_value != 1:
+        out = out ** norm_value
+    return out
+
+
+def bft_linear(x, num, fft_length, samplate, hop, low=0.0, window_type=1, data_type="power",
+               result_type=1):
+    """linear scale = bin slice [lowIndex, lowIndex+num) (bft_algorithm.c:209-222, 472-513)"""
+    det = f32(samplate) / f32(fft_length)
+    lo = int(np.round(f32(low) / det))
+    S = stft(x, fft_length, hop, window_type)[:, lo:lo + num]
+    if result_type == 0:
+        return S * S if data_type == "power" else S
+    P = np.abs(S) ** 2
+    return np.sqrt(P) if data_type == "mag" else P
+
+
+def temporal(x, fft_length, hop, window_type=1):
+    """energy / rms / zero-cross-rate of the windowed frames (temporal_algorithm.c:138-144,
+    flux_vector.c:1765-1790)"""
+    fr = frames_of(x, fft_length, hop) * fft_window(window_type, fft_length)[None, :]
+    fr = fr.astype(f32).astype(np.float64)
+    e = (fr ** 2).sum(1)
+    z = ((fr[:, 1:] * fr[:, :-1]) < 0).sum(1) / fft_length
+    return e, np.sqrt(e / fft_length), z
+
+
+# --------------------------------------------------------------------------
+# cepstral coefficients -- src/feature/xxcc_algorithm.c:95-156, 168-296
+# --------------------------------------------------------------------------
+def dct2_ortho(v):
+    """orthonormal DCT-II along the last axis (fft_algorithm.c:625-674 with isNorm,
+    or dct_algorithm.c:81-109): s0 = sqrt(1/M), s = sqrt(2/M)"""
+    m = v.shape[-1]
+    n = np.arange(m)
+    D = np.cos(np.pi * (2 * n[None, :] + 1) * n[:, None] / (2 * m))
+    D *= np.sqrt(2.0 / m)
+    D[0] *= np.sqrt(0.5)
+    return v @ D.T
+
+
+def rectify(m, kind="log"):
+    m = np.asarray(m, np.float64)
+    if kind == "log":
+        return np.log10(np.maximum(m, 1e-8))  # xxcc_algorithm.c:130-139
+    return np.power(m, np.float64(f32(1.0 / 3)))  # :124-128
+
+
+def xxcc(m, cc_num=13, kind="log"):
+    return dct2_ortho(rectify(m, kind))[..., :cc_num]
+
+
+def delta_taps(order):
+    """filterDesign_smooth1 (dsp/filterDesign_fir.c:194-217)"""
+    m = order // 2
+    return np.arange(m, -m - 1, -1) / float(sum(i * i for i in range(1, m + 1)))
+
+
+def delta(row, order):
+    """causal FIR y[i] = sum_{j<=i} b[j] x[i-j] (filterDesign_fir.c:229-248)"""
+    return np.convolve(row, delta_taps(order))[: len(row)]
+
+
+def xxcc_standard(m, energy, cc_num=13, delta_len=9, energy_type="replace", kind="log"):
+    """xxccObj_xxccStandard: deltas run ALONG THE COEFFICIENT AXIS (xxcc_algorithm.c:283-288)"""
+    cc = xxcc(m, cc_num, kind)
+    loge = np.log(np.maximum(np.asarray(energy, np.float64), 1e-8))
+    if energy_type == "replace":
+        coe = cc.copy()
+        coe[:, 0] = loge
+    elif energy_type == "append":
+        coe = np.concatenate([loge[:, None], cc], axis=1)
+    else:
+        coe = cc
+    d1 = np.stack([delta(r, delta_len) for r in coe])
+    d2 = np.stack([delta(r, delta_len) for r in d1])
+    return coe, d1, d2

@@ -1,0 +1,109 @@
+"""Parity cases shared by the golden-vector generator (tests/golden/make_golden.py),
+the oracle tests and the GPU parity tests.  Inputs are regenerated from seeds
+(numpy PCG64 streams are version-stable), so fixtures hold outputs only."""
+import numpy as np
+
+WIN = dict(rect=0, hann=1, hamm=2, blackman=3, kaiser=4, bartlett=5, triang=6, flattop=7, gauss=8,
+           bh=9, bn=10, barthann=11, bohman=12, tukey=13)
+SCALE = dict(linear=0, linspace=1, mel=2, bark=3, erb=4, octave=5, log=6)
+STYLE = dict(slaney=0, etsi=1, gammatone=2, point=3, rect=4, hann=5, hamm=6, blackman=7, bohman=8,
+             kaiser=9, gauss=10)
+NORMAL = dict(none=0, area=1, bandwidth=2)
+
+
+def noise(seed, n, amp=0.1):
+    return (amp * np.random.default_rng(seed).standard_normal(n)).astype(np.float32)
+
+
+def tones(seed, n, sr):
+    """sum of 3 sines + 1e-3 noise (cfg 2 second distribution)"""
+    t = np.arange(n) / sr
+    x = 0.3 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 880 * t) + 0.1 * np.sin(2 * np.pi * 3520 * t)
+    return (x + 1e-3 * np.random.default_rng(seed).standard_normal(n)).astype(np.float32)
+
+
+# name -> dict(ctor kwargs for BFT, input spec, result_type, norm)
+BFT_CASES = {
+    # BASELINE cfg 1: 1 x 5 s mono 16 kHz, n_fft 2048, hop 512, mel-128 slaney power
+    "cfg1_mel_power": dict(num=128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                           window_type=WIN["hann"], slide_length=512, scale_type=SCALE["mel"],
+                           style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=0,
+                           x=("noise", 0, 80000), result_type=1),
+    "cfg1_mel_complex": dict(num=128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                             window_type=WIN["hann"], slide_length=512, scale_type=SCALE["mel"],
+                             style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=0,
+                             x=("noise", 0, 80000), result_type=0),
+    "tones_mel_mag_area": dict(num=80, radix2_exp=10, samplate=16000, low_fre=50.0, high_fre=7600.0,
+                               window_type=WIN["hamm"], slide_length=160, scale_type=SCALE["mel"],
+                               style_type=STYLE["etsi"], normal_type=NORMAL["area"], data_type=1,
+                               x=("tones", 2, 24000), result_type=1),
+    "bark_blackman_bw_norm": dict(num=40, radix2_exp=10, samplate=32000, low_fre=0.0,
+                                  high_fre=16000.0, window_type=WIN["blackman"], slide_length=256,
+                                  scale_type=SCALE["bark"], style_type=STYLE["slaney"],
+                                  normal_type=NORMAL["bandwidth"], data_type=0,
+                                  x=("noise", 5, 20000), result_type=1, norm=0.5),
+    "erb_gammatone_mag": dict(num=32, radix2_exp=9, samplate=16000, low_fre=100.0, high_fre=7000.0,
+                              window_type=WIN["hann"], slide_length=128, scale_type=SCALE["erb"],
+                              style_type=STYLE["gammatone"], normal_type=NORMAL["none"], data_type=1,
+                              x=("noise", 6, 9000), result_type=1, norm=2.0),
+    "octave_hann_style": dict(num=60, radix2_exp=12, samplate=32000, low_fre=32.703,
+                              high_fre=16000.0, bin_per_octave=12, window_type=WIN["kaiser"],
+                              slide_length=1024, scale_type=SCALE["octave"], style_type=STYLE["hann"],
+                              normal_type=NORMAL["none"], data_type=0, x=("tones", 7, 40000),
+                              result_type=1),
+    "linspace_rect_complex_mag": dict(num=64, radix2_exp=8, samplate=8000, low_fre=500.0,
+                                      high_fre=3000.0, window_type=WIN["rect"], slide_length=64,
+                                      scale_type=SCALE["linspace"], style_type=STYLE["rect"],
+                                      normal_type=NORMAL["none"], data_type=1,
+                                      x=("noise", 8, 3000), result_type=0),
+    "linear_slice_power": dict(num=100, radix2_exp=11, samplate=16000, low_fre=1000.0,
+                               high_fre=8000.0, window_type=WIN["gauss"], slide_length=300,
+                               scale_type=SCALE["linear"], style_type=STYLE["slaney"],
+                               normal_type=NORMAL["none"], data_type=0, x=("noise", 9, 30000),
+                               result_type=1),
+    "linear_full_complex": dict(num=257, radix2_exp=9, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                                window_type=WIN["tukey"], slide_length=100,
+                                scale_type=SCALE["linear"], style_type=STYLE["slaney"],
+                                normal_type=NORMAL["none"], data_type=0, x=("tones", 10, 5000),
+                                result_type=0),
+    "log_gauss_small_fft": dict(num=24, radix2_exp=7, samplate=44100, low_fre=800.0,
+                                high_fre=15000.0, window_type=WIN["bohman"], slide_length=32,
+                                scale_type=SCALE["log"], style_type=STYLE["gauss"],
+                                normal_type=NORMAL["area"], data_type=0, x=("noise", 11, 2000),
+                                result_type=1),
+    "mel_temporal": dict(num=64, radix2_exp=10, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                         window_type=WIN["hann"], slide_length=256, scale_type=SCALE["mel"],
+                         style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=0,
+                         is_temporal=1, x=("tones", 12, 12000), result_type=1),
+    "one_frame_exact": dict(num=128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                            window_type=WIN["hann"], slide_length=512, scale_type=SCALE["mel"],
+                            style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=0,
+                            x=("noise", 13, 2048), result_type=1),
+    "ragged_tail": dict(num=128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                        window_type=WIN["hann"], slide_length=512, scale_type=SCALE["mel"],
+                        style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=0,
+                        x=("noise", 14, 2048 + 512 * 3 + 511), result_type=1),
+}
+
+CTOR_KEYS = ("num", "radix2_exp", "samplate", "low_fre", "high_fre", "bin_per_octave", "window_type",
+             "slide_length", "scale_type", "style_type", "normal_type", "data_type", "is_temporal")
+
+
+def make_input(spec, samplate):
+    kind, seed, n = spec
+    return noise(seed, n) if kind == "noise" else tones(seed, n, samplate)
+
+
+def ctor_kwargs(case):
+    return {k: case[k] for k in CTOR_KEYS if k in case}
+
+
+# xxcc cases: (num, cc_num, rectify, standard?(delta_len, energy_type))
+XXCC_CASES = {
+    "mfcc13_log": dict(num=128, cc_num=13, rectify=0, src="cfg1_mel_power"),
+    "cc20_cuberoot": dict(num=128, cc_num=20, rectify=1, src="cfg1_mel_power"),
+    "cc_nonpow2": dict(num=80, cc_num=80, rectify=0, src="tones_mel_mag_area"),
+    "std_replace": dict(num=128, cc_num=13, rectify=0, src="cfg1_mel_power", standard=(9, 0)),
+    "std_append": dict(num=128, cc_num=13, rectify=0, src="cfg1_mel_power", standard=(5, 1)),
+    "std_ignore": dict(num=80, cc_num=12, rectify=1, src="tones_mel_mag_area", standard=(3, 2)),
+}

@@ -1,0 +1,66 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (the library
+compiled from /root/reference by oracle/Makefile) on the seeded inputs of
+tests/cases.py.  The reference ships no tests or golden vectors of its own
+(SURVEY.md section 4), so these fixtures are what pins the oracle and the GPU path
+where /root/reference is not mounted.
+
+    python tests/golden/make_golden.py        # needs oracle/_ref/libaudioflux_ref.so
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import ref  # noqa: E402
+from tests import cases  # noqa: E402
+
+
+def run_bft_case(c):
+    kw = cases.ctor_kwargs(c)
+    o = ref.RefBFT(kw.pop("num"), kw.pop("radix2_exp"), **kw)
+    assert o.status == 0, o.status
+    o.set_result_type(c["result_type"])
+    if "norm" in c:
+        o.set_norm(c["norm"])
+    x = cases.make_input(c["x"], c["samplate"])
+    re, im = o.bft(x)
+    out = {"re": re, "fre": o.fre_band(), "bin": o.bin_band()}
+    if c["result_type"] == 0:
+        out["im"] = im
+    if c.get("is_temporal"):
+        e, r, z = o.temporal(re.shape[0])
+        out.update(energy=e, rms=r, zcr=z)
+    return out
+
+
+def main():
+    assert ref.available(), "build the reference oracle first: make -C oracle"
+    bft_out = {}
+    for name, c in cases.BFT_CASES.items():
+        for k, v in run_bft_case(c).items():
+            bft_out[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "bft.npz"), **bft_out)
+
+    xx_out = {}
+    rng = np.random.default_rng(99)
+    for name, c in cases.XXCC_CASES.items():
+        m = np.abs(bft_out[c["src"] + "/re"])
+        o = ref.RefXXCC(c["num"])
+        if "standard" in c:
+            dlen, etype = c["standard"]
+            energy = np.abs(rng.standard_normal(m.shape[0])).astype(np.float32) + 1e-3
+            coe, d1, d2 = o.standard(m, energy, c["cc_num"], dlen, etype, c["rectify"])
+            xx_out[f"{name}/energy"] = energy
+            xx_out[f"{name}/coe"], xx_out[f"{name}/d1"], xx_out[f"{name}/d2"] = coe, d1, d2
+        else:
+            xx_out[f"{name}/cc"] = o.xxcc(m, c["cc_num"], c["rectify"])
+    np.savez_compressed(os.path.join(HERE, "xxcc.npz"), **xx_out)
+    for f in ("bft.npz", "xxcc.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/*.h declares,
+and refuses to construct objects when no MI355X is present (no CPU fallback)."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+from tests.conftest import ROOT
+
+import audioflux_amd as af
+
+
+def declared_functions():
+    names = set()
+    pat = re.compile(r"^\s*(?:const\s+)?(?:int|void|float|char)\s*\*?\s*(\w+)\s*\(", re.M)
+    for h in glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names.update(pat.findall(src))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = af.get_lib()
+    names = declared_functions()
+    # the 39 reference entry points of SURVEY.md 8b that this round implements + the additive ones
+    assert "bftObj_new" in names and "xxccObj_xxccStandard" in names and "bftObj_bftBatchDevice" in names
+    # headers already committed for objects that land later this round; shrink to ()
+    pending = ("cwtObj_", "cqtObj_", "cepstrogramObj_")
+    missing = [n for n in names if not hasattr(lib, n) and not n.startswith(pending)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+
+
+def test_enum_values_are_abi():
+    from audioflux_amd import types as t
+    assert t.WindowType.HANN == 1 and t.WindowType.TUKEY == 13
+    assert t.SpectralFilterBankScaleType.MEL == 2 and t.SpectralFilterBankScaleType.LOG == 6
+    assert t.SpectralFilterBankStyleType.GAMMATONE == 2 and t.SpectralFilterBankStyleType.GAUSS == 10
+    assert t.SpectralFilterBankNormalType.BAND_WIDTH == 2
+    assert t.CepstralRectifyType.CUBIC_ROOT == 1 and t.CepstralEnergyType.IGNORE == 2
+    assert t.WaveletContinueType.MORLET == 1 and t.ChromaDataNormalType.MAX == 1
+    hdr = open(os.path.join(ROOT, "include", "flux_base.h")).read()
+    for name, val in [("Window_Tukey", 13), ("SpectralFilterBankScale_Log", 6),
+                      ("SpectralFilterBankStyle_Gauss", 10), ("WaveletContinue_Ricker", 7)]:
+        assert re.search(rf"{name}\s*=\s*{val}\b", hdr), name
+
+
+def test_argument_validation_status_codes():
+    """status codes that do not need a device (src/bft_algorithm.c:124-128,144-147,240-243)"""
+    lib = af.get_lib()
+    obj = ctypes.c_void_p(None)
+    f = lib.bftObj_new
+    f.restype = ctypes.c_int
+    P = ctypes.POINTER
+    f.argtypes = [P(ctypes.c_void_p), ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 12
+    assert f(ctypes.byref(obj), 128, 31, *([None] * 12)) == -100 and not obj
+    scale = ctypes.c_int(7)
+    args = [None] * 12
+    args[6] = ctypes.cast(ctypes.pointer(scale), ctypes.c_void_p)
+    assert f(ctypes.byref(obj), 128, 11, *args) == 1 and not obj
+    assert f(ctypes.byref(obj), 1, 11, *([None] * 12)) == -1 and not obj  # num < 2
+    assert f(ctypes.byref(obj), 5000, 11, *([None] * 12)) == -1 and not obj  # num > N/2+1
+    g = lib.xxccObj_new
+    g.restype = ctypes.c_int
+    g.argtypes = [P(ctypes.c_void_p), ctypes.c_int]
+    assert g(ctypes.byref(obj), 1) == -1 and not obj
+    # NULL-safe frees
+    lib.bftObj_free.argtypes = [ctypes.c_void_p]
+    lib.bftObj_free(None)
+    lib.xxccObj_free.argtypes = [ctypes.c_void_p]
+    lib.xxccObj_free(None)
+
+
+def test_no_cpu_fallback_without_device():
+    if af.runtime_status() == 0:
+        pytest.skip("a device is present; covered by the gpu tests")
+    with pytest.raises(RuntimeError, match="status -2"):
+        af.BFT(128, radix2_exp=11, samplate=16000, scale_type=af.SpectralFilterBankScaleType.MEL)
+    with pytest.raises(RuntimeError, match="status -2"):
+        af.XXCC(128)
+
+
+def test_product_does_not_import_oracle():
+    for path in glob.glob(os.path.join(ROOT, "audioflux_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+            src = open(path, errors="replace").read()
+            assert "oracle" not in src.replace("no oracle", ""), f"{path} mentions the oracle"

@@ -1,0 +1,125 @@
+"""GPU parity: the product C-ABI (through the wrapper classes that mirror the
+reference's ctypes wrapper) against (a) the committed golden vectors produced by
+the reference and (b) the compiled reference itself when oracle/_ref is present.
+Tolerance: 1e-5 peak-relative and L2-relative per output tensor (north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+import audioflux_amd as af
+from oracle import ref
+from tests import cases
+from tests.conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "bft.npz"))
+
+
+def make_bft(c):
+    kw = cases.ctor_kwargs(c)
+    o = af.BFT(kw.pop("num"), radix2_exp=kw.pop("radix2_exp"),
+               samplate=kw["samplate"], low_fre=kw.get("low_fre"), high_fre=kw.get("high_fre"),
+               bin_per_octave=kw.get("bin_per_octave", 12),
+               window_type=af.WindowType(kw["window_type"]), slide_length=kw["slide_length"],
+               scale_type=af.SpectralFilterBankScaleType(kw["scale_type"]),
+               style_type=af.SpectralFilterBankStyleType(kw["style_type"]),
+               normal_type=af.SpectralFilterBankNormalType(kw["normal_type"]),
+               data_type=af.SpectralDataType(kw["data_type"]),
+               is_temporal=bool(kw.get("is_temporal", 0)))
+    if "norm" in c:
+        o.set_data_norm_value(c["norm"])
+    return o
+
+
+@pytest.mark.parametrize("name", list(cases.BFT_CASES))
+def test_bft_matches_golden(name, gold):
+    c = cases.BFT_CASES[name]
+    o = make_bft(c)
+    assert np.array_equal(o.get_fre_band_arr(), gold[f"{name}/fre"])
+    assert np.array_equal(o.get_bin_band_arr(), gold[f"{name}/bin"])
+    x = cases.make_input(c["x"], c["samplate"])
+    got = o.bft(x, result_type=c["result_type"]).T  # wrapper returns (num, time)
+    want = gold[f"{name}/re"]
+    if c["result_type"] == 0:
+        want = want + 1j * gold[f"{name}/im"]
+    assert_parity(got, want, TOL, name)
+    if c.get("is_temporal"):
+        e, r, z = o.get_temporal_data()
+        assert_parity(e, gold[f"{name}/energy"], TOL, "energy")
+        assert_parity(r, gold[f"{name}/rms"], TOL, "rms")
+        assert np.array_equal(z, gold[f"{name}/zcr"])
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", [21, 22])
+def test_bft_matches_compiled_reference_fresh_inputs(seed):
+    """fresh seeds (not in the fixtures) straight against the reference library"""
+    x = cases.noise(seed, 16000 * 3 + 123)
+    for rt in (1, 0):
+        for dt in (0, 1):
+            r = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1,
+                           slide_length=512, scale_type=2, style_type=0, normal_type=0, data_type=dt)
+            r.set_result_type(rt)
+            re, im = r.bft(x)
+            o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                       slide_length=512, scale_type=af.SpectralFilterBankScaleType.MEL,
+                       data_type=af.SpectralDataType(dt))
+            got = o.bft(x, result_type=rt).T
+            assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"rt{rt} dt{dt}")
+
+
+def test_batch_equals_per_clip_loop():
+    o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+               scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+    xs = np.stack([cases.noise(30 + i, 20000) for i in range(5)])
+    loop = np.stack([o.bft(x, result_type=1).T for x in xs])
+    batch = o.bft_batch(xs, result_type=1)
+    assert np.array_equal(loop, batch)  # same kernels, same order of operations
+
+
+def test_device_resident_api_matches_host_api():
+    import torch
+    o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+               scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+    xs = np.stack([cases.noise(40 + i, 30000) for i in range(7)])
+    host = o.bft_batch(xs, result_type=1)
+    xd = torch.from_numpy(xs).cuda()
+    out = o.bft_device(xd)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host)
+    # strided clips (rows of a wider buffer)
+    wide = torch.zeros((7, 30000 + 64), dtype=torch.float32, device="cuda")
+    wide[:, :30000] = xd
+    out2 = o.bft_device(wide[:, :30000])
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), host)
+
+
+def test_short_and_degenerate_inputs():
+    o = af.BFT(128, radix2_exp=11, samplate=16000, slide_length=512,
+               scale_type=af.SpectralFilterBankScaleType.MEL)
+    assert o.cal_time_length(2047) == 0 and o.cal_time_length(2048) == 1
+    with pytest.raises(ValueError):
+        o.bft(np.zeros(100, np.float32))
+    z = o.bft(np.zeros(4096, np.float32), result_type=1)
+    assert z.shape == (128, 5) and not z.any()
+    # reuse of one object across lengths (scratch regrowth)
+    for n in (5000, 60000, 9000):
+        assert o.bft(cases.noise(1, n), result_type=1).shape == (128, (n - 2048) // 512 + 1)
+
+
+def test_linearity_and_scaling_property():
+    """size-independent property: power-mel is quadratic, magnitude-mel is linear in the input gain"""
+    x = cases.noise(50, 40000)
+    p = af.BFT(64, radix2_exp=10, samplate=16000, slide_length=256,
+               scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+    m = af.BFT(64, radix2_exp=10, samplate=16000, slide_length=256,
+               scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.MAG)
+    assert_parity(p.bft(2 * x, 1), 4 * p.bft(x, 1), 1e-6, "power gain")
+    assert_parity(m.bft(2 * x, 1), 2 * m.bft(x, 1), 1e-6, "mag gain")

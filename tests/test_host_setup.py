@@ -1,0 +1,76 @@
+"""CPU-only: the host-side plan construction of the product library (windows,
+filter banks -- float32, setup-time) is BIT-IDENTICAL to the reference's, because
+band edges are decided by float32 comparisons (SURVEY.md section 7 hard part 2)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import audioflux_amd as af
+from oracle import ref
+
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+
+
+@pytest.mark.parametrize("wt", range(14))
+def test_fft_windows_bit_exact(wt):
+    R, N = ref.lib(), af.get_lib()
+    R.window_calFFTWindow.restype = fp
+    R.window_calFFTWindow.argtypes = [C.c_int, C.c_int]
+    N.afx_window_fft.restype = fp
+    N.afx_window_fft.argtypes = [C.c_int, C.c_int]
+    for n in (2, 3, 4, 5, 8, 17, 64, 512, 2048, 4096):
+        a = np.ctypeslib.as_array(R.window_calFFTWindow(wt, n), (n,)).copy()
+        b = np.ctypeslib.as_array(N.afx_window_fft(wt, n), (n,)).copy()
+        assert np.array_equal(a, b), (wt, n, np.abs(a - b).max())
+
+
+SHAPES = [(128, 2048, 16000, 0.0, 8000.0), (40, 1024, 32000, 27.5, 16000.0),
+          (64, 4096, 44100, 50.0, 20000.0), (13, 512, 8000, 100.0, 3500.0)]
+
+
+@pytest.mark.parametrize("scale", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("style", range(11))
+def test_filter_banks_bit_exact(scale, style):
+    R, N = ref.lib(), af.get_lib()
+    R.auditory_filterBank.restype = None
+    R.auditory_filterBank.argtypes = [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, fp, fp, ip]
+    N.afx_auditory_bank.restype = None
+    N.afx_auditory_bank.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_int, fp, fp, ip]
+    for norm in range(3):
+        for num, n, sr, lo, hi in SHAPES:
+            if scale in (5, 6) and lo == 0:
+                lo = 27.5
+            if scale == 1:  # keep the widened linspace edges inside [0, sr/2]: outside is UB in the reference
+                lo, hi = 1000.0, hi - 1200.0
+            if scale == 5 and num == 128:  # 128 semitones above 27.5 Hz overflow Nyquist (reference UB; bftObj_new rejects it)
+                continue
+            F = n // 2 + 1
+            a = np.zeros(num * F + 8 * n, np.float32)
+            b = np.zeros((num, F), np.float32)
+            fa, fb = np.zeros(num + 8, np.float32), np.zeros(num + 8, np.float32)
+            ba, bb = np.zeros(num + 8, np.int32), np.zeros(num + 8, np.int32)
+            R.auditory_filterBank(num, n, sr, 0, scale, style, norm, lo, hi, 12,
+                                  a.ctypes.data_as(fp), fa.ctypes.data_as(fp), ba.ctypes.data_as(ip))
+            N.afx_auditory_bank(num, n, sr, scale, style, norm, lo, hi, 12,
+                                b.ctypes.data_as(fp), fb.ctypes.data_as(fp), bb.ctypes.data_as(ip))
+            a = a[: num * F].reshape(num, F)
+            tag = (scale, style, norm, num, n, sr)
+            assert np.array_equal(fa, fb) and np.array_equal(ba, bb), tag
+            assert np.array_equal(a, b, equal_nan=True), (tag, np.nanmax(np.abs(a - b)))
+
+
+def test_dct_and_twiddle_tables():
+    N = af.get_lib()
+    N.afx_dct2_matrix.restype = fp
+    N.afx_dct2_matrix.argtypes = [C.c_int, C.c_int]
+    for num in (13, 80, 128):
+        d = np.ctypeslib.as_array(N.afx_dct2_matrix(num, num), (num, num)).astype(np.float64)
+        assert np.abs(d @ d.T - np.eye(num)).max() < 1e-6  # orthonormal
+    N.afx_twiddle_table.restype = fp
+    N.afx_twiddle_table.argtypes = [C.c_int]
+    t = np.ctypeslib.as_array(N.afx_twiddle_table(2048), (1024, 2)).astype(np.float64)
+    w = np.exp(-2j * np.pi * np.arange(1024) / 2048)
+    assert np.abs(t[:, 0] + 1j * t[:, 1] - w).max() < 1e-7

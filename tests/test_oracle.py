@@ -1,0 +1,95 @@
+"""CPU-only: pins the oracle.  (1) the compiled reference reproduces the committed
+golden fixtures bit for bit (deterministic, same build recipe); (2) the numpy
+restatement agrees with those fixtures to the error floor of the reference's own
+float32 FFT.  Both must hold before either is trusted as a checker."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref, restate
+from tests import cases
+from tests.conftest import assert_parity
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "bft.npz")), np.load(os.path.join(golden_dir, "xxcc.npz"))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", list(cases.BFT_CASES))
+def test_compiled_reference_reproduces_golden(name, gold):
+    from tests.golden.make_golden import run_bft_case
+    out = run_bft_case(cases.BFT_CASES[name])
+    for k, v in out.items():
+        assert np.array_equal(v, gold[0][f"{name}/{k}"]), (name, k)
+
+
+RESTATE_BANK = {"cfg1_mel_power": ("slaney", "none"), "cfg1_mel_complex": ("slaney", "none"),
+                "tones_mel_mag_area": ("etsi", "area"), "mel_temporal": ("slaney", "none"),
+                "one_frame_exact": ("slaney", "none"), "ragged_tail": ("slaney", "none")}
+
+
+@pytest.mark.parametrize("name", list(RESTATE_BANK))
+def test_restatement_matches_golden_mel(name, gold):
+    c = cases.BFT_CASES[name]
+    style, normal = RESTATE_BANK[name]
+    n = 1 << c["radix2_exp"]
+    bank, fre, bins = restate.mel_bank(c["num"], n, c["samplate"], c["low_fre"], c["high_fre"],
+                                       style, normal)
+    assert np.array_equal(bins, gold[0][f"{name}/bin"])
+    assert np.abs(fre - gold[0][f"{name}/fre"]).max() <= 2e-3  # 1 ulp at kHz (numpy vs libm powf)
+    x = cases.make_input(c["x"], c["samplate"])
+    got = restate.bft(x, bank, n, c["slide_length"], c["window_type"],
+                      "mag" if c["data_type"] == 1 else "power", c["result_type"],
+                      c.get("norm", 1.0))
+    want = gold[0][f"{name}/re"]
+    if c["result_type"] == 0:
+        want = want + 1j * gold[0][f"{name}/im"]
+    assert_parity(got, want, 1e-5, name)
+    if c.get("is_temporal"):
+        e, r, z = restate.temporal(x, n, c["slide_length"], c["window_type"])
+        assert_parity(e, gold[0][f"{name}/energy"], 1e-5, "energy")
+        assert_parity(r, gold[0][f"{name}/rms"], 1e-5, "rms")
+        assert np.array_equal(z.astype(np.float32), gold[0][f"{name}/zcr"])
+
+
+@pytest.mark.parametrize("name", ["linear_slice_power", "linear_full_complex"])
+def test_restatement_matches_golden_linear(name, gold):
+    c = cases.BFT_CASES[name]
+    x = cases.make_input(c["x"], c["samplate"])
+    got = restate.bft_linear(x, c["num"], 1 << c["radix2_exp"], c["samplate"], c["slide_length"],
+                             c["low_fre"], c["window_type"], "power", c["result_type"])
+    want = gold[0][f"{name}/re"]
+    if c["result_type"] == 0:
+        want = want + 1j * gold[0][f"{name}/im"]
+    assert_parity(got, want, 1e-5, name)
+
+
+@pytest.mark.parametrize("name", list(cases.XXCC_CASES))
+def test_restatement_matches_golden_xxcc(name, gold):
+    c = cases.XXCC_CASES[name]
+    m = np.abs(gold[0][c["src"] + "/re"])
+    kind = "log" if c["rectify"] == 0 else "cuberoot"
+    if "standard" in c:
+        dlen, et = c["standard"]
+        got = restate.xxcc_standard(m, gold[1][f"{name}/energy"], c["cc_num"], dlen,
+                                    ("replace", "append", "ignore")[et], kind)
+        for g, k in zip(got, ("coe", "d1", "d2")):
+            assert_parity(g, gold[1][f"{name}/{k}"], 1e-5, f"{name}/{k}")
+    else:
+        assert_parity(restate.xxcc(m, c["cc_num"], kind), gold[1][f"{name}/cc"], 1e-5, name)
+
+
+def test_windows_match_reference_formulas():
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    import ctypes as C
+    L = ref.lib()
+    L.window_calFFTWindow.restype = C.POINTER(C.c_float)
+    L.window_calFFTWindow.argtypes = [C.c_int, C.c_int]
+    for wt in range(14):
+        for n in (8, 9, 512, 2048):
+            a = np.ctypeslib.as_array(L.window_calFFTWindow(wt, n), (n,)).copy()
+            assert np.abs(a - restate.fft_window(wt, n)).max() < 2e-6, (wt, n)
