@@ -105,6 +105,41 @@ int afxk_xxcc_standard(const float *cc, const float *energy, long long rows, int
                        int energyType, int deltaLen, float *coe, float *delta1, float *delta2,
                        void *stream);
 
+/* ---- fused STFT -> banded filter bank kernel (afx_melfused.hip) ---------- */
+
+/* Banded view of a filter bank, one entry per lane of a 64-lane wave: every
+ * lane owns up to two bank rows, a long one (A) and a short one (B); each row
+ * is the contiguous bin range [start, start+len) that holds all its non-zero
+ * weights.  Weight arrays are tap-major, [taps][64], zero padded. */
+typedef struct {
+    int num;        /* bank rows                                  */
+    int tapsA;      /* longest A row                              */
+    int tapsB;      /* longest B row                              */
+    int startA[64];
+    int startB[64];
+    int rowA[64];   /* bank row stored by lane (-1: none)         */
+    int rowB[64];
+    float *wA;      /* host, [tapsA][64]                          */
+    float *wB;      /* host, [tapsB][64]                          */
+} AfxBandPlan;
+
+typedef struct {
+    const float *x;
+    long long clipStride;
+    int batch, dataLength, timeLength, hop;
+    int specMap;    /* 0 |S|^2, 1 |S|, 2 |S|^(2*normValue)                  */
+    int postPow;    /* 1: powf(result, normValue)                           */
+    float normValue;
+    float *out;     /* device [batch*timeLength, num]                       */
+} AfxMelFusedArgs;
+
+/* variant index able to run (radix2Exp, tapsA, tapsB), or -1 */
+int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB);
+int afxk_melfused_create(void **plan, int radix2Exp, const float *hWindow,
+                         const AfxBandPlan *band, void *stream);
+int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream);
+void afxk_melfused_destroy(void *plan);
+
 #ifdef __cplusplus
 }
 #endif

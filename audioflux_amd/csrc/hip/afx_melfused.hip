@@ -1,17 +1,477 @@
-// placeholder: fused-kernel hooks (filled in by the register-resident kernel)
-#include "afx_device.h"
-#include "afx_objects.h"
+// afx_melfused.hip -- the headline kernel: framed STFT -> |S|^2 (or |S|,
+// |S|^2p) -> banded filter bank, one 64-lane wave per 2048-sample frame, with
+// no HBM round trip between the stages ("K1+K2+K3" of SURVEY.md 2b fused).
+//
+// What it replaces in the reference (per frame): window multiply + N-point
+// radix-2 FFT (src/stft_algorithm.c:696-715, src/dsp/fft_algorithm.c:450-519),
+// crop to N/2+1 bins (src/vector/flux_complex.c:254-286), re^2+im^2 / sqrt / pow
+// (flux_complex.c:469-503, src/bft_algorithm.c:489-504) and the filter-bank
+// product (src/vector/flux_vector.c:55-86) -- the [T,N] complex scratch and the
+// [T,F] power spectrum the reference materialises never exist here.
+//
+// Per frame, all inside one wave (no workgroup barriers; waves are independent):
+//   1. 16 coalesced float2 loads per lane of the hop-overlapped frame, times the
+//      window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1]), n = 64*n1 + lane
+//   2. 1024-point complex FFT of z: radix-16 DFT in registers over n1, twiddle
+//      W_1024^(lane*k1), transpose through LDS (pitch 68 float2: conflict-free
+//      ds_read_b64), radix-16 DFT in registers, twiddle W_64, radix-4 across each
+//      lane quad with DPP quad_perm moves (no LDS)
+//   3. real-input split: Z is written to LDS in natural order, each lane reads
+//      the pairs (k, 1024-k), forms X[k] = E + W_2048^k O and X[1024-k] =
+//      conj(E - W O), and stores the spectrum value of both bins into the wave's
+//      power row in LDS
+//   4. banded filter bank: lane i owns a long row A and a short row B of the bank
+//      (AfxBandPlan); its weights stay in VGPRs for the life of the kernel, the
+//      power row is read from LDS with immediate offsets: acc = fma(w[t], P[s+t])
+//      in ascending bin order
+//   5. two dword stores per lane: out[frame, rowA], out[frame, rowB]
+//
+// HBM traffic per frame = 4*hop bytes in (each sample once; the 4x frame overlap
+// is served by L1/L2) + 4*num bytes out.  Index algebra validated by
+// tools/proto_fft1024.py.
+#include <hip/hip_runtime.h>
 
-extern "C" int afx_bft_plan_fast(struct OpaqueBFT *, const float *, const float *) { return AFX_OK; }
-extern "C" int afx_bft_try_fast(struct OpaqueBFT *, const float *, int, int, long long, float *,
-                                float *, void *, int *used) {
-    *used = 0;
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "afx_device.h"
+#include "afx_hipcheck.h"
+
+namespace {
+
+constexpr int NFFT = 2048;
+constexpr int MC = 1024;        // complex FFT length
+constexpr int EX_PITCH = 68;    // float2 per k1 row of the exchange image
+constexpr int EX_F2 = 16 * EX_PITCH;  // 1088 float2; also holds the 1040-float2 natural image
+constexpr int PROW_F = 1104;    // 1025 bins + zero pad for the fixed-length band loops (>= 1025 + 72)
+constexpr int WAVE_LDS_BYTES = EX_F2 * 8;  // 8704; the power row (4416 B) aliases the exchange image
+constexpr int WAVES = 4;
+// workgroup-shared constant tables staged in LDS once per workgroup
+constexpr int TAB_WIN_F2 = 1024;     // (w[2n], w[2n+1])
+constexpr int TAB_TW1_F2 = 16 * 64;  // W_1024^(lane*k1)
+constexpr int TAB_TW2_F2 = 64;       // W_64^(m2*j1)
+constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2;
+constexpr int TAB_BYTES = TAB_F2 * 8;  // 16896
+constexpr int BLOCK_LDS_BYTES = TAB_BYTES + WAVES * WAVE_LDS_BYTES;  // 51712 -> 3 workgroups per CU
+
+struct KArgs {
+    const float *x;
+    long long clipStride;
+    long long totalFrames;
+    int timeLength, hop;
+    int framesPerWave;
+    int aligned;  // frame starts are 8-byte aligned -> float2 loads
+    const float2 *win2;  // [1024]  (w[2n], w[2n+1])
+    const float2 *tw1;   // [16][64] W_1024^(lane*k1)
+    const float2 *tw2;   // [4][16]  W_64^(m2*j1)
+    const float2 *tw3;   // [512]    0.5 * W_2048^k
+    const float *wA, *wB;  // [taps][64]
+    const int *meta;       // [4][64]: startA, startB, rowA, rowB
+    int specMap, postPow;
+    float normValue;
+    float *out;
+    int num;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // orders this wave's LDS stores before its later LDS loads (other lanes' data);
+    // DS operations of one wave execute in issue order, the fences pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// forward 4-point DFT in place: (p0,p1,p2,p3) -> (X0,X1,X2,X3)
+__device__ __forceinline__ void dft4(float2 &p0, float2 &p1, float2 &p2, float2 &p3) {
+    const float2 s0 = make_float2(p0.x + p2.x, p0.y + p2.y);
+    const float2 s1 = make_float2(p0.x - p2.x, p0.y - p2.y);
+    const float2 s2 = make_float2(p1.x + p3.x, p1.y + p3.y);
+    const float2 s3 = make_float2(p1.x - p3.x, p1.y - p3.y);
+    p0 = make_float2(s0.x + s2.x, s0.y + s2.y);
+    p2 = make_float2(s0.x - s2.x, s0.y - s2.y);
+    p1 = make_float2(s1.x + s3.y, s1.y - s3.x);  // s1 - i s3
+    p3 = make_float2(s1.x - s3.y, s1.y + s3.x);  // s1 + i s3
+}
+
+// forward 16-point DFT in place, radix-4 x radix-4.  Input x[n] = v[n];
+// output X[k] = v[4*(k&3) + (k>>2)]  (base-4 digit reversal).
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // t[b][c] sits at v[4c+b]; multiply by W16^(b*c), W16 = exp(-2 pi i / 16)
+    v[5] = cmul(v[5], make_float2(C1, -S1));                       // b1 c1: W^1
+    v[9] = make_float2(H * (v[9].x + v[9].y), H * (v[9].y - v[9].x));    // b1 c2: W^2
+    v[13] = cmul(v[13], make_float2(S1, -C1));                     // b1 c3: W^3
+    v[6] = make_float2(H * (v[6].x + v[6].y), H * (v[6].y - v[6].x));    // b2 c1: W^2
+    v[10] = make_float2(v[10].y, -v[10].x);                        // b2 c2: W^4 = -i
+    v[14] = make_float2(H * (v[14].y - v[14].x), -H * (v[14].x + v[14].y));  // b2 c3: W^6
+    v[7] = cmul(v[7], make_float2(S1, -C1));                       // b3 c1: W^3
+    v[11] = make_float2(H * (v[11].y - v[11].x), -H * (v[11].x + v[11].y));  // b3 c2: W^6
+    v[15] = cmul(v[15], make_float2(-C1, S1));                     // b3 c3: W^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+__host__ __device__ constexpr int rev4(int k) { return 4 * (k & 3) + (k >> 2); }
+
+// value of lane (l ^ mask) inside each quad, via a DPP quad_perm move
+template <int CTRL>
+__device__ __forceinline__ float quad_swap(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// GENERAL = false: plain |S|^2 (the hot configuration; no sqrt/pow code in the loop)
+template <int TA, int TB, bool GENERAL>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_stft_mel_banded(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float2 *tabWin = reinterpret_cast<float2 *>(smem);
+    float2 *tabTw1 = tabWin + TAB_WIN_F2;
+    float2 *tabTw2 = tabTw1 + TAB_TW1_F2;
+    float2 *ex = reinterpret_cast<float2 *>(smem + TAB_BYTES + wave * WAVE_LDS_BYTES);
+    float *prow = reinterpret_cast<float *>(ex);  // aliases ex: written only after the pair reads
+
+    // ---- workgroup-shared tables -> LDS (once) ----------------------------------
+    for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = a.win2[i];
+    for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = a.tw1[i];
+    if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = a.tw2[threadIdx.x];
+    __syncthreads();
+
+    // ---- per-lane constants, resident in VGPRs for the whole kernel ---------------
+    const int k1 = lane >> 2, m2 = lane & 3;
+    const int j2 = ((lane & 1) << 1) | ((lane >> 1) & 1);
+    const float sgnA = (m2 & 2) ? -1.f : 1.f;  // quad stage A: o + sgnA * v
+    const float sgnB = (m2 & 1) ? -1.f : 1.f;  // quad stage B
+    const bool rot = (m2 == 3);                // multiply by -i between the stages
+
+    float wA[TA], wB[TB];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) wA[t] = a.wA[t * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) wB[t] = a.wB[t * 64 + lane];
+    float2 tw3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tw3[i] = a.tw3[lane + 64 * i];  // 0.5 * W_2048^k
+    const int startA = a.meta[lane], startB = a.meta[64 + lane];
+    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+
+    const long long gw = (long long)blockIdx.x * WAVES + wave;
+    long long f = gw * a.framesPerWave;
+    long long fEnd = f + a.framesPerWave;
+    if (fEnd > a.totalFrames) fEnd = a.totalFrames;
+    if (f >= fEnd) return;
+    int clip = (int)(f / a.timeLength);
+    int t = (int)(f - (long long)clip * a.timeLength);
+
+    for (; f < fEnd; ++f) {
+        const float *px = a.x + (long long)clip * a.clipStride + (long long)t * a.hop;
+        float2 v[16];
+        // ---- 1. load + window ---------------------------------------------------
+        if (a.aligned) {
+            const float2 *p2 = reinterpret_cast<const float2 *>(px);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = p2[64 * n1 + lane];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int n = 64 * n1 + lane;
+                v[n1] = make_float2(px[2 * n], px[2 * n + 1]);
+            }
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const float2 w = tabWin[64 * n1 + lane];
+            v[n1] = make_float2(v[n1].x * w.x, v[n1].y * w.y);
+        }
+
+        // ---- 2a. radix-16 over n1, twiddle, transpose through LDS ---------------
+        dft16(v);
+        ex[lane] = v[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) ex[k * EX_PITCH + lane] = cmul(v[rev4(k)], tabTw1[k * 64 + lane]);
+        wave_lds_sync();
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = ex[k1 * EX_PITCH + 4 * m1 + m2];
+        wave_lds_sync();
+
+        // ---- 2b. radix-16 over m1, twiddle W_64^(m2*j1), radix-4 across the quad --
+        dft16(v);
+#pragma unroll
+        for (int j1 = 0; j1 < 16; ++j1) {
+            float2 c = v[rev4(j1)];
+            if (j1 > 0) c = cmul(c, tabTw2[m2 * 16 + j1]);
+            // stage A: lanes {0,1} get V0+V2, V1+V3; lanes {2,3} get V0-V2, V1-V3
+            float rx = fmaf(sgnA, c.x, quad_swap<0x4E>(c.x));
+            float ry = fmaf(sgnA, c.y, quad_swap<0x4E>(c.y));
+            // lane 3 (V1-V3) is multiplied by -i
+            const float tx = rot ? ry : rx;
+            const float ty = rot ? -rx : ry;
+            // stage B: even lanes r + o, odd lanes o - r  ->  lane m holds U[j2(m)]
+            rx = fmaf(sgnB, tx, quad_swap<0xB1>(tx));
+            ry = fmaf(sgnB, ty, quad_swap<0xB1>(ty));
+            // Z[k1 + 16 j1 + 256 j2] -> natural-order image, 4 float2 of pad per 256
+            ex[k1 + 16 * j1 + 260 * j2] = make_float2(rx, ry);
+        }
+        wave_lds_sync();
+
+        // ---- 3. real-input split + spectrum value -> power row --------------------
+        float pk[8], pq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = lane + 64 * i;
+            const int kp = (MC - k) & (MC - 1);
+            const float2 A = ex[k + 4 * (k >> 8)];
+            const float2 B = ex[kp + 4 * (kp >> 8)];
+            const float2 w = tw3[i];
+            const float ex2 = 0.5f * (A.x + B.x), ey2 = 0.5f * (A.y - B.y);  // E
+            const float ox = A.y + B.y, oy = B.x - A.x;                      // 2 O
+            const float wx = w.x * ox - w.y * oy, wy = w.x * oy + w.y * ox;  // W O
+            const float xr = ex2 + wx, xi = ey2 + wy;   // X[k]
+            const float yr = ex2 - wx, yi = ey2 - wy;   // conj(X[1024-k])
+            pk[i] = xr * xr + xi * xi;
+            pq[i] = yr * yr + yi * yi;
+        }
+        float pmid;
+        {
+            const float2 zc = ex[512 + 4 * 2];
+            pmid = zc.x * zc.x + zc.y * zc.y;
+        }
+        if (GENERAL && a.specMap == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pk[i] = sqrtf(pk[i]);
+                pq[i] = sqrtf(pq[i]);
+            }
+            pmid = sqrtf(pmid);
+        } else if (GENERAL && a.specMap == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pk[i] = powf(pk[i], a.normValue);
+                pq[i] = powf(pq[i], a.normValue);
+            }
+            pmid = powf(pmid, a.normValue);
+        }
+        wave_lds_sync();  // every lane has its pairs in registers; ex becomes the power row
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = lane + 64 * i;
+            prow[k] = pk[i];
+            prow[MC - k] = pq[i];
+        }
+        if (lane == 0) prow[512] = pmid;
+        // zero pad behind bin 1024: the fixed-length band loops read it with zero weights
+        prow[1025 + lane] = 0.f;
+        if (lane < PROW_F - 1025 - 64) prow[1025 + 64 + lane] = 0.f;
+        wave_lds_sync();
+
+        // ---- 4. banded filter bank ------------------------------------------------
+        float accA = 0.f, accB = 0.f;
+        {
+            const float *pa = prow + startA;
+#pragma unroll
+            for (int tt = 0; tt < TA; ++tt) accA = fmaf(wA[tt], pa[tt], accA);
+            const float *pb = prow + startB;
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt) accB = fmaf(wB[tt], pb[tt], accB);
+        }
+        if (GENERAL && a.postPow) {
+            accA = powf(accA, a.normValue);
+            accB = powf(accB, a.normValue);
+        }
+        // ---- 5. store ---------------------------------------------------------------
+        float *orow = a.out + f * a.num;
+        if (rowA >= 0) orow[rowA] = accA;
+        if (rowB >= 0) orow[rowB] = accB;
+        wave_lds_sync();  // the next frame overwrites ex / prow
+
+        if (++t == a.timeLength) {
+            t = 0;
+            ++clip;
+        }
+    }
+}
+
+struct Plan {
+    int variant;
+    int num;
+    float2 *dWin2, *dTw1, *dTw2, *dTw3;
+    float *dWA, *dWB;
+    int *dMeta;
+};
+
+struct Variant {
+    int tapsA, tapsB;
+};
+constexpr Variant kVariants[] = {{48, 16}, {72, 24}};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+template <int TA, int TB, bool GENERAL>
+int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    if (total <= 0) return AFX_OK;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    // 2 workgroups of 4 waves per CU are resident (VGPR-limited: 2 waves per SIMD);
+    // a few rounds of them per CU keep the tail short while each wave still streams
+    // a contiguous, L2-friendly run of frames
+    long long waves = (long long)cus * 2 * WAVES * 4;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 8) fpw = 8;
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+
+    KArgs k;
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.aligned = ((a->clipStride & 1) == 0) && ((a->hop & 1) == 0) &&
+                ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
+    k.win2 = p->dWin2;
+    k.tw1 = p->dTw1;
+    k.tw2 = p->dTw2;
+    k.tw3 = p->dTw3;
+    k.wA = p->dWA;
+    k.wB = p->dWB;
+    k.meta = p->dMeta;
+    k.specMap = a->specMap;
+    k.postPow = a->postPow;
+    k.normValue = a->normValue;
+    k.out = a->out;
+    k.num = p->num;
+    const size_t lds = (size_t)BLOCK_LDS_BYTES;
+    static bool attrSet = false;
+    if (!attrSet) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_mel_banded");
     return AFX_OK;
 }
-extern "C" int afx_bft_try_fast_cc(struct OpaqueBFT *, struct OpaqueXXCC *, const float *, int, int,
-                                   long long, int, CepstralRectifyType *, float *, float *, void *,
-                                   int *used) {
-    *used = 0;
+
+template <typename T>
+int upload(T **dptr, const void *src, size_t bytes, void *stream) {
+    int st = afxdev_malloc(reinterpret_cast<void **>(dptr), bytes);
+    if (st != AFX_OK) return st;
+    return afxdev_h2d(*dptr, src, bytes, stream);
+}
+
+}  // namespace
+
+extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
+    if (radix2Exp != 11) return -1;
+    if (getenv("AFX_NO_FUSED")) return -1;
+    for (int i = 0; i < kNumVariants; ++i) {
+        if (tapsA <= kVariants[i].tapsA && tapsB <= kVariants[i].tapsB) return i;
+    }
+    return -1;
+}
+
+extern "C" void afxk_melfused_destroy(void *plan) {
+    Plan *p = static_cast<Plan *>(plan);
+    if (!p) return;
+    afxdev_free(p->dWin2);
+    afxdev_free(p->dTw1);
+    afxdev_free(p->dTw2);
+    afxdev_free(p->dTw3);
+    afxdev_free(p->dWA);
+    afxdev_free(p->dWB);
+    afxdev_free(p->dMeta);
+    free(p);
+}
+
+extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWindow,
+                                    const AfxBandPlan *band, void *stream) {
+    *plan = nullptr;
+    const int variant = afxk_melfused_variant(radix2Exp, band->tapsA, band->tapsB);
+    if (variant < 0) return AFX_ERR_UNSUPPORTED;
+    const int TA = kVariants[variant].tapsA, TB = kVariants[variant].tapsB;
+    Plan *p = static_cast<Plan *>(calloc(1, sizeof(Plan)));
+    if (!p) return AFX_ERR_NOMEM;
+    p->variant = variant;
+    p->num = band->num;
+
+    // twiddle tables in double, rounded once
+    float *tw1 = static_cast<float *>(malloc(sizeof(float) * 2 * 16 * 64));
+    float *tw2 = static_cast<float *>(malloc(sizeof(float) * 2 * 4 * 16));
+    float *tw3 = static_cast<float *>(malloc(sizeof(float) * 2 * 512));
+    float *wA = static_cast<float *>(calloc((size_t)TA * 64, sizeof(float)));
+    float *wB = static_cast<float *>(calloc((size_t)TB * 64, sizeof(float)));
+    int meta[256];
+    int st = (tw1 && tw2 && tw3 && wA && wB) ? AFX_OK : AFX_ERR_NOMEM;
+    if (st == AFX_OK) {
+        const double PI = 3.14159265358979323846;
+        for (int k = 0; k < 16; ++k)
+            for (int l = 0; l < 64; ++l) {
+                const double ang = -2.0 * PI * (double)(k * l) / MC;
+                tw1[2 * (k * 64 + l)] = (float)cos(ang);
+                tw1[2 * (k * 64 + l) + 1] = (float)sin(ang);
+            }
+        for (int m = 0; m < 4; ++m)
+            for (int j = 0; j < 16; ++j) {
+                const double ang = -2.0 * PI * (double)(m * j) / 64.0;
+                tw2[2 * (m * 16 + j)] = (float)cos(ang);
+                tw2[2 * (m * 16 + j) + 1] = (float)sin(ang);
+            }
+        for (int k = 0; k < 512; ++k) {
+            const double ang = -2.0 * PI * (double)k / NFFT;
+            tw3[2 * k] = (float)(0.5 * cos(ang));
+            tw3[2 * k + 1] = (float)(0.5 * sin(ang));
+        }
+        memcpy(wA, band->wA, sizeof(float) * (size_t)band->tapsA * 64);
+        memcpy(wB, band->wB, sizeof(float) * (size_t)band->tapsB * 64);
+        for (int l = 0; l < 64; ++l) {
+            meta[l] = band->startA[l];
+            meta[64 + l] = band->startB[l];
+            meta[128 + l] = band->rowA[l];
+            meta[192 + l] = band->rowB[l];
+        }
+        st = upload(&p->dWin2, hWindow, sizeof(float) * NFFT, stream);
+    }
+    if (st == AFX_OK) st = upload(&p->dTw1, tw1, sizeof(float) * 2 * 16 * 64, stream);
+    if (st == AFX_OK) st = upload(&p->dTw2, tw2, sizeof(float) * 2 * 4 * 16, stream);
+    if (st == AFX_OK) st = upload(&p->dTw3, tw3, sizeof(float) * 2 * 512, stream);
+    if (st == AFX_OK) st = upload(&p->dWA, wA, sizeof(float) * (size_t)TA * 64, stream);
+    if (st == AFX_OK) st = upload(&p->dWB, wB, sizeof(float) * (size_t)TB * 64, stream);
+    if (st == AFX_OK) st = upload(&p->dMeta, meta, sizeof(meta), stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(stream);  // host staging buffers are freed below
+    free(tw1);
+    free(tw2);
+    free(tw3);
+    free(wA);
+    free(wB);
+    if (st != AFX_OK) {
+        afxk_melfused_destroy(p);
+        return st;
+    }
+    *plan = p;
     return AFX_OK;
 }
-extern "C" void afx_bft_free_fast(struct OpaqueBFT *) {}
+
+extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
+    const Plan *p = static_cast<const Plan *>(plan);
+    if (!p) return AFX_ERR_ARG;
+    const bool general = (a->specMap != 0) || a->postPow;
+    switch (p->variant) {
+        case 0:
+            return general ? launch<48, 16, true>(p, a, stream) : launch<48, 16, false>(p, a, stream);
+        case 1:
+            return general ? launch<72, 24, true>(p, a, stream) : launch<72, 24, false>(p, a, stream);
+        default:
+            return AFX_ERR_UNSUPPORTED;
+    }
+}

@@ -21,7 +21,7 @@ int afx_bftXxccBatchDevice(BFTObj bft, XXCCObj xxcc, const float *dData, int bat
         afxdev_set_error("afx_bftXxccBatchDevice: needs a real-result BFT and an XXCC of the same num");
         return AFX_ERR_ARG;
     }
-    void *stream = hipStream ? hipStream : bft->stream;
+    void *stream = hipStream;
     const int T = bftObj_calTimeLength(bft, dataLength);
     if (T <= 0 || batch <= 0) return AFX_OK;
     const long long frames = (long long)batch * T;

@@ -243,6 +243,14 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
                        void *stream) {
     const int T = bftObj_calTimeLength(o, dataLength);
     if (T <= 0 || batch <= 0) return AFX_OK;
+    /* scratch buffers belong to the object: drain the previous stream when the
+     * caller switches streams between calls */
+    if (o->lastStreamSet && o->lastStream != stream) {
+        int sst = afxdev_stream_sync(o->lastStream);
+        if (sst != AFX_OK) return sst;
+    }
+    o->lastStream = stream;
+    o->lastStreamSet = 1;
     int specMode, post;
     pick_modes(o, &specMode, &post);
     const int complexOut = !o->resultType;
@@ -332,7 +340,7 @@ int bftObj_bftBatchDevice(BFTObj o, const float *dData, int batch, int dataLengt
     if (!o || !dData || !dReal) return AFX_ERR_ARG;
     if (!o->resultType && !dImag) return AFX_ERR_ARG;
     return afx_bft_run_device(o, dData, batch, dataLength, clipStride, dReal, dImag, NULL,
-                              hipStream ? hipStream : o->stream);
+                              hipStream);
 }
 
 int bftObj_bftBatch(BFTObj o, const float *dataArr, int batch, int dataLength, float *mRealArr3,

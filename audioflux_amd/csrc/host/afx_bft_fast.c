@@ -1,0 +1,73 @@
+/* afx_bft_fast.c -- glue between the BFT object and the fused
+ * STFT -> banded-filter-bank kernel (afx_melfused.hip).  The plan is built once
+ * per object when the configuration qualifies (n_fft 2048, a banded bank whose
+ * rows fit one of the compiled tap variants); everything else keeps using the
+ * size-generic kernels. */
+#include <stdlib.h>
+#include <string.h>
+
+#include "afx_device.h"
+#include "afx_host.h"
+#include "afx_objects.h"
+
+int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p);
+void afx_bandplan_free(AfxBandPlan *p);
+
+int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hBank) {
+    o->fast = NULL;
+    if (!hBank || o->scale == SpectralFilterBankScale_Linear) return AFX_OK;
+    if (afxk_melfused_variant(o->radix2Exp, 1, 1) < 0) return AFX_OK;
+    AfxBandPlan band;
+    if (afx_bandplan_build(hBank, o->num, o->F, &band) != 0) return AFX_OK;
+    int st = AFX_OK;
+    if (afxk_melfused_variant(o->radix2Exp, band.tapsA, band.tapsB) >= 0) {
+        void *plan = NULL;
+        st = afxk_melfused_create(&plan, o->radix2Exp, hWindow, &band, o->stream);
+        if (st == AFX_OK) o->fast = (struct AfxMelFusedPlan *)plan;
+    }
+    afx_bandplan_free(&band);
+    return st;
+}
+
+int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
+                     long long clipStride, float *dRe, float *dIm, void *stream, int *used) {
+    (void)dIm;
+    *used = 0;
+    if (!o->fast || !o->resultType) return AFX_OK; /* complex results: generic path */
+    AfxMelFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dData;
+    a.clipStride = clipStride;
+    a.batch = batch;
+    a.dataLength = dataLength;
+    a.timeLength = (dataLength - o->fftLength) / o->slideLength + 1;
+    a.hop = o->slideLength;
+    a.normValue = o->normValue;
+    a.out = dRe;
+    if (o->dataType == SpectralData_Mag) {
+        a.specMap = 1;
+        a.postPow = (o->normValue != 1);
+    } else {
+        a.specMap = (o->dataType == SpectralData_Power && o->normValue != 1) ? 2 : 0;
+    }
+    int st = afxk_melfused_run(o->fast, &a, stream);
+    if (st == AFX_OK) *used = 1;
+    return st;
+}
+
+int afx_bft_try_fast_cc(struct OpaqueBFT *o, struct OpaqueXXCC *x, const float *dData, int batch,
+                        int dataLength, long long clipStride, int ccNum,
+                        CepstralRectifyType *rectifyType, float *dMel, float *dCc, void *stream,
+                        int *used) {
+    (void)o; (void)x; (void)dData; (void)batch; (void)dataLength; (void)clipStride; (void)ccNum;
+    (void)rectifyType; (void)dMel; (void)dCc; (void)stream;
+    *used = 0; /* cepstra are produced by the DCT GEMM right after the fused mel kernel */
+    return AFX_OK;
+}
+
+void afx_bft_free_fast(struct OpaqueBFT *o) {
+    if (o && o->fast) {
+        afxk_melfused_destroy(o->fast);
+        o->fast = NULL;
+    }
+}

@@ -47,4 +47,7 @@ float *afx_twiddle_table(int n);
 float *afx_dct2_matrix(int num, int rows);
 int afx_is_pow2(int v);
 
+/* ---- afx_bandplan.c ----------------------------------------------------- */
+struct AfxBandPlanTag; /* AfxBandPlan is declared in afx_device.h */
+
 #endif /* AFX_HOST_H */

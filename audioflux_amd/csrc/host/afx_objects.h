@@ -42,6 +42,8 @@ struct OpaqueBFT {
     int hTemporalCap, hTemporalFrames;
     int lastTimeLength;
     int status; /* last failure of a void entry point */
+    void *lastStream; /* stream of the previous launch (scratch is shared) */
+    int lastStreamSet;
 };
 
 struct OpaqueXXCC {

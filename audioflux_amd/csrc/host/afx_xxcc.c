@@ -58,8 +58,7 @@ int xxccObj_xxccDevice(XXCCObj o, const float *dIn, long long rows, int ccNum,
     if (!o || !dIn || !dOut) return AFX_ERR_ARG;
     if (ccNum > o->num || ccNum < 1) return AFX_ERR_ARG;
     return afxk_gemm_nt(dIn, o->num, o->dDct, o->num, dOut, ccNum, rows, ccNum, o->num,
-                        rectify_to_map(rectifyType), AFX_MAP_NONE, 1.f,
-                        hipStream ? hipStream : o->stream);
+                        rectify_to_map(rectifyType), AFX_MAP_NONE, 1.f, hipStream);
 }
 
 /* upload [T,num], run the rectify+DCT GEMM into dOut[T,ccNum] */

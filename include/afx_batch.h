@@ -5,8 +5,9 @@
  * already live in HBM.  Results are identical to looping the legacy call.
  *
  * Device pointers are plain `float*` HBM addresses (e.g. torch.Tensor.data_ptr())
- * and `hipStream` is a hipStream_t passed as void* (NULL = the object's own
- * stream).  Device variants are asynchronous on that stream; host variants
+ * and `hipStream` is a hipStream_t passed as void*, used as given (NULL is HIP's
+ * default stream, which is what torch.cuda.current_stream().cuda_stream is
+ * unless the caller switched streams).  Device variants are asynchronous on that stream; host variants
  * return with the result in host memory.  All return 0 or a negative status
  * (see afx_last_error()).
  */
