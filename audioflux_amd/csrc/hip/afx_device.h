@@ -105,6 +105,12 @@ int afxk_xxcc_standard(const float *cc, const float *energy, long long rows, int
                        int energyType, int deltaLen, float *coe, float *delta1, float *delta2,
                        void *stream);
 
+/* specialised rectify + DCT for cepstra (afx_cepstrum.hip): out[rows, ccNum] =
+ * pre(in)[rows, num] . dct[ccNum, num]^T */
+int afxk_cepstrum_supported(const float *in, int num, int ccNum);
+int afxk_cepstrum(const float *in, long long rows, int num, const float *dct, int ccNum, int pre,
+                  float *out, void *stream);
+
 /* ---- fused STFT -> banded filter bank kernel (afx_melfused.hip) ---------- */
 
 /* Banded view of a filter bank, one entry per lane of a 64-lane wave: every

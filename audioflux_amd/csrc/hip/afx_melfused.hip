@@ -46,14 +46,20 @@ constexpr int EX_PITCH = 68;    // float2 per k1 row of the exchange image
 constexpr int EX_F2 = 16 * EX_PITCH;  // 1088 float2; also holds the 1040-float2 natural image
 constexpr int PROW_F = 1104;    // 1025 bins + zero pad for the fixed-length band loops (>= 1025 + 72)
 constexpr int WAVE_LDS_BYTES = EX_F2 * 8;  // 8704; the power row (4416 B) aliases the exchange image
-constexpr int WAVES = 4;
+constexpr int WAVES = 12;       // one workgroup per CU: 3 waves per SIMD
 // workgroup-shared constant tables staged in LDS once per workgroup
 constexpr int TAB_WIN_F2 = 1024;     // (w[2n], w[2n+1])
 constexpr int TAB_TW1_F2 = 16 * 64;  // W_1024^(lane*k1)
 constexpr int TAB_TW2_F2 = 64;       // W_64^(m2*j1)
-constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2;
-constexpr int TAB_BYTES = TAB_F2 * 8;  // 16896
-constexpr int BLOCK_LDS_BYTES = TAB_BYTES + WAVES * WAVE_LDS_BYTES;  // 51712 -> 3 workgroups per CU
+constexpr int TAB_TW3_F2 = 512;      // 0.5 * W_2048^k
+constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
+constexpr int TAB_BYTES = TAB_F2 * 8;  // 20992
+// band weights: one row of TA+TB floats per lane, row pitch TA+TB+4 floats (pitch/4 odd:
+// the ds_read_b128 of any 16 consecutive lanes touch 64 distinct banks)
+__host__ __device__ constexpr int wpitch(int ta, int tb) { return ta + tb + 4; }
+__host__ __device__ constexpr int block_lds_bytes(int ta, int tb) {
+    return TAB_BYTES + 64 * wpitch(ta, tb) * 4 + WAVES * WAVE_LDS_BYTES;
+}
 
 struct KArgs {
     const float *x;
@@ -66,7 +72,7 @@ struct KArgs {
     const float2 *tw1;   // [16][64] W_1024^(lane*k1)
     const float2 *tw2;   // [4][16]  W_64^(m2*j1)
     const float2 *tw3;   // [512]    0.5 * W_2048^k
-    const float *wA, *wB;  // [taps][64]
+    const float *wLane;    // [64][wpitch]: lane-major band weights, A taps then B taps
     const int *meta;       // [4][64]: startA, startB, rowA, rowB
     int specMap, postPow;
     float normValue;
@@ -127,40 +133,40 @@ __device__ __forceinline__ float quad_swap(float v) {
 }
 
 // GENERAL = false: plain |S|^2 (the hot configuration; no sqrt/pow code in the loop)
-template <int TA, int TB, bool GENERAL>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_stft_mel_banded(KArgs a) {
+// SHIFT: consecutive frames of a clip overlap; with hop = 128*SHIFT samples the next
+// frame's register image is the current one moved down by SHIFT registers, so only SHIFT
+// new float2 per lane are fetched per frame (SHIFT = 0: every frame is fetched whole)
+template <int TA, int TB, bool GENERAL, int SHIFT>
+__global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    constexpr int WP = wpitch(TA, TB);
     float2 *tabWin = reinterpret_cast<float2 *>(smem);
     float2 *tabTw1 = tabWin + TAB_WIN_F2;
     float2 *tabTw2 = tabTw1 + TAB_TW1_F2;
-    float2 *ex = reinterpret_cast<float2 *>(smem + TAB_BYTES + wave * WAVE_LDS_BYTES);
+    float2 *tabTw3 = tabTw2 + TAB_TW2_F2;
+    float *tabW = reinterpret_cast<float *>(smem + TAB_BYTES);
+    float2 *ex = reinterpret_cast<float2 *>(smem + TAB_BYTES + 64 * WP * 4 + wave * WAVE_LDS_BYTES);
     float *prow = reinterpret_cast<float *>(ex);  // aliases ex: written only after the pair reads
 
     // ---- workgroup-shared tables -> LDS (once) ----------------------------------
     for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = a.win2[i];
     for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = a.tw1[i];
+    for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = a.tw3[i];
+    for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
     if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = a.tw2[threadIdx.x];
     __syncthreads();
 
-    // ---- per-lane constants, resident in VGPRs for the whole kernel ---------------
+    // ---- per-lane constants -----------------------------------------------------
     const int k1 = lane >> 2, m2 = lane & 3;
     const int j2 = ((lane & 1) << 1) | ((lane >> 1) & 1);
     const float sgnA = (m2 & 2) ? -1.f : 1.f;  // quad stage A: o + sgnA * v
     const float sgnB = (m2 & 1) ? -1.f : 1.f;  // quad stage B
     const bool rot = (m2 == 3);                // multiply by -i between the stages
-
-    float wA[TA], wB[TB];
-#pragma unroll
-    for (int t = 0; t < TA; ++t) wA[t] = a.wA[t * 64 + lane];
-#pragma unroll
-    for (int t = 0; t < TB; ++t) wB[t] = a.wB[t * 64 + lane];
-    float2 tw3[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) tw3[i] = a.tw3[lane + 64 * i];  // 0.5 * W_2048^k
     const int startA = a.meta[lane], startB = a.meta[64 + lane];
     const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const float4 *wrow = reinterpret_cast<const float4 *>(tabW + lane * WP);
 
     const long long gw = (long long)blockIdx.x * WAVES + wave;
     long long f = gw * a.framesPerWave;
@@ -170,25 +176,48 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_mel_banded(KArgs a) {
     int clip = (int)(f / a.timeLength);
     int t = (int)(f - (long long)clip * a.timeLength);
 
-    for (; f < fEnd; ++f) {
-        const float *px = a.x + (long long)clip * a.clipStride + (long long)t * a.hop;
-        float2 v[16];
-        // ---- 1. load + window ---------------------------------------------------
+    // raw samples of the frame about to be transformed: raw[n1] = (x[2n], x[2n+1]), n = 64 n1 + lane
+    float2 raw[16];
+    auto fetch = [&](const float *px, int first) {
         if (a.aligned) {
             const float2 *p2 = reinterpret_cast<const float2 *>(px);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) v[n1] = p2[64 * n1 + lane];
+            for (int n1 = 0; n1 < 16; ++n1)
+                if (n1 >= first) raw[n1] = p2[64 * n1 + lane];
         } else {
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int n = 64 * n1 + lane;
-                v[n1] = make_float2(px[2 * n], px[2 * n + 1]);
-            }
+            for (int n1 = 0; n1 < 16; ++n1)
+                if (n1 >= first) {
+                    const int n = 64 * n1 + lane;
+                    raw[n1] = make_float2(px[2 * n], px[2 * n + 1]);
+                }
         }
+    };
+    fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
+
+    for (; f < fEnd; ++f) {
+        float2 v[16];
+        // ---- 1. window (samples were fetched during the previous frame) ---------------
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const float2 w = tabWin[64 * n1 + lane];
-            v[n1] = make_float2(v[n1].x * w.x, v[n1].y * w.y);
+            v[n1] = make_float2(raw[n1].x * w.x, raw[n1].y * w.y);
+        }
+        // ---- 1b. start fetching the next frame: in flight under the whole transform ---
+        if (f + 1 < fEnd) {
+            int tn = t + 1, cn = clip;
+            if (tn == a.timeLength) {
+                tn = 0;
+                ++cn;
+            }
+            const float *pn = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
+            if (SHIFT > 0 && tn != 0) {
+#pragma unroll
+                for (int n1 = 0; n1 + SHIFT < 16; ++n1) raw[n1] = raw[n1 + SHIFT];
+                fetch(pn, 16 - SHIFT);
+            } else {
+                fetch(pn, 0);
+            }
         }
 
         // ---- 2a. radix-16 over n1, twiddle, transpose through LDS ---------------
@@ -229,7 +258,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_mel_banded(KArgs a) {
             const int kp = (MC - k) & (MC - 1);
             const float2 A = ex[k + 4 * (k >> 8)];
             const float2 B = ex[kp + 4 * (kp >> 8)];
-            const float2 w = tw3[i];
+            const float2 w = tabTw3[k];  // 0.5 * W_2048^k
             const float ex2 = 0.5f * (A.x + B.x), ey2 = 0.5f * (A.y - B.y);  // E
             const float ox = A.y + B.y, oy = B.x - A.x;                      // 2 O
             const float wx = w.x * ox - w.y * oy, wy = w.x * oy + w.y * ox;  // W O
@@ -271,16 +300,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_mel_banded(KArgs a) {
         if (lane < PROW_F - 1025 - 64) prow[1025 + 64 + lane] = 0.f;
         wave_lds_sync();
 
-        // ---- 4. banded filter bank ------------------------------------------------
-        float accA = 0.f, accB = 0.f;
+        // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset
+        //         ds_read_b32 (conflict-free by the plan's bank-aware lane assignment) ------
+        float accA0 = 0.f, accA1 = 0.f, accB = 0.f;
         {
             const float *pa = prow + startA;
 #pragma unroll
-            for (int tt = 0; tt < TA; ++tt) accA = fmaf(wA[tt], pa[tt], accA);
+            for (int q = 0; q < TA / 4; ++q) {
+                const float4 w = wrow[q];
+                accA0 = fmaf(w.x, pa[4 * q], accA0);
+                accA1 = fmaf(w.y, pa[4 * q + 1], accA1);
+                accA0 = fmaf(w.z, pa[4 * q + 2], accA0);
+                accA1 = fmaf(w.w, pa[4 * q + 3], accA1);
+            }
             const float *pb = prow + startB;
 #pragma unroll
-            for (int tt = 0; tt < TB; ++tt) accB = fmaf(wB[tt], pb[tt], accB);
+            for (int q = 0; q < TB / 4; ++q) {
+                const float4 w = wrow[TA / 4 + q];
+                accB = fmaf(w.x, pb[4 * q], accB);
+                accB = fmaf(w.y, pb[4 * q + 1], accB);
+                accB = fmaf(w.z, pb[4 * q + 2], accB);
+                accB = fmaf(w.w, pb[4 * q + 3], accB);
+            }
         }
+        float accA = accA0 + accA1;
         if (GENERAL && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
@@ -302,7 +345,7 @@ struct Plan {
     int variant;
     int num;
     float2 *dWin2, *dTw1, *dTw2, *dTw3;
-    float *dWA, *dWB;
+    float *dWLane;
     int *dMeta;
 };
 
@@ -312,20 +355,20 @@ struct Variant {
 constexpr Variant kVariants[] = {{48, 16}, {72, 24}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-template <int TA, int TB, bool GENERAL>
-int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
+template <int TA, int TB, bool GENERAL, int SHIFT>
+int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
-    // 2 workgroups of 4 waves per CU are resident (VGPR-limited: 2 waves per SIMD);
-    // a few rounds of them per CU keep the tail short while each wave still streams
-    // a contiguous, L2-friendly run of frames
-    long long waves = (long long)cus * 2 * WAVES * 4;
+    // one 12-wave workgroup is resident per CU (LDS ~140 KB); two rounds of workgroups keep
+    // the tail short while each wave still streams a long contiguous, L2-friendly run of
+    // frames (and re-uses 3/4 of every frame from registers)
+    long long waves = (long long)cus * WAVES * 2;
     long long fpw = (total + waves - 1) / waves;
-    if (fpw < 8) fpw = 8;
+    if (fpw < 16) fpw = 16;
     const long long usedWaves = (total + fpw - 1) / fpw;
     const long long blocks = (usedWaves + WAVES - 1) / WAVES;
 
@@ -342,25 +385,37 @@ int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.tw1 = p->dTw1;
     k.tw2 = p->dTw2;
     k.tw3 = p->dTw3;
-    k.wA = p->dWA;
-    k.wB = p->dWB;
+    k.wLane = p->dWLane;
     k.meta = p->dMeta;
     k.specMap = a->specMap;
     k.postPow = a->postPow;
     k.normValue = a->normValue;
     k.out = a->out;
     k.num = p->num;
-    const size_t lds = (size_t)BLOCK_LDS_BYTES;
+    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet = false;
     if (!attrSet) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AFX_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL, SHIFT>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet = true;
     }
-    hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
-                       (hipStream_t)stream, k);
+    hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL, SHIFT>), dim3((unsigned)blocks),
+                       dim3(WAVES * 64), lds, (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_mel_banded");
     return AFX_OK;
+}
+
+template <int TA, int TB>
+int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
+    const bool general = (a->specMap != 0) || a->postPow;
+    const bool shift4 = (a->hop == 512);  // hop = 128 * SHIFT
+    if (general) {
+        return shift4 ? launch_variant<TA, TB, true, 4>(p, a, stream)
+                      : launch_variant<TA, TB, true, 0>(p, a, stream);
+    }
+    return shift4 ? launch_variant<TA, TB, false, 4>(p, a, stream)
+                  : launch_variant<TA, TB, false, 0>(p, a, stream);
 }
 
 template <typename T>
@@ -388,8 +443,7 @@ extern "C" void afxk_melfused_destroy(void *plan) {
     afxdev_free(p->dTw1);
     afxdev_free(p->dTw2);
     afxdev_free(p->dTw3);
-    afxdev_free(p->dWA);
-    afxdev_free(p->dWB);
+    afxdev_free(p->dWLane);
     afxdev_free(p->dMeta);
     free(p);
 }
@@ -409,10 +463,10 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     float *tw1 = static_cast<float *>(malloc(sizeof(float) * 2 * 16 * 64));
     float *tw2 = static_cast<float *>(malloc(sizeof(float) * 2 * 4 * 16));
     float *tw3 = static_cast<float *>(malloc(sizeof(float) * 2 * 512));
-    float *wA = static_cast<float *>(calloc((size_t)TA * 64, sizeof(float)));
-    float *wB = static_cast<float *>(calloc((size_t)TB * 64, sizeof(float)));
+    const int WP = TA + TB + 4;
+    float *wL = static_cast<float *>(calloc((size_t)64 * WP, sizeof(float)));
     int meta[256];
-    int st = (tw1 && tw2 && tw3 && wA && wB) ? AFX_OK : AFX_ERR_NOMEM;
+    int st = (tw1 && tw2 && tw3 && wL) ? AFX_OK : AFX_ERR_NOMEM;
     if (st == AFX_OK) {
         const double PI = 3.14159265358979323846;
         for (int k = 0; k < 16; ++k)
@@ -432,8 +486,10 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
             tw3[2 * k] = (float)(0.5 * cos(ang));
             tw3[2 * k + 1] = (float)(0.5 * sin(ang));
         }
-        memcpy(wA, band->wA, sizeof(float) * (size_t)band->tapsA * 64);
-        memcpy(wB, band->wB, sizeof(float) * (size_t)band->tapsB * 64);
+        for (int l = 0; l < 64; ++l) {
+            for (int t = 0; t < band->tapsA; ++t) wL[(size_t)l * WP + t] = band->wA[(size_t)t * 64 + l];
+            for (int t = 0; t < band->tapsB; ++t) wL[(size_t)l * WP + TA + t] = band->wB[(size_t)t * 64 + l];
+        }
         for (int l = 0; l < 64; ++l) {
             meta[l] = band->startA[l];
             meta[64 + l] = band->startB[l];
@@ -445,15 +501,13 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     if (st == AFX_OK) st = upload(&p->dTw1, tw1, sizeof(float) * 2 * 16 * 64, stream);
     if (st == AFX_OK) st = upload(&p->dTw2, tw2, sizeof(float) * 2 * 4 * 16, stream);
     if (st == AFX_OK) st = upload(&p->dTw3, tw3, sizeof(float) * 2 * 512, stream);
-    if (st == AFX_OK) st = upload(&p->dWA, wA, sizeof(float) * (size_t)TA * 64, stream);
-    if (st == AFX_OK) st = upload(&p->dWB, wB, sizeof(float) * (size_t)TB * 64, stream);
+    if (st == AFX_OK) st = upload(&p->dWLane, wL, sizeof(float) * (size_t)64 * WP, stream);
     if (st == AFX_OK) st = upload(&p->dMeta, meta, sizeof(meta), stream);
     if (st == AFX_OK) st = afxdev_stream_sync(stream);  // host staging buffers are freed below
     free(tw1);
     free(tw2);
     free(tw3);
-    free(wA);
-    free(wB);
+    free(wL);
     if (st != AFX_OK) {
         afxk_melfused_destroy(p);
         return st;
@@ -465,12 +519,11 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
 extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return AFX_ERR_ARG;
-    const bool general = (a->specMap != 0) || a->postPow;
     switch (p->variant) {
         case 0:
-            return general ? launch<48, 16, true>(p, a, stream) : launch<48, 16, false>(p, a, stream);
+            return launch<48, 16>(p, a, stream);
         case 1:
-            return general ? launch<72, 24, true>(p, a, stream) : launch<72, 24, false>(p, a, stream);
+            return launch<72, 24>(p, a, stream);
         default:
             return AFX_ERR_UNSUPPORTED;
     }

@@ -33,6 +33,77 @@ void afx_bandplan_free(AfxBandPlan *p) {
     p->wA = p->wB = NULL;
 }
 
+/* ---- LDS-bank-aware lane assignment ------------------------------------------
+ * In the kernel every lane reads P[start_lane + t] for t = 0,1,2,... with one
+ * ds_read per tap; a 32-lane half-wave is conflict-free exactly when its 32
+ * start addresses are distinct mod 32 (LDS has 32 dword banks for ds_read_b32).
+ * A row may start up to `d` bins early (leading zero weights) to land on a free
+ * residue.  Rows are matched to the 64 (half, residue) slots so that the
+ * longest padded row, max(len + d), is as short as possible: bottleneck
+ * assignment by binary search over the bound + Kuhn's augmenting-path matching
+ * (64 x 64, plan time only). */
+static int shift_for(const RowBand *r, int residue) {
+    int d = (r->start - residue) % 32;
+    if (d < 0) d += 32;
+    return d; /* new start = start - d is congruent to residue */
+}
+
+static int try_augment(int row, int n, const RowBand *rows, int bound, int *slotOwner, char *seen) {
+    (void)n;
+    for (int slot = 0; slot < 64; slot++) {
+        if (seen[slot]) continue;
+        const int d = shift_for(&rows[row], slot & 31);
+        if (d > rows[row].start || rows[row].len + d > bound) continue;
+        seen[slot] = 1;
+        if (slotOwner[slot] < 0 ||
+            try_augment(slotOwner[slot], n, rows, bound, slotOwner, seen)) {
+            slotOwner[slot] = row;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static int match_with_bound(const RowBand *rows, int n, int bound, int *slotOwner) {
+    for (int s = 0; s < 64; s++) slotOwner[s] = -1;
+    for (int i = 0; i < n; i++) {
+        char seen[64];
+        memset(seen, 0, sizeof(seen));
+        if (!try_augment(i, n, rows, bound, slotOwner, seen)) return 0;
+    }
+    return 1;
+}
+
+/* assigns n (<= 64) rows to lanes; returns the padded tap count, fills
+ * laneRow[64] (index into rows, -1 = idle lane) and laneShift[64] */
+static int assign_lanes(const RowBand *rows, int n, int *laneRow, int *laneShift) {
+    int slotOwner[64];
+    int lo = 1, hi = 1;
+    for (int i = 0; i < n; i++) {
+        if (rows[i].len > lo) lo = rows[i].len;
+    }
+    hi = lo + 31;
+    if (!match_with_bound(rows, n, hi, slotOwner)) {
+        /* cannot happen (a shift of < 32 always exists unless start is tiny and
+         * residues clash); fall back to identity placement, conflicts allowed */
+        for (int l = 0; l < 64; l++) {
+            laneRow[l] = l < n ? l : -1;
+            laneShift[l] = 0;
+        }
+        return lo;
+    }
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (match_with_bound(rows, n, mid, slotOwner)) hi = mid; else lo = mid + 1;
+    }
+    match_with_bound(rows, n, lo, slotOwner);
+    for (int slot = 0; slot < 64; slot++) { /* slot = 32*half + residue = lane */
+        laneRow[slot] = slotOwner[slot];
+        laneShift[slot] = slotOwner[slot] >= 0 ? shift_for(&rows[slotOwner[slot]], slot & 31) : 0;
+    }
+    return lo;
+}
+
 /* returns 0 and fills *p when the bank fits the banded scheme, 1 otherwise */
 int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p) {
     memset(p, 0, sizeof(*p));
@@ -54,23 +125,18 @@ int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p) {
     }
     qsort(rb, (size_t)num, sizeof(RowBand), cmp_len_desc);
 
+    /* the 64 longest rows form set A, the rest set B: every lane gets one of each */
     const int nA = num < 64 ? num : 64;
     const int nB = num - nA;
+    int laneRowA[64], laneShiftA[64], laneRowB[64], laneShiftB[64];
     p->num = num;
-    for (int i = 0; i < 64; i++) {
-        p->rowA[i] = p->rowB[i] = -1;
+    p->tapsA = assign_lanes(rb, nA, laneRowA, laneShiftA);
+    p->tapsB = 1;
+    for (int l = 0; l < 64; l++) {
+        laneRowB[l] = -1;
+        laneShiftB[l] = 0;
     }
-    for (int i = 0; i < nA; i++) {
-        p->rowA[i] = i; /* index into rb for now */
-        if (rb[i].len > p->tapsA) p->tapsA = rb[i].len;
-    }
-    for (int i = 0; i < nB; i++) {
-        const int j = num - 1 - i; /* shortest rows first */
-        p->rowB[i] = j;
-        if (rb[j].len > p->tapsB) p->tapsB = rb[j].len;
-    }
-    if (p->tapsA < 1) p->tapsA = 1;
-    if (p->tapsB < 1) p->tapsB = 1;
+    if (nB > 0) p->tapsB = assign_lanes(rb + nA, nB, laneRowB, laneShiftB);
     p->wA = (float *)calloc((size_t)p->tapsA * 64, sizeof(float));
     p->wB = (float *)calloc((size_t)p->tapsB * 64, sizeof(float));
     if (!p->wA || !p->wB) {
@@ -78,20 +144,27 @@ int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p) {
         afx_bandplan_free(p);
         return 1;
     }
-    for (int i = 0; i < 64; i++) {
-        if (p->rowA[i] >= 0) {
-            const RowBand *r = &rb[p->rowA[i]];
+    for (int l = 0; l < 64; l++) {
+        p->rowA[l] = p->rowB[l] = -1;
+        /* idle lanes still execute the reads: give them their own residue so they
+         * do not collide with a working lane of the same half */
+        p->startA[l] = l & 31;
+        p->startB[l] = l & 31;
+        if (laneRowA[l] >= 0) {
+            const RowBand *r = &rb[laneRowA[l]];
+            const int d = laneShiftA[l];
             for (int t = 0; t < r->len; t++)
-                p->wA[(size_t)t * 64 + i] = bank[(size_t)r->row * F + r->start + t];
-            p->startA[i] = r->start;
-            p->rowA[i] = r->row;
+                p->wA[(size_t)(t + d) * 64 + l] = bank[(size_t)r->row * F + r->start + t];
+            p->startA[l] = r->start - d;
+            p->rowA[l] = r->row;
         }
-        if (p->rowB[i] >= 0) {
-            const RowBand *r = &rb[p->rowB[i]];
+        if (laneRowB[l] >= 0) {
+            const RowBand *r = &rb[nA + laneRowB[l]];
+            const int d = laneShiftB[l];
             for (int t = 0; t < r->len; t++)
-                p->wB[(size_t)t * 64 + i] = bank[(size_t)r->row * F + r->start + t];
-            p->startB[i] = r->start;
-            p->rowB[i] = r->row;
+                p->wB[(size_t)(t + d) * 64 + l] = bank[(size_t)r->row * F + r->start + t];
+            p->startB[l] = r->start - d;
+            p->rowB[l] = r->row;
         }
     }
     free(rb);

@@ -57,6 +57,9 @@ int xxccObj_xxccDevice(XXCCObj o, const float *dIn, long long rows, int ccNum,
                        CepstralRectifyType *rectifyType, float *dOut, void *hipStream) {
     if (!o || !dIn || !dOut) return AFX_ERR_ARG;
     if (ccNum > o->num || ccNum < 1) return AFX_ERR_ARG;
+    if (afxk_cepstrum_supported(dIn, o->num, ccNum) && !getenv("AFX_NO_FUSED"))
+        return afxk_cepstrum(dIn, rows, o->num, o->dDct, ccNum, rectify_to_map(rectifyType), dOut,
+                             hipStream);
     return afxk_gemm_nt(dIn, o->num, o->dDct, o->num, dOut, ccNum, rows, ccNum, o->num,
                         rectify_to_map(rectifyType), AFX_MAP_NONE, 1.f, hipStream);
 }
