@@ -8,7 +8,9 @@ from ._lib import LIB_PATH, build, get_lib, last_error, runtime_status
 from .types import *  # noqa: F401,F403
 from .bft import BFT
 from .xxcc import XXCC
+from .cepstrogram import Cepstrogram
+from .cqt import CQT
 from .batch import mel_mfcc_device
 
-__all__ = ["BFT", "XXCC", "mel_mfcc_device", "get_lib", "build", "runtime_status",
+__all__ = ["BFT", "XXCC", "Cepstrogram", "CQT", "mel_mfcc_device", "get_lib", "build", "runtime_status",
            "last_error", "LIB_PATH"]

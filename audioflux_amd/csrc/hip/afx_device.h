@@ -105,6 +105,40 @@ int afxk_xxcc_standard(const float *cc, const float *energy, long long rows, int
                        int energyType, int deltaLen, float *coe, float *delta1, float *delta2,
                        void *stream);
 
+/* ---- constant-Q transform (afx_cqt.hip) ----------------------------------- */
+typedef struct {
+    const float *x;        /* device: this octave's signal                            */
+    int validLength;       /* samples framed (length minus the dropped tail)          */
+    int timeLength, radix2Exp, hop;
+    const float *twiddle;  /* device [N/2] float2                                     */
+    const int *kStart, *kLen, *kOff; /* device, per kernel row: first bin, taps, offset */
+    const float *kTaps;    /* device float2 taps, rows packed back to back            */
+    int rowBase;           /* first kernel row of this octave (0 unless variable-Q)   */
+    int rows;              /* bins per octave                                         */
+    const float *scale;    /* device [num]: sqrt(len_j) (or 1 when scaling is off)    */
+    float octScale;        /* sqrt(2^k) of the octave                                 */
+    int num, colBase;      /* output row pitch / first output column of this octave   */
+    float *outRe, *outIm;  /* device [T, num]                                         */
+} AfxCqtOctaveArgs;
+int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
+int afxk_cqt_decimate(const float *x, int srcLen, float *y, int dstLen, const float *taps32,
+                      float sqrtRatio, void *stream);
+int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
+                    const unsigned char *fold, int chromaNum, int isMag, int normType, float *out,
+                    void *stream);
+
+/* cepstrogram (afx_cepstrogram.hip): one clip, timeLength frames */
+typedef struct {
+    const float *x;      /* device samples, or NULL to start from specRe/specIm     */
+    int timeLength, radix2Exp, hop, cepNum;
+    const float *window; /* device [N]                                              */
+    const float *twiddle;/* device [N/2] float2                                     */
+    float *specRe;       /* device [T,N] spectrum cache: written when x != NULL     */
+    float *specIm;       /*   (may be NULL), read when x == NULL                    */
+    float *out1, *out2, *out3; /* device [T, N/2+1]; any may be NULL                */
+} AfxCepstrogramArgs;
+int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream);
+
 /* specialised rectify + DCT for cepstra (afx_cepstrum.hip): out[rows, ccNum] =
  * pre(in)[rows, num] . dct[ccNum, num]^T */
 int afxk_cepstrum_supported(const float *in, int num, int ccNum);

@@ -1,0 +1,509 @@
+/* afx_cqt.c -- the constant-Q transform object (C host side) behind
+ * include/cqt_algorithm.h.
+ *
+ * Plan construction follows the reference in float32: bin frequencies and
+ * lengths (src/filterbank/cqt_filterBank.c:159-246), the temporal kernels
+ * w[n] e^{2 pi j n f / fs} centred in fftLength, their FFT and the magnitude
+ * threshold (cqt_filterBank.c:57-148, :253-336), the 2:1 resampler table
+ * (src/dsp/resample_algorithm.c:546-634) and the chroma folding matrix
+ * (src/filterbank/chroma_filterBank.c:176-264).  Execution is the octave
+ * recursion of _cqtObj_cqt (src/cqt_algorithm.c:845-1061) on the GPU: per
+ * octave one fused frame-FFT + sparse-kernel launch, then a decimation launch.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "afx_device.h"
+#include "afx_host.h"
+#include "cqt_algorithm.h"
+
+struct OpaqueCQT {
+    int num, octaveNum, binPerOctave, samplate;
+    int fftLength, radix2Exp, slideLength;
+    int isScale, vFlag;
+    float minFre;
+    WindowType windowType;
+    SpectralFilterBankNormalType normType;
+    float *freBandArr;       /* host, num+2 */
+    float *sLenArr;          /* host, num: sqrt(len) */
+    float taps[32];          /* resampler FIR h_j = table[256 j] */
+    int timeLength;          /* frames of the last cqt call */
+    /* device */
+    void *stream;
+    float *dTwiddle, *dKTaps, *dScaleOn, *dScaleOff;
+    int *dKStart, *dKLen, *dKOff;
+    unsigned char *dFold;
+    int foldChromaNum;
+    float *dSig[2];          /* ping-pong octave signals */
+    size_t capSig[2];
+    float *dOut;             /* re | im [T,num] */
+    size_t capOut;
+    float *dIn;              /* chroma / cqcc staging */
+    size_t capIn;
+    float *dDct;             /* [num,num] for cqcc */
+    int status;
+};
+
+static void fail(CQTObj o, int st, const char *who) {
+    o->status = st;
+    fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+}
+
+int cqtObj_new(CQTObj *cqtObj, int num, int samplate, float minFre, int *isContinue) {
+    return cqtObj_newWith(cqtObj, num, &samplate, &minFre, NULL, NULL, NULL, NULL, NULL, NULL,
+                          isContinue, NULL, NULL);
+}
+
+/* one octave of temporal kernels -> spectral kernels (cqt_filterBank.c:253-336 + FFT) */
+static void octave_kernels(int bpo, const float *fre /* fre[-1], fre[bpo] readable */,
+                           int samplate, const float *lenArr, int fftLength, int r,
+                           SpectralFilterBankNormalType normType, WindowType winType,
+                           float *outRe, float *outIm /* [bpo, fftLength] */) {
+    float *tr = (float *)calloc((size_t)fftLength, sizeof(float));
+    float *ti = (float *)calloc((size_t)fftLength, sizeof(float));
+    if (winType == Window_Rect) winType = Window_Hann; /* cqt_filterBank.c:259-263 */
+    for (int i = 0; i < bpo; i++) {
+        const int len = (int)ceilf(lenArr[i]);
+        const float f = fre[i];
+        float *w = afx_window_fft(winType, len);
+        const int start = (fftLength - len) / 2;
+        memset(tr, 0, sizeof(float) * (size_t)fftLength);
+        memset(ti, 0, sizeof(float) * (size_t)fftLength);
+        float weight = 1;
+        for (int j = 0; j < len; j++) {
+            if (normType == SpectralFilterBankNormal_None) weight = lenArr[i];
+            const float n = (float)j; /* arange(0, len, 1) */
+            const float v = (float)(2 * M_PI * n * f / samplate);
+            tr[j + start] = cosf(v) * w[j] / weight;
+            ti[j + start] = sinf(v) * w[j] / weight;
+        }
+        weight = 0;
+        if (normType == SpectralFilterBankNormal_Area) {
+            for (int j = 0; j < len; j++) {
+                const float a = tr[j + start], b = ti[j + start];
+                weight += sqrtf(a * a + b * b);
+            }
+            for (int j = 0; j < len; j++) {
+                tr[j + start] /= weight;
+                ti[j + start] /= weight;
+            }
+        } else if (normType == SpectralFilterBankNormal_BandWidth) {
+            weight = (fre[i + 1] - fre[i - 1]) / 2;
+            for (int j = 0; j < len; j++) {
+                tr[j + start] /= weight;
+                ti[j + start] /= weight;
+            }
+        }
+        for (int j = 0; j < len; j++) {
+            tr[j + start] *= (lenArr[i] / fftLength);
+            ti[j + start] *= (lenArr[i] / fftLength);
+        }
+        afx_fft_ref32(r, tr, ti, outRe + (size_t)i * fftLength, outIm + (size_t)i * fftLength);
+        free(w);
+    }
+    free(tr);
+    free(ti);
+}
+
+int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *binPerOctave,
+                   float *factor, float *beta, float *thresh, WindowType *windowType,
+                   int *slideLength, int *isContinue, SpectralFilterBankNormalType *normalType,
+                   int *isScale) {
+    int sr = 32000, bpo = 12, slide = 0, cont = 0, vFlag = 0, scaleFlag = 1;
+    float fmin = 32.703196f, fac = 1, bet = 0, thr = 0.01f;
+    WindowType win = Window_Hann;
+    SpectralFilterBankNormalType norm = SpectralFilterBankNormal_None;
+    if (!cqtObj) return -1;
+    *cqtObj = NULL;
+
+    /* validation in the reference's order (cqt_algorithm.c:150-222) */
+    if (binPerOctave && *binPerOctave > 0) bpo = *binPerOctave;
+    if (bpo % 12 != 0) {
+        printf("binPerOctave is error\n");
+        return -1;
+    }
+    if (num < bpo || num % bpo != 0) {
+        printf("num is error\n");
+        return -1;
+    }
+    if (samplate && *samplate > 0) sr = *samplate;
+    if (minFre && *minFre > 0) fmin = *minFre;
+    if (factor && *factor > 0) fac = *factor;
+    if (beta) {
+        if (*beta > 0) bet = *beta;
+        if (bet != 0) vFlag = 1;
+    }
+    if (thresh && *thresh > 0) thr = *thresh;
+    if (windowType) win = *windowType;
+    if (slideLength && *slideLength > 0) slide = *slideLength;
+    if (isContinue) cont = *isContinue;
+    if (normalType) norm = *normalType;
+    if (isScale) scaleFlag = *isScale;
+    if (cont) {
+        afxdev_set_error("cqtObj_newWith: isContinue=1 (streaming) is not implemented by the MI355X backend");
+        return AFX_ERR_UNSUPPORTED;
+    }
+    const int octaveNum = num / bpo;
+    if (norm == SpectralFilterBankNormal_BandWidth && (octaveNum < 2 || vFlag)) {
+        afxdev_set_error("cqtObj_newWith: BandWidth normalisation of a single octave reads before the "
+                         "frequency table in the reference (undefined); refused");
+        return AFX_ERR_UNSUPPORTED;
+    }
+
+    int st = afxdev_ensure();
+    if (st != AFX_OK) return st;
+    CQTObj o = (CQTObj)calloc(1, sizeof(struct OpaqueCQT));
+    if (!o) return AFX_ERR_NOMEM;
+    o->num = num;
+    o->octaveNum = octaveNum;
+    o->binPerOctave = bpo;
+    o->samplate = sr;
+    o->isScale = scaleFlag;
+    o->vFlag = vFlag;
+    o->minFre = fmin;
+    o->windowType = win;
+    o->normType = norm;
+
+    /* ---- frequencies, lengths (cqt_filterBank.c:159-246) */
+    o->freBandArr = (float *)calloc((size_t)num + 2, sizeof(float));
+    o->sLenArr = (float *)calloc((size_t)num, sizeof(float));
+    float *lenTop = (float *)calloc((size_t)bpo, sizeof(float));
+    const float ratio = powf(2, (float)(1.0 / bpo));
+    for (int i = 0; i < octaveNum; i++) {
+        float f = fmin * (1 << i);
+        o->freBandArr[i * bpo] = f;
+        for (int j = 1; j < bpo; j++) {
+            f *= ratio;
+            o->freBandArr[i * bpo + j] = f;
+        }
+    }
+    const int topIndex = (octaveNum - 1) * bpo;
+    const float value = powf(2, (float)(1.0 / bpo)) - 1;
+    const float q = fac / value;
+    {
+        const int len = (int)ceilf(q * sr / (o->freBandArr[topIndex] + bet / value));
+        o->fftLength = afx_ceil_pow2(len);
+    }
+    o->radix2Exp = afx_log2_exact(o->fftLength);
+    for (int i = 0; i < bpo; i++) lenTop[i] = q * sr / (o->freBandArr[topIndex + i] + bet / value);
+    for (int i = 0; i < num; i++) o->sLenArr[i] = sqrtf(q * sr / (o->freBandArr[i] + bet / value));
+    if (slide <= 0) slide = o->fftLength / 4;
+    o->slideLength = slide;
+    if (o->radix2Exp < 1 || o->radix2Exp > 14 || (slide >> (octaveNum - 1)) < 1) {
+        afxdev_set_error("cqtObj_newWith: fftLength %d / slideLength %d unsupported for %d octaves",
+                         o->fftLength, slide, octaveNum);
+        cqtObj_free(o);
+        free(lenTop);
+        return AFX_ERR_UNSUPPORTED;
+    }
+
+    /* ---- spectral kernels, thresholded, stored as bands */
+    const int N = o->fftLength, F = N / 2 + 1;
+    const int rowsTotal = vFlag ? num : bpo;
+    float *kre = (float *)calloc((size_t)rowsTotal * N, sizeof(float));
+    float *kim = (float *)calloc((size_t)rowsTotal * N, sizeof(float));
+    if (!vFlag) {
+        octave_kernels(bpo, o->freBandArr + topIndex, sr, lenTop, N, o->radix2Exp, norm, win, kre, kim);
+    } else { /* variable-Q: every octave has its own kernels at its own (halved) rate */
+        int srOct = sr;
+        for (int i = octaveNum - 1; i >= 0; i--) {
+            octave_kernels(bpo, o->freBandArr + i * bpo, srOct, lenTop, N, o->radix2Exp, norm, win,
+                           kre + (size_t)i * bpo * N, kim + (size_t)i * bpo * N);
+            srOct /= 2;
+        }
+    }
+    int *kStart = (int *)calloc((size_t)rowsTotal, sizeof(int));
+    int *kLen = (int *)calloc((size_t)rowsTotal, sizeof(int));
+    int *kOff = (int *)calloc((size_t)rowsTotal, sizeof(int));
+    float *kTaps = (float *)calloc((size_t)rowsTotal * F * 2 + 2, sizeof(float));
+    int total = 0;
+    const float thr2 = thr * thr;
+    for (int i = 0; i < rowsTotal; i++) {
+        int first = -1, last = -1;
+        for (int j = 0; j < F; j++) {
+            const float a = kre[(size_t)i * N + j], b = kim[(size_t)i * N + j];
+            if (a * a + b * b > thr2) {
+                if (first < 0) first = j;
+                last = j;
+            }
+        }
+        kStart[i] = first < 0 ? 0 : first;
+        kLen[i] = first < 0 ? 0 : last - first + 1;
+        kOff[i] = total;
+        for (int j = 0; j < kLen[i]; j++) {
+            const float a = kre[(size_t)i * N + first + j], b = kim[(size_t)i * N + first + j];
+            const int keep = (a * a + b * b > thr2);
+            kTaps[2 * (total + j)] = keep ? a : 0.f;
+            kTaps[2 * (total + j) + 1] = keep ? b : 0.f;
+        }
+        total += kLen[i];
+    }
+
+    /* ---- 2:1 resampler taps: h_j = 0.5 * rollOff*sinc(rollOff*j/2) * kaiser(j), j < 32
+     *      (resample_algorithm.c:546-634 with zeroNum 16, nbit 9, beta 8.5555046, rollOff 0.85) */
+    {
+        const float rollOff = 0.85f;
+        float *kw = afx_window_kaiser(2 * 8192 + 1, 8.5555046f);
+        const float step = (16.f - 0.f) / 8192;
+        for (int j = 0; j < 32; j++) {
+            const int m = 256 * j;
+            float x = 0.f + m * step;
+            x *= rollOff;
+            const float px = (float)(x * M_PI);
+            float sc = (fabsf(px) < 1e-9) ? 1.f : sinf(px) / px;
+            sc *= rollOff;
+            sc = sc * kw[8192 + m];
+            o->taps[j] = sc * 0.5f; /* interpArr *= ratio */
+        }
+        free(kw);
+    }
+
+    /* ---- device constants */
+    float *tw = afx_twiddle_table(N);
+    float *ones = (float *)calloc((size_t)num, sizeof(float));
+    for (int i = 0; i < num; i++) ones[i] = 1.f;
+    st = afxdev_stream_create(&o->stream);
+#define UP(dst, src, bytes)                                                        \
+    if (st == AFX_OK) st = afxdev_malloc((void **)&(dst), (bytes));                \
+    if (st == AFX_OK) st = afxdev_h2d((dst), (src), (bytes), o->stream)
+    UP(o->dTwiddle, tw, sizeof(float) * (size_t)(N < 2 ? 2 : N));
+    UP(o->dKTaps, kTaps, sizeof(float) * 2 * (size_t)(total + 1));
+    UP(o->dKStart, kStart, sizeof(int) * (size_t)rowsTotal);
+    UP(o->dKLen, kLen, sizeof(int) * (size_t)rowsTotal);
+    UP(o->dKOff, kOff, sizeof(int) * (size_t)rowsTotal);
+    UP(o->dScaleOn, o->sLenArr, sizeof(float) * (size_t)num);
+    UP(o->dScaleOff, ones, sizeof(float) * (size_t)num);
+#undef UP
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    free(tw);
+    free(ones);
+    free(kre);
+    free(kim);
+    free(kStart);
+    free(kLen);
+    free(kOff);
+    free(kTaps);
+    free(lenTop);
+    if (st != AFX_OK) {
+        cqtObj_free(o);
+        return st;
+    }
+    *cqtObj = o;
+    return 0;
+}
+
+int cqtObj_calTimeLength(CQTObj o, int dataLength) {
+    if (!o || dataLength <= 0) return 0;
+    return dataLength / o->slideLength + 1; /* padded framing, cqt_algorithm.c:289-297 */
+}
+
+int cqtObj_getFFTLength(CQTObj o) { return o ? o->fftLength : 0; }
+float *cqtObj_getFreBandArr(CQTObj o) { return o ? o->freBandArr : NULL; }
+
+void cqtObj_setScale(CQTObj o, int flag) {
+    if (o) o->isScale = flag;
+}
+
+void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float *mImageArr) {
+    if (!o) {
+        afxdev_set_error("cqtObj_cqt: NULL object");
+        return;
+    }
+    if (!dataArr || dataLength <= 0 || !mRealArr || !mImageArr) return;
+    const int T = dataLength / o->slideLength + 1;
+    const size_t outB = sizeof(float) * (size_t)T * o->num;
+    int st = afxdev_reserve((void **)&o->dOut, &o->capOut, 2 * outB);
+    for (int i = 0; i < 2 && st == AFX_OK; i++)
+        st = afxdev_reserve((void **)&o->dSig[i], &o->capSig[i], sizeof(float) * (size_t)dataLength);
+    if (st == AFX_OK) st = afxdev_h2d(o->dSig[0], dataArr, sizeof(float) * (size_t)dataLength, o->stream);
+
+    AfxCqtOctaveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.timeLength = T;
+    a.radix2Exp = o->radix2Exp;
+    a.twiddle = o->dTwiddle;
+    a.kStart = o->dKStart;
+    a.kLen = o->dKLen;
+    a.kOff = o->dKOff;
+    a.kTaps = o->dKTaps;
+    a.rows = o->binPerOctave;
+    a.scale = o->isScale ? o->dScaleOn : o->dScaleOff;
+    a.num = o->num;
+    a.outRe = o->dOut;
+    a.outIm = o->dOut + (size_t)T * o->num;
+
+    int cur = 0, len = dataLength, hop = o->slideLength;
+    for (int oct = o->octaveNum - 1; oct >= 0 && st == AFX_OK; oct--) {
+        const int k = o->octaveNum - 1 - oct; /* decimations so far */
+        const int frames = len / hop + 1;
+        a.x = o->dSig[cur];
+        a.hop = hop;
+        a.validLength = len - (frames > 1 ? len % hop : 0); /* stft_algorithm.c:838-843 */
+        a.rowBase = o->vFlag ? oct * o->binPerOctave : 0;
+        a.colBase = oct * o->binPerOctave;
+        a.octScale = k == 0 ? 1.f : sqrtf((float)(1 << k)); /* dLenArr, cqt_algorithm.c:1218-1221 */
+        st = afxk_cqt_octave(&a, o->stream);
+        if (st != AFX_OK || oct == 0) break;
+        const int next = (int)floorf(len * 0.5f); /* resampleObj_calDataLength */
+        st = afxk_cqt_decimate(o->dSig[cur], len, o->dSig[cur ^ 1], next, o->taps, sqrtf(0.5f),
+                               o->stream);
+        cur ^= 1;
+        len = next;
+        hop /= 2;
+    }
+    if (st == AFX_OK) st = afxdev_d2h(mRealArr, a.outRe, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mImageArr, a.outIm, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    o->timeLength = T;
+    if (st != AFX_OK) fail(o, st, "cqtObj_cqt");
+}
+
+/* 0/1 folding matrix bins -> chroma (chroma_filterBank.c:176-264), host side */
+static unsigned char *chroma_fold(int chromaNum, int num, int bpo, float minFre) {
+    unsigned char *tmp = (unsigned char *)calloc((size_t)chromaNum * num, 1);
+    unsigned char *out = (unsigned char *)calloc((size_t)chromaNum * num, 1);
+    int n = bpo / chromaNum;
+    const int offset = (int)ceilf((float)(n / 2.0));
+    const int sub = n - offset;
+    int midi = (int)roundf((float)(12 * log2(minFre / 440) + 69));
+    midi = midi % 12;
+    if (midi > 6) midi = 12 - midi;
+    int start = 0;
+    for (int i = 0; i < chromaNum; i++) {
+        if (i) start = offset + (i - 1) * n;
+        for (int j = 0; j < num; j++) {
+            const int mod = j % bpo;
+            if (i != 0) {
+                if (mod >= start && mod < start + n) tmp[(size_t)i * num + j] = 1;
+            } else {
+                if (mod >= 0 && mod < offset) tmp[j] = 1;
+                if (sub && mod >= bpo - sub && mod < bpo) tmp[j] = 1;
+            }
+        }
+    }
+    if (midi) { /* row rotation; n is chromaNum/bpo here, i.e. 1 only when they are equal */
+        n = chromaNum / bpo;
+        int k = 0;
+        for (int i = midi * n; i < chromaNum; i++, k++) memcpy(out + (size_t)k * num, tmp + (size_t)i * num, (size_t)num);
+        k = chromaNum - midi * n;
+        for (int i = 0; i < midi * n; i++, k++) memcpy(out + (size_t)k * num, tmp + (size_t)i * num, (size_t)num);
+        free(tmp);
+        return out;
+    }
+    free(out);
+    return tmp;
+}
+
+void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
+                   ChromaDataNormalType *normType, float *mRealArr, float *mImageArr,
+                   float *mDataArr) {
+    if (!o) {
+        afxdev_set_error("cqtObj_chroma: NULL object");
+        return;
+    }
+    int cn = 12;
+    SpectralDataType dt = SpectralData_Power;
+    ChromaDataNormalType nt = ChromaDataNormal_Max;
+    if (chromaNum) cn = *chromaNum;
+    if (dataType) dt = *dataType;
+    if (normType) nt = *normType;
+    if (cn <= 0 || cn > o->binPerOctave || o->binPerOctave % cn != 0) {
+        printf("chromaNum and binPerOctave not map!!!");
+        return;
+    }
+    const int T = o->timeLength;
+    if (T <= 0 || !mRealArr || !mImageArr || !mDataArr) return;
+    int st = AFX_OK;
+    if (cn != o->foldChromaNum) {
+        unsigned char *fold = chroma_fold(cn, o->num, o->binPerOctave, o->minFre);
+        afxdev_free(o->dFold);
+        o->dFold = NULL;
+        st = afxdev_malloc((void **)&o->dFold, (size_t)cn * o->num);
+        if (st == AFX_OK) st = afxdev_h2d(o->dFold, fold, (size_t)cn * o->num, o->stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+        free(fold);
+        if (st == AFX_OK) o->foldChromaNum = cn;
+    }
+    const size_t inB = sizeof(float) * (size_t)T * o->num;
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dIn, &o->capIn, 2 * inB + sizeof(float) * (size_t)T * cn);
+    float *dRe = o->dIn, *dIm = o->dIn + (size_t)T * o->num, *dC = o->dIn + 2 * (size_t)T * o->num;
+    if (st == AFX_OK) st = afxdev_h2d(dRe, mRealArr, inB, o->stream);
+    if (st == AFX_OK) st = afxdev_h2d(dIm, mImageArr, inB, o->stream);
+    int nrm = 0;
+    if (nt == ChromaDataNormal_Max) nrm = 1;
+    else if (nt == ChromaDataNormal_Min) nrm = 2;
+    else if (nt == ChromaDataNormal_P2) nrm = 3;
+    else if (nt != ChromaDataNormal_None) nrm = 4;
+    if (st == AFX_OK)
+        st = afxk_cqt_chroma(dRe, dIm, T, o->num, o->dFold, cn, dt == SpectralData_Mag, nrm, dC, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mDataArr, dC, sizeof(float) * (size_t)T * cn, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    if (st != AFX_OK) fail(o, st, "cqtObj_chroma");
+}
+
+void cqtObj_cqcc(CQTObj o, float *mDataArr1, int ccNum, CepstralRectifyType *rectifyType,
+                 float *mDataArr2) {
+    if (!o) {
+        afxdev_set_error("cqtObj_cqcc: NULL object");
+        return;
+    }
+    const int T = o->timeLength;
+    if (ccNum > o->num || ccNum < 1 || T <= 0 || !mDataArr1 || !mDataArr2) return;
+    int st = AFX_OK;
+    if (!o->dDct) {
+        float *d = afx_dct2_matrix(o->num, o->num);
+        st = afxdev_malloc((void **)&o->dDct, sizeof(float) * (size_t)o->num * o->num);
+        if (st == AFX_OK) st = afxdev_h2d(o->dDct, d, sizeof(float) * (size_t)o->num * o->num, o->stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+        free(d);
+    }
+    const size_t inB = sizeof(float) * (size_t)T * o->num, outB = sizeof(float) * (size_t)T * ccNum;
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dIn, &o->capIn, inB + outB + 64);
+    float *dA = o->dIn, *dC = o->dIn + (((size_t)T * o->num + 3) & ~(size_t)3);
+    if (st == AFX_OK) st = afxdev_h2d(dA, mDataArr1, inB, o->stream);
+    const int pre = (rectifyType && *rectifyType == CepstralRectify_CubicRoot) ? AFX_MAP_CBRT : AFX_MAP_LOG10;
+    if (st == AFX_OK) {
+        if (afxk_cepstrum_supported(dA, o->num, ccNum))
+            st = afxk_cepstrum(dA, T, o->num, o->dDct, ccNum, pre, dC, o->stream);
+        else
+            st = afxk_gemm_nt(dA, o->num, o->dDct, o->num, dC, ccNum, T, ccNum, o->num, pre,
+                              AFX_MAP_NONE, 1.f, o->stream);
+    }
+    if (st == AFX_OK) st = afxdev_d2h(mDataArr2, dC, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    if (st != AFX_OK) fail(o, st, "cqtObj_cqcc");
+}
+
+void cqtObj_cqhc(CQTObj o, float *mDataArr1, int hcNum, float *mDataArr2) {
+    (void)o; (void)mDataArr1; (void)hcNum; (void)mDataArr2;
+    afxdev_set_error("cqtObj_cqhc is not implemented by the MI355X backend (outputs untouched)");
+}
+
+void cqtObj_deconv(CQTObj o, float *mDataArr1, float *mDataArr2, float *mDataArr3) {
+    (void)o; (void)mDataArr1; (void)mDataArr2; (void)mDataArr3;
+    afxdev_set_error("cqtObj_deconv is not implemented by the MI355X backend (outputs untouched)");
+}
+
+void cqtObj_free(CQTObj o) {
+    if (!o) return;
+    if (o->stream) afxdev_stream_sync(o->stream);
+    afxdev_free(o->dTwiddle);
+    afxdev_free(o->dKTaps);
+    afxdev_free(o->dKStart);
+    afxdev_free(o->dKLen);
+    afxdev_free(o->dKOff);
+    afxdev_free(o->dScaleOn);
+    afxdev_free(o->dScaleOff);
+    afxdev_free(o->dFold);
+    afxdev_free(o->dSig[0]);
+    afxdev_free(o->dSig[1]);
+    afxdev_free(o->dOut);
+    afxdev_free(o->dIn);
+    afxdev_free(o->dDct);
+    afxdev_stream_destroy(o->stream);
+    free(o->freBandArr);
+    free(o->sLenArr);
+    free(o);
+}

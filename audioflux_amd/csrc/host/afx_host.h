@@ -23,6 +23,7 @@ float *afx_window_create(WindowType type, int length, int periodic);
 /* the window an STFT of frame length `length` uses (periodic for the cosine
  * family, symmetric for bartlett/triang/bartlett-hann/bohman) */
 float *afx_window_fft(WindowType type, int length);
+float *afx_window_kaiser(int length, float beta);
 
 /* ---- afx_auditory.c ---------------------------------------------------- */
 /* fills bank[num*(fftLength/2+1)] (must be zeroed), fre[num], bin[num] */
@@ -46,6 +47,11 @@ float *afx_twiddle_table(int n);
 /* orthonormal DCT-II matrix rows 0..rows-1, D[c*num+n] */
 float *afx_dct2_matrix(int num, int rows);
 int afx_is_pow2(int v);
+int afx_ceil_pow2(int v);
+int afx_log2_exact(int v);
+/* the reference's float32 radix-2 DIT FFT, operation for operation (kernel banks are
+ * thresholded on its output, so the host copy must round identically) */
+void afx_fft_ref32(int radix2Exp, const float *re1, const float *im1, float *re2, float *im2);
 
 /* ---- afx_bandplan.c ----------------------------------------------------- */
 struct AfxBandPlanTag; /* AfxBandPlan is declared in afx_device.h */

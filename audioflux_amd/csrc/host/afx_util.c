@@ -52,3 +52,60 @@ float *afx_dct2_matrix(int num, int rows) {
 }
 
 int afx_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+/* util_ceilPowerTwo (src/util/flux_util.c:33-51) */
+int afx_ceil_pow2(int value) {
+    int n = 1;
+    if (value < 1) return n;
+    if (afx_is_pow2(value)) return value;
+    while (value) {
+        value >>= 1;
+        n <<= 1;
+    }
+    return n;
+}
+
+int afx_log2_exact(int v) {
+    int r = 0;
+    if (!afx_is_pow2(v)) return 0;
+    while ((1 << r) < v) r++;
+    return r;
+}
+
+/* Radix-2 decimation-in-time FFT in float32 with cosf/sinf twiddles, bit-reversed
+ * load then log2(N) butterfly passes -- the arithmetic of the reference's built-in
+ * _fftObj_fft (src/dsp/fft_algorithm.c:450-519, twiddles :882-891).  Only used at plan
+ * time for the CQT spectral kernels, whose entries are kept or dropped by a float32
+ * threshold test (src/filterbank/cqt_filterBank.c:124-138). */
+void afx_fft_ref32(int r, const float *re1, const float *im1, float *re2, float *im2) {
+    const int n = 1 << r, half = n / 2;
+    float *wc = (float *)malloc(sizeof(float) * (size_t)(half > 0 ? half : 1));
+    float *ws = (float *)malloc(sizeof(float) * (size_t)(half > 0 ? half : 1));
+    for (int i = 0; i < half; i++) {
+        wc[i] = cosf((float)(2 * M_PI * i / n));
+        ws[i] = -sinf((float)(2 * M_PI * i / n));
+    }
+    for (int i = 0; i < n; i++) {
+        unsigned rev = 0;
+        for (int b = 0; b < r; b++) rev |= ((unsigned)(i >> b) & 1u) << (r - 1 - b);
+        re2[i] = re1[rev];
+        im2[i] = im1 ? im1[rev] : 0.f;
+    }
+    for (int p = 1; p <= r; p++) {
+        const int s = 1 << (p - 1);
+        for (int g = 0; g < s; g++) {
+            const int w = g * (1 << (r - p));
+            const float c = wc[w], sn = ws[w];
+            for (int b = g; b <= n - 1; b += (1 << p)) {
+                const float tr = re2[b + s] * c - im2[b + s] * sn;
+                const float ti = re2[b + s] * sn + im2[b + s] * c;
+                re2[b + s] = re2[b] - tr;
+                im2[b + s] = im2[b] - ti;
+                re2[b] = re2[b] + tr;
+                im2[b] = im2[b] + ti;
+            }
+        }
+    }
+    free(wc);
+    free(ws);
+}

@@ -25,6 +25,8 @@ static float bessel_i0(float a) {
     return sum;
 }
 
+static float g_kaiser_beta = 5.0f; /* overridden only inside afx_window_kaiser */
+
 typedef struct {
     int n;          /* symmetric length being generated                 */
     int half;       /* samples computed from the formula                */
@@ -70,7 +72,7 @@ static float half_value(WindowType type, const WinCtx *c, int i) {
             return v;
         }
         case Window_Kaiser: { /* :696-716, beta 5 */
-            const float a = 5.0f;
+            const float a = g_kaiser_beta;
             float u = (float)(2.0 * i / d - 1);
             float b = a * sqrtf(1 - u * u);
             return bessel_i0(b) / c->den_i0;
@@ -132,7 +134,7 @@ static void fill_symmetric(WindowType type, int n, float *out) {
         }
         return;
     }
-    if (type == Window_Kaiser) c.den_i0 = bessel_i0(5.0f);
+    if (type == Window_Kaiser) c.den_i0 = bessel_i0(g_kaiser_beta);
     if (type == Window_Bohman) c.step = (1.f - (-1.f)) / (n - 1 > 0 ? n - 1 : 1);
     if (type == Window_Gauss) {
         /* the gauss family computes one extra sample for even n (flux_window.c:533-538) */
@@ -175,4 +177,14 @@ float *afx_window_fft(WindowType type, int length) {
     }
     if ((int)type < 0 || (int)type > (int)Window_Tukey) type = Window_Rect;
     return afx_window_create(type, length, periodic);
+}
+
+/* symmetric Kaiser window with an explicit beta (window_createKaiser(length, 0, &beta),
+ * flux_window.c:112-127); used by the resampler table */
+float *afx_window_kaiser(int length, float beta) {
+    const float saved = g_kaiser_beta;
+    if (beta > 0) g_kaiser_beta = beta;
+    float *w = afx_window_create(Window_Kaiser, length, 0);
+    g_kaiser_beta = saved;
+    return w;
 }

@@ -148,6 +148,90 @@ class RefXXCC:
             self.obj = C.c_void_p(None)
 
 
+class RefCepstrogram:
+    def __init__(self, radix2_exp, window_type=None, slide_length=None):
+        L = lib()
+        self.L = L
+        self.n = 1 << radix2_exp
+        self.obj = C.c_void_p(None)
+        L.cepstrogramObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, ip, ip]
+        self.status = L.cepstrogramObj_new(C.byref(self.obj), radix2_exp, _pi(window_type), _pi(slide_length))
+        L.cepstrogramObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
+        L.cepstrogramObj_cepstrogram.restype = None
+        L.cepstrogramObj_cepstrogram.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, fp, fp, fp]
+        L.cepstrogramObj_free.argtypes = [C.c_void_p]
+
+    def cepstrogram(self, x, cep_num):
+        x = np.ascontiguousarray(x, np.float32)
+        t = self.L.cepstrogramObj_calTimeLength(self.obj, x.shape[0])
+        f = self.n // 2 + 1
+        outs = [np.zeros((t, f), np.float32) for _ in range(3)]
+        self.L.cepstrogramObj_cepstrogram(self.obj, cep_num, _f(x), x.shape[0], _f(outs[0]), _f(outs[1]), _f(outs[2]))
+        return outs
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.cepstrogramObj_free(self.obj)
+            self.obj = C.c_void_p(None)
+
+
+class RefCQT:
+    def __init__(self, num=84, samplate=None, min_fre=None, bin_per_octave=None, factor=None, beta=None,
+                 thresh=None, window_type=None, slide_length=None, normal_type=None, is_scale=None):
+        L = lib()
+        self.L = L
+        self.num = num
+        self.obj = C.c_void_p(None)
+        L.cqtObj_newWith.argtypes = [C.POINTER(C.c_void_p), C.c_int, ip, fp, ip, fp, fp, fp, ip, ip, ip, ip, ip]
+        self.status = L.cqtObj_newWith(C.byref(self.obj), num, _pi(samplate), _pf(min_fre),
+                                       _pi(bin_per_octave), _pf(factor), _pf(beta), _pf(thresh),
+                                       _pi(window_type), _pi(slide_length), None, _pi(normal_type),
+                                       _pi(is_scale))
+        L.cqtObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
+        L.cqtObj_getFFTLength.argtypes = [C.c_void_p]
+        L.cqtObj_getFreBandArr.argtypes = [C.c_void_p]
+        L.cqtObj_getFreBandArr.restype = fp
+        L.cqtObj_cqt.restype = None
+        L.cqtObj_cqt.argtypes = [C.c_void_p, fp, C.c_int, fp, fp]
+        L.cqtObj_chroma.restype = None
+        L.cqtObj_chroma.argtypes = [C.c_void_p, ip, ip, ip, fp, fp, fp]
+        L.cqtObj_cqcc.restype = None
+        L.cqtObj_cqcc.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
+        L.cqtObj_free.argtypes = [C.c_void_p]
+
+    def fft_length(self):
+        return self.L.cqtObj_getFFTLength(self.obj)
+
+    def fre_band(self):
+        return np.ctypeslib.as_array(self.L.cqtObj_getFreBandArr(self.obj), (self.num,)).copy()
+
+    def cqt(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        t = self.L.cqtObj_calTimeLength(self.obj, x.shape[0])
+        re = np.zeros((t, self.num), np.float32)
+        im = np.zeros((t, self.num), np.float32)
+        self.L.cqtObj_cqt(self.obj, _f(x), x.shape[0], _f(re), _f(im))
+        return re, im
+
+    def chroma(self, re, im, chroma_num=12, data_type=None, norm_type=None):
+        re = np.ascontiguousarray(re, np.float32)
+        im = np.ascontiguousarray(im, np.float32)
+        out = np.zeros((re.shape[0], chroma_num), np.float32)
+        self.L.cqtObj_chroma(self.obj, _pi(chroma_num), _pi(data_type), _pi(norm_type), _f(re), _f(im), _f(out))
+        return out
+
+    def cqcc(self, mag, cc_num=13, rectify=None):
+        mag = np.ascontiguousarray(mag, np.float32)
+        out = np.zeros((mag.shape[0], cc_num), np.float32)
+        self.L.cqtObj_cqcc(self.obj, _f(mag), cc_num, _pi(rectify), _f(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.cqtObj_free(self.obj)
+            self.obj = C.c_void_p(None)
+
+
 def mel_mfcc(x_clips, num=128, radix2_exp=11, samplate=16000, hop=512, cc_num=13):
     """reference mel (real power) + MFCC for each clip of x_clips[b,n]; the timed
     region of BASELINE.md section 3.  Returns (mel[b,T,num], mfcc[b,T,cc])."""

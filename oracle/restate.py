@@ -251,3 +251,164 @@ def xxcc_standard(m, energy, cc_num=13, delta_len=9, energy_type="replace", kind
     d1 = np.stack([delta(r, delta_len) for r in coe])
     d2 = np.stack([delta(r, delta_len) for r in d1])
     return coe, d1, d2
+
+
+# --------------------------------------------------------------------------
+# cepstrogram -- src/cepstrogram_algorithm.c:127-298
+# --------------------------------------------------------------------------
+def cepstrogram(x, fft_length, hop, cep_num, window_type=0):
+    """returns (cepstrum, envelope, details), each [T, N/2+1]"""
+    n = fft_length
+    fr = frames_of(x, n, hop) * fft_window(window_type, n)[None, :]
+    S = np.fft.fft(fr, axis=1)  # all N bins (:211)
+    L = np.log(np.maximum(np.abs(S) ** 2, 1e-16))  # :219-229
+    c = np.real(np.fft.ifft(L, axis=1))  # :232-234
+    F = n // 2 + 1
+    low = np.zeros_like(c)  # :258-263: keep 0..cepNum and mirror it to the tail
+    low[:, : cep_num + 1] = c[:, : cep_num + 1]
+    for j in range(cep_num):
+        low[:, n - 1 - j] = low[:, j + 1]
+    high = np.zeros_like(c)  # :282-283: indices cepNum+1 .. N-cepNum inclusive
+    high[:, cep_num + 1: n - cep_num + 1] = c[:, cep_num + 1: n - cep_num + 1]
+    env = np.real(np.fft.fft(low, axis=1))[:, :F]
+    det = np.real(np.fft.fft(high, axis=1))[:, :F]
+    return c[:, :F], env, det
+
+
+# --------------------------------------------------------------------------
+# constant-Q transform -- src/cqt_algorithm.c:845-1061, src/filterbank/cqt_filterBank.c,
+# src/dsp/resample_algorithm.c:430-634, src/filterbank/chroma_filterBank.c:176-264
+# --------------------------------------------------------------------------
+def cqt_plan(num=84, samplate=32000, min_fre=32.703196, bpo=12, window_type=1, normal="none",
+             factor=1.0, thresh=0.01):
+    """bin frequencies, fft length, per-bin lengths and the top-octave spectral kernel K[bpo, F]"""
+    octaves = num // bpo
+    # cqt_filterBank.c:159-185: float32, one multiply per semitone -- a pure tone's response is
+    # sensitive to the bin frequency at the 1e-7 level, so the rounding chain is reproduced
+    ratio = f32(2.0 ** float(f32(1.0 / bpo)))  # powf(2, (float)(1.0/bpo)), correctly rounded
+    fre32 = np.zeros(num, f32)
+    for i in range(octaves):
+        f = f32(f32(min_fre) * f32(1 << i))
+        fre32[i * bpo] = f
+        for j in range(1, bpo):
+            f = f32(f * ratio)
+            fre32[i * bpo + j] = f
+    fre = fre32.astype(np.float64)
+    q = factor / (2.0 ** (1.0 / bpo) - 1)
+    lens = q * samplate / fre  # :187-213
+    top = fre[(octaves - 1) * bpo:]
+    n = 1
+    while n < int(np.ceil(q * samplate / top[0])):  # :215-246 (ceil power of two)
+        n *= 2
+    ltop = lens[(octaves - 1) * bpo:]
+    K = np.zeros((bpo, n), complex)
+    for i in range(bpo):  # :253-336
+        ln = int(np.ceil(f32(ltop[i])))
+        w = fft_window(window_type if window_type != 0 else 1, ln)
+        start = (n - ln) // 2
+        t = np.arange(ln)
+        k = w * np.exp(2j * np.pi * t * top[i] / samplate)
+        if normal == "none":
+            k = k / ltop[i]
+        elif normal == "area":
+            k = k / np.abs(k).sum()
+        k = k * (ltop[i] / n)
+        K[i, start:start + ln] = k
+    Kf = np.fft.fft(K, axis=1)[:, : n // 2 + 1]
+    Kf[np.abs(Kf) ** 2 <= thresh * thresh] = 0  # :124-138
+    return fre, n, lens, Kf
+
+
+def halfband_taps():
+    """h_j of the 'Fast' 2:1 resampler, j = 0..31 (resample_algorithm.c:546-634): sinc with
+    roll-off 0.85 times a Kaiser(beta 8.5555046) half window, 16 zero crossings, times ratio"""
+    j = np.arange(32)
+    x = j / 2.0
+    sinc = np.sinc(0.85 * x) * 0.85
+    n = 2 * 8192 + 1
+    u = 2.0 * (8192 - 256 * j) / (n - 1) - 1  # kaiser sample 8192 + 256 j mirrors 8192 - 256 j
+    beta = float(f32(8.5555046))
+
+    def i0(a):
+        k = np.arange(1, 16)
+        terms = np.cumprod(np.broadcast_to((np.asarray(a, float)[..., None] / 2) / k, np.shape(a) + (15,)), axis=-1)
+        return 1 + np.sum(terms ** 2, axis=-1)
+    kais = i0(beta * np.sqrt(np.maximum(1 - u * u, 0))) / i0(np.array(beta))
+    return 0.5 * sinc * kais
+
+
+def decimate2(x):
+    """y[i] = (sum_{j=0}^{31} h_j x[2i-j] + sum_{j=1}^{31} h_j x[2i+j]) / sqrt(0.5), edges truncated"""
+    h = halfband_taps()
+    x = np.asarray(x, np.float64)
+    m = len(x) // 2
+    full = np.concatenate([h[:0:-1], h])  # taps for offsets -31..31 around sample 2i
+    y = np.convolve(x, full)[31:31 + 2 * m:2]
+    return y / np.sqrt(0.5)
+
+
+def cqt(x, num=84, samplate=32000, min_fre=32.703196, bpo=12, window_type=1, normal="none",
+        hop=None, is_scale=True):
+    """[T, num] complex: the octave recursion of _cqtObj_cqt"""
+    fre, n, lens, K = cqt_plan(num, samplate, min_fre, bpo, window_type, normal)
+    octaves = num // bpo
+    hop = hop or n // 4
+    x = np.asarray(x, np.float64)
+    T = len(x) // hop + 1
+    out = np.zeros((T, num), complex)
+    h = hop
+    for k, o in enumerate(range(octaves - 1, -1, -1)):
+        frames = len(x) // h + 1
+        valid = len(x) - (len(x) % h if frames > 1 else 0)  # stft_algorithm.c:838-843
+        xp = np.concatenate([np.zeros(n // 2), x[:valid], np.zeros(n // 2 + n)])
+        idx = np.arange(n)[None, :] + h * np.arange(T)[:, None]
+        S = np.fft.rfft(xp[idx], axis=1)
+        Q = S @ K.T  # plain complex product, no conjugate (flux_complex.c:53-87)
+        Q = Q * np.sqrt(2.0 ** k)
+        if is_scale:
+            Q = Q / np.sqrt(lens[o * bpo:(o + 1) * bpo])[None, :]
+        out[:, o * bpo:(o + 1) * bpo] = Q
+        if o > 0:
+            x = decimate2(x)
+            h //= 2
+    return out
+
+
+def chroma_fold(chroma_num, num, bpo, min_fre=32.703196):
+    """0/1 matrix [chroma_num, num] (chroma_filterBank.c:176-264, including its rotation quirk)"""
+    n = bpo // chroma_num
+    offset = int(np.ceil(n / 2.0))
+    sub = n - offset
+    midi = int(np.round(12 * np.log2(min_fre / 440) + 69)) % 12
+    if midi > 6:
+        midi = 12 - midi
+    m = np.zeros((chroma_num, num))
+    mod = np.arange(num) % bpo
+    for i in range(chroma_num):
+        if i:
+            start = offset + (i - 1) * n
+            m[i, (mod >= start) & (mod < start + n)] = 1
+        else:
+            m[0, mod < offset] = 1
+            if sub:
+                m[0, mod >= bpo - sub] = 1
+    r = midi * (chroma_num // bpo)
+    return np.concatenate([m[r:], m[:r]]) if r else m
+
+
+def cqt_chroma(Q, chroma_num=12, bpo=12, data_type="power", norm="max", min_fre=32.703196):
+    s = np.abs(Q) ** 2
+    if data_type == "mag":
+        s = np.sqrt(s)
+    c = s @ chroma_fold(chroma_num, Q.shape[1], bpo, min_fre).T
+    if norm == "max":
+        d = np.abs(c).max(1, keepdims=True)
+    elif norm == "min":
+        d = np.abs(c).min(1, keepdims=True)
+    elif norm == "p2":
+        d = np.sqrt((c ** 2).sum(1, keepdims=True))
+    elif norm == "p1":
+        d = np.abs(c).sum(1, keepdims=True)
+    else:
+        return c
+    return np.where(d != 0, c / np.where(d != 0, d, 1), c)

@@ -91,7 +91,11 @@ CTOR_KEYS = ("num", "radix2_exp", "samplate", "low_fre", "high_fre", "bin_per_oc
 
 def make_input(spec, samplate):
     kind, seed, n = spec
-    return noise(seed, n) if kind == "noise" else tones(seed, n, samplate)
+    if kind == "noise":
+        return noise(seed, n)
+    if kind == "mix":
+        return mix(seed, n, samplate)
+    return tones(seed, n, samplate)
 
 
 def ctor_kwargs(case):
@@ -106,4 +110,35 @@ XXCC_CASES = {
     "std_replace": dict(num=128, cc_num=13, rectify=0, src="cfg1_mel_power", standard=(9, 0)),
     "std_append": dict(num=128, cc_num=13, rectify=0, src="cfg1_mel_power", standard=(5, 1)),
     "std_ignore": dict(num=80, cc_num=12, rectify=1, src="tones_mel_mag_area", standard=(3, 2)),
+}
+
+
+# cepstrogram: white-noise inputs (ln|S|^2 of near-empty bins is dominated by the FFT's
+# own rounding noise, so tonal inputs are ill-conditioned for ANY float32 implementation)
+CEPS_CASES = {
+    "hann_2048": dict(radix2_exp=11, window_type=WIN["hann"], slide_length=512, cep_num=20, x=("noise", 31, 16000)),
+    "rect_1024": dict(radix2_exp=10, window_type=WIN["rect"], slide_length=256, cep_num=4, x=("noise", 32, 9000)),
+    "hamm_512": dict(radix2_exp=9, window_type=WIN["hamm"], slide_length=100, cep_num=40, x=("noise", 33, 6000)),
+}
+
+
+def mix(seed, n, sr):
+    return (tones(seed, n, sr) + noise(seed + 100, n, 0.05)).astype(np.float32)
+
+
+# constant-Q: ctor kwargs (reference argument order) + input
+CQT_CASES = {
+    "c84_32k_area": dict(num=84, samplate=32000, min_fre=32.703, bin_per_octave=12, window_type=WIN["hann"],
+                         normal_type=NORMAL["area"], is_scale=1, x=("mix", 41, 20000)),
+    "c84_44k_none_noscale": dict(num=84, samplate=44100, min_fre=32.703, bin_per_octave=12,
+                                 window_type=WIN["hamm"], normal_type=NORMAL["none"], is_scale=0,
+                                 x=("mix", 42, 30011)),
+    "c48_16k_area": dict(num=48, samplate=16000, min_fre=32.703, bin_per_octave=12, window_type=WIN["hann"],
+                         normal_type=NORMAL["area"], is_scale=1, x=("mix", 43, 20000)),
+    "c72_24bpo_hop200": dict(num=72, samplate=32000, min_fre=65.406, bin_per_octave=24,
+                             window_type=WIN["blackman"], normal_type=NORMAL["area"], is_scale=1,
+                             slide_length=200, x=("noise", 44, 9000)),
+}
+CQT_CHROMA = {  # (chroma_num, data_type, norm_type)
+    "power_max": (12, 0, 1), "mag_p2": (12, 1, 3), "six_min": (6, 0, 2), "p1": (12, 0, 4), "none": (12, 1, 0),
 }

@@ -58,7 +58,29 @@ def main():
         else:
             xx_out[f"{name}/cc"] = o.xxcc(m, c["cc_num"], c["rectify"])
     np.savez_compressed(os.path.join(HERE, "xxcc.npz"), **xx_out)
-    for f in ("bft.npz", "xxcc.npz"):
+    cp_out = {}
+    for name, c in cases.CEPS_CASES.items():
+        o = ref.RefCepstrogram(c["radix2_exp"], c["window_type"], c["slide_length"])
+        outs = o.cepstrogram(cases.make_input(c["x"], 16000), c["cep_num"])
+        for k, v in zip(("cep", "env", "det"), outs):
+            cp_out[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "cepstrogram.npz"), **cp_out)
+    cq_out = {}
+    for name, c in cases.CQT_CASES.items():
+        kw = {k: v for k, v in c.items() if k != "x"}
+        o = ref.RefCQT(kw.pop("num"), **kw)
+        assert o.status == 0
+        x = cases.make_input(c["x"], c["samplate"])
+        re, im = o.cqt(x)
+        cq_out[f"{name}/re"], cq_out[f"{name}/im"] = re, im
+        cq_out[f"{name}/fre"] = o.fre_band()
+        cq_out[f"{name}/fft"] = np.array([o.fft_length()])
+        if c["bin_per_octave"] == 12:
+            for cname, (cn, dt, nt) in cases.CQT_CHROMA.items():
+                cq_out[f"{name}/chroma_{cname}"] = o.chroma(re, im, cn, dt, nt)
+        cq_out[f"{name}/cqcc"] = o.cqcc(np.abs(re + 1j * im), 13, 0)
+    np.savez_compressed(os.path.join(HERE, "cqt.npz"), **cq_out)
+    for f in ("bft.npz", "xxcc.npz", "cepstrogram.npz", "cqt.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -93,3 +93,31 @@ def test_windows_match_reference_formulas():
         for n in (8, 9, 512, 2048):
             a = np.ctypeslib.as_array(L.window_calFFTWindow(wt, n), (n,)).copy()
             assert np.abs(a - restate.fft_window(wt, n)).max() < 2e-6, (wt, n)
+
+
+@pytest.mark.parametrize("name", list(cases.CEPS_CASES))
+def test_restatement_matches_golden_cepstrogram(name, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "cepstrogram.npz"))
+    c = cases.CEPS_CASES[name]
+    outs = restate.cepstrogram(cases.make_input(c["x"], 16000), 1 << c["radix2_exp"],
+                               c["slide_length"], c["cep_num"], c["window_type"])
+    for k, got, tol in zip(("cep", "env", "det"), outs, (1e-5, 1e-5, 2e-5)):
+        assert_parity(got, gold[f"{name}/{k}"], tol, f"{name}/{k}")
+
+
+@pytest.mark.parametrize("name", ["c84_32k_area", "c84_44k_none_noscale", "c48_16k_area"])
+def test_restatement_matches_golden_cqt(name, golden_dir):
+    """float64 restatement vs the reference: agrees to a few 1e-6 once the float32 frequency
+    chain is reproduced (a tone's response moves by ~2e-5 per 1e-7 of relative bin frequency)"""
+    gold = np.load(os.path.join(golden_dir, "cqt.npz"))
+    c = cases.CQT_CASES[name]
+    x = cases.make_input(c["x"], c["samplate"])
+    q = restate.cqt(x, c["num"], c["samplate"], float(np.float32(c["min_fre"])), 12, c["window_type"],
+                    "area" if c["normal_type"] == 1 else "none", None, bool(c["is_scale"]))
+    want = gold[f"{name}/re"] + 1j * gold[f"{name}/im"]
+    assert_parity(q, want, 1e-5, name)
+    assert_parity(restate.cqt_chroma(q, 12, 12, "power", "max", c["min_fre"]),
+                  gold[f"{name}/chroma_power_max"], 1e-5, "chroma")
+    assert_parity(restate.cqt_chroma(q, 6, 12, "power", "min", c["min_fre"]),
+                  gold[f"{name}/chroma_six_min"], 5e-5, "chroma6")  # divides by the frame MINIMUM: ill-conditioned
+    assert_parity(restate.xxcc(np.abs(q), 13), gold[f"{name}/cqcc"], 1e-5, "cqcc")
