@@ -10,7 +10,8 @@ from .bft import BFT
 from .xxcc import XXCC
 from .cepstrogram import Cepstrogram
 from .cqt import CQT
+from .cwt import CWT
 from .batch import mel_mfcc_device
 
-__all__ = ["BFT", "XXCC", "Cepstrogram", "CQT", "mel_mfcc_device", "get_lib", "build", "runtime_status",
+__all__ = ["BFT", "XXCC", "Cepstrogram", "CQT", "CWT", "mel_mfcc_device", "get_lib", "build", "runtime_status",
            "last_error", "LIB_PATH"]

@@ -105,6 +105,20 @@ int afxk_xxcc_standard(const float *cc, const float *energy, long long rows, int
                        int energyType, int deltaLen, float *coe, float *delta1, float *delta2,
                        void *stream);
 
+/* ---- continuous wavelet transform (afx_cwt.hip) ---------------------------- */
+typedef struct {
+    int r1, r2;      /* L = 2^(r1+r2): columns FFT 2^r1, rows FFT 2^r2               */
+    int dataLength;  /* 2^radix2Exp samples in / per scale out                       */
+    int pad;         /* reflect padding on each side                                 */
+    int tileCols;    /* columns per workgroup in the column passes (divides 2^r2)    */
+} AfxCwtPlanDims;
+/* x[dataLength] -> Xt[L] complex (transposed layout: frequency k1 + 2^r1 k2 at [k1][k2]) */
+int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x, float *scratchA,
+                     float *Xt, void *stream);
+/* Xt, bankT[num][L] (same layout) -> outRe/outIm [num][dataLength]; scratchB: num*L complex */
+int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, const float *bankT,
+                     int num, int isDet, float *scratchB, float *outRe, float *outIm, void *stream);
+
 /* ---- constant-Q transform (afx_cqt.hip) ----------------------------------- */
 typedef struct {
     const float *x;        /* device: this octave's signal                            */

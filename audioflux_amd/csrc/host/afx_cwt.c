@@ -1,0 +1,533 @@
+/* afx_cwt.c -- the continuous wavelet transform object (C host side) behind
+ * include/cwt_algorithm.h.
+ *
+ * Parameter handling follows cwtObj_new (src/cwt_algorithm.c:73-334); the
+ * frequency-domain wavelet bank follows cwt_filterBank
+ * (src/filterbank/cwt_filterBank.c:85-290 and the per-family functions :368-600)
+ * in the reference's own float / long double arithmetic, then is stored in the
+ * transposed frequency layout the four-step FFT kernels use (afx_cwt.hip).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "afx_device.h"
+#include "afx_host.h"
+#include "cwt_algorithm.h"
+
+#ifndef M_E
+#define M_E 2.7182818284590452354
+#endif
+
+struct OpaqueCWT {
+    int num, radix2Exp, dataLength, padLength;
+    long long fftLength;
+    int samplate, binPerOctave;
+    float lowFre, highFre, gamma, beta;
+    WaveletContinueType waveletType;
+    SpectralFilterBankScaleType scaleType;
+    float *freBandArr; /* host, num+2 */
+    int *binBandArr;
+    float *hBank;      /* host copy, natural layout [num][L] (kept for the det bank) */
+    AfxCwtPlanDims dims;
+    void *stream;
+    float *dTw, *dBankT, *dBankDetT;
+    float *dX, *dA, *dXt, *dB, *dOut; /* scratch */
+    int haveSpectrum;
+    int status;
+};
+
+/* ---- scale maps shared with the auditory bank (same formulas, see afx_auditory.c) ---- */
+static float c_fre_to_mel(float f) { return 2595 * log10f(1 + f / 700); }
+static float c_mel_to_fre(float m) { return 700 * (powf(10, m / 2595) - 1); }
+static float c_fre_to_bark(float f) {
+    float bark = (float)(26.81 * f / (1960 + f) - 0.53);
+    if (bark < 2) bark = (float)(bark + 0.15 * (2 - bark));
+    else if (bark > 20.1) bark = (float)(bark + 0.22 * (bark - 20.1));
+    return bark;
+}
+static float c_bark_to_fre(float bark) {
+    if (bark < 2) bark = (float)((bark - 0.3) / 0.85);
+    else if (bark > 20.1) bark = (float)((bark + 4.422) / 1.22);
+    return (float)(1960 * (bark + 0.53) / (26.28 - bark));
+}
+static float c_fre_to_erb(float f) { return 21.3654f * log10f((float)(1 + f * 0.004368)); }
+static float c_erb_to_fre(float e) { return (float)((powf(10, e / 21.3654f) - 1) / 0.004368); }
+static float c_fre_to_logspace(float f) { return (float)log2(f / 440); }
+static float c_logspace_to_fre(float v) { return (float)(pow(2, v) * 440); }
+
+/* util_gammal (src/util/flux_util.c:731-768) */
+static long double gammal_ref(long double x) {
+    const long double err = 1e-5;
+    if (fabsl(x - 1.0) < err) return 1.0;
+    if (fabsl(x - 0.5) < err) return sqrt(M_PI);
+    if (x > 1.0) return (x - 1) * gammal_ref(x - 1);
+    if (x < 0) return gammal_ref(x + 1) / x;
+    int i = 1;
+    long double cur = 1.0, pre = 0;
+    while (fabsl(cur - pre) / cur > err) {
+        pre = cur;
+        cur *= i / (x - 1 + i);
+        i++;
+    }
+    return cur * powl(i, x - 1);
+}
+
+/* natural-layout bank [num][L] (cwt_filterBank.c:85-290) */
+static void build_bank(struct OpaqueCWT *o, float *bank) {
+    const int num = o->num, D = o->dataLength, sr = o->samplate;
+    const long long L = o->fftLength;
+    float low = o->lowFre, high = o->highFre, ref = 0;
+    const WaveletContinueType type = o->waveletType;
+    const float gamma = o->gamma, beta = o->beta;
+
+    /* band centres: num+2 points equally spaced on the scale axis, edges excluded */
+    switch (o->scaleType) {
+        case SpectralFilterBankScale_Octave:
+            ref = (o->binPerOctave >= 4 && o->binPerOctave <= 48) ? (float)o->binPerOctave : 12.f;
+            afx_auditory_revise_log(num, low, high, (int)ref, 0, &low, &high);
+            break;
+        case SpectralFilterBankScale_Linear:
+            ref = (float)(sr * 1.0 / D);
+            afx_auditory_revise_linear(num, low, high, ref, 0, &low, &high);
+            break;
+        case SpectralFilterBankScale_Linspace: {
+            float d = (high - low) / (num - 1);
+            low = low - d;
+            high = high + d;
+            break;
+        }
+        case SpectralFilterBankScale_Log: {
+            float a = c_fre_to_logspace(low), b = c_fre_to_logspace(high);
+            float d = (b - a) / (num - 1);
+            low = c_logspace_to_fre(a - d);
+            high = c_logspace_to_fre(b + d);
+            break;
+        }
+        default:
+            break;
+    }
+    float a, b;
+    switch (o->scaleType) {
+        case SpectralFilterBankScale_Linear: a = roundf(low / ref); b = roundf(high / ref); break;
+        case SpectralFilterBankScale_Mel: a = c_fre_to_mel(low); b = c_fre_to_mel(high); break;
+        case SpectralFilterBankScale_Bark: a = c_fre_to_bark(low); b = c_fre_to_bark(high); break;
+        case SpectralFilterBankScale_Erb: a = c_fre_to_erb(low); b = c_fre_to_erb(high); break;
+        case SpectralFilterBankScale_Octave: a = afx_fre_to_log(low, ref); b = afx_fre_to_log(high, ref); break;
+        case SpectralFilterBankScale_Log: a = c_fre_to_logspace(low); b = c_fre_to_logspace(high); break;
+        default: a = low; b = high; break;
+    }
+    float *f = afx_linspace(a, b, num + 2, 0);
+    for (int i = 0; i < num + 2; i++) {
+        switch (o->scaleType) {
+            case SpectralFilterBankScale_Linear: f[i] = f[i] * ref; break;
+            case SpectralFilterBankScale_Mel: f[i] = c_mel_to_fre(f[i]); break;
+            case SpectralFilterBankScale_Bark: f[i] = c_bark_to_fre(f[i]); break;
+            case SpectralFilterBankScale_Erb: f[i] = c_erb_to_fre(f[i]); break;
+            case SpectralFilterBankScale_Octave: f[i] = afx_log_to_fre(f[i], ref); break;
+            case SpectralFilterBankScale_Log: f[i] = c_logspace_to_fre(f[i]); break;
+            default: break;
+        }
+    }
+    for (int i = 0; i < num; i++) {
+        o->freBandArr[i] = f[i + 1];
+        o->binBandArr[i] = (int)roundf(D * f[i + 1] / sr);
+    }
+
+    /* centre frequency of the mother wavelet (cwt_filterBank.c:136-163) */
+    float cf = gamma;
+    if (type == WaveletContinue_Morse) cf = expf((float)(1.0 / gamma * (logf(beta) - logf(gamma))));
+    else if (type == WaveletContinue_Paul) cf = (float)(gamma + 0.5);
+    else if (type == WaveletContinue_DOG) cf = sqrtf((float)(gamma + 0.5));
+    else if (type == WaveletContinue_Mexican) cf = sqrtf((float)(2 + 0.5));
+    else if (type == WaveletContinue_Hermit) cf = gamma + 1;
+
+    /* angular frequency grid and scales, highest frequency first (:218-236) */
+    float *w = (float *)calloc((size_t)L, sizeof(float));
+    for (long long i = 0; i <= L / 2; i++) w[i] = (float)(i * 2 * M_PI / L);
+    for (long long i = L / 2 + 1, j = L / 2 - 1; i < L && j >= 0; i++, j--) w[i] = -w[j];
+    float *s = (float *)calloc((size_t)num, sizeof(float));
+    for (int i = num, j = 0; i >= 1; i--, j++) {
+        float v = f[i];
+        if (v < 1e-6) v = 1e-6f;
+        s[j] = (float)(cf / (v / sr * 2 * M_PI));
+    }
+
+    long double factor = 0;
+    float factorF = 0;
+    if (type == WaveletContinue_Morse) factorF = expf(-beta * logf(cf) + powf(cf, gamma));
+    else if (type == WaveletContinue_Paul) {
+        long double v1 = 1;
+        const int p = (int)roundf(gamma);
+        for (int i = 2 * p - 1; i >= 2; i--) v1 *= i;
+        factor = powl(2, p) / sqrtl(p * v1);
+    } else if (type == WaveletContinue_DOG || type == WaveletContinue_Mexican) {
+        const int p = (int)roundf(type == WaveletContinue_Mexican ? 2.f : gamma);
+        factor = -1.0 / sqrtl(gammal_ref(p + 0.5));
+        if ((p / 2) % 2 == 1) factor = -factor;
+    } else if (type == WaveletContinue_Hermit) factor = 2.0 / sqrtf(gamma) * powl(M_PI, -0.25);
+    else if (type == WaveletContinue_Ricker) factor = 2.0 / sqrtf((float)M_PI);
+
+    const float dogGamma = (type == WaveletContinue_Mexican) ? 2.f : gamma;
+    for (int i = 0; i < num; i++) {
+        float *row = bank + (size_t)i * L;
+        for (long long j = 0; j < L; j++) {
+            const float x = s[i] * w[j]; /* __mdot of a column by a row: one float product */
+            float out = 0.f;
+            switch (type) {
+                case WaveletContinue_Morse:
+                    if (x > 0) {
+                        const float v1 = fabsf(x);
+                        const float v2 = (gamma == 3) ? v1 * v1 * v1 : powf(v1, gamma);
+                        out = 2 * factorF * expf(beta * logf(v1) - v2);
+                    }
+                    break;
+                case WaveletContinue_Morlet:
+                    if (x > 0) {
+                        float v1 = -(x - gamma) * (x - gamma) / beta;
+                        out = 2 * expf(v1);
+                    }
+                    break;
+                case WaveletContinue_Bump: {
+                    const float eps = 1e-6f;
+                    const float v1 = (x - gamma) / beta;
+                    float v2 = v1 * v1;
+                    v2 = -1 / (1 - v2);
+                    if (fabsf(v1) < 1 - eps) {
+                        const float v3 = (float)(2 * M_E * expf(v2));
+                        out = isnan(v3) ? 0.f : v3;
+                    }
+                    break;
+                }
+                case WaveletContinue_Paul:
+                    if (x > 0) {
+                        long double v = x;
+                        v = powl(v, gamma) * expl(-v);
+                        out = (float)(factor * v);
+                    }
+                    break;
+                case WaveletContinue_DOG:
+                case WaveletContinue_Mexican:
+                    if (x > 0) {
+                        long double v = x;
+                        v = powl(v, dogGamma) * expl(-v * v / beta);
+                        out = (float)(factor * v);
+                    }
+                    break;
+                case WaveletContinue_Hermit:
+                    if (x > 0) {
+                        long double v = x;
+                        v = (v - gamma) * (1 + v - gamma) * expl(-(v - gamma) * (v - gamma) / beta);
+                        out = (float)(factor * v);
+                    }
+                    break;
+                case WaveletContinue_Ricker:
+                    if (x > 0) {
+                        long double v = x;
+                        v = v * v / (gamma * gamma * gamma) * expl(-v * v / (gamma * gamma));
+                        out = (float)(factor * v);
+                    }
+                    break;
+                default:
+                    break;
+            }
+            row[j] = out;
+        }
+    }
+    free(f);
+    free(w);
+    free(s);
+}
+
+/* device-free entry used by the CPU tests: the same bank cwtObj_new uploads, natural
+ * layout, for already-resolved parameters (the signature of the reference's
+ * cwt_filterBank, src/filterbank/cwt_filterBank.c:85) */
+int afx_cwt_bank_host(int num, int dataLength, int samplate, int padLength, int waveletType,
+                      float gamma, float beta, int scaleType, float lowFre, float highFre,
+                      int binPerOctave, float *bank, float *freBandArr, int *binBandArr) {
+    struct OpaqueCWT o;
+    memset(&o, 0, sizeof(o));
+    o.num = num;
+    o.dataLength = dataLength;
+    o.padLength = padLength;
+    o.fftLength = (long long)dataLength + 2LL * padLength;
+    o.samplate = samplate;
+    o.binPerOctave = binPerOctave;
+    o.lowFre = lowFre;
+    o.highFre = highFre;
+    o.gamma = gamma;
+    o.beta = beta;
+    o.waveletType = (WaveletContinueType)waveletType;
+    o.scaleType = (SpectralFilterBankScaleType)scaleType;
+    o.freBandArr = (float *)calloc((size_t)num + 2, sizeof(float));
+    o.binBandArr = (int *)calloc((size_t)num + 2, sizeof(int));
+    if (!o.freBandArr || !o.binBandArr) return AFX_ERR_NOMEM;
+    build_bank(&o, bank);
+    if (freBandArr) memcpy(freBandArr, o.freBandArr, sizeof(float) * (size_t)num);
+    if (binBandArr) memcpy(binBandArr, o.binBandArr, sizeof(int) * (size_t)num);
+    free(o.freBandArr);
+    free(o.binBandArr);
+    return 0;
+}
+
+/* natural [num][L] -> transposed frequency layout [num][k1][k2], k = k1 + L1*k2 */
+static float *to_transposed(const float *bank, int num, int r1, int r2, const float *mul) {
+    const long long L1 = 1LL << r1, L2 = 1LL << r2, L = L1 * L2;
+    float *t = (float *)malloc(sizeof(float) * (size_t)num * L);
+    if (!t) return NULL;
+    for (int i = 0; i < num; i++)
+        for (long long k1 = 0; k1 < L1; k1++)
+            for (long long k2 = 0; k2 < L2; k2++) {
+                const long long k = k1 + L1 * k2;
+                float v = bank[(size_t)i * L + k];
+                if (mul) v = v * mul[k];
+                t[(size_t)i * L + k1 * L2 + k2] = v;
+            }
+    return t;
+}
+
+int cwtObj_new(CWTObj *cwtObj, int num, int radix2Exp, int *samplate, float *lowFre, float *highFre,
+               int *binPerOctave, WaveletContinueType *waveletType,
+               SpectralFilterBankScaleType *scaleType, float *gamma, float *beta, int *isPadding) {
+    int sr = 32000, bpo = 12, isPad = 0;
+    float low = 0, high = 0, g = 3, b = 20;
+    WaveletContinueType wt = WaveletContinue_Morse;
+    SpectralFilterBankScaleType sc = SpectralFilterBankScale_Octave;
+    if (!cwtObj) return -1;
+    *cwtObj = NULL;
+    if (radix2Exp) {
+        if (radix2Exp < 1 || radix2Exp > 30) {
+            printf("radix2Exp is error!\n");
+            return -100;
+        }
+    }
+    long long fftLength = 1LL << radix2Exp;
+    if (samplate && *samplate > 0 && *samplate <= 196000) sr = *samplate;
+    if (waveletType) wt = *waveletType;
+    if (scaleType) {
+        sc = *scaleType;
+        if ((int)sc > (int)SpectralFilterBankScale_Log) {
+            printf("scaleType is error!\n");
+            return 1;
+        }
+    }
+    high = (float)(sr / 2.0);
+    if (lowFre && *lowFre >= 0 && *lowFre < sr / 2.0) low = *lowFre;
+    const int logLike = (sc == SpectralFilterBankScale_Octave || sc == SpectralFilterBankScale_Log);
+    if (low == 0 && logLike) {
+        low = (float)(powf(2, (float)(-45 / 12.0)) * 440);
+        high = (float)(powf(2, (float)(38 / 12.0)) * 440);
+    }
+    if (highFre && *highFre > 0 && *highFre <= sr / 2.0) high = *highFre;
+    if (high < low) {
+        low = 0;
+        high = (float)(sr / 2.0);
+        if (logLike) {
+            low = (float)(powf(2, (float)(-45 / 12.0)) * 440);
+            high = (float)(powf(2, (float)(38 / 12.0)) * 440);
+        }
+    }
+    if (binPerOctave && *binPerOctave >= 4 && *binPerOctave <= 48) bpo = *binPerOctave;
+    if (sc == SpectralFilterBankScale_Linear) {
+        float det = sr / (float)fftLength;
+        afx_auditory_revise_linear(num, low, high, det, 1, &low, &high);
+        if (high > sr / 2.0) {
+            printf("scale linear: lowFre and num is large, overflow error\n");
+            return -1;
+        }
+    } else if (sc == SpectralFilterBankScale_Octave) {
+        afx_auditory_revise_log(num, low, high, bpo, 1, &low, &high);
+        if (high > sr / 2.0) {
+            printf("scale log: lowFre and num is large, overflow error!\n");
+            return -1;
+        }
+    }
+    switch (wt) { /* family defaults (cwt_algorithm.c:202-232) */
+        case WaveletContinue_Morlet: g = 6; b = 2; break;
+        case WaveletContinue_Bump: g = 5; b = 0.6f; break;
+        case WaveletContinue_Paul: g = 4; break;
+        case WaveletContinue_DOG: g = 2; b = 2; break;
+        case WaveletContinue_Mexican: b = 2; break;
+        case WaveletContinue_Hermit: g = 5; b = 2; break;
+        case WaveletContinue_Ricker: g = 4; break;
+        default: break;
+    }
+    if (gamma && *gamma > 0) {
+        g = *gamma;
+        if (wt == WaveletContinue_DOG) {
+            const int p = (int)roundf(g);
+            g = (p % 2 == 0) ? (float)p : 2.f;
+        }
+    }
+    if (beta && *beta > 0) b = *beta;
+    if (isPadding) isPad = *isPadding;
+    if (num < 2 || num > fftLength / 2 + 1) {
+        printf("num is error!\n");
+        return -1;
+    }
+    const int D = 1 << radix2Exp;
+    int pad = 0;
+    if (isPad) {
+        if (D <= 1e5) {
+            pad = D / 2;
+        } else {
+            /* the reference pads by ceil(log2 N) here, which makes the length a
+             * non-power-of-two and sends it down an O(N^2) DFT with N x N double tables
+             * (cwt_algorithm.c:264-289) -- unusable at these sizes */
+            afxdev_set_error("cwtObj_new: padding with 2^%d samples needs a non-power-of-two transform; "
+                             "use isPadding=0 or radix2Exp<=16", radix2Exp);
+            return AFX_ERR_UNSUPPORTED;
+        }
+    }
+    fftLength = (long long)D + 2LL * pad;
+    int rL = 0;
+    while ((1LL << rL) < fftLength) rL++;
+    if (rL > 26) {
+        afxdev_set_error("cwtObj_new: transform length 2^%d exceeds the supported 2^26", rL);
+        return AFX_ERR_UNSUPPORTED;
+    }
+
+    int st = afxdev_ensure();
+    if (st != AFX_OK) return st;
+    CWTObj o = (CWTObj)calloc(1, sizeof(struct OpaqueCWT));
+    if (!o) return AFX_ERR_NOMEM;
+    o->num = num;
+    o->radix2Exp = radix2Exp;
+    o->dataLength = D;
+    o->padLength = pad;
+    o->fftLength = fftLength;
+    o->samplate = sr;
+    o->binPerOctave = bpo;
+    o->lowFre = low;
+    o->highFre = high;
+    o->gamma = g;
+    o->beta = b;
+    o->waveletType = wt;
+    o->scaleType = sc;
+    o->dims.r1 = rL / 2;
+    o->dims.r2 = rL - rL / 2;
+    o->dims.dataLength = D;
+    o->dims.pad = pad;
+    {
+        int c = 8192 >> o->dims.r1; /* <= 64 KB of LDS per column tile */
+        if (c > 32) c = 32;
+        if (c > (1 << o->dims.r2)) c = 1 << o->dims.r2;
+        if (c < 1) c = 1;
+        o->dims.tileCols = c;
+    }
+    o->freBandArr = (float *)calloc((size_t)num + 2, sizeof(float));
+    o->binBandArr = (int *)calloc((size_t)num + 2, sizeof(int));
+    o->hBank = (float *)calloc((size_t)num * fftLength, sizeof(float));
+    float *tw = NULL, *bankT = NULL;
+    if (!o->freBandArr || !o->binBandArr || !o->hBank) st = AFX_ERR_NOMEM;
+    if (st == AFX_OK) {
+        build_bank(o, o->hBank);
+        bankT = to_transposed(o->hBank, num, o->dims.r1, o->dims.r2, NULL);
+        tw = afx_twiddle_table((int)fftLength);
+        if (!bankT || !tw) st = AFX_ERR_NOMEM;
+    }
+    const size_t L = (size_t)fftLength;
+    if (st == AFX_OK) st = afxdev_stream_create(&o->stream);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTw, sizeof(float) * (L < 2 ? 2 : L));
+    if (st == AFX_OK) st = afxdev_h2d(o->dTw, tw, sizeof(float) * (L < 2 ? 2 : L), o->stream);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBankT, sizeof(float) * num * L);
+    if (st == AFX_OK) st = afxdev_h2d(o->dBankT, bankT, sizeof(float) * num * L, o->stream);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dX, sizeof(float) * (size_t)D);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dA, sizeof(float) * 2 * L);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dXt, sizeof(float) * 2 * L);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dB, sizeof(float) * 2 * L * num);
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dOut, sizeof(float) * 2 * (size_t)D * num);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    free(tw);
+    free(bankT);
+    if (st != AFX_OK) {
+        cwtObj_free(o);
+        return st;
+    }
+    *cwtObj = o;
+    return 0;
+}
+
+float *cwtObj_getFreBandArr(CWTObj o) { return o ? o->freBandArr : NULL; }
+int *cwtObj_getBinBandArr(CWTObj o) { return o ? o->binBandArr : NULL; }
+
+static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *re, float *im,
+                const char *who) {
+    int st = AFX_OK;
+    if (dataArr) {
+        st = afxdev_h2d(o->dX, dataArr, sizeof(float) * (size_t)o->dataLength, o->stream);
+        if (st == AFX_OK) st = afxk_cwt_forward(&o->dims, o->dTw, o->dX, o->dA, o->dXt, o->stream);
+        if (st == AFX_OK) o->haveSpectrum = 1;
+    } else if (!o->haveSpectrum) {
+        return; /* nothing to re-use yet */
+    }
+    const size_t outB = sizeof(float) * (size_t)o->num * o->dataLength;
+    float *dRe = o->dOut, *dIm = o->dOut + (size_t)o->num * o->dataLength;
+    if (st == AFX_OK)
+        st = afxk_cwt_inverse(&o->dims, o->dTw, o->dXt, dBank, o->num, isDet, o->dB, dRe, dIm, o->stream);
+    if (st == AFX_OK && re) st = afxdev_d2h(re, dRe, outB, o->stream);
+    if (st == AFX_OK && im) st = afxdev_d2h(im, dIm, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    if (st != AFX_OK) {
+        o->status = st;
+        fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+    }
+}
+
+void cwtObj_cwt(CWTObj o, float *dataArr, float *mRealArr3, float *mImageArr3) {
+    if (!o) {
+        afxdev_set_error("cwtObj_cwt: NULL object");
+        return;
+    }
+    run(o, dataArr, o->dBankT, 0, mRealArr3, mImageArr3, "cwtObj_cwt");
+}
+
+void cwtObj_enableDet(CWTObj o, int flag) {
+    if (!o || !flag || o->dBankDetT) return;
+    /* bank times the angular frequency (cwt_algorithm.c:485-528) */
+    const long long L = o->fftLength;
+    float *w = (float *)calloc((size_t)L, sizeof(float));
+    if (!w) return;
+    for (long long i = 0; i <= L / 2; i++) w[i] = (float)(i * 2 * M_PI / L);
+    for (long long i = L / 2 + 1, j = L / 2 - 1; i < L && j >= 0; i++, j--) w[i] = -w[j];
+    float *t = to_transposed(o->hBank, o->num, o->dims.r1, o->dims.r2, w);
+    int st = t ? AFX_OK : AFX_ERR_NOMEM;
+    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBankDetT, sizeof(float) * (size_t)o->num * L);
+    if (st == AFX_OK) st = afxdev_h2d(o->dBankDetT, t, sizeof(float) * (size_t)o->num * L, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    free(t);
+    free(w);
+    if (st != AFX_OK) {
+        afxdev_free(o->dBankDetT);
+        o->dBankDetT = NULL;
+        o->status = st;
+    }
+}
+
+void cwtObj_cwtDet(CWTObj o, float *dataArr, float *mRealArr3, float *mImageArr3) {
+    if (!o) {
+        afxdev_set_error("cwtObj_cwtDet: NULL object");
+        return;
+    }
+    if (!o->dBankDetT) return; /* enableDet was not called: the reference does nothing either */
+    run(o, dataArr, o->dBankDetT, 1, mRealArr3, mImageArr3, "cwtObj_cwtDet");
+}
+
+void cwtObj_free(CWTObj o) {
+    if (!o) return;
+    if (o->stream) afxdev_stream_sync(o->stream);
+    afxdev_free(o->dTw);
+    afxdev_free(o->dBankT);
+    afxdev_free(o->dBankDetT);
+    afxdev_free(o->dX);
+    afxdev_free(o->dA);
+    afxdev_free(o->dXt);
+    afxdev_free(o->dB);
+    afxdev_free(o->dOut);
+    afxdev_stream_destroy(o->stream);
+    free(o->freBandArr);
+    free(o->binBandArr);
+    free(o->hBank);
+    free(o);
+}

@@ -232,6 +232,51 @@ class RefCQT:
             self.obj = C.c_void_p(None)
 
 
+class RefCWT:
+    def __init__(self, num, radix2_exp, samplate=None, low_fre=None, high_fre=None, bin_per_octave=None,
+                 wavelet_type=None, scale_type=None, gamma=None, beta=None, is_padding=None):
+        L = lib()
+        self.L = L
+        self.num = num
+        self.n = 1 << radix2_exp
+        self.obj = C.c_void_p(None)
+        L.cwtObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, ip, fp, fp, ip, ip, ip, fp, fp, ip]
+        self.status = L.cwtObj_new(C.byref(self.obj), num, radix2_exp, _pi(samplate), _pf(low_fre),
+                                   _pf(high_fre), _pi(bin_per_octave), _pi(wavelet_type),
+                                   _pi(scale_type), _pf(gamma), _pf(beta), _pi(is_padding))
+        L.cwtObj_getFreBandArr.restype = fp
+        L.cwtObj_getFreBandArr.argtypes = [C.c_void_p]
+        L.cwtObj_getBinBandArr.restype = ip
+        L.cwtObj_getBinBandArr.argtypes = [C.c_void_p]
+        for f in (L.cwtObj_cwt, L.cwtObj_cwtDet):
+            f.restype = None
+            f.argtypes = [C.c_void_p, fp, fp, fp]
+        L.cwtObj_enableDet.argtypes = [C.c_void_p, C.c_int]
+        L.cwtObj_free.argtypes = [C.c_void_p]
+
+    def fre_band(self):
+        return np.ctypeslib.as_array(self.L.cwtObj_getFreBandArr(self.obj), (self.num,)).copy()
+
+    def bin_band(self):
+        return np.ctypeslib.as_array(self.L.cwtObj_getBinBandArr(self.obj), (self.num,)).copy()
+
+    def cwt(self, x, det=False):
+        x = np.ascontiguousarray(x, np.float32)
+        re = np.zeros((self.num, self.n), np.float32)
+        im = np.zeros((self.num, self.n), np.float32)
+        if det:
+            self.L.cwtObj_enableDet(self.obj, 1)
+            self.L.cwtObj_cwtDet(self.obj, _f(x), _f(re), _f(im))
+        else:
+            self.L.cwtObj_cwt(self.obj, _f(x), _f(re), _f(im))
+        return re, im
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.cwtObj_free(self.obj)
+            self.obj = C.c_void_p(None)
+
+
 def mel_mfcc(x_clips, num=128, radix2_exp=11, samplate=16000, hop=512, cc_num=13):
     """reference mel (real power) + MFCC for each clip of x_clips[b,n]; the timed
     region of BASELINE.md section 3.  Returns (mel[b,T,num], mfcc[b,T,cc])."""

@@ -412,3 +412,41 @@ def cqt_chroma(Q, chroma_num=12, bpo=12, data_type="power", norm="max", min_fre=
     else:
         return c
     return np.where(d != 0, c / np.where(d != 0, d, 1), c)
+
+
+# --------------------------------------------------------------------------
+# continuous wavelet transform -- src/cwt_algorithm.c:361-483,
+# src/filterbank/cwt_filterBank.c:85-290, :399-426 (morlet), :368-397 (morse), :428-460 (bump)
+# --------------------------------------------------------------------------
+def cwt(x, fre_desc, samplate, wavelet="morlet", gamma=6.0, beta=2.0, pad=True):
+    """x[2^r]; fre_desc = centre frequencies in DESCENDING order (row 0 = highest, as the C
+    result).  Returns complex [num, 2^r]."""
+    x = np.asarray(x, np.float64)
+    n = len(x)
+    p = n // 2 if pad else 0
+    xp = np.concatenate([x[:p][::-1], x, x[n - p:][::-1]])  # :404-414
+    L = len(xp)
+    w = 2 * np.pi * np.arange(L) / L
+    w[L // 2 + 1:] = -w[1:L - L // 2][::-1]  # negative mirror (:222-228)
+    if wavelet == "morse":
+        cf = np.exp((np.log(beta) - np.log(gamma)) / gamma)
+    else:
+        cf = gamma
+    s = cf / (2 * np.pi * np.asarray(fre_desc, np.float64) / samplate)
+    sw = s[:, None] * w[None, :]
+    pos = sw > 0
+    if wavelet == "morlet":
+        psi = np.where(pos, 2 * np.exp(-(sw - gamma) ** 2 / beta), 0.0)
+    elif wavelet == "morse":
+        fac = np.exp(-beta * np.log(cf) + cf ** gamma)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            psi = np.where(pos, 2 * fac * np.exp(beta * np.log(np.abs(sw)) - np.abs(sw) ** gamma), 0.0)
+    elif wavelet == "bump":
+        v = (sw - gamma) / beta
+        with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+            psi = np.where(np.abs(v) < 1 - 1e-6, 2 * np.e * np.exp(-1 / (1 - v * v)), 0.0)
+    else:
+        raise ValueError(wavelet)
+    X = np.fft.fft(xp)
+    W = np.fft.ifft(psi * X[None, :], axis=1)
+    return W[:, p:p + n]

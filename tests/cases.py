@@ -142,3 +142,30 @@ CQT_CASES = {
 CQT_CHROMA = {  # (chroma_num, data_type, norm_type)
     "power_max": (12, 0, 1), "mag_p2": (12, 1, 3), "six_min": (6, 0, 2), "p1": (12, 0, 4), "none": (12, 1, 0),
 }
+
+
+WAVELET = dict(morse=0, morlet=1, bump=2, paul=3, dog=4, mexican=5, hermit=6, ricker=7)
+# continuous wavelet transform: ctor kwargs (reference argument names) + input seed; input length = 2**radix2_exp
+CWT_CASES = {
+    "morlet_84_pad": dict(num=84, radix2_exp=12, samplate=32000, low_fre=32.703, bin_per_octave=12,
+                          wavelet_type=WAVELET["morlet"], scale_type=SCALE["octave"], is_padding=1, x=("mix", 51)),
+    "morse_nopad": dict(num=40, radix2_exp=11, samplate=16000, low_fre=65.406, bin_per_octave=12,
+                        wavelet_type=WAVELET["morse"], scale_type=SCALE["octave"], is_padding=0, x=("mix", 52)),
+    "bump_mel": dict(num=32, radix2_exp=10, samplate=16000, low_fre=50.0, high_fre=7000.0,
+                     wavelet_type=WAVELET["bump"], scale_type=SCALE["mel"], is_padding=1, x=("noise", 53)),
+    "paul_linspace": dict(num=24, radix2_exp=9, samplate=8000, low_fre=200.0, high_fre=3000.0,
+                          wavelet_type=WAVELET["paul"], scale_type=SCALE["linspace"], is_padding=1, x=("noise", 54)),
+    "dog_log_gamma4": dict(num=16, radix2_exp=13, samplate=32000, low_fre=100.0, high_fre=9000.0,
+                           wavelet_type=WAVELET["dog"], scale_type=SCALE["log"], gamma=4.0, is_padding=0,
+                           x=("mix", 55)),
+    "hermit_bark": dict(num=20, radix2_exp=8, samplate=16000, low_fre=100.0, high_fre=6000.0,
+                        wavelet_type=WAVELET["hermit"], scale_type=SCALE["bark"], is_padding=1, x=("noise", 56)),
+    "ricker_erb_tiny": dict(num=3, radix2_exp=3, samplate=16000, low_fre=500.0, high_fre=6000.0,
+                            wavelet_type=WAVELET["ricker"], scale_type=SCALE["erb"], is_padding=1, x=("noise", 57)),
+    "mexican_big": dict(num=12, radix2_exp=16, samplate=44100, low_fre=32.703, bin_per_octave=4,
+                        wavelet_type=WAVELET["mexican"], scale_type=SCALE["octave"], is_padding=1, x=("mix", 58)),
+}
+
+
+def cwt_stride(case):
+    return max(1, (1 << case["radix2_exp"]) // 512)

@@ -80,7 +80,21 @@ def main():
                 cq_out[f"{name}/chroma_{cname}"] = o.chroma(re, im, cn, dt, nt)
         cq_out[f"{name}/cqcc"] = o.cqcc(np.abs(re + 1j * im), 13, 0)
     np.savez_compressed(os.path.join(HERE, "cqt.npz"), **cq_out)
-    for f in ("bft.npz", "xxcc.npz", "cepstrogram.npz", "cqt.npz"):
+    cw_out = {}
+    for name, c in cases.CWT_CASES.items():
+        kw = {k: v for k, v in c.items() if k != "x"}
+        o = ref.RefCWT(kw.pop("num"), kw.pop("radix2_exp"), **kw)
+        assert o.status == 0, (name, o.status)
+        x = cases.make_input((c["x"][0], c["x"][1], 1 << c["radix2_exp"]), c["samplate"])
+        re, im = o.cwt(x)
+        st = cases.cwt_stride(c)  # fixtures keep <= 512 time samples per scale
+        cw_out[f"{name}/re"], cw_out[f"{name}/im"] = re[:, ::st], im[:, ::st]
+        cw_out[f"{name}/fre"], cw_out[f"{name}/bin"] = o.fre_band(), o.bin_band()
+        if name in ("morlet_84_pad", "morse_nopad"):
+            dre, dim = o.cwt(x, det=True)
+            cw_out[f"{name}/det_re"], cw_out[f"{name}/det_im"] = dre[:, ::st], dim[:, ::st]
+    np.savez_compressed(os.path.join(HERE, "cwt.npz"), **cw_out)
+    for f in ("bft.npz", "xxcc.npz", "cepstrogram.npz", "cqt.npz", "cwt.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

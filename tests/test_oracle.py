@@ -121,3 +121,15 @@ def test_restatement_matches_golden_cqt(name, golden_dir):
     assert_parity(restate.cqt_chroma(q, 6, 12, "power", "min", c["min_fre"]),
                   gold[f"{name}/chroma_six_min"], 5e-5, "chroma6")  # divides by the frame MINIMUM: ill-conditioned
     assert_parity(restate.xxcc(np.abs(q), 13), gold[f"{name}/cqcc"], 1e-5, "cqcc")
+
+
+@pytest.mark.parametrize("name,wavelet,gb", [("morlet_84_pad", "morlet", (6.0, 2.0)),
+                                             ("morse_nopad", "morse", (3.0, 20.0)),
+                                             ("bump_mel", "bump", (5.0, 0.6))])
+def test_restatement_matches_golden_cwt(name, wavelet, gb, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "cwt.npz"))
+    c = cases.CWT_CASES[name]
+    x = cases.make_input((c["x"][0], c["x"][1], 1 << c["radix2_exp"]), c["samplate"])
+    got = restate.cwt(x, gold[f"{name}/fre"][::-1], c["samplate"], wavelet, gb[0], gb[1],
+                      bool(c["is_padding"]))[:, ::cases.cwt_stride(c)]
+    assert_parity(got, gold[f"{name}/re"] + 1j * gold[f"{name}/im"], 1e-5, name)
