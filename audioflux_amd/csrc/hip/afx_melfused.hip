@@ -12,14 +12,18 @@
 // Per frame, all inside one wave (no workgroup barriers; waves are independent):
 //   1. 16 coalesced float2 loads per lane of the hop-overlapped frame, times the
 //      window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1]), n = 64*n1 + lane
-//   2. 1024-point complex FFT of z: radix-16 DFT in registers over n1, twiddle
-//      W_1024^(lane*k1), transpose through LDS (pitch 68 float2: conflict-free
-//      ds_read_b64), radix-16 DFT in registers, twiddle W_64, radix-4 across each
-//      lane quad with DPP quad_perm moves (no LDS)
-//   3. real-input split: Z is written to LDS in natural order, each lane reads
-//      the pairs (k, 1024-k), forms X[k] = E + W_2048^k O and X[1024-k] =
-//      conj(E - W O), and stores the spectrum value of both bins into the wave's
-//      power row in LDS
+//   2. 1024-point complex FFT of z (1024 = 16 x 16 x 4): radix-16 DFT in registers
+//      over n1, twiddle W_1024^(lane*k1), transpose through LDS (pitch 68 float2:
+//      conflict-free ds_read_b64), radix-16 DFT in registers, twiddle W_64, second
+//      LDS image V[m2][q]
+//   3. last radix-4 + real-input split, fused: lane takes the bases q = lane,
+//      64+lane (and 128), reads V[0..3][q] and V[0..3][256-q], finishes both
+//      radix-4 butterflies in registers -> Z[q+256j], Z[(256-q)+256j], and forms the
+//      conjugate pairs (k, 1024-k): X[k] = E + W_2048^k O, X[1024-k] = conj(E - W O);
+//      the spectrum value of both bins goes to the wave's power row in LDS
+//      (complex arithmetic is written on float2 vectors with v_pk_{add,mul,fma}_f32
+//      operand swizzles/negations, see pk_* helpers: 2 instructions per complex
+//      multiply, 8 per radix-4 butterfly)
 //   4. banded filter bank: lane i owns a long row A and a short row B of the bank
 //      (AfxBandPlan); its weights stay in VGPRs for the life of the kernel, the
 //      power row is read from LDS with immediate offsets: acc = fma(w[t], P[s+t])
@@ -51,7 +55,7 @@ constexpr int WAVES = 12;       // one workgroup per CU: 3 waves per SIMD
 constexpr int TAB_WIN_F2 = 1024;     // (w[2n], w[2n+1])
 constexpr int TAB_TW1_F2 = 16 * 64;  // W_1024^(lane*k1)
 constexpr int TAB_TW2_F2 = 64;       // W_64^(m2*j1)
-constexpr int TAB_TW3_F2 = 512;      // 0.5 * W_2048^k
+constexpr int TAB_TW3_F2 = 1024;     // 0.5 * W_2048^k, k < 1024
 constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
 constexpr int TAB_BYTES = TAB_F2 * 8;  // 20992
 // band weights: one row of TA+TB floats per lane, row pitch TA+TB+4 floats (pitch/4 odd:
@@ -71,7 +75,7 @@ struct KArgs {
     const float2 *win2;  // [1024]  (w[2n], w[2n+1])
     const float2 *tw1;   // [16][64] W_1024^(lane*k1)
     const float2 *tw2;   // [4][16]  W_64^(m2*j1)
-    const float2 *tw3;   // [512]    0.5 * W_2048^k
+    const float2 *tw3;   // [1024]   0.5 * W_2048^k
     const float *wLane;    // [64][wpitch]: lane-major band weights, A taps then B taps
     const int *meta;       // [4][64]: startA, startB, rowA, rowB
     int specMap, postPow;
@@ -88,48 +92,103 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
+
+// ---- packed-f32 complex primitives -------------------------------------------------------
+// VOP3P operand modifiers: op_sel[i] / op_sel_hi[i] pick the half of source i that feeds the
+// low / high result lane, neg_lo / neg_hi negate it.  hipcc does not fold a swap+negate into
+// these modifiers (it emits v_xor + v_mov per complex multiply), so the three patterns that
+// need them are spelled out.  Plain VALU->VALU dependences are hardware-interlocked on gfx9.
+
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2 pk_add_mi(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2 pk_add_pi(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y)
+__device__ __forceinline__ v2 pk_add_conj(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - conj(b) = (a.x - b.x, a.y + b.y)
+__device__ __forceinline__ v2 pk_sub_conj(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// complex product a * b
+__device__ __forceinline__ v2 cmul(v2 a, v2 b) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (ax bx, ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-ay by + ., ay bx + .)
+    return r;
+}
+// w * (-i d):  real = w.x d.y + w.y d.x,  imag = w.y d.y - w.x d.x
+__device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(d), "v"(w));  // (dy wx, dy wy)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(d), "v"(w), "v"(t));  // (dx wy + ., -dx wx + .)
+    return r;
+}
+// (-i) a = (a.y, -a.x) as one multiply by the constant pair (1, -1)
+__device__ __forceinline__ v2 mul_mi(v2 a) {
+    v2 r;
+    const v2 c = {1.f, -1.f};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(c));
+    return r;
 }
 
-// forward 4-point DFT in place: (p0,p1,p2,p3) -> (X0,X1,X2,X3)
-__device__ __forceinline__ void dft4(float2 &p0, float2 &p1, float2 &p2, float2 &p3) {
-    const float2 s0 = make_float2(p0.x + p2.x, p0.y + p2.y);
-    const float2 s1 = make_float2(p0.x - p2.x, p0.y - p2.y);
-    const float2 s2 = make_float2(p1.x + p3.x, p1.y + p3.y);
-    const float2 s3 = make_float2(p1.x - p3.x, p1.y - p3.y);
-    p0 = make_float2(s0.x + s2.x, s0.y + s2.y);
-    p2 = make_float2(s0.x - s2.x, s0.y - s2.y);
-    p1 = make_float2(s1.x + s3.y, s1.y - s3.x);  // s1 - i s3
-    p3 = make_float2(s1.x - s3.y, s1.y + s3.x);  // s1 + i s3
+// forward 4-point DFT in place: (p0,p1,p2,p3) -> (X0,X1,X2,X3); 8 v_pk_add_f32
+__device__ __forceinline__ void dft4(v2 &p0, v2 &p1, v2 &p2, v2 &p3) {
+    const v2 s0 = p0 + p2, s1 = p0 - p2, s2 = p1 + p3, s3 = p1 - p3;
+    p0 = s0 + s2;
+    p2 = s0 - s2;
+    p1 = pk_add_mi(s1, s3);  // s1 - i s3
+    p3 = pk_add_pi(s1, s3);  // s1 + i s3
 }
 
 // forward 16-point DFT in place, radix-4 x radix-4.  Input x[n] = v[n];
 // output X[k] = v[4*(k&3) + (k>>2)]  (base-4 digit reversal).
-__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+__device__ __forceinline__ void dft16(v2 (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+    const v2 w1 = {C1, -S1}, w3 = {S1, -C1}, w9 = {-C1, S1};
 #pragma unroll
     for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
     // t[b][c] sits at v[4c+b]; multiply by W16^(b*c), W16 = exp(-2 pi i / 16)
-    v[5] = cmul(v[5], make_float2(C1, -S1));                       // b1 c1: W^1
-    v[9] = make_float2(H * (v[9].x + v[9].y), H * (v[9].y - v[9].x));    // b1 c2: W^2
-    v[13] = cmul(v[13], make_float2(S1, -C1));                     // b1 c3: W^3
-    v[6] = make_float2(H * (v[6].x + v[6].y), H * (v[6].y - v[6].x));    // b2 c1: W^2
-    v[10] = make_float2(v[10].y, -v[10].x);                        // b2 c2: W^4 = -i
-    v[14] = make_float2(H * (v[14].y - v[14].x), -H * (v[14].x + v[14].y));  // b2 c3: W^6
-    v[7] = cmul(v[7], make_float2(S1, -C1));                       // b3 c1: W^3
-    v[11] = make_float2(H * (v[11].y - v[11].x), -H * (v[11].x + v[11].y));  // b3 c2: W^6
-    v[15] = cmul(v[15], make_float2(-C1, S1));                     // b3 c3: W^9
+    v[5] = cmul(v[5], w1);                 // W^1
+    v[9] = pk_add_mi(v[9], v[9]) * H;      // W^2 = H(1 - i):  H (x + y, y - x)
+    v[13] = cmul(v[13], w3);               // W^3
+    v[6] = pk_add_mi(v[6], v[6]) * H;      // W^2
+    v[10] = mul_mi(v[10]);                 // W^4 = -i
+    v[14] = pk_add_pi(v[14], v[14]) * -H;  // W^6 = -H(1 + i): -H (x - y, x + y)
+    v[7] = cmul(v[7], w3);                 // W^3
+    v[11] = pk_add_pi(v[11], v[11]) * -H;  // W^6
+    v[15] = cmul(v[15], w9);               // W^9
 #pragma unroll
     for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 }
 
 __host__ __device__ constexpr int rev4(int k) { return 4 * (k & 3) + (k >> 2); }
 
-// value of lane (l ^ mask) inside each quad, via a DPP quad_perm move
-template <int CTRL>
-__device__ __forceinline__ float quad_swap(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+// |X|^2 (optionally mapped) of the conjugate pair (k, 1024-k) from A = Z[k], B = Z[1024-k]
+__device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w /* 0.5 W_2048^k */, float &pk, float &pq) {
+    const v2 e2 = pk_add_conj(A, B);   // 2 E
+    const v2 d = pk_sub_conj(A, B);    // 2 i O  ->  2 O = -i d
+    const v2 wo = cmul_mi(d, w);       // W O   (w carries the 1/2)
+    const v2 x = e2 * 0.5f + wo;       // X[k]
+    const v2 y = e2 * 0.5f - wo;       // conj(X[1024-k])
+    pk = x.x * x.x + x.y * x.y;
+    pq = y.x * y.x + y.y * y.y;
 }
 
 // GENERAL = false: plain |S|^2 (the hot configuration; no sqrt/pow code in the loop)
@@ -142,31 +201,32 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     constexpr int WP = wpitch(TA, TB);
-    float2 *tabWin = reinterpret_cast<float2 *>(smem);
-    float2 *tabTw1 = tabWin + TAB_WIN_F2;
-    float2 *tabTw2 = tabTw1 + TAB_TW1_F2;
-    float2 *tabTw3 = tabTw2 + TAB_TW2_F2;
+    v2 *tabWin = reinterpret_cast<v2 *>(smem);
+    v2 *tabTw1 = tabWin + TAB_WIN_F2;
+    v2 *tabTw2 = tabTw1 + TAB_TW1_F2;
+    v2 *tabTw3 = tabTw2 + TAB_TW2_F2;
     float *tabW = reinterpret_cast<float *>(smem + TAB_BYTES);
-    float2 *ex = reinterpret_cast<float2 *>(smem + TAB_BYTES + 64 * WP * 4 + wave * WAVE_LDS_BYTES);
+    v2 *ex = reinterpret_cast<v2 *>(smem + TAB_BYTES + 64 * WP * 4 + wave * WAVE_LDS_BYTES);
     float *prow = reinterpret_cast<float *>(ex);  // aliases ex: written only after the pair reads
 
     // ---- workgroup-shared tables -> LDS (once) ----------------------------------
-    for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = a.win2[i];
-    for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = a.tw1[i];
-    for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = a.tw3[i];
-    for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
-    if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = a.tw2[threadIdx.x];
+    {
+        const v2 *gWin = reinterpret_cast<const v2 *>(a.win2), *gTw1 = reinterpret_cast<const v2 *>(a.tw1);
+        const v2 *gTw2 = reinterpret_cast<const v2 *>(a.tw2), *gTw3 = reinterpret_cast<const v2 *>(a.tw3);
+        for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = gWin[i];
+        for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = gTw1[i];
+        for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = gTw3[i];
+        for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
+        if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = gTw2[threadIdx.x];
+    }
     __syncthreads();
 
     // ---- per-lane constants -----------------------------------------------------
     const int k1 = lane >> 2, m2 = lane & 3;
-    const int j2 = ((lane & 1) << 1) | ((lane >> 1) & 1);
-    const float sgnA = (m2 & 2) ? -1.f : 1.f;  // quad stage A: o + sgnA * v
-    const float sgnB = (m2 & 1) ? -1.f : 1.f;  // quad stage B
-    const bool rot = (m2 == 3);                // multiply by -i between the stages
     const int startA = a.meta[lane], startB = a.meta[64 + lane];
     const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
     const float4 *wrow = reinterpret_cast<const float4 *>(tabW + lane * WP);
+    const int qm = (256 - lane) & 255;  // mirror base of q = lane (lane 0 mirrors itself)
 
     const long long gw = (long long)blockIdx.x * WAVES + wave;
     long long f = gw * a.framesPerWave;
@@ -177,10 +237,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     int t = (int)(f - (long long)clip * a.timeLength);
 
     // raw samples of the frame about to be transformed: raw[n1] = (x[2n], x[2n+1]), n = 64 n1 + lane
-    float2 raw[16];
+    v2 raw[16];
     auto fetch = [&](const float *px, int first) {
         if (a.aligned) {
-            const float2 *p2 = reinterpret_cast<const float2 *>(px);
+            const v2 *p2 = reinterpret_cast<const v2 *>(px);
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1)
                 if (n1 >= first) raw[n1] = p2[64 * n1 + lane];
@@ -189,20 +249,17 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
             for (int n1 = 0; n1 < 16; ++n1)
                 if (n1 >= first) {
                     const int n = 64 * n1 + lane;
-                    raw[n1] = make_float2(px[2 * n], px[2 * n + 1]);
+                    raw[n1] = v2{px[2 * n], px[2 * n + 1]};
                 }
         }
     };
     fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
 
     for (; f < fEnd; ++f) {
-        float2 v[16];
+        v2 v[16];
         // ---- 1. window (samples were fetched during the previous frame) ---------------
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            const float2 w = tabWin[64 * n1 + lane];
-            v[n1] = make_float2(raw[n1].x * w.x, raw[n1].y * w.y);
-        }
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * tabWin[64 * n1 + lane];
         // ---- 1b. start fetching the next frame: in flight under the whole transform ---
         if (f + 1 < fEnd) {
             int tn = t + 1, cn = clip;
@@ -230,71 +287,74 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         for (int m1 = 0; m1 < 16; ++m1) v[m1] = ex[k1 * EX_PITCH + 4 * m1 + m2];
         wave_lds_sync();
 
-        // ---- 2b. radix-16 over m1, twiddle W_64^(m2*j1), radix-4 across the quad --
+        // ---- 2b. radix-16 over m1, twiddle W_64^(m2*j1) -> image V[m2][q = k1 + 16 j1] ----
         dft16(v);
+        ex[m2 * 260 + k1] = v[0];
 #pragma unroll
-        for (int j1 = 0; j1 < 16; ++j1) {
-            float2 c = v[rev4(j1)];
-            if (j1 > 0) c = cmul(c, tabTw2[m2 * 16 + j1]);
-            // stage A: lanes {0,1} get V0+V2, V1+V3; lanes {2,3} get V0-V2, V1-V3
-            float rx = fmaf(sgnA, c.x, quad_swap<0x4E>(c.x));
-            float ry = fmaf(sgnA, c.y, quad_swap<0x4E>(c.y));
-            // lane 3 (V1-V3) is multiplied by -i
-            const float tx = rot ? ry : rx;
-            const float ty = rot ? -rx : ry;
-            // stage B: even lanes r + o, odd lanes o - r  ->  lane m holds U[j2(m)]
-            rx = fmaf(sgnB, tx, quad_swap<0xB1>(tx));
-            ry = fmaf(sgnB, ty, quad_swap<0xB1>(ty));
-            // Z[k1 + 16 j1 + 256 j2] -> natural-order image, 4 float2 of pad per 256
-            ex[k1 + 16 * j1 + 260 * j2] = make_float2(rx, ry);
-        }
+        for (int j1 = 1; j1 < 16; ++j1)
+            ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], tabTw2[m2 * 16 + j1]);
         wave_lds_sync();
 
-        // ---- 3. real-input split + spectrum value -> power row --------------------
-        float pk[8], pq[8];
+        // ---- 3. last radix-4 + real-input split -> spectrum values in registers -------
+        float pk[20], pq[20];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = lane + 64 * i;
-            const int kp = (MC - k) & (MC - 1);
-            const float2 A = ex[k + 4 * (k >> 8)];
-            const float2 B = ex[kp + 4 * (kp >> 8)];
-            const float2 w = tabTw3[k];  // 0.5 * W_2048^k
-            const float ex2 = 0.5f * (A.x + B.x), ey2 = 0.5f * (A.y - B.y);  // E
-            const float ox = A.y + B.y, oy = B.x - A.x;                      // 2 O
-            const float wx = w.x * ox - w.y * oy, wy = w.x * oy + w.y * ox;  // W O
-            const float xr = ex2 + wx, xi = ey2 + wy;   // X[k]
-            const float yr = ex2 - wx, yi = ey2 - wy;   // conj(X[1024-k])
-            pk[i] = xr * xr + xi * xi;
-            pq[i] = yr * yr + yi * yi;
+        for (int s = 0; s < 2; ++s) {
+            const int q = lane + 64 * s;
+            const int qp = s == 0 ? qm : 192 - lane;  // (256 - q) & 255
+            v2 za0 = ex[q], za1 = ex[260 + q], za2 = ex[520 + q], za3 = ex[780 + q];
+            v2 zb0 = ex[qp], zb1 = ex[260 + qp], zb2 = ex[520 + qp], zb3 = ex[780 + qp];
+            dft4(za0, za1, za2, za3);  // Z[q + 256 j]
+            dft4(zb0, zb1, zb2, zb3);  // Z[qp + 256 j]
+            // partner of Z[q + 256 j] is Z[qp + 256 (3 - j)]; for q = 0 it is Z[256 ((4 - j) & 3)]
+            v2 b0 = zb3, b1 = zb2, b2 = zb1, b3 = zb0;
+            if (s == 0) {
+                const bool self = (lane == 0);
+                b0 = self ? zb0 : zb3;
+                b1 = self ? zb3 : zb2;
+                b2 = self ? zb2 : zb1;
+                b3 = self ? zb1 : zb0;
+            }
+            split_pair(za0, b0, tabTw3[q], pk[8 * s + 0], pq[8 * s + 0]);
+            split_pair(za1, b1, tabTw3[q + 256], pk[8 * s + 1], pq[8 * s + 1]);
+            split_pair(za2, b2, tabTw3[q + 512], pk[8 * s + 2], pq[8 * s + 2]);
+            split_pair(za3, b3, tabTw3[q + 768], pk[8 * s + 3], pq[8 * s + 3]);
         }
-        float pmid;
-        {
-            const float2 zc = ex[512 + 4 * 2];
-            pmid = zc.x * zc.x + zc.y * zc.y;
+        {   // base 128 mirrors itself: bins 128, 384 and their partners 896, 640 (every lane
+            // computes them, lane 0 stores them)
+            v2 z0 = ex[128], z1 = ex[260 + 128], z2 = ex[520 + 128], z3 = ex[780 + 128];
+            dft4(z0, z1, z2, z3);
+            split_pair(z0, z3, tabTw3[128], pk[16], pq[16]);
+            split_pair(z1, z2, tabTw3[384], pk[17], pq[17]);
         }
         if (GENERAL && a.specMap == 1) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 18; ++i) {
                 pk[i] = sqrtf(pk[i]);
                 pq[i] = sqrtf(pq[i]);
             }
-            pmid = sqrtf(pmid);
         } else if (GENERAL && a.specMap == 2) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 18; ++i) {
                 pk[i] = powf(pk[i], a.normValue);
                 pq[i] = powf(pq[i], a.normValue);
             }
-            pmid = powf(pmid, a.normValue);
         }
-        wave_lds_sync();  // every lane has its pairs in registers; ex becomes the power row
+        wave_lds_sync();  // every lane has its bins in registers; ex becomes the power row
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = lane + 64 * i;
-            prow[k] = pk[i];
-            prow[MC - k] = pq[i];
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * s + 256 * j;
+                prow[k] = pk[8 * s + j];
+                prow[MC - k] = pq[8 * s + j];
+            }
         }
-        if (lane == 0) prow[512] = pmid;
+        if (lane == 0) {
+            prow[128] = pk[16];
+            prow[896] = pq[16];
+            prow[384] = pk[17];
+            prow[640] = pq[17];
+        }
         // zero pad behind bin 1024: the fixed-length band loops read it with zero weights
         prow[1025 + lane] = 0.f;
         if (lane < PROW_F - 1025 - 64) prow[1025 + 64 + lane] = 0.f;
@@ -462,7 +522,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     // twiddle tables in double, rounded once
     float *tw1 = static_cast<float *>(malloc(sizeof(float) * 2 * 16 * 64));
     float *tw2 = static_cast<float *>(malloc(sizeof(float) * 2 * 4 * 16));
-    float *tw3 = static_cast<float *>(malloc(sizeof(float) * 2 * 512));
+    float *tw3 = static_cast<float *>(malloc(sizeof(float) * 2 * 1024));
     const int WP = TA + TB + 4;
     float *wL = static_cast<float *>(calloc((size_t)64 * WP, sizeof(float)));
     int meta[256];
@@ -481,7 +541,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
                 tw2[2 * (m * 16 + j)] = (float)cos(ang);
                 tw2[2 * (m * 16 + j) + 1] = (float)sin(ang);
             }
-        for (int k = 0; k < 512; ++k) {
+        for (int k = 0; k < 1024; ++k) {
             const double ang = -2.0 * PI * (double)k / NFFT;
             tw3[2 * k] = (float)(0.5 * cos(ang));
             tw3[2 * k + 1] = (float)(0.5 * sin(ang));
@@ -500,7 +560,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     }
     if (st == AFX_OK) st = upload(&p->dTw1, tw1, sizeof(float) * 2 * 16 * 64, stream);
     if (st == AFX_OK) st = upload(&p->dTw2, tw2, sizeof(float) * 2 * 4 * 16, stream);
-    if (st == AFX_OK) st = upload(&p->dTw3, tw3, sizeof(float) * 2 * 512, stream);
+    if (st == AFX_OK) st = upload(&p->dTw3, tw3, sizeof(float) * 2 * 1024, stream);
     if (st == AFX_OK) st = upload(&p->dWLane, wL, sizeof(float) * (size_t)64 * WP, stream);
     if (st == AFX_OK) st = upload(&p->dMeta, meta, sizeof(meta), stream);
     if (st == AFX_OK) st = afxdev_stream_sync(stream);  // host staging buffers are freed below

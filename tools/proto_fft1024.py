@@ -87,3 +87,37 @@ X[512] = np.conj(zl[phys(512)])
 ref = np.fft.rfft(x)
 assert np.allclose(X, ref), np.abs(X - ref).max()
 print("prototype OK: max err", np.abs(X - ref).max())
+
+# ---------------------------------------------------------------------------------------
+# v4 final stage: the cross-quad radix-4 is folded into the real-input split.  After pass 2
+# and the W_64 twiddle, lane (k1, m2) writes V_m2[q = k1 + 16 j1] to the LDS image
+# img[m2*260 + q]; then every lane takes bases q = lane, 64 + lane (and all lanes q = 128),
+# runs the radix-4 for base q and its mirror 256 - q in registers and forms the pairs.
+def dft4(p):
+    s0, s1, s2, s3 = p[0] + p[2], p[0] - p[2], p[1] + p[3], p[1] - p[3]
+    return [s0 + s2, s1 - 1j * s3, s0 - s2, s1 + 1j * s3]
+
+img = np.zeros(4 * 260, complex)
+for j1 in range(16):
+    img[m2 * 260 + k1 + 16 * j1] = V[:, j1]
+W2 = np.exp(-2j * np.pi * np.arange(1024) / N)
+X4 = np.full(M + 1, np.nan + 0j)
+def pair(k, A, B):
+    E = 0.5 * (A + np.conj(B)); O = -0.5j * (A - np.conj(B))
+    X4[k] = E + W2[k] * O
+    X4[M - k] = np.conj(E - W2[k] * O)
+for ln in range(64):
+    for s in range(2):
+        q = ln + 64 * s
+        qp = (256 - q) & 255
+        Za = dft4([img[m * 260 + q] for m in range(4)])
+        Zb = dft4([img[m * 260 + qp] for m in range(4)])
+        for j in range(4):
+            B = Zb[(4 - j) & 3] if q == 0 else Zb[3 - j]
+            pair(q + 256 * j, Za[j], B)
+Zc = dft4([img[m * 260 + 128] for m in range(4)])
+for j in range(2):
+    pair(128 + 256 * j, Zc[j], Zc[3 - j])
+assert not np.isnan(X4).any()
+assert np.allclose(X4, ref), np.abs(X4 - ref).max()
+print("v4 final stage OK: max err", np.abs(X4 - ref).max())
