@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaudioflux_mi355x.so")
+LIB_PATH = os.environ.get("AFX_LIB") or os.path.join(_HERE, "lib", "libaudioflux_mi355x.so")
 _lib = None
 
 

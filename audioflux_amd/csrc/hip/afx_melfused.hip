@@ -26,8 +26,8 @@
 //      multiply, 8 per radix-4 butterfly)
 //   4. banded filter bank: lane i owns a long row A and a short row B of the bank
 //      (AfxBandPlan); its weights stay in VGPRs for the life of the kernel, the
-//      power row is read from LDS with immediate offsets: acc = fma(w[t], P[s+t])
-//      in ascending bin order
+//      power row is read from LDS with immediate offsets, two bins per ds_read_b64:
+//      (acc0, acc1) += (w[2t], w[2t+1]) * (P[s+2t], P[s+2t+1]), ascending bins
 //   5. two dword stores per lane: out[frame, rowA], out[frame, rowB]
 //
 // HBM traffic per frame = 4*hop bytes in (each sample once; the 4x frame overlap
@@ -42,6 +42,16 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 
+#ifndef AFX_V
+// Compile-time experiment switches (tools/variants.sh builds variants, tools/ab.py runs them
+// interleaved on the GPU).  0 = shipped configuration.  Measured on MI355X, 934 000 frames
+// (profiles/r01_ab_variants.txt): shipped 1.57 ms; +2 (W_64 twiddles read in one batch) 1.64;
+// +16 (W_1024 twiddles through L1 instead of LDS) 1.64; +32 (window through L1) 1.68;
+// +8 (band loop one quad at a time) 5.1; fence-based wave sync (+1) and per-half operand
+// batching of the last stage (+4): no difference.
+#define AFX_V 0
+#endif
+
 namespace {
 
 constexpr int NFFT = 2048;
@@ -52,10 +62,10 @@ constexpr int PROW_F = 1104;    // 1025 bins + zero pad for the fixed-length ban
 constexpr int WAVE_LDS_BYTES = EX_F2 * 8;  // 8704; the power row (4416 B) aliases the exchange image
 constexpr int WAVES = 12;       // one workgroup per CU: 3 waves per SIMD
 // workgroup-shared constant tables staged in LDS once per workgroup
-constexpr int TAB_WIN_F2 = 1024;     // (w[2n], w[2n+1])
 constexpr int TAB_TW1_F2 = 16 * 64;  // W_1024^(lane*k1)
 constexpr int TAB_TW2_F2 = 64;       // W_64^(m2*j1)
 constexpr int TAB_TW3_F2 = 1024;     // 0.5 * W_2048^k, k < 1024
+constexpr int TAB_WIN_F2 = (AFX_V & 32) ? 0 : 1024;  // (w[2n], w[2n+1])
 constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
 constexpr int TAB_BYTES = TAB_F2 * 8;  // 20992
 // band weights: one row of TA+TB floats per lane, row pitch TA+TB+4 floats (pitch/4 odd:
@@ -85,11 +95,19 @@ struct KArgs {
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
-    // orders this wave's LDS stores before its later LDS loads (other lanes' data);
-    // DS operations of one wave execute in issue order, the fences pin the compiler
+    // Orders this wave's LDS stores before its later LDS loads of other lanes' data.  DS
+    // operations of one wave execute in issue order; lgkmcnt(0) drains them and the wave
+    // barrier pins the compiler.  Deliberately NOT a fence: a wavefront-scope fence also
+    // emits vmcnt(0), which would drain the next frame's prefetch and the previous frame's
+    // stores at every exchange.
+#if AFX_V & 1
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt/expcnt untouched
+    __builtin_amdgcn_wave_barrier();
+#endif
 }
 
 typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
@@ -211,9 +229,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
 
     // ---- workgroup-shared tables -> LDS (once) ----------------------------------
     {
-        const v2 *gWin = reinterpret_cast<const v2 *>(a.win2), *gTw1 = reinterpret_cast<const v2 *>(a.tw1);
+        const v2 *gTw1 = reinterpret_cast<const v2 *>(a.tw1);
         const v2 *gTw2 = reinterpret_cast<const v2 *>(a.tw2), *gTw3 = reinterpret_cast<const v2 *>(a.tw3);
-        for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = gWin[i];
+        for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = reinterpret_cast<const v2 *>(a.win2)[i];
         for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = gTw1[i];
         for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = gTw3[i];
         for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
@@ -254,12 +272,24 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         }
     };
     fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
+    // experiment variant: window re-fetched through L1 while the filter-bank stage runs
+#if AFX_V & 32
+    const v2 *gWin = reinterpret_cast<const v2 *>(a.win2) + lane;
+    v2 win[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = gWin[64 * n1];
+#endif
 
     for (; f < fEnd; ++f) {
         v2 v[16];
         // ---- 1. window (samples were fetched during the previous frame) ---------------
+#if !(AFX_V & 32)
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * tabWin[64 * n1 + lane];
+#else
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * win[n1];
+#endif
         // ---- 1b. start fetching the next frame: in flight under the whole transform ---
         if (f + 1 < fEnd) {
             int tn = t + 1, cn = clip;
@@ -278,31 +308,81 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         }
 
         // ---- 2a. radix-16 over n1, twiddle, transpose through LDS ---------------
+        v2 t1[16];
+#if !(AFX_V & 16)
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t1[k] = tabTw1[k * 64 + lane];
+#else
+        {
+            const v2 *gt = reinterpret_cast<const v2 *>(a.tw1) + lane;
+            asm volatile("" : "+v"(gt));
+#pragma unroll
+            for (int k = 1; k < 16; ++k) t1[k] = gt[64 * k];
+        }
+#endif
         dft16(v);
         ex[lane] = v[0];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) ex[k * EX_PITCH + lane] = cmul(v[rev4(k)], tabTw1[k * 64 + lane]);
+        for (int k = 1; k < 16; ++k) ex[k * EX_PITCH + lane] = cmul(v[rev4(k)], t1[k]);
         wave_lds_sync();
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) v[m1] = ex[k1 * EX_PITCH + 4 * m1 + m2];
         wave_lds_sync();
 
         // ---- 2b. radix-16 over m1, twiddle W_64^(m2*j1) -> image V[m2][q = k1 + 16 j1] ----
+        // all twiddles are read in one batch before the butterflies (LDS reads interleaved with
+        // the image writes would be serialised one round trip at a time: same array, may alias)
+#if !(AFX_V & 2)
         dft16(v);
         ex[m2 * 260 + k1] = v[0];
 #pragma unroll
-        for (int j1 = 1; j1 < 16; ++j1)
-            ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], tabTw2[m2 * 16 + j1]);
+        for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], tabTw2[m2 * 16 + j1]);
+#else
+        v2 t2[16];
+#pragma unroll
+        for (int j1 = 1; j1 < 16; ++j1) t2[j1] = tabTw2[m2 * 16 + j1];
+        dft16(v);
+        ex[m2 * 260 + k1] = v[0];
+#pragma unroll
+        for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], t2[j1]);
+#endif
         wave_lds_sync();
 
         // ---- 3. last radix-4 + real-input split -> spectrum values in registers -------
         float pk[20], pq[20];
+        // every LDS operand of this stage is requested up front (24 + 6 reads in flight)
+        v2 zin[2][8], w3[2][4];
+#if !(AFX_V & 4)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int q = lane + 64 * s;
             const int qp = s == 0 ? qm : 192 - lane;  // (256 - q) & 255
-            v2 za0 = ex[q], za1 = ex[260 + q], za2 = ex[520 + q], za3 = ex[780 + q];
-            v2 zb0 = ex[qp], zb1 = ex[260 + qp], zb2 = ex[520 + qp], zb3 = ex[780 + qp];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                zin[s][m] = ex[260 * m + q];
+                zin[s][4 + m] = ex[260 * m + qp];
+                w3[s][m] = tabTw3[q + 256 * m];
+            }
+        }
+#endif
+        v2 zc0 = ex[128], zc1 = ex[260 + 128], zc2 = ex[520 + 128], zc3 = ex[780 + 128];
+        const v2 wc0 = tabTw3[128], wc1 = tabTw3[384];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#if AFX_V & 4
+            {
+                const int q = lane + 64 * s;
+                const int qp = s == 0 ? qm : 192 - lane;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    zin[s][m] = ex[260 * m + q];
+                    zin[s][4 + m] = ex[260 * m + qp];
+                    w3[s][m] = tabTw3[q + 256 * m];
+                }
+            }
+#endif
+            v2 za0 = zin[s][0], za1 = zin[s][1], za2 = zin[s][2], za3 = zin[s][3];
+            v2 zb0 = zin[s][4], zb1 = zin[s][5], zb2 = zin[s][6], zb3 = zin[s][7];
             dft4(za0, za1, za2, za3);  // Z[q + 256 j]
             dft4(zb0, zb1, zb2, zb3);  // Z[qp + 256 j]
             // partner of Z[q + 256 j] is Z[qp + 256 (3 - j)]; for q = 0 it is Z[256 ((4 - j) & 3)]
@@ -314,17 +394,16 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                 b2 = self ? zb2 : zb1;
                 b3 = self ? zb1 : zb0;
             }
-            split_pair(za0, b0, tabTw3[q], pk[8 * s + 0], pq[8 * s + 0]);
-            split_pair(za1, b1, tabTw3[q + 256], pk[8 * s + 1], pq[8 * s + 1]);
-            split_pair(za2, b2, tabTw3[q + 512], pk[8 * s + 2], pq[8 * s + 2]);
-            split_pair(za3, b3, tabTw3[q + 768], pk[8 * s + 3], pq[8 * s + 3]);
+            split_pair(za0, b0, w3[s][0], pk[8 * s + 0], pq[8 * s + 0]);
+            split_pair(za1, b1, w3[s][1], pk[8 * s + 1], pq[8 * s + 1]);
+            split_pair(za2, b2, w3[s][2], pk[8 * s + 2], pq[8 * s + 2]);
+            split_pair(za3, b3, w3[s][3], pk[8 * s + 3], pq[8 * s + 3]);
         }
         {   // base 128 mirrors itself: bins 128, 384 and their partners 896, 640 (every lane
             // computes them, lane 0 stores them)
-            v2 z0 = ex[128], z1 = ex[260 + 128], z2 = ex[520 + 128], z3 = ex[780 + 128];
-            dft4(z0, z1, z2, z3);
-            split_pair(z0, z3, tabTw3[128], pk[16], pq[16]);
-            split_pair(z1, z2, tabTw3[384], pk[17], pq[17]);
+            dft4(zc0, zc1, zc2, zc3);
+            split_pair(zc0, zc3, wc0, pk[16], pq[16]);
+            split_pair(zc1, zc2, wc1, pk[17], pq[17]);
         }
         if (GENERAL && a.specMap == 1) {
 #pragma unroll
@@ -360,30 +439,59 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         if (lane < PROW_F - 1025 - 64) prow[1025 + 64 + lane] = 0.f;
         wave_lds_sync();
 
-        // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset
-        //         ds_read_b32 (conflict-free by the plan's bank-aware lane assignment) ------
-        float accA0 = 0.f, accA1 = 0.f, accB = 0.f;
+        // window for the next frame: lands while the band loops run.  The empty asm makes the
+        // pointer opaque so the (loop-invariant) loads are not hoisted into 32 resident VGPRs.
+#if AFX_V & 32
         {
-            const float *pa = prow + startA;
+            const v2 *gw = gWin;
+            asm volatile("" : "+v"(gw));
 #pragma unroll
-            for (int q = 0; q < TA / 4; ++q) {
-                const float4 w = wrow[q];
-                accA0 = fmaf(w.x, pa[4 * q], accA0);
-                accA1 = fmaf(w.y, pa[4 * q + 1], accA1);
-                accA0 = fmaf(w.z, pa[4 * q + 2], accA0);
-                accA1 = fmaf(w.w, pa[4 * q + 3], accA1);
-            }
-            const float *pb = prow + startB;
-#pragma unroll
-            for (int q = 0; q < TB / 4; ++q) {
-                const float4 w = wrow[TA / 4 + q];
-                accB = fmaf(w.x, pb[4 * q], accB);
-                accB = fmaf(w.y, pb[4 * q + 1], accB);
-                accB = fmaf(w.z, pb[4 * q + 2], accB);
-                accB = fmaf(w.w, pb[4 * q + 3], accB);
-            }
+            for (int n1 = 0; n1 < 16; ++n1) win[n1] = gw[64 * n1];
         }
-        float accA = accA0 + accA1;
+#endif
+
+        // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset
+        //         ds_read_b64 (conflict-free by the plan's bank-aware lane assignment) ------
+        float accA, accB;
+        {
+            // startA / startB are even: the power row is read as pairs (ds_read_b64)
+            const v2 *pa = reinterpret_cast<const v2 *>(prow + startA);
+            v2 sA = {0.f, 0.f}, sB = {0.f, 0.f};
+            const v2 *pb = reinterpret_cast<const v2 *>(prow + startB);
+            // operands are requested in blocks of 4 quads (12 LDS reads in flight) so that one
+            // LDS round trip is paid per block instead of per quad
+            constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = (AFX_V & 8) ? 1 : (AFX_V & 64) ? 8 : (AFX_V & 128) ? 2 : 4;
+#pragma unroll
+            for (int q0 = 0; q0 < QT; q0 += BLK) {
+                float4 w[BLK];
+                v2 p0[BLK], p1[BLK];
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const int q = q0 + i;
+                    if (q < QT) {
+                        w[i] = wrow[q];
+                        const v2 *src = q < QA ? pa + 2 * q : pb + 2 * (q - QA);
+                        p0[i] = src[0];
+                        p1[i] = src[1];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const int q = q0 + i;
+                    if (q < QT) {
+                        if (q < QA) {
+                            sA += v2{w[i].x, w[i].y} * p0[i];
+                            sA += v2{w[i].z, w[i].w} * p1[i];
+                        } else {
+                            sB += v2{w[i].x, w[i].y} * p0[i];
+                            sB += v2{w[i].z, w[i].w} * p1[i];
+                        }
+                    }
+                }
+            }
+            accA = sA.x + sA.y;
+            accB = sB.x + sB.y;
+        }
         if (GENERAL && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
@@ -412,7 +520,7 @@ struct Plan {
 struct Variant {
     int tapsA, tapsB;
 };
-constexpr Variant kVariants[] = {{48, 16}, {72, 24}};
+constexpr Variant kVariants[] = {{48, 16}, {72, 32}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 template <int TA, int TB, bool GENERAL, int SHIFT>
@@ -583,7 +691,7 @@ extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *str
         case 0:
             return launch<48, 16>(p, a, stream);
         case 1:
-            return launch<72, 24>(p, a, stream);
+            return launch<72, 32>(p, a, stream);
         default:
             return AFX_ERR_UNSUPPORTED;
     }

@@ -34,18 +34,18 @@ void afx_bandplan_free(AfxBandPlan *p) {
 }
 
 /* ---- LDS-bank-aware lane assignment ------------------------------------------
- * In the kernel every lane reads P[start_lane + t] for t = 0,1,2,... with one
- * ds_read per tap; a 32-lane half-wave is conflict-free exactly when its 32
- * start addresses are distinct mod 32 (LDS has 32 dword banks for ds_read_b32).
- * A row may start up to `d` bins early (leading zero weights) to land on a free
- * residue.  Rows are matched to the 64 (half, residue) slots so that the
+ * In the kernel every lane reads the pairs P[start_lane + 2t .. +1], t = 0,1,2,...
+ * with one ds_read_b64 per pair (start_lane even); ds_read_b64 sees 64 dword
+ * banks, so a 32-lane half-wave is conflict-free exactly when its 32 values of
+ * start/2 are distinct mod 32.  A row may start up to `d` bins early (leading
+ * zero weights) to land on a free residue.  Rows are matched to the 64 (half, residue) slots so that the
  * longest padded row, max(len + d), is as short as possible: bottleneck
  * assignment by binary search over the bound + Kuhn's augmenting-path matching
  * (64 x 64, plan time only). */
 static int shift_for(const RowBand *r, int residue) {
-    int d = (r->start - residue) % 32;
-    if (d < 0) d += 32;
-    return d; /* new start = start - d is congruent to residue */
+    int d = (r->start - 2 * residue) % 64;
+    if (d < 0) d += 64;
+    return d; /* new start = start - d is even and (start - d)/2 is congruent to residue mod 32 */
 }
 
 static int try_augment(int row, int n, const RowBand *rows, int bound, int *slotOwner, char *seen) {
@@ -82,7 +82,7 @@ static int assign_lanes(const RowBand *rows, int n, int *laneRow, int *laneShift
     for (int i = 0; i < n; i++) {
         if (rows[i].len > lo) lo = rows[i].len;
     }
-    hi = lo + 31;
+    hi = lo + 63;
     if (!match_with_bound(rows, n, hi, slotOwner)) {
         /* cannot happen (a shift of < 32 always exists unless start is tiny and
          * residues clash); fall back to identity placement, conflicts allowed */
@@ -148,8 +148,8 @@ int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p) {
         p->rowA[l] = p->rowB[l] = -1;
         /* idle lanes still execute the reads: give them their own residue so they
          * do not collide with a working lane of the same half */
-        p->startA[l] = l & 31;
-        p->startB[l] = l & 31;
+        p->startA[l] = 2 * (l & 31);
+        p->startB[l] = 2 * (l & 31);
         if (laneRowA[l] >= 0) {
             const RowBand *r = &rb[laneRowA[l]];
             const int d = laneShiftA[l];

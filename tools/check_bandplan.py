@@ -9,7 +9,7 @@ for (num,N,sr) in [(128,2048,16000),(128,2048,32000),(80,2048,16000),(64,2048,16
     b=Band()
     rc=lib.afx_bandplan_build(bank.ctypes.data_as(C.POINTER(C.c_float)),num,F,C.byref(b))
     sA=np.array(b.startA); sB=np.array(b.startB); rA=np.array(b.rowA); rB=np.array(b.rowB)
-    okA=all(len(set(sA[h*32:(h+1)*32]%32))==32 for h in range(2)); okB=all(len(set(sB[h*32:(h+1)*32]%32))==32 for h in range(2))
+    okA=all(len(set((sA[h*32:(h+1)*32]//2)%32))==32 for h in range(2)) and (sA%2==0).all(); okB=all(len(set((sB[h*32:(h+1)*32]//2)%32))==32 for h in range(2)) and (sB%2==0).all()
     # reconstruct bank from plan
     wA=np.ctypeslib.as_array(b.wA,(b.tapsA,64)); wB=np.ctypeslib.as_array(b.wB,(b.tapsB,64))
     rec=np.zeros_like(bank)
