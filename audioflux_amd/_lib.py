@@ -26,6 +26,28 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def _share_torch_hip_runtime():
+    """One process must hold ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64.so (SONAME libamdhip64.so.7, same as /opt/rocm's, which our library
+    links).  If both copies get loaded, whichever initialises second sees "no
+    ROCm-capable device" and device pointers could not be shared anyway.  So when torch
+    is installed, map its copy first: our DT_NEEDED libamdhip64.so.7 then resolves to
+    the already-loaded object by SONAME, and torch finds the same file later.
+    AFX_HIP_RUNTIME=system skips this (pure C/ctypes deployments without torch)."""
+    if os.environ.get("AFX_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def get_lib():
     global _lib
     if _lib is None:
@@ -33,6 +55,7 @@ def get_lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: run `make -C audioflux_amd/csrc` "
                 "(or __graft_entry__.build()); there is no fallback implementation")
+        _share_torch_hip_runtime()
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.afx_last_error.restype = ctypes.c_char_p
         _lib.afx_version.restype = ctypes.c_char_p

@@ -14,6 +14,7 @@ namespace {
 thread_local char g_err[512] = "";
 std::once_flag g_once;
 int g_init_status = AFX_ERR_NODEVICE;
+char g_init_why[256] = "HIP runtime not initialised";
 }  // namespace
 
 extern "C" void afxdev_set_error(const char *fmt, ...) {
@@ -31,6 +32,7 @@ extern "C" int afxdev_ensure(void) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || n <= 0) {
+            snprintf(g_init_why, sizeof(g_init_why), "hipGetDeviceCount: %s, %d device(s)", hipGetErrorString(e), n);
             g_init_status = AFX_ERR_NODEVICE;
             return;
         }
@@ -39,6 +41,7 @@ extern "C" int afxdev_ensure(void) {
         if (dev < 0 || dev >= n) dev = 0;
         e = hipSetDevice(dev);
         if (e != hipSuccess) {
+            snprintf(g_init_why, sizeof(g_init_why), "hipSetDevice(%d): %s", dev, hipGetErrorString(e));
             g_init_status = AFX_ERR_NODEVICE;
             return;
         }
@@ -46,8 +49,8 @@ extern "C" int afxdev_ensure(void) {
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
             if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
                 // kernels are built for gfx950 only; anything else cannot run them
-                fprintf(stderr, "[audioflux_mi355x] device %d is %s, this library targets gfx950 (MI355X)\n",
-                        dev, prop.gcnArchName);
+                snprintf(g_init_why, sizeof(g_init_why), "device %d is %s, this library targets gfx950", dev,
+                         prop.gcnArchName);
                 g_init_status = AFX_ERR_NODEVICE;
                 return;
             }
@@ -55,7 +58,7 @@ extern "C" int afxdev_ensure(void) {
         g_init_status = AFX_OK;
     });
     if (g_init_status != AFX_OK) {
-        afxdev_set_error("no usable MI355X (gfx950) HIP device: this backend has no CPU fallback");
+        afxdev_set_error("no usable MI355X (gfx950) HIP device (%s): this backend has no CPU fallback", g_init_why);
     }
     return g_init_status;
 }

@@ -84,3 +84,19 @@ def test_product_does_not_import_oracle():
         if os.path.isfile(path) and path.endswith((".py", ".c", ".h", ".hip", "Makefile")):
             src = open(path, errors="replace").read()
             assert "oracle" not in src.replace("no oracle", ""), f"{path} mentions the oracle"
+
+
+def test_single_hip_runtime_in_process():
+    """The loader maps torch's bundled libamdhip64 first so that the process holds ONE
+    HIP runtime whichever of {our library, torch} is imported or initialised first
+    (two copies => the second to initialise reports "no ROCm-capable device")."""
+    import subprocess
+    import sys
+    code = (
+        "import audioflux_amd as af; af.get_lib(); import torch; torch.cuda.is_available()\n"
+        "s=set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)\n"
+        "print(len(s))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
