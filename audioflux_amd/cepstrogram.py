@@ -1,7 +1,7 @@
 """Cepstrogram -- ctypes mirror of python/audioflux/cepstrogram.py:81-189 over
 libaudioflux_mi355x.so."""
 import ctypes
-from ctypes import POINTER, c_int, c_void_p
+from ctypes import POINTER, c_int, c_longlong, c_void_p
 
 import numpy as np
 
@@ -48,6 +48,25 @@ class Cepstrogram:
                _util.fptr(outs[1][i]), _util.fptr(outs[2][i]))
         return tuple(np.ascontiguousarray(np.swapaxes(_util.restore_leading(o, lead), -1, -2))
                      for o in outs)
+
+    def cepstrogram_device(self, x, cep_num=4, stream=None):
+        """Additive (cepstrogramObj_cepstrogramBatchDevice): x HIP torch.float32 (clips, n) ->
+        three torch tensors (clips, time, fft_length/2+1), time-major."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        b, n = x.shape
+        t = self.cal_time_length(n)
+        f = self.fft_length // 2 + 1
+        outs = [torch.empty((b, t, f), dtype=torch.float32, device=x.device) for _ in range(3)]
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        fn = self._lib.cepstrogramObj_cepstrogramBatchDevice
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p,
+                       c_void_p, c_void_p]
+        _lib.check(fn(self._obj, int(cep_num), x.data_ptr(), b, n, x.stride(0), outs[0].data_ptr(),
+                      outs[1].data_ptr(), outs[2].data_ptr(), s.cuda_stream),
+                   "cepstrogramObj_cepstrogramBatchDevice")
+        return tuple(outs)
 
     def y_coords(self):
         return np.linspace(0, self.samplate / 2, self.fft_length // 2 + 1 + 1)

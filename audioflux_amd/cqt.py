@@ -1,7 +1,7 @@
 """CQT -- ctypes mirror of python/audioflux/cqt.py (CQTBase :20-222, CQT :600-660)
 over libaudioflux_mi355x.so: constant-Q transform, CQT-chroma and CQCC."""
 import ctypes
-from ctypes import POINTER, c_float, c_int, c_void_p
+from ctypes import POINTER, c_float, c_int, c_longlong, c_void_p
 
 import numpy as np
 
@@ -93,6 +93,46 @@ class CQT:
             fn(self._obj, _util.opt_int(chroma_num), _util.opt_int(int(data_type)),
                _util.opt_int(int(norm_type)), _util.fptr(re), _util.fptr(im), _util.fptr(out[i]))
         return np.ascontiguousarray(np.swapaxes(_util.restore_leading(out, lead), -1, -2))
+
+    def cqt_device(self, x, out_real=None, out_imag=None, stream=None):
+        """Additive (include/afx_batch.h: cqtObj_cqtBatchDevice): x is a HIP torch.float32
+        tensor (clips, n), contiguous rows -> (real, imag) torch tensors (clips, time, num),
+        time-major as the library writes them; asynchronous on `stream`."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        b, n = x.shape
+        t = self.cal_time_length(n)
+        if out_real is None:
+            out_real = torch.empty((b, t, self.num), dtype=torch.float32, device=x.device)
+        if out_imag is None:
+            out_imag = torch.empty_like(out_real)
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        fn = self._lib.cqtObj_cqtBatchDevice
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]
+        _lib.check(fn(self._obj, x.data_ptr(), b, n, x.stride(0), out_real.data_ptr(),
+                      out_imag.data_ptr(), s.cuda_stream), "cqtObj_cqtBatchDevice")
+        return out_real, out_imag
+
+    def chroma_device(self, real, imag, chroma_num=12, data_type=SpectralDataType.POWER,
+                      norm_type=ChromaDataNormalType.MAX, out=None, stream=None):
+        """Additive (cqtObj_chromaBatchDevice): real/imag (..., time, num) HIP tensors from
+        cqt_device -> (..., time, chroma_num)."""
+        import torch
+        assert real.is_cuda and real.is_contiguous() and imag.is_contiguous()
+        assert real.shape == imag.shape and real.shape[-1] == self.num
+        rows = real.numel() // self.num
+        if out is None:
+            out = torch.empty(real.shape[:-1] + (chroma_num,), dtype=torch.float32, device=real.device)
+        s = stream if stream is not None else torch.cuda.current_stream(real.device)
+        fn = self._lib.cqtObj_chromaBatchDevice
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_void_p, c_void_p,
+                       c_longlong, c_void_p, c_void_p]
+        _lib.check(fn(self._obj, _util.opt_int(chroma_num), _util.opt_int(int(data_type)),
+                      _util.opt_int(int(norm_type)), real.data_ptr(), imag.data_ptr(), rows,
+                      out.data_ptr(), s.cuda_stream), "cqtObj_chromaBatchDevice")
+        return out
 
     def cqcc(self, m_data_arr, cc_num=13, rectify_type=CepstralRectifyType.LOG):
         """real (..., num, time) magnitudes of the LAST cqt call -> (..., cc_num, time)"""

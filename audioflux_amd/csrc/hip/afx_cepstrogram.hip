@@ -50,7 +50,10 @@ __global__ void k_cepstrogram(AfxCepstrogramArgs a) {
 
     // 1. spectrum of the windowed frame (or the cached spectrum: cepstrogram2)
     if (a.x) {
-        const float *x = a.x + frame * (long long)a.hop;
+        const float *x = a.framesPerClip > 0
+                             ? a.x + (frame / a.framesPerClip) * a.clipStride +
+                                   (frame % a.framesPerClip) * (long long)a.hop
+                             : a.x + frame * (long long)a.hop;
         for (int i = tid; i < N; i += nth) s[i] = make_float2(x[i] * a.window[i], 0.f);
         __syncthreads();
         fft_dif(s, r, tw, tid, nth);

@@ -15,6 +15,8 @@
 //                  (__mnormalize, src/vector/flux_vector.c:1058-1160), cqt_algorithm.c:542-592.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 
@@ -30,12 +32,15 @@ __global__ void k_cqt_octave(AfxCqtOctaveArgs a) {
     const int tid = threadIdx.x, nth = blockDim.x;
     const long long frame = blockIdx.x;
     const long long start = frame * (long long)a.hop - (N >> 1);
+    const float *x = a.x + (long long)blockIdx.y * a.xStride;
+    float *outRe = a.outRe + (long long)blockIdx.y * a.outStride;
+    float *outIm = a.outIm + (long long)blockIdx.y * a.outStride;
 
     // frame of the zero-padded signal (rect window; samples past validLength are dropped by
     // the reference's padded framing, src/stft_algorithm.c:650-653)
     for (int i = tid; i < N; i += nth) {
         const long long p = start + i;
-        const float v = (p >= 0 && p < a.validLength) ? a.x[p] : 0.f;
+        const float v = (p >= 0 && p < a.validLength) ? x[p] : 0.f;
         s[i] = make_float2(v, 0.f);
     }
     __syncthreads();
@@ -65,8 +70,185 @@ __global__ void k_cqt_octave(AfxCqtOctaveArgs a) {
             im += sv.y * kv.x + sv.x * kv.y;
         }
         const float sl = a.scale[a.colBase + j];  // sqrt(len_j), or 1 when scaling is off
-        a.outRe[frame * a.num + a.colBase + j] = (re * a.octScale) / sl;
-        a.outIm[frame * a.num + a.colBase + j] = (im * a.octScale) / sl;
+        outRe[frame * a.num + a.colBase + j] = (re * a.octScale) / sl;
+        outIm[frame * a.num + a.colBase + j] = (im * a.octScale) / sl;
+    }
+}
+
+
+// ---- matrix-core path -----------------------------------------------------------------
+// Q[t][j] = sum_n x_t[n] G_j[n]: the octave's frames (a Toeplitz view of the signal) times the
+// time-domain image G of the thresholded spectral kernels (AfxCqtOctaveArgs::timeKernel) --
+// the same linear map as FFT + sparse spectral product, as one [32 frames] x [N] x [2*rows]
+// product per workgroup on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate).
+//
+// Workgroup = N/128 waves, all on the same 32 consecutive frames; wave w owns the k range
+// [128 w, 128 w + 128): its slice of G (64 MFMA steps x CT column tiles) stays in VGPRs for
+// the life of the workgroup, the frames come from a zero-filled LDS copy of the signal
+// window (A operand: lane (i = lane&31, kk = lane>>5) reads sample (t0+i) hop + k + kk; the
+// copy is skewed by one word per 2^SH samples, hop = odd * 2^SH, so the 32 frames of a read
+// fall on 32 distinct banks).  The waves' partial tiles are summed through LDS.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CQ_KS = 64;  // MFMA steps per wave (2 samples each)
+
+template <int CT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_cqt_octave_mfma(AfxCqtOctaveArgs a, int tilesPerClip,
+                                                                int SH, int sigWords, int PRE) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sig = reinterpret_cast<float *>(smem_raw);
+    float *red = sig + sigWords;  // [waves][16][64]
+    const int N = 1 << a.radix2Exp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int nth = 64 * WAVES;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: k offsets stay on the SALU
+    const int i = lane & 31, kk = lane >> 5;
+    const int cols = CT * 32;
+
+    // this wave's slice of G: B operand of step ks is G[k = 128 wave + 2 ks + kk][j = lane & 31]
+    float breg[CT][CQ_KS];
+    {
+        const float *g = a.timeKernel + (long long)(128 * wave + kk) * cols + i;
+#pragma unroll
+        for (int ks = 0; ks < CQ_KS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) breg[ct][ks] = g[(long long)(2 * ks) * cols + ct * 32];
+    }
+    // output column owned by this lane in each column tile (re block | im block)
+    bool colOk[CT], colIm[CT];
+    int colOff[CT];
+    float colScale[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = ct * 32 + i;
+        colOk[ct] = col < 2 * a.rows;
+        colIm[ct] = col >= a.rows;
+        const int j = colIm[ct] ? col - a.rows : col;
+        colOff[ct] = a.colBase + (colOk[ct] ? j : 0);
+        colScale[ct] = a.scale[colOff[ct]];  // sqrt(len_j), or 1 when scaling is off
+    }
+    const int S = 31 * a.hop + N;  // samples of the signal window of one tile
+    const int ih = i * a.hop;
+    const int laneBase = SH ? ih + (ih >> SH) + kk : 2 * (ih + kk);
+
+    // persistent workgroups: tile g = (clip, 32-frame block), g = blockIdx.x, += gridDim.x
+    const int totalTiles = tilesPerClip * a.batch;
+    // PRE: the window of the NEXT tile is fetched into registers (float4, 16-byte aligned by
+    // construction: t0 hop and N/2 are multiples of 4) while this tile's MFMAs run
+    constexpr int NV = 5;
+    float4 wnd[NV];
+    auto fetch = [&](int g) {
+        const int clip = g / tilesPerClip, t0 = (g - clip * tilesPerClip) * 32;
+        const float *x = a.x + (long long)clip * a.xStride;
+        const long long p0 = (long long)t0 * a.hop - (N >> 1);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int s = 4 * (tid + u * nth);
+            const long long p = p0 + s;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s < S) {
+                if (p >= 0 && p + 3 < a.validLength) {
+                    v = *reinterpret_cast<const float4 *>(x + p);
+                } else {
+                    if (p >= 0 && p < a.validLength) v.x = x[p];
+                    if (p + 1 >= 0 && p + 1 < a.validLength) v.y = x[p + 1];
+                    if (p + 2 >= 0 && p + 2 < a.validLength) v.z = x[p + 2];
+                    if (p + 3 >= 0 && p + 3 < a.validLength) v.w = x[p + 3];
+                }
+            }
+            wnd[u] = v;
+        }
+    };
+    auto skew = [&](int s) { return SH ? s + (s >> SH) : 2 * s; };
+    if (PRE && (int)blockIdx.x < totalTiles) fetch(blockIdx.x);
+    for (int g = blockIdx.x; g < totalTiles; g += gridDim.x) {
+        const int clip = g / tilesPerClip, t0 = (g - clip * tilesPerClip) * 32;
+        const float *x = a.x + (long long)clip * a.xStride;
+        float *outRe = a.outRe + (long long)clip * a.outStride;
+        float *outIm = a.outIm + (long long)clip * a.outStride;
+        // zero-filled, skewed copy of the window (src/stft_algorithm.c:650-653: samples past
+        // validLength are dropped by the reference's padded framing)
+        if (PRE) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int s = 4 * (tid + u * nth);
+                if (s < S) {  // up to 3 samples past S land in the buffer's slack
+                    const float4 v = wnd[u];
+                    sig[skew(s)] = v.x;
+                    sig[skew(s + 1)] = v.y;
+                    sig[skew(s + 2)] = v.z;
+                    sig[skew(s + 3)] = v.w;
+                }
+            }
+            __syncthreads();
+            if (g + (int)gridDim.x < totalTiles) fetch(g + gridDim.x);
+        } else {
+            const long long p0 = (long long)t0 * a.hop - (N >> 1);
+            // (eight independent loads in flight per thread: one load per trip would serialise
+            // the whole window on memory latency)
+            for (int sb = tid; sb < S; sb += 8 * nth) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = sb + u * nth;
+                    const long long p = p0 + s;
+                    v[u] = (s < S && p >= 0 && p < a.validLength) ? x[p] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = sb + u * nth;
+                    if (s < S) sig[skew(s)] = v[u];
+                }
+            }
+            __syncthreads();
+        }
+
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        const int kBase = 128 * wave;
+        // opaque every 8 steps: otherwise the 64 loop-invariant read addresses are formed up
+        // front into 64 resident VGPRs (occupancy); one v_add per MFMA is free
+        int lb = laneBase;
+#pragma unroll
+        for (int ks = 0; ks < CQ_KS; ++ks) {
+            if ((ks & 7) == 0) asm volatile("" : "+v"(lb));
+            const int k0 = kBase + 2 * ks;                       // wave-uniform
+            const int off = SH ? k0 + (k0 >> SH) : 2 * k0;
+            const float av = sig[lb + off];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[ct][ks], acc[ct], 0, 0, 0);
+        }
+
+        // sum the waves' partial tiles; D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[ct][r];
+            __syncthreads();
+            // thread (wave, lane) sums the 16/WAVES accumulator registers r = wave + q WAVES
+            float part[16 / WAVES];
+#pragma unroll
+            for (int q = 0; q < 16 / WAVES; ++q) {
+                const int r = wave + q * WAVES;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) v += red[(w * 16 + r) * 64 + lane];
+                part[q] = v;
+            }
+            if (colOk[ct]) {
+#pragma unroll
+                for (int q = 0; q < 16 / WAVES; ++q) {
+                    const int r = wave + q * WAVES;
+                    const long long frame = t0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (frame < a.timeLength)
+                        (colIm[ct] ? outIm : outRe)[frame * a.num + colOff[ct]] = (part[q] * a.octScale) / colScale[ct];
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -74,68 +256,177 @@ struct Taps32 {
     float h[32];
 };
 
-__global__ void k_cqt_decimate(const float *__restrict__ x, int srcLen, float *__restrict__ y,
-                               int dstLen, Taps32 tp, float sqrtRatio) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= dstLen) return;
-    const int n = 2 * i;
-    float acc = 0.f;
-    int left = n + 1 < 32 ? n + 1 : 32;
-#pragma unroll 8
-    for (int j = 0; j < left; ++j) acc += tp.h[j] * x[n - j];
-    int right = srcLen - n - 1;
-    if (right > 31) right = 31;
-#pragma unroll 8
-    for (int j = 0; j < right; ++j) acc += tp.h[j + 1] * x[n + j + 1];
-    y[i] = acc / sqrtRatio;
+// 1024 outputs per workgroup, 4 consecutive outputs per thread.  The input window is staged
+// in LDS split into even and odd samples (XE[k] = x[2 (i0-16+k)], XO[k] = x[2 (i0-16+k) + 1],
+// zero outside the signal: a dropped tap and a zero tap add the same), so that x[2i -/+ j] for
+// consecutive outputs are consecutive words and each thread gets its 36 + 36 operands with 18
+// ds_read_b128.  Taps are applied in the reference's order (left taps j = 0..31 at x[2i - j],
+// then right taps j = 1..31 at x[2i + j]) as one fma chain.
+constexpr int DEC_OUT = 1024, DEC_LDS = DEC_OUT + 40;
+
+__global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ x, int srcLen,
+                                                      long long xStride, float *__restrict__ y,
+                                                      int dstLen, long long yStride, Taps32 tp,
+                                                      float sqrtRatio) {
+    __shared__ __attribute__((aligned(16))) float XE[DEC_LDS];
+    __shared__ __attribute__((aligned(16))) float XO[DEC_LDS];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * DEC_OUT;
+    x += (long long)blockIdx.y * xStride;
+    y += (long long)blockIdx.y * yStride;
+    for (int k = tid; k < DEC_LDS; k += 256) {
+        const long long s = 2LL * (i0 - 16 + k);
+        XE[k] = (s >= 0 && s < srcLen) ? x[s] : 0.f;
+        XO[k] = (s + 1 >= 0 && s + 1 < srcLen) ? x[s + 1] : 0.f;
+    }
+    __syncthreads();
+    // outputs i = i0 + 4 tid + q; LDS index of x[2 (i + d)] is 4 tid + q + d + 16
+    float E[36], O[36];
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+        const float4 e = *reinterpret_cast<const float4 *>(&XE[4 * tid + 4 * b]);
+        const float4 o = *reinterpret_cast<const float4 *>(&XO[4 * tid + 4 * b]);
+        E[4 * b] = e.x; E[4 * b + 1] = e.y; E[4 * b + 2] = e.z; E[4 * b + 3] = e.w;
+        O[4 * b] = o.x; O[4 * b + 1] = o.y; O[4 * b + 2] = o.z; O[4 * b + 3] = o.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = i0 + 4 * tid + q;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {  // x[2i - j]: even j -> XE[i - j/2], odd j -> XO[i - (j+1)/2]
+            const float v = (j & 1) ? O[q + 16 - (j + 1) / 2] : E[q + 16 - j / 2];
+            acc = __fmaf_rn(tp.h[j], v, acc);
+        }
+#pragma unroll
+        for (int j = 1; j < 32; ++j) {  // x[2i + j]: even j -> XE[i + j/2], odd j -> XO[i + (j-1)/2]
+            const float v = (j & 1) ? O[q + 16 + (j - 1) / 2] : E[q + 16 + j / 2];
+            acc = __fmaf_rn(tp.h[j], v, acc);
+        }
+        if (i < dstLen) y[i] = acc / sqrtRatio;
+    }
 }
 
-__global__ void k_cqt_chroma(const float *__restrict__ re, const float *__restrict__ im,
-                             long long rows, int num, const unsigned char *__restrict__ fold,
-                             int chromaNum, int isMag, int normType, float *__restrict__ out) {
-    // one thread per (frame): chromaNum <= 48 accumulators in registers would need static
-    // indexing; use one thread per (frame, chroma bin) with a wave-local normalisation instead
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long frame = gid / 64;
-    const int c = (int)(gid & 63);
-    if (frame >= rows) return;
-    float v = 0.f;
-    if (c < chromaNum) {
-        const float *pr = re + frame * num, *pi = im + frame * num;
-        const unsigned char *f = fold + (long long)c * num;
-        for (int j = 0; j < num; ++j) {
-            if (f[j]) {
-                float p = pr[j] * pr[j] + pi[j] * pi[j];
-                if (isMag) p = sqrtf(p);
-                v += p;
+constexpr int CH_FRAMES = 64;  // frames per workgroup
+
+// |Q|^2 (or |Q|) of CH_FRAMES frames is staged in LDS with fully coalesced loads, every
+// (frame, chroma bin) pair then folds its bins in ascending order (the 0/1 matrix product of
+// cqt_algorithm.c:553-560) and the frame's chroma vector is normalised in place.
+__global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re,
+                                                    const float *__restrict__ im, long long rows,
+                                                    int num, const unsigned char *__restrict__ fold,
+                                                    int chromaNum, int isMag, int normType,
+                                                    float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *p = reinterpret_cast<float *>(smem_raw);          // [CH_FRAMES][num]
+    float *cv = p + CH_FRAMES * num;                          // [CH_FRAMES][chromaNum]
+    float *nrm = cv + CH_FRAMES * chromaNum;                  // [CH_FRAMES]
+    unsigned char *fl = reinterpret_cast<unsigned char *>(nrm + CH_FRAMES);  // [chromaNum][num]
+    const int tid = threadIdx.x;
+    const long long f0 = (long long)blockIdx.x * CH_FRAMES;
+    const int nf = rows - f0 < CH_FRAMES ? (int)(rows - f0) : CH_FRAMES;
+    const float *pr = re + f0 * num, *pi = im + f0 * num;
+    for (int e = tid; e < nf * num; e += 256) {
+        const float a = pr[e], b = pi[e];
+        // explicit fma: left to the compiler, the unrolled body and the remainder of this loop
+        // contract differently and the value of a frame depends on its position in the batch
+        float v = __fmaf_rn(a, a, b * b);
+        if (isMag) v = sqrtf(v);
+        p[e] = v;
+    }
+    for (int e = tid; e < chromaNum * num; e += 256) fl[e] = fold[e];
+    __syncthreads();
+    for (int it = tid; it < nf * chromaNum; it += 256) {
+        const int f = it / chromaNum, c = it - f * chromaNum;
+        const float *row = p + f * num;
+        const unsigned char *fr = fl + c * num;
+        float v = 0.f;
+        for (int j = 0; j < num; ++j)
+            if (fr[j]) v += row[j];
+        cv[it] = v;
+    }
+    __syncthreads();
+    if (normType != 0) {  // 1 max, 2 min, 3 P2, 4 P1 over the frame's chroma vector (__mnormalize)
+        if (tid < nf) {
+            const float *c = cv + tid * chromaNum;
+            float red = normType == 2 ? 3.4e38f : 0.f;
+            for (int k = 0; k < chromaNum; ++k) {
+                const float av = fabsf(c[k]);
+                if (normType == 1) red = fmaxf(red, av);
+                else if (normType == 2) red = fminf(red, av);
+                else if (normType == 3) red += av * av;
+                else red += av;
             }
-        }
-    }
-    if (normType != 0) {  // 1 max, 2 min, 3 P2, 4 P1 over the frame's chroma vector
-        const float av = fabsf(v);
-        float red;
-        if (normType == 1) {
-            red = (c < chromaNum) ? av : 0.f;
-            for (int off = 32; off > 0; off >>= 1) red = fmaxf(red, __shfl_xor(red, off, 64));
-        } else if (normType == 2) {
-            red = (c < chromaNum) ? av : 3.4e38f;
-            for (int off = 32; off > 0; off >>= 1) red = fminf(red, __shfl_xor(red, off, 64));
-        } else {
-            red = (c < chromaNum) ? (normType == 3 ? av * av : av) : 0.f;
-            for (int off = 32; off > 0; off >>= 1) red += __shfl_xor(red, off, 64);
             if (normType == 3) red = sqrtf(red);
+            nrm[tid] = red;
         }
-        if (red != 0.f) v = v / red;
+        __syncthreads();
     }
-    if (c < chromaNum) out[frame * chromaNum + c] = v;
+    float *po = out + f0 * chromaNum;
+    for (int it = tid; it < nf * chromaNum; it += 256) {
+        float v = cv[it];
+        if (normType != 0) {
+            const float red = nrm[it / chromaNum];
+            if (red != 0.f) v = v / red;
+        }
+        po[it] = v;
+    }
 }
 
 }  // namespace
+
+
+template <int CT, int WAVES>
+static int launch_cqt_mfma(const AfxCqtOctaveArgs *a, void *stream) {
+    const int N = 1 << a->radix2Exp;
+    int SH = 0;
+    while (SH < 30 && !((a->hop >> SH) & 1)) ++SH;           // hop = odd * 2^SH
+    const int S = 31 * a->hop + N;
+    const int sigWords = ((SH ? S + (S >> SH) : 2 * S) + 67) & ~3;
+    const size_t lds = sizeof(float) * ((size_t)sigWords + (size_t)WAVES * 16 * 64);
+    if (lds > 150 * 1024) return AFX_ERR_UNSUPPORTED;
+    const void *fn = reinterpret_cast<const void *>(k_cqt_octave_mfma<CT, WAVES>);
+    if (lds > 48 * 1024) AFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tilesPerClip = (a->timeLength + 31) / 32;
+    const long long total = (long long)tilesPerClip * (a->batch > 0 ? a->batch : 1);
+    if (total > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+    // register prefetch of the next window needs 16-byte aligned rows and <= 5 float4 per thread
+    const int pre = (reinterpret_cast<uintptr_t>(a->x) % 16 == 0) && (a->xStride % 4 == 0) &&
+                    S <= 4 * 5 * (N / 2);
+    // persistent workgroups (each keeps its slice of G in registers): two rounds of the 256 CUs
+    const unsigned grid = (unsigned)(total < 512 ? total : 512);
+    AfxCqtOctaveArgs b = *a;
+    if (b.batch <= 0) b.batch = 1;
+    hipLaunchKernelGGL((k_cqt_octave_mfma<CT, WAVES>), dim3(grid), dim3(64 * WAVES), lds,
+                       (hipStream_t)stream, b, tilesPerClip, SH, sigWords, pre);
+    AFX_LAUNCH_CHECK("k_cqt_octave_mfma");
+    return AFX_OK;
+}
+
+template <int CT>
+static int dispatch_cqt_mfma(const AfxCqtOctaveArgs *a, void *stream) {
+    // the wave's slice of G lives in VGPRs (64 x CT), which caps the workgroup size (N/2 threads)
+    switch (1 << a->radix2Exp) {
+        case 256: return launch_cqt_mfma<CT, 2>(a, stream);
+        case 512: return launch_cqt_mfma<CT, 4>(a, stream);
+        case 1024: if (CT <= 2) return launch_cqt_mfma<CT, (CT <= 2 ? 8 : 4)>(a, stream); break;
+        case 2048: if (CT == 1) return launch_cqt_mfma<CT, (CT == 1 ? 16 : 4)>(a, stream); break;
+        default: break;
+    }
+    return AFX_ERR_UNSUPPORTED;
+}
 
 extern "C" int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream) {
     if (a->radix2Exp < 1 || a->radix2Exp > 14) return AFX_ERR_UNSUPPORTED;
     if (a->timeLength <= 0) return AFX_OK;
     const int N = 1 << a->radix2Exp;
+    if (a->timeKernel && a->colTiles >= 1 && a->colTiles <= 3) {
+        int st = AFX_ERR_UNSUPPORTED;
+        if (a->colTiles == 1) st = dispatch_cqt_mfma<1>(a, stream);
+        else if (a->colTiles == 2) st = dispatch_cqt_mfma<2>(a, stream);
+        else st = dispatch_cqt_mfma<3>(a, stream);
+        if (st != AFX_ERR_UNSUPPORTED) return st;  // otherwise: FFT path below
+    }
     int threads = N / 2;
     if (threads < 64) threads = 64;
     if (threads > 256) threads = 256;
@@ -144,19 +435,21 @@ extern "C" int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream) {
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_octave),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(k_cqt_octave, dim3((unsigned)a->timeLength), dim3(threads), lds,
+    hipLaunchKernelGGL(k_cqt_octave, dim3((unsigned)a->timeLength, (unsigned)(a->batch > 0 ? a->batch : 1)), dim3(threads), lds,
                        (hipStream_t)stream, *a);
     AFX_LAUNCH_CHECK("k_cqt_octave");
     return AFX_OK;
 }
 
-extern "C" int afxk_cqt_decimate(const float *x, int srcLen, float *y, int dstLen,
-                                 const float *taps32, float sqrtRatio, void *stream) {
-    if (dstLen <= 0) return AFX_OK;
+extern "C" int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y,
+                                 int dstLen, long long yStride, int batch, const float *taps32,
+                                 float sqrtRatio, void *stream) {
+    if (dstLen <= 0 || batch <= 0) return AFX_OK;
     Taps32 tp;
     for (int i = 0; i < 32; ++i) tp.h[i] = taps32[i];
-    hipLaunchKernelGGL(k_cqt_decimate, dim3((unsigned)((dstLen + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, srcLen, y, dstLen, tp, sqrtRatio);
+    hipLaunchKernelGGL(k_cqt_decimate, dim3((unsigned)((dstLen + DEC_OUT - 1) / DEC_OUT), (unsigned)batch),
+                       dim3(256), 0, (hipStream_t)stream, x, srcLen, xStride, y, dstLen, yStride, tp,
+                       sqrtRatio);
     AFX_LAUNCH_CHECK("k_cqt_decimate");
     return AFX_OK;
 }
@@ -165,10 +458,14 @@ extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows,
                                const unsigned char *fold, int chromaNum, int isMag, int normType,
                                float *out, void *stream) {
     if (rows <= 0) return AFX_OK;
-    if (chromaNum > 64) return AFX_ERR_UNSUPPORTED;
-    const long long threads = rows * 64;
-    hipLaunchKernelGGL(k_cqt_chroma, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, re, im, rows, num, fold, chromaNum, isMag, normType, out);
+    const size_t lds = sizeof(float) * ((size_t)CH_FRAMES * num + (size_t)CH_FRAMES * chromaNum + CH_FRAMES) +
+                       (size_t)chromaNum * num;
+    if (lds > 150 * 1024) return AFX_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024)
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cqt_chroma, dim3((unsigned)((rows + CH_FRAMES - 1) / CH_FRAMES)), dim3(256),
+                       lds, (hipStream_t)stream, re, im, rows, num, fold, chromaNum, isMag, normType, out);
     AFX_LAUNCH_CHECK("k_cqt_chroma");
     return AFX_OK;
 }

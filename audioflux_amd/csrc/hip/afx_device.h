@@ -132,11 +132,19 @@ typedef struct {
     const float *scale;    /* device [num]: sqrt(len_j) (or 1 when scaling is off)    */
     float octScale;        /* sqrt(2^k) of the octave                                 */
     int num, colBase;      /* output row pitch / first output column of this octave   */
-    float *outRe, *outIm;  /* device [T, num]                                         */
+    float *outRe, *outIm;  /* device [batch][T, num]                                  */
+    int batch;             /* clips per launch (grid.y)                               */
+    long long xStride;     /* samples between consecutive clips in x                  */
+    long long outStride;   /* floats between consecutive clips in outRe/outIm         */
+    const float *timeKernel; /* device [N][colTiles*32] time-domain kernels of this octave,
+                              * columns [Re 0..rows-1 | Im 0..rows-1]; NULL: FFT path      */
+    int colTiles;
 } AfxCqtOctaveArgs;
 int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
-int afxk_cqt_decimate(const float *x, int srcLen, float *y, int dstLen, const float *taps32,
-                      float sqrtRatio, void *stream);
+/* batch clips: x + b*xStride -> y + b*yStride */
+int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, int dstLen,
+                      long long yStride, int batch, const float *taps32, float sqrtRatio,
+                      void *stream);
 int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
                     const unsigned char *fold, int chromaNum, int isMag, int normType, float *out,
                     void *stream);
@@ -150,6 +158,8 @@ typedef struct {
     float *specRe;       /* device [T,N] spectrum cache: written when x != NULL     */
     float *specIm;       /*   (may be NULL), read when x == NULL                    */
     float *out1, *out2, *out3; /* device [T, N/2+1]; any may be NULL                */
+    int framesPerClip;   /* > 0: timeLength counts the frames of several clips,      */
+    long long clipStride;/*      frame f starts at x + (f / fpc) * clipStride + (f % fpc) * hop */
 } AfxCepstrogramArgs;
 int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream);
 

@@ -120,6 +120,45 @@ static void run(CepstrogramObj o, int cepNum, const float *hData, int dataLength
     }
 }
 
+/* clips already in HBM -> dOut1/2/3 [batch][T, N/2+1] left in HBM (include/afx_batch.h);
+ * any output may be NULL.  The spectrum cache of cepstrogram2 is not touched. */
+int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj o, int cepNum, const float *dData,
+                                          int batch, int dataLength, long long clipStride,
+                                          float *dOut1, float *dOut2, float *dOut3,
+                                          void *hipStream) {
+    if (!o || !dData || batch <= 0 || dataLength <= 0 || clipStride < 0) {
+        afxdev_set_error("cepstrogramObj_cepstrogramBatchDevice: bad argument");
+        return AFX_ERR_ARG;
+    }
+    const int T = cepstrogramObj_calTimeLength(o, dataLength);
+    if (T <= 0) return AFX_OK;
+    if ((long long)T * batch > 2147483647LL) {
+        afxdev_set_error("cepstrogramObj_cepstrogramBatchDevice: more than 2^31-1 frames in one call");
+        return AFX_ERR_UNSUPPORTED;
+    }
+    AfxCepstrogramArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dData;
+    a.timeLength = T * batch;
+    a.framesPerClip = T;
+    a.clipStride = clipStride;
+    a.radix2Exp = o->radix2Exp;
+    a.hop = o->slideLength;
+    a.cepNum = cepNum < 0 ? 0 : cepNum;
+    a.window = o->dWindow;
+    a.twiddle = o->dTwiddle;
+    a.out1 = dOut1;
+    a.out2 = dOut2;
+    a.out3 = dOut3;
+    int st = afxk_cepstrogram(&a, hipStream);
+    if (st != AFX_OK) {
+        o->status = st;
+        fprintf(stderr, "[audioflux_mi355x] cepstrogramObj_cepstrogramBatchDevice failed (%d): %s\n", st,
+                afxdev_last_error());
+    }
+    return st;
+}
+
 void cepstrogramObj_cepstrogram(CepstrogramObj o, int cepNum, float *dataArr, int dataLength,
                                 float *mDataArr1, float *mDataArr2, float *mDataArr3) {
     if (!o) {

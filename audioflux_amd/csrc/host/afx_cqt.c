@@ -34,10 +34,16 @@ struct OpaqueCQT {
     void *stream;
     float *dTwiddle, *dKTaps, *dScaleOn, *dScaleOff;
     int *dKStart, *dKLen, *dKOff;
+    float *dTimeKernel;      /* [groups][N][colTiles*32]: time-domain image of the spectral kernels */
+    int colTiles;            /* 0: the matrix-core path is not available for this plan */
     unsigned char *dFold;
     int foldChromaNum;
-    float *dSig[2];          /* ping-pong octave signals */
+    float *dX;               /* staged input of the host-pointer calls */
+    size_t capX;
+    float *dSig[2];          /* ping-pong decimated signals, all clips of a batch */
     size_t capSig[2];
+    void *lastStream;        /* stream of the previous device call (scratch ordering) */
+    int lastUsed;
     float *dOut;             /* re | im [T,num] */
     size_t capOut;
     float *dIn;              /* chroma / cqcc staging */
@@ -241,6 +247,44 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
         total += kLen[i];
     }
 
+    /* ---- time-domain image of the thresholded spectral kernels, for the matrix-core path:
+     *      Q[t][j] = sum_k K_j[k] X_t[k] = sum_n x_t[n] G_j[n],  G_j[n] = sum_k K_j[k] e^{-2 pi i k n / N}
+     *      (exactly the same linear map; evaluated in double, rounded once).  Columns of a
+     *      group: [Re G_0 .. Re G_{bpo-1} | Im G_0 .. Im G_{bpo-1}], padded to 32*colTiles. */
+    float *timeKernel = NULL;
+    size_t timeKernelBytes = 0;
+    o->colTiles = 0;
+    if (N >= 256 && N <= 2048 && 2 * bpo <= 96 && !getenv("AFX_NO_FUSED")) {
+        const int ct = (2 * bpo + 31) / 32, cols = ct * 32;
+        const int groups = rowsTotal / bpo;
+        timeKernelBytes = sizeof(float) * (size_t)groups * N * cols;
+        timeKernel = (float *)calloc((size_t)groups * N * cols, sizeof(float));
+        double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+        if (timeKernel && cs) {
+            for (int m = 0; m < N; m++) {
+                cs[2 * m] = cos(2.0 * M_PI * m / N);
+                cs[2 * m + 1] = -sin(2.0 * M_PI * m / N);
+            }
+            for (int row = 0; row < rowsTotal; row++) {
+                const int g = row / bpo, j = row % bpo;
+                float *dst = timeKernel + (size_t)g * N * cols;
+                for (int n = 0; n < N; n++) {
+                    double re = 0, im = 0;
+                    for (int q = 0; q < kLen[row]; q++) {
+                        const double a = kTaps[2 * (kOff[row] + q)], b = kTaps[2 * (kOff[row] + q) + 1];
+                        const int m = (int)(((long long)(kStart[row] + q) * n) % N);
+                        re += a * cs[2 * m] - b * cs[2 * m + 1];
+                        im += a * cs[2 * m + 1] + b * cs[2 * m];
+                    }
+                    dst[(size_t)n * cols + j] = (float)re;
+                    dst[(size_t)n * cols + bpo + j] = (float)im;
+                }
+            }
+            o->colTiles = ct;
+        }
+        free(cs);
+    }
+
     /* ---- 2:1 resampler taps: h_j = 0.5 * rollOff*sinc(rollOff*j/2) * kaiser(j), j < 32
      *      (resample_algorithm.c:546-634 with zeroNum 16, nbit 9, beta 8.5555046, rollOff 0.85) */
     {
@@ -275,6 +319,9 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     UP(o->dKOff, kOff, sizeof(int) * (size_t)rowsTotal);
     UP(o->dScaleOn, o->sLenArr, sizeof(float) * (size_t)num);
     UP(o->dScaleOff, ones, sizeof(float) * (size_t)num);
+    if (o->colTiles) {
+        UP(o->dTimeKernel, timeKernel, timeKernelBytes);
+    }
 #undef UP
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     free(tw);
@@ -286,6 +333,7 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     free(kOff);
     free(kTaps);
     free(lenTop);
+    free(timeKernel);
     if (st != AFX_OK) {
         cqtObj_free(o);
         return st;
@@ -306,18 +354,21 @@ void cqtObj_setScale(CQTObj o, int flag) {
     if (o) o->isScale = flag;
 }
 
-void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float *mImageArr) {
-    if (!o) {
-        afxdev_set_error("cqtObj_cqt: NULL object");
-        return;
-    }
-    if (!dataArr || dataLength <= 0 || !mRealArr || !mImageArr) return;
+/* The octave recursion on HBM-resident clips: dX + b*xStride (b < batch, dataLength
+ * samples each) -> dRe/dIm [batch][T, num].  dSig[0/1] hold the decimated signals of all
+ * clips (pitch = dataLength/2 samples).  Asynchronous on `stream`. */
+static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, long long xStride,
+                          float *dRe, float *dIm, void *stream) {
     const int T = dataLength / o->slideLength + 1;
-    const size_t outB = sizeof(float) * (size_t)T * o->num;
-    int st = afxdev_reserve((void **)&o->dOut, &o->capOut, 2 * outB);
-    for (int i = 0; i < 2 && st == AFX_OK; i++)
-        st = afxdev_reserve((void **)&o->dSig[i], &o->capSig[i], sizeof(float) * (size_t)dataLength);
-    if (st == AFX_OK) st = afxdev_h2d(o->dSig[0], dataArr, sizeof(float) * (size_t)dataLength, o->stream);
+    const long long pitch = ((long long)dataLength / 2 + 3) & ~3LL;
+    int st = AFX_OK;
+    if (o->octaveNum > 1) {
+        /* buffer 0 holds the first decimation (pitch samples per clip), buffer 1 the second */
+        st = afxdev_reserve((void **)&o->dSig[0], &o->capSig[0], sizeof(float) * (size_t)pitch * batch);
+        if (st == AFX_OK && o->octaveNum > 2)
+            st = afxdev_reserve((void **)&o->dSig[1], &o->capSig[1], sizeof(float) * (size_t)pitch * batch);
+    }
+    if (st != AFX_OK) return st;
 
     AfxCqtOctaveArgs a;
     memset(&a, 0, sizeof(a));
@@ -331,33 +382,107 @@ void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float
     a.rows = o->binPerOctave;
     a.scale = o->isScale ? o->dScaleOn : o->dScaleOff;
     a.num = o->num;
-    a.outRe = o->dOut;
-    a.outIm = o->dOut + (size_t)T * o->num;
+    a.outRe = dRe;
+    a.outIm = dIm;
+    a.batch = batch;
+    a.outStride = (long long)T * o->num;
 
-    int cur = 0, len = dataLength, hop = o->slideLength;
+    const float *cur = dX;
+    long long curStride = xStride;
+    int nextBuf = 0, len = dataLength, hop = o->slideLength;
     for (int oct = o->octaveNum - 1; oct >= 0 && st == AFX_OK; oct--) {
         const int k = o->octaveNum - 1 - oct; /* decimations so far */
         const int frames = len / hop + 1;
-        a.x = o->dSig[cur];
+        a.x = cur;
+        a.xStride = curStride;
         a.hop = hop;
         a.validLength = len - (frames > 1 ? len % hop : 0); /* stft_algorithm.c:838-843 */
         a.rowBase = o->vFlag ? oct * o->binPerOctave : 0;
         a.colBase = oct * o->binPerOctave;
         a.octScale = k == 0 ? 1.f : sqrtf((float)(1 << k)); /* dLenArr, cqt_algorithm.c:1218-1221 */
-        st = afxk_cqt_octave(&a, o->stream);
+        a.colTiles = o->colTiles;
+        a.timeKernel = o->colTiles ? o->dTimeKernel + (size_t)(o->vFlag ? oct : 0) * o->fftLength * o->colTiles * 32
+                                   : NULL;
+        st = afxk_cqt_octave(&a, stream);
         if (st != AFX_OK || oct == 0) break;
         const int next = (int)floorf(len * 0.5f); /* resampleObj_calDataLength */
-        st = afxk_cqt_decimate(o->dSig[cur], len, o->dSig[cur ^ 1], next, o->taps, sqrtf(0.5f),
-                               o->stream);
-        cur ^= 1;
+        st = afxk_cqt_decimate(cur, len, curStride, o->dSig[nextBuf], next, pitch, batch, o->taps,
+                               sqrtf(0.5f), stream);
+        cur = o->dSig[nextBuf];
+        curStride = pitch;
+        nextBuf ^= 1;
         len = next;
         hop /= 2;
     }
-    if (st == AFX_OK) st = afxdev_d2h(mRealArr, a.outRe, outB, o->stream);
-    if (st == AFX_OK) st = afxdev_d2h(mImageArr, a.outIm, outB, o->stream);
+    return st;
+}
+
+void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float *mImageArr) {
+    if (!o) {
+        afxdev_set_error("cqtObj_cqt: NULL object");
+        return;
+    }
+    if (!dataArr || dataLength <= 0 || !mRealArr || !mImageArr) return;
+    const int T = dataLength / o->slideLength + 1;
+    const size_t outB = sizeof(float) * (size_t)T * o->num;
+    int st = AFX_OK;
+    if (o->lastUsed && o->lastStream != o->stream) st = afxdev_stream_sync(o->lastStream);
+    o->lastUsed = 0;
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dOut, &o->capOut, 2 * outB);
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dX, &o->capX, sizeof(float) * (size_t)dataLength);
+    if (st == AFX_OK) st = afxdev_h2d(o->dX, dataArr, sizeof(float) * (size_t)dataLength, o->stream);
+    float *dRe = o->dOut, *dIm = o->dOut + (size_t)T * o->num;
+    if (st == AFX_OK) st = cqt_run_device(o, o->dX, 1, dataLength, dataLength, dRe, dIm, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mRealArr, dRe, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mImageArr, dIm, outB, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     o->timeLength = T;
     if (st != AFX_OK) fail(o, st, "cqtObj_cqt");
+}
+
+/* clips already in HBM, results left in HBM (include/afx_batch.h) */
+int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLength,
+                          long long clipStride, float *dReal, float *dImag, void *hipStream) {
+    if (!o || !dData || !dReal || !dImag || batch <= 0 || dataLength <= 0 || clipStride < dataLength) {
+        afxdev_set_error("cqtObj_cqtBatchDevice: bad argument");
+        return AFX_ERR_ARG;
+    }
+    int st = AFX_OK;
+    const int T = dataLength / o->slideLength + 1;
+    /* scratch is shared between calls: order this call after the previous one's stream */
+    if (o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
+    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += 32768) {
+        const int nb = batch - b0 < 32768 ? batch - b0 : 32768;
+        st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride,
+                            dReal + (long long)b0 * T * o->num, dImag + (long long)b0 * T * o->num,
+                            hipStream);
+    }
+    o->lastStream = hipStream;
+    o->lastUsed = 1;
+    o->timeLength = T;
+    if (st != AFX_OK) fail(o, st, "cqtObj_cqtBatchDevice");
+    return st;
+}
+
+int cqtObj_cqtBatch(CQTObj o, const float *dataArr, int batch, int dataLength, float *mRealArr,
+                    float *mImageArr) {
+    if (!o || !dataArr || !mRealArr || !mImageArr || batch <= 0 || dataLength <= 0) {
+        afxdev_set_error("cqtObj_cqtBatch: bad argument");
+        return AFX_ERR_ARG;
+    }
+    const int T = dataLength / o->slideLength + 1;
+    const size_t inB = sizeof(float) * (size_t)batch * dataLength;
+    const size_t outB = sizeof(float) * (size_t)batch * T * o->num;
+    int st = afxdev_reserve((void **)&o->dOut, &o->capOut, 2 * outB);
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dX, &o->capX, inB);
+    if (st == AFX_OK) st = afxdev_h2d(o->dX, dataArr, inB, o->stream);
+    float *dRe = o->dOut, *dIm = o->dOut + (size_t)batch * T * o->num;
+    if (st == AFX_OK) st = cqtObj_cqtBatchDevice(o, o->dX, batch, dataLength, dataLength, dRe, dIm, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mRealArr, dRe, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mImageArr, dIm, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    if (st != AFX_OK) fail(o, st, "cqtObj_cqtBatch");
+    return st;
 }
 
 /* 0/1 folding matrix bins -> chroma (chroma_filterBank.c:176-264), host side */
@@ -396,13 +521,9 @@ static unsigned char *chroma_fold(int chromaNum, int num, int bpo, float minFre)
     return tmp;
 }
 
-void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
-                   ChromaDataNormalType *normType, float *mRealArr, float *mImageArr,
-                   float *mDataArr) {
-    if (!o) {
-        afxdev_set_error("cqtObj_chroma: NULL object");
-        return;
-    }
+/* resolve the optional chroma parameters; upload the folding matrix when chromaNum changed */
+static int chroma_prepare(CQTObj o, int *chromaNum, SpectralDataType *dataType,
+                          ChromaDataNormalType *normType, int *cnOut, int *isMag, int *nrmOut) {
     int cn = 12;
     SpectralDataType dt = SpectralData_Power;
     ChromaDataNormalType nt = ChromaDataNormal_Max;
@@ -411,13 +532,12 @@ void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
     if (normType) nt = *normType;
     if (cn <= 0 || cn > o->binPerOctave || o->binPerOctave % cn != 0) {
         printf("chromaNum and binPerOctave not map!!!");
-        return;
+        return AFX_ERR_ARG;
     }
-    const int T = o->timeLength;
-    if (T <= 0 || !mRealArr || !mImageArr || !mDataArr) return;
     int st = AFX_OK;
     if (cn != o->foldChromaNum) {
         unsigned char *fold = chroma_fold(cn, o->num, o->binPerOctave, o->minFre);
+        if (o->lastUsed) afxdev_stream_sync(o->lastStream); /* a launch may still read the old one */
         afxdev_free(o->dFold);
         o->dFold = NULL;
         st = afxdev_malloc((void **)&o->dFold, (size_t)cn * o->num);
@@ -426,21 +546,60 @@ void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
         free(fold);
         if (st == AFX_OK) o->foldChromaNum = cn;
     }
-    const size_t inB = sizeof(float) * (size_t)T * o->num;
-    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dIn, &o->capIn, 2 * inB + sizeof(float) * (size_t)T * cn);
-    float *dRe = o->dIn, *dIm = o->dIn + (size_t)T * o->num, *dC = o->dIn + 2 * (size_t)T * o->num;
-    if (st == AFX_OK) st = afxdev_h2d(dRe, mRealArr, inB, o->stream);
-    if (st == AFX_OK) st = afxdev_h2d(dIm, mImageArr, inB, o->stream);
     int nrm = 0;
     if (nt == ChromaDataNormal_Max) nrm = 1;
     else if (nt == ChromaDataNormal_Min) nrm = 2;
     else if (nt == ChromaDataNormal_P2) nrm = 3;
     else if (nt != ChromaDataNormal_None) nrm = 4;
+    *cnOut = cn;
+    *isMag = dt == SpectralData_Mag;
+    *nrmOut = nrm;
+    return st;
+}
+
+void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
+                   ChromaDataNormalType *normType, float *mRealArr, float *mImageArr,
+                   float *mDataArr) {
+    if (!o) {
+        afxdev_set_error("cqtObj_chroma: NULL object");
+        return;
+    }
+    int cn, isMag, nrm;
+    if (chroma_prepare(o, chromaNum, dataType, normType, &cn, &isMag, &nrm) == AFX_ERR_ARG) return;
+    const int T = o->timeLength;
+    if (T <= 0 || !mRealArr || !mImageArr || !mDataArr) return;
+    int st = o->foldChromaNum == cn ? AFX_OK : AFX_ERR_HIP;
+    const size_t inB = sizeof(float) * (size_t)T * o->num;
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dIn, &o->capIn, 2 * inB + sizeof(float) * (size_t)T * cn);
+    float *dRe = o->dIn, *dIm = o->dIn + (size_t)T * o->num, *dC = o->dIn + 2 * (size_t)T * o->num;
+    if (st == AFX_OK) st = afxdev_h2d(dRe, mRealArr, inB, o->stream);
+    if (st == AFX_OK) st = afxdev_h2d(dIm, mImageArr, inB, o->stream);
     if (st == AFX_OK)
-        st = afxk_cqt_chroma(dRe, dIm, T, o->num, o->dFold, cn, dt == SpectralData_Mag, nrm, dC, o->stream);
+        st = afxk_cqt_chroma(dRe, dIm, T, o->num, o->dFold, cn, isMag, nrm, dC, o->stream);
     if (st == AFX_OK) st = afxdev_d2h(mDataArr, dC, sizeof(float) * (size_t)T * cn, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) fail(o, st, "cqtObj_chroma");
+}
+
+/* chroma of `rows` = batch*T HBM-resident CQT frames (include/afx_batch.h) */
+int cqtObj_chromaBatchDevice(CQTObj o, int *chromaNum, SpectralDataType *dataType,
+                             ChromaDataNormalType *normType, const float *dReal,
+                             const float *dImag, long long rows, float *dData, void *hipStream) {
+    if (!o || !dReal || !dImag || !dData || rows <= 0) {
+        afxdev_set_error("cqtObj_chromaBatchDevice: bad argument");
+        return AFX_ERR_ARG;
+    }
+    int cn, isMag, nrm;
+    int st = chroma_prepare(o, chromaNum, dataType, normType, &cn, &isMag, &nrm);
+    if (st == AFX_OK)
+        st = afxk_cqt_chroma(dReal, dImag, rows, o->num, o->dFold, cn, isMag, nrm, dData, hipStream);
+    if (st == AFX_OK) {
+        o->lastStream = hipStream;
+        o->lastUsed = 1;
+    } else if (st != AFX_ERR_ARG) {
+        fail(o, st, "cqtObj_chromaBatchDevice");
+    }
+    return st;
 }
 
 void cqtObj_cqcc(CQTObj o, float *mDataArr1, int ccNum, CepstralRectifyType *rectifyType,
@@ -497,6 +656,8 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dScaleOn);
     afxdev_free(o->dScaleOff);
     afxdev_free(o->dFold);
+    afxdev_free(o->dTimeKernel);
+    afxdev_free(o->dX);
     afxdev_free(o->dSig[0]);
     afxdev_free(o->dSig[1]);
     afxdev_free(o->dOut);

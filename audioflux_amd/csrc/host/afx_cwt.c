@@ -36,6 +36,8 @@ struct OpaqueCWT {
     float *dX, *dA, *dXt, *dB, *dOut; /* scratch */
     int haveSpectrum;
     int status;
+    void *lastStream;        /* stream of the previous batched device call (scratch ordering) */
+    int lastUsed;
 };
 
 /* ---- scale maps shared with the auditory bank (same formulas, see afx_auditory.c) ---- */
@@ -455,11 +457,15 @@ int *cwtObj_getBinBandArr(CWTObj o) { return o ? o->binBandArr : NULL; }
 static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *re, float *im,
                 const char *who) {
     int st = AFX_OK;
-    if (dataArr) {
+    if (o->lastUsed && o->lastStream != o->stream) {
+        st = afxdev_stream_sync(o->lastStream);
+        o->lastUsed = 0;
+    }
+    if (st == AFX_OK && dataArr) {
         st = afxdev_h2d(o->dX, dataArr, sizeof(float) * (size_t)o->dataLength, o->stream);
         if (st == AFX_OK) st = afxk_cwt_forward(&o->dims, o->dTw, o->dX, o->dA, o->dXt, o->stream);
         if (st == AFX_OK) o->haveSpectrum = 1;
-    } else if (!o->haveSpectrum) {
+    } else if (!dataArr && !o->haveSpectrum) {
         return; /* nothing to re-use yet */
     }
     const size_t outB = sizeof(float) * (size_t)o->num * o->dataLength;
@@ -481,6 +487,69 @@ void cwtObj_cwt(CWTObj o, float *dataArr, float *mRealArr3, float *mImageArr3) {
         return;
     }
     run(o, dataArr, o->dBankT, 0, mRealArr3, mImageArr3, "cwtObj_cwt");
+}
+
+/* chunks of 2^radix2Exp samples already in HBM (chunk c at dData + c*chunkStride) ->
+ * dReal/dImag [chunks][num][2^radix2Exp], left in HBM (include/afx_batch.h).  The
+ * spectrum / intermediate scratch belongs to the object, so chunks run back to back on
+ * `hipStream`. */
+static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long chunkStride,
+                            const float *dBank, int isDet, float *dReal, float *dImag,
+                            void *hipStream, const char *who) {
+    if (!o || !dData || !dReal || !dImag || chunks <= 0 || chunkStride < 0) {
+        afxdev_set_error("%s: bad argument", who);
+        return AFX_ERR_ARG;
+    }
+    if (!dBank) {
+        afxdev_set_error("%s: cwtObj_enableDet was not called", who);
+        return AFX_ERR_ARG;
+    }
+    int st = AFX_OK;
+    if (o->lastUsed && o->lastStream != hipStream) st = afxdev_stream_sync(o->lastStream);
+    const size_t plane = (size_t)o->num * o->dataLength;
+    for (int c = 0; c < chunks && st == AFX_OK; c++) {
+        st = afxk_cwt_forward(&o->dims, o->dTw, dData + (long long)c * chunkStride, o->dA, o->dXt, hipStream);
+        if (st == AFX_OK)
+            st = afxk_cwt_inverse(&o->dims, o->dTw, o->dXt, dBank, o->num, isDet, o->dB,
+                                  dReal + c * plane, dImag + c * plane, hipStream);
+    }
+    o->lastStream = hipStream;
+    o->lastUsed = 1;
+    o->haveSpectrum = 1; /* dXt holds the spectrum of the last chunk */
+    if (st != AFX_OK) {
+        o->status = st;
+        fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+    }
+    return st;
+}
+
+int cwtObj_cwtBatchDevice(CWTObj o, const float *dData, int chunks, long long chunkStride,
+                          float *dReal, float *dImag, void *hipStream) {
+    return cwt_batch_device(o, dData, chunks, chunkStride, o ? o->dBankT : NULL, 0, dReal, dImag,
+                            hipStream, "cwtObj_cwtBatchDevice");
+}
+
+int cwtObj_cwtDetBatchDevice(CWTObj o, const float *dData, int chunks, long long chunkStride,
+                             float *dReal, float *dImag, void *hipStream) {
+    return cwt_batch_device(o, dData, chunks, chunkStride, o ? o->dBankDetT : NULL, 1, dReal, dImag,
+                            hipStream, "cwtObj_cwtDetBatchDevice");
+}
+
+/* host pointers: dataArr[chunks][2^r] -> mRealArr3/mImageArr3 [chunks][num][2^r]; chunks are
+ * streamed through the object's one-chunk staging buffers */
+int cwtObj_cwtBatch(CWTObj o, const float *dataArr, int chunks, float *mRealArr3, float *mImageArr3) {
+    if (!o || !dataArr || !mRealArr3 || !mImageArr3 || chunks <= 0) {
+        afxdev_set_error("cwtObj_cwtBatch: bad argument");
+        return AFX_ERR_ARG;
+    }
+    const size_t plane = (size_t)o->num * o->dataLength;
+    for (int c = 0; c < chunks; c++) {
+        o->status = AFX_OK;
+        run(o, (float *)dataArr + (size_t)c * o->dataLength, o->dBankT, 0, mRealArr3 + c * plane,
+            mImageArr3 + c * plane, "cwtObj_cwtBatch");
+        if (o->status != AFX_OK) return o->status;
+    }
+    return AFX_OK;
 }
 
 void cwtObj_enableDet(CWTObj o, int flag) {

@@ -93,6 +93,28 @@ void xxccObj_xxcc(XXCCObj o, float *mDataArr1, int ccNum, CepstralRectifyType *r
     }
 }
 
+/* host pointers, explicit row count: mDataArr1[rows,num] -> mDataArr2[rows,ccNum]; the same
+ * as xxccObj_setTimeLength(rows) + xxccObj_xxcc, with a status (include/afx_batch.h) */
+int xxccObj_xxccBatch(XXCCObj o, const float *mDataArr1, long long rows, int ccNum,
+                      CepstralRectifyType *rectifyType, float *mDataArr2) {
+    if (!o || !mDataArr1 || !mDataArr2 || rows <= 0 || rows > 2147483647LL || ccNum > o->num || ccNum < 1) {
+        afxdev_set_error("xxccObj_xxccBatch: bad argument");
+        return AFX_ERR_ARG;
+    }
+    const int keep = o->timeLength;
+    o->timeLength = (int)rows;
+    int st = run_cc(o, mDataArr1, ccNum, rectifyType);
+    if (st == AFX_OK)
+        st = afxdev_d2h(mDataArr2, o->dOut, sizeof(float) * (size_t)rows * ccNum, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    o->timeLength = keep;
+    if (st != AFX_OK) {
+        o->status = st;
+        fprintf(stderr, "[audioflux_mi355x] xxccObj_xxccBatch failed (%d): %s\n", st, afxdev_last_error());
+    }
+    return st;
+}
+
 void xxccObj_xxccStandard(XXCCObj o, float *mDataArr1, int ccNum, float *energyArr,
                           int *deltaWindowLength, CepstralEnergyType *energyType,
                           CepstralRectifyType *rectifyType, float *mCoeArr, float *mDeltaArr1,

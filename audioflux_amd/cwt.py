@@ -1,6 +1,6 @@
 """CWT -- ctypes mirror of python/audioflux/cwt.py:126-318 over libaudioflux_mi355x.so."""
 import ctypes
-from ctypes import POINTER, c_float, c_int, c_void_p
+from ctypes import POINTER, c_float, c_int, c_longlong, c_void_p
 
 import numpy as np
 
@@ -93,6 +93,29 @@ class CWT:
 
     def cwt_det(self, data_arr):
         return self._run("cwtObj_cwtDet", data_arr)
+
+    def cwt_device(self, x, out_real=None, out_imag=None, det=False, stream=None):
+        """Additive (include/afx_batch.h: cwtObj_cwtBatchDevice): x is a HIP torch.float32
+        tensor (chunks, 2**radix2_exp) with contiguous rows.  Returns (real, imag) torch
+        tensors (chunks, num, 2**radix2_exp) in the LIBRARY's row order (row 0 = highest
+        frequency, as cwtObj_cwt writes them); asynchronous on `stream`."""
+        import torch
+        n = 1 << self.radix2_exp
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        assert x.shape[1] == n, f"chunks must be 2**radix2_exp = {n} samples"
+        c = x.shape[0]
+        if out_real is None:
+            out_real = torch.empty((c, self.num, n), dtype=torch.float32, device=x.device)
+        if out_imag is None:
+            out_imag = torch.empty_like(out_real)
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        name = "cwtObj_cwtDetBatchDevice" if det else "cwtObj_cwtBatchDevice"
+        fn = getattr(self._lib, name)
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p]
+        _lib.check(fn(self._obj, x.data_ptr(), c, x.stride(0), out_real.data_ptr(),
+                      out_imag.data_ptr(), s.cuda_stream), name)
+        return out_real, out_imag
 
     def __del__(self):
         if getattr(self, "_obj", None):

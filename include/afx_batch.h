@@ -15,6 +15,9 @@
 #define AFX_BATCH_H
 
 #include "bft_algorithm.h"
+#include "cepstrogram_algorithm.h"
+#include "cqt_algorithm.h"
+#include "cwt_algorithm.h"
 #include "feature/xxcc_algorithm.h"
 
 #ifdef __cplusplus
@@ -52,6 +55,45 @@ int afx_bftXxccBatchDevice(BFTObj bftObj, XXCCObj xxccObj, const float *dData, i
                            int dataLength, long long clipStride, int ccNum,
                            CepstralRectifyType *rectifyType, float *dMel, float *dCc,
                            void *hipStream);
+
+/* xxccObj_xxcc (feature/xxcc_algorithm.h) with the row count passed explicitly instead of
+ * through xxccObj_setTimeLength: mDataArr1[rows*num] -> mDataArr2[rows*ccNum], host pointers */
+int xxccObj_xxccBatch(XXCCObj xxccObj, const float *mDataArr1, long long rows, int ccNum,
+                      CepstralRectifyType *rectifyType, float *mDataArr2);
+
+/* ---- CWT (BASELINE config 4) --------------------------------------------------------
+ * chunks of 2^radix2Exp samples, chunk c at data + c*chunkStride ->
+ * real/imag [chunks][num][2^radix2Exp] (row 0 = highest frequency, as cwtObj_cwt).
+ * Same as calling cwtObj_cwt (cwt_algorithm.h) per chunk. */
+int cwtObj_cwtBatch(CWTObj cwtObj, const float *dataArr, int chunks, float *mRealArr3,
+                    float *mImageArr3);
+int cwtObj_cwtBatchDevice(CWTObj cwtObj, const float *dData, int chunks, long long chunkStride,
+                          float *dReal, float *dImag, void *hipStream);
+/* the d/dt variant (cwtObj_cwtDet); cwtObj_enableDet(obj, 1) must have been called */
+int cwtObj_cwtDetBatchDevice(CWTObj cwtObj, const float *dData, int chunks, long long chunkStride,
+                             float *dReal, float *dImag, void *hipStream);
+
+/* ---- CQT + chroma (BASELINE config 5) -----------------------------------------------
+ * batch clips of dataLength samples -> real/imag [batch][T, num], T = cqtObj_calTimeLength.
+ * Same as calling cqtObj_cqt (cqt_algorithm.h) per clip; all clips of the batch go through
+ * each octave of the recursion in one launch. */
+int cqtObj_cqtBatch(CQTObj cqtObj, const float *dataArr, int batch, int dataLength,
+                    float *mRealArr, float *mImageArr);
+int cqtObj_cqtBatchDevice(CQTObj cqtObj, const float *dData, int batch, int dataLength,
+                          long long clipStride, float *dReal, float *dImag, void *hipStream);
+/* cqtObj_chroma on `rows` (= batch*T) HBM-resident CQT frames -> dData[rows*chromaNum];
+ * the optional parameters keep the meaning and defaults of cqtObj_chroma */
+int cqtObj_chromaBatchDevice(CQTObj cqtObj, int *chromaNum, SpectralDataType *dataType,
+                             ChromaDataNormalType *normType, const float *dReal,
+                             const float *dImag, long long rows, float *dData, void *hipStream);
+
+/* ---- cepstrogram ----------------------------------------------------------------------
+ * batch clips -> dOut1/dOut2/dOut3 [batch][T, N/2+1] (cepstrum, envelope, details; any may
+ * be NULL).  Same as calling cepstrogramObj_cepstrogram (cepstrogram_algorithm.h) per clip. */
+int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj cepstrogramObj, int cepNum,
+                                          const float *dData, int batch, int dataLength,
+                                          long long clipStride, float *dOut1, float *dOut2,
+                                          float *dOut3, void *hipStream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,137 @@
+"""Batched / HBM-resident entry points of include/afx_batch.h for CWT, CQT(+chroma),
+cepstrogram and xxcc: identical to looping the legacy one-clip call (bit-exact, same
+kernels), and within tolerance of the compiled reference on sampled clips."""
+import numpy as np
+import pytest
+
+import audioflux_amd as af
+from oracle import ref
+from tests.conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def test_cwt_batch_device_equals_loop_and_reference():
+    torch = _torch()
+    rng = np.random.default_rng(31)
+    x = (0.1 * rng.standard_normal((5, 4096))).astype(np.float32)
+    o = af.CWT(num=40, radix2_exp=12, samplate=16000, low_fre=40.0, bin_per_octave=8,
+               wavelet_type=af.WaveletContinueType.MORLET, scale_type=af.SpectralFilterBankScaleType.OCTAVE)
+    xd = torch.from_numpy(x).cuda()
+    re, im = o.cwt_device(xd)
+    torch.cuda.synchronize()
+    got = (re.cpu().numpy() + 1j * im.cpu().numpy())[:, ::-1, :]   # -> ascending frequency
+    for i in range(x.shape[0]):
+        loop = o.cwt(x[i])
+        assert np.array_equal(got[i], loop), f"chunk {i}: batch != loop"
+    if ref.available():
+        r = ref.RefCWT(num=40, radix2_exp=12, samplate=16000, low_fre=40.0, bin_per_octave=8,
+                       wavelet_type=int(af.WaveletContinueType.MORLET),
+                       scale_type=int(af.SpectralFilterBankScaleType.OCTAVE), is_padding=1)
+        rre, rim = r.cwt(x[3])
+        assert_parity(got[3][::-1], rre + 1j * rim, what="cwt batch vs reference")
+    # strided input (chunks cut out of longer clips) and the d/dt variant
+    long = (0.1 * rng.standard_normal((2, 3 * 4096))).astype(np.float32)
+    ld = torch.from_numpy(long).cuda()
+    chunks = ld.view(2, 3, 4096)[:, 1, :]                     # stride 3*4096 between chunks
+    re2, im2 = o.cwt_device(chunks)
+    torch.cuda.synchronize()
+    assert np.array_equal((re2.cpu().numpy() + 1j * im2.cpu().numpy())[1, ::-1], o.cwt(long[1, 4096:8192]))
+    o.enable_det(True)
+    dre, dim = o.cwt_device(xd, det=True)
+    torch.cuda.synchronize()
+    assert np.array_equal((dre.cpu().numpy() + 1j * dim.cpu().numpy())[2, ::-1], o.cwt_det(x[2]))
+
+
+def test_cwt_batch_host():
+    import ctypes
+    rng = np.random.default_rng(32)
+    x = (0.1 * rng.standard_normal((3, 2048))).astype(np.float32)
+    o = af.CWT(num=24, radix2_exp=11, samplate=16000, low_fre=60.0, bin_per_octave=6,
+               wavelet_type=af.WaveletContinueType.MORLET)
+    re = np.zeros((3, 24, 2048), np.float32)
+    im = np.zeros_like(re)
+    fn = o._lib.cwtObj_cwtBatch
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert fn(o._obj, x.ctypes.data, 3, re.ctypes.data, im.ctypes.data) == 0
+    for i in range(3):
+        assert np.array_equal((re[i] + 1j * im[i])[::-1], o.cwt(x[i]))
+
+
+def test_cqt_batch_device_equals_loop_and_reference():
+    torch = _torch()
+    rng = np.random.default_rng(33)
+    n = 30000
+    x = (0.1 * rng.standard_normal((4, n))).astype(np.float32)
+    o = af.CQT(num=84, samplate=44100, low_fre=32.703, bin_per_octave=12,
+               normal_type=af.SpectralFilterBankNormalType.AREA)
+    xd = torch.from_numpy(x).cuda()
+    re, im = o.cqt_device(xd)
+    ch = o.chroma_device(re, im)
+    torch.cuda.synchronize()
+    got = np.swapaxes(re.cpu().numpy() + 1j * im.cpu().numpy(), -1, -2)      # (clips, num, time)
+    gch = np.swapaxes(ch.cpu().numpy(), -1, -2)
+    for i in range(x.shape[0]):
+        q = o.cqt(x[i])
+        assert np.array_equal(got[i], q), f"clip {i}: batch != loop"
+        assert np.array_equal(gch[i], o.chroma(q)), f"clip {i}: chroma batch != loop"
+    if ref.available():
+        r = ref.RefCQT(num=84, samplate=44100, min_fre=32.703, bin_per_octave=12, normal_type=1)
+        rre, rim = r.cqt(x[2])
+        assert_parity(got[2].T, rre + 1j * rim, what="cqt batch vs reference")
+        assert_parity(gch[2].T, r.chroma(rre, rim), tol=5e-5, what="chroma batch vs reference")
+    # ragged tail + padded row stride
+    wide = torch.zeros((3, n + 77), dtype=torch.float32, device="cuda")
+    wide[:, :n - 13] = xd[:3, :n - 13]
+    re2, im2 = o.cqt_device(wide[:, :n - 13])
+    torch.cuda.synchronize()
+    assert np.array_equal(np.swapaxes(re2.cpu().numpy() + 1j * im2.cpu().numpy(), -1, -2)[1], o.cqt(x[1, :n - 13]))
+
+
+def test_cqt_batch_host():
+    import ctypes
+    rng = np.random.default_rng(34)
+    x = (0.1 * rng.standard_normal((3, 9000))).astype(np.float32)
+    o = af.CQT(num=48, samplate=22050, low_fre=55.0, bin_per_octave=12)
+    t = o.cal_time_length(9000)
+    re = np.zeros((3, t, 48), np.float32)
+    im = np.zeros_like(re)
+    fn = o._lib.cqtObj_cqtBatch
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert fn(o._obj, x.ctypes.data, 3, 9000, re.ctypes.data, im.ctypes.data) == 0
+    for i in range(3):
+        assert np.array_equal(np.swapaxes(re[i] + 1j * im[i], 0, 1), o.cqt(x[i]))
+
+
+def test_cepstrogram_batch_device_equals_loop():
+    torch = _torch()
+    rng = np.random.default_rng(35)
+    x = (0.1 * rng.standard_normal((3, 12000))).astype(np.float32)
+    o = af.Cepstrogram(radix2_exp=10, samplate=16000, window_type=af.WindowType.HANN, slide_length=256)
+    outs = o.cepstrogram_device(torch.from_numpy(x).cuda(), cep_num=6)
+    torch.cuda.synchronize()
+    for i in range(3):
+        loop = o.cepstrogram(x[i], cep_num=6)
+        for k in range(3):
+            assert np.array_equal(outs[k][i].cpu().numpy().T, loop[k]), f"clip {i} output {k}"
+
+
+def test_xxcc_batch_host():
+    import ctypes
+    rng = np.random.default_rng(36)
+    m = np.abs(rng.standard_normal((700, 128))).astype(np.float32)
+    o = af.XXCC(128)
+    out = np.zeros((700, 13), np.float32)
+    fn = o._lib.xxccObj_xxccBatch
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert fn(o._obj, m.ctypes.data, 700, 13, None, out.ctypes.data) == 0
+    assert np.array_equal(out, o.xxcc(m.T, 13).T)
+    assert fn(o._obj, m.ctypes.data, 700, 200, None, out.ctypes.data) != 0
