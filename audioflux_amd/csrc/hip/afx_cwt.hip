@@ -21,8 +21,11 @@
 // multiplies by j*omega*wavelet: (re,im) -> (-b*im, b*re), cwt_algorithm.c:432-435.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "afx_device.h"
 #include "afx_hipcheck.h"
+#include "afx_pkmath.h"
 
 namespace {
 
@@ -68,14 +71,20 @@ struct CwtGeom {
     int pad;
     int C;             // columns per tile
     const float2 *tw;  // W_L^m, m < L/2
+    const float2 *fastTw;
+    const int *support;  // [num][2] non-zero k2 range per scale, or NULL
+    int num;           // scales (chunk stride of the per-scale buffers = num * L)
 };
 
 // forward pass 1: reflect-padded real input -> A[k1][n2] * W_L^(k1 n2)
-__global__ void k_cwt_fwd_cols(CwtGeom g, const float *__restrict__ x, float2 *__restrict__ A) {
+__global__ void k_cwt_fwd_cols(CwtGeom g, const float *__restrict__ x, long long xStride,
+                               float2 *__restrict__ A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
     const int L1 = 1 << g.r1, L2 = 1 << g.r2;
     const long long L = (long long)L1 * L2;
+    x += (long long)blockIdx.y * xStride;
+    A += (long long)blockIdx.y * L;
     const int c0 = blockIdx.x * g.C;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int D = g.dataLength, P = g.pad;
@@ -103,7 +112,7 @@ __global__ void k_cwt_fwd_rows(CwtGeom g, const float2 *__restrict__ A, float2 *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
     const int L1 = 1 << g.r1, L2 = 1 << g.r2;
-    const long long row = (long long)blockIdx.x * L2;
+    const long long row = (long long)blockIdx.y * L1 * L2 + (long long)blockIdx.x * L2;
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int i = tid; i < L2; i += nth) s[i] = A[row + i];
     __syncthreads();
@@ -123,6 +132,8 @@ __global__ void k_cwt_inv_rows(CwtGeom g, const float2 *__restrict__ Xt,
     const long long row = (long long)k1 * L2;
     const float *bank = bankT + (long long)j * L + row;
     const int tid = threadIdx.x, nth = blockDim.x;
+    Xt += (long long)blockIdx.z * L;
+    B += (long long)blockIdx.z * g.num * L;
     for (int i = tid; i < L2; i += nth) {
         const float2 xv = Xt[row + i];
         const float b = bank[i];
@@ -154,7 +165,9 @@ __global__ void k_cwt_inv_cols(CwtGeom g, const float2 *__restrict__ B, float *_
     const int L1 = 1 << g.r1, L2 = 1 << g.r2;
     const long long L = (long long)L1 * L2;
     const int c0 = blockIdx.x * g.C, j = blockIdx.y;
-    const float2 *in = B + (long long)j * L;
+    const float2 *in = B + ((long long)blockIdx.z * g.num + j) * L;
+    outRe += (long long)blockIdx.z * g.num * g.dataLength;
+    outIm += (long long)blockIdx.z * g.num * g.dataLength;
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int idx = tid; idx < L1 * g.C; idx += nth) {
         const int c = idx % g.C, k1 = idx / g.C;
@@ -175,6 +188,147 @@ __global__ void k_cwt_inv_cols(CwtGeom g, const float2 *__restrict__ B, float *_
     }
 }
 
+
+// ---- register-FFT inverse for L = 2^17 (L1 = 256 columns, L2 = 512 rows) -----------------
+// Same two passes and the same intermediate B[j][k1][m1] as the generic kernels, with the
+// transforms held in VGPRs (packed-f32 butterflies, afx_pkmath.h) instead of radix-2 passes
+// through LDS with a workgroup barrier per stage:
+//   rows : one wave per row.  512 = 8 x 8 x 8: lane l holds z[64 a + l], a < 8; radix-8 over a,
+//          twiddle W_512^(l d0), exchange, radix-8, twiddle W_64^(c d1), exchange, radix-8.
+//          Output m1 = lam + 64 d2 sits in lane lam, register d2: stores are lane-contiguous.
+//          (index algebra: tools/proto_fft512.py)
+//   cols : 16 columns per workgroup, thread (c = tid & 15, g = tid >> 4) holds B[16 a + g][c],
+//          a < 16; 256 = 16 x 16: radix-16 over a, twiddle W_256^(g p), exchange, radix-16.
+//          Output m2 = p + 16 q sits in thread (c, p), register q: each store covers 16
+//          consecutive time samples (64 B) of 4 rows.
+constexpr int RP = 9;  // exchange pitch (float2) of the 64 x 8 images of the row transform
+
+__device__ __forceinline__ v2 ld2(const float2 *p) {
+    const float2 t = *p;
+    v2 r = {t.x, t.y};
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2 *__restrict__ Xt,
+                                                         const float *__restrict__ bankT, int isDet,
+                                                         float2 *__restrict__ B) {
+    __shared__ v2 ex[4][64 * RP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
+    const int k1 = blockIdx.x * 4 + wave, j = blockIdx.y;
+    const long long row = (long long)k1 * L2;
+    const float2 *xr = Xt + (long long)blockIdx.z * L + row;
+    const float *bank = bankT + (long long)j * L + row;
+    float2 *out = B + ((long long)blockIdx.z * g.num + j) * L + row;
+    v2 *e = ex[wave];
+
+    // every global operand of the row is requested up front (data, wavelet, three twiddle
+    // sets: 39 loads in flight); left to the scheduler they are issued next to their use and
+    // the row pays ~25 serial L2 latencies
+    float2 xv[8], t1[8], t2[8], wus[8];
+    float bw[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        xv[a] = xr[64 * a + lane];
+        bw[a] = bank[64 * a + lane];
+    }
+#pragma unroll
+    for (int d = 1; d < 8; ++d) {
+        t1[d] = g.fastTw[64 * d + lane];                 // W_512^(lane d)
+        t2[d] = g.fastTw[8 * 64 + 8 * d + (lane & 7)];   // W_64^(c d)
+    }
+    const float2 wlv = g.tw[lane * k1];                  // W_L^(lane k1), lane k1 < 2^14 < L/2
+#pragma unroll
+    for (int d2 = 0; d2 < 8; ++d2) wus[d2] = g.tw[(64 * k1 * d2) & ((1 << 16) - 1)];  // W_L^(m mod L/2)
+    __builtin_amdgcn_sched_barrier(0);
+
+    v2 r[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        // conj(X * wavelet): IFFT through a forward FFT (cwt_algorithm.c:428-435)
+        if (!isDet) r[a] = v2{bw[a] * xv[a].x, -(bw[a] * xv[a].y)};
+        else r[a] = v2{-bw[a] * xv[a].y, -(bw[a] * xv[a].x)};
+    }
+    dft8(r);  // r[rev8(d0)] = sum_a z[64 a + l] W_8^(a d0)
+#pragma unroll
+    for (int d0 = 1; d0 < 8; ++d0) r[rev8(d0)] = cmul(r[rev8(d0)], v2{t1[d0].x, t1[d0].y});
+    // exchange 1: lane l = 8 b + c, register d0  ->  lane 8 d0 + c, register b
+    {
+        const int b = lane >> 3, c = lane & 7;
+#pragma unroll
+        for (int d0 = 0; d0 < 8; ++d0) e[(8 * d0 + c) * RP + b] = r[rev8(d0)];
+        wave_lds_order();
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) r[bb] = e[lane * RP + bb];
+    }
+    dft8(r);  // r[rev8(d1)], lane = 8 d0 + c
+#pragma unroll
+    for (int d1 = 1; d1 < 8; ++d1) r[rev8(d1)] = cmul(r[rev8(d1)], v2{t2[d1].x, t2[d1].y});
+    // exchange 2: lane 8 d0 + c, register d1  ->  lane d0 + 8 d1, register c
+    {
+        const int d0 = lane >> 3, c = lane & 7;
+        wave_lds_order();  // the reads of exchange 1 are done before the image is overwritten
+#pragma unroll
+        for (int d1 = 0; d1 < 8; ++d1) e[(d0 + 8 * d1) * RP + c] = r[rev8(d1)];
+        wave_lds_order();
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) r[cc] = e[lane * RP + cc];
+    }
+    dft8(r);  // r[rev8(d2)] = Z[m1 = lane + 64 d2]
+    // four-step twiddle W_L^(m1 k1) = W_L^(lane k1) W_L^(64 k1 d2): one gathered and eight
+    // wave-uniform table values instead of eight gathers
+    const v2 wl = {wlv.x, wlv.y};
+#pragma unroll
+    for (int d2 = 0; d2 < 8; ++d2) {
+        const float sgn = ((64 * k1 * d2) >> 16) & 1 ? -1.f : 1.f;  // W_L^(m + L/2) = -W_L^m
+        const v2 w = cmul(wl, v2{wus[d2].x * sgn, wus[d2].y * sgn});
+        const v2 o = cmul(r[rev8(d2)], w);
+        out[64 * d2 + lane] = make_float2(o.x, o.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2 *__restrict__ B,
+                                                         float *__restrict__ outRe,
+                                                         float *__restrict__ outIm) {
+    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
+    const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
+    const int c0 = blockIdx.x * 16, j = blockIdx.y;
+    const float2 *in = B + ((long long)blockIdx.z * g.num + j) * L + c0 + c;
+    v2 r[16];
+    float2 t3[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) r[a] = ld2(in + (long long)(16 * a + gq) * L2);
+#pragma unroll
+    for (int p = 1; p < 16; ++p) t3[p] = g.fastTw[8 * 64 + 8 * 8 + 16 * p + gq];  // W_256^(g p)
+    __builtin_amdgcn_sched_barrier(0);  // all 31 loads in flight before the first butterfly
+    dft16(r);  // r[rev4(p)] = sum_a B[16 a + g] W_16^(a p)
+#pragma unroll
+    for (int p = 1; p < 16; ++p) r[rev4(p)] = cmul(r[rev4(p)], v2{t3[p].x, t3[p].y});
+#pragma unroll
+    for (int p = 0; p < 16; ++p) ex[(p * 16 + gq) * 16 + c] = r[rev4(p)];
+    __syncthreads();
+    const int p = gq;  // this thread now owns outputs m2 = p + 16 q of column c
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) r[gg] = ex[(p * 16 + gg) * 16 + c];
+    dft16(r);  // r[rev4(q)] = Y[m2 = p + 16 q]
+    const float invL = 1.f / (float)L;
+    const long long D = g.dataLength, P = g.pad;
+    float *oRe = outRe + ((long long)blockIdx.z * g.num + j) * D;
+    float *oIm = outIm + ((long long)blockIdx.z * g.num + j) * D;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const long long n = (long long)(p + 16 * q) * L2 + c0 + c;
+        if (n >= P && n < P + D) {  // conj, 1/L, crop (cwt_algorithm.c:449-458)
+            const v2 a = r[rev4(q)];
+            oRe[n - P] = a.x * invL;
+            oIm[n - P] = -a.y * invL;
+        }
+    }
+}
+
 int lds_opt_in(const void *fn, size_t lds) {
     if (lds > 48 * 1024) AFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return AFX_OK;
@@ -188,42 +342,61 @@ CwtGeom make_geom(const AfxCwtPlanDims *d, const float *tw) {
     g.pad = d->pad;
     g.C = d->tileCols;
     g.tw = reinterpret_cast<const float2 *>(tw);
+    g.fastTw = reinterpret_cast<const float2 *>(d->fastTw);
+    g.support = d->support;
+    g.num = 0;
     return g;
 }
 
 }  // namespace
 
 extern "C" int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x,
-                                float *scratchA, float *Xt, void *stream) {
+                                long long xStride, int chunks, float *scratchA, float *Xt,
+                                void *stream) {
+    if (chunks <= 0) return AFX_OK;
+    if (chunks > 65535) return AFX_ERR_UNSUPPORTED;
     const CwtGeom g = make_geom(d, tw);
     const int L1 = 1 << d->r1, L2 = 1 << d->r2;
     const size_t ldsC = (size_t)L1 * d->tileCols * sizeof(float2), ldsR = (size_t)L2 * sizeof(float2);
     int st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_fwd_cols), ldsC);
     if (st == AFX_OK) st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_fwd_rows), ldsR);
     if (st != AFX_OK) return st;
-    hipLaunchKernelGGL(k_cwt_fwd_cols, dim3(L2 / d->tileCols), dim3(256), ldsC, (hipStream_t)stream,
-                       g, x, reinterpret_cast<float2 *>(scratchA));
+    hipLaunchKernelGGL(k_cwt_fwd_cols, dim3(L2 / d->tileCols, chunks), dim3(256), ldsC,
+                       (hipStream_t)stream, g, x, xStride, reinterpret_cast<float2 *>(scratchA));
     AFX_LAUNCH_CHECK("k_cwt_fwd_cols");
-    hipLaunchKernelGGL(k_cwt_fwd_rows, dim3(L1), dim3(256), ldsR, (hipStream_t)stream, g,
+    hipLaunchKernelGGL(k_cwt_fwd_rows, dim3(L1, chunks), dim3(256), ldsR, (hipStream_t)stream, g,
                        reinterpret_cast<const float2 *>(scratchA), reinterpret_cast<float2 *>(Xt));
     AFX_LAUNCH_CHECK("k_cwt_fwd_rows");
     return AFX_OK;
 }
 
 extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt,
-                                const float *bankT, int num, int isDet, float *scratchB,
+                                const float *bankT, int num, int isDet, int chunks, float *scratchB,
                                 float *outRe, float *outIm, void *stream) {
-    const CwtGeom g = make_geom(d, tw);
+    if (chunks <= 0) return AFX_OK;
+    if (chunks > 65535 || num > 65535) return AFX_ERR_UNSUPPORTED;
+    CwtGeom g = make_geom(d, tw);
+    g.num = num;
     const int L1 = 1 << d->r1, L2 = 1 << d->r2;
+    if (d->fastTw && d->r1 == 8 && d->r2 == 9 && !getenv("AFX_NO_FUSED")) {
+        hipLaunchKernelGGL(k_cwt_inv_rows512, dim3(L1 / 4, num, chunks), dim3(256), 0, (hipStream_t)stream,
+                           g, reinterpret_cast<const float2 *>(Xt), bankT, isDet,
+                           reinterpret_cast<float2 *>(scratchB));
+        AFX_LAUNCH_CHECK("k_cwt_inv_rows512");
+        hipLaunchKernelGGL(k_cwt_inv_cols256, dim3(L2 / 16, num, chunks), dim3(256), 0, (hipStream_t)stream,
+                           g, reinterpret_cast<const float2 *>(scratchB), outRe, outIm);
+        AFX_LAUNCH_CHECK("k_cwt_inv_cols256");
+        return AFX_OK;
+    }
     const size_t ldsC = (size_t)L1 * d->tileCols * sizeof(float2), ldsR = (size_t)L2 * sizeof(float2);
     int st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_inv_cols), ldsC);
     if (st == AFX_OK) st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_inv_rows), ldsR);
     if (st != AFX_OK) return st;
-    hipLaunchKernelGGL(k_cwt_inv_rows, dim3(L1, num), dim3(256), ldsR, (hipStream_t)stream, g,
+    hipLaunchKernelGGL(k_cwt_inv_rows, dim3(L1, num, chunks), dim3(256), ldsR, (hipStream_t)stream, g,
                        reinterpret_cast<const float2 *>(Xt), bankT, isDet,
                        reinterpret_cast<float2 *>(scratchB));
     AFX_LAUNCH_CHECK("k_cwt_inv_rows");
-    hipLaunchKernelGGL(k_cwt_inv_cols, dim3(L2 / d->tileCols, num), dim3(256), ldsC,
+    hipLaunchKernelGGL(k_cwt_inv_cols, dim3(L2 / d->tileCols, num, chunks), dim3(256), ldsC,
                        (hipStream_t)stream, g, reinterpret_cast<const float2 *>(scratchB), outRe, outIm);
     AFX_LAUNCH_CHECK("k_cwt_inv_cols");
     return AFX_OK;

@@ -111,13 +111,21 @@ typedef struct {
     int dataLength;  /* 2^radix2Exp samples in / per scale out                       */
     int pad;         /* reflect padding on each side                                 */
     int tileCols;    /* columns per workgroup in the column passes (divides 2^r2)    */
+    const float *fastTw; /* device float2 tables of the register-FFT kernels (r1 = 8, r2 = 9):
+                          * [8][64] W_512^(lane d) | [8][8] W_64^(c d) | [16][16] W_256^(g p);
+                          * NULL: size-generic kernels only                            */
+    const int *support;  /* device [num][2]: k2 range of each wavelet's non-zeros (or NULL)  */
 } AfxCwtPlanDims;
-/* x[dataLength] -> Xt[L] complex (transposed layout: frequency k1 + 2^r1 k2 at [k1][k2]) */
-int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x, float *scratchA,
-                     float *Xt, void *stream);
-/* Xt, bankT[num][L] (same layout) -> outRe/outIm [num][dataLength]; scratchB: num*L complex */
+#define AFX_CWT_FASTTW_FLOATS (2 * (8 * 64 + 8 * 8 + 16 * 16))
+/* `chunks` signals, chunk c at x + c*xStride -> Xt[c][L] complex (transposed layout:
+ * frequency k1 + 2^r1 k2 at [k1][k2]); scratchA: chunks*L complex */
+int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x, long long xStride,
+                     int chunks, float *scratchA, float *Xt, void *stream);
+/* Xt[chunks][L], bankT[num][L] (same layout) -> outRe/outIm [chunks][num][dataLength];
+ * scratchB: chunks*num*L complex */
 int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, const float *bankT,
-                     int num, int isDet, float *scratchB, float *outRe, float *outIm, void *stream);
+                     int num, int isDet, int chunks, float *scratchB, float *outRe, float *outIm,
+                     void *stream);
 
 /* ---- constant-Q transform (afx_cqt.hip) ----------------------------------- */
 typedef struct {

@@ -41,6 +41,7 @@
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
+#include "afx_pkmath.h"
 
 #ifndef AFX_V
 // Compile-time experiment switches (tools/variants.sh builds variants, tools/ab.py runs them
@@ -109,94 +110,6 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 #endif
 }
-
-typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
-
-// ---- packed-f32 complex primitives -------------------------------------------------------
-// VOP3P operand modifiers: op_sel[i] / op_sel_hi[i] pick the half of source i that feeds the
-// low / high result lane, neg_lo / neg_hi negate it.  hipcc does not fold a swap+negate into
-// these modifiers (it emits v_xor + v_mov per complex multiply), so the three patterns that
-// need them are spelled out.  Plain VALU->VALU dependences are hardware-interlocked on gfx9.
-
-// a + (-i) b = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ v2 pk_add_mi(v2 a, v2 b) {
-    v2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a + i b = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ v2 pk_add_pi(v2 a, v2 b) {
-    v2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a + conj(b) = (a.x + b.x, a.y - b.y)
-__device__ __forceinline__ v2 pk_add_conj(v2 a, v2 b) {
-    v2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a - conj(b) = (a.x - b.x, a.y + b.y)
-__device__ __forceinline__ v2 pk_sub_conj(v2 a, v2 b) {
-    v2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// complex product a * b
-__device__ __forceinline__ v2 cmul(v2 a, v2 b) {
-    v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (ax bx, ax by)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-ay by + ., ay bx + .)
-    return r;
-}
-// w * (-i d):  real = w.x d.y + w.y d.x,  imag = w.y d.y - w.x d.x
-__device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
-    v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(d), "v"(w));  // (dy wx, dy wy)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"
-        : "=v"(r) : "v"(d), "v"(w), "v"(t));  // (dx wy + ., -dx wx + .)
-    return r;
-}
-// (-i) a = (a.y, -a.x) as one multiply by the constant pair (1, -1)
-__device__ __forceinline__ v2 mul_mi(v2 a) {
-    v2 r;
-    const v2 c = {1.f, -1.f};
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(c));
-    return r;
-}
-
-// forward 4-point DFT in place: (p0,p1,p2,p3) -> (X0,X1,X2,X3); 8 v_pk_add_f32
-__device__ __forceinline__ void dft4(v2 &p0, v2 &p1, v2 &p2, v2 &p3) {
-    const v2 s0 = p0 + p2, s1 = p0 - p2, s2 = p1 + p3, s3 = p1 - p3;
-    p0 = s0 + s2;
-    p2 = s0 - s2;
-    p1 = pk_add_mi(s1, s3);  // s1 - i s3
-    p3 = pk_add_pi(s1, s3);  // s1 + i s3
-}
-
-// forward 16-point DFT in place, radix-4 x radix-4.  Input x[n] = v[n];
-// output X[k] = v[4*(k&3) + (k>>2)]  (base-4 digit reversal).
-__device__ __forceinline__ void dft16(v2 (&v)[16]) {
-    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
-    const v2 w1 = {C1, -S1}, w3 = {S1, -C1}, w9 = {-C1, S1};
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
-    // t[b][c] sits at v[4c+b]; multiply by W16^(b*c), W16 = exp(-2 pi i / 16)
-    v[5] = cmul(v[5], w1);                 // W^1
-    v[9] = pk_add_mi(v[9], v[9]) * H;      // W^2 = H(1 - i):  H (x + y, y - x)
-    v[13] = cmul(v[13], w3);               // W^3
-    v[6] = pk_add_mi(v[6], v[6]) * H;      // W^2
-    v[10] = mul_mi(v[10]);                 // W^4 = -i
-    v[14] = pk_add_pi(v[14], v[14]) * -H;  // W^6 = -H(1 + i): -H (x - y, x + y)
-    v[7] = cmul(v[7], w3);                 // W^3
-    v[11] = pk_add_pi(v[11], v[11]) * -H;  // W^6
-    v[15] = cmul(v[15], w9);               // W^9
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
-}
-
-__host__ __device__ constexpr int rev4(int k) { return 4 * (k & 3) + (k >> 2); }
 
 // |X|^2 (optionally mapped) of the conjugate pair (k, 1024-k) from A = Z[k], B = Z[1024-k]
 __device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w /* 0.5 W_2048^k */, float &pk, float &pq) {

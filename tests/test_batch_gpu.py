@@ -135,3 +135,34 @@ def test_xxcc_batch_host():
     assert fn(o._obj, m.ctypes.data, 700, 13, None, out.ctypes.data) == 0
     assert np.array_equal(out, o.xxcc(m.T, 13).T)
     assert fn(o._obj, m.ctypes.data, 700, 200, None, out.ctypes.data) != 0
+
+
+def test_cwt_register_fft_path_L131072():
+    """radix2_exp 16 with padding (L = 2^17) runs the register-FFT inverse kernels
+    (k_cwt_inv_rows512 / k_cwt_inv_cols256): parity with the compiled reference, plus the
+    d/dt variant, plus batch == loop."""
+    torch = _torch()
+    rng = np.random.default_rng(41)
+    x = (0.1 * rng.standard_normal((3, 65536))).astype(np.float32)
+    kw = dict(num=12, radix2_exp=16, samplate=44100, low_fre=110.0, bin_per_octave=2)
+    o = af.CWT(wavelet_type=af.WaveletContinueType.MORLET, scale_type=af.SpectralFilterBankScaleType.OCTAVE,
+               is_padding=True, **kw)
+    re, im = o.cwt_device(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    got = re.cpu().numpy() + 1j * im.cpu().numpy()           # library order: descending frequency
+    assert np.array_equal(got[1][::-1], o.cwt(x[1]))
+    if ref.available():
+        r = ref.RefCWT(wavelet_type=int(af.WaveletContinueType.MORLET),
+                       scale_type=int(af.SpectralFilterBankScaleType.OCTAVE), is_padding=1, **kw)
+        rre, rim = r.cwt(x[2])
+        assert_parity(got[2], rre + 1j * rim, what="cwt L=2^17 vs reference")
+        o.enable_det(True)
+        dre, dim = o.cwt_device(torch.from_numpy(x[:1]).cuda(), det=True)
+        torch.cuda.synchronize()
+        rdr, rdi = r.cwt(x[0], det=True)
+        assert_parity(dre.cpu().numpy()[0] + 1j * dim.cpu().numpy()[0], rdr + 1j * rdi, what="cwtDet L=2^17")
+    # linearity at full size (size-independent property)
+    y = (0.1 * rng.standard_normal(65536)).astype(np.float32)
+    wa, wb = o.cwt(x[0]), o.cwt(y)
+    ws = o.cwt((x[0] - 2 * y).astype(np.float32))
+    assert np.abs(ws - (wa - 2 * wb)).max() <= 2e-5 * np.abs(ws).max()
