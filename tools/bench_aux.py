@@ -69,6 +69,67 @@ def cqt(args):
             "alg_GBps": alg / sec / 1e9, "frac_hbm": alg / sec / HBM_PEAK}
 
 
+def _cpu_cwt(args):
+    """worker: reference CWT on `n` chunks; returns (chunks, seconds)"""
+    seed, n = args
+    from oracle import ref
+    r = ref.RefCWT(num=84, radix2_exp=16, samplate=44100, low_fre=32.703, bin_per_octave=12,
+                   wavelet_type=int(af.WaveletContinueType.MORLET),
+                   scale_type=int(af.SpectralFilterBankScaleType.OCTAVE), is_padding=1)
+    x = (0.1 * np.random.default_rng(seed).standard_normal((n + 1, 65536))).astype(np.float32)
+    r.cwt(x[0])
+    t0 = time.perf_counter()
+    for i in range(n):
+        r.cwt(x[1 + i])
+    return n, time.perf_counter() - t0
+
+
+def _cpu_cqt(args):
+    """worker: reference CQT + chroma on `n` clips of 30 s @ 44.1 kHz; returns (frames, seconds)"""
+    seed, n = args
+    from oracle import ref
+    r = ref.RefCQT(num=84, samplate=44100, min_fre=32.703, bin_per_octave=12, normal_type=1)
+    x = (0.1 * np.random.default_rng(seed).standard_normal((n + 1, 1323000))).astype(np.float32)
+    r.chroma(*r.cqt(x[0]))  # (a shorter warm-up clip makes the reference corrupt its heap)
+    t0 = time.perf_counter()
+    frames = 0
+    for i in range(n):
+        re, im = r.cqt(x[1 + i])
+        r.chroma(re, im)
+        frames += re.shape[0]
+    return frames, time.perf_counter() - t0
+
+
+def cpu_baseline(worker, unit, per):
+    """compiled reference (oracle/_ref) on the host cores: (A) one process as shipped (OpenMP
+    default), (B) P single-FFT-thread processes; best aggregate reported with the count used"""
+    import multiprocessing as mp
+    from oracle import ref
+    if not ref.available():
+        return None
+    ncpu = len(os.sched_getaffinity(0))
+    try:
+        q, per_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            ncpu = max(1, min(ncpu, int(int(q) / int(per_))))
+    except (OSError, ValueError):
+        pass
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        u, t = pool.map_async(worker, [(100, per)]).get(timeout=120)[0]
+    best = {"value": u / t, "cores": ncpu, "how": "A: 1 process, default OpenMP"}
+    os.environ["OMP_NUM_THREADS"] = "2"
+    p = min(ncpu, 16)
+    with ctx.Pool(p) as pool:
+        res = pool.map_async(worker, [(200 + i, per) for i in range(p)]).get(timeout=180)
+    os.environ.pop("OMP_NUM_THREADS")
+    rate = sum(r[0] for r in res) / max(r[1] for r in res)
+    if rate > best["value"]:
+        best = {"value": rate, "cores": p, "how": f"B: {p} processes x 1 FFT thread"}
+    return {"value": best["value"], "unit": unit, "cores": best["cores"], "kind": "reference",
+            "sample": f"{best['how']}, {per} unit(s) per process; visible cpus {ncpu}"}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
@@ -76,8 +137,12 @@ if __name__ == "__main__":
     ap.add_argument("--cwt-chunks", type=int, default=16)
     ap.add_argument("--cqt-clips", type=int, default=16)
     ap.add_argument("--only", default="")
+    ap.add_argument("--cpu-baseline", action="store_true")
     args = ap.parse_args()
-    for name, fn in (("cwt", cwt), ("cqt", cqt)):
+    for name, fn, worker, unit, per in (("cwt", cwt, _cpu_cwt, "chunks/s", 2), ("cqt", cqt, _cpu_cqt, "frames/s", 1)):
         if args.only and args.only != name:
             continue
-        print(json.dumps(fn(args)), flush=True)
+        out = fn(args)
+        if args.cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(worker, unit, per)
+        print(json.dumps(out), flush=True)
