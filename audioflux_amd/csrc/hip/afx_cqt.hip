@@ -16,9 +16,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
+#include "afx_pkmath.h"
 
 namespace {
 
@@ -252,6 +254,144 @@ __global__ __launch_bounds__(64 * WAVES) void k_cqt_octave_mfma(AfxCqtOctaveArgs
     }
 }
 
+// ---- matrix-core path, independent waves (N <= 512, one column tile) ------------------------
+// The whole kernel image G [N][32] sits in LDS (64 KB at N = 512) and every WAVE owns its own
+// 32-frame tiles: private signal window, full k range (N/2 MFMA steps, A and B operands by
+// ds_read_b32, double-buffered in registers eight steps ahead), results stored straight from
+// the accumulator -- no cross-wave reduction and no workgroup barrier after the one-time load
+// of G, so the waves of a CU drift apart and the MFMA pipe is fed while others stage or store.
+// Two accumulators (even / odd steps) break the dependent-issue chain; they are added at the end.
+// SHC > 0: the skew shift is a compile-time constant, so every operand read of the k loop is
+// `ds_read vbase offset:imm` -- no address arithmetic between the MFMAs (regular VALU work does
+// not overlap the matrix pipe of its own SIMD: measured 112 cycles per MFMA with ~5 VALU per
+// step, 72 with none, tools/micro/mfma_peak.hip).  SHC = 0: shift taken from the argument.
+template <int NBLK /* N / 16 */, int NV /* float4 window loads per lane */, int SHC>
+__global__ __launch_bounds__(NV > 10 ? 256 : 512) void k_cqt_octave_mfma_w(AfxCqtOctaveArgs a, int tilesPerClip,
+                                                           int SHrt, int sigWords) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = NBLK * 16;
+    const int SH = SHC > 0 ? SHC : SHrt;
+    float *Bl = reinterpret_cast<float *>(smem_raw);  // [N][32]
+    const int tid = threadIdx.x, lane = tid & 63, nth = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = nth >> 6;
+    float *sig = Bl + N * 32 + wave * sigWords;
+    const int i = lane & 31, kk = lane >> 5;
+    {   // G -> LDS, eight float4 in flight per thread (a load-store loop pays one memory
+        // latency per trip: 30 us for the 64 KB)
+        const float4 *src = reinterpret_cast<const float4 *>(a.timeKernel);
+        float4 *dstl = reinterpret_cast<float4 *>(Bl);
+        for (int e0 = tid; e0 < N * 8; e0 += 8 * nth) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[min(e0 + u * nth, N * 8 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * nth < N * 8) dstl[e0 + u * nth] = t[u];
+        }
+    }
+    __syncthreads();
+
+    const bool colOk = i < 2 * a.rows, colIm = i >= a.rows;
+    const int colOff = a.colBase + (colOk ? (colIm ? i - a.rows : i) : 0);
+    const float colScale = a.scale[colOff];
+    const int S = 31 * a.hop + N;
+    const int ih = i * a.hop;
+    const int laneBase = SH ? ih + (ih >> SH) + kk : 2 * (ih + kk);
+    const float *bl = Bl + kk * 32 + i;  // + 64 * step
+
+    const int totalTiles = tilesPerClip * a.batch;
+    const int stride = gridDim.x * waves;
+    float4 wnd[NV];
+    auto fetch = [&](int g) {
+        const int clip = g / tilesPerClip, t0 = (g - clip * tilesPerClip) * 32;
+        const float *x = a.x + (long long)clip * a.xStride;
+        const long long p0 = (long long)t0 * a.hop - (N >> 1);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int s = 4 * (lane + 64 * u);
+            const long long p = p0 + s;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s < S) {
+                if (p >= 0 && p + 3 < a.validLength) {
+                    v = *reinterpret_cast<const float4 *>(x + p);
+                } else {
+                    if (p >= 0 && p < a.validLength) v.x = x[p];
+                    if (p + 1 >= 0 && p + 1 < a.validLength) v.y = x[p + 1];
+                    if (p + 2 >= 0 && p + 2 < a.validLength) v.z = x[p + 2];
+                    if (p + 3 >= 0 && p + 3 < a.validLength) v.w = x[p + 3];
+                }
+            }
+            wnd[u] = v;
+        }
+    };
+    auto skew = [&](int s) { return SH ? s + (s >> SH) : 2 * s; };
+    int g = blockIdx.x * waves + wave;
+    if (g < totalTiles) fetch(g);
+    for (; g < totalTiles; g += stride) {
+        const int clip = g / tilesPerClip, t0 = (g - clip * tilesPerClip) * 32;
+        wave_lds_order();  // the MFMA reads of the previous tile are done
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int s = 4 * (lane + 64 * u);
+            if (s < S) {  // up to 3 samples past S land in the buffer's slack
+                sig[skew(s)] = wnd[u].x;
+                sig[skew(s + 1)] = wnd[u].y;
+                sig[skew(s + 2)] = wnd[u].z;
+                sig[skew(s + 3)] = wnd[u].w;
+            }
+        }
+        wave_lds_order();
+        if (g + stride < totalTiles) fetch(g + stride);
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        float av[2][8], bv[2][8];
+        auto load_block = [&](int blk, float (&ao)[8], float (&bo)[8]) {
+            // opaque per block: the 256 loop-invariant A addresses would otherwise be formed
+            // once, outside the tile loop, and live in (spilled) VGPRs
+            int lb = laneBase;
+            if (SHC == 0) asm volatile("" : "+v"(lb));
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int k0 = 16 * blk + 2 * s8;  // compile-time after unrolling
+                ao[s8] = sig[lb + (SHC > 0 ? k0 + (k0 >> SHC) : SH ? k0 + (k0 >> SH) : 2 * k0)];
+                bo[s8] = bl[32 * k0];
+            }
+        };
+        load_block(0, av[0], bv[0]);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            // the scheduler must not pull later blocks' reads up here (512 live operands)
+            __builtin_amdgcn_sched_barrier(0);
+            if (blk + 1 < NBLK) load_block(blk + 1, av[(blk + 1) & 1], bv[(blk + 1) & 1]);
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8 += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[blk & 1][s8], bv[blk & 1][s8], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[blk & 1][s8 + 1], bv[blk & 1][s8 + 1], acc1, 0, 0, 0);
+            }
+            // issue order inside the block: one MFMA, then the address adds and the two operand
+            // reads of one step of the NEXT block -- the reads land ~8 MFMAs (512 cycles) ahead
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                if (SHC == 0) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU (addresses)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
+        if (colOk) {
+            float *dst = (colIm ? a.outIm : a.outRe) + (long long)clip * a.outStride + colOff;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long frame = t0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (frame < a.timeLength) dst[frame * a.num] = ((acc0[r] + acc1[r]) * a.octScale) / colScale;
+            }
+        }
+    }
+}
+
 struct Taps32 {
     float h[32];
 };
@@ -416,12 +556,64 @@ static int dispatch_cqt_mfma(const AfxCqtOctaveArgs *a, void *stream) {
     return AFX_ERR_UNSUPPORTED;
 }
 
+
+// independent-wave variant: needs G in LDS (N <= 512, one column tile), float4-aligned rows
+template <int NBLK, int NV, int SHC>
+static int launch_cqt_mfma_w(const AfxCqtOctaveArgs *a, int SH, int sigWords, int waves, void *stream) {
+    const int N = NBLK * 16;
+    const size_t lds = sizeof(float) * ((size_t)N * 32 + (size_t)waves * sigWords);
+    const void *fn = reinterpret_cast<const void *>(k_cqt_octave_mfma_w<NBLK, NV, SHC>);
+    if (lds > 48 * 1024) AFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tilesPerClip = (a->timeLength + 31) / 32;
+    const long long total = (long long)tilesPerClip * (a->batch > 0 ? a->batch : 1);
+    if (total > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+    long long wgs = (total + waves - 1) / waves;
+    if (wgs > 256) wgs = 256;  // one persistent workgroup per CU
+    AfxCqtOctaveArgs b = *a;
+    if (b.batch <= 0) b.batch = 1;
+    hipLaunchKernelGGL((k_cqt_octave_mfma_w<NBLK, NV, SHC>), dim3((unsigned)wgs), dim3(64 * waves), lds,
+                       (hipStream_t)stream, b, tilesPerClip, SH, sigWords);
+    AFX_LAUNCH_CHECK("k_cqt_octave_mfma_w");
+    return AFX_OK;
+}
+
+static int try_cqt_mfma_w(const AfxCqtOctaveArgs *a, void *stream) {
+    const int N = 1 << a->radix2Exp;
+    if (a->colTiles != 1 || (N != 256 && N != 512) || getenv("AFX_CQT_KSPLIT")) return AFX_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(a->x) % 16) || (a->xStride % 4)) return AFX_ERR_UNSUPPORTED;
+    int SH = 0;
+    while (SH < 30 && !((a->hop >> SH) & 1)) ++SH;
+    const int S = 31 * a->hop + N;
+    const int sigWords = ((SH ? S + (S >> SH) : 2 * S) + 67) & ~3;
+    const int nv = (S + 255) / 256;  // float4 loads per lane
+    int waves = (int)((150 * 1024 - (size_t)N * 128) / (sizeof(float) * sigWords));
+    if (waves > (nv > 10 ? 4 : 8)) waves = nv > 10 ? 4 : 8;  // 18 window registers x 4: 256-thread build
+    if (waves < 4 || nv > 18) return AFX_ERR_UNSUPPORTED;
+    if (N == 512) {
+        // the octave ladder of the default plan (hop = N/4 halving down to 2): shift compiled in
+        if (a->hop == 128) return launch_cqt_mfma_w<32, 18, 7>(a, SH, sigWords, waves, stream);
+        if (a->hop == 64) return launch_cqt_mfma_w<32, 10, 6>(a, SH, sigWords, waves, stream);
+        if (a->hop == 32) return launch_cqt_mfma_w<32, 10, 5>(a, SH, sigWords, waves, stream);
+        if (a->hop == 16) return launch_cqt_mfma_w<32, 5, 4>(a, SH, sigWords, waves, stream);
+        if (a->hop == 8) return launch_cqt_mfma_w<32, 5, 3>(a, SH, sigWords, waves, stream);
+        if (a->hop == 4) return launch_cqt_mfma_w<32, 5, 2>(a, SH, sigWords, waves, stream);
+        if (a->hop == 2) return launch_cqt_mfma_w<32, 5, 1>(a, SH, sigWords, waves, stream);
+        if (nv <= 5) return launch_cqt_mfma_w<32, 5, 0>(a, SH, sigWords, waves, stream);
+        if (nv <= 10) return launch_cqt_mfma_w<32, 10, 0>(a, SH, sigWords, waves, stream);
+        return launch_cqt_mfma_w<32, 18, 0>(a, SH, sigWords, waves, stream);
+    }
+    if (nv <= 5) return launch_cqt_mfma_w<16, 5, 0>(a, SH, sigWords, waves, stream);
+    if (nv <= 10) return launch_cqt_mfma_w<16, 10, 0>(a, SH, sigWords, waves, stream);
+    return launch_cqt_mfma_w<16, 18, 0>(a, SH, sigWords, waves, stream);
+}
+
 extern "C" int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream) {
     if (a->radix2Exp < 1 || a->radix2Exp > 14) return AFX_ERR_UNSUPPORTED;
     if (a->timeLength <= 0) return AFX_OK;
     const int N = 1 << a->radix2Exp;
     if (a->timeKernel && a->colTiles >= 1 && a->colTiles <= 3) {
-        int st = AFX_ERR_UNSUPPORTED;
+        int st = try_cqt_mfma_w(a, stream);
+        if (st != AFX_ERR_UNSUPPORTED) return st;
         if (a->colTiles == 1) st = dispatch_cqt_mfma<1>(a, stream);
         else if (a->colTiles == 2) st = dispatch_cqt_mfma<2>(a, stream);
         else st = dispatch_cqt_mfma<3>(a, stream);
