@@ -148,6 +148,41 @@ class CQT:
                _util.fptr(out[i]))
         return np.ascontiguousarray(np.swapaxes(_util.restore_leading(out, lead), -1, -2))
 
+    def cqhc(self, m_data_arr, hc_num=20):
+        """(..., num, time) magnitudes/powers of the LAST cqt call (complex: power, as the
+        reference wrapper, python/audioflux/cqt.py:300-301) -> (..., hc_num, time)"""
+        m = np.asarray(m_data_arr)
+        if np.iscomplexobj(m):
+            m = np.abs(m) ** 2
+        m = _util.as_f32(np.swapaxes(m, -1, -2))
+        frames, lead = _util.flatten_leading(m, 2)
+        t = m.shape[-2]
+        out = np.zeros((frames.shape[0], t, hc_num), np.float32)
+        fn = self._lib.cqtObj_cqhc
+        fn.restype = None
+        fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p]
+        for i in range(frames.shape[0]):
+            fn(self._obj, _util.fptr(frames[i]), hc_num, _util.fptr(out[i]))
+        return np.ascontiguousarray(np.swapaxes(_util.restore_leading(out, lead), -1, -2))
+
+    def deconv(self, m_data_arr):
+        """(..., num, time) magnitudes of the LAST cqt call (complex: magnitude) ->
+        (timbre, pitch), each (..., num, time)"""
+        m = np.asarray(m_data_arr)
+        if np.iscomplexobj(m):
+            m = np.abs(m)
+        m = _util.as_f32(np.swapaxes(m, -1, -2))
+        frames, lead = _util.flatten_leading(m, 2)
+        tone = np.zeros_like(frames)
+        pitch = np.zeros_like(frames)
+        fn = self._lib.cqtObj_deconv
+        fn.restype = None
+        fn.argtypes = [c_void_p, _util.c_float_p, _util.c_float_p, _util.c_float_p]
+        for i in range(frames.shape[0]):
+            fn(self._obj, _util.fptr(frames[i]), _util.fptr(tone[i]), _util.fptr(pitch[i]))
+        return tuple(np.ascontiguousarray(np.swapaxes(_util.restore_leading(o, lead), -1, -2))
+                     for o in (tone, pitch))
+
     def __del__(self):
         if getattr(self, "_obj", None):
             fn = self._lib.cqtObj_free

@@ -392,6 +392,77 @@ __global__ __launch_bounds__(NV > 10 ? 256 : 512) void k_cqt_octave_mfma_w(AfxCq
     }
 }
 
+// ---- cqhc / deconv (src/cqt_algorithm.c:662-781) ---------------------------------------------
+// Per frame: the num magnitudes, zero padded to M = ceil_pow2(2 num), go through FFT_M; the
+// magnitude of that spectrum back through an inverse FFT gives the "timbre" cepstrum-like
+// sequence (real part), the spectrum divided by its magnitude gives the "pitch" sequence.
+//   cqhc  : out[j] = timbre[round(bpo log2(j + 1))], j < hcNum     (idx precomputed on the host)
+//   deconv: timbre[0..num), pitch[0..num)
+// One workgroup per frame, radix-2 DIF in LDS (M is 256 for 84 bins: a few kFLOP per frame).
+__device__ __forceinline__ void lds_fft_dif(float2 *s, int r, const float2 *tw, int tid, int nth) {
+    const int N = 1 << r;
+    for (int st = 0; st < r; ++st) {
+        const int half = N >> (st + 1);
+        for (int j = tid; j < (N >> 1); j += nth) {
+            const int pos = j & (half - 1);
+            const int i0 = ((j - pos) << 1) + pos;
+            const int i1 = i0 + half;
+            const float2 u = s[i0], v = s[i1];
+            const float2 w = tw[pos << st];
+            const float dx = u.x - v.x, dy = u.y - v.y;
+            s[i0] = make_float2(u.x + v.x, u.y + v.y);
+            s[i1] = make_float2(dx * w.x - dy * w.y, dx * w.y + dy * w.x);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_cqt_deconv(const float *__restrict__ in, long long rows, int num, int r,
+                             const float2 *__restrict__ tw, const int *__restrict__ hcIdx, int hcNum,
+                             float *__restrict__ outTimbre, float *__restrict__ outPitch,
+                             float *__restrict__ outHc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = 1 << r;
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);  // spectrum, then the pitch transform
+    float2 *t = s + M;                                  // magnitude transform
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const long long frame = blockIdx.x;
+    const float *x = in + frame * num;
+    for (int i = tid; i < M; i += nth) s[i] = make_float2(i < num ? x[i] : 0.f, 0.f);
+    __syncthreads();
+    lds_fft_dif(s, r, tw, tid, nth);  // X[k] at s[brev(k)]
+    const float invM = 1.f / (float)M;
+    for (int k = tid; k < M; k += nth) {
+        const float2 c = s[brev(k, r)];
+        const float mag = sqrtf(c.x * c.x + c.y * c.y);           // __vcabs
+        t[k] = make_float2(mag, 0.f);                              // conj of a real value
+    }
+    __syncthreads();
+    if (outPitch) {  // X / max(|X|, 1e-16), conjugated for the inverse transform
+        for (int k = tid; k < M; k += nth) {
+            const int b = brev(k, r);
+            if (b >= k) {  // in-place bit-reversal permutation: swap pairs once
+                const float2 ck = s[b], cb = s[k];
+                float mk = t[k].x, mb = t[b].x;
+                if (mk < 1e-16f) mk = 1e-16f;
+                if (mb < 1e-16f) mb = 1e-16f;
+                s[k] = make_float2(ck.x / mk, -(ck.y / mk));
+                s[b] = make_float2(cb.x / mb, -(cb.y / mb));
+            }
+        }
+        __syncthreads();
+    }
+    lds_fft_dif(t, r, tw, tid, nth);  // IFFT(mag)[n] = conj(FFT(mag))[n] / M: real part Re(.)/M
+    if (outTimbre)
+        for (int n = tid; n < num; n += nth) outTimbre[frame * num + n] = t[brev(n, r)].x * invM;
+    if (outHc)
+        for (int j = tid; j < hcNum; j += nth) outHc[frame * hcNum + j] = t[brev(hcIdx[j], r)].x * invM;
+    if (outPitch) {
+        lds_fft_dif(s, r, tw, tid, nth);
+        for (int n = tid; n < num; n += nth) outPitch[frame * num + n] = s[brev(n, r)].x * invM;
+    }
+}
+
 struct Taps32 {
     float h[32];
 };
@@ -643,6 +714,26 @@ extern "C" int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, 
                        dim3(256), 0, (hipStream_t)stream, x, srcLen, xStride, y, dstLen, yStride, tp,
                        sqrtRatio);
     AFX_LAUNCH_CHECK("k_cqt_decimate");
+    return AFX_OK;
+}
+
+extern "C" int afxk_cqt_deconv(const float *in, long long rows, int num, int radix2Exp,
+                               const float *twiddle, const int *hcIdx, int hcNum, float *outTimbre,
+                               float *outPitch, float *outHc, void *stream) {
+    if (rows <= 0) return AFX_OK;
+    if (radix2Exp < 1 || radix2Exp > 12 || rows > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+    const int M = 1 << radix2Exp;
+    int threads = M / 2;
+    if (threads < 64) threads = 64;
+    if (threads > 256) threads = 256;
+    const size_t lds = (size_t)2 * M * sizeof(float2);
+    if (lds > 48 * 1024)
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_deconv),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cqt_deconv, dim3((unsigned)rows), dim3(threads), lds, (hipStream_t)stream, in, rows,
+                       num, radix2Exp, reinterpret_cast<const float2 *>(twiddle), hcIdx, hcNum, outTimbre,
+                       outPitch, outHc);
+    AFX_LAUNCH_CHECK("k_cqt_deconv");
     return AFX_OK;
 }
 

@@ -153,6 +153,12 @@ int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
 int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, int dstLen,
                       long long yStride, int batch, const float *taps32, float sqrtRatio,
                       void *stream);
+/* cqhc / deconv: in[rows, num] -> timbre / pitch [rows, num] and/or hc [rows, hcNum]
+ * (hcIdx[hcNum]: positions in the timbre sequence); transform length 2^radix2Exp >= 2 num;
+ * twiddle: device [M/2] float2 */
+int afxk_cqt_deconv(const float *in, long long rows, int num, int radix2Exp, const float *twiddle,
+                    const int *hcIdx, int hcNum, float *outTimbre, float *outPitch, float *outHc,
+                    void *stream);
 int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
                     const unsigned char *fold, int chromaNum, int isMag, int normType, float *out,
                     void *stream);

@@ -49,6 +49,8 @@ struct OpaqueCQT {
     float *dIn;              /* chroma / cqcc staging */
     size_t capIn;
     float *dDct;             /* [num,num] for cqcc */
+    float *dDevTw;           /* twiddles of the cqhc / deconv transform (length 2^devRadix) */
+    int devRadix;
     int status;
 };
 
@@ -635,14 +637,70 @@ void cqtObj_cqcc(CQTObj o, float *mDataArr1, int ccNum, CepstralRectifyType *rec
     if (st != AFX_OK) fail(o, st, "cqtObj_cqcc");
 }
 
-void cqtObj_cqhc(CQTObj o, float *mDataArr1, int hcNum, float *mDataArr2) {
-    (void)o; (void)mDataArr1; (void)hcNum; (void)mDataArr2;
-    afxdev_set_error("cqtObj_cqhc is not implemented by the MI355X backend (outputs untouched)");
+/* transform length and twiddles of cqhc / deconv (_cqtObj_dealDeconv, cqt_algorithm.c:783-843) */
+static int deconv_prepare(CQTObj o) {
+    if (o->dDevTw) return AFX_OK;
+    const int M = afx_ceil_pow2(2 * o->num);
+    o->devRadix = afx_log2_exact(M);
+    float *tw = afx_twiddle_table(M);
+    if (!tw) return AFX_ERR_NOMEM;
+    int st = afxdev_malloc((void **)&o->dDevTw, sizeof(float) * (size_t)(M < 2 ? 2 : M));
+    if (st == AFX_OK) st = afxdev_h2d(o->dDevTw, tw, sizeof(float) * (size_t)(M < 2 ? 2 : M), o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    free(tw);
+    return st;
 }
 
+void cqtObj_cqhc(CQTObj o, float *mDataArr1, int hcNum, float *mDataArr2) {
+    if (!o) {
+        afxdev_set_error("cqtObj_cqhc: NULL object");
+        return;
+    }
+    const int T = o->timeLength;
+    if (T <= 0 || hcNum < 1 || !mDataArr1 || !mDataArr2) return;
+    int st = deconv_prepare(o);
+    const int M = 1 << o->devRadix;
+    int *idx = (int *)malloc(sizeof(int) * (size_t)hcNum);
+    if (!idx) st = AFX_ERR_NOMEM;
+    for (int j = 0; j < hcNum && st == AFX_OK; j++) {
+        int v = (int)roundf(o->binPerOctave * log2f((float)(j + 1))); /* cqt_algorithm.c:706 */
+        if (v > M - 1) v = M - 1; /* the reference reads past its buffer here */
+        idx[j] = v;
+    }
+    const size_t inB = sizeof(float) * (size_t)T * o->num, outB = sizeof(float) * (size_t)T * hcNum;
+    const size_t idxOff = ((inB + outB) + 15) & ~(size_t)15;
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dIn, &o->capIn, idxOff + sizeof(int) * (size_t)hcNum);
+    float *dA = o->dIn, *dC = o->dIn + (size_t)T * o->num;
+    int *dIdx = (int *)((char *)o->dIn + idxOff);
+    if (st == AFX_OK) st = afxdev_h2d(dA, mDataArr1, inB, o->stream);
+    if (st == AFX_OK) st = afxdev_h2d(dIdx, idx, sizeof(int) * (size_t)hcNum, o->stream);
+    if (st == AFX_OK)
+        st = afxk_cqt_deconv(dA, T, o->num, o->devRadix, o->dDevTw, dIdx, hcNum, NULL, NULL, dC, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mDataArr2, dC, outB, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    free(idx);
+    if (st != AFX_OK) fail(o, st, "cqtObj_cqhc");
+}
+
+/* mDataArr1 [T,num] magnitudes -> mDataArr2 timbre (formant), mDataArr3 pitch, both [T,num] */
 void cqtObj_deconv(CQTObj o, float *mDataArr1, float *mDataArr2, float *mDataArr3) {
-    (void)o; (void)mDataArr1; (void)mDataArr2; (void)mDataArr3;
-    afxdev_set_error("cqtObj_deconv is not implemented by the MI355X backend (outputs untouched)");
+    if (!o) {
+        afxdev_set_error("cqtObj_deconv: NULL object");
+        return;
+    }
+    const int T = o->timeLength;
+    if (T <= 0 || !mDataArr1 || !mDataArr2 || !mDataArr3) return;
+    int st = deconv_prepare(o);
+    const size_t inB = sizeof(float) * (size_t)T * o->num;
+    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dIn, &o->capIn, 3 * inB);
+    float *dA = o->dIn, *dT = o->dIn + (size_t)T * o->num, *dP = o->dIn + 2 * (size_t)T * o->num;
+    if (st == AFX_OK) st = afxdev_h2d(dA, mDataArr1, inB, o->stream);
+    if (st == AFX_OK)
+        st = afxk_cqt_deconv(dA, T, o->num, o->devRadix, o->dDevTw, NULL, 0, dT, dP, NULL, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mDataArr2, dT, inB, o->stream);
+    if (st == AFX_OK) st = afxdev_d2h(mDataArr3, dP, inB, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    if (st != AFX_OK) fail(o, st, "cqtObj_deconv");
 }
 
 void cqtObj_free(CQTObj o) {
@@ -663,6 +721,7 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dOut);
     afxdev_free(o->dIn);
     afxdev_free(o->dDct);
+    afxdev_free(o->dDevTw);
     afxdev_stream_destroy(o->stream);
     free(o->freBandArr);
     free(o->sLenArr);

@@ -197,6 +197,10 @@ class RefCQT:
         L.cqtObj_chroma.argtypes = [C.c_void_p, ip, ip, ip, fp, fp, fp]
         L.cqtObj_cqcc.restype = None
         L.cqtObj_cqcc.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
+        L.cqtObj_cqhc.restype = None
+        L.cqtObj_cqhc.argtypes = [C.c_void_p, fp, C.c_int, fp]
+        L.cqtObj_deconv.restype = None
+        L.cqtObj_deconv.argtypes = [C.c_void_p, fp, fp, fp]
         L.cqtObj_free.argtypes = [C.c_void_p]
 
     def fft_length(self):
@@ -225,6 +229,21 @@ class RefCQT:
         out = np.zeros((mag.shape[0], cc_num), np.float32)
         self.L.cqtObj_cqcc(self.obj, _f(mag), cc_num, _pi(rectify), _f(out))
         return out
+
+    def cqhc(self, mag, hc_num=20):
+        """mag [T,num] of the LAST cqt call -> [T,hc_num] (src/cqt_algorithm.c:662-711)"""
+        mag = np.ascontiguousarray(mag, np.float32)
+        out = np.zeros((mag.shape[0], hc_num), np.float32)
+        self.L.cqtObj_cqhc(self.obj, _f(mag), hc_num, _f(out))
+        return out
+
+    def deconv(self, mag):
+        """mag [T,num] -> (timbre [T,num], pitch [T,num]) (src/cqt_algorithm.c:718-781)"""
+        mag = np.ascontiguousarray(mag, np.float32)
+        tone = np.zeros_like(mag)
+        pitch = np.zeros_like(mag)
+        self.L.cqtObj_deconv(self.obj, _f(mag), _f(tone), _f(pitch))
+        return tone, pitch
 
     def __del__(self):
         if getattr(self, "obj", None):

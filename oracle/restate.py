@@ -374,6 +374,40 @@ def cqt(x, num=84, samplate=32000, min_fre=32.703196, bpo=12, window_type=1, nor
     return out
 
 
+def cqt_deconv(mag):
+    """cqtObj_deconv (src/cqt_algorithm.c:718-781): mag [T,num] -> (timbre, pitch) [T,num].
+    Per frame: zero pad to M = ceil_pow2(2 num), F = FFT_M, a = |F|; timbre = Re IFFT(a),
+    pitch = Re IFFT(F / max(a, 1e-16)); the first num samples of each are kept."""
+    mag = np.asarray(mag, np.float64)
+    t, num = mag.shape
+    m = 1
+    while m < 2 * num:
+        m *= 2
+    d = np.zeros((t, m))
+    d[:, :num] = mag
+    f = np.fft.fft(d, axis=1)
+    a = np.abs(f)
+    timbre = np.real(np.fft.ifft(a, axis=1))
+    pitch = np.real(np.fft.ifft(f / np.maximum(a, 1e-16), axis=1))
+    return timbre, pitch
+
+
+def cqt_cqhc(mag, bpo=12, hc_num=20):
+    """cqtObj_cqhc (src/cqt_algorithm.c:662-711): timbre sequence sampled at
+    round(bpo * log2(j + 1)), j < hc_num (float32 log2f / roundf as the reference)"""
+    mag = np.asarray(mag, np.float64)
+    t, num = mag.shape
+    m = 1
+    while m < 2 * num:
+        m *= 2
+    d = np.zeros((t, m))
+    d[:, :num] = mag
+    timbre = np.real(np.fft.ifft(np.abs(np.fft.fft(d, axis=1)), axis=1))
+    idx = [int(np.floor(np.float32(bpo) * np.log2(np.float32(j + 1)).astype(np.float32) + np.float32(0.5)))
+           for j in range(hc_num)]
+    return timbre[:, idx]
+
+
 def chroma_fold(chroma_num, num, bpo, min_fre=32.703196):
     """0/1 matrix [chroma_num, num] (chroma_filterBank.c:176-264, including its rotation quirk)"""
     n = bpo // chroma_num

@@ -78,7 +78,10 @@ def main():
         if c["bin_per_octave"] == 12:
             for cname, (cn, dt, nt) in cases.CQT_CHROMA.items():
                 cq_out[f"{name}/chroma_{cname}"] = o.chroma(re, im, cn, dt, nt)
-        cq_out[f"{name}/cqcc"] = o.cqcc(np.abs(re + 1j * im), 13, 0)
+        mag = np.abs(re + 1j * im).astype(np.float32)
+        cq_out[f"{name}/cqcc"] = o.cqcc(mag, 13, 0)
+        cq_out[f"{name}/cqhc"] = o.cqhc(mag, 20)
+        cq_out[f"{name}/timbre"], cq_out[f"{name}/pitch"] = o.deconv(mag)
     np.savez_compressed(os.path.join(HERE, "cqt.npz"), **cq_out)
     cw_out = {}
     for name, c in cases.CWT_CASES.items():

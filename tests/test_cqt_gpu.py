@@ -41,6 +41,12 @@ def test_cqt_chroma_cqcc_match_golden(name, golden_dir):
             assert_parity(ch.T, gold[f"{name}/chroma_{cname}"], tol, f"{name}/chroma_{cname}")
     cc = o.cqcc(np.abs(q), 13)
     assert_parity(cc.T, gold[f"{name}/cqcc"], TOL, f"{name}/cqcc")
+    # cqhc / deconv on the reference's own magnitudes (isolates them from the cqt error)
+    mag = np.abs(want).astype(np.float32).T          # (num, T)
+    assert_parity(o.cqhc(mag, 20).T, gold[f"{name}/cqhc"], TOL, f"{name}/cqhc")
+    tone, pitch = o.deconv(mag)
+    assert_parity(tone.T, gold[f"{name}/timbre"], TOL, f"{name}/timbre")
+    assert_parity(pitch.T, gold[f"{name}/pitch"], 2e-5, f"{name}/pitch")
 
 
 def test_cqt_tone_lands_on_its_bin():

@@ -121,6 +121,12 @@ def test_restatement_matches_golden_cqt(name, golden_dir):
     assert_parity(restate.cqt_chroma(q, 6, 12, "power", "min", c["min_fre"]),
                   gold[f"{name}/chroma_six_min"], 5e-5, "chroma6")  # divides by the frame MINIMUM: ill-conditioned
     assert_parity(restate.xxcc(np.abs(q), 13), gold[f"{name}/cqcc"], 1e-5, "cqcc")
+    # cqhc / deconv restated on the reference's own magnitudes
+    mag = np.abs(want).astype(np.float32)
+    assert_parity(restate.cqt_cqhc(mag, 12, 20), gold[f"{name}/cqhc"], 1e-5, "cqhc")
+    tone, pitch = restate.cqt_deconv(mag)
+    assert_parity(tone[:, :c["num"]], gold[f"{name}/timbre"], 1e-5, "timbre")
+    assert_parity(pitch[:, :c["num"]], gold[f"{name}/pitch"], 2e-5, "pitch")
 
 
 @pytest.mark.parametrize("name,wavelet,gb", [("morlet_84_pad", "morlet", (6.0, 2.0)),
