@@ -55,8 +55,12 @@ void cqtObj_chroma(CQTObj cqtObj, int *chromaNum, SpectralDataType *dataType,
 void cqtObj_cqcc(CQTObj cqtObj, float *mDataArr1, int ccNum,
                  CepstralRectifyType *rectifyType, float *mDataArr2);
 
-/* NOT IMPLEMENTED in this backend yet: both print
- * a diagnostic to stderr and leave the outputs untouched. */
+/* harmonic coefficients: mDataArr1 [T,num] (magnitude or power of the LAST cqt call) ->
+ * mDataArr2 [T,hcNum]: the frame, zero padded to ceil_pow2(2 num), through FFT -> |.| ->
+ * inverse FFT, sampled at round(binPerOctave * log2(j + 1)).
+ * replaces cqtObj_cqhc, cqt_algorithm.c:662-711.
+ * cqtObj_deconv: same transform -> mDataArr2 "timbre" [T,num] (Re IFFT |F|) and mDataArr3
+ * "pitch" [T,num] (Re IFFT F / max(|F|, 1e-16)); replaces cqt_algorithm.c:718-781 */
 void cqtObj_cqhc(CQTObj cqtObj, float *mDataArr1, int hcNum, float *mDataArr2);
 void cqtObj_deconv(CQTObj cqtObj, float *mDataArr1, float *mDataArr2, float *mDataArr3);
 
