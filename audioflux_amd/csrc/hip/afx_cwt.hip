@@ -209,6 +209,8 @@ __device__ __forceinline__ v2 ld2(const float2 *p) {
     return r;
 }
 
+constexpr int ROWS_PER_WAVE = 4;
+
 __global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2 *__restrict__ Xt,
                                                          const float *__restrict__ bankT, int isDet,
                                                          float2 *__restrict__ B) {
@@ -216,75 +218,106 @@ __global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
-    const int k1 = blockIdx.x * 4 + wave, j = blockIdx.y;
-    const long long row = (long long)k1 * L2;
-    const float2 *xr = Xt + (long long)blockIdx.z * L + row;
-    const float *bank = bankT + (long long)j * L + row;
-    float2 *out = B + ((long long)blockIdx.z * g.num + j) * L + row;
+    const int j = blockIdx.y;
+    // wave w of workgroup b owns rows k1 = 16 b + w + 4 it, it < ROWS_PER_WAVE
+    const int k1base = blockIdx.x * (4 * ROWS_PER_WAVE) + wave;
+    const float2 *xc = Xt + (long long)blockIdx.z * L;
+    const float *bankj = bankT + (long long)j * L;
+    float2 *outj = B + ((long long)blockIdx.z * g.num + j) * L;
     v2 *e = ex[wave];
 
-    // every global operand of the row is requested up front (data, wavelet, three twiddle
-    // sets: 39 loads in flight); left to the scheduler they are issued next to their use and
-    // the row pays ~25 serial L2 latencies
-    float2 xv[8], t1[8], t2[8], wus[8];
-    float bw[8];
+    // The wavelet is zero outside k2 in [lo, hi): a 64-wide block outside that range reads ONE
+    // known-zero entry of the row instead of its own 256 bytes (the products are exact zeros
+    // either way; the select keeps the code branch-free) -- the bank read of a chunk shrinks
+    // from 44 MB to the support of the wavelets.
+    const int lo = g.support ? g.support[2 * j] : 0, hi = g.support ? g.support[2 * j + 1] : L2;
+    const int zeroAt = lo > 0 ? 0 : (hi < L2 ? L2 - 1 : -1);
+    int boff[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        xv[a] = xr[64 * a + lane];
-        bw[a] = bank[64 * a + lane];
-    }
+    for (int a = 0; a < 8; ++a)
+        boff[a] = (zeroAt >= 0 && (64 * a + 64 <= lo || 64 * a >= hi)) ? zeroAt : 64 * a + lane;
+
+    // twiddle tables of the transform: once per wave
+    float2 t1[8], t2[8];
 #pragma unroll
     for (int d = 1; d < 8; ++d) {
         t1[d] = g.fastTw[64 * d + lane];                 // W_512^(lane d)
         t2[d] = g.fastTw[8 * 64 + 8 * d + (lane & 7)];   // W_64^(c d)
     }
-    const float2 wlv = g.tw[lane * k1];                  // W_L^(lane k1), lane k1 < 2^14 < L/2
+    // operands of one row: data, wavelet, four-step twiddles (one gathered + eight wave-uniform
+    // table values instead of eight gathers); the NEXT row's are requested before this row's
+    // butterflies start, so a wave never waits on memory after its first row
+    float2 xv[8], wus[8], wlv, xvN[8], wusN[8], wlvN;
+    float bw[8], bwN[8];
+    auto request = [&](int k1, float2 (&x)[8], float (&bq)[8], float2 (&wu)[8], float2 &wl) {
+        const long long row = (long long)k1 * L2;
 #pragma unroll
-    for (int d2 = 0; d2 < 8; ++d2) wus[d2] = g.tw[(64 * k1 * d2) & ((1 << 16) - 1)];  // W_L^(m mod L/2)
-    __builtin_amdgcn_sched_barrier(0);
+        for (int a = 0; a < 8; ++a) {
+            x[a] = xc[row + 64 * a + lane];
+            bq[a] = bankj[row + boff[a]];
+        }
+        wl = g.tw[lane * k1];  // W_L^(lane k1), lane k1 < 2^14 < L/2
+#pragma unroll
+        for (int d2 = 0; d2 < 8; ++d2) wu[d2] = g.tw[(64 * k1 * d2) & ((1 << 16) - 1)];  // W_L^(m mod L/2)
+    };
+    request(k1base, xvN, bwN, wusN, wlvN);
+#pragma unroll
+    for (int it = 0; it < ROWS_PER_WAVE; ++it) {
+        const int k1 = k1base + 4 * it;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            xv[a] = xvN[a];
+            bw[a] = bwN[a];
+            wus[a] = wusN[a];
+        }
+        wlv = wlvN;
+        if (it + 1 < ROWS_PER_WAVE) request(k1 + 4, xvN, bwN, wusN, wlvN);
+        __builtin_amdgcn_sched_barrier(0);
 
-    v2 r[8];
+        v2 r[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        // conj(X * wavelet): IFFT through a forward FFT (cwt_algorithm.c:428-435)
-        if (!isDet) r[a] = v2{bw[a] * xv[a].x, -(bw[a] * xv[a].y)};
-        else r[a] = v2{-bw[a] * xv[a].y, -(bw[a] * xv[a].x)};
-    }
-    dft8(r);  // r[rev8(d0)] = sum_a z[64 a + l] W_8^(a d0)
+        for (int a = 0; a < 8; ++a) {
+            // conj(X * wavelet): IFFT through a forward FFT (cwt_algorithm.c:428-435)
+            if (!isDet) r[a] = v2{bw[a] * xv[a].x, -(bw[a] * xv[a].y)};
+            else r[a] = v2{-bw[a] * xv[a].y, -(bw[a] * xv[a].x)};
+        }
+        dft8(r);  // r[rev8(d0)] = sum_a z[64 a + l] W_8^(a d0)
 #pragma unroll
-    for (int d0 = 1; d0 < 8; ++d0) r[rev8(d0)] = cmul(r[rev8(d0)], v2{t1[d0].x, t1[d0].y});
-    // exchange 1: lane l = 8 b + c, register d0  ->  lane 8 d0 + c, register b
-    {
-        const int b = lane >> 3, c = lane & 7;
+        for (int d0 = 1; d0 < 8; ++d0) r[rev8(d0)] = cmul(r[rev8(d0)], v2{t1[d0].x, t1[d0].y});
+        // exchange 1: lane l = 8 b + c, register d0  ->  lane 8 d0 + c, register b
+        {
+            const int b = lane >> 3, c = lane & 7;
+            wave_lds_order();  // the previous row's reads of the image are done
 #pragma unroll
-        for (int d0 = 0; d0 < 8; ++d0) e[(8 * d0 + c) * RP + b] = r[rev8(d0)];
-        wave_lds_order();
+            for (int d0 = 0; d0 < 8; ++d0) e[(8 * d0 + c) * RP + b] = r[rev8(d0)];
+            wave_lds_order();
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) r[bb] = e[lane * RP + bb];
-    }
-    dft8(r);  // r[rev8(d1)], lane = 8 d0 + c
+            for (int bb = 0; bb < 8; ++bb) r[bb] = e[lane * RP + bb];
+        }
+        dft8(r);  // r[rev8(d1)], lane = 8 d0 + c
 #pragma unroll
-    for (int d1 = 1; d1 < 8; ++d1) r[rev8(d1)] = cmul(r[rev8(d1)], v2{t2[d1].x, t2[d1].y});
-    // exchange 2: lane 8 d0 + c, register d1  ->  lane d0 + 8 d1, register c
-    {
-        const int d0 = lane >> 3, c = lane & 7;
-        wave_lds_order();  // the reads of exchange 1 are done before the image is overwritten
+        for (int d1 = 1; d1 < 8; ++d1) r[rev8(d1)] = cmul(r[rev8(d1)], v2{t2[d1].x, t2[d1].y});
+        // exchange 2: lane 8 d0 + c, register d1  ->  lane d0 + 8 d1, register c
+        {
+            const int d0 = lane >> 3, c = lane & 7;
+            wave_lds_order();  // the reads of exchange 1 are done before the image is overwritten
 #pragma unroll
-        for (int d1 = 0; d1 < 8; ++d1) e[(d0 + 8 * d1) * RP + c] = r[rev8(d1)];
-        wave_lds_order();
+            for (int d1 = 0; d1 < 8; ++d1) e[(d0 + 8 * d1) * RP + c] = r[rev8(d1)];
+            wave_lds_order();
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) r[cc] = e[lane * RP + cc];
-    }
-    dft8(r);  // r[rev8(d2)] = Z[m1 = lane + 64 d2]
-    // four-step twiddle W_L^(m1 k1) = W_L^(lane k1) W_L^(64 k1 d2): one gathered and eight
-    // wave-uniform table values instead of eight gathers
-    const v2 wl = {wlv.x, wlv.y};
+            for (int cc = 0; cc < 8; ++cc) r[cc] = e[lane * RP + cc];
+        }
+        dft8(r);  // r[rev8(d2)] = Z[m1 = lane + 64 d2]
+        // four-step twiddle W_L^(m1 k1) = W_L^(lane k1) W_L^(64 k1 d2)
+        const v2 wl = {wlv.x, wlv.y};
+        float2 *out = outj + (long long)k1 * L2;
 #pragma unroll
-    for (int d2 = 0; d2 < 8; ++d2) {
-        const float sgn = ((64 * k1 * d2) >> 16) & 1 ? -1.f : 1.f;  // W_L^(m + L/2) = -W_L^m
-        const v2 w = cmul(wl, v2{wus[d2].x * sgn, wus[d2].y * sgn});
-        const v2 o = cmul(r[rev8(d2)], w);
-        out[64 * d2 + lane] = make_float2(o.x, o.y);
+        for (int d2 = 0; d2 < 8; ++d2) {
+            const float sgn = ((64 * k1 * d2) >> 16) & 1 ? -1.f : 1.f;  // W_L^(m + L/2) = -W_L^m
+            const v2 w = cmul(wl, v2{wus[d2].x * sgn, wus[d2].y * sgn});
+            const v2 o = cmul(r[rev8(d2)], w);
+            out[64 * d2 + lane] = make_float2(o.x, o.y);
+        }
     }
 }
 
@@ -379,7 +412,7 @@ extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const 
     g.num = num;
     const int L1 = 1 << d->r1, L2 = 1 << d->r2;
     if (d->fastTw && d->r1 == 8 && d->r2 == 9 && !getenv("AFX_NO_FUSED")) {
-        hipLaunchKernelGGL(k_cwt_inv_rows512, dim3(L1 / 4, num, chunks), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_cwt_inv_rows512, dim3(L1 / (4 * ROWS_PER_WAVE), num, chunks), dim3(256), 0, (hipStream_t)stream,
                            g, reinterpret_cast<const float2 *>(Xt), bankT, isDet,
                            reinterpret_cast<float2 *>(scratchB));
         AFX_LAUNCH_CHECK("k_cwt_inv_rows512");
