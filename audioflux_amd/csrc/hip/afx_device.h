@@ -205,10 +205,12 @@ typedef struct {
     const float *x;
     long long clipStride;
     int batch, dataLength, timeLength, hop;
-    int specMap;    /* 0 |S|^2, 1 |S|, 2 |S|^(2*normValue)                  */
+    int specMap;    /* 0 |S|^2, 1 |S|, 2 |S|^(2*normValue); complex results:
+                     * 3 S, 4 S^2 (real plane -> out, imaginary plane -> outIm) */
     int postPow;    /* 1: powf(result, normValue)                           */
     float normValue;
     float *out;     /* device [batch*timeLength, num]                       */
+    float *outIm;   /* device, same shape; complex result modes only        */
 } AfxMelFusedArgs;
 
 /* variant index able to run (radix2Exp, tapsA, tapsB), or -1 */

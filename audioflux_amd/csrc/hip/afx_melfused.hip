@@ -92,6 +92,7 @@ struct KArgs {
     int specMap, postPow;
     float normValue;
     float *out;
+    float *outIm;  // complex result mode only
     int num;
 };
 
@@ -122,11 +123,35 @@ __device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w /* 0.5 W_2048^k */, 
     pq = y.x * y.x + y.y * y.y;
 }
 
+// complex result mode (bftObj_setResultType 0): the spectrum value itself (sq = false:
+// data type MAG) or its complex square (sq = true: POWER, __mcsquare, flux_complex.c:469-503)
+// of bins k and 1024-k; the bank is real, so real and imaginary parts go through it separately
+__device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &kr, float &ki, float &qr,
+                                             float &qi) {
+    const v2 e2 = pk_add_conj(A, B);
+    const v2 d = pk_sub_conj(A, B);
+    const v2 wo = cmul_mi(d, w);
+    const v2 x = e2 * 0.5f + wo;  // X[k]
+    const v2 y = e2 * 0.5f - wo;  // conj(X[1024-k])
+    if (sq) {
+        kr = x.x * x.x - x.y * x.y;
+        ki = 2.f * (x.x * x.y);
+        qr = y.x * y.x - y.y * y.y;
+        qi = -2.f * (y.x * y.y);
+    } else {
+        kr = x.x;
+        ki = x.y;
+        qr = y.x;
+        qi = -y.y;
+    }
+}
+
 // GENERAL = false: plain |S|^2 (the hot configuration; no sqrt/pow code in the loop)
+// CPLX (with GENERAL): complex result, two passes of the filter-bank stage (real, imaginary)
 // SHIFT: consecutive frames of a clip overlap; with hop = 128*SHIFT samples the next
 // frame's register image is the current one moved down by SHIFT registers, so only SHIFT
 // new float2 per lane are fetched per frame (SHIFT = 0: every frame is fetched whole)
-template <int TA, int TB, bool GENERAL, int SHIFT>
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX = false>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -263,6 +288,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
 
         // ---- 3. last radix-4 + real-input split -> spectrum values in registers -------
         float pk[20], pq[20];
+        float pkI[CPLX ? 20 : 1], pqI[CPLX ? 20 : 1];  // imaginary parts (complex result mode)
         // every LDS operand of this stage is requested up front (24 + 6 reads in flight)
         v2 zin[2][8], w3[2][4];
 #if !(AFX_V & 4)
@@ -307,18 +333,33 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                 b2 = self ? zb2 : zb1;
                 b3 = self ? zb1 : zb0;
             }
-            split_pair(za0, b0, w3[s][0], pk[8 * s + 0], pq[8 * s + 0]);
-            split_pair(za1, b1, w3[s][1], pk[8 * s + 1], pq[8 * s + 1]);
-            split_pair(za2, b2, w3[s][2], pk[8 * s + 2], pq[8 * s + 2]);
-            split_pair(za3, b3, w3[s][3], pk[8 * s + 3], pq[8 * s + 3]);
+            if (CPLX) {
+                const bool sq = a.specMap == 4;
+                split_pair_c(za0, b0, w3[s][0], sq, pk[8 * s + 0], pkI[CPLX ? 8 * s + 0 : 0], pq[8 * s + 0], pqI[CPLX ? 8 * s + 0 : 0]);
+                split_pair_c(za1, b1, w3[s][1], sq, pk[8 * s + 1], pkI[CPLX ? 8 * s + 1 : 0], pq[8 * s + 1], pqI[CPLX ? 8 * s + 1 : 0]);
+                split_pair_c(za2, b2, w3[s][2], sq, pk[8 * s + 2], pkI[CPLX ? 8 * s + 2 : 0], pq[8 * s + 2], pqI[CPLX ? 8 * s + 2 : 0]);
+                split_pair_c(za3, b3, w3[s][3], sq, pk[8 * s + 3], pkI[CPLX ? 8 * s + 3 : 0], pq[8 * s + 3], pqI[CPLX ? 8 * s + 3 : 0]);
+            } else {
+                split_pair(za0, b0, w3[s][0], pk[8 * s + 0], pq[8 * s + 0]);
+                split_pair(za1, b1, w3[s][1], pk[8 * s + 1], pq[8 * s + 1]);
+                split_pair(za2, b2, w3[s][2], pk[8 * s + 2], pq[8 * s + 2]);
+                split_pair(za3, b3, w3[s][3], pk[8 * s + 3], pq[8 * s + 3]);
+            }
         }
         {   // base 128 mirrors itself: bins 128, 384 and their partners 896, 640 (every lane
             // computes them, lane 0 stores them)
             dft4(zc0, zc1, zc2, zc3);
-            split_pair(zc0, zc3, wc0, pk[16], pq[16]);
-            split_pair(zc1, zc2, wc1, pk[17], pq[17]);
+            if (CPLX) {
+                const bool sq = a.specMap == 4;
+                split_pair_c(zc0, zc3, wc0, sq, pk[16], pkI[CPLX ? 16 : 0], pq[16], pqI[CPLX ? 16 : 0]);
+                split_pair_c(zc1, zc2, wc1, sq, pk[17], pkI[CPLX ? 17 : 0], pq[17], pqI[CPLX ? 17 : 0]);
+            } else {
+                split_pair(zc0, zc3, wc0, pk[16], pq[16]);
+                split_pair(zc1, zc2, wc1, pk[17], pq[17]);
+            }
         }
-        if (GENERAL && a.specMap == 1) {
+        if (CPLX) {
+        } else if (GENERAL && a.specMap == 1) {
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
                 pk[i] = sqrtf(pk[i]);
@@ -333,19 +374,22 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         }
         wave_lds_sync();  // every lane has its bins in registers; ex becomes the power row
 #pragma unroll
+        for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
+        if (pass == 1) wave_lds_sync();  // the real pass has read the row; now the imaginary parts
+#pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = lane + 64 * s + 256 * j;
-                prow[k] = pk[8 * s + j];
-                prow[MC - k] = pq[8 * s + j];
+                prow[k] = (CPLX && pass) ? pkI[CPLX ? 8 * s + j : 0] : pk[8 * s + j];
+                prow[MC - k] = (CPLX && pass) ? pqI[CPLX ? 8 * s + j : 0] : pq[8 * s + j];
             }
         }
         if (lane == 0) {
-            prow[128] = pk[16];
-            prow[896] = pq[16];
-            prow[384] = pk[17];
-            prow[640] = pq[17];
+            prow[128] = (CPLX && pass) ? pkI[CPLX ? 16 : 0] : pk[16];
+            prow[896] = (CPLX && pass) ? pqI[CPLX ? 16 : 0] : pq[16];
+            prow[384] = (CPLX && pass) ? pkI[CPLX ? 17 : 0] : pk[17];
+            prow[640] = (CPLX && pass) ? pqI[CPLX ? 17 : 0] : pq[17];
         }
         // zero pad behind bin 1024: the fixed-length band loops read it with zero weights
         prow[1025 + lane] = 0.f;
@@ -405,14 +449,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
         }
-        if (GENERAL && a.postPow) {
+        if (GENERAL && !CPLX && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
         }
         // ---- 5. store ---------------------------------------------------------------
-        float *orow = a.out + f * a.num;
+        float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
         if (rowA >= 0) orow[rowA] = accA;
         if (rowB >= 0) orow[rowB] = accB;
+        }  // pass
         wave_lds_sync();  // the next frame overwrites ex / prow
 
         if (++t == a.timeLength) {
@@ -436,7 +481,7 @@ struct Variant {
 constexpr Variant kVariants[] = {{48, 16}, {72, 32}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-template <int TA, int TB, bool GENERAL, int SHIFT>
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX = false>
 int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -472,16 +517,17 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.postPow = a->postPow;
     k.normValue = a->normValue;
     k.out = a->out;
+    k.outIm = a->outIm;
     k.num = p->num;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet = false;
     if (!attrSet) {
         AFX_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL, SHIFT>),
+            reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet = true;
     }
-    hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL, SHIFT>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX>), dim3((unsigned)blocks),
                        dim3(WAVES * 64), lds, (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_mel_banded");
     return AFX_OK;
@@ -491,6 +537,11 @@ template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const bool general = (a->specMap != 0) || a->postPow;
     const bool shift4 = (a->hop == 512);  // hop = 128 * SHIFT
+    if (a->specMap >= 3) {  // complex result: S (3) or S^2 (4), real and imaginary planes
+        if (!a->outIm) return AFX_ERR_ARG;
+        return shift4 ? launch_variant<TA, TB, true, 4, true>(p, a, stream)
+                      : launch_variant<TA, TB, true, 0, true>(p, a, stream);
+    }
     if (general) {
         return shift4 ? launch_variant<TA, TB, true, 4>(p, a, stream)
                       : launch_variant<TA, TB, true, 0>(p, a, stream);

@@ -31,9 +31,9 @@ int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hB
 
 int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
                      long long clipStride, float *dRe, float *dIm, void *stream, int *used) {
-    (void)dIm;
     *used = 0;
-    if (!o->fast || !o->resultType) return AFX_OK; /* complex results: generic path */
+    if (!o->fast) return AFX_OK;
+    if (!o->resultType && !dIm) return AFX_OK;
     AfxMelFusedArgs a;
     memset(&a, 0, sizeof(a));
     a.x = dData;
@@ -44,7 +44,12 @@ int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dat
     a.hop = o->slideLength;
     a.normValue = o->normValue;
     a.out = dRe;
-    if (o->dataType == SpectralData_Mag) {
+    a.outIm = dIm;
+    if (!o->resultType) {
+        /* complex result (bft_algorithm.c:457-485): the spectrum itself for MAG, its complex
+         * square for POWER; the norm exponent plays no part */
+        a.specMap = (o->dataType == SpectralData_Power) ? 4 : 3;
+    } else if (o->dataType == SpectralData_Mag) {
         a.specMap = 1;
         a.postPow = (o->normValue != 1);
     } else {

@@ -61,17 +61,20 @@ def test_bft_matches_golden(name, gold):
 def test_bft_matches_compiled_reference_fresh_inputs(seed):
     """fresh seeds (not in the fixtures) straight against the reference library"""
     x = cases.noise(seed, 16000 * 3 + 123)
-    for rt in (1, 0):
-        for dt in (0, 1):
-            r = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1,
-                           slide_length=512, scale_type=2, style_type=0, normal_type=0, data_type=dt)
-            r.set_result_type(rt)
-            re, im = r.bft(x)
-            o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
-                       slide_length=512, scale_type=af.SpectralFilterBankScaleType.MEL,
-                       data_type=af.SpectralDataType(dt))
-            got = o.bft(x, result_type=rt).T
-            assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"rt{rt} dt{dt}")
+    # hop 512 runs the register-reuse variant of the fused kernel, hop 300 the plain one;
+    # result type 0 (complex, the wrapper's default) its two-pass filter-bank stage
+    for hop in (512, 300):
+        for rt in (1, 0):
+            for dt in (0, 1):
+                r = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1,
+                               slide_length=hop, scale_type=2, style_type=0, normal_type=0, data_type=dt)
+                r.set_result_type(rt)
+                re, im = r.bft(x)
+                o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                           slide_length=hop, scale_type=af.SpectralFilterBankScaleType.MEL,
+                           data_type=af.SpectralDataType(dt))
+                got = o.bft(x, result_type=rt).T
+                assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"hop{hop} rt{rt} dt{dt}")
 
 
 def test_batch_equals_per_clip_loop():
