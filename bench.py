@@ -217,10 +217,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          # HBM bytes per launch from rocprofv3 PMC passes of this same command
-                         # (profiles/r01_v6_rocprofv3_bench_summary.txt): 2*FETCH_SIZE (gfx950 counts
+                         # (profiles/r01_final_rocprofv3_bench_summary.txt): 2*FETCH_SIZE (gfx950 counts
                          # wide coalesced reads at half) + WRITE_SIZE, in KiB -> bytes; scales with clips
-                         "traffic": (2 * 955749 + 467001) * 1024 * (a.clips / 1000.0),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_v6_*",
+                         "traffic": (2 * 955752 + 467001) * 1024 * (a.clips / 1000.0),
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_final_*",
                          "kernel": "k_stft_mel_banded (framed FFT -> |S|^2 -> banded mel bank), "
                                    "one launch per step",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": BYTES_PER_FRAME_MEL_KERNEL,
