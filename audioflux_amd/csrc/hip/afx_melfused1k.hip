@@ -1,0 +1,475 @@
+// afx_melfused1k.hip -- the fused STFT -> spectrum value -> banded filter bank kernel for
+// n_fft = 1024 (radix2Exp 10): same design as afx_melfused.hip (one wave per frame, tables in
+// LDS, register re-use of the overlapping frames, lane-owned bank rows), with the 512-point
+// complex FFT of the packed real frame as 8 x 8 x 8 in eight registers per lane -- the
+// transform of the CWT row pass (afx_cwt.hip, index algebra in tools/proto_fft512.py).
+// Eight data registers and a 4.6 KB exchange image per wave leave room for 16 waves per CU.
+//
+// Replaces, per frame, the same reference code as afx_melfused.hip (stft_algorithm.c:696-803,
+// fft_algorithm.c:450-519, flux_complex.c:254-286,469-503, bft_algorithm.c:457-529,
+// flux_vector.c:55-86).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "afx_device.h"
+#include "afx_hipcheck.h"
+#include "afx_pkmath.h"
+
+namespace {
+
+constexpr int NFFT = 1024;
+constexpr int MC = 512;            // complex FFT length
+constexpr int RP = 9;              // exchange pitch (float2) of the 64 x 8 images
+constexpr int EX_F2 = 64 * RP;     // 576 float2; also holds the 512-float2 natural image
+constexpr int PROW_F = 640;        // 513 bins + zero pad for the fixed-length band loops
+constexpr int WAVE_LDS_BYTES = EX_F2 * 8;  // 4608; the power row (2560 B) aliases the image
+constexpr int WAVES = 16;          // one workgroup per CU: 4 waves per SIMD
+constexpr int TAB_WIN_F2 = 512;    // (w[2n], w[2n+1])
+constexpr int TAB_TW1_F2 = 8 * 64; // W_512^(lane d0)
+constexpr int TAB_TW2_F2 = 8 * 8;  // W_64^(c d1)
+constexpr int TAB_TW3_F2 = 320;    // 0.5 * W_1024^k, k <= 256
+constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
+constexpr int TAB_BYTES = TAB_F2 * 8;
+__host__ __device__ constexpr int wpitch(int ta, int tb) { return ta + tb + 4; }
+__host__ __device__ constexpr int block_lds_bytes(int ta, int tb) {
+    return TAB_BYTES + 64 * wpitch(ta, tb) * 4 + WAVES * WAVE_LDS_BYTES;
+}
+
+struct KArgs {
+    const float *x;
+    long long clipStride;
+    long long totalFrames;
+    int timeLength, hop;
+    int framesPerWave;
+    int aligned;
+    const float2 *win2, *tw1, *tw2, *tw3;
+    const float *wLane;
+    const int *meta;
+    int specMap, postPow;
+    float normValue;
+    float *out, *outIm;
+    int num;
+};
+
+// |X|^2 of the conjugate pair (k, 512-k) from A = Z[k], B = Z[512-k], w = 0.5 W_1024^k
+__device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w, float &pk, float &pq) {
+    const v2 e2 = pk_add_conj(A, B);
+    const v2 d = pk_sub_conj(A, B);
+    const v2 wo = cmul_mi(d, w);
+    const v2 x = e2 * 0.5f + wo;  // X[k]
+    const v2 y = e2 * 0.5f - wo;  // conj(X[512-k])
+    pk = x.x * x.x + x.y * x.y;
+    pq = y.x * y.x + y.y * y.y;
+}
+__device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &kr, float &ki, float &qr,
+                                             float &qi) {
+    const v2 e2 = pk_add_conj(A, B);
+    const v2 d = pk_sub_conj(A, B);
+    const v2 wo = cmul_mi(d, w);
+    const v2 x = e2 * 0.5f + wo;
+    const v2 y = e2 * 0.5f - wo;
+    if (sq) {
+        kr = x.x * x.x - x.y * x.y;
+        ki = 2.f * (x.x * x.y);
+        qr = y.x * y.x - y.y * y.y;
+        qi = -2.f * (y.x * y.y);
+    } else {
+        kr = x.x;
+        ki = x.y;
+        qr = y.x;
+        qi = -y.y;
+    }
+}
+
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX>
+__global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr int WP = wpitch(TA, TB);
+    v2 *tabWin = reinterpret_cast<v2 *>(smem);
+    v2 *tabTw1 = tabWin + TAB_WIN_F2;
+    v2 *tabTw2 = tabTw1 + TAB_TW1_F2;
+    v2 *tabTw3 = tabTw2 + TAB_TW2_F2;
+    float *tabW = reinterpret_cast<float *>(smem + TAB_BYTES);
+    v2 *ex = reinterpret_cast<v2 *>(smem + TAB_BYTES + 64 * WP * 4 + wave * WAVE_LDS_BYTES);
+    float *prow = reinterpret_cast<float *>(ex);
+
+    for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = reinterpret_cast<const v2 *>(a.win2)[i];
+    for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = reinterpret_cast<const v2 *>(a.tw1)[i];
+    for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = reinterpret_cast<const v2 *>(a.tw3)[i];
+    for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
+    if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = reinterpret_cast<const v2 *>(a.tw2)[threadIdx.x];
+    __syncthreads();
+
+    const int startA = a.meta[lane], startB = a.meta[64 + lane];
+    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const float4 *wrow = reinterpret_cast<const float4 *>(tabW + lane * WP);
+
+    const long long gw = (long long)blockIdx.x * WAVES + wave;
+    long long f = gw * a.framesPerWave;
+    long long fEnd = f + a.framesPerWave;
+    if (fEnd > a.totalFrames) fEnd = a.totalFrames;
+    if (f >= fEnd) return;
+    int clip = (int)(f / a.timeLength);
+    int t = (int)(f - (long long)clip * a.timeLength);
+
+    // raw[r] = (x[2n], x[2n+1]), n = 64 r + lane
+    v2 raw[8];
+    auto fetch = [&](const float *px, int first) {
+        if (a.aligned) {
+            const v2 *p2 = reinterpret_cast<const v2 *>(px);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r >= first) raw[r] = p2[64 * r + lane];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r >= first) {
+                    const int n = 64 * r + lane;
+                    raw[r] = v2{px[2 * n], px[2 * n + 1]};
+                }
+        }
+    };
+    fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
+
+    for (; f < fEnd; ++f) {
+        v2 v[8];
+        // ---- 1. window; start fetching the next frame ------------------------------------
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = raw[r] * tabWin[64 * r + lane];
+        if (f + 1 < fEnd) {
+            int tn = t + 1, cn = clip;
+            if (tn == a.timeLength) {
+                tn = 0;
+                ++cn;
+            }
+            const float *pn = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
+            if (SHIFT > 0 && tn != 0) {  // hop = 128 SHIFT samples = SHIFT registers
+#pragma unroll
+                for (int r = 0; r + SHIFT < 8; ++r) raw[r] = raw[r + SHIFT];
+                fetch(pn, 8 - SHIFT);
+            } else {
+                fetch(pn, 0);
+            }
+        }
+        // ---- 2. 512-point complex FFT, 8 x 8 x 8 ------------------------------------------
+        {
+            v2 t1[8];
+#pragma unroll
+            for (int d = 1; d < 8; ++d) t1[d] = tabTw1[64 * d + lane];
+            dft8(v);  // v[rev8(d0)]
+            const int b = lane >> 3, c = lane & 7;
+            ex[c * RP + b] = v[0];
+#pragma unroll
+            for (int d0 = 1; d0 < 8; ++d0) ex[(8 * d0 + c) * RP + b] = cmul(v[rev8(d0)], t1[d0]);
+            wave_lds_order();
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) v[bb] = ex[lane * RP + bb];
+            wave_lds_order();
+        }
+        {
+            v2 t2[8];
+            const int d0 = lane >> 3, c = lane & 7;
+#pragma unroll
+            for (int d = 1; d < 8; ++d) t2[d] = tabTw2[8 * d + c];
+            dft8(v);  // v[rev8(d1)], lane = 8 d0 + c
+            ex[d0 * RP + c] = v[0];
+#pragma unroll
+            for (int d1 = 1; d1 < 8; ++d1) ex[(d0 + 8 * d1) * RP + c] = cmul(v[rev8(d1)], t2[d1]);
+            wave_lds_order();
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) v[cc] = ex[lane * RP + cc];
+            wave_lds_order();
+        }
+        dft8(v);  // v[rev8(d2)] = Z[lane + 64 d2]
+        // ---- 3. natural-order image, conjugate pairs (k, 512-k), spectrum values ---------
+#pragma unroll
+        for (int d2 = 0; d2 < 8; ++d2) ex[lane + 64 * d2] = v[rev8(d2)];
+        wave_lds_order();
+        float pk[5], pq[5];
+        float pkI[CPLX ? 5 : 1], pqI[CPLX ? 5 : 1];
+        {
+            v2 za[4], zb[4], w3[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * j;
+                za[j] = ex[k];
+                zb[j] = ex[(MC - k) & (MC - 1)];  // k = 0 pairs with itself: X[0] and X[512]
+                w3[j] = tabTw3[k];
+            }
+            const v2 zm = ex[256], wm = tabTw3[256];  // bin 256 pairs with itself
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (CPLX) split_pair_c(za[j], zb[j], w3[j], a.specMap == 4, pk[j], pkI[CPLX ? j : 0], pq[j], pqI[CPLX ? j : 0]);
+                else split_pair(za[j], zb[j], w3[j], pk[j], pq[j]);
+            }
+            if (CPLX) split_pair_c(zm, zm, wm, a.specMap == 4, pk[4], pkI[CPLX ? 4 : 0], pq[4], pqI[CPLX ? 4 : 0]);
+            else split_pair(zm, zm, wm, pk[4], pq[4]);
+        }
+        if (CPLX) {
+        } else if (GENERAL && a.specMap == 1) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                pk[i] = sqrtf(pk[i]);
+                pq[i] = sqrtf(pq[i]);
+            }
+        } else if (GENERAL && a.specMap == 2) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                pk[i] = powf(pk[i], a.normValue);
+                pq[i] = powf(pq[i], a.normValue);
+            }
+        }
+        wave_lds_order();  // every lane has its bins in registers; ex becomes the power row
+#pragma unroll
+        for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
+            if (pass == 1) wave_lds_order();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * j;
+                prow[k] = (CPLX && pass) ? pkI[CPLX ? j : 0] : pk[j];
+                prow[MC - k] = (CPLX && pass) ? pqI[CPLX ? j : 0] : pq[j];
+            }
+            if (lane == 0) prow[256] = (CPLX && pass) ? pkI[CPLX ? 4 : 0] : pk[4];
+            // zero pad behind bin 512: the fixed-length band loops read it with zero weights
+            prow[513 + lane] = 0.f;
+            if (lane < PROW_F - 513 - 64) prow[513 + 64 + lane] = 0.f;
+            wave_lds_order();
+
+            // ---- 4. banded filter bank (see afx_melfused.hip) ----------------------------
+            float accA, accB;
+            {
+                const v2 *pa = reinterpret_cast<const v2 *>(prow + startA);
+                const v2 *pb = reinterpret_cast<const v2 *>(prow + startB);
+                v2 sA = {0.f, 0.f}, sB = {0.f, 0.f};
+                constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 4;
+#pragma unroll
+                for (int q0 = 0; q0 < QT; q0 += BLK) {
+                    float4 w[BLK];
+                    v2 p0[BLK], p1[BLK];
+#pragma unroll
+                    for (int i = 0; i < BLK; ++i) {
+                        const int q = q0 + i;
+                        if (q < QT) {
+                            w[i] = wrow[q];
+                            const v2 *src = q < QA ? pa + 2 * q : pb + 2 * (q - QA);
+                            p0[i] = src[0];
+                            p1[i] = src[1];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < BLK; ++i) {
+                        const int q = q0 + i;
+                        if (q < QT) {
+                            if (q < QA) {
+                                sA += v2{w[i].x, w[i].y} * p0[i];
+                                sA += v2{w[i].z, w[i].w} * p1[i];
+                            } else {
+                                sB += v2{w[i].x, w[i].y} * p0[i];
+                                sB += v2{w[i].z, w[i].w} * p1[i];
+                            }
+                        }
+                    }
+                }
+                accA = sA.x + sA.y;
+                accB = sB.x + sB.y;
+            }
+            if (GENERAL && !CPLX && a.postPow) {
+                accA = powf(accA, a.normValue);
+                accB = powf(accB, a.normValue);
+            }
+            // ---- 5. store --------------------------------------------------------------
+            float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
+            if (rowA >= 0) orow[rowA] = accA;
+            if (rowB >= 0) orow[rowB] = accB;
+        }
+        wave_lds_order();  // the next frame overwrites ex / prow
+
+        if (++t == a.timeLength) {
+            t = 0;
+            ++clip;
+        }
+    }
+}
+
+struct Plan {
+    int variant;  // >= 100: this file (afxk_melfused_* dispatches on it)
+    int num;
+    float2 *dWin2, *dTw1, *dTw2, *dTw3;
+    float *dWLane;
+    int *dMeta;
+};
+struct Variant {
+    int tapsA, tapsB;
+};
+// ordered by cost; the plan's conflict-free lane assignment can stretch the short rows of a
+// dense low band (mel-128 at n_fft 1024: 23 / 25 taps), hence the square variant
+constexpr Variant kVariants[] = {{24, 8}, {32, 32}, {48, 16}, {72, 32}};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX>
+int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    if (total <= 0) return AFX_OK;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long waves = (long long)cus * WAVES * 2;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 16) fpw = 16;
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+    KArgs k;
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.aligned = ((a->clipStride & 1) == 0) && ((a->hop & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
+    k.win2 = p->dWin2;
+    k.tw1 = p->dTw1;
+    k.tw2 = p->dTw2;
+    k.tw3 = p->dTw3;
+    k.wLane = p->dWLane;
+    k.meta = p->dMeta;
+    k.specMap = a->specMap;
+    k.postPow = a->postPow;
+    k.normValue = a->normValue;
+    k.out = a->out;
+    k.outIm = a->outIm;
+    k.num = p->num;
+    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
+    static bool attrSet = false;
+    if (!attrSet) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL((k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_band_1k");
+    return AFX_OK;
+}
+
+template <int TA, int TB>
+int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
+    const bool general = (a->specMap != 0) || a->postPow;
+    const bool shift2 = (a->hop == 256);  // hop = 128 * SHIFT
+    if (a->specMap >= 3) {
+        if (!a->outIm) return AFX_ERR_ARG;
+        return shift2 ? launch_variant<TA, TB, true, 2, true>(p, a, stream)
+                      : launch_variant<TA, TB, true, 0, true>(p, a, stream);
+    }
+    if (general)
+        return shift2 ? launch_variant<TA, TB, true, 2, false>(p, a, stream)
+                      : launch_variant<TA, TB, true, 0, false>(p, a, stream);
+    return shift2 ? launch_variant<TA, TB, false, 2, false>(p, a, stream)
+                  : launch_variant<TA, TB, false, 0, false>(p, a, stream);
+}
+
+template <typename T>
+int upload(T **dptr, const void *src, size_t bytes, void *stream) {
+    int st = afxdev_malloc(reinterpret_cast<void **>(dptr), bytes);
+    if (st != AFX_OK) return st;
+    return afxdev_h2d(*dptr, src, bytes, stream);
+}
+
+}  // namespace
+
+extern "C" int afxk_mel1k_variant(int tapsA, int tapsB) {
+    for (int i = 0; i < kNumVariants; ++i)
+        if (tapsA <= kVariants[i].tapsA && tapsB <= kVariants[i].tapsB) return 100 + i;
+    return -1;
+}
+
+extern "C" void afxk_mel1k_destroy(void *plan) {
+    Plan *p = static_cast<Plan *>(plan);
+    if (!p) return;
+    afxdev_free(p->dWin2);
+    afxdev_free(p->dTw1);
+    afxdev_free(p->dTw2);
+    afxdev_free(p->dTw3);
+    afxdev_free(p->dWLane);
+    afxdev_free(p->dMeta);
+    free(p);
+}
+
+extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream) {
+    *plan = nullptr;
+    const int variant = afxk_mel1k_variant(band->tapsA, band->tapsB);
+    if (variant < 0) return AFX_ERR_UNSUPPORTED;
+    const int TA = kVariants[variant - 100].tapsA, TB = kVariants[variant - 100].tapsB;
+    Plan *p = static_cast<Plan *>(calloc(1, sizeof(Plan)));
+    if (!p) return AFX_ERR_NOMEM;
+    p->variant = variant;
+    p->num = band->num;
+    const int WP = TA + TB + 4;
+    float *tw1 = static_cast<float *>(malloc(sizeof(float) * 2 * TAB_TW1_F2));
+    float *tw2 = static_cast<float *>(malloc(sizeof(float) * 2 * TAB_TW2_F2));
+    float *tw3 = static_cast<float *>(calloc(2 * TAB_TW3_F2, sizeof(float)));
+    float *wL = static_cast<float *>(calloc((size_t)64 * WP, sizeof(float)));
+    int meta[256];
+    int st = (tw1 && tw2 && tw3 && wL) ? AFX_OK : AFX_ERR_NOMEM;
+    if (st == AFX_OK) {
+        const double PI = 3.14159265358979323846;
+        for (int d = 0; d < 8; ++d)
+            for (int l = 0; l < 64; ++l) {
+                const double ang = -2.0 * PI * (double)(d * l) / MC;
+                tw1[2 * (d * 64 + l)] = (float)cos(ang);
+                tw1[2 * (d * 64 + l) + 1] = (float)sin(ang);
+            }
+        for (int d = 0; d < 8; ++d)
+            for (int c = 0; c < 8; ++c) {
+                const double ang = -2.0 * PI * (double)(d * c) / 64.0;
+                tw2[2 * (d * 8 + c)] = (float)cos(ang);
+                tw2[2 * (d * 8 + c) + 1] = (float)sin(ang);
+            }
+        for (int k = 0; k <= 256; ++k) {
+            const double ang = -2.0 * PI * (double)k / NFFT;
+            tw3[2 * k] = (float)(0.5 * cos(ang));
+            tw3[2 * k + 1] = (float)(0.5 * sin(ang));
+        }
+        for (int l = 0; l < 64; ++l) {
+            for (int t = 0; t < band->tapsA; ++t) wL[(size_t)l * WP + t] = band->wA[(size_t)t * 64 + l];
+            for (int t = 0; t < band->tapsB; ++t) wL[(size_t)l * WP + TA + t] = band->wB[(size_t)t * 64 + l];
+            meta[l] = band->startA[l];
+            meta[64 + l] = band->startB[l];
+            meta[128 + l] = band->rowA[l];
+            meta[192 + l] = band->rowB[l];
+        }
+        st = upload(&p->dWin2, hWindow, sizeof(float) * NFFT, stream);
+    }
+    if (st == AFX_OK) st = upload(&p->dTw1, tw1, sizeof(float) * 2 * TAB_TW1_F2, stream);
+    if (st == AFX_OK) st = upload(&p->dTw2, tw2, sizeof(float) * 2 * TAB_TW2_F2, stream);
+    if (st == AFX_OK) st = upload(&p->dTw3, tw3, sizeof(float) * 2 * TAB_TW3_F2, stream);
+    if (st == AFX_OK) st = upload(&p->dWLane, wL, sizeof(float) * (size_t)64 * WP, stream);
+    if (st == AFX_OK) st = upload(&p->dMeta, meta, sizeof(meta), stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(stream);
+    free(tw1);
+    free(tw2);
+    free(tw3);
+    free(wL);
+    if (st != AFX_OK) {
+        afxk_mel1k_destroy(p);
+        return st;
+    }
+    *plan = p;
+    return AFX_OK;
+}
+
+extern "C" int afxk_mel1k_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
+    const Plan *p = static_cast<const Plan *>(plan);
+    if (!p) return AFX_ERR_ARG;
+    switch (p->variant) {
+        case 100: return launch<24, 8>(p, a, stream);
+        case 101: return launch<32, 32>(p, a, stream);
+        case 102: return launch<48, 16>(p, a, stream);
+        case 103: return launch<72, 32>(p, a, stream);
+        default: return AFX_ERR_UNSUPPORTED;
+    }
+}

@@ -126,3 +126,29 @@ def test_linearity_and_scaling_property():
                scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.MAG)
     assert_parity(p.bft(2 * x, 1), 4 * p.bft(x, 1), 1e-6, "power gain")
     assert_parity(m.bft(2 * x, 1), 2 * m.bft(x, 1), 1e-6, "mag gain")
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("scale", [2, 3, 4])   # mel, bark, erb
+def test_bft_nfft1024_fused_kernel_matches_compiled_reference(scale):
+    """n_fft 1024 runs k_stft_band_1k (512-point complex FFT in 8 registers per lane):
+    hop 256 (register re-use) and 200 (plain), real / complex results, power / magnitude,
+    with and without a norm exponent, against the reference library."""
+    x = cases.noise(60 + scale, 16000 * 2 + 77)
+    for hop in (256, 200):
+        for rt, dt, norm in ((1, 0, None), (1, 1, None), (0, 0, None), (0, 1, None), (1, 0, 0.5), (1, 1, 2.0)):
+            r = ref.RefBFT(64 if scale != 2 else 128, 10, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                           window_type=1, slide_length=hop, scale_type=scale, style_type=0, normal_type=0,
+                           data_type=dt)
+            assert r.status == 0
+            r.set_result_type(rt)
+            if norm:
+                r.set_norm(norm)
+            re, im = r.bft(x)
+            o = af.BFT(64 if scale != 2 else 128, radix2_exp=10, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                       slide_length=hop, scale_type=af.SpectralFilterBankScaleType(scale),
+                       data_type=af.SpectralDataType(dt))
+            if norm:
+                o.set_data_norm_value(norm)
+            got = o.bft(x, result_type=rt).T
+            assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"scale{scale} hop{hop} rt{rt} dt{dt} norm{norm}")
