@@ -80,6 +80,14 @@ typedef struct {
      * [i*hop - padLeft, i*hop - padLeft + fftLength) of the clip, reads
      * outside [0,dataLength) give 0 */
     int padLeft;
+    /* optional banded filter bank applied in the same launch (all NULL/0: bins are stored):
+     * row j = sum_q bandW[bandOff[j] + q] * value[bandStart[j] + q], q < bandLen[j];
+     * outRe/outIm then are [batch*timeLength, bandNum]; bandPost = AFX_MAP_POW applies
+     * powf(., bandPostArg) to the real plane.  The spans must lie inside [binLo, binLo+binCount) */
+    const int *bandStart, *bandLen, *bandOff;
+    const float *bandW;
+    int bandNum, bandPost;
+    float bandPostArg;
 } AfxStftArgs;
 
 /* generic framed FFT, any radix2Exp in 1..14 */

@@ -33,12 +33,38 @@ __device__ __forceinline__ float block_sum(float v, float *red /* >= 16 floats o
     return t;
 }
 
+// W_N^k for 0 <= k <= N/2 from the half table tw[0..N/2)
+__device__ __forceinline__ float2 twn(const float2 *tw, int k, int halfN) {
+    return k < halfN ? tw[k] : make_float2(-1.f, 0.f);
+}
+
+// spectrum value of one bin -> up to two planes (re / im); returns the first
+__device__ __forceinline__ void map_bin(float2 c, int mode, float normValue, float &v0, float &v1) {
+    v1 = 0.f;
+    switch (mode) {
+        case AFX_SPEC_COMPLEX: v0 = c.x; v1 = c.y; break;
+        case AFX_SPEC_POWER: v0 = c.x * c.x + c.y * c.y; break;
+        case AFX_SPEC_MAG: v0 = sqrtf(c.x * c.x + c.y * c.y); break;
+        case AFX_SPEC_SQUARE: v0 = c.x * c.x - c.y * c.y; v1 = 2.f * c.x * c.y; break;
+        case AFX_SPEC_MAG_NORM: v0 = powf(sqrtf(c.x * c.x + c.y * c.y), normValue); break;
+        default: v0 = powf(c.x * c.x + c.y * c.y, normValue); break;  // AFX_SPEC_POWER_NORM
+    }
+}
+
+// The real frame is packed as M = N/2 complex samples z[n] = (x[2n], x[2n+1]) w (half the
+// transform of the reference's zero-imaginary complex FFT), transformed in LDS by in-place
+// DIF passes -- two radix-2 stages per pass held in registers (a radix-4 butterfly with the
+// radix-2 layout: Z[k] ends at bitrev_m(k), one barrier per two stages) -- and un-packed per
+// requested bin: X[k] = E + W_N^k O, E/O from Z[k], conj Z[M-k].  With a banded bank
+// (AfxStftArgs::band*) the spectrum values stay in LDS and the filter-bank rows are formed in
+// the same launch: no [T,F] round trip through HBM and no dense GEMM.
 __global__ void k_stft_generic(AfxStftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
     const int r = a.radix2Exp;
-    const int N = 1 << r;
-    float *red = reinterpret_cast<float *>(s + N);
+    const int N = 1 << r, M = N >> 1, m = r - 1;
+    float *red = reinterpret_cast<float *>(s + M);
+    float *prow = red + 16;  // [planes][binCount], band mode only
 
     const long long frame = blockIdx.x;
     const int b = (int)(frame / a.timeLength);
@@ -47,23 +73,25 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     const long long start = (long long)t * a.hop - a.padLeft;
     const int tid = threadIdx.x, nth = blockDim.x;
 
-    // 1. gather + window (frames overlap by N-hop samples: neighbouring
-    //    workgroups re-read them through L2, HBM sees each sample once)
-    for (int i = tid; i < N; i += nth) {
-        const long long p = start + i;
-        float v = (p >= 0 && p < a.dataLength) ? x[p] : 0.f;
-        v *= a.window[i];
-        s[i] = make_float2(v, 0.f);
+    // 1. gather + window (frames overlap by N-hop samples: neighbouring workgroups re-read
+    //    them through L2, HBM sees each sample once)
+    for (int i = tid; i < M; i += nth) {
+        const long long p = start + 2 * i;
+        float v0 = (p >= 0 && p < a.dataLength) ? x[p] : 0.f;
+        float v1 = (p + 1 >= 0 && p + 1 < a.dataLength) ? x[p + 1] : 0.f;
+        s[i] = make_float2(v0 * a.window[2 * i], v1 * a.window[2 * i + 1]);
     }
     __syncthreads();
 
     // 1b. temporal features of the windowed frame (temporal_algorithm.c:138-144)
     if (a.energy) {
         float e = 0.f, z = 0.f;
-        for (int i = tid; i < N; i += nth) {
-            const float v = s[i].x;
-            e += v * v;
-            if (i > 0 && v * s[i - 1].x < 0.f) z += 1.f;
+        for (int i = tid; i < M; i += nth) {
+            const float2 v = s[i];
+            e += v.x * v.x;
+            e += v.y * v.y;
+            if (i > 0 && v.x * s[i - 1].y < 0.f) z += 1.f;
+            if (v.y * v.x < 0.f) z += 1.f;
         }
         e = block_sum(e, red);
         z = block_sum(z, red);
@@ -75,16 +103,42 @@ __global__ void k_stft_generic(AfxStftArgs a) {
         __syncthreads();
     }
 
-    // 2. in-place radix-2 DIF: after r stages X[k] sits at index bitrev_r(k)
+    // 2. M-point complex FFT; W_M^j = W_N^(2j) = tw[2j]
     const float2 *tw = reinterpret_cast<const float2 *>(a.twiddle);
-    for (int st = 0; st < r; ++st) {
-        const int half = N >> (st + 1);
-        for (int j = tid; j < (N >> 1); j += nth) {
+    int st = 0;
+    for (; st + 1 < m; st += 2) {  // stages st and st+1 in one pass
+        const int half = M >> (st + 1), half2 = half >> 1;
+        for (int j = tid; j < (M >> 2); j += nth) {
+            const int p = j & (half2 - 1);
+            const int i0 = ((j - p) << 2) + p;  // block base (size 2 half) + p
+            float2 va = s[i0], vb = s[i0 + half2], vc = s[i0 + half], vd = s[i0 + half + half2];
+            const float2 wa = tw[(p << st) << 1];         // W_M^(p << st)
+            const float2 w2 = tw[(p << (st + 1)) << 1];   // W_M^(p << (st+1))
+            // stage st: (a,c) twiddle wa, (b,d) twiddle -i wa
+            const float2 a1 = make_float2(va.x + vc.x, va.y + vc.y);
+            const float2 dc = make_float2(va.x - vc.x, va.y - vc.y);
+            const float2 c1 = make_float2(dc.x * wa.x - dc.y * wa.y, dc.x * wa.y + dc.y * wa.x);
+            const float2 b1 = make_float2(vb.x + vd.x, vb.y + vd.y);
+            const float2 dd = make_float2(vb.x - vd.x, vb.y - vd.y);
+            const float2 d0 = make_float2(dd.x * wa.x - dd.y * wa.y, dd.x * wa.y + dd.y * wa.x);
+            const float2 d1 = make_float2(d0.y, -d0.x);  // times -i
+            // stage st+1: (a1,b1) and (c1,d1), twiddle w2
+            s[i0] = make_float2(a1.x + b1.x, a1.y + b1.y);
+            const float2 e1 = make_float2(a1.x - b1.x, a1.y - b1.y);
+            s[i0 + half2] = make_float2(e1.x * w2.x - e1.y * w2.y, e1.x * w2.y + e1.y * w2.x);
+            s[i0 + half] = make_float2(c1.x + d1.x, c1.y + d1.y);
+            const float2 e2 = make_float2(c1.x - d1.x, c1.y - d1.y);
+            s[i0 + half + half2] = make_float2(e2.x * w2.x - e2.y * w2.y, e2.x * w2.y + e2.y * w2.x);
+        }
+        __syncthreads();
+    }
+    if (st < m) {  // odd stage count: last radix-2 stage (half = 1, twiddle 1)
+        const int half = M >> (st + 1);
+        for (int j = tid; j < (M >> 1); j += nth) {
             const int pos = j & (half - 1);
-            const int i0 = ((j - pos) << 1) + pos;
-            const int i1 = i0 + half;
+            const int i0 = ((j - pos) << 1) + pos, i1 = i0 + half;
             const float2 u = s[i0], v = s[i1];
-            const float2 w = tw[pos << st];
+            const float2 w = tw[(pos << st) << 1];
             const float dx = u.x - v.x, dy = u.y - v.y;
             s[i0] = make_float2(u.x + v.x, u.y + v.y);
             s[i1] = make_float2(dx * w.x - dy * w.y, dx * w.y + dy * w.x);
@@ -92,34 +146,44 @@ __global__ void k_stft_generic(AfxStftArgs a) {
         __syncthreads();
     }
 
-    // 3. store the requested bins
+    // 3. un-pack the requested bins, map them, store (or keep for the filter bank)
+    const bool band = a.bandStart != nullptr;
+    const bool two = (a.mode == AFX_SPEC_COMPLEX || a.mode == AFX_SPEC_SQUARE);
     const long long row = frame * (long long)a.binCount;
     for (int j = tid; j < a.binCount; j += nth) {
-        const unsigned k = (unsigned)(a.binLo + j);
-        const unsigned idx = __brev(k) >> (32 - r);
-        const float2 c = s[idx];
-        switch (a.mode) {
-            case AFX_SPEC_COMPLEX:
-                a.outRe[row + j] = c.x;
-                a.outIm[row + j] = c.y;
-                break;
-            case AFX_SPEC_POWER:
-                a.outRe[row + j] = c.x * c.x + c.y * c.y;
-                break;
-            case AFX_SPEC_MAG:
-                a.outRe[row + j] = sqrtf(c.x * c.x + c.y * c.y);
-                break;
-            case AFX_SPEC_SQUARE:
-                a.outRe[row + j] = c.x * c.x - c.y * c.y;
-                a.outIm[row + j] = 2.f * c.x * c.y;
-                break;
-            case AFX_SPEC_MAG_NORM:
-                a.outRe[row + j] = powf(sqrtf(c.x * c.x + c.y * c.y), a.normValue);
-                break;
-            default:  // AFX_SPEC_POWER_NORM
-                a.outRe[row + j] = powf(c.x * c.x + c.y * c.y, a.normValue);
-                break;
+        const int k = a.binLo + j;  // 0 <= k <= M
+        const int ka = k & (M - 1), kb = (M - k) & (M - 1);
+        const float2 zk = s[m ? (int)(__brev((unsigned)ka) >> (32 - m)) : 0];
+        const float2 zm = s[m ? (int)(__brev((unsigned)kb) >> (32 - m)) : 0];
+        const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+        const float2 w = twn(tw, k, M);
+        const float2 c = make_float2(E.x + (w.x * O.x - w.y * O.y), E.y + (w.x * O.y + w.y * O.x));
+        float v0, v1;
+        map_bin(c, a.mode, a.normValue, v0, v1);
+        if (band) {
+            prow[j] = v0;
+            if (two) prow[a.binCount + j] = v1;
+        } else {
+            a.outRe[row + j] = v0;
+            if (two) a.outIm[row + j] = v1;
         }
+    }
+    if (!band) return;
+    __syncthreads();
+    // 4. filter bank rows: ascending taps of the row's non-zero span (src/vector/flux_vector.c:55-86)
+    for (int j = tid; j < a.bandNum; j += nth) {
+        const int k0 = a.bandStart[j] - a.binLo, n = a.bandLen[j];
+        const float *wj = a.bandW + a.bandOff[j];
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int q = 0; q < n; ++q) {
+            const float wv = wj[q];
+            acc0 += wv * prow[k0 + q];
+            if (two) acc1 += wv * prow[a.binCount + k0 + q];
+        }
+        if (a.bandPost == AFX_MAP_POW) acc0 = powf(acc0, a.bandPostArg);
+        a.outRe[frame * a.bandNum + j] = acc0;
+        if (two) a.outIm[frame * a.bandNum + j] = acc1;
     }
 }
 
@@ -137,10 +201,16 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
         return AFX_ERR_UNSUPPORTED;
     }
     const int N = 1 << a->radix2Exp;
-    int threads = N / 2;
+    int threads = N / 4;
     if (threads < 64) threads = 64;
     if (threads > 256) threads = 256;
-    const size_t lds = (size_t)N * sizeof(float2) + 16 * sizeof(float);
+    const bool two = (a->mode == AFX_SPEC_COMPLEX || a->mode == AFX_SPEC_SQUARE);
+    const size_t lds = (size_t)(N / 2 > 0 ? N / 2 : 1) * sizeof(float2) + 16 * sizeof(float) +
+                       (a->bandStart ? sizeof(float) * (size_t)a->binCount * (two ? 2 : 1) : 0);
+    if (lds > 150 * 1024) {
+        afxdev_set_error("stft: %zu bytes of LDS per frame", lds);
+        return AFX_ERR_UNSUPPORTED;
+    }
     if (lds > 48 * 1024) {
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_generic),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -184,6 +184,39 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
         if (st == AFX_OK)
             st = afxdev_h2d(o->dBank, hBank, sizeof(float) * (size_t)num * o->F, o->stream);
     }
+    if (st == AFX_OK && hBank) {
+        /* row spans of the bank: [first non-zero, last non-zero] of every row.  Used when the
+         * spans hold at most 1/4 of the dense matrix (triangular / window banks: ~1-3 %) */
+        int *meta = (int *)calloc(3 * (size_t)num, sizeof(int));
+        size_t total = 0;
+        if (!meta) st = AFX_ERR_NOMEM;
+        for (int i = 0; i < num && st == AFX_OK; i++) {
+            const float *row = hBank + (size_t)i * o->F;
+            int first = -1, last = -1;
+            for (int k = 0; k < o->F; k++)
+                if (row[k] != 0.f) {
+                    if (first < 0) first = k;
+                    last = k;
+                }
+            meta[i] = first < 0 ? 0 : first;
+            meta[num + i] = first < 0 ? 0 : last - first + 1;
+            meta[2 * num + i] = (int)total;
+            total += (size_t)meta[num + i];
+        }
+        if (st == AFX_OK && total * 4 <= (size_t)num * o->F) {
+            float *w = (float *)malloc(sizeof(float) * (total ? total : 1));
+            if (!w) st = AFX_ERR_NOMEM;
+            for (int i = 0; i < num && st == AFX_OK; i++)
+                memcpy(w + meta[2 * num + i], hBank + (size_t)i * o->F + meta[i], sizeof(float) * (size_t)meta[num + i]);
+            if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBandMeta, sizeof(int) * 3 * (size_t)num);
+            if (st == AFX_OK) st = afxdev_h2d(o->dBandMeta, meta, sizeof(int) * 3 * (size_t)num, o->stream);
+            if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBandW, sizeof(float) * (total ? total : 1));
+            if (st == AFX_OK) st = afxdev_h2d(o->dBandW, w, sizeof(float) * (total ? total : 1), o->stream);
+            if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+            free(w);
+        }
+        free(meta);
+    }
     if (st == AFX_OK) st = afx_bft_plan_fast(o, hWindow, hBank);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     free(hWindow);
@@ -298,7 +331,30 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
         if (st != AFX_OK || used) return st;
     }
 
-    /* generic path: spectrum scratch in HBM, chunked over clips */
+    /* banded bank: STFT and filter bank in one launch of the size-generic kernel */
+    if (o->dBandMeta && !getenv("AFX_NO_BAND")) {
+        a.x = dData;
+        a.batch = batch;
+        a.binLo = 0;
+        a.binCount = o->F;
+        a.outRe = dRe;
+        a.outIm = complexOut ? dIm : NULL;
+        a.bandStart = o->dBandMeta;
+        a.bandLen = o->dBandMeta + o->num;
+        a.bandOff = o->dBandMeta + 2 * o->num;
+        a.bandW = o->dBandW;
+        a.bandNum = o->num;
+        a.bandPost = post;
+        a.bandPostArg = o->normValue;
+        if (dTemporal) {
+            a.energy = dTemporal;
+            a.rms = dTemporal + framesAll;
+            a.zcr = dTemporal + 2 * framesAll;
+        }
+        return afxk_stft(&a, stream);
+    }
+
+    /* dense bank (gammatone): spectrum scratch in HBM + MFMA GEMM, chunked over clips */
     const int planes = complexOut ? 2 : 1;
     const size_t perClip = (size_t)T * o->F * sizeof(float) * planes;
     long long chunk = (long long)(scratch_budget_bytes() / (perClip ? perClip : 1));
@@ -416,6 +472,8 @@ void bftObj_free(BFTObj o) {
     afxdev_free(o->dWindow);
     afxdev_free(o->dTwiddle);
     afxdev_free(o->dBank);
+    afxdev_free(o->dBandMeta);
+    afxdev_free(o->dBandW);
     afxdev_free(o->dX);
     afxdev_free(o->dSpec);
     afxdev_free(o->dOut);

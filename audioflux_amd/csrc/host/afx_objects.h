@@ -33,6 +33,10 @@ struct OpaqueBFT {
     /* device constants */
     void *stream;
     float *dWindow, *dTwiddle, *dBank;
+    /* banded (row span) view of the bank for the in-kernel filter-bank epilogue of the
+     * size-generic STFT kernel; NULL when the bank is too dense for it */
+    int *dBandMeta;   /* [3][num]: start, len, offset */
+    float *dBandW;
     struct AfxMelFusedPlan *fast; /* NULL when the fused kernel does not apply */
     /* grow-only device scratch of the legacy host-pointer calls */
     float *dX, *dSpec, *dOut, *dTemporal;
