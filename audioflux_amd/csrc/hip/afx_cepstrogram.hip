@@ -15,26 +15,13 @@
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
+#include "afx_ldsfft.h"
 
 namespace {
 
-// in-place radix-2 decimation-in-frequency; afterwards X[k] sits at bitrev_r(k)
+// in-place DIF transform in LDS (afx_ldsfft.h); afterwards X[k] sits at bitrev_r(k)
 __device__ __forceinline__ void fft_dif(float2 *s, int r, const float2 *tw, int tid, int nth) {
-    const int N = 1 << r;
-    for (int st = 0; st < r; ++st) {
-        const int half = N >> (st + 1);
-        for (int j = tid; j < (N >> 1); j += nth) {
-            const int pos = j & (half - 1);
-            const int i0 = ((j - pos) << 1) + pos;
-            const int i1 = i0 + half;
-            const float2 u = s[i0], v = s[i1];
-            const float2 w = tw[pos << st];
-            const float dx = u.x - v.x, dy = u.y - v.y;
-            s[i0] = make_float2(u.x + v.x, u.y + v.y);
-            s[i1] = make_float2(dx * w.x - dy * w.y, dx * w.y + dy * w.x);
-        }
-        __syncthreads();
-    }
+    afx_lds_fft_dif(s, r, tw, 1, tid, nth);
 }
 
 __device__ __forceinline__ int brev(int k, int r) { return (int)(__brev((unsigned)k) >> (32 - r)); }

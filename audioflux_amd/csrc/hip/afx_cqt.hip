@@ -20,6 +20,7 @@
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
+#include "afx_ldsfft.h"
 #include "afx_pkmath.h"
 
 namespace {
@@ -46,20 +47,7 @@ __global__ void k_cqt_octave(AfxCqtOctaveArgs a) {
         s[i] = make_float2(v, 0.f);
     }
     __syncthreads();
-    for (int st = 0; st < r; ++st) {
-        const int half = N >> (st + 1);
-        for (int j = tid; j < (N >> 1); j += nth) {
-            const int pos = j & (half - 1);
-            const int i0 = ((j - pos) << 1) + pos;
-            const int i1 = i0 + half;
-            const float2 u = s[i0], v = s[i1];
-            const float2 w = tw[pos << st];
-            const float dx = u.x - v.x, dy = u.y - v.y;
-            s[i0] = make_float2(u.x + v.x, u.y + v.y);
-            s[i1] = make_float2(dx * w.x - dy * w.y, dx * w.y + dy * w.x);
-        }
-        __syncthreads();
-    }
+    afx_lds_fft_dif(s, r, tw, 1, tid, nth);
     // banded complex kernel: row j covers bins [kStart[j], kStart[j]+kLen[j])
     for (int j = tid; j < a.rows; j += nth) {
         const int k0 = a.kStart[a.rowBase + j], n = a.kLen[a.rowBase + j];
@@ -400,21 +388,7 @@ __global__ __launch_bounds__(NV > 10 ? 256 : 512) void k_cqt_octave_mfma_w(AfxCq
 //   deconv: timbre[0..num), pitch[0..num)
 // One workgroup per frame, radix-2 DIF in LDS (M is 256 for 84 bins: a few kFLOP per frame).
 __device__ __forceinline__ void lds_fft_dif(float2 *s, int r, const float2 *tw, int tid, int nth) {
-    const int N = 1 << r;
-    for (int st = 0; st < r; ++st) {
-        const int half = N >> (st + 1);
-        for (int j = tid; j < (N >> 1); j += nth) {
-            const int pos = j & (half - 1);
-            const int i0 = ((j - pos) << 1) + pos;
-            const int i1 = i0 + half;
-            const float2 u = s[i0], v = s[i1];
-            const float2 w = tw[pos << st];
-            const float dx = u.x - v.x, dy = u.y - v.y;
-            s[i0] = make_float2(u.x + v.x, u.y + v.y);
-            s[i1] = make_float2(dx * w.x - dy * w.y, dx * w.y + dy * w.x);
-        }
-        __syncthreads();
-    }
+    afx_lds_fft_dif(s, r, tw, 1, tid, nth);
 }
 
 __global__ void k_cqt_deconv(const float *__restrict__ in, long long rows, int num, int r,

@@ -17,6 +17,7 @@
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
+#include "afx_ldsfft.h"
 
 namespace {
 
@@ -105,46 +106,7 @@ __global__ void k_stft_generic(AfxStftArgs a) {
 
     // 2. M-point complex FFT; W_M^j = W_N^(2j) = tw[2j]
     const float2 *tw = reinterpret_cast<const float2 *>(a.twiddle);
-    int st = 0;
-    for (; st + 1 < m; st += 2) {  // stages st and st+1 in one pass
-        const int half = M >> (st + 1), half2 = half >> 1;
-        for (int j = tid; j < (M >> 2); j += nth) {
-            const int p = j & (half2 - 1);
-            const int i0 = ((j - p) << 2) + p;  // block base (size 2 half) + p
-            float2 va = s[i0], vb = s[i0 + half2], vc = s[i0 + half], vd = s[i0 + half + half2];
-            const float2 wa = tw[(p << st) << 1];         // W_M^(p << st)
-            const float2 w2 = tw[(p << (st + 1)) << 1];   // W_M^(p << (st+1))
-            // stage st: (a,c) twiddle wa, (b,d) twiddle -i wa
-            const float2 a1 = make_float2(va.x + vc.x, va.y + vc.y);
-            const float2 dc = make_float2(va.x - vc.x, va.y - vc.y);
-            const float2 c1 = make_float2(dc.x * wa.x - dc.y * wa.y, dc.x * wa.y + dc.y * wa.x);
-            const float2 b1 = make_float2(vb.x + vd.x, vb.y + vd.y);
-            const float2 dd = make_float2(vb.x - vd.x, vb.y - vd.y);
-            const float2 d0 = make_float2(dd.x * wa.x - dd.y * wa.y, dd.x * wa.y + dd.y * wa.x);
-            const float2 d1 = make_float2(d0.y, -d0.x);  // times -i
-            // stage st+1: (a1,b1) and (c1,d1), twiddle w2
-            s[i0] = make_float2(a1.x + b1.x, a1.y + b1.y);
-            const float2 e1 = make_float2(a1.x - b1.x, a1.y - b1.y);
-            s[i0 + half2] = make_float2(e1.x * w2.x - e1.y * w2.y, e1.x * w2.y + e1.y * w2.x);
-            s[i0 + half] = make_float2(c1.x + d1.x, c1.y + d1.y);
-            const float2 e2 = make_float2(c1.x - d1.x, c1.y - d1.y);
-            s[i0 + half + half2] = make_float2(e2.x * w2.x - e2.y * w2.y, e2.x * w2.y + e2.y * w2.x);
-        }
-        __syncthreads();
-    }
-    if (st < m) {  // odd stage count: last radix-2 stage (half = 1, twiddle 1)
-        const int half = M >> (st + 1);
-        for (int j = tid; j < (M >> 1); j += nth) {
-            const int pos = j & (half - 1);
-            const int i0 = ((j - pos) << 1) + pos, i1 = i0 + half;
-            const float2 u = s[i0], v = s[i1];
-            const float2 w = tw[(pos << st) << 1];
-            const float dx = u.x - v.x, dy = u.y - v.y;
-            s[i0] = make_float2(u.x + v.x, u.y + v.y);
-            s[i1] = make_float2(dx * w.x - dy * w.y, dx * w.y + dy * w.x);
-        }
-        __syncthreads();
-    }
+    afx_lds_fft_dif(s, m, tw, 2, tid, nth);
 
     // 3. un-pack the requested bins, map them, store (or keep for the filter bank)
     const bool band = a.bandStart != nullptr;
