@@ -96,6 +96,20 @@ struct KArgs {
     int num;
 };
 
+// ---- un-paired LDS reads ----------------------------------------------------------------
+// hipcc's load/store optimizer fuses two float2 reads from one base into ds_read2_b64 /
+// ds_read2st64_b64, which the LDS serves at 128 B/clk; two plain ds_read_b64 run at 256 B/clk
+// (MI355X_MICROARCH.md LDS table; tools/micro/lds_read_rate.hip: 107 vs 68 TB/s aggregate at
+// 12 waves per CU).  The wide read sites therefore issue ds_read_b64 themselves: RD64 requests
+// (immediate offset, no wait), lds_wait() drains, PIN ties each value to the drained state so
+// that no use is scheduled above the wait.  AFX_V & 512 restores the compiler's reads.
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
+#define RD64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define PIN(x) asm volatile("" : "+v"(x))
+#define LDS_WAIT_N(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ void wave_lds_sync() {
     // Orders this wave's LDS stores before its later LDS loads of other lanes' data.  DS
     // operations of one wave execute in issue order; lgkmcnt(0) drains them and the wave
@@ -221,7 +235,42 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     for (; f < fEnd; ++f) {
         v2 v[16];
         // ---- 1. window (samples were fetched during the previous frame) ---------------
-#if !(AFX_V & 32)
+#if !(AFX_V & 32) && !(AFX_V & 512)
+        {
+            // two groups of eight: sixteen window values in flight on top of raw[] and v[] spill
+            const unsigned aw = lds_addr(tabWin + lane);
+#if AFX_V & 2048
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                v2 wv[8];
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) RD64(wv[n1], aw, 512 * (8 * h + n1));
+                lds_wait();
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    PIN(wv[n1]);
+                    v[8 * h + n1] = raw[8 * h + n1] * wv[n1];
+                }
+            }
+#else
+            v2 wv[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) RD64(wv[n1], aw, 512 * n1);
+            LDS_WAIT_N(8);  // in-order return: the first eight have landed
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                PIN(wv[n1]);
+                v[n1] = raw[n1] * wv[n1];
+            }
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int n1 = 8; n1 < 16; ++n1) {
+                PIN(wv[n1]);
+                v[n1] = raw[n1] * wv[n1];
+            }
+#endif
+        }
+#elif !(AFX_V & 32)
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * tabWin[64 * n1 + lane];
 #else
@@ -247,7 +296,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
 
         // ---- 2a. radix-16 over n1, twiddle, transpose through LDS ---------------
         v2 t1[16];
-#if !(AFX_V & 16)
+#if !(AFX_V & 16) && !(AFX_V & 512)
+        // (requested after the butterflies: held across them they cost 30 live VGPRs and spill)
+#elif !(AFX_V & 16)
 #pragma unroll
         for (int k = 1; k < 16; ++k) t1[k] = tabTw1[k * 64 + lane];
 #else
@@ -259,13 +310,34 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         }
 #endif
         dft16(v);
+#if !(AFX_V & 16) && !(AFX_V & 512)
+        {
+            const unsigned a1 = lds_addr(tabTw1 + lane);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) RD64(t1[k], a1, 512 * k);
+        }
+        lds_wait();
+#pragma unroll
+        for (int k = 1; k < 16; ++k) PIN(t1[k]);
+#endif
         ex[lane] = v[0];
 #pragma unroll
         for (int k = 1; k < 16; ++k) ex[k * EX_PITCH + lane] = cmul(v[rev4(k)], t1[k]);
         wave_lds_sync();
+#if !(AFX_V & 512)
+        {
+            const unsigned ae = lds_addr(ex + k1 * EX_PITCH + m2);
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) RD64(v[m1], ae, 32 * m1);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) PIN(v[m1]);
+#else
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) v[m1] = ex[k1 * EX_PITCH + 4 * m1 + m2];
         wave_lds_sync();
+#endif
 
         // ---- 2b. radix-16 over m1, twiddle W_64^(m2*j1) -> image V[m2][q = k1 + 16 j1] ----
         // all twiddles are read in one batch before the butterflies (LDS reads interleaved with
@@ -291,6 +363,43 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         float pkI[CPLX ? 20 : 1], pqI[CPLX ? 20 : 1];  // imaginary parts (complex result mode)
         // every LDS operand of this stage is requested up front (24 + 6 reads in flight)
         v2 zin[2][8], w3[2][4];
+#if !(AFX_V & 4) && !(AFX_V & 512)
+        v2 zc0, zc1, zc2, zc3, wc0, wc1;
+        {
+            const unsigned aq = lds_addr(ex + lane), aq0 = lds_addr(ex + qm), aq1 = lds_addr(ex + 192 - lane);
+            const unsigned a3 = lds_addr(tabTw3 + lane), ac = lds_addr(ex), a3c = lds_addr(tabTw3);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                RD64(zin[0][m], aq, 2080 * m);
+                RD64(zin[0][4 + m], aq0, 2080 * m);
+                RD64(w3[0][m], a3, 2048 * m);
+            }
+            RD64(zc0, ac, 8 * 128);
+            RD64(zc1, ac, 8 * (260 + 128));
+            RD64(zc2, ac, 8 * (520 + 128));
+            RD64(zc3, ac, 8 * (780 + 128));
+            RD64(wc0, a3c, 8 * 128);
+            RD64(wc1, a3c, 8 * 384);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                RD64(zin[1][m], aq, 2080 * m + 512);
+                RD64(zin[1][4 + m], aq1, 2080 * m);
+                RD64(w3[1][m], a3, 2048 * m + 512);
+            }
+            lds_wait();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                PIN(zin[0][m]);
+                PIN(zin[1][m]);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                PIN(w3[0][m]);
+                PIN(w3[1][m]);
+            }
+            PIN(zc0); PIN(zc1); PIN(zc2); PIN(zc3); PIN(wc0); PIN(wc1);
+        }
+#else
 #if !(AFX_V & 4)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -306,6 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
 #endif
         v2 zc0 = ex[128], zc1 = ex[260 + 128], zc2 = ex[520 + 128], zc3 = ex[780 + 128];
         const v2 wc0 = tabTw3[128], wc1 = tabTw3[384];
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #if AFX_V & 4
@@ -358,6 +468,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                 split_pair(zc1, zc2, wc1, pk[17], pq[17]);
             }
         }
+#if !(AFX_V & 512)
+        // a scheduling fence where the GENERAL variants have their map branches: without it the
+        // plain-power variant overlaps the split stage with the row stores and spills
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (CPLX) {
         } else if (GENERAL && a.specMap == 1) {
 #pragma unroll
@@ -417,11 +532,87 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
             const v2 *pb = reinterpret_cast<const v2 *>(prow + startB);
             // operands are requested in blocks of 4 quads (12 LDS reads in flight) so that one
             // LDS round trip is paid per block instead of per quad
+#if !(AFX_V & 512) && !(AFX_V & 1024)
+            // every operand by hand-issued reads, the NEXT block of four quads requested before
+            // this block's values are waited for (in-order return: lgkmcnt(12) = "all but the
+            // 12 reads of the next block"), so one LDS round trip overlaps the previous block's FMAs
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 4, NB = (QT + BLK - 1) / BLK;
+            const unsigned apa = lds_addr(pa), apb = lds_addr(pb), aw = lds_addr(wrow);
+            v4f w[2][BLK];
+            v2 p0[2][BLK], p1[2][BLK];
+            auto request = [&](int blk, v4f (&wq)[BLK], v2 (&q0v)[BLK], v2 (&q1v)[BLK]) {
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const int q = blk * BLK + i;
+                    if (q >= QT) continue;
+                    RD128(wq[i], aw, 16 * q);
+                    if (q < QA) {
+                        RD64(q0v[i], apa, 16 * q);
+                        RD64(q1v[i], apa, 16 * q + 8);
+                    } else {
+                        RD64(q0v[i], apb, 16 * (q - QA));
+                        RD64(q1v[i], apb, 16 * (q - QA) + 8);
+                    }
+                }
+            };
+            request(0, w[0], p0[0], p1[0]);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int cur = blk & 1;
+                const int nextQuads = (blk + 1 < NB) ? ((QT - (blk + 1) * BLK) < BLK ? (QT - (blk + 1) * BLK) : BLK) : 0;
+                if (blk + 1 < NB) request(blk + 1, w[cur ^ 1], p0[cur ^ 1], p1[cur ^ 1]);
+                if (nextQuads == 4) LDS_WAIT_N(12);
+                else if (nextQuads == 3) LDS_WAIT_N(9);
+                else if (nextQuads == 2) LDS_WAIT_N(6);
+                else if (nextQuads == 1) LDS_WAIT_N(3);
+                else LDS_WAIT_N(0);
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    if (blk * BLK + i >= QT) continue;
+                    PIN(w[cur][i]);
+                    PIN(p0[cur][i]);
+                    PIN(p1[cur][i]);
+                    const int q = blk * BLK + i;
+                    if (q < QA) {
+                        sA += v2{w[cur][i].x, w[cur][i].y} * p0[cur][i];
+                        sA += v2{w[cur][i].z, w[cur][i].w} * p1[cur][i];
+                    } else {
+                        sB += v2{w[cur][i].x, w[cur][i].y} * p0[cur][i];
+                        sB += v2{w[cur][i].z, w[cur][i].w} * p1[cur][i];
+                    }
+                }
+            }
+#else
             constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = (AFX_V & 8) ? 1 : (AFX_V & 64) ? 8 : (AFX_V & 128) ? 2 : 4;
 #pragma unroll
             for (int q0 = 0; q0 < QT; q0 += BLK) {
                 float4 w[BLK];
                 v2 p0[BLK], p1[BLK];
+#if !(AFX_V & 512)
+                const unsigned apa = lds_addr(pa), apb = lds_addr(pb);
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const int q = q0 + i;
+                    if (q < QT) {
+                        w[i] = wrow[q];
+                        if (q < QA) {
+                            RD64(p0[i], apa, 16 * q);
+                            RD64(p1[i], apa, 16 * q + 8);
+                        } else {
+                            RD64(p0[i], apb, 16 * (q - QA));
+                            RD64(p1[i], apb, 16 * (q - QA) + 8);
+                        }
+                    }
+                }
+                lds_wait();
+#pragma unroll
+                for (int i = 0; i < BLK; ++i)
+                    if (q0 + i < QT) {
+                        PIN(p0[i]);
+                        PIN(p1[i]);
+                    }
+#else
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) {
                     const int q = q0 + i;
@@ -432,6 +623,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                         p1[i] = src[1];
                     }
                 }
+#endif
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) {
                     const int q = q0 + i;
@@ -446,6 +638,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                     }
                 }
             }
+#endif
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
         }
@@ -535,7 +728,10 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
 
 template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
-    const bool general = (a->specMap != 0) || a->postPow;
+    // the GENERAL instantiation also serves plain |S|^2 (its map branches are two scalar
+    // compares per frame): with the hand-issued LDS reads the branch-free instantiation is
+    // scheduled into 156 B/lane of scratch, the branched one into 150 VGPRs and none
+    const bool general = true;
     const bool shift4 = (a->hop == 512);  // hop = 128 * SHIFT
     if (a->specMap >= 3) {  // complex result: S (3) or S^2 (4), real and imaginary planes
         if (!a->outIm) return AFX_ERR_ARG;
