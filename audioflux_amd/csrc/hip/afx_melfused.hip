@@ -44,12 +44,11 @@
 #include "afx_pkmath.h"
 
 #ifndef AFX_V
-// Compile-time experiment switches (tools/variants.sh builds variants, tools/ab.py runs them
-// interleaved on the GPU).  0 = shipped configuration.  Measured on MI355X, 934 000 frames
-// (profiles/r01_ab_variants.txt): shipped 1.57 ms; +2 (W_64 twiddles read in one batch) 1.64;
-// +16 (W_1024 twiddles through L1 instead of LDS) 1.64; +32 (window through L1) 1.68;
-// +8 (band loop one quad at a time) 5.1; fence-based wave sync (+1) and per-half operand
-// batching of the last stage (+4): no difference.
+// Compile-time experiment switch for within-probe A/B runs (tools/variants.sh builds variants,
+// tools/ab.py runs them interleaved on the GPU).  0 = shipped.  1: fence-based wave sync;
+// 512: compiler-generated LDS reads instead of the hand-issued ones.  Earlier experiments and
+// their timings (W_64 / W_1024 / window tables through L1, band-loop block sizes, operand
+// batching, software pipelining across frames) are recorded in profiles/r01_ab_variants.txt.
 #define AFX_V 0
 #endif
 
@@ -66,7 +65,7 @@ constexpr int WAVES = 12;       // one workgroup per CU: 3 waves per SIMD
 constexpr int TAB_TW1_F2 = 16 * 64;  // W_1024^(lane*k1)
 constexpr int TAB_TW2_F2 = 64;       // W_64^(m2*j1)
 constexpr int TAB_TW3_F2 = 1024;     // 0.5 * W_2048^k, k < 1024
-constexpr int TAB_WIN_F2 = (AFX_V & 32) ? 0 : 1024;  // (w[2n], w[2n+1])
+constexpr int TAB_WIN_F2 = 1024;  // (w[2n], w[2n+1])
 constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
 constexpr int TAB_BYTES = TAB_F2 * 8;  // 20992
 // band weights: one row of TA+TB floats per lane, row pitch TA+TB+4 floats (pitch/4 odd:
@@ -224,35 +223,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         }
     };
     fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
-    // experiment variant: window re-fetched through L1 while the filter-bank stage runs
-#if AFX_V & 32
-    const v2 *gWin = reinterpret_cast<const v2 *>(a.win2) + lane;
-    v2 win[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) win[n1] = gWin[64 * n1];
-#endif
+    // hand-issued LDS reads need register headroom: the complex-result instantiation (two extra
+    // 20-float arrays) keeps the compiler's reads
+    constexpr bool HAND = !(AFX_V & 512) && !CPLX;
 
     for (; f < fEnd; ++f) {
         v2 v[16];
         // ---- 1. window (samples were fetched during the previous frame) ---------------
-#if !(AFX_V & 32) && !(AFX_V & 512)
-        {
-            // two groups of eight: sixteen window values in flight on top of raw[] and v[] spill
+        if constexpr (HAND) {
             const unsigned aw = lds_addr(tabWin + lane);
-#if AFX_V & 2048
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                v2 wv[8];
-#pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) RD64(wv[n1], aw, 512 * (8 * h + n1));
-                lds_wait();
-#pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) {
-                    PIN(wv[n1]);
-                    v[8 * h + n1] = raw[8 * h + n1] * wv[n1];
-                }
-            }
-#else
             v2 wv[16];
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) RD64(wv[n1], aw, 512 * n1);
@@ -268,15 +247,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                 PIN(wv[n1]);
                 v[n1] = raw[n1] * wv[n1];
             }
-#endif
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * tabWin[64 * n1 + lane];
         }
-#elif !(AFX_V & 32)
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * tabWin[64 * n1 + lane];
-#else
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * win[n1];
-#endif
         // ---- 1b. start fetching the next frame: in flight under the whole transform ---
         if (f + 1 < fEnd) {
             int tn = t + 1, cn = clip;
@@ -296,66 +270,44 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
 
         // ---- 2a. radix-16 over n1, twiddle, transpose through LDS ---------------
         v2 t1[16];
-#if !(AFX_V & 16) && !(AFX_V & 512)
-        // (requested after the butterflies: held across them they cost 30 live VGPRs and spill)
-#elif !(AFX_V & 16)
+        if constexpr (!HAND) {
 #pragma unroll
-        for (int k = 1; k < 16; ++k) t1[k] = tabTw1[k * 64 + lane];
-#else
-        {
-            const v2 *gt = reinterpret_cast<const v2 *>(a.tw1) + lane;
-            asm volatile("" : "+v"(gt));
-#pragma unroll
-            for (int k = 1; k < 16; ++k) t1[k] = gt[64 * k];
+            for (int k = 1; k < 16; ++k) t1[k] = tabTw1[k * 64 + lane];
         }
-#endif
         dft16(v);
-#if !(AFX_V & 16) && !(AFX_V & 512)
-        {
+        if constexpr (HAND) {
+            // requested after the butterflies: held across them they cost 30 live VGPRs and spill
             const unsigned a1 = lds_addr(tabTw1 + lane);
 #pragma unroll
             for (int k = 1; k < 16; ++k) RD64(t1[k], a1, 512 * k);
-        }
-        lds_wait();
+            lds_wait();
 #pragma unroll
-        for (int k = 1; k < 16; ++k) PIN(t1[k]);
-#endif
+            for (int k = 1; k < 16; ++k) PIN(t1[k]);
+        }
         ex[lane] = v[0];
 #pragma unroll
         for (int k = 1; k < 16; ++k) ex[k * EX_PITCH + lane] = cmul(v[rev4(k)], t1[k]);
         wave_lds_sync();
-#if !(AFX_V & 512)
-        {
+        if constexpr (HAND) {
             const unsigned ae = lds_addr(ex + k1 * EX_PITCH + m2);
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1) RD64(v[m1], ae, 32 * m1);
+            wave_lds_sync();
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) PIN(v[m1]);
+        } else {
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) v[m1] = ex[k1 * EX_PITCH + 4 * m1 + m2];
+            wave_lds_sync();
         }
-        wave_lds_sync();
-#pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) PIN(v[m1]);
-#else
-#pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) v[m1] = ex[k1 * EX_PITCH + 4 * m1 + m2];
-        wave_lds_sync();
-#endif
 
         // ---- 2b. radix-16 over m1, twiddle W_64^(m2*j1) -> image V[m2][q = k1 + 16 j1] ----
         // all twiddles are read in one batch before the butterflies (LDS reads interleaved with
         // the image writes would be serialised one round trip at a time: same array, may alias)
-#if !(AFX_V & 2)
         dft16(v);
         ex[m2 * 260 + k1] = v[0];
 #pragma unroll
         for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], tabTw2[m2 * 16 + j1]);
-#else
-        v2 t2[16];
-#pragma unroll
-        for (int j1 = 1; j1 < 16; ++j1) t2[j1] = tabTw2[m2 * 16 + j1];
-        dft16(v);
-        ex[m2 * 260 + k1] = v[0];
-#pragma unroll
-        for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], t2[j1]);
-#endif
         wave_lds_sync();
 
         // ---- 3. last radix-4 + real-input split -> spectrum values in registers -------
@@ -363,9 +315,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         float pkI[CPLX ? 20 : 1], pqI[CPLX ? 20 : 1];  // imaginary parts (complex result mode)
         // every LDS operand of this stage is requested up front (24 + 6 reads in flight)
         v2 zin[2][8], w3[2][4];
-#if !(AFX_V & 4) && !(AFX_V & 512)
         v2 zc0, zc1, zc2, zc3, wc0, wc1;
-        {
+        if constexpr (HAND) {
             const unsigned aq = lds_addr(ex + lane), aq0 = lds_addr(ex + qm), aq1 = lds_addr(ex + 192 - lane);
             const unsigned a3 = lds_addr(tabTw3 + lane), ac = lds_addr(ex), a3c = lds_addr(tabTw3);
 #pragma unroll
@@ -398,30 +349,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                 PIN(w3[1][m]);
             }
             PIN(zc0); PIN(zc1); PIN(zc2); PIN(zc3); PIN(wc0); PIN(wc1);
-        }
-#else
-#if !(AFX_V & 4)
+        } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int q = lane + 64 * s;
-            const int qp = s == 0 ? qm : 192 - lane;  // (256 - q) & 255
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                zin[s][m] = ex[260 * m + q];
-                zin[s][4 + m] = ex[260 * m + qp];
-                w3[s][m] = tabTw3[q + 256 * m];
-            }
-        }
-#endif
-        v2 zc0 = ex[128], zc1 = ex[260 + 128], zc2 = ex[520 + 128], zc3 = ex[780 + 128];
-        const v2 wc0 = tabTw3[128], wc1 = tabTw3[384];
-#endif
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#if AFX_V & 4
-            {
+            for (int s = 0; s < 2; ++s) {
                 const int q = lane + 64 * s;
-                const int qp = s == 0 ? qm : 192 - lane;
+                const int qp = s == 0 ? qm : 192 - lane;  // (256 - q) & 255
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     zin[s][m] = ex[260 * m + q];
@@ -429,7 +361,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                     w3[s][m] = tabTw3[q + 256 * m];
                 }
             }
-#endif
+            zc0 = ex[128]; zc1 = ex[260 + 128]; zc2 = ex[520 + 128]; zc3 = ex[780 + 128];
+            wc0 = tabTw3[128]; wc1 = tabTw3[384];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
             v2 za0 = zin[s][0], za1 = zin[s][1], za2 = zin[s][2], za3 = zin[s][3];
             v2 zb0 = zin[s][4], zb1 = zin[s][5], zb2 = zin[s][6], zb3 = zin[s][7];
             dft4(za0, za1, za2, za3);  // Z[q + 256 j]
@@ -468,11 +404,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                 split_pair(zc1, zc2, wc1, pk[17], pq[17]);
             }
         }
-#if !(AFX_V & 512)
-        // a scheduling fence where the GENERAL variants have their map branches: without it the
-        // plain-power variant overlaps the split stage with the row stores and spills
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (CPLX) {
         } else if (GENERAL && a.specMap == 1) {
 #pragma unroll
@@ -511,17 +442,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         if (lane < PROW_F - 1025 - 64) prow[1025 + 64 + lane] = 0.f;
         wave_lds_sync();
 
-        // window for the next frame: lands while the band loops run.  The empty asm makes the
-        // pointer opaque so the (loop-invariant) loads are not hoisted into 32 resident VGPRs.
-#if AFX_V & 32
-        {
-            const v2 *gw = gWin;
-            asm volatile("" : "+v"(gw));
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) win[n1] = gw[64 * n1];
-        }
-#endif
-
         // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset
         //         ds_read_b64 (conflict-free by the plan's bank-aware lane assignment) ------
         float accA, accB;
@@ -532,7 +452,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
             const v2 *pb = reinterpret_cast<const v2 *>(prow + startB);
             // operands are requested in blocks of 4 quads (12 LDS reads in flight) so that one
             // LDS round trip is paid per block instead of per quad
-#if !(AFX_V & 512) && !(AFX_V & 1024)
+            if constexpr (HAND) {
             // every operand by hand-issued reads, the NEXT block of four quads requested before
             // this block's values are waited for (in-order return: lgkmcnt(12) = "all but the
             // 12 reads of the next block"), so one LDS round trip overlaps the previous block's FMAs
@@ -583,36 +503,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                     }
                 }
             }
-#else
-            constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = (AFX_V & 8) ? 1 : (AFX_V & 64) ? 8 : (AFX_V & 128) ? 2 : 4;
+            } else {
+            constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 4;
 #pragma unroll
             for (int q0 = 0; q0 < QT; q0 += BLK) {
                 float4 w[BLK];
                 v2 p0[BLK], p1[BLK];
-#if !(AFX_V & 512)
-                const unsigned apa = lds_addr(pa), apb = lds_addr(pb);
-#pragma unroll
-                for (int i = 0; i < BLK; ++i) {
-                    const int q = q0 + i;
-                    if (q < QT) {
-                        w[i] = wrow[q];
-                        if (q < QA) {
-                            RD64(p0[i], apa, 16 * q);
-                            RD64(p1[i], apa, 16 * q + 8);
-                        } else {
-                            RD64(p0[i], apb, 16 * (q - QA));
-                            RD64(p1[i], apb, 16 * (q - QA) + 8);
-                        }
-                    }
-                }
-                lds_wait();
-#pragma unroll
-                for (int i = 0; i < BLK; ++i)
-                    if (q0 + i < QT) {
-                        PIN(p0[i]);
-                        PIN(p1[i]);
-                    }
-#else
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) {
                     const int q = q0 + i;
@@ -623,7 +519,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                         p1[i] = src[1];
                     }
                 }
-#endif
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) {
                     const int q = q0 + i;
@@ -638,7 +533,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
                     }
                 }
             }
-#endif
+            }
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
         }
@@ -728,22 +623,17 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
 
 template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
-    // the GENERAL instantiation also serves plain |S|^2 (its map branches are two scalar
+    // The GENERAL instantiation also serves plain |S|^2 (its map branches cost two scalar
     // compares per frame): with the hand-issued LDS reads the branch-free instantiation is
-    // scheduled into 156 B/lane of scratch, the branched one into 150 VGPRs and none
-    const bool general = true;
+    // scheduled into 148 B/lane of scratch, the branched one into 150 VGPRs and none.
     const bool shift4 = (a->hop == 512);  // hop = 128 * SHIFT
     if (a->specMap >= 3) {  // complex result: S (3) or S^2 (4), real and imaginary planes
         if (!a->outIm) return AFX_ERR_ARG;
         return shift4 ? launch_variant<TA, TB, true, 4, true>(p, a, stream)
                       : launch_variant<TA, TB, true, 0, true>(p, a, stream);
     }
-    if (general) {
-        return shift4 ? launch_variant<TA, TB, true, 4>(p, a, stream)
-                      : launch_variant<TA, TB, true, 0>(p, a, stream);
-    }
-    return shift4 ? launch_variant<TA, TB, false, 4>(p, a, stream)
-                  : launch_variant<TA, TB, false, 0>(p, a, stream);
+    return shift4 ? launch_variant<TA, TB, true, 4>(p, a, stream)
+                  : launch_variant<TA, TB, true, 0>(p, a, stream);
 }
 
 template <typename T>
