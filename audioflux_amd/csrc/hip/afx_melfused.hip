@@ -555,6 +555,348 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     }
 }
 
+// ---- two frames per wave -------------------------------------------------------------------
+// k_stft_mel_banded is bound by dependency latency at 12 waves per CU, not by
+// LDS bandwidth or VALU throughput.  This variant (hop 512, real results) lets one wave carry
+// TWO consecutive frames t, t+1 of a clip through every stage: two independent butterfly
+// chains for the scheduler to interleave, and every table read (window, W_1024, W_64, W_2048)
+// and every filter-bank weight read serves both frames.  The frames overlap by 1536 samples:
+// their union is 20 float2 registers per lane, the next pair re-uses 12 of them (8 fetched per
+// pair = 4 per frame, as before).  The exchange image is used by frame A, then by frame B; the
+// two power rows fit the same 8.8 KB.  8 waves per CU (2 per SIMD, 256-VGPR budget), 16 frames
+// in flight per CU instead of 12.
+constexpr int PWAVES = 8;
+constexpr int PAIR_LDS_BYTES = 2 * PROW_F * 4;  // 8832 >= the 8704-byte exchange image
+__host__ __device__ constexpr int pair_block_lds_bytes(int ta, int tb) {
+    return TAB_BYTES + 64 * wpitch(ta, tb) * 4 + PWAVES * PAIR_LDS_BYTES;
+}
+
+template <int TA, int TB, bool GENERAL>
+__global__ __launch_bounds__(PWAVES * 64, 2) void k_stft_mel_pair(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr int WP = wpitch(TA, TB);
+    v2 *tabWin = reinterpret_cast<v2 *>(smem);
+    v2 *tabTw1 = tabWin + TAB_WIN_F2;
+    v2 *tabTw2 = tabTw1 + TAB_TW1_F2;
+    v2 *tabTw3 = tabTw2 + TAB_TW2_F2;
+    float *tabW = reinterpret_cast<float *>(smem + TAB_BYTES);
+    v2 *ex = reinterpret_cast<v2 *>(smem + TAB_BYTES + 64 * WP * 4 + wave * PAIR_LDS_BYTES);
+    float *prow = reinterpret_cast<float *>(ex);  // [2][PROW_F], aliases the exchange image
+
+    {
+        const v2 *gTw1 = reinterpret_cast<const v2 *>(a.tw1);
+        const v2 *gTw2 = reinterpret_cast<const v2 *>(a.tw2), *gTw3 = reinterpret_cast<const v2 *>(a.tw3);
+        for (int i = threadIdx.x; i < TAB_WIN_F2; i += PWAVES * 64) tabWin[i] = reinterpret_cast<const v2 *>(a.win2)[i];
+        for (int i = threadIdx.x; i < TAB_TW1_F2; i += PWAVES * 64) tabTw1[i] = gTw1[i];
+        for (int i = threadIdx.x; i < TAB_TW3_F2; i += PWAVES * 64) tabTw3[i] = gTw3[i];
+        for (int i = threadIdx.x; i < 64 * WP; i += PWAVES * 64) tabW[i] = a.wLane[i];
+        if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = gTw2[threadIdx.x];
+    }
+    __syncthreads();
+
+    const int k1 = lane >> 2, m2 = lane & 3;
+    const int startA = a.meta[lane], startB = a.meta[64 + lane];
+    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const float *wrow = tabW + lane * WP;
+    const int qm = (256 - lane) & 255;
+
+    const long long gw = (long long)blockIdx.x * PWAVES + wave;
+    long long f = gw * a.framesPerWave;
+    long long fEnd = f + a.framesPerWave;
+    if (fEnd > a.totalFrames) fEnd = a.totalFrames;
+    if (f >= fEnd) return;
+    int clip = (int)(f / a.timeLength);
+    int t = (int)(f - (long long)clip * a.timeLength);
+
+    // raw[r] = (x[2n], x[2n+1]), n = 64 r + lane, r < 20: frame t is r 0..15, frame t+1 is r 4..19
+    v2 raw[20];
+    auto fetch = [&](const float *px, int first, bool hasNext) {
+        const v2 *p2 = reinterpret_cast<const v2 *>(px);  // launch requires float2-aligned frames
+#pragma unroll
+        for (int r = 0; r < 20; ++r)
+            if (r >= first) raw[r] = (r < 16 || hasNext) ? p2[64 * r + lane] : v2{0.f, 0.f};
+    };
+    fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0, t + 1 < a.timeLength);
+
+    while (f < fEnd) {
+        const bool two = (f + 1 < fEnd) && (t + 1 < a.timeLength);
+        v2 v[2][16];
+        // ---- 1. window: one read per sample position serves both frames -------------------
+        {
+            const unsigned aw = lds_addr(tabWin + lane);
+            v2 wv[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) RD64(wv[n1], aw, 512 * n1);
+            lds_wait();
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                PIN(wv[n1]);
+                v[0][n1] = raw[n1] * wv[n1];
+                v[1][n1] = raw[n1 + 4] * wv[n1];
+            }
+        }
+        // ---- 1b. fetch for the next pair -----------------------------------------------
+        const int adv = two ? 2 : 1;
+        {
+            int tn = t + adv, cn = clip;
+            if (tn >= a.timeLength) {
+                tn = 0;
+                ++cn;
+            }
+            if (f + adv < fEnd) {
+                const float *pn = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
+                const bool hasNext = tn + 1 < a.timeLength;
+                if (two && tn != 0) {  // same clip, two frames on: registers 8..19 become 0..11
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) raw[r] = raw[r + 8];
+                    fetch(pn, 12, hasNext);
+                } else {
+                    fetch(pn, 0, hasNext);
+                }
+            }
+            t = tn;
+            clip = cn;
+        }
+        // ---- 2a. radix-16 over n1, twiddle, transpose through LDS (A, then B) -------------
+        {
+            dft16(v[0]);
+            dft16(v[1]);
+            v2 t1[16];
+            const unsigned a1 = lds_addr(tabTw1 + lane);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) RD64(t1[k], a1, 512 * k);
+            lds_wait();
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                PIN(t1[k]);
+                v[0][rev4(k)] = cmul(v[0][rev4(k)], t1[k]);
+                v[1][rev4(k)] = cmul(v[1][rev4(k)], t1[k]);
+            }
+        }
+        const unsigned ae = lds_addr(ex + k1 * EX_PITCH + m2);
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+            ex[lane] = v[fr][0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) ex[k * EX_PITCH + lane] = v[fr][rev4(k)];
+            wave_lds_sync();
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) RD64(v[fr][m1], ae, 32 * m1);
+            wave_lds_sync();
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) PIN(v[fr][m1]);
+        }
+        // ---- 2b. radix-16 over m1, twiddle W_64^(m2 j1) ------------------------------------
+        dft16(v[0]);
+        dft16(v[1]);
+        {
+            v2 t2[16];
+#pragma unroll
+            for (int j1 = 1; j1 < 16; ++j1) t2[j1] = tabTw2[m2 * 16 + j1];
+#pragma unroll
+            for (int j1 = 1; j1 < 16; ++j1) {
+                v[0][rev4(j1)] = cmul(v[0][rev4(j1)], t2[j1]);
+                v[1][rev4(j1)] = cmul(v[1][rev4(j1)], t2[j1]);
+            }
+        }
+        // ---- 3. image V[m2][q], last radix-4 + real-input split (A, then B) ----------------
+        float pk[2][20], pq[2][20];
+        v2 w3[2][4], wc0, wc1;
+        {
+            const unsigned a3 = lds_addr(tabTw3 + lane), a3c = lds_addr(tabTw3);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                RD64(w3[0][m], a3, 2048 * m);
+                RD64(w3[1][m], a3, 2048 * m + 512);
+            }
+            RD64(wc0, a3c, 8 * 128);
+            RD64(wc1, a3c, 8 * 384);
+        }
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+            ex[m2 * 260 + k1] = v[fr][0];
+#pragma unroll
+            for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = v[fr][rev4(j1)];
+            wave_lds_sync();
+            v2 zin[2][8], zc0, zc1, zc2, zc3;
+            {
+                const unsigned aq = lds_addr(ex + lane), aq0 = lds_addr(ex + qm), aq1 = lds_addr(ex + 192 - lane);
+                const unsigned ac = lds_addr(ex);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    RD64(zin[0][m], aq, 2080 * m);
+                    RD64(zin[0][4 + m], aq0, 2080 * m);
+                    RD64(zin[1][m], aq, 2080 * m + 512);
+                    RD64(zin[1][4 + m], aq1, 2080 * m);
+                }
+                RD64(zc0, ac, 8 * 128);
+                RD64(zc1, ac, 8 * (260 + 128));
+                RD64(zc2, ac, 8 * (520 + 128));
+                RD64(zc3, ac, 8 * (780 + 128));
+                wave_lds_sync();  // drains the reads (and the table reads above on the first pass)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    PIN(zin[0][m]);
+                    PIN(zin[1][m]);
+                }
+                PIN(zc0); PIN(zc1); PIN(zc2); PIN(zc3);
+                if (fr == 0) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        PIN(w3[0][m]);
+                        PIN(w3[1][m]);
+                    }
+                    PIN(wc0);
+                    PIN(wc1);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                v2 za0 = zin[s][0], za1 = zin[s][1], za2 = zin[s][2], za3 = zin[s][3];
+                v2 zb0 = zin[s][4], zb1 = zin[s][5], zb2 = zin[s][6], zb3 = zin[s][7];
+                dft4(za0, za1, za2, za3);
+                dft4(zb0, zb1, zb2, zb3);
+                v2 b0 = zb3, b1 = zb2, b2 = zb1, b3 = zb0;
+                if (s == 0) {
+                    const bool self = (lane == 0);
+                    b0 = self ? zb0 : zb3;
+                    b1 = self ? zb3 : zb2;
+                    b2 = self ? zb2 : zb1;
+                    b3 = self ? zb1 : zb0;
+                }
+                split_pair(za0, b0, w3[s][0], pk[fr][8 * s + 0], pq[fr][8 * s + 0]);
+                split_pair(za1, b1, w3[s][1], pk[fr][8 * s + 1], pq[fr][8 * s + 1]);
+                split_pair(za2, b2, w3[s][2], pk[fr][8 * s + 2], pq[fr][8 * s + 2]);
+                split_pair(za3, b3, w3[s][3], pk[fr][8 * s + 3], pq[fr][8 * s + 3]);
+            }
+            dft4(zc0, zc1, zc2, zc3);
+            split_pair(zc0, zc3, wc0, pk[fr][16], pq[fr][16]);
+            split_pair(zc1, zc2, wc1, pk[fr][17], pq[fr][17]);
+        }
+        if (GENERAL && a.specMap == 1) {
+#pragma unroll
+            for (int fr = 0; fr < 2; ++fr)
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    pk[fr][i] = sqrtf(pk[fr][i]);
+                    pq[fr][i] = sqrtf(pq[fr][i]);
+                }
+        } else if (GENERAL && a.specMap == 2) {
+#pragma unroll
+            for (int fr = 0; fr < 2; ++fr)
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    pk[fr][i] = powf(pk[fr][i], a.normValue);
+                    pq[fr][i] = powf(pq[fr][i], a.normValue);
+                }
+        }
+        // ---- power rows of both frames (the image is no longer needed) ----------------------
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+            float *pr = prow + fr * PROW_F;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * s + 256 * j;
+                    pr[k] = pk[fr][8 * s + j];
+                    pr[MC - k] = pq[fr][8 * s + j];
+                }
+            if (lane == 0) {
+                pr[128] = pk[fr][16];
+                pr[896] = pq[fr][16];
+                pr[384] = pk[fr][17];
+                pr[640] = pq[fr][17];
+            }
+            pr[1025 + lane] = 0.f;
+            if (lane < PROW_F - 1025 - 64) pr[1025 + 64 + lane] = 0.f;
+        }
+        wave_lds_sync();
+        // ---- 4. banded filter bank: every weight read serves both frames -------------------
+        float acc[2][2];
+        {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 2, NB = (QT + BLK - 1) / BLK;
+            const unsigned apa = lds_addr(prow + startA), apb = lds_addr(prow + startB), awr = lds_addr(wrow);
+            v2 sA[2] = {{0.f, 0.f}, {0.f, 0.f}}, sB[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            v4f w[2][BLK];
+            v2 p0[2][2][BLK], p1[2][2][BLK];  // [buffer][frame][quad]
+            auto request = [&](int blk, int buf) {
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const int q = blk * BLK + i;
+                    if (q >= QT) continue;
+                    RD128(w[buf][i], awr, 16 * q);
+#pragma unroll
+                    for (int fr = 0; fr < 2; ++fr) {
+                        if (q < QA) {
+                            RD64(p0[buf][fr][i], apa, 16 * q + 4 * PROW_F * fr);
+                            RD64(p1[buf][fr][i], apa, 16 * q + 8 + 4 * PROW_F * fr);
+                        } else {
+                            RD64(p0[buf][fr][i], apb, 16 * (q - QA) + 4 * PROW_F * fr);
+                            RD64(p1[buf][fr][i], apb, 16 * (q - QA) + 8 + 4 * PROW_F * fr);
+                        }
+                    }
+                }
+            };
+            request(0, 0);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int cur = blk & 1;
+                const int nextQuads = (blk + 1 < NB) ? ((QT - (blk + 1) * BLK) < BLK ? (QT - (blk + 1) * BLK) : BLK) : 0;
+                if (blk + 1 < NB) request(blk + 1, cur ^ 1);
+                if (nextQuads == 2) LDS_WAIT_N(10);  // 5 reads per quad
+                else if (nextQuads == 1) LDS_WAIT_N(5);
+                else LDS_WAIT_N(0);
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const int q = blk * BLK + i;
+                    if (q >= QT) continue;
+                    PIN(w[cur][i]);
+#pragma unroll
+                    for (int fr = 0; fr < 2; ++fr) {
+                        PIN(p0[cur][fr][i]);
+                        PIN(p1[cur][fr][i]);
+                        if (q < QA) {
+                            sA[fr] += v2{w[cur][i].x, w[cur][i].y} * p0[cur][fr][i];
+                            sA[fr] += v2{w[cur][i].z, w[cur][i].w} * p1[cur][fr][i];
+                        } else {
+                            sB[fr] += v2{w[cur][i].x, w[cur][i].y} * p0[cur][fr][i];
+                            sB[fr] += v2{w[cur][i].z, w[cur][i].w} * p1[cur][fr][i];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int fr = 0; fr < 2; ++fr) {
+                acc[fr][0] = sA[fr].x + sA[fr].y;
+                acc[fr][1] = sB[fr].x + sB[fr].y;
+            }
+        }
+        if (GENERAL && a.postPow) {
+#pragma unroll
+            for (int fr = 0; fr < 2; ++fr) {
+                acc[fr][0] = powf(acc[fr][0], a.normValue);
+                acc[fr][1] = powf(acc[fr][1], a.normValue);
+            }
+        }
+        // ---- 5. store -----------------------------------------------------------------
+        {
+            float *orow = a.out + f * a.num;
+            if (rowA >= 0) orow[rowA] = acc[0][0];
+            if (rowB >= 0) orow[rowB] = acc[0][1];
+            if (two) {
+                if (rowA >= 0) orow[a.num + rowA] = acc[1][0];
+                if (rowB >= 0) orow[a.num + rowB] = acc[1][1];
+            }
+        }
+        wave_lds_sync();  // the next pair overwrites the rows
+        f += adv;
+    }
+}
+
 struct Plan {
     int variant;
     int num;
@@ -621,6 +963,52 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     return AFX_OK;
 }
 
+
+template <int TA, int TB>
+int launch_pair(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    if (total <= 0) return AFX_OK;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long waves = (long long)cus * PWAVES * 2;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 16) fpw = 16;
+    fpw = (fpw + 1) & ~1LL;  // pairs
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + PWAVES - 1) / PWAVES;
+    KArgs k;
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.aligned = 1;
+    k.win2 = p->dWin2;
+    k.tw1 = p->dTw1;
+    k.tw2 = p->dTw2;
+    k.tw3 = p->dTw3;
+    k.wLane = p->dWLane;
+    k.meta = p->dMeta;
+    k.specMap = a->specMap;
+    k.postPow = a->postPow;
+    k.normValue = a->normValue;
+    k.out = a->out;
+    k.outIm = nullptr;
+    k.num = p->num;
+    constexpr size_t lds = (size_t)pair_block_lds_bytes(TA, TB);
+    static bool attrSet = false;
+    if (!attrSet) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_pair<TA, TB, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL((k_stft_mel_pair<TA, TB, true>), dim3((unsigned)blocks), dim3(PWAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_mel_pair");
+    return AFX_OK;
+}
+
 template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     // The GENERAL instantiation also serves plain |S|^2 (its map branches cost two scalar
@@ -632,6 +1020,10 @@ int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
         return shift4 ? launch_variant<TA, TB, true, 4, true>(p, a, stream)
                       : launch_variant<TA, TB, true, 0, true>(p, a, stream);
     }
+    // hop 512, float2-aligned frames, real results: two frames per wave
+    const bool alignedFrames = ((a->clipStride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
+    if (shift4 && alignedFrames && a->dataLength >= 2048 && getenv("AFX_PAIR"))
+        return launch_pair<TA, TB>(p, a, stream);
     return shift4 ? launch_variant<TA, TB, true, 4>(p, a, stream)
                   : launch_variant<TA, TB, true, 0>(p, a, stream);
 }
