@@ -81,7 +81,8 @@ typedef struct {
      * outside [0,dataLength) give 0 */
     int padLeft;
     /* optional banded filter bank applied in the same launch (all NULL/0: bins are stored):
-     * row j = sum_q bandW[bandOff[j] + q] * value[bandStart[j] + q], q < bandLen[j];
+     * row j = sum_q bandW[q * bandNum + j] * value[bandStart[j] + q], q < bandLen[j]
+     * (weights tap-major so that the rows of a wave read neighbouring words; bandOff unused);
      * outRe/outIm then are [batch*timeLength, bandNum]; bandPost = AFX_MAP_POW applies
      * powf(., bandPostArg) to the real plane.  The spans must lie inside [binLo, binLo+binCount) */
     const int *bandStart, *bandLen, *bandOff;

@@ -15,6 +15,8 @@
 // served by the register-resident fused kernel in afx_melfused.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_ldsfft.h"
@@ -64,7 +66,7 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
     const int r = a.radix2Exp;
     const int N = 1 << r, M = N >> 1, m = r - 1;
-    float *red = reinterpret_cast<float *>(s + M);
+    float *red = reinterpret_cast<float *>(s + afx_lds_padded_size(M));
     float *prow = red + 16;  // [planes][binCount], band mode only
 
     const long long frame = blockIdx.x;
@@ -80,7 +82,7 @@ __global__ void k_stft_generic(AfxStftArgs a) {
         const long long p = start + 2 * i;
         float v0 = (p >= 0 && p < a.dataLength) ? x[p] : 0.f;
         float v1 = (p + 1 >= 0 && p + 1 < a.dataLength) ? x[p + 1] : 0.f;
-        s[i] = make_float2(v0 * a.window[2 * i], v1 * a.window[2 * i + 1]);
+        s[afx_lds_pad(i)] = make_float2(v0 * a.window[2 * i], v1 * a.window[2 * i + 1]);
     }
     __syncthreads();
 
@@ -88,10 +90,10 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     if (a.energy) {
         float e = 0.f, z = 0.f;
         for (int i = tid; i < M; i += nth) {
-            const float2 v = s[i];
+            const float2 v = s[afx_lds_pad(i)];
             e += v.x * v.x;
             e += v.y * v.y;
-            if (i > 0 && v.x * s[i - 1].y < 0.f) z += 1.f;
+            if (i > 0 && v.x * s[afx_lds_pad(i - 1)].y < 0.f) z += 1.f;
             if (v.y * v.x < 0.f) z += 1.f;
         }
         e = block_sum(e, red);
@@ -106,7 +108,7 @@ __global__ void k_stft_generic(AfxStftArgs a) {
 
     // 2. M-point complex FFT; W_M^j = W_N^(2j) = tw[2j]
     const float2 *tw = reinterpret_cast<const float2 *>(a.twiddle);
-    afx_lds_fft_dif(s, m, tw, 2, tid, nth);
+    afx_lds_fft_dif_t<true>(s, m, tw, 2, tid, nth);
 
     // 3. un-pack the requested bins, map them, store (or keep for the filter bank)
     const bool band = a.bandStart != nullptr;
@@ -115,8 +117,8 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     for (int j = tid; j < a.binCount; j += nth) {
         const int k = a.binLo + j;  // 0 <= k <= M
         const int ka = k & (M - 1), kb = (M - k) & (M - 1);
-        const float2 zk = s[m ? (int)(__brev((unsigned)ka) >> (32 - m)) : 0];
-        const float2 zm = s[m ? (int)(__brev((unsigned)kb) >> (32 - m)) : 0];
+        const float2 zk = s[afx_lds_pad(m ? (int)(__brev((unsigned)ka) >> (32 - m)) : 0)];
+        const float2 zm = s[afx_lds_pad(m ? (int)(__brev((unsigned)kb) >> (32 - m)) : 0)];
         const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
         const float2 w = twn(tw, k, M);
@@ -136,10 +138,10 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     // 4. filter bank rows: ascending taps of the row's non-zero span (src/vector/flux_vector.c:55-86)
     for (int j = tid; j < a.bandNum; j += nth) {
         const int k0 = a.bandStart[j] - a.binLo, n = a.bandLen[j];
-        const float *wj = a.bandW + a.bandOff[j];
+        const float *wj = a.bandW + j;  // tap-major [maxLen][bandNum]: lanes (rows) read neighbours
         float acc0 = 0.f, acc1 = 0.f;
         for (int q = 0; q < n; ++q) {
-            const float wv = wj[q];
+            const float wv = wj[(long long)q * a.bandNum];
             acc0 += wv * prow[k0 + q];
             if (two) acc1 += wv * prow[a.binCount + k0 + q];
         }
@@ -167,7 +169,7 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     if (threads < 64) threads = 64;
     if (threads > 256) threads = 256;
     const bool two = (a->mode == AFX_SPEC_COMPLEX || a->mode == AFX_SPEC_SQUARE);
-    const size_t lds = (size_t)(N / 2 > 0 ? N / 2 : 1) * sizeof(float2) + 16 * sizeof(float) +
+    const size_t lds = (size_t)afx_lds_padded_size(N / 2 > 0 ? N / 2 : 1) * sizeof(float2) + 16 * sizeof(float) +
                        (a->bandStart ? sizeof(float) * (size_t)a->binCount * (two ? 2 : 1) : 0);
     if (lds > 150 * 1024) {
         afxdev_set_error("stft: %zu bytes of LDS per frame", lds);

@@ -204,10 +204,15 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
             total += (size_t)meta[num + i];
         }
         if (st == AFX_OK && total * 4 <= (size_t)num * o->F) {
-            float *w = (float *)malloc(sizeof(float) * (total ? total : 1));
+            /* tap-major weights [maxLen][num]: the kernel's lanes are bank rows */
+            int maxLen = 1;
+            for (int i = 0; i < num; i++)
+                if (meta[num + i] > maxLen) maxLen = meta[num + i];
+            total = (size_t)maxLen * num;
+            float *w = (float *)calloc(total, sizeof(float));
             if (!w) st = AFX_ERR_NOMEM;
             for (int i = 0; i < num && st == AFX_OK; i++)
-                memcpy(w + meta[2 * num + i], hBank + (size_t)i * o->F + meta[i], sizeof(float) * (size_t)meta[num + i]);
+                for (int q = 0; q < meta[num + i]; q++) w[(size_t)q * num + i] = hBank[(size_t)i * o->F + meta[i] + q];
             if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBandMeta, sizeof(int) * 3 * (size_t)num);
             if (st == AFX_OK) st = afxdev_h2d(o->dBandMeta, meta, sizeof(int) * 3 * (size_t)num, o->stream);
             if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBandW, sizeof(float) * (total ? total : 1));
