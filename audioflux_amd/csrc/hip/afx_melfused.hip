@@ -1043,9 +1043,16 @@ extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBan
 extern "C" int afxk_mel1k_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 extern "C" void afxk_mel1k_destroy(void *plan);
 
+// n_fft = 4096 lives in afx_melfused4k.hip (variant numbers >= 200)
+extern "C" int afxk_mel4k_variant(int tapsA, int tapsB);
+extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream);
+extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream);
+extern "C" void afxk_mel4k_destroy(void *plan);
+
 extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
     if (getenv("AFX_NO_FUSED")) return -1;
     if (radix2Exp == 10) return afxk_mel1k_variant(tapsA, tapsB);
+    if (radix2Exp == 12) return afxk_mel4k_variant(tapsA, tapsB);
     if (radix2Exp != 11) return -1;
     for (int i = 0; i < kNumVariants; ++i) {
         if (tapsA <= kVariants[i].tapsA && tapsB <= kVariants[i].tapsB) return i;
@@ -1056,6 +1063,10 @@ extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
 extern "C" void afxk_melfused_destroy(void *plan) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p) return;
+    if (p->variant >= 200) {
+        afxk_mel4k_destroy(plan);
+        return;
+    }
     if (p->variant >= 100) {
         afxk_mel1k_destroy(plan);
         return;
@@ -1074,6 +1085,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     *plan = nullptr;
     const int variant = afxk_melfused_variant(radix2Exp, band->tapsA, band->tapsB);
     if (variant < 0) return AFX_ERR_UNSUPPORTED;
+    if (variant >= 200) return afxk_mel4k_create(plan, hWindow, band, stream);
     if (variant >= 100) return afxk_mel1k_create(plan, hWindow, band, stream);
     const int TA = kVariants[variant].tapsA, TB = kVariants[variant].tapsB;
     Plan *p = static_cast<Plan *>(calloc(1, sizeof(Plan)));
@@ -1141,6 +1153,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
 extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return AFX_ERR_ARG;
+    if (p->variant >= 200) return afxk_mel4k_run(plan, a, stream);
     if (p->variant >= 100) return afxk_mel1k_run(plan, a, stream);
     switch (p->variant) {
         case 0:

@@ -56,6 +56,7 @@ int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dat
         a.specMap = (o->dataType == SpectralData_Power && o->normValue != 1) ? 2 : 0;
     }
     int st = afxk_melfused_run(o->fast, &a, stream);
+    if (st == AFX_ERR_UNSUPPORTED) return AFX_OK; /* e.g. complex results at n_fft 4096: generic kernels */
     if (st == AFX_OK) *used = 1;
     return st;
 }
