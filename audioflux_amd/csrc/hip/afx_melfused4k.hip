@@ -116,13 +116,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
     // raw[n1] = x[4m .. 4m+3], m = 64 n1 + lane
     float4 raw[16];
     auto fetch = [&](const float *px, int first) {
+        if (a.aligned) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(px);
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1)
-            if (n1 >= first) {
-                const int m = 64 * n1 + lane;
-                if (a.aligned) raw[n1] = reinterpret_cast<const float4 *>(px)[m];
-                else raw[n1] = make_float4(px[4 * m], px[4 * m + 1], px[4 * m + 2], px[4 * m + 3]);
-            }
+            for (int n1 = 0; n1 < 16; ++n1)
+                if (n1 >= first) raw[n1] = p4[64 * n1 + lane];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1)
+                if (n1 >= first) {
+                    const int m = 64 * n1 + lane;
+                    raw[n1] = make_float4(px[4 * m], px[4 * m + 1], px[4 * m + 2], px[4 * m + 3]);
+                }
+        }
     };
     fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
 
