@@ -56,7 +56,7 @@ struct KArgs {
     const int *meta;
     int specMap, postPow;
     float normValue;
-    float *out;
+    float *out, *outIm;
     int num;
 };
 
@@ -75,7 +75,7 @@ __device__ __forceinline__ void split_pair_h(v2 A, v2 B, v2 w /* 0.5 W_2048^k */
     hq = v2{y.x, -y.y};
 }
 
-template <int TA, int TB, int SHIFT>
+template <int TA, int TB, int SHIFT, bool CPLX>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
         // spectrum of the even samples at the lane's bins: hk[i] = E[k_i], hq[i] = E[1024 - k_i],
         // i = 8 s + j <-> k = lane + 64 s + 256 j; [16], [17]: k = 128, 384 (every lane)
         v2 ek[18], eq[18];
+        float imv[CPLX ? 18 : 1][4];  // imaginary parts of the lane's bins (complex results)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             v2 v[16];
@@ -232,26 +233,63 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
             } else {
                 // ---- combine: X[k] = E + W_4096^k O, X[2048-k] = conj(E - W O); the spectrum
                 //      values go straight to the power row (the image is no longer needed) -------
-                auto mapv = [&](v2 c) { return c.x * c.x + c.y * c.y; };
+                // complex results (CPLX): S (specMap 3) or S^2 (4); the imaginary parts wait in
+                // registers (E's are free now) for the second pass of the filter-bank stage
+                auto mapv = [&](v2 c, float &im) {
+                    if (!CPLX) return c.x * c.x + c.y * c.y;
+                    if (a.specMap == 4) {
+                        im = 2.f * (c.x * c.y);
+                        return c.x * c.x - c.y * c.y;
+                    }
+                    im = c.y;
+                    return c.x;
+                };
 #pragma unroll
                 for (int i = 0; i < 18; ++i) {
                     if ((i & 7) >= 4 && i < 16) continue;
                     const int k = i < 16 ? lane + 64 * (i >> 3) + 256 * (i & 7) : (i == 16 ? 128 : 384);
                     const v2 tk = cmul(hk[i], tabTw4[k]);         // bins k and 2048 - k
                     const v2 tq = cmul(hq[i], tabTw4[MC - k]);    // bins 1024 - k and 1024 + k
-                    if (i < 16 || lane == 0) {
-                        prow[k] = mapv(ek[i] + tk);
-                        prow[2048 - k] = mapv(ek[i] - tk);
-                        prow[MC - k] = mapv(eq[i] + tq);
-                        prow[MC + k] = mapv(eq[i] - tq);
+                    const v2 xa = ek[i] + tk, xb = ek[i] - tk, ya = eq[i] + tq, yb = eq[i] - tq;
+                    // X[2048-k] = conj(E - T), X[1024+k] = conj(E' - T')
+                    float i0 = 0.f, i1 = 0.f, i2 = 0.f, i3 = 0.f;
+                    const float r0 = mapv(xa, i0), r1 = mapv(v2{xb.x, -xb.y}, i1);
+                    const float r2 = mapv(ya, i2), r3 = mapv(v2{yb.x, -yb.y}, i3);
+                    if (CPLX) {
+                        imv[CPLX ? i : 0][0] = i0;
+                        imv[CPLX ? i : 0][1] = i1;
+                        imv[CPLX ? i : 0][2] = i2;
+                        imv[CPLX ? i : 0][3] = i3;
                     }
+                    if (i < 16 || lane == 0) {
+                        prow[k] = r0;
+                        prow[2048 - k] = r1;
+                        prow[MC - k] = r2;
+                        prow[MC + k] = r3;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
+        if (CPLX && pass == 1) {
+            wave_lds_sync();  // the real pass has read the row
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                if ((i & 7) >= 4 && i < 16) continue;
+                const int k = i < 16 ? lane + 64 * (i >> 3) + 256 * (i & 7) : (i == 16 ? 128 : 384);
+                if (i < 16 || lane == 0) {
+                    prow[k] = imv[CPLX ? i : 0][0];
+                    prow[2048 - k] = imv[CPLX ? i : 0][1];
+                    prow[MC - k] = imv[CPLX ? i : 0][2];
+                    prow[MC + k] = imv[CPLX ? i : 0][3];
                 }
             }
         }
         prow[2049 + lane] = 0.f;
         if (lane < PROW_F - 2049 - 64) prow[2049 + 64 + lane] = 0.f;
         wave_lds_sync();
-        if (a.specMap) {  // magnitude / norm exponent: one compact pass over the row (rare path)
+        if (!CPLX && a.specMap) {  // magnitude / norm exponent: one compact pass over the row (rare path)
             for (int k = lane; k < 2049; k += 64) {
                 const float p = prow[k];
                 prow[k] = a.specMap == 1 ? sqrtf(p) : powf(p, a.normValue);
@@ -297,13 +335,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
         }
-        if (a.postPow) {
+        if (!CPLX && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
         }
-        float *orow = a.out + f * a.num;
+        float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
         if (rowA >= 0) orow[rowA] = accA;
         if (rowB >= 0) orow[rowB] = accB;
+        }  // pass
         wave_lds_sync();
 
         if (++t == a.timeLength) {
@@ -330,7 +369,7 @@ static_assert(block_lds_bytes(96, 32) <= 160 * 1024 && block_lds_bytes(128, 64) 
                   block_lds_bytes(176, 8) <= 160 * 1024,
               "tables + weights + 8 wave images must fit the 160 KB LDS");
 
-template <int TA, int TB, int SHIFT>
+template <int TA, int TB, int SHIFT, bool CPLX>
 int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -360,15 +399,16 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.postPow = a->postPow;
     k.normValue = a->normValue;
     k.out = a->out;
+    k.outIm = a->outIm;
     k.num = p->num;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet = false;
     if (!attrSet) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k<TA, TB, SHIFT>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k<TA, TB, SHIFT, CPLX>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet = true;
     }
-    hipLaunchKernelGGL((k_stft_band_4k<TA, TB, SHIFT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_band_4k<TA, TB, SHIFT, CPLX>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_band_4k");
     return AFX_OK;
@@ -376,8 +416,13 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
 
 template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
-    if (a->specMap >= 3) return AFX_ERR_UNSUPPORTED;  // complex results: size-generic kernel
-    return a->hop == 1024 ? launch_variant<TA, TB, 4>(p, a, stream) : launch_variant<TA, TB, 0>(p, a, stream);
+    if (a->specMap >= 3) {
+        if (!a->outIm) return AFX_ERR_ARG;
+        return a->hop == 1024 ? launch_variant<TA, TB, 4, true>(p, a, stream)
+                              : launch_variant<TA, TB, 0, true>(p, a, stream);
+    }
+    return a->hop == 1024 ? launch_variant<TA, TB, 4, false>(p, a, stream)
+                          : launch_variant<TA, TB, 0, false>(p, a, stream);
 }
 
 template <typename T>

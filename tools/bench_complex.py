@@ -4,8 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import audioflux_amd as af
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 11
 x = 0.1 * torch.randn((200, 480000), device="cuda")
-bft = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+bft = af.BFT(128, radix2_exp=R, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=(1 << R) // 4,
              scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
 bft.set_result_type(0)
 re, im = bft.bft_device(x)
@@ -17,4 +18,4 @@ for _ in range(5):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print(f"fused={'0' if os.environ.get('AFX_NO_FUSED') else '1'} complex mel: {ms:.3f} ms, {200*934/ms/1e3:.1f} M frames/s, checksum {float(re.abs().sum()):.6e} {float(im.abs().sum()):.6e}")
+print(f"fused={'0' if os.environ.get('AFX_NO_FUSED') else '1'} complex mel: {ms:.3f} ms, {re.shape[0]*re.shape[1]/ms/1e3:.1f} M frames/s (n_fft {1 << R}), checksum {float(re.abs().sum()):.6e} {float(im.abs().sum()):.6e}")
