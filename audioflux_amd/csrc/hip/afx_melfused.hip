@@ -1024,8 +1024,13 @@ int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const bool alignedFrames = ((a->clipStride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
     if (shift4 && alignedFrames && a->dataLength >= 2048 && getenv("AFX_PAIR"))
         return launch_pair<TA, TB>(p, a, stream);
-    return shift4 ? launch_variant<TA, TB, true, 4>(p, a, stream)
-                  : launch_variant<TA, TB, true, 0>(p, a, stream);
+    // register re-use of the overlapping frames for hop = 128 * SHIFT: N/8, N/4, N/2
+    switch (a->hop) {
+        case 256: return launch_variant<TA, TB, true, 2>(p, a, stream);
+        case 512: return launch_variant<TA, TB, true, 4>(p, a, stream);
+        case 1024: return launch_variant<TA, TB, true, 8>(p, a, stream);
+        default: return launch_variant<TA, TB, true, 0>(p, a, stream);
+    }
 }
 
 template <typename T>

@@ -63,7 +63,7 @@ def test_bft_matches_compiled_reference_fresh_inputs(seed):
     x = cases.noise(seed, 16000 * 3 + 123)
     # hop 512 runs the register-reuse variant of the fused kernel, hop 300 the plain one;
     # result type 0 (complex, the wrapper's default) its two-pass filter-bank stage
-    for hop in (512, 300):
+    for hop in (512, 300, 256, 1024):
         for rt in (1, 0):
             for dt in (0, 1):
                 r = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1,
