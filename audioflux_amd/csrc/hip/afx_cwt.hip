@@ -25,6 +25,7 @@
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
+#include "afx_ldsfft.h"
 #include "afx_pkmath.h"
 
 namespace {
@@ -362,6 +363,57 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2
     }
 }
 
+// ---- transforms that fit one CU's LDS (L <= 16384: the reference wrapper's default sizes) ----
+// No four-step split, no HBM intermediate: the forward kernel transforms one reflect-padded chunk
+// per workgroup into the natural-order spectrum X[chunk][k]; the inverse kernel takes one
+// (scale, chunk) per workgroup -- conj(X * wavelet) in LDS, forward FFT, conjugate, 1/L, crop.
+__global__ __launch_bounds__(512) void k_cwt_small_fwd(const float *__restrict__ x, long long xStride, int D,
+                                                       int P, int rL, const float2 *__restrict__ tw,
+                                                       float2 *__restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const int L = 1 << rL, tid = threadIdx.x, nth = blockDim.x;
+    x += (long long)blockIdx.x * xStride;
+    for (int n = tid; n < L; n += nth) {
+        float v;  // cwt_algorithm.c:404-414
+        if (n < P) v = x[P - 1 - n];
+        else if (n < P + D) v = x[n - P];
+        else v = x[D - 1 - (n - P - D)];
+        s[afx_lds_pad(n)] = make_float2(v, 0.f);
+    }
+    __syncthreads();
+    afx_lds_fft_dif_t<true>(s, rL, tw, 1, tid, nth);
+    float2 *out = X + (long long)blockIdx.x * L;
+    for (int k = tid; k < L; k += nth) out[k] = s[afx_lds_pad(brev(k, rL))];
+}
+
+__global__ __launch_bounds__(512) void k_cwt_small_inv(const float2 *__restrict__ X,
+                                                       const float *__restrict__ bank, int isDet, int D, int P,
+                                                       int rL, const float2 *__restrict__ tw, int num,
+                                                       float *__restrict__ outRe, float *__restrict__ outIm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const int L = 1 << rL, tid = threadIdx.x, nth = blockDim.x;
+    const int j = blockIdx.x, c = blockIdx.y;
+    const float2 *xc = X + (long long)c * L;
+    const float *bj = bank + (long long)j * L;
+    for (int k = tid; k < L; k += nth) {
+        const float2 xv = xc[k];
+        const float b = bj[k];
+        // conj(X * wavelet) (cwt_algorithm.c:428-435): IFFT through a forward FFT
+        s[afx_lds_pad(k)] = isDet ? make_float2(-b * xv.y, -(b * xv.x)) : make_float2(b * xv.x, -(b * xv.y));
+    }
+    __syncthreads();
+    afx_lds_fft_dif_t<true>(s, rL, tw, 1, tid, nth);
+    const float invL = 1.f / (float)L;
+    float *oRe = outRe + ((long long)c * num + j) * D, *oIm = outIm + ((long long)c * num + j) * D;
+    for (int n = tid; n < D; n += nth) {
+        const float2 a = s[afx_lds_pad(brev(n + P, rL))];
+        oRe[n] = a.x * invL;
+        oIm[n] = -a.y * invL;
+    }
+}
+
 int lds_opt_in(const void *fn, size_t lds) {
     if (lds > 48 * 1024) AFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return AFX_OK;
@@ -382,6 +434,34 @@ CwtGeom make_geom(const AfxCwtPlanDims *d, const float *tw) {
 }
 
 }  // namespace
+
+
+extern "C" int afxk_cwt_small(const AfxCwtPlanDims *d, const float *tw, const float *x, long long xStride,
+                              int chunks, const float *bankNatural, int num, int isDet, float *X,
+                              float *outRe, float *outIm, void *stream) {
+    const int rL = d->r1 + d->r2;
+    if (rL > 14 || chunks <= 0) return rL > 14 ? AFX_ERR_UNSUPPORTED : AFX_OK;
+    if (chunks > 65535 || num > 0x7fffffff) return AFX_ERR_UNSUPPORTED;
+    const int L = 1 << rL;
+    const size_t lds = sizeof(float2) * (size_t)afx_lds_padded_size(L);
+    int st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_small_fwd), lds);
+    if (st == AFX_OK) st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_small_inv), lds);
+    if (st != AFX_OK) return st;
+    int threads = L / 4;
+    if (threads < 64) threads = 64;
+    if (threads > 512) threads = 512;
+    const float2 *tw2 = reinterpret_cast<const float2 *>(tw);
+    if (x) {
+        hipLaunchKernelGGL(k_cwt_small_fwd, dim3(chunks), dim3(threads), lds, (hipStream_t)stream, x, xStride,
+                           d->dataLength, d->pad, rL, tw2, reinterpret_cast<float2 *>(X));
+        AFX_LAUNCH_CHECK("k_cwt_small_fwd");
+    }
+    hipLaunchKernelGGL(k_cwt_small_inv, dim3(num, chunks), dim3(threads), lds, (hipStream_t)stream,
+                       reinterpret_cast<const float2 *>(X), bankNatural, isDet, d->dataLength, d->pad, rL, tw2,
+                       num, outRe, outIm);
+    AFX_LAUNCH_CHECK("k_cwt_small_inv");
+    return AFX_OK;
+}
 
 extern "C" int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x,
                                 long long xStride, int chunks, float *scratchA, float *Xt,

@@ -136,6 +136,12 @@ int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, 
                      int num, int isDet, int chunks, float *scratchB, float *outRe, float *outIm,
                      void *stream);
 
+/* transforms with L = 2^(r1+r2) <= 8192, entirely in LDS: x (NULL: re-use the spectra in X) ->
+ * X[chunks][L] natural order -> outRe/outIm [chunks][num][dataLength]; bankNatural [num][L] */
+int afxk_cwt_small(const AfxCwtPlanDims *d, const float *tw, const float *x, long long xStride,
+                   int chunks, const float *bankNatural, int num, int isDet, float *X, float *outRe,
+                   float *outIm, void *stream);
+
 /* ---- constant-Q transform (afx_cqt.hip) ----------------------------------- */
 typedef struct {
     const float *x;        /* device: this octave's signal                            */

@@ -35,6 +35,7 @@ struct OpaqueCWT {
     float *dTw, *dBankT, *dBankDetT;
     float *dX, *dA, *dXt, *dB, *dOut; /* scratch of the one-chunk calls */
     float *dFastTw;          /* twiddle tables of the register-FFT kernels (L = 2^17) */
+    float *dBankN, *dBankDetN; /* natural-layout banks of the in-LDS path (L <= 16384), else NULL */
     int *dSupport;           /* [num][2]: k2 range holding every non-zero of the scale's wavelet */
     float *dGA, *dGXt, *dGB; /* scratch of the batched calls: `group` chunks at a time */
     size_t capGA, capGXt, capGB;
@@ -489,6 +490,10 @@ int cwtObj_new(CWTObj *cwtObj, int num, int radix2Exp, int *samplate, float *low
     }
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBankT, sizeof(float) * num * L);
     if (st == AFX_OK) st = afxdev_h2d(o->dBankT, bankT, sizeof(float) * num * L, o->stream);
+    if (st == AFX_OK && fftLength <= 16384 && !getenv("AFX_NO_FUSED")) {
+        st = afxdev_malloc((void **)&o->dBankN, sizeof(float) * num * L);
+        if (st == AFX_OK) st = afxdev_h2d(o->dBankN, o->hBank, sizeof(float) * num * L, o->stream);
+    }
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dX, sizeof(float) * (size_t)D);
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dA, sizeof(float) * 2 * L);
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dXt, sizeof(float) * 2 * L);
@@ -515,16 +520,21 @@ static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *
         st = afxdev_stream_sync(o->lastStream);
         o->lastUsed = 0;
     }
+    const int small = o->dBankN != NULL; /* whole transform in LDS: natural-order spectrum in dXt */
     if (st == AFX_OK && dataArr) {
         st = afxdev_h2d(o->dX, dataArr, sizeof(float) * (size_t)o->dataLength, o->stream);
-        if (st == AFX_OK) st = afxk_cwt_forward(&o->dims, o->dTw, o->dX, 0, 1, o->dA, o->dXt, o->stream);
+        if (st == AFX_OK && !small)
+            st = afxk_cwt_forward(&o->dims, o->dTw, o->dX, 0, 1, o->dA, o->dXt, o->stream);
         if (st == AFX_OK) o->haveSpectrum = 1;
     } else if (!dataArr && !o->haveSpectrum) {
         return; /* nothing to re-use yet */
     }
     const size_t outB = sizeof(float) * (size_t)o->num * o->dataLength;
     float *dRe = o->dOut, *dIm = o->dOut + (size_t)o->num * o->dataLength;
-    if (st == AFX_OK)
+    if (st == AFX_OK && small)
+        st = afxk_cwt_small(&o->dims, o->dTw, dataArr ? o->dX : NULL, 0, 1, isDet ? o->dBankDetN : o->dBankN,
+                            o->num, isDet, o->dXt, dRe, dIm, o->stream);
+    else if (st == AFX_OK)
         st = afxk_cwt_inverse(&o->dims, o->dTw, o->dXt, dBank, o->num, isDet, 1, o->dB, dRe, dIm, o->stream);
     if (st == AFX_OK && re) st = afxdev_d2h(re, dRe, outB, o->stream);
     if (st == AFX_OK && im) st = afxdev_d2h(im, dIm, outB, o->stream);
@@ -562,19 +572,41 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
     if (o->lastUsed && o->lastStream != hipStream) st = afxdev_stream_sync(o->lastStream);
     const size_t plane = (size_t)o->num * o->dataLength;
     const size_t L = (size_t)o->fftLength;
+    if (st == AFX_OK && o->dBankN) {
+        /* L <= 16384: forward and inverse entirely in LDS, up to 4096 chunks per launch pair */
+        const int step = 4096;
+        st = afxdev_reserve((void **)&o->dGXt, &o->capGXt, sizeof(float) * 2 * L * (chunks < step ? chunks : step));
+        for (int c = 0; c < chunks && st == AFX_OK; c += step) {
+            const int n = chunks - c < step ? chunks - c : step;
+            st = afxk_cwt_small(&o->dims, o->dTw, dData + (long long)c * chunkStride, chunkStride, n,
+                                isDet ? o->dBankDetN : o->dBankN, o->num, isDet, o->dGXt, dReal + c * plane,
+                                dImag + c * plane, hipStream);
+        }
+        o->lastStream = hipStream;
+        o->lastUsed = 1;
+        if (st != AFX_OK) {
+            o->status = st;
+            fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+        }
+        return st;
+    }
     /* Forward transforms of up to 32 chunks share one launch (a single chunk is only
      * 2^r2/tileCols workgroups).  The inverse runs `group` chunks per launch; its per-scale
      * intermediate is group * num * L complex (88 MB per chunk at num 84, L 2^17), and with
      * group = 1 it is re-read while still resident in the 256 MB memory-side cache
      * (measured: column pass 22.6 us per chunk at group 1, 32 us at group 4). */
-    int group = 1;
+    /* ... i.e. about 88 MB of intermediate per launch pair whatever the transform length:
+     * one chunk at L = 2^17, 16 at the wrapper's default L = 2^13 (otherwise launch-bound) */
+    int group = (int)(96.0e6 / ((double)o->num * L * 8.0));
+    if (group < 1) group = 1;
     {
         const char *e = getenv("AFX_CWT_GROUP");
         if (e && atoi(e) > 0) group = atoi(e);
         while (group > 1 && (double)group * o->num * L * 8.0 > 4.0e9) group /= 2;
         if (group > chunks) group = chunks;
     }
-    const int fwdBatch = chunks < 32 ? chunks : 32;
+    int fwdBatch = group > 32 ? group : 32;
+    if (fwdBatch > chunks) fwdBatch = chunks;
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGA, &o->capGA, sizeof(float) * 2 * L * fwdBatch);
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGXt, &o->capGXt, sizeof(float) * 2 * L * fwdBatch);
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGB, &o->capGB, sizeof(float) * 2 * L * group * o->num);
@@ -636,6 +668,18 @@ void cwtObj_enableDet(CWTObj o, int flag) {
     if (!w) return;
     for (long long i = 0; i <= L / 2; i++) w[i] = (float)(i * 2 * M_PI / L);
     for (long long i = L / 2 + 1, j = L / 2 - 1; i < L && j >= 0; i++, j--) w[i] = -w[j];
+    if (o->dBankN && !o->dBankDetN) { /* in-LDS path: natural layout, same products bank * w */
+        float *dn = (float *)malloc(sizeof(float) * (size_t)o->num * L);
+        if (dn) {
+            for (int i = 0; i < o->num; i++)
+                for (long long k = 0; k < L; k++) dn[(size_t)i * L + k] = o->hBank[(size_t)i * L + k] * w[k];
+            int s2 = afxdev_malloc((void **)&o->dBankDetN, sizeof(float) * (size_t)o->num * L);
+            if (s2 == AFX_OK) s2 = afxdev_h2d(o->dBankDetN, dn, sizeof(float) * (size_t)o->num * L, o->stream);
+            if (s2 == AFX_OK) s2 = afxdev_stream_sync(o->stream);
+            if (s2 != AFX_OK) o->status = s2;
+            free(dn);
+        }
+    }
     float *t = to_transposed(o->hBank, o->num, o->dims.r1, o->dims.r2, w);
     int st = t ? AFX_OK : AFX_ERR_NOMEM;
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBankDetT, sizeof(float) * (size_t)o->num * L);
@@ -670,6 +714,8 @@ void cwtObj_free(CWTObj o) {
     afxdev_free(o->dXt);
     afxdev_free(o->dB);
     afxdev_free(o->dFastTw);
+    afxdev_free(o->dBankN);
+    afxdev_free(o->dBankDetN);
     afxdev_free(o->dSupport);
     afxdev_free(o->dGA);
     afxdev_free(o->dGXt);
