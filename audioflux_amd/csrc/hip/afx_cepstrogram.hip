@@ -30,7 +30,7 @@ __global__ void k_cepstrogram(AfxCepstrogramArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int r = a.radix2Exp, N = 1 << r, F = N / 2 + 1;
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
-    float2 *t = s + N;
+    float2 *t = s + afx_lds_padded_size(N);  // both buffers use skewed addressing (afx_ldsfft.h)
     const float2 *tw = reinterpret_cast<const float2 *>(a.twiddle);
     const int tid = threadIdx.x, nth = blockDim.x;
     const long long frame = blockIdx.x;
@@ -41,56 +41,56 @@ __global__ void k_cepstrogram(AfxCepstrogramArgs a) {
                              ? a.x + (frame / a.framesPerClip) * a.clipStride +
                                    (frame % a.framesPerClip) * (long long)a.hop
                              : a.x + frame * (long long)a.hop;
-        for (int i = tid; i < N; i += nth) s[i] = make_float2(x[i] * a.window[i], 0.f);
+        for (int i = tid; i < N; i += nth) s[afx_lds_pad(i)] = make_float2(x[i] * a.window[i], 0.f);
         __syncthreads();
-        fft_dif(s, r, tw, tid, nth);
+        afx_lds_fft_dif_t<true>(s, r, tw, 1, tid, nth);
         for (int k = tid; k < N; k += nth) {
-            const float2 c = s[brev(k, r)];
+            const float2 c = s[afx_lds_pad(brev(k, r))];
             if (a.specRe) {
                 a.specRe[frame * N + k] = c.x;
                 a.specIm[frame * N + k] = c.y;
             }
             float p = c.x * c.x + c.y * c.y;
             if (p < 1e-16f) p = 1e-16f;
-            t[k] = make_float2(logf(p), 0.f);
+            t[afx_lds_pad(k)] = make_float2(logf(p), 0.f);
         }
     } else {
         for (int k = tid; k < N; k += nth) {
             const float re = a.specRe[frame * N + k], im = a.specIm[frame * N + k];
             float p = re * re + im * im;
             if (p < 1e-16f) p = 1e-16f;
-            t[k] = make_float2(logf(p), 0.f);
+            t[afx_lds_pad(k)] = make_float2(logf(p), 0.f);
         }
     }
     __syncthreads();
 
     // 2. real cepstrum: IFFT(L) = conj(FFT(conj L))/N; L is real, only the real part is kept
-    fft_dif(t, r, tw, tid, nth);
+    afx_lds_fft_dif_t<true>(t, r, tw, 1, tid, nth);
     const float invN = 1.f / (float)N;
     const int q = a.cepNum;
     for (int n = tid; n < N; n += nth) {
-        const float y = t[brev(n, r)].x * invN;
+        const float y = t[afx_lds_pad(brev(n, r))].x * invN;
         if (a.out1 && n < F) a.out1[frame * F + n] = y;
         // lifters (cepstrogram_algorithm.c:258-263, :282-283)
         float l = 0.f, d = 0.f;
         if (n <= q) l = y;
         if (n >= q + 1 && n <= N - q) d = y;
-        s[n] = make_float2(l, d);
+        s[afx_lds_pad(n)] = make_float2(l, d);
     }
     __syncthreads();
     // mirrored low-quefrency part: l[N-1-j] = l[j+1], j < cepNum
     for (int j = tid; j < q && j + 1 < N; j += nth) {
         const int dst = N - 1 - j;
-        if (dst > q) s[dst].x = s[j + 1].x;
+        if (dst > q) s[afx_lds_pad(dst)].x = s[afx_lds_pad(j + 1)].x;
     }
     __syncthreads();
     if (!a.out2 && !a.out3) return;
 
     // 3. one complex FFT carries both real sequences: F = FFT(l) + i FFT(d)
-    fft_dif(s, r, tw, tid, nth);
+    afx_lds_fft_dif_t<true>(s, r, tw, 1, tid, nth);
     for (int k = tid; k < F; k += nth) {
-        const float2 A = s[brev(k, r)];
-        const float2 B = s[brev((N - k) & (N - 1), r)];
+        const float2 A = s[afx_lds_pad(brev(k, r))];
+        const float2 B = s[afx_lds_pad(brev((N - k) & (N - 1), r))];
         if (a.out2) a.out2[frame * F + k] = 0.5f * (A.x + B.x);  // Re FFT(l)[k]
         if (a.out3) a.out3[frame * F + k] = 0.5f * (A.y + B.y);  // Re FFT(d)[k]
     }
@@ -108,7 +108,7 @@ extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
     int threads = N / 2;
     if (threads < 64) threads = 64;
     if (threads > 512) threads = 512;
-    const size_t lds = (size_t)2 * N * sizeof(float2);
+    const size_t lds = (size_t)2 * afx_lds_padded_size(N) * sizeof(float2);
     if (lds > 48 * 1024) {
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
