@@ -54,7 +54,8 @@ enum {
     AFX_SPEC_MAG = 2,     /* sqrt(re^2+im^2)              */
     AFX_SPEC_SQUARE = 3,  /* (re+j im)^2 = re^2-im^2, 2 re im */
     AFX_SPEC_POWER_NORM = 4, /* powf(re^2+im^2, normValue) */
-    AFX_SPEC_MAG_NORM = 5    /* powf(sqrt(re^2+im^2), normValue) */
+    AFX_SPEC_MAG_NORM = 5,   /* powf(sqrt(re^2+im^2), normValue) */
+    AFX_SPEC_PHASE = 6       /* atan2f(im, max(re, 1e-16)) (spectrogram_algorithm.c:1037-1053) */
 };
 
 typedef struct {
@@ -89,10 +90,54 @@ typedef struct {
     const float *bandW;
     int bandNum, bandPost;
     float bandPostArg;
+    /* stftObj_stft: bins binLo+j above fftLength/2 are stored as the conjugate mirror
+     * X[N-k]* (the reference keeps all fftLength bins of its complex transform) */
+    int fullSpectrum;
+    /* what a frame reads outside [0, dataLength): AFX_PAD_ZERO, or the stftObj padding modes
+     * (stft_algorithm.c:601-694) applied as an index map -- no padded copy of the clip exists */
+    int padMode;
+    float padValueL, padValueR; /* AFX_PAD_CONST: left of sample 0 / right of the last sample */
 } AfxStftArgs;
+enum { AFX_PAD_ZERO = 0, AFX_PAD_CONST = 1, AFX_PAD_REFLECT = 2, AFX_PAD_WRAP = 3 };
+/* clip index a padded position maps to (-1: constant), shared by the kernel and the host tests */
+#ifdef __HIPCC__
+#define AFX_HD __host__ __device__
+#else
+#define AFX_HD
+#endif
+AFX_HD static inline long long afx_pad_index(long long q, int n, int mode) {
+    if (q >= 0 && q < n) return q;
+    if (n < 2) return -1;
+    if (mode == AFX_PAD_REFLECT) {
+        const long long P = 2LL * (n - 1);
+        long long m = q % P;
+        if (m < 0) m += P;
+        return m < n ? m : P - m;
+    }
+    if (mode == AFX_PAD_WRAP) {
+        long long m = q % n;
+        if (m < 0) m += n;
+        return m;
+    }
+    return -1;
+}
 
 /* generic framed FFT, any radix2Exp in 1..14 */
 int afxk_stft(const AfxStftArgs *a, void *stream);
+
+/* inverse STFT (afx_istft.hip): re/im [batch*timeLength, N] -> out[b*outStride + j],
+ * j < (timeLength-1)*hop + N: out = (out + sum_frames ifft*win1) / clamp(sum_frames win2) */
+typedef struct {
+    const float *re, *im;  /* device, split planes, row pitch N = 1 << radix2Exp            */
+    int batch, timeLength, radix2Exp, hop;
+    const float *twiddle;  /* device [N/2] float2                                            */
+    const float *win1;     /* device [N]: window^e   (e = 1 weighted overlap-add, 0 plain)  */
+    const float *win2;     /* device [N]: window^(e+1)                                       */
+    float *frames;         /* device scratch [batch*timeLength, N]                           */
+    float *out;            /* device; read-modify-write                                      */
+    long long outStride;
+} AfxIstftArgs;
+int afxk_istft(const AfxIstftArgs *a, void *stream);
 
 enum { AFX_MAP_NONE = 0, AFX_MAP_LOG10 = 1, AFX_MAP_CBRT = 2, AFX_MAP_POW = 3 };
 

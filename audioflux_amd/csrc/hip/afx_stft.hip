@@ -50,8 +50,18 @@ __device__ __forceinline__ void map_bin(float2 c, int mode, float normValue, flo
         case AFX_SPEC_MAG: v0 = sqrtf(c.x * c.x + c.y * c.y); break;
         case AFX_SPEC_SQUARE: v0 = c.x * c.x - c.y * c.y; v1 = 2.f * c.x * c.y; break;
         case AFX_SPEC_MAG_NORM: v0 = powf(sqrtf(c.x * c.x + c.y * c.y), normValue); break;
+        case AFX_SPEC_PHASE: v0 = atan2f(c.y, c.x < 1e-16f ? 1e-16f : c.x); break;
         default: v0 = powf(c.x * c.x + c.y * c.y, normValue); break;  // AFX_SPEC_POWER_NORM
     }
+}
+
+// sample q of the (virtually padded) clip
+__device__ __forceinline__ float fetch(const float *x, long long q, const AfxStftArgs &a) {
+    if (q >= 0 && q < a.dataLength) return x[q];
+    if (a.padMode == AFX_PAD_ZERO) return 0.f;
+    if (a.padMode == AFX_PAD_CONST) return q < 0 ? a.padValueL : a.padValueR;
+    const long long m = afx_pad_index(q, a.dataLength, a.padMode);
+    return m < 0 ? 0.f : x[m];
 }
 
 // The real frame is packed as M = N/2 complex samples z[n] = (x[2n], x[2n+1]) w (half the
@@ -80,8 +90,8 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     //    them through L2, HBM sees each sample once)
     for (int i = tid; i < M; i += nth) {
         const long long p = start + 2 * i;
-        float v0 = (p >= 0 && p < a.dataLength) ? x[p] : 0.f;
-        float v1 = (p + 1 >= 0 && p + 1 < a.dataLength) ? x[p + 1] : 0.f;
+        const float v0 = fetch(x, p, a);
+        const float v1 = fetch(x, p + 1, a);
         s[afx_lds_pad(i)] = make_float2(v0 * a.window[2 * i], v1 * a.window[2 * i + 1]);
     }
     __syncthreads();
@@ -115,14 +125,17 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     const bool two = (a.mode == AFX_SPEC_COMPLEX || a.mode == AFX_SPEC_SQUARE);
     const long long row = frame * (long long)a.binCount;
     for (int j = tid; j < a.binCount; j += nth) {
-        const int k = a.binLo + j;  // 0 <= k <= M
+        int k = a.binLo + j;  // 0 <= k <= M, or up to N-1 with fullSpectrum
+        const bool mirror = k > M;
+        if (mirror) k = N - k;
         const int ka = k & (M - 1), kb = (M - k) & (M - 1);
         const float2 zk = s[afx_lds_pad(m ? (int)(__brev((unsigned)ka) >> (32 - m)) : 0)];
         const float2 zm = s[afx_lds_pad(m ? (int)(__brev((unsigned)kb) >> (32 - m)) : 0)];
         const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
         const float2 w = twn(tw, k, M);
-        const float2 c = make_float2(E.x + (w.x * O.x - w.y * O.y), E.y + (w.x * O.y + w.y * O.x));
+        float2 c = make_float2(E.x + (w.x * O.x - w.y * O.y), E.y + (w.x * O.y + w.y * O.x));
+        if (mirror) c.y = -c.y;
         float v0, v1;
         map_bin(c, a.mode, a.normValue, v0, v1);
         if (band) {

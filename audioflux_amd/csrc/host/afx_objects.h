@@ -60,6 +60,29 @@ struct OpaqueXXCC {
     int status;
 };
 
+struct OpaqueSTFT {
+    int fftLength, radix2Exp, slideLength;
+    WindowType windowType;
+    int isContinue, isPad;
+    PaddingPositionType positionType;
+    PaddingModeType modeType;
+    float padValue1, padValue2;
+    float *windowDataArr; /* host [fftLength]; stftObj_useWindowDataArr overwrites it */
+    int windowDirty;      /* dWindow is stale */
+    float *tailDataArr;   /* host [fftLength]: samples carried to the next streaming call */
+    int tailDataLength;   /* may be negative (hop > fftLength: samples still to skip) */
+    int timeLength;       /* frames of the last stft call */
+    int methodType;       /* inverse: 0 weighted overlap-add, 1 overlap-add, -1 not built */
+    float *winArr1, *winArr2; /* host: window^e, window^(e+1) */
+    void *stream;
+    float *dWindow, *dTwiddle, *dWin12;
+    float *dX, *dOut, *dFrames; /* grow-only device scratch */
+    size_t capX, capOut, capFrames;
+    void *lastStream;
+    int lastStreamSet;
+    int status;
+};
+
 /* fused-kernel hooks (afx_melfused.hip) */
 int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hBank);
 int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,

@@ -34,6 +34,10 @@ class SpectralFilterBankScaleType(IntEnum):
     ERB = 4
     OCTAVE = 5
     LOG = 6
+    DEEP = 7
+    CHROMA = 8
+    OCTAVE_CHROMA = 9
+    DEEP_CHROMA = 10
 
 
 class SpectralFilterBankStyleType(IntEnum):
@@ -84,3 +88,15 @@ class WaveletContinueType(IntEnum):
     MEXICAN = 5
     HERMIT = 6
     RICKER = 7
+
+
+class PaddingPositionType(IntEnum):
+    CENTER = 0
+    RIGHT = 1
+    LEFT = 2
+
+
+class PaddingModeType(IntEnum):
+    CONSTANT = 0
+    REFLECT = 1
+    WRAP = 2

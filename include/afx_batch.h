@@ -19,6 +19,7 @@
 #include "cqt_algorithm.h"
 #include "cwt_algorithm.h"
 #include "feature/xxcc_algorithm.h"
+#include "stft_algorithm.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -94,6 +95,19 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj cepstrogramObj, int cep
                                           const float *dData, int batch, int dataLength,
                                           long long clipStride, float *dOut1, float *dOut2,
                                           float *dOut3, void *hipStream);
+
+/* ---- STFT / inverse STFT ---------------------------------------------------------------
+ * batch clips of dataLength samples -> dReal/dImag [batch][T, fftLength] (all fftLength bins),
+ * T = stftObj_calTimeLength of ONE clip.  The padding switches of the object apply per clip;
+ * the streaming tail (isContinue) is not used: clips of a batch are independent signals.
+ * Same as calling stftObj_stft (stft_algorithm.h) per clip. */
+int stftObj_stftBatchDevice(STFTObj stftObj, const float *dData, int batch, int dataLength,
+                            long long clipStride, float *dReal, float *dImag, void *hipStream);
+/* dReal/dImag [batch][nLength, fftLength] -> dData[b*dataStride + j], j < (nLength-1)*slideLength
+ * + fftLength.  dData is read-modify-write (zero it for a plain inverse), like stftObj_istft. */
+int stftObj_istftBatchDevice(STFTObj stftObj, const float *dReal, const float *dImag, int batch,
+                             int nLength, int type, float *dData, long long dataStride,
+                             void *hipStream);
 
 #ifdef __cplusplus
 }

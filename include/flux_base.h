@@ -95,6 +95,19 @@ typedef enum {
     CepstralEnergy_Ignore = 2
 } CepstralEnergyType;
 
+/* STFT frame padding (reference flux_base.h:142-154) */
+typedef enum {
+    PaddingPosition_Center = 0,
+    PaddingPosition_Right = 1,
+    PaddingPosition_Left = 2
+} PaddingPositionType;
+
+typedef enum {
+    PaddingMode_Constant = 0,
+    PaddingMode_Reflect = 1,
+    PaddingMode_Wrap = 2
+} PaddingModeType;
+
 /* continuous wavelet family (reference flux_base.h:156-169) */
 typedef enum {
     WaveletContinue_Morse = 0,

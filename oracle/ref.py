@@ -310,3 +310,77 @@ def mel_mfcc(x_clips, num=128, radix2_exp=11, samplate=16000, hop=512, cc_num=13
         mels.append(re)
         ccs.append(cc.xxcc(re, cc_num, 0))
     return np.stack(mels), np.stack(ccs)
+
+
+class RefSTFT:
+    """src/stft_algorithm.h:16-39"""
+
+    def __init__(self, radix2_exp, window_type=None, slide_length=None, is_continue=None):
+        L = lib()
+        self.L = L
+        self.n = 1 << radix2_exp
+        self.obj = C.c_void_p(None)
+        L.stftObj_new.restype = C.c_int
+        L.stftObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, ip, ip, ip]
+        self.status = L.stftObj_new(C.byref(self.obj), radix2_exp, _pi(window_type), _pi(slide_length),
+                                    _pi(is_continue))
+        L.stftObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
+        L.stftObj_calDataLength.argtypes = [C.c_void_p, C.c_int]
+        L.stftObj_enablePadding.restype = None
+        L.stftObj_enablePadding.argtypes = [C.c_void_p, C.c_int]
+        L.stftObj_enableContinue.restype = None
+        L.stftObj_enableContinue.argtypes = [C.c_void_p, C.c_int]
+        L.stftObj_setPadding.restype = None
+        L.stftObj_setPadding.argtypes = [C.c_void_p, ip, ip, fp, fp]
+        L.stftObj_setSlideLength.restype = None
+        L.stftObj_setSlideLength.argtypes = [C.c_void_p, C.c_int]
+        L.stftObj_useWindowDataArr.restype = None
+        L.stftObj_useWindowDataArr.argtypes = [C.c_void_p, fp]
+        L.stftObj_getWindowDataArr.restype = fp
+        L.stftObj_getWindowDataArr.argtypes = [C.c_void_p]
+        L.stftObj_stft.restype = None
+        L.stftObj_stft.argtypes = [C.c_void_p, fp, C.c_int, fp, fp]
+        L.stftObj_istft.restype = None
+        L.stftObj_istft.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, fp]
+        L.stftObj_free.argtypes = [C.c_void_p]
+
+    def enable_padding(self, flag):
+        self.L.stftObj_enablePadding(self.obj, int(flag))
+
+    def set_padding(self, position=None, mode=None, value1=None, value2=None):
+        self.L.stftObj_setPadding(self.obj, _pi(position), _pi(mode), _pf(value1), _pf(value2))
+
+    def use_window(self, w):
+        w = np.ascontiguousarray(w, np.float32)
+        self.L.stftObj_useWindowDataArr(self.obj, _f(w))
+
+    def window(self):
+        return np.ctypeslib.as_array(self.L.stftObj_getWindowDataArr(self.obj), (self.n,)).copy()
+
+    def time_length(self, n):
+        return self.L.stftObj_calTimeLength(self.obj, n)
+
+    def data_length(self, t):
+        return self.L.stftObj_calDataLength(self.obj, t)
+
+    def stft(self, x):
+        """x[n] -> (re[T, N], im[T, N]); T as reported BEFORE the call (streaming tail included)"""
+        x = np.ascontiguousarray(x, np.float32)
+        t = self.time_length(x.shape[0])
+        re = np.zeros((t, self.n), np.float32)
+        im = np.zeros((t, self.n), np.float32)
+        self.L.stftObj_stft(self.obj, _f(x), x.shape[0], _f(re), _f(im))
+        return re, im
+
+    def istft(self, re, im, method=0, init=None):
+        re = np.ascontiguousarray(re, np.float32)
+        im = np.ascontiguousarray(im, np.float32)
+        n = self.data_length(re.shape[0])
+        out = np.zeros(n, np.float32) if init is None else np.ascontiguousarray(init, np.float32).copy()
+        self.L.stftObj_istft(self.obj, _f(re), _f(im), re.shape[0], int(method), _f(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.stftObj_free(self.obj)
+            self.obj = C.c_void_p(None)

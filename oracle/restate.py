@@ -159,6 +159,96 @@ def stft(x, fft_length, hop, window_type=1):
     return np.fft.rfft(frames_of(x, fft_length, hop) * w[None, :], axis=1)
 
 
+# --------------------------------------------------------------------------
+# STFT object: padding modes, streaming tail, inverse -- src/stft_algorithm.c
+# --------------------------------------------------------------------------
+def pad_index(q, n, mode):
+    """clip index a position q outside [0, n) of the padded clip reads (or -1: constant/zero):
+    reflect = triangular wave of period 2(n-1) (the zig-zag walk of __vpad_center2,
+    vector/flux_vectorOp.c:654-722), wrap = q mod n (__vpad_center3, :734-768)"""
+    q = np.asarray(q, np.int64)
+    if n < 2:
+        return np.where((q >= 0) & (q < n), q, -1)
+    if mode == "reflect":
+        p = 2 * (n - 1)
+        m = np.mod(q, p)
+        return np.where(m < n, m, p - m)
+    if mode == "wrap":
+        return np.mod(q, n)
+    return np.where((q >= 0) & (q < n), q, -1)
+
+
+def padded_clip(x, fft_length, hop, position="center", mode="constant", value1=0.0, value2=0.0):
+    """the reference's curDataArr in padding mode (stft_algorithm.c:601-694): the ragged tail
+    len % hop is dropped when more than one frame exists (:836-841), the data is placed at
+    N/2 | N | 0 (centre | left | right) inside a buffer of len + N samples"""
+    x = np.asarray(x, np.float64)
+    n_frames = len(x) // hop + 1
+    tail = len(x) % hop if n_frames > 1 else 0
+    x = x[: len(x) - tail]
+    n = len(x)
+    start = {"center": fft_length // 2, "left": fft_length, "right": 0}[position]
+    q = np.arange(n + fft_length) - start
+    if mode == "constant":
+        if position == "center":
+            lo, hi = value1, value2
+        else:  # __vpad_left1 / __vpad_right1 receive the constant as an int (:641-651)
+            lo = hi = float(int(value1))
+        out = np.where(q < 0, lo, hi).astype(np.float64)
+        inside = (q >= 0) & (q < n)
+        out[inside] = x[q[inside]]
+        return out, n_frames
+    idx = pad_index(q, n, mode)
+    out = np.where(idx >= 0, x[np.clip(idx, 0, max(n - 1, 0))], 0.0)
+    return out, n_frames
+
+
+def stft_full(x, fft_length, hop, window):
+    """[T, N] complex128, all N bins (stftObj_stft stores the whole complex transform)"""
+    return np.fft.fft(frames_of(x, fft_length, hop) * np.asarray(window, np.float64)[None, :], axis=1)
+
+
+def stft_padded(x, fft_length, hop, window, **pad):
+    clip, t = padded_clip(x, fft_length, hop, **pad)
+    S = stft_full(clip, fft_length, hop, window)
+    assert S.shape[0] == t
+    return S
+
+
+def istft_norm(t, fft_length, hop, window, method=0):
+    """(gain, normaliser) of stftObj_istft per output sample: sum_frames w^e and the clamped
+    sum_frames w^(e+1).  Tests use gain / normaliser as the condition number of a sample: the
+    float32 rounding of the inverse FFT reaches the output multiplied by it"""
+    w = np.asarray(window, np.float64)
+    e = 1.0 if method == 0 else 0.0
+    gain = np.zeros((t - 1) * hop + fft_length)
+    norm = np.zeros_like(gain)
+    for i in range(t):
+        gain[i * hop:i * hop + fft_length] += np.abs(w) ** e
+        norm[i * hop:i * hop + fft_length] += w ** (e + 1)
+    norm[norm < 1e-6] = 1.0
+    return gain, norm
+
+
+def istft(S, fft_length, hop, window, method=0, init=None):
+    """stftObj_istft (stft_algorithm.c:304-409): per-frame inverse FFT, real part times w^e added
+    onto the caller's buffer, normaliser sum w^(e+1) clamped at 1e-6; e = 1 for method 0"""
+    S = np.asarray(S)
+    t = S.shape[0]
+    n = (t - 1) * hop + fft_length
+    w = np.asarray(window, np.float64)
+    e = 1.0 if method == 0 else 0.0
+    w1, w2 = w ** e, w ** (e + 1)
+    y = np.zeros(n) if init is None else np.asarray(init, np.float64).copy()
+    norm = np.zeros(n)
+    fr = np.fft.ifft(S, axis=1).real
+    for i in range(t):
+        y[i * hop:i * hop + fft_length] += fr[i] * w1
+        norm[i * hop:i * hop + fft_length] += w2
+    norm[norm < 1e-6] = 1.0
+    return y / norm
+
+
 def bft(x, bank, fft_length, hop, window_type=1, data_type="power", result_type=1, norm_value=1.0):
     """bftObj_bft with a filter bank (bft_algorithm.c:456-529).
     result_type 1 -> real [T,num]; 0 -> complex [T,num]"""

@@ -169,3 +169,52 @@ CWT_CASES = {
 
 def cwt_stride(case):
     return max(1, (1 << case["radix2_exp"]) // 512)
+
+
+# STFT object: ctor (radix2_exp, window_type, slide_length) + padding switches + input
+POS = dict(center=0, right=1, left=2)
+PADMODE = dict(constant=0, reflect=1, wrap=2)
+STFT_CASES = {
+    "plain_hann_1024": dict(radix2_exp=10, window_type=WIN["hann"], slide_length=256, x=("noise", 61, 5000)),
+    "plain_nooverlap": dict(radix2_exp=6, window_type=WIN["hamm"], slide_length=100, x=("noise", 62, 2000)),
+    "pad_center_zero_2048": dict(radix2_exp=11, window_type=WIN["hann"], slide_length=512, pad=("center", "constant"),
+                                 x=("tones", 63, 8037)),
+    "pad_center_const": dict(radix2_exp=8, window_type=WIN["hamm"], slide_length=100,
+                             pad=("center", "constant", 0.37, -1.6), x=("noise", 64, 3000)),
+    "pad_left_reflect": dict(radix2_exp=9, window_type=WIN["blackman"], slide_length=128, pad=("left", "reflect"),
+                             x=("noise", 65, 5000)),
+    "pad_right_wrap": dict(radix2_exp=7, window_type=WIN["rect"], slide_length=32, pad=("right", "wrap"),
+                           x=("noise", 66, 1000)),
+    "pad_center_reflect_short": dict(radix2_exp=8, window_type=WIN["hann"], slide_length=64,
+                                     pad=("center", "reflect"), x=("noise", 67, 100)),   # multi-bounce reflect
+    "pad_center_wrap_tiny": dict(radix2_exp=6, window_type=WIN["hann"], slide_length=16,
+                                 pad=("center", "wrap"), x=("noise", 68, 3)),
+    "pad_left_const_trunc": dict(radix2_exp=6, window_type=WIN["gauss"], slide_length=16,
+                                 pad=("left", "constant", 2.7, 0.0), x=("noise", 69, 500)),  # constant -> (int)2.7
+    "pad_right_const_trunc": dict(radix2_exp=6, window_type=WIN["hann"], slide_length=20,
+                                  pad=("right", "constant", -1.5, 0.0), x=("noise", 70, 333)),
+}
+# streaming (isContinue): chunk lengths fed call after call
+STFT_STREAMS = {
+    "stream_hop_quarter": dict(radix2_exp=8, window_type=WIN["hann"], slide_length=64,
+                               chunks=(1000, 5, 3, 300, 256, 1, 700), seed=71),
+    "stream_short_starts": dict(radix2_exp=6, window_type=WIN["hamm"], slide_length=16,
+                                chunks=(10, 20, 30, 3, 1, 64, 63, 65), seed=72),
+    "stream_hop_gt_fft": dict(radix2_exp=5, window_type=WIN["rect"], slide_length=50,
+                              chunks=(100, 40, 7, 200, 33, 90, 10, 10, 10, 10, 10, 10, 100), seed=73),
+}
+# inverse: (source STFT case, method, accumulate onto a non-zero buffer?)
+ISTFT_CASES = {
+    "wola_hann_1024": ("plain_hann_1024", 0, False),
+    "ola_hann_1024": ("plain_hann_1024", 1, False),
+    "wola_gaps": ("plain_nooverlap", 0, False),
+    "ola_accumulate": ("plain_hann_1024", 1, True),
+}
+
+
+def stft_pad_args(case):
+    """(position, mode, value1, value2) ints/floats of a STFT case, or None"""
+    if "pad" not in case:
+        return None
+    p = case["pad"]
+    return (POS[p[0]], PADMODE[p[1]], p[2] if len(p) > 2 else None, p[3] if len(p) > 3 else None)

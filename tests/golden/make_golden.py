@@ -36,6 +36,40 @@ def run_bft_case(c):
     return out
 
 
+def make_stft():
+    """stft.npz: STFT object (padding modes, streaming, inverse) from the compiled reference"""
+    out = {}
+    for name, c in cases.STFT_CASES.items():
+        o = ref.RefSTFT(c["radix2_exp"], c["window_type"], c["slide_length"])
+        assert o.status == 0
+        pad = cases.stft_pad_args(c)
+        if pad:
+            o.enable_padding(1)
+            o.set_padding(*pad)
+        re, im = o.stft(cases.make_input(c["x"], 16000))
+        out[f"{name}/re"], out[f"{name}/im"] = re, im
+    for name, c in cases.STFT_STREAMS.items():
+        o = ref.RefSTFT(c["radix2_exp"], c["window_type"], c["slide_length"], 1)
+        x = cases.noise(c["seed"], sum(c["chunks"]))
+        off, res, ims, tl = 0, [], [], []
+        for n in c["chunks"]:
+            re, im = o.stft(x[off:off + n])
+            off += n
+            tl.append(re.shape[0])
+            res.append(re)
+            ims.append(im)
+        out[f"{name}/re"], out[f"{name}/im"] = np.concatenate(res), np.concatenate(ims)
+        out[f"{name}/tl"] = np.array(tl, np.int32)
+    for name, (src, method, acc) in cases.ISTFT_CASES.items():
+        c = cases.STFT_CASES[src]
+        o = ref.RefSTFT(c["radix2_exp"], c["window_type"], c["slide_length"])
+        re, im = out[f"{src}/re"], out[f"{src}/im"]
+        init = cases.noise(80, o.data_length(re.shape[0])) if acc else None
+        out[f"{name}/y"] = o.istft(re, im, method, init)
+    np.savez_compressed(os.path.join(HERE, "stft.npz"), **out)
+    print("stft.npz", os.path.getsize(os.path.join(HERE, "stft.npz")) // 1024, "KiB")
+
+
 def main():
     assert ref.available(), "build the reference oracle first: make -C oracle"
     bft_out = {}
@@ -102,4 +136,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # `make_golden.py stft ...` regenerates only the named fixture files
+    if len(sys.argv) > 1:
+        for which in sys.argv[1:]:
+            globals()["make_" + which]()
+    else:
+        main()
+        make_stft()
