@@ -11,7 +11,8 @@ from .xxcc import XXCC
 from .cepstrogram import Cepstrogram
 from .cqt import CQT
 from .cwt import CWT
+from .stft import STFT
 from .batch import mel_mfcc_device
 
-__all__ = ["BFT", "XXCC", "Cepstrogram", "CQT", "CWT", "mel_mfcc_device", "get_lib", "build", "runtime_status",
+__all__ = ["BFT", "XXCC", "Cepstrogram", "CQT", "CWT", "STFT", "mel_mfcc_device", "get_lib", "build", "runtime_status",
            "last_error", "LIB_PATH"]
