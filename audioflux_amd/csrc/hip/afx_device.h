@@ -139,6 +139,15 @@ typedef struct {
 } AfxIstftArgs;
 int afxk_istft(const AfxIstftArgs *a, void *stream);
 
+/* afx_spectral.hip: per-bin value (AFX_SPEC_POWER / MAG / *_NORM / PHASE) of the bins
+ * [binLo, binLo+binCount) of a complex spectrum re/im [rows, rowPitch] -> out [rows, binCount] */
+int afxk_spec_map(const float *re, const float *im, long long rows, int rowPitch, int binLo,
+                  int binCount, int mode, float normValue, float *out, void *stream);
+/* in place on data [rows, n]: optional powf(., powArg), then per-row normalisation
+ * (normType = ChromaDataNormalType: 0 none, 1 max, 2 min, 3 P2, 4 P1) */
+int afxk_row_post(float *data, long long rows, int n, int doPow, float powArg, int normType,
+                  void *stream);
+
 enum { AFX_MAP_NONE = 0, AFX_MAP_LOG10 = 1, AFX_MAP_CBRT = 2, AFX_MAP_POW = 3 };
 
 /* C[M,N] = post( pre(A)[M,K] * B[N,K]^T ), row-major, f32 MFMA.

@@ -333,6 +333,12 @@ void afx_auditory_bank(int num, int fftLength, int samplate, SpectralFilterBankS
             fwd = afx_fre_to_log;
             inv = afx_log_to_fre;
             break;
+        case SpectralFilterBankScale_LogChroma: /* the spectrogram object's log-chroma base bank (:106-117, :147-150) */
+            ref = (binPerOctave >= 12 && binPerOctave % 12 == 0) ? (float)binPerOctave : 12.f;
+            afx_auditory_revise_log(num, lowFre, highFre, (int)ref, isEdge, &lowFre, &highFre);
+            fwd = afx_fre_to_log;
+            inv = afx_log_to_fre;
+            break;
         case SpectralFilterBankScale_Linspace:
             revise_linspace(num, lowFre, highFre, isEdge, &lowFre, &highFre);
             break;

@@ -121,6 +121,40 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
         return AFX_ERR_UNSUPPORTED;
     }
 
+    AfxBftPlan p;
+    memset(&p, 0, sizeof(p));
+    p.num = num;
+    p.radix2Exp = r;
+    p.samplate = sr;
+    p.lowFre = low;
+    p.highFre = high;
+    p.lowIndex = lowIndex;
+    p.highIndex = highIndex;
+    p.binPerOctave = bpo;
+    p.windowType = win;
+    p.slideLength = hop;
+    p.dataType = dtype;
+    p.scale = scale;
+    p.style = style;
+    p.normal = normal;
+    p.isTemporal = isTemporal ? *isTemporal : 0;
+    return afx_bft_create(&p, bftObj);
+}
+
+/* builds the object for already-validated parameters: host plan (window, band arrays, bank),
+ * device constants, banded view of the bank, fused-kernel plan.  Shared by bftObj_new and
+ * spectrogramObj_new (their defaults and checks differ, the execution plan does not). */
+int afx_bft_create(const AfxBftPlan *p, BFTObj *bftObj) {
+    const int num = p->num, r = p->radix2Exp, fftLength = 1 << p->radix2Exp, sr = p->samplate;
+    const float low = p->lowFre, high = p->highFre;
+    const int lowIndex = p->lowIndex, highIndex = p->highIndex, bpo = p->binPerOctave;
+    const WindowType win = p->windowType;
+    const SpectralFilterBankScaleType scale = p->scale;
+    *bftObj = NULL;
+    if (r > 14) {
+        afxdev_set_error("fftLength 2^%d exceeds the on-chip FFT limit 2^14", r);
+        return AFX_ERR_UNSUPPORTED;
+    }
     int st = afxdev_ensure();
     if (st != AFX_OK) return st;
 
@@ -137,13 +171,13 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
     o->highIndex = highIndex;
     o->binPerOctave = bpo;
     o->windowType = win;
-    o->slideLength = hop;
-    o->dataType = dtype;
+    o->slideLength = p->slideLength;
+    o->dataType = p->dataType;
     o->scale = scale;
-    o->style = style;
-    o->normal = normal;
+    o->style = p->style;
+    o->normal = p->normal;
     o->normValue = 1;
-    o->isTemporal = isTemporal ? *isTemporal : 0;
+    o->isTemporal = p->isTemporal;
 
     /* --- host-side plan: window, band arrays, bank (bft_algorithm.c:278-389) */
     float *hWindow = afx_window_fft(win, fftLength);
@@ -164,8 +198,11 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
             hBank = (float *)calloc((size_t)num * o->F, sizeof(float));
             if (!hBank) {
                 st = AFX_ERR_NOMEM;
+            } else if (p->customBank) {
+                /* caller-built [num, F] matrix (the STFT-chroma bank of the spectrogram object) */
+                memcpy(hBank, p->customBank, sizeof(float) * (size_t)num * o->F);
             } else {
-                afx_auditory_bank(num, fftLength, sr, scale, style, normal, low, high, bpo, hBank,
+                afx_auditory_bank(num, fftLength, sr, scale, p->style, p->normal, low, high, bpo, hBank,
                                   o->freBandArr, o->binBandArr);
             }
         }

@@ -488,7 +488,7 @@ int cqtObj_cqtBatch(CQTObj o, const float *dataArr, int batch, int dataLength, f
 }
 
 /* 0/1 folding matrix bins -> chroma (chroma_filterBank.c:176-264), host side */
-static unsigned char *chroma_fold(int chromaNum, int num, int bpo, float minFre) {
+unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre) {
     unsigned char *tmp = (unsigned char *)calloc((size_t)chromaNum * num, 1);
     unsigned char *out = (unsigned char *)calloc((size_t)chromaNum * num, 1);
     int n = bpo / chromaNum;
@@ -538,7 +538,7 @@ static int chroma_prepare(CQTObj o, int *chromaNum, SpectralDataType *dataType,
     }
     int st = AFX_OK;
     if (cn != o->foldChromaNum) {
-        unsigned char *fold = chroma_fold(cn, o->num, o->binPerOctave, o->minFre);
+        unsigned char *fold = afx_chroma_fold(cn, o->num, o->binPerOctave, o->minFre);
         if (o->lastUsed) afxdev_stream_sync(o->lastStream); /* a launch may still read the old one */
         afxdev_free(o->dFold);
         o->dFold = NULL;

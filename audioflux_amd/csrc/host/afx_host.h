@@ -53,6 +53,14 @@ int afx_log2_exact(int v);
  * thresholded on its output, so the host copy must round identically) */
 void afx_fft_ref32(int radix2Exp, const float *re1, const float *im1, float *re2, float *im2);
 
+/* ---- chroma banks ------------------------------------------------------ */
+/* afx_cqt.c: 0/1 folding matrix [chromaNum, num] of log-spaced bins onto chroma classes
+ * (src/filterbank/chroma_filterBank.c:176-264); calloc'ed, caller frees */
+unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre);
+/* afx_spectrogram.c: Gaussian STFT-chroma bank [num, fftLength/2+1]
+ * (src/filterbank/chroma_filterBank.c:13-174, default octave centre 5 / width 2) */
+float *afx_chroma_stft_bank(int num, int fftLength, int samplate);
+
 /* ---- afx_bandplan.c ----------------------------------------------------- */
 struct AfxBandPlanTag; /* AfxBandPlan is declared in afx_device.h */
 

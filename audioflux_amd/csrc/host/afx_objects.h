@@ -83,6 +83,29 @@ struct OpaqueSTFT {
     int status;
 };
 
+/* framing state machine of a legacy stftObj_stft call, host fields of the object only
+ * (afx_stft.c; also used by the spectrogram object for its isContinue mode) */
+int afx_stft_deal_data(struct OpaqueSTFT *o, const float *dataArr, int dataLength, int *valid,
+                       int *headTail, int *skip);
+void afx_stft_keep_tail(struct OpaqueSTFT *o, const float *dataArr, int dataLength, int total);
+
+/* validated parameters of a BFT execution plan (afx_bft.c) */
+typedef struct {
+    int num, radix2Exp, samplate;
+    float lowFre, highFre;
+    int lowIndex, highIndex, binPerOctave;
+    WindowType windowType;
+    int slideLength;
+    SpectralDataType dataType;
+    SpectralFilterBankScaleType scale;
+    SpectralFilterBankStyleType style;
+    SpectralFilterBankNormalType normal;
+    int isTemporal;
+    const float *customBank; /* optional host [num, fftLength/2+1] matrix used instead of the
+                              * auditory bank of `scale` (band arrays are then left zero) */
+} AfxBftPlan;
+int afx_bft_create(const AfxBftPlan *p, struct OpaqueBFT **bftObj);
+
 /* fused-kernel hooks (afx_melfused.hip) */
 int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hBank);
 int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,

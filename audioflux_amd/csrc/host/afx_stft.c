@@ -198,7 +198,7 @@ int stftObj_stftBatchDevice(STFTObj o, const float *dData, int batch, int dataLe
 /* streaming / padded framing state of one legacy call (stft_algorithm.c:474-599):
  * returns the frame count (0: nothing to transform), *total = samples to upload (tail + data),
  * *skip = leading samples of dataArr to drop (negative tail of a hop > fftLength stream) */
-static int deal_data(STFTObj o, const float *dataArr, int dataLength, int *valid, int *headTail,
+int afx_stft_deal_data(STFTObj o, const float *dataArr, int dataLength, int *valid, int *headTail,
                      int *skip) {
     const int N = o->fftLength, H = o->slideLength;
     int timeLen = 0, tailLen = 0;
@@ -236,7 +236,7 @@ static int deal_data(STFTObj o, const float *dataArr, int dataLength, int *valid
 }
 
 /* after the upload: the last tailLen samples of [old tail | data] become the new tail (:548-557) */
-static void keep_tail(STFTObj o, const float *dataArr, int dataLength, int total) {
+void afx_stft_keep_tail(STFTObj o, const float *dataArr, int dataLength, int total) {
     if (!o->isContinue || o->isPad) {
         o->tailDataLength = 0;
         return;
@@ -269,7 +269,7 @@ void stftObj_stft(STFTObj o, float *dataArr, int dataLength, float *mRealArr, fl
     if (!dataArr || dataLength <= 0) return; /* stft_algorithm.c:267-269 */
     int valid = dataLength, headTail = 0, skip = 0, T;
     if (o->isPad || o->isContinue) {
-        T = deal_data(o, dataArr, dataLength, &valid, &headTail, &skip);
+        T = afx_stft_deal_data(o, dataArr, dataLength, &valid, &headTail, &skip);
     } else {
         T = stftObj_calTimeLength(o, dataLength);
         o->timeLength = T;
@@ -295,7 +295,7 @@ void stftObj_stft(STFTObj o, float *dataArr, int dataLength, float *mRealArr, fl
     if (st == AFX_OK) st = afxdev_d2h(mRealArr, o->dOut, outB, o->stream);
     if (st == AFX_OK) st = afxdev_d2h(mImageArr, o->dOut + (size_t)T * N, outB, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
-    if (o->isContinue && !o->isPad) keep_tail(o, dataArr + skip, dataLength - skip, total);
+    if (o->isContinue && !o->isPad) afx_stft_keep_tail(o, dataArr + skip, dataLength - skip, total);
     if (st != AFX_OK) fail(o, st, "stftObj_stft");
 }
 
@@ -421,7 +421,7 @@ int afx_test_stft_stream(int radix2Exp, int slideLength, int isPad, const float 
         const int n = chunkLens[c];
         int valid = n, headTail = 0, skip = 0;
         if (stftObj_calTimeLength(&s, n) < 0) return AFX_ERR_ARG;
-        const int T = deal_data(&s, chunk, n, &valid, &headTail, &skip);
+        const int T = afx_stft_deal_data(&s, chunk, n, &valid, &headTail, &skip);
         timeLens[c] = T;
         curLens[c] = 0;
         if (T > 0) {
@@ -430,7 +430,7 @@ int afx_test_stft_stream(int radix2Exp, int slideLength, int isPad, const float 
             memcpy(cur + w + headTail, chunk + skip, sizeof(float) * (size_t)upData);
             curLens[c] = headTail + upData;
             w += curLens[c];
-            if (!s.isPad) keep_tail(&s, chunk + skip, n - skip, headTail + upData);
+            if (!s.isPad) afx_stft_keep_tail(&s, chunk + skip, n - skip, headTail + upData);
         }
         tails[c] = s.tailDataLength;
         off += n;

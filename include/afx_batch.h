@@ -19,6 +19,7 @@
 #include "cqt_algorithm.h"
 #include "cwt_algorithm.h"
 #include "feature/xxcc_algorithm.h"
+#include "spectrogram_algorithm.h"
 #include "stft_algorithm.h"
 
 #ifdef __cplusplus
@@ -95,6 +96,14 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj cepstrogramObj, int cep
                                           const float *dData, int batch, int dataLength,
                                           long long clipStride, float *dOut1, float *dOut2,
                                           float *dOut3, void *hipStream);
+
+/* ---- spectrogram object ------------------------------------------------------------------
+ * batch clips of dataLength samples -> dSpect [batch][T, num] (T = frames of ONE clip without the
+ * streaming tail).  Same as calling spectrogramObj_spectrogram (spectrogram_algorithm.h) per
+ * clip on a non-continuing object; mel / bark / erb run the fused STFT -> filter-bank kernels. */
+int spectrogramObj_spectrogramBatchDevice(SpectrogramObj spectrogramObj, const float *dData, int batch,
+                                          int dataLength, long long clipStride, float *dSpect,
+                                          void *hipStream);
 
 /* ---- STFT / inverse STFT ---------------------------------------------------------------
  * batch clips of dataLength samples -> dReal/dImag [batch][T, fftLength] (all fftLength bins),

@@ -384,3 +384,103 @@ class RefSTFT:
         if getattr(self, "obj", None):
             self.L.stftObj_free(self.obj)
             self.obj = C.c_void_p(None)
+
+
+class RefSpectrogram:
+    """src/spectrogram_algorithm.h:43-106 (core entry points)"""
+
+    def __init__(self, num=0, samplate=None, low_fre=None, high_fre=None, bin_per_octave=None, radix2_exp=None,
+                 window_type=None, slide_length=None, is_continue=None, data_type=None, scale_type=None,
+                 style_type=None, normal_type=None, preset=None):
+        L = lib()
+        self.L = L
+        self.obj = C.c_void_p(None)
+        if preset:  # ("Mel", num, samplate, radix2_exp) | ("Linear"/"Chroma", samplate, radix2_exp)
+            fn = getattr(L, "spectrogramObj_new" + preset[0])
+            fn.restype = C.c_int
+            ints = [int(v) for v in preset[1:]]
+            fn.argtypes = [C.POINTER(C.c_void_p)] + [C.c_int] * len(ints) + [ip]
+            self.status = fn(C.byref(self.obj), *ints, _pi(is_continue))
+            self.n = 1 << ints[-1]
+        else:
+            L.spectrogramObj_new.restype = C.c_int
+            L.spectrogramObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, ip, fp, fp] + [ip] * 9
+            self.status = L.spectrogramObj_new(C.byref(self.obj), num, _pi(samplate), _pf(low_fre), _pf(high_fre),
+                                               _pi(bin_per_octave), _pi(radix2_exp), _pi(window_type),
+                                               _pi(slide_length), _pi(is_continue), _pi(data_type),
+                                               _pi(scale_type), _pi(style_type), _pi(normal_type))
+            self.n = 1 << (12 if radix2_exp is None else radix2_exp)
+        L.spectrogramObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
+        L.spectrogramObj_getBandNum.argtypes = [C.c_void_p]
+        L.spectrogramObj_getFreBandArr.restype = fp
+        L.spectrogramObj_getFreBandArr.argtypes = [C.c_void_p]
+        L.spectrogramObj_getBinBandArr.restype = ip
+        L.spectrogramObj_getBinBandArr.argtypes = [C.c_void_p]
+        L.spectrogramObj_setDataNormValue.restype = None
+        L.spectrogramObj_setDataNormValue.argtypes = [C.c_void_p, C.c_float]
+        L.spectrogramObj_setChromaDataNormalType.restype = None
+        L.spectrogramObj_setChromaDataNormalType.argtypes = [C.c_void_p, C.c_int]
+        L.spectrogramObj_spectrogram.restype = None
+        L.spectrogramObj_spectrogram.argtypes = [C.c_void_p, fp, C.c_int, fp, fp]
+        L.spectrogramObj_spectrogram1.restype = None
+        L.spectrogramObj_spectrogram1.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, fp, fp]
+        for name in ("mfcc", "bfcc", "gtcc"):
+            f = getattr(L, "spectrogramObj_" + name)
+            f.restype, f.argtypes = None, [C.c_void_p, fp, C.c_int, fp]
+        L.spectrogramObj_xxcc.restype = None
+        L.spectrogramObj_xxcc.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
+        L.spectrogramObj_deconv.restype = None
+        L.spectrogramObj_deconv.argtypes = [C.c_void_p, fp, fp, fp]
+        L.spectrogramObj_free.argtypes = [C.c_void_p]
+        self.num = L.spectrogramObj_getBandNum(self.obj) if self.status == 0 else 0
+
+    def set_norm(self, v):
+        self.L.spectrogramObj_setDataNormValue(self.obj, v)
+
+    def set_chroma_norm(self, t):
+        self.L.spectrogramObj_setChromaDataNormalType(self.obj, int(t))
+
+    def time_length(self, n):
+        return self.L.spectrogramObj_calTimeLength(self.obj, n)
+
+    def fre_band(self, count=None):
+        return np.ctypeslib.as_array(self.L.spectrogramObj_getFreBandArr(self.obj), (count or self.num,)).copy()
+
+    def bin_band(self, count=None):
+        return np.ctypeslib.as_array(self.L.spectrogramObj_getBinBandArr(self.obj), (count or self.num,)).copy()
+
+    def spectrogram(self, x, phase=False):
+        x = np.ascontiguousarray(x, np.float32)
+        t = self.time_length(x.shape[0])
+        out = np.zeros((t, self.num), np.float32)
+        ph = np.zeros((t, self.num), np.float32) if phase else None
+        self.L.spectrogramObj_spectrogram(self.obj, _f(x), x.shape[0], _f(out), _f(ph) if phase else None)
+        return (out, ph) if phase else out
+
+    def spectrogram1(self, re, im, phase=False):
+        re, im = np.ascontiguousarray(re, np.float32), np.ascontiguousarray(im, np.float32)
+        out = np.zeros((re.shape[0], self.num), np.float32)
+        ph = np.zeros((re.shape[0], self.num), np.float32) if phase else None
+        self.L.spectrogramObj_spectrogram1(self.obj, _f(re), _f(im), re.shape[0], re.shape[1], _f(out),
+                                           _f(ph) if phase else None)
+        return (out, ph) if phase else out
+
+    def cc(self, kind, m, cc_num, rectify=None):
+        m = np.ascontiguousarray(m, np.float32)
+        out = np.zeros((m.shape[0], cc_num), np.float32)
+        if kind == "xxcc":
+            self.L.spectrogramObj_xxcc(self.obj, _f(m), cc_num, _pi(rectify), _f(out))
+        else:
+            getattr(self.L, "spectrogramObj_" + kind)(self.obj, _f(m), cc_num, _f(out))
+        return out
+
+    def deconv(self, m):
+        m = np.ascontiguousarray(m, np.float32)
+        a, b = np.zeros_like(m), np.zeros_like(m)
+        self.L.spectrogramObj_deconv(self.obj, _f(m), _f(a), _f(b))
+        return a, b
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.spectrogramObj_free(self.obj)
+            self.obj = C.c_void_p(None)

@@ -218,3 +218,60 @@ def stft_pad_args(case):
         return None
     p = case["pad"]
     return (POS[p[0]], PADMODE[p[1]], p[2] if len(p) > 2 else None, p[3] if len(p) > 3 else None)
+
+
+# spectrogram object: reference ctor kwargs (RefSpectrogram names) + switches + input
+SCALE_X = dict(SCALE, deep=7, chroma=8, logchroma=9, deepchroma=10)
+SPEC_CASES = {
+    # the reference's published benchmark configuration (benchmark/run_audioflux.py:15-22)
+    "bench_mel128": dict(num=128, samplate=32000, low_fre=0.0, high_fre=16000.0, radix2_exp=11,
+                         window_type=WIN["hann"], slide_length=512, data_type=0, scale_type=SCALE["mel"],
+                         style_type=STYLE["slaney"], normal_type=NORMAL["none"], x=("noise", 201, 48000),
+                         cc=("mfcc", 13), from_stft=True),
+    "bark64_mag_norm": dict(num=64, samplate=16000, low_fre=0.0, high_fre=8000.0, radix2_exp=10,
+                            window_type=WIN["hamm"], slide_length=256, data_type=1, scale_type=SCALE["bark"],
+                            style_type=STYLE["slaney"], normal_type=NORMAL["area"], norm=0.5,
+                            x=("tones", 202, 12000), cc=("bfcc", 20), from_stft=True),
+    "erb32_gammatone": dict(num=32, samplate=16000, low_fre=100.0, high_fre=7000.0, radix2_exp=9,
+                            window_type=WIN["hann"], slide_length=128, data_type=0, scale_type=SCALE["erb"],
+                            style_type=STYLE["gammatone"], normal_type=NORMAL["none"], x=("noise", 203, 6000),
+                            cc=("gtcc", 13)),
+    "octave84_mag": dict(num=84, samplate=32000, low_fre=32.703, radix2_exp=12, bin_per_octave=12,
+                         window_type=WIN["hann"], slide_length=1024, data_type=1, scale_type=SCALE["octave"],
+                         style_type=STYLE["slaney"], normal_type=NORMAL["none"], x=("mix", 204, 30000),
+                         cc=("xxcc", 20, 1), deconv=True),
+    "linear_default": dict(num=0, samplate=16000, radix2_exp=9, window_type=WIN["hann"], data_type=0,
+                           scale_type=SCALE["linear"], x=("noise", 205, 5000), phase=True, from_stft=True),
+    "linear_slice_mag_norm": dict(num=0, samplate=16000, low_fre=1000.0, high_fre=5000.0, radix2_exp=10,
+                                  window_type=WIN["blackman"], slide_length=200, data_type=1,
+                                  scale_type=SCALE["linear"], norm=2.0, x=("tones", 206, 9000), phase=True),
+    "linspace40_power_norm": dict(num=40, samplate=8000, low_fre=200.0, high_fre=3500.0, radix2_exp=8,
+                                  window_type=WIN["hann"], slide_length=64, data_type=0,
+                                  scale_type=SCALE["linspace"], style_type=STYLE["hann"],
+                                  normal_type=NORMAL["none"], norm=0.7, x=("noise", 207, 3000)),
+    "chroma12_power": dict(num=12, samplate=32000, radix2_exp=12, window_type=WIN["hann"], data_type=0,
+                           scale_type=SCALE_X["chroma"], x=("mix", 208, 30000), from_stft=True),
+    "chroma24_mag_range_p2": dict(num=24, samplate=16000, low_fre=100.0, high_fre=5000.0, radix2_exp=11,
+                                  window_type=WIN["hann"], slide_length=512, data_type=1,
+                                  scale_type=SCALE_X["chroma"], norm=0.5, chroma_norm=3, x=("mix", 209, 20000)),
+    # high_fre well below Nyquist: with the wrapper default (samplate / 2) the reference's base bank has
+    # band edges above Nyquist and writes past its matrix (heap overflow at auditory_filterBank.c:474)
+    "logchroma12_power": dict(num=12, samplate=32000, low_fre=32.703, high_fre=8000.0, radix2_exp=12, bin_per_octave=12,
+                              window_type=WIN["hann"], data_type=0, scale_type=SCALE_X["logchroma"],
+                              x=("mix", 210, 30000), from_stft=True),
+    "logchroma_bpo36_mag_p1": dict(num=12, samplate=44100, low_fre=65.406, high_fre=8000.0, radix2_exp=12,
+                                   bin_per_octave=36, window_type=WIN["hann"], slide_length=1024, data_type=1,
+                                   scale_type=SCALE_X["logchroma"], norm=2.0, chroma_norm=4,
+                                   x=("mix", 211, 40000)),
+    "chroma_none_norm": dict(num=12, samplate=16000, radix2_exp=10, window_type=WIN["hann"], data_type=0,
+                             scale_type=SCALE_X["chroma"], chroma_norm=0, x=("noise", 212, 9000)),
+}
+SPEC_STREAM = dict(num=64, samplate=16000, low_fre=0.0, high_fre=8000.0, radix2_exp=10, window_type=WIN["hann"],
+                   slide_length=256, data_type=0, scale_type=SCALE["mel"], style_type=STYLE["slaney"],
+                   normal_type=NORMAL["none"], is_continue=1, chunks=(3000, 100, 5000, 1024, 7), seed=213)
+SPEC_CTOR = ("num", "samplate", "low_fre", "high_fre", "bin_per_octave", "radix2_exp", "window_type",
+             "slide_length", "is_continue", "data_type", "scale_type", "style_type", "normal_type")
+
+
+def spec_ctor(case):
+    return {k: case[k] for k in SPEC_CTOR if k in case}

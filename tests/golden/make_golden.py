@@ -70,6 +70,50 @@ def make_stft():
     print("stft.npz", os.path.getsize(os.path.join(HERE, "stft.npz")) // 1024, "KiB")
 
 
+def run_spec_case(c):
+    kw = cases.spec_ctor(c)
+    o = ref.RefSpectrogram(kw.pop("num"), **kw)
+    assert o.status == 0, o.status
+    if "norm" in c:
+        o.set_norm(c["norm"])
+    if "chroma_norm" in c:
+        o.set_chroma_norm(c["chroma_norm"])
+    x = cases.make_input(c["x"], c["samplate"])
+    out = {"num": np.array([o.num], np.int32)}
+    if c.get("phase"):
+        out["spec"], out["phase"] = o.spectrogram(x, phase=True)
+    else:
+        out["spec"] = o.spectrogram(x)
+    if c["scale_type"] not in (8, 9):
+        out["fre"], out["bin"] = o.fre_band(), o.bin_band()
+    if "cc" in c:
+        kind, ccn = c["cc"][0], c["cc"][1]
+        out["cc"] = o.cc(kind, np.abs(out["spec"]), ccn, c["cc"][2] if len(c["cc"]) > 2 else None)
+    if c.get("deconv"):
+        out["timbre"], out["pitch"] = o.deconv(out["spec"])
+    return out
+
+
+def make_spectrogram():
+    """spectrogram.npz: the spectrogram object (every supported scale, switches, streaming)"""
+    out = {}
+    for name, c in cases.SPEC_CASES.items():
+        for k, v in run_spec_case(c).items():
+            out[f"{name}/{k}"] = v
+    c = cases.SPEC_STREAM
+    kw = cases.spec_ctor(c)
+    o = ref.RefSpectrogram(kw.pop("num"), **kw)
+    x = cases.noise(c["seed"], sum(c["chunks"]))
+    off, rows, tl = 0, [], []
+    for n in c["chunks"]:
+        tl.append(o.time_length(n))
+        rows.append(o.spectrogram(x[off:off + n]))
+        off += n
+    out["stream/spec"], out["stream/tl"] = np.concatenate(rows), np.array(tl, np.int32)
+    np.savez_compressed(os.path.join(HERE, "spectrogram.npz"), **out)
+    print("spectrogram.npz", os.path.getsize(os.path.join(HERE, "spectrogram.npz")) // 1024, "KiB")
+
+
 def main():
     assert ref.available(), "build the reference oracle first: make -C oracle"
     bft_out = {}
@@ -143,3 +187,4 @@ if __name__ == "__main__":
     else:
         main()
         make_stft()
+        make_spectrogram()

@@ -1,0 +1,181 @@
+"""GPU parity of the spectrogram object (spectrogram_algorithm.h): every supported scale
+(linear + phase, linspace, mel, bark, erb, octave, STFT-chroma, log-chroma), the switches
+(norm exponent, chroma normalisation), the spectrum-input variant, the cepstra
+(mfcc / bfcc / gtcc / xxcc) and deconv, streaming continuation and the batched device call --
+against the golden vectors of the reference and the compiled reference on fresh inputs."""
+import os
+
+import numpy as np
+import pytest
+
+import audioflux_amd as af
+from oracle import ref, restate
+from tests import cases
+from tests.conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "spectrogram.npz"))
+
+
+def make_spec(c):
+    kw = cases.spec_ctor(c)
+    o = af.Spectrogram(num=kw.get("num", 0), samplate=kw["samplate"], low_fre=kw.get("low_fre"),
+                       high_fre=kw.get("high_fre"), bin_per_octave=kw.get("bin_per_octave", 12),
+                       radix2_exp=kw["radix2_exp"], window_type=af.WindowType(kw["window_type"]),
+                       slide_length=kw.get("slide_length"), data_type=af.SpectralDataType(kw["data_type"]),
+                       filter_bank_type=af.SpectralFilterBankScaleType(kw["scale_type"]),
+                       style_type=af.SpectralFilterBankStyleType(kw.get("style_type", 0)),
+                       normal_type=af.SpectralFilterBankNormalType(kw.get("normal_type", 0)),
+                       is_continue=bool(kw.get("is_continue", 0)))
+    if "norm" in c:
+        o.set_data_norm_value(c["norm"])
+    if "chroma_norm" in c:
+        o.set_chroma_data_normal_type(af.ChromaDataNormalType(c["chroma_norm"]))
+    return o
+
+
+def phase_ok(got, want, spec_power_like):
+    """phase is conditioned by 1/|S|: compare the bins that carry signal"""
+    ok = spec_power_like > 1e-6 * spec_power_like.max()
+    assert ok.mean() > 0.2
+    d = np.abs(got[ok] - want[ok])
+    assert d.max() < 2e-3, d.max()
+
+
+@pytest.mark.parametrize("name", list(cases.SPEC_CASES))
+def test_spectrogram_matches_golden(name, gold):
+    c = cases.SPEC_CASES[name]
+    o = make_spec(c)
+    assert o.num == int(gold[f"{name}/num"][0]) == o.get_band_num() == o.get_bin_band_length()
+    if f"{name}/fre" in gold.files:
+        assert np.array_equal(o.get_bin_band_arr(), gold[f"{name}/bin"])
+        if c["scale_type"] == cases.SCALE["linear"]:
+            assert np.array_equal(o.get_fre_band_arr(), gold[f"{name}/fre"])
+        else:
+            assert np.array_equal(o.get_fre_band_arr(), gold[f"{name}/fre"])
+    x = cases.make_input(c["x"], c["samplate"])
+    want = gold[f"{name}/spec"]
+    if c.get("phase"):
+        got, ph = o.spectrogram(x, is_phase_arr=True)
+        power_like = want if c["data_type"] == 0 and "norm" not in c else np.abs(want) ** 2
+        phase_ok(ph.T, gold[f"{name}/phase"], power_like)
+    else:
+        got = o.spectrogram(x)
+    assert_parity(got.T, want, TOL, name)
+    if "cc" in c:
+        kind, ccn = c["cc"][0], c["cc"][1]
+        if kind == "xxcc":
+            cc = o.xxcc(np.abs(want).T, ccn, af.CepstralRectifyType(c["cc"][2]))
+        else:
+            cc = getattr(o, kind)(np.abs(want).T, ccn)
+        assert_parity(cc.T, gold[f"{name}/cc"], TOL, name + " " + kind)
+    if c.get("deconv"):
+        tm, pt = o.deconv(want.T)
+        assert_parity(tm.T, gold[f"{name}/timbre"], TOL, name + " timbre")
+        assert_parity(pt.T, gold[f"{name}/pitch"], 5e-5, name + " pitch")   # X/|X| at near-empty bins
+    if c.get("from_stft"):
+        # spectrogramObj_spectrogram1: the same result from a caller-supplied STFT
+        n = 1 << c["radix2_exp"]
+        s = af.STFT(radix2_exp=c["radix2_exp"], window_type=af.WindowType(c["window_type"]),
+                    slide_length=c.get("slide_length", n // 4))
+        re, im = s.stft_full(x)
+        if c.get("phase"):
+            got1, ph1 = o.spectrogram_from_stft(re, im, is_phase_arr=True)
+            phase_ok(ph1.T, gold[f"{name}/phase"], power_like)
+        else:
+            got1 = o.spectrogram_from_stft(re, im)
+        assert_parity(got1.T, want, TOL, name + " from stft")
+
+
+def test_streaming_matches_golden(gold):
+    c = cases.SPEC_STREAM
+    o = make_spec(c)
+    x = cases.noise(c["seed"], sum(c["chunks"]))
+    off, rows, tl = 0, [], []
+    for n in c["chunks"]:
+        t = o.cal_time_length(n)
+        tl.append(t)
+        if t > 0 or n >= o.fft_length:
+            rows.append(o.spectrogram(x[off:off + n]).T)
+        else:   # the wrapper refuses chunks shorter than one frame; feed the C entry directly
+            import ctypes as C
+            fn = o._lib.spectrogramObj_spectrogram
+            fp = C.POINTER(C.c_float)
+            fn.restype, fn.argtypes = None, [C.c_void_p, fp, C.c_int, fp, fp]
+            chunk = np.ascontiguousarray(x[off:off + n])
+            fn(o._obj, chunk.ctypes.data_as(fp), n, None, None)
+        off += n
+    assert np.array_equal(np.array(tl), gold["stream/tl"])
+    assert_parity(np.concatenate(rows), gold["stream/spec"], TOL, "stream")
+
+
+def test_presets_and_named_classes():
+    x = cases.noise(220, 20000)
+    m = af.Mel(num=64, samplate=16000, radix2_exp=10)
+    g = af.MelSpectrogram(num=64, samplate=16000, low_fre=0.0, high_fre=8000.0, radix2_exp=10)
+    assert np.array_equal(m.spectrogram(x), g.spectrogram(x))
+    assert np.array_equal(m.get_fre_band_arr(), g.get_fre_band_arr())
+    lin = af.Linear(samplate=16000, radix2_exp=9)
+    assert lin.num == 257 and lin.spectrogram(x).shape == (257, (20000 - 512) // 128 + 1)
+    ch = af.Chroma(samplate=16000, radix2_exp=11)
+    c = ch.spectrogram(x)
+    assert c.shape[0] == 12 and np.allclose(c.max(axis=0), 1.0)   # default per-frame max normalisation
+    for cls in (af.Bark, af.Erb, af.BarkSpectrogram, af.ErbSpectrogram):
+        assert cls(num=40, samplate=16000, radix2_exp=10).spectrogram(x).shape == (40, (20000 - 1024) // 256 + 1)
+    with pytest.raises(RuntimeError, match="status -4"):
+        af.Spectrogram(num=84, samplate=32000, filter_bank_type=af.SpectralFilterBankScaleType.DEEP)
+    with pytest.raises(ValueError):
+        m.spectrogram(np.zeros(100, np.float32))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("scale,num,r,hop", [(2, 128, 11, 512), (2, 128, 12, 1024), (3, 64, 10, 256), (4, 40, 11, 300),
+                                             (8, 12, 12, 1024), (9, 12, 11, 512), (0, 0, 10, 256)])
+def test_matches_compiled_reference_fresh_inputs(scale, num, r, hop):
+    """fresh seeds straight against the reference library: the fused kernels (n_fft 1024 / 2048 / 4096
+    with the mel / bark banks), the generic path, both chroma scales, the linear slice"""
+    sr = 32000
+    x = cases.noise(230 + scale + r, sr * 2 + 91)
+    low = 32.703 if scale == 9 else 0.0
+    high = 8000.0 if scale == 9 else 16000.0
+    for dt, norm in ((0, None), (1, None), (0, 0.5), (1, 2.0)):
+        rr = ref.RefSpectrogram(num, samplate=sr, low_fre=low, high_fre=high, radix2_exp=r, window_type=1,
+                                slide_length=hop, data_type=dt, scale_type=scale, style_type=0, normal_type=0)
+        assert rr.status == 0
+        o = af.Spectrogram(num=num, samplate=sr, low_fre=low, high_fre=high, radix2_exp=r,
+                           window_type=af.WindowType.HANN, slide_length=hop, data_type=af.SpectralDataType(dt),
+                           filter_bank_type=af.SpectralFilterBankScaleType(scale))
+        if norm:
+            rr.set_norm(norm)
+            o.set_data_norm_value(norm)
+        assert o.num == rr.num
+        assert_parity(o.spectrogram(x).T, rr.spectrogram(x), TOL, f"scale{scale} r{r} dt{dt} norm{norm}")
+
+
+def test_device_batch_matches_host_calls():
+    import torch
+    xs = np.stack([cases.noise(240 + i, 30000) for i in range(6)])
+    for scale, num in ((af.SpectralFilterBankScaleType.MEL, 128), (af.SpectralFilterBankScaleType.CHROMA, 12),
+                       (af.SpectralFilterBankScaleType.OCTAVE_CHROMA, 12), (af.SpectralFilterBankScaleType.LINEAR, 0)):
+        o = af.Spectrogram(num=num, samplate=16000, low_fre=32.703 if scale == 9 else 0.0,
+                           high_fre=4000.0 if scale == 9 else 8000.0, radix2_exp=11, slide_length=512,
+                           filter_bank_type=scale)
+        host = np.stack([o.spectrogram(x).T for x in xs])
+        dev = o.spectrogram_device(torch.from_numpy(xs).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), host), scale
+
+
+def test_quadratic_and_linear_gain_property():
+    """size-independent: power spectrograms scale with gain^2, magnitude ones with gain; max-normalised
+    chroma does not change with the gain at all"""
+    x = cases.noise(250, 16000 * 10)
+    p = af.MelSpectrogram(num=128, samplate=16000, radix2_exp=11, slide_length=512)
+    assert_parity(p.spectrogram(2 * x), 4 * p.spectrogram(x), 1e-6, "power gain")
+    c = af.Chroma(samplate=16000, radix2_exp=11)
+    assert_parity(c.spectrogram(2 * x), c.spectrogram(x), 1e-6, "chroma gain")
