@@ -249,7 +249,7 @@ SPEC_CASES = {
                                   window_type=WIN["hann"], slide_length=64, data_type=0,
                                   scale_type=SCALE["linspace"], style_type=STYLE["hann"],
                                   normal_type=NORMAL["none"], norm=0.7, x=("noise", 207, 3000)),
-    "chroma12_power": dict(num=12, samplate=32000, radix2_exp=12, window_type=WIN["hann"], data_type=0,
+    "chroma12_power": dict(num=12, samplate=32000, low_fre=0.0, radix2_exp=12, window_type=WIN["hann"], data_type=0,
                            scale_type=SCALE_X["chroma"], x=("mix", 208, 30000), from_stft=True),
     "chroma24_mag_range_p2": dict(num=24, samplate=16000, low_fre=100.0, high_fre=5000.0, radix2_exp=11,
                                   window_type=WIN["hann"], slide_length=512, data_type=1,
@@ -263,7 +263,7 @@ SPEC_CASES = {
                                    bin_per_octave=36, window_type=WIN["hann"], slide_length=1024, data_type=1,
                                    scale_type=SCALE_X["logchroma"], norm=2.0, chroma_norm=4,
                                    x=("mix", 211, 40000)),
-    "chroma_none_norm": dict(num=12, samplate=16000, radix2_exp=10, window_type=WIN["hann"], data_type=0,
+    "chroma_none_norm": dict(num=12, samplate=16000, low_fre=0.0, radix2_exp=10, window_type=WIN["hann"], data_type=0,
                              scale_type=SCALE_X["chroma"], chroma_norm=0, x=("noise", 212, 9000)),
 }
 SPEC_STREAM = dict(num=64, samplate=16000, low_fre=0.0, high_fre=8000.0, radix2_exp=10, window_type=WIN["hann"],
