@@ -294,6 +294,9 @@ static float *to_transposed(const float *bank, int num, int r1, int r2, const fl
     return t;
 }
 
+static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, const float *customBank,
+                      const float *customFre, const int *customBin);
+
 int cwtObj_new(CWTObj *cwtObj, int num, int radix2Exp, int *samplate, float *lowFre, float *highFre,
                int *binPerOctave, WaveletContinueType *waveletType,
                SpectralFilterBankScaleType *scaleType, float *gamma, float *beta, int *isPadding) {
@@ -395,23 +398,83 @@ int cwtObj_new(CWTObj *cwtObj, int num, int radix2Exp, int *samplate, float *low
         return AFX_ERR_UNSUPPORTED;
     }
 
+    struct OpaqueCWT proto;
+    memset(&proto, 0, sizeof(proto));
+    proto.num = num;
+    proto.radix2Exp = radix2Exp;
+    proto.dataLength = D;
+    proto.padLength = pad;
+    proto.fftLength = fftLength;
+    proto.samplate = sr;
+    proto.binPerOctave = bpo;
+    proto.lowFre = low;
+    proto.highFre = high;
+    proto.gamma = g;
+    proto.beta = b;
+    proto.waveletType = wt;
+    proto.scaleType = sc;
+    return cwt_create(cwtObj, &proto, rL, NULL, NULL, NULL);
+}
+
+/* transform-length rule shared by cwtObj_new and pwtObj_new (cwt_algorithm.c:264-289,
+ * pwt_algorithm.c:205-219); returns the padding or a negative status */
+static int pad_rule(int radix2Exp, int isPad, const char *who, long long *fftLength, int *rL) {
+    const int D = 1 << radix2Exp;
+    int pad = 0;
+    if (isPad) {
+        if (D <= 1e5) {
+            pad = D / 2;
+        } else {
+            afxdev_set_error("%s: padding with 2^%d samples needs a non-power-of-two transform; "
+                             "use isPadding=0 or radix2Exp<=16", who, radix2Exp);
+            return AFX_ERR_UNSUPPORTED;
+        }
+    }
+    *fftLength = (long long)D + 2LL * pad;
+    *rL = 0;
+    while ((1LL << *rL) < *fftLength) (*rL)++;
+    if (*rL > 26) {
+        afxdev_set_error("%s: transform length 2^%d exceeds the supported 2^26", who, *rL);
+        return AFX_ERR_UNSUPPORTED;
+    }
+    return pad;
+}
+
+/* the pseudo-wavelet object (afx_pwt.c) is this object with a caller-built frequency-domain
+ * bank [num][L] and band arrays instead of the analytic wavelet bank */
+int afx_cwt_create_custom(CWTObj *cwtObj, int num, int radix2Exp, int samplate, int isPadding,
+                          const float *bank, const float *fre, const int *bin, const char *who) {
+    long long fftLength;
+    int rL;
+    const int pad = pad_rule(radix2Exp, isPadding, who, &fftLength, &rL);
+    if (pad < 0) return pad;
+    struct OpaqueCWT proto;
+    memset(&proto, 0, sizeof(proto));
+    proto.num = num;
+    proto.radix2Exp = radix2Exp;
+    proto.dataLength = 1 << radix2Exp;
+    proto.padLength = pad;
+    proto.fftLength = fftLength;
+    proto.samplate = samplate;
+    return cwt_create(cwtObj, &proto, rL, bank, fre, bin);
+}
+
+long long afx_cwt_fft_length(int radix2Exp, int isPadding) {
+    long long fftLength;
+    int rL;
+    return pad_rule(radix2Exp, isPadding, "transform length", &fftLength, &rL) < 0 ? -1 : fftLength;
+}
+
+static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, const float *customBank,
+                      const float *customFre, const int *customBin) {
+    const int num = proto->num, D = proto->dataLength, pad = proto->padLength;
+    const long long fftLength = proto->fftLength;
+    *cwtObj = NULL;
     int st = afxdev_ensure();
     if (st != AFX_OK) return st;
     CWTObj o = (CWTObj)calloc(1, sizeof(struct OpaqueCWT));
     if (!o) return AFX_ERR_NOMEM;
-    o->num = num;
-    o->radix2Exp = radix2Exp;
-    o->dataLength = D;
-    o->padLength = pad;
-    o->fftLength = fftLength;
-    o->samplate = sr;
-    o->binPerOctave = bpo;
-    o->lowFre = low;
-    o->highFre = high;
-    o->gamma = g;
-    o->beta = b;
-    o->waveletType = wt;
-    o->scaleType = sc;
+    *o = *proto;
     o->dims.r1 = rL / 2;
     o->dims.r2 = rL - rL / 2;
     o->dims.dataLength = D;
@@ -429,7 +492,13 @@ int cwtObj_new(CWTObj *cwtObj, int num, int radix2Exp, int *samplate, float *low
     float *tw = NULL, *bankT = NULL;
     if (!o->freBandArr || !o->binBandArr || !o->hBank) st = AFX_ERR_NOMEM;
     if (st == AFX_OK) {
-        build_bank(o, o->hBank);
+        if (customBank) {
+            memcpy(o->hBank, customBank, sizeof(float) * (size_t)num * fftLength);
+            memcpy(o->freBandArr, customFre, sizeof(float) * (size_t)num);
+            memcpy(o->binBandArr, customBin, sizeof(int) * (size_t)num);
+        } else {
+            build_bank(o, o->hBank);
+        }
         bankT = to_transposed(o->hBank, num, o->dims.r1, o->dims.r2, NULL);
         tw = afx_twiddle_table((int)fftLength);
         if (!bankT || !tw) st = AFX_ERR_NOMEM;

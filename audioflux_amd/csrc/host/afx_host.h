@@ -61,6 +61,14 @@ unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre);
  * (src/filterbank/chroma_filterBank.c:13-174, default octave centre 5 / width 2) */
 float *afx_chroma_stft_bank(int num, int fftLength, int samplate);
 
+/* ---- afx_cwt.c: shared with the pseudo wavelet object (afx_pwt.c) ------------------------ */
+struct OpaqueCWT;
+/* the CWT execution plan over a caller-built frequency-domain bank [num][L] (natural bin order)
+ * and band arrays; L = afx_cwt_fft_length(radix2Exp, isPadding) (-1: unsupported) */
+int afx_cwt_create_custom(struct OpaqueCWT **cwtObj, int num, int radix2Exp, int samplate, int isPadding,
+                          const float *bank, const float *fre, const int *bin, const char *who);
+long long afx_cwt_fft_length(int radix2Exp, int isPadding);
+
 /* ---- afx_bandplan.c ----------------------------------------------------- */
 struct AfxBandPlanTag; /* AfxBandPlan is declared in afx_device.h */
 

@@ -19,6 +19,7 @@
 #include "cqt_algorithm.h"
 #include "cwt_algorithm.h"
 #include "feature/xxcc_algorithm.h"
+#include "pwt_algorithm.h"
 #include "spectrogram_algorithm.h"
 #include "stft_algorithm.h"
 
@@ -96,6 +97,10 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj cepstrogramObj, int cep
                                           const float *dData, int batch, int dataLength,
                                           long long clipStride, float *dOut1, float *dOut2,
                                           float *dOut3, void *hipStream);
+
+/* ---- PWT: as cwtObj_cwtBatchDevice, bands in ascending order --------------------------------- */
+int pwtObj_pwtBatchDevice(PWTObj pwtObj, const float *dData, int chunks, long long chunkStride,
+                          float *dReal, float *dImag, void *hipStream);
 
 /* ---- spectrogram object ------------------------------------------------------------------
  * batch clips of dataLength samples -> dSpect [batch][T, num] (T = frames of ONE clip without the

@@ -484,3 +484,51 @@ class RefSpectrogram:
         if getattr(self, "obj", None):
             self.L.spectrogramObj_free(self.obj)
             self.obj = C.c_void_p(None)
+
+
+class RefPWT:
+    """src/pwt_algorithm.h:14-31"""
+
+    def __init__(self, num, radix2_exp, samplate=None, low_fre=None, high_fre=None, bin_per_octave=None,
+                 scale_type=None, style_type=None, normal_type=None, is_padding=None):
+        L = lib()
+        self.L = L
+        self.num = num
+        self.n = 1 << radix2_exp
+        self.obj = C.c_void_p(None)
+        L.pwtObj_new.restype = C.c_int
+        L.pwtObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, ip, fp, fp, ip, ip, ip, ip, ip]
+        self.status = L.pwtObj_new(C.byref(self.obj), num, radix2_exp, _pi(samplate), _pf(low_fre), _pf(high_fre),
+                                   _pi(bin_per_octave), _pi(scale_type), _pi(style_type), _pi(normal_type),
+                                   _pi(is_padding))
+        L.pwtObj_getFreBandArr.restype = fp
+        L.pwtObj_getFreBandArr.argtypes = [C.c_void_p]
+        L.pwtObj_getBinBandArr.restype = ip
+        L.pwtObj_getBinBandArr.argtypes = [C.c_void_p]
+        for f in (L.pwtObj_pwt, L.pwtObj_pwtDet):
+            f.restype = None
+            f.argtypes = [C.c_void_p, fp, fp, fp]
+        L.pwtObj_enableDet.argtypes = [C.c_void_p, C.c_int]
+        L.pwtObj_free.argtypes = [C.c_void_p]
+
+    def fre_band(self):
+        return np.ctypeslib.as_array(self.L.pwtObj_getFreBandArr(self.obj), (self.num,)).copy()
+
+    def bin_band(self):
+        return np.ctypeslib.as_array(self.L.pwtObj_getBinBandArr(self.obj), (self.num,)).copy()
+
+    def pwt(self, x, det=False):
+        x = np.ascontiguousarray(x, np.float32)
+        re = np.zeros((self.num, self.n), np.float32)
+        im = np.zeros((self.num, self.n), np.float32)
+        if det:
+            self.L.pwtObj_enableDet(self.obj, 1)
+            self.L.pwtObj_pwtDet(self.obj, _f(x), _f(re), _f(im))
+        else:
+            self.L.pwtObj_pwt(self.obj, _f(x), _f(re), _f(im))
+        return re, im
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.pwtObj_free(self.obj)
+            self.obj = C.c_void_p(None)

@@ -574,3 +574,24 @@ def cwt(x, fre_desc, samplate, wavelet="morlet", gamma=6.0, beta=2.0, pad=True):
     X = np.fft.fft(xp)
     W = np.fft.ifft(psi * X[None, :], axis=1)
     return W[:, p:p + n]
+
+
+# --------------------------------------------------------------------------
+# pseudo wavelet transform -- src/pwt_algorithm.c:398-515
+# --------------------------------------------------------------------------
+def pwt(x, bank, pad, det=False):
+    """x[D], bank[num, L] (L = D + 2 pad, natural bin order) -> complex [num, D]:
+    symmetric reflection by `pad` samples on both sides (:437-447, the edge sample is repeated),
+    FFT, one product per band (bank * j omega for the derivative, :310-396), inverse FFT, crop"""
+    x = np.asarray(x, np.float64)
+    d = len(x)
+    cur = np.concatenate([x[:pad][::-1], x, x[d - pad:][::-1]]) if pad else x
+    L = len(cur)
+    X = np.fft.fft(cur)
+    B = np.asarray(bank, np.float64)
+    if det:
+        w = 2 * np.pi * np.arange(L) / L
+        w[L // 2 + 1:] = -w[1:(L - 1) // 2 + 1][::-1] if L % 2 == 0 else -w[1:L // 2 + 1][::-1]
+        B = B * w[None, :] * 1j
+    Y = np.fft.ifft(B * X[None, :], axis=1)
+    return Y[:, pad:pad + d]

@@ -275,3 +275,28 @@ SPEC_CTOR = ("num", "samplate", "low_fre", "high_fre", "bin_per_octave", "radix2
 
 def spec_ctor(case):
     return {k: case[k] for k in SPEC_CTOR if k in case}
+
+
+# pseudo wavelet transform: ctor kwargs (reference argument names) + input seed; input length = 2**radix2_exp
+PWT_CASES = {
+    "octave84_pad": dict(num=84, radix2_exp=12, samplate=32000, low_fre=32.703, bin_per_octave=12,
+                         scale_type=SCALE["octave"], style_type=STYLE["slaney"], normal_type=NORMAL["none"],
+                         is_padding=1, x=("mix", 301)),
+    "mel40_area_nopad": dict(num=40, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                             scale_type=SCALE["mel"], style_type=STYLE["slaney"], normal_type=NORMAL["area"],
+                             is_padding=0, x=("mix", 302)),
+    "bark32_etsi_bw": dict(num=32, radix2_exp=10, samplate=16000, low_fre=50.0, high_fre=7000.0,
+                           scale_type=SCALE["bark"], style_type=STYLE["etsi"], normal_type=NORMAL["bandwidth"],
+                           is_padding=1, x=("noise", 303)),
+    "erb20_hann_style": dict(num=20, radix2_exp=13, samplate=16000, low_fre=100.0, high_fre=6000.0,
+                             scale_type=SCALE["erb"], style_type=STYLE["hann"], normal_type=NORMAL["none"],
+                             is_padding=0, x=("mix", 304)),
+    "linear50_points": dict(num=50, radix2_exp=9, samplate=16000, low_fre=500.0, scale_type=SCALE["linear"],
+                            style_type=STYLE["slaney"], normal_type=NORMAL["none"], is_padding=1, x=("noise", 305)),
+    "log24_gauss_big": dict(num=24, radix2_exp=16, samplate=44100, low_fre=800.0, high_fre=15000.0,
+                            scale_type=SCALE["log"], style_type=STYLE["gauss"], normal_type=NORMAL["area"],
+                            is_padding=1, x=("mix", 306)),
+    "linspace_rect_tiny": dict(num=3, radix2_exp=5, samplate=8000, low_fre=1000.0, high_fre=2500.0,
+                                 scale_type=SCALE["linspace"], style_type=STYLE["rect"], normal_type=NORMAL["none"],
+                                 is_padding=1, x=("noise", 307)),
+}

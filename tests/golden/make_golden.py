@@ -114,6 +114,25 @@ def make_spectrogram():
     print("spectrogram.npz", os.path.getsize(os.path.join(HERE, "spectrogram.npz")) // 1024, "KiB")
 
 
+def make_pwt():
+    """pwt.npz: pseudo wavelet transform (time axis strided like the CWT fixtures)"""
+    out = {}
+    for name, c in cases.PWT_CASES.items():
+        kw = {k: v for k, v in c.items() if k != "x"}
+        o = ref.RefPWT(kw.pop("num"), kw.pop("radix2_exp"), **kw)
+        assert o.status == 0, (name, o.status)
+        x = cases.make_input((c["x"][0], c["x"][1], 1 << c["radix2_exp"]), c["samplate"])
+        re, im = o.pwt(x)
+        st = cases.cwt_stride(c)
+        out[f"{name}/re"], out[f"{name}/im"] = re[:, ::st], im[:, ::st]
+        out[f"{name}/fre"], out[f"{name}/bin"] = o.fre_band(), o.bin_band()
+        if name in ("octave84_pad", "mel40_area_nopad"):
+            dre, dim = o.pwt(x, det=True)
+            out[f"{name}/det_re"], out[f"{name}/det_im"] = dre[:, ::st], dim[:, ::st]
+    np.savez_compressed(os.path.join(HERE, "pwt.npz"), **out)
+    print("pwt.npz", os.path.getsize(os.path.join(HERE, "pwt.npz")) // 1024, "KiB")
+
+
 def main():
     assert ref.available(), "build the reference oracle first: make -C oracle"
     bft_out = {}
@@ -188,3 +207,4 @@ if __name__ == "__main__":
         main()
         make_stft()
         make_spectrogram()
+        make_pwt()
