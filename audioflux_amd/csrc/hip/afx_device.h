@@ -196,6 +196,20 @@ int afxk_cwt_small(const AfxCwtPlanDims *d, const float *tw, const float *x, lon
                    int chunks, const float *bankNatural, int num, int isDet, float *X, float *outRe,
                    float *outIm, void *stream);
 
+/* synchrosqueezing pass (afx_wsst.hip): W, W' [batch][num][length] -> out += W at the row the
+ * instantaneous frequency maps to.  mode 0: log axis (logMin/logMax = log2f(fmin), log2f(fmax)),
+ * 1: linear axis (fmin, fmax), 2: nearest entry of freNorm[num] (band centres / samplate) */
+typedef struct {
+    const float *wRe, *wIm, *dRe, *dIm;
+    float *outRe, *outIm; /* read-modify-write */
+    int num, batch;
+    long long length;
+    int mode;
+    float fmin, fmax, logMin, logMax, thresh;
+    const float *freNorm;
+} AfxWsstArgs;
+int afxk_wsst_squeeze(const AfxWsstArgs *a, void *stream);
+
 /* ---- constant-Q transform (afx_cqt.hip) ----------------------------------- */
 typedef struct {
     const float *x;        /* device: this octave's signal                            */

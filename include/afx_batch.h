@@ -22,6 +22,7 @@
 #include "pwt_algorithm.h"
 #include "spectrogram_algorithm.h"
 #include "stft_algorithm.h"
+#include "wsst_algorithm.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -101,6 +102,12 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj cepstrogramObj, int cep
 /* ---- PWT: as cwtObj_cwtBatchDevice, bands in ascending order --------------------------------- */
 int pwtObj_pwtBatchDevice(PWTObj pwtObj, const float *dData, int chunks, long long chunkStride,
                           float *dReal, float *dImag, void *hipStream);
+
+/* ---- WSST: chunks of 2^radix2Exp samples -> squeezed coefficients ADDED to dReal1/dImag1
+ * [chunks][num][2^radix2Exp] (zero them for a plain transform); dReal2/dImag2 (both or neither
+ * NULL) receive the CWT itself.  Same as calling wsstObj_wsst (wsst_algorithm.h) per chunk. */
+int wsstObj_wsstBatchDevice(WSSTObj wsstObj, const float *dData, int chunks, long long chunkStride,
+                            float *dReal1, float *dImag1, float *dReal2, float *dImag2, void *hipStream);
 
 /* ---- spectrogram object ------------------------------------------------------------------
  * batch clips of dataLength samples -> dSpect [batch][T, num] (T = frames of ONE clip without the

@@ -532,3 +532,40 @@ class RefPWT:
         if getattr(self, "obj", None):
             self.L.pwtObj_free(self.obj)
             self.obj = C.c_void_p(None)
+
+
+class RefWSST:
+    """src/wsst_algorithm.h:28-49"""
+
+    def __init__(self, num, radix2_exp, samplate=None, low_fre=None, high_fre=None, bin_per_octave=None,
+                 wavelet_type=None, scale_type=None, gamma=None, beta=None, thresh=None, is_padding=None):
+        L = lib()
+        self.L = L
+        self.num = num
+        self.n = 1 << radix2_exp
+        self.obj = C.c_void_p(None)
+        L.wsstObj_new.restype = C.c_int
+        L.wsstObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, ip, fp, fp, ip, ip, ip, fp, fp, fp, ip]
+        self.status = L.wsstObj_new(C.byref(self.obj), num, radix2_exp, _pi(samplate), _pf(low_fre), _pf(high_fre),
+                                    _pi(bin_per_octave), _pi(wavelet_type), _pi(scale_type), _pf(gamma), _pf(beta),
+                                    _pf(thresh), _pi(is_padding))
+        L.wsstObj_getFreBandArr.restype = fp
+        L.wsstObj_getFreBandArr.argtypes = [C.c_void_p]
+        L.wsstObj_wsst.restype = None
+        L.wsstObj_wsst.argtypes = [C.c_void_p, fp, fp, fp, fp, fp]
+        L.wsstObj_free.argtypes = [C.c_void_p]
+
+    def fre_band(self):
+        return np.ctypeslib.as_array(self.L.wsstObj_getFreBandArr(self.obj), (self.num,)).copy()
+
+    def wsst(self, x):
+        """-> (squeezed [num, n] complex, cwt [num, n] complex) in the C row order"""
+        x = np.ascontiguousarray(x, np.float32)
+        a = [np.zeros((self.num, self.n), np.float32) for _ in range(4)]
+        self.L.wsstObj_wsst(self.obj, _f(x), _f(a[0]), _f(a[1]), _f(a[2]), _f(a[3]))
+        return a[0] + 1j * a[1], a[2] + 1j * a[3]
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.wsstObj_free(self.obj)
+            self.obj = C.c_void_p(None)

@@ -595,3 +595,68 @@ def pwt(x, bank, pad, det=False):
         B = B * w[None, :] * 1j
     Y = np.fft.ifft(B * X[None, :], axis=1)
     return Y[:, pad:pad + d]
+
+
+# --------------------------------------------------------------------------
+# wavelet synchrosqueezed transform -- src/wsst_algorithm.c:242-347
+# --------------------------------------------------------------------------
+def wsst_coordinates(W, Wd, fre, samplate, scale="octave"):
+    """continuous (un-rounded) target-row coordinate of every coefficient: instantaneous frequency
+    Im(W'/W)/2pi mapped on the band axis (:259-260, :276-301).  NaN where undefined."""
+    W = np.asarray(W, np.complex128)
+    Wd = np.asarray(Wd, np.complex128)
+    num = W.shape[0]
+    with np.errstate(all="ignore"):
+        ph = np.abs((Wd / W).imag / (2 * np.pi))
+        fmin, fmax = float(fre[0]) / samplate, float(fre[num - 1]) / samplate
+        if scale in ("octave", "log"):
+            v = (np.log2(ph) - np.log2(fmin)) * num / (np.log2(fmax) - np.log2(fmin))
+        elif scale in ("linear", "linspace"):
+            v = np.abs((Wd / W).imag / (2 * np.pi) - fmin) * num / (fmax - fmin)  # signed frequency (:289)
+        else:  # nearest band centre: fractional position between neighbours, rounding boundary at the midpoint
+            c = np.asarray(fre, np.float64) / samplate
+            k = np.clip(np.searchsorted(c, ph, side="right") - 1, 0, num - 2)
+            v = k + (ph - c[k]) / (c[k + 1] - c[k])
+            v = np.where((ph >= c[0]) & (ph < c[-1]), v, np.nan)
+    return v
+
+
+def wsst_squeeze(W, v, thresh, init=None):
+    """out[round(v)[i, j], j] += W[i, j] for |W| > thresh, rows in ascending order (:318-335)"""
+    W = np.asarray(W, np.complex128)
+    num, n = W.shape
+    out = np.zeros((num, n), np.complex128) if init is None else np.asarray(init, np.complex128).copy()
+    with np.errstate(all="ignore"):
+        idx = np.floor(v + 0.5)  # roundf, half away from zero (v >= 0 where it matters)
+    ok = np.isfinite(idx) & (idx >= 0) & (idx < num) & (np.abs(W) ** 2 > thresh * thresh)
+    cols = np.broadcast_to(np.arange(n)[None, :], W.shape)
+    np.add.at(out, (idx[ok].astype(np.int64), cols[ok]), W[ok])
+    return out
+
+
+def wsst_allowance(W, v, thresh, c_rel=1e-4):
+    """per output cell: the total magnitude of coefficients whose target row is not determined at
+    float32 accuracy -- their coordinate lies within dv of a rounding boundary, dv = the coordinate
+    perturbation caused by a relative error c_rel * max|W| / |W| of the frequency estimate (weak
+    coefficients have noisy estimates), or |W| lies within c_rel of the threshold.  A float32
+    implementation may place each of them in either neighbouring row; nothing else may differ."""
+    W = np.asarray(W, np.complex128)
+    num, n = W.shape
+    mag = np.abs(W)
+    wmax = mag.max()
+    with np.errstate(all="ignore"):
+        rel = c_rel * wmax / np.maximum(mag, 1e-300)
+        # d(coordinate) for a relative frequency error `rel`: slope * rel, slope estimated from the
+        # coordinate itself (log axis: num / log2-range / ln 2; linear axes: |v| bounded by num)
+        dv = np.minimum(0.5, rel * (num / np.log(2) + np.abs(np.nan_to_num(v))))
+        lo = np.floor(v)
+        near = np.abs(v - (lo + 0.5)) < dv
+    edge_thresh = np.abs(mag - thresh) <= c_rel * max(thresh, 1e-30)
+    amb = (near | edge_thresh) & np.isfinite(v) & (mag > thresh * (1 - c_rel))
+    allow = np.zeros((num, n))
+    cols = np.broadcast_to(np.arange(n)[None, :], W.shape)
+    for off in (0, 1, -1):
+        r = np.where(amb, lo + off, -1)
+        ok = amb & (r >= 0) & (r < num)
+        np.add.at(allow, (r[ok].astype(np.int64), cols[ok]), mag[ok])
+    return allow, amb

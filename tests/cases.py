@@ -300,3 +300,19 @@ PWT_CASES = {
                                  scale_type=SCALE["linspace"], style_type=STYLE["rect"], normal_type=NORMAL["none"],
                                  is_padding=1, x=("noise", 307)),
 }
+
+
+# wavelet synchrosqueezed transform: ctor kwargs (reference argument names) + input seed
+WSST_CASES = {
+    "morlet_octave48": dict(num=48, radix2_exp=11, samplate=16000, low_fre=32.703, wavelet_type=WAVELET["morlet"],
+                            scale_type=SCALE["octave"], is_padding=1, x=("mix", 401)),
+    "morse_mel40": dict(num=40, radix2_exp=12, samplate=16000, low_fre=50.0, high_fre=7000.0,
+                        wavelet_type=WAVELET["morse"], scale_type=SCALE["mel"], is_padding=1, x=("mix", 402)),
+    "bump_linspace_thresh": dict(num=32, radix2_exp=10, samplate=16000, low_fre=200.0, high_fre=6000.0,
+                                 wavelet_type=WAVELET["bump"], scale_type=SCALE["linspace"], thresh=0.01,
+                                 is_padding=0, x=("mix", 403)),
+    "morlet_log_big": dict(num=60, radix2_exp=14, samplate=32000, low_fre=100.0, high_fre=9000.0,
+                           wavelet_type=WAVELET["morlet"], scale_type=SCALE["log"], is_padding=1, x=("mix", 404)),
+}
+WSST_SCALE_NAME = {SCALE["octave"]: "octave", SCALE["log"]: "log", SCALE["linear"]: "linear",
+                   SCALE["linspace"]: "linspace", SCALE["mel"]: "mel", SCALE["bark"]: "bark", SCALE["erb"]: "erb"}

@@ -133,6 +133,22 @@ def make_pwt():
     print("pwt.npz", os.path.getsize(os.path.join(HERE, "pwt.npz")) // 1024, "KiB")
 
 
+def make_wsst():
+    """wsst.npz: squeezed coefficients of the reference; the squeezing moves coefficients along the
+    band axis only, so fixtures keep whole columns at the time stride of the CWT fixtures"""
+    out = {}
+    for name, c in cases.WSST_CASES.items():
+        kw = {k: v for k, v in c.items() if k != "x"}
+        o = ref.RefWSST(kw.pop("num"), kw.pop("radix2_exp"), **kw)
+        assert o.status == 0, (name, o.status)
+        x = cases.make_input((c["x"][0], c["x"][1], 1 << c["radix2_exp"]), c["samplate"])
+        s, w = o.wsst(x)
+        out[f"{name}/s"] = s[:, ::cases.cwt_stride(c)].astype(np.complex64)
+        out[f"{name}/fre"] = o.fre_band()
+    np.savez_compressed(os.path.join(HERE, "wsst.npz"), **out)
+    print("wsst.npz", os.path.getsize(os.path.join(HERE, "wsst.npz")) // 1024, "KiB")
+
+
 def main():
     assert ref.available(), "build the reference oracle first: make -C oracle"
     bft_out = {}
@@ -208,3 +224,4 @@ if __name__ == "__main__":
         make_stft()
         make_spectrogram()
         make_pwt()
+        make_wsst()
