@@ -139,10 +139,10 @@ typedef struct {
 } AfxIstftArgs;
 int afxk_istft(const AfxIstftArgs *a, void *stream);
 
-/* afx_spectral.hip: per-bin value (AFX_SPEC_POWER / MAG / *_NORM / PHASE) of the bins
- * [binLo, binLo+binCount) of a complex spectrum re/im [rows, rowPitch] -> out [rows, binCount] */
+/* afx_spectral.hip: per-bin value (AFX_SPEC_*) of the bins [binLo, binLo+binCount) of a complex
+ * spectrum re/im [rows, rowPitch] -> out [rows, binCount] (+ out2 for COMPLEX / SQUARE) */
 int afxk_spec_map(const float *re, const float *im, long long rows, int rowPitch, int binLo,
-                  int binCount, int mode, float normValue, float *out, void *stream);
+                  int binCount, int mode, float normValue, float *out, float *out2, void *stream);
 /* in place on data [rows, n]: optional powf(., powArg), then per-row normalisation
  * (normType = ChromaDataNormalType: 0 none, 1 max, 2 min, 3 P2, 4 P1) */
 int afxk_row_post(float *data, long long rows, int n, int doPow, float powArg, int normType,
@@ -209,6 +209,20 @@ typedef struct {
     const float *freNorm;
 } AfxWsstArgs;
 int afxk_wsst_squeeze(const AfxWsstArgs *a, void *stream);
+
+/* time-frequency reassignment (afx_reassign.hip): planes are [batch][timeLength][F] */
+typedef struct {
+    const float *hRe, *hIm;   /* STFT with the analysis window                         */
+    const float *dhRe, *dhIm; /* ... with its derivative (doFre)                       */
+    const float *thRe, *thIm; /* ... with the time-weighted window (doTime)            */
+    const float *freArr;      /* device [F]: bin centre frequencies                    */
+    int *timeIdx, *freIdx;    /* device scratch, same shape as the planes              */
+    float *outRe, *outIm;     /* accumulated into (float atomics); outIm unused for amplitudes */
+    int batch, timeLength, F, hop, samplate;
+    int doFre, doTime, resultType;
+    float thresh, freScale /* -0.5 sr / pi */, timeScale /* 1 / sr */;
+} AfxReassignArgs;
+int afxk_reassign(const AfxReassignArgs *a, int order, int *idxScratch, void *stream);
 
 /* ---- constant-Q transform (afx_cqt.hip) ----------------------------------- */
 typedef struct {

@@ -17,7 +17,7 @@ namespace {
 
 __global__ void k_spec_map(const float *__restrict__ re, const float *__restrict__ im, long long rows,
                            int rowPitch, int binLo, int binCount, int mode, float normValue,
-                           float *__restrict__ out) {
+                           float *__restrict__ out, float *__restrict__ out2) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * binCount) return;
     const long long row = e / binCount;
@@ -25,6 +25,8 @@ __global__ void k_spec_map(const float *__restrict__ re, const float *__restrict
     const float a = re[row * rowPitch + binLo + j], b = im[row * rowPitch + binLo + j];
     float v;
     switch (mode) {
+        case AFX_SPEC_COMPLEX: v = a; out2[e] = b; break;
+        case AFX_SPEC_SQUARE: v = a * a - b * b; out2[e] = 2 * a * b; break;  // bft_algorithm.c:459-468
         case AFX_SPEC_POWER: v = a * a + b * b; break;
         case AFX_SPEC_MAG: v = sqrtf(a * a + b * b); break;
         case AFX_SPEC_MAG_NORM: v = powf(sqrtf(a * a + b * b), normValue); break;
@@ -62,7 +64,7 @@ __global__ void k_row_post(float *__restrict__ data, long long rows, int n, int 
 }  // namespace
 
 extern "C" int afxk_spec_map(const float *re, const float *im, long long rows, int rowPitch, int binLo,
-                             int binCount, int mode, float normValue, float *out, void *stream) {
+                             int binCount, int mode, float normValue, float *out, float *out2, void *stream) {
     const long long total = rows * binCount;
     if (total <= 0) return AFX_OK;
     const long long blocks = (total + 255) / 256;
@@ -70,8 +72,12 @@ extern "C" int afxk_spec_map(const float *re, const float *im, long long rows, i
         afxdev_set_error("spec_map: %lld elements in one launch", total);
         return AFX_ERR_UNSUPPORTED;
     }
+    if ((mode == AFX_SPEC_COMPLEX || mode == AFX_SPEC_SQUARE) && !out2) {
+        afxdev_set_error("spec_map: complex modes need a second output plane");
+        return AFX_ERR_ARG;
+    }
     hipLaunchKernelGGL(k_spec_map, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, re, im, rows,
-                       rowPitch, binLo, binCount, mode, normValue, out);
+                       rowPitch, binLo, binCount, mode, normValue, out, out2);
     AFX_LAUNCH_CHECK("k_spec_map");
     return AFX_OK;
 }

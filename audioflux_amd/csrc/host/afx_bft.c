@@ -110,12 +110,6 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
         printf("num is error!\n");
         return -1;
     }
-    if (isReassign && *isReassign) {
-        /* time-frequency reassignment is a scatter pass outside this round's
-         * scope; refuse instead of computing something else */
-        afxdev_set_error("bftObj_new: isReassign=1 is not implemented by the MI355X backend");
-        return AFX_ERR_UNSUPPORTED;
-    }
     if (r > 14) {
         afxdev_set_error("bftObj_new: fftLength 2^%d exceeds the on-chip FFT limit 2^14", r);
         return AFX_ERR_UNSUPPORTED;
@@ -138,6 +132,7 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
     p.style = style;
     p.normal = normal;
     p.isTemporal = isTemporal ? *isTemporal : 0;
+    p.isReassign = (isReassign && *isReassign) ? 1 : 0;
     return afx_bft_create(&p, bftObj);
 }
 
@@ -259,7 +254,14 @@ int afx_bft_create(const AfxBftPlan *p, BFTObj *bftObj) {
         }
         free(meta);
     }
-    if (st == AFX_OK) st = afx_bft_plan_fast(o, hWindow, hBank);
+    if (st == AFX_OK && p->isReassign) {
+        /* __bftObj_init (bft_algorithm.c:332-340): reassignment of both axes, default threshold */
+        ReassignType reType = Reassign_All;
+        int srv = sr, hopv = p->slideLength;
+        WindowType wv = win;
+        st = reassignObj_new(&o->reassign, r, &srv, &wv, &hopv, &reType, NULL, NULL, NULL);
+    }
+    if (st == AFX_OK && !p->isReassign) st = afx_bft_plan_fast(o, hWindow, hBank);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     free(hWindow);
     free(hTw);
@@ -312,6 +314,69 @@ static void pick_modes(const struct OpaqueBFT *o, int *specMode, int *post) {
     }
 }
 
+/* isReassign = 1 (bft_algorithm.c:451-529): the reassigned complex spectrum [frames, F] takes the
+ * place of the STFT; per-bin value, bank and norm exponent follow the same rules as below.
+ * The reference accumulates into a scratch it zeroes only when (re)allocated, so a second call on
+ * the same object adds onto the previous call's post-processed content; here every call starts
+ * from zero. */
+static int run_reassigned(BFTObj o, const float *dData, int batch, int dataLength, long long clipStride,
+                          float *dRe, float *dIm, float *dTemporal, void *stream) {
+    const int T = bftObj_calTimeLength(o, dataLength), F = o->F;
+    const long long frames = (long long)batch * T;
+    int specMode, post;
+    pick_modes(o, &specMode, &post);
+    const int complexOut = !o->resultType;
+    const int linear = (o->scale == SpectralFilterBankScale_Linear);
+    const size_t plane = (size_t)frames * F;
+    int st = afxdev_reserve((void **)&o->dSpec, &o->capSpec, sizeof(float) * plane * 4);
+    if (st != AFX_OK) return st;
+    float *rRe = o->dSpec, *rIm = o->dSpec + plane, *mRe = o->dSpec + 2 * plane, *mIm = o->dSpec + 3 * plane;
+    st = afxdev_memset(rRe, 0, sizeof(float) * plane * 2, stream);
+    if (st == AFX_OK)
+        st = reassignObj_reassignBatchDevice(o->reassign, dData, batch, dataLength, clipStride, rRe, rIm, NULL,
+                                             NULL, stream);
+    if (st != AFX_OK) return st;
+    if (dTemporal) {
+        /* energy / rms / zcr come from the windowed frames, not from the spectrum: one STFT pass
+         * whose bins are discarded (binCount 1) */
+        AfxStftArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = dData;
+        a.clipStride = clipStride;
+        a.batch = batch;
+        a.dataLength = dataLength;
+        a.timeLength = T;
+        a.radix2Exp = o->radix2Exp;
+        a.hop = o->slideLength;
+        a.window = o->dWindow;
+        a.twiddle = o->dTwiddle;
+        a.mode = AFX_SPEC_POWER;
+        a.binCount = 1;
+        a.outRe = mRe;
+        a.energy = dTemporal;
+        a.rms = dTemporal + frames;
+        a.zcr = dTemporal + 2 * frames;
+        st = afxk_stft(&a, stream);
+        if (st != AFX_OK) return st;
+    }
+    if (linear) {
+        if (o->highIndex - o->lowIndex + 1 != o->num) {
+            afxdev_set_error("bft linear: %d bins for num=%d", o->highIndex - o->lowIndex + 1, o->num);
+            return AFX_ERR_ARG;
+        }
+        return afxk_spec_map(rRe, rIm, frames, F, o->lowIndex, o->num, specMode, o->normValue, dRe,
+                             complexOut ? dIm : NULL, stream);
+    }
+    st = afxk_spec_map(rRe, rIm, frames, F, 0, F, specMode, o->normValue, mRe, complexOut ? mIm : NULL, stream);
+    if (st == AFX_OK)
+        st = afxk_gemm_nt(mRe, F, o->dBank, F, dRe, o->num, frames, o->num, F, AFX_MAP_NONE, post, o->normValue,
+                          stream);
+    if (st == AFX_OK && complexOut)
+        st = afxk_gemm_nt(mIm, F, o->dBank, F, dIm, o->num, frames, o->num, F, AFX_MAP_NONE, AFX_MAP_NONE, 1.f,
+                          stream);
+    return st;
+}
+
 /* device-resident core: dData -> dRe (, dIm); dTemporal = 3 planes of frames or NULL */
 int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
                        long long clipStride, float *dRe, float *dIm, float *dTemporal,
@@ -343,6 +408,8 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
     a.twiddle = o->dTwiddle;
     a.mode = specMode;
     a.normValue = o->normValue;
+
+    if (o->reassign) return run_reassigned(o, dData, batch, dataLength, clipStride, dRe, dIm, dTemporal, stream);
 
     if (linear) {
         /* the "bank" is a bin slice: store straight into the result */
@@ -511,6 +578,7 @@ void bftObj_free(BFTObj o) {
     if (!o) return;
     if (o->stream) afxdev_stream_sync(o->stream);
     afx_bft_free_fast(o);
+    reassignObj_free(o->reassign);
     afxdev_free(o->dWindow);
     afxdev_free(o->dTwiddle);
     afxdev_free(o->dBank);

@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 #include "flux_base.h"
+#include "reassign_algorithm.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -38,6 +39,7 @@ struct OpaqueBFT {
     int *dBandMeta;   /* [3][num]: start, len, offset */
     float *dBandW;
     struct AfxMelFusedPlan *fast; /* NULL when the fused kernel does not apply */
+    struct OpaqueReassign *reassign; /* isReassign = 1: the reassigned spectrum replaces the STFT */
     /* grow-only device scratch of the legacy host-pointer calls */
     float *dX, *dSpec, *dOut, *dTemporal;
     size_t capX, capSpec, capOut, capTemporal;
@@ -83,6 +85,22 @@ struct OpaqueSTFT {
     int status;
 };
 
+struct OpaqueReassign {
+    int radix2Exp, fftLength, F, samplate, slideLength, isPadding;
+    WindowType windowType;
+    ReassignType resType;
+    float thresh;
+    int resultType, order;
+    void *stream;
+    float *dWin;      /* device [3][N]: h, dh, t.h */
+    float *dTwiddle, *dFre;
+    float *dPlanes, *dX, *dOut; /* grow-only scratch */
+    int *dIdx;
+    size_t capPlanes, capIdx, capX, capOut;
+    void *lastStream;
+    int lastStreamSet, status;
+};
+
 /* framing state machine of a legacy stftObj_stft call, host fields of the object only
  * (afx_stft.c; also used by the spectrogram object for its isContinue mode) */
 int afx_stft_deal_data(struct OpaqueSTFT *o, const float *dataArr, int dataLength, int *valid,
@@ -100,7 +118,7 @@ typedef struct {
     SpectralFilterBankScaleType scale;
     SpectralFilterBankStyleType style;
     SpectralFilterBankNormalType normal;
-    int isTemporal;
+    int isTemporal, isReassign;
     const float *customBank; /* optional host [num, fftLength/2+1] matrix used instead of the
                               * auditory bank of `scale` (band arrays are then left zero) */
 } AfxBftPlan;

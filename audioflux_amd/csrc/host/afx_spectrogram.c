@@ -556,15 +556,15 @@ void spectrogramObj_spectrogram1(SpectrogramObj o, float *mRealArr, float *mImag
     if (st == AFX_OK) st = afxdev_h2d(dRe, mRealArr, specB, stream);
     if (st == AFX_OK) st = afxdev_h2d(dIm, mImageArr, specB, stream);
     if (st == AFX_OK && linear) {
-        st = afxk_spec_map(dRe, dIm, T, N, o->lowIndex, o->num, mode, o->core->normValue, o->dOut, stream);
+        st = afxk_spec_map(dRe, dIm, T, N, o->lowIndex, o->num, mode, o->core->normValue, o->dOut, NULL, stream);
         if (st == AFX_OK && mPhaseArr) {
             float *dPh = o->dOut + (size_t)T * o->num;
-            st = afxk_spec_map(dRe, dIm, T, N, o->lowIndex, o->num, AFX_SPEC_PHASE, 1.f, dPh, stream);
+            st = afxk_spec_map(dRe, dIm, T, N, o->lowIndex, o->num, AFX_SPEC_PHASE, 1.f, dPh, NULL, stream);
             if (st == AFX_OK) st = afxdev_d2h(mPhaseArr, dPh, outB, stream);
         }
     } else if (st == AFX_OK) {
         float *dBase = (o->scale == SpectralFilterBankScale_LogChroma) ? o->dTmp : o->dOut;
-        st = afxk_spec_map(dRe, dIm, T, N, 0, F, mode, o->core->normValue, dS, stream);
+        st = afxk_spec_map(dRe, dIm, T, N, 0, F, mode, o->core->normValue, dS, NULL, stream);
         if (st == AFX_OK)
             st = afxk_gemm_nt(dS, F, o->core->dBank, F, dBase, o->coreRows, T, o->coreRows, F, AFX_MAP_NONE,
                               post, o->core->normValue, stream);

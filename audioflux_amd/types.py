@@ -100,3 +100,10 @@ class PaddingModeType(IntEnum):
     CONSTANT = 0
     REFLECT = 1
     WRAP = 2
+
+
+class ReassignType(IntEnum):
+    ALL = 0
+    FRE = 1
+    TIME = 2
+    NONE = 3

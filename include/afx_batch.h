@@ -20,6 +20,7 @@
 #include "cwt_algorithm.h"
 #include "feature/xxcc_algorithm.h"
 #include "pwt_algorithm.h"
+#include "reassign_algorithm.h"
 #include "spectrogram_algorithm.h"
 #include "stft_algorithm.h"
 #include "wsst_algorithm.h"
@@ -108,6 +109,13 @@ int pwtObj_pwtBatchDevice(PWTObj pwtObj, const float *dData, int chunks, long lo
  * NULL) receive the CWT itself.  Same as calling wsstObj_wsst (wsst_algorithm.h) per chunk. */
 int wsstObj_wsstBatchDevice(WSSTObj wsstObj, const float *dData, int chunks, long long chunkStride,
                             float *dReal1, float *dImag1, float *dReal2, float *dImag2, void *hipStream);
+
+/* ---- reassignment: batch clips -> reassigned coefficients ADDED to dReal1/dImag1 [batch][T, F]
+ * (zero them first; dImag1 may be NULL in amplitude result mode); dReal2/dImag2 (both or neither
+ * NULL) receive the plain STFT.  Same as calling reassignObj_reassign per clip. */
+int reassignObj_reassignBatchDevice(ReassignObj reassignObj, const float *dData, int batch, int dataLength,
+                                    long long clipStride, float *dReal1, float *dImag1, float *dReal2,
+                                    float *dImag2, void *hipStream);
 
 /* ---- spectrogram object ------------------------------------------------------------------
  * batch clips of dataLength samples -> dSpect [batch][T, num] (T = frames of ONE clip without the

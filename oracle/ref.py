@@ -43,7 +43,7 @@ def _f(a):
 class RefBFT:
     def __init__(self, num, radix2_exp, samplate=None, low_fre=None, high_fre=None,
                  bin_per_octave=None, window_type=None, slide_length=None, scale_type=None,
-                 style_type=None, normal_type=None, data_type=None, is_temporal=None):
+                 style_type=None, normal_type=None, data_type=None, is_temporal=None, is_reassign=None):
         L = lib()
         self.L = L
         self.num = num
@@ -54,7 +54,7 @@ class RefBFT:
         self.status = L.bftObj_new(C.byref(self.obj), num, radix2_exp, _pi(samplate), _pf(low_fre),
                                    _pf(high_fre), _pi(bin_per_octave), _pi(window_type),
                                    _pi(slide_length), _pi(scale_type), _pi(style_type),
-                                   _pi(normal_type), _pi(data_type), None, _pi(is_temporal))
+                                   _pi(normal_type), _pi(data_type), _pi(is_reassign), _pi(is_temporal))
         L.bftObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
         L.bftObj_bft.restype = None
         L.bftObj_bft.argtypes = [C.c_void_p, fp, C.c_int, fp, fp]
@@ -568,4 +568,49 @@ class RefWSST:
     def __del__(self):
         if getattr(self, "obj", None):
             self.L.wsstObj_free(self.obj)
+            self.obj = C.c_void_p(None)
+
+
+class RefReassign:
+    """src/reassign_algorithm.h:15-56"""
+
+    def __init__(self, radix2_exp, samplate=None, window_type=None, slide_length=None, re_type=None, thresh=None,
+                 is_padding=None):
+        L = lib()
+        self.L = L
+        self.n = 1 << radix2_exp
+        self.obj = C.c_void_p(None)
+        L.reassignObj_new.restype = C.c_int
+        L.reassignObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, ip, ip, ip, ip, fp, ip, ip]
+        self.status = L.reassignObj_new(C.byref(self.obj), radix2_exp, _pi(samplate), _pi(window_type),
+                                        _pi(slide_length), _pi(re_type), _pf(thresh), _pi(is_padding), None)
+        L.reassignObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
+        L.reassignObj_setResultType.restype = None
+        L.reassignObj_setResultType.argtypes = [C.c_void_p, C.c_int]
+        L.reassignObj_setOrder.restype = None
+        L.reassignObj_setOrder.argtypes = [C.c_void_p, C.c_int]
+        L.reassignObj_reassign.restype = None
+        L.reassignObj_reassign.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp, fp]
+        L.reassignObj_free.argtypes = [C.c_void_p]
+
+    def set_result_type(self, t):
+        self.L.reassignObj_setResultType(self.obj, int(t))
+
+    def set_order(self, k):
+        self.L.reassignObj_setOrder(self.obj, int(k))
+
+    def time_length(self, n):
+        return self.L.reassignObj_calTimeLength(self.obj, n)
+
+    def reassign(self, x):
+        """-> four float32 [T, F] planes: reassigned re, im, stft re, im"""
+        x = np.ascontiguousarray(x, np.float32)
+        t, f = self.time_length(x.shape[0]), self.n // 2 + 1
+        a = [np.zeros((t, f), np.float32) for _ in range(4)]
+        self.L.reassignObj_reassign(self.obj, _f(x), x.shape[0], _f(a[0]), _f(a[1]), _f(a[2]), _f(a[3]))
+        return a
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.reassignObj_free(self.obj)
             self.obj = C.c_void_p(None)

@@ -660,3 +660,86 @@ def wsst_allowance(W, v, thresh, c_rel=1e-4):
         ok = amb & (r >= 0) & (r < num)
         np.add.at(allow, (r[ok].astype(np.int64), cols[ok]), mag[ok])
     return allow, amb
+
+
+# --------------------------------------------------------------------------
+# time-frequency reassignment -- src/reassign_algorithm.c:256-414, :611-832
+# --------------------------------------------------------------------------
+def reassign_windows(window, n):
+    """h, dh (central difference of the periodically extended window, :429-437), t.h (:439-441)"""
+    w = np.asarray(window, np.float64)
+    return w, (np.roll(w, -1) - np.roll(w, 1)) / 2, (np.arange(n) - n // 2) * w
+
+
+def reassign_coordinates(Sh, Sdh, Sth, samplate, hop, thresh, re_type="all"):
+    """continuous (un-rounded) target (frame, bin) coordinates of every STFT coefficient [T, F]"""
+    Sh = np.asarray(Sh, np.complex128)
+    t_len, f_len = Sh.shape
+    fre = np.linspace(0, samplate / 2, f_len)
+    tim = np.arange(t_len) * hop / samplate
+    strong = np.abs(Sh) ** 2 >= thresh * thresh
+    with np.errstate(all="ignore"):
+        re_f = np.broadcast_to(fre[None, :], Sh.shape).copy()
+        re_t = np.broadcast_to(tim[:, None], Sh.shape).copy()
+        if re_type in ("all", "fre"):
+            v = fre[None, :] - (np.asarray(Sdh, np.complex128) / Sh).imag * 0.5 * samplate / np.pi
+            re_f = np.clip(np.where(strong, v, re_f), 0, fre[-1])
+        if re_type in ("all", "time"):
+            v = tim[:, None] + (np.asarray(Sth, np.complex128) / Sh).real / samplate
+            re_t = np.clip(np.where(strong, v, re_t), 0, tim[-1])
+        vt = re_t * (t_len - 1) / tim[-1] if t_len > 1 else np.zeros_like(re_t)
+        vf = re_f * (f_len - 1) / fre[-1]
+    return vt, vf
+
+
+def reassign_scatter(Sh, vt, vf, amplitude=False, order=1):
+    """out[round(vt), round(vf)] += (-1)^bin * S  (|S| in amplitude mode), :362-398; `order` iterates
+    the bin index map inside each frame (:340-358)"""
+    Sh = np.asarray(Sh, np.complex128)
+    t_len, f_len = Sh.shape
+    it, jf = np.floor(vt + 0.5), np.floor(vf + 0.5)
+    jf = np.where(np.isfinite(jf), jf, -1).astype(np.int64)
+    it = np.where(np.isfinite(it), it, -1).astype(np.int64)
+    if order > 1:
+        tmp = np.zeros_like(jf)
+        rows = np.arange(t_len)[:, None]
+        for _ in range(order - 1):
+            ok = (jf >= 0) & (jf < f_len)
+            tmp = np.where(ok, jf[rows, np.clip(jf, 0, f_len - 1)], tmp)
+            jf = tmp.copy()
+    sign = np.where(np.arange(f_len) % 2 == 1, -1.0, 1.0)[None, :]
+    val = np.abs(Sh) if amplitude else Sh * sign
+    ok = (it >= 0) & (it < t_len) & (jf >= 0) & (jf < f_len)
+    out = np.zeros((t_len, f_len), np.float64 if amplitude else np.complex128)
+    np.add.at(out, (it[ok], jf[ok]), val[ok])
+    return out
+
+
+def reassign_allowance(Sh, vt, vf, thresh, c_rel=1e-5):
+    """per target cell: total magnitude of the coefficients whose target cell is not determined at
+    float32 accuracy -- a coordinate within dv of a rounding boundary (dv = the coordinate shift a
+    relative error c_rel * max|S| / |S| of the ratios S_dh/S_h, S_th/S_h produces: they scale the
+    OFFSET from the coefficient's own cell), or |S|^2 within c_rel of the threshold (the
+    coefficient then falls back to its own cell).  Each may land anywhere in the 3 x 3
+    neighbourhood of its nominal target or in its own cell; nothing else may differ."""
+    Sh = np.asarray(Sh, np.complex128)
+    t_len, f_len = Sh.shape
+    mag = np.abs(Sh)
+    rel = c_rel * mag.max() / np.maximum(mag, 1e-300)
+    own_t = np.broadcast_to(np.arange(t_len)[:, None], Sh.shape)
+    own_f = np.broadcast_to(np.arange(f_len)[None, :], Sh.shape)
+    with np.errstate(all="ignore"):
+        dt = np.minimum(0.5, rel * (np.abs(vt - own_t) + 1) + 1e-6)
+        df = np.minimum(0.5, rel * (np.abs(vf - own_f) + 1) + 1e-6)
+        near = (np.abs(vt - (np.floor(vt) + 0.5)) < dt) | (np.abs(vf - (np.floor(vf) + 0.5)) < df)
+    edge = np.abs(mag - thresh) <= 10 * c_rel * max(thresh, 1e-30)
+    amb = (near | edge) & np.isfinite(vt) & np.isfinite(vf)
+    allow = np.zeros((t_len, f_len))
+    it, jf = np.floor(vt + 0.5), np.floor(vf + 0.5)
+    for a in (-1, 0, 1):
+        for b in (-1, 0, 1):
+            r, c = it + a, jf + b
+            ok = amb & (r >= 0) & (r < t_len) & (c >= 0) & (c < f_len)
+            np.add.at(allow, (r[ok].astype(np.int64), c[ok].astype(np.int64)), mag[ok])
+    np.add.at(allow, (own_t[edge], own_f[edge]), mag[edge])
+    return allow, amb

@@ -316,3 +316,39 @@ WSST_CASES = {
 }
 WSST_SCALE_NAME = {SCALE["octave"]: "octave", SCALE["log"]: "log", SCALE["linear"]: "linear",
                    SCALE["linspace"]: "linspace", SCALE["mel"]: "mel", SCALE["bark"]: "bark", SCALE["erb"]: "erb"}
+
+
+# reassignment: RefReassign ctor kwargs + switches + input
+RETYPE = dict(all=0, fre=1, time=2, none=3)
+REASSIGN_CASES = {
+    "all_hann_1024": dict(radix2_exp=10, samplate=16000, window_type=WIN["hann"], slide_length=256,
+                          re_type=RETYPE["all"], x=("mix", 501, 12000)),
+    "fre_hamm_512": dict(radix2_exp=9, samplate=16000, window_type=WIN["hamm"], slide_length=100,
+                         re_type=RETYPE["fre"], thresh=0.01, x=("mix", 502, 9000)),
+    "time_pad_amplitude": dict(radix2_exp=10, samplate=32000, window_type=WIN["hann"], slide_length=256,
+                               re_type=RETYPE["time"], is_padding=1, result_type=1, x=("mix", 503, 10000)),
+    "all_order2": dict(radix2_exp=8, samplate=16000, window_type=WIN["blackman"], slide_length=64,
+                       re_type=RETYPE["all"], order=2, x=("mix", 504, 5000)),
+    "none_plain_stft": dict(radix2_exp=9, samplate=16000, window_type=WIN["hann"], slide_length=128,
+                            re_type=RETYPE["none"], x=("noise", 505, 4000)),
+}
+RETYPE_NAME = {v: k for k, v in RETYPE.items()}
+# bftObj_new(isReassign = 1): mel bank over the reassigned spectrum
+BFT_REASSIGN_CASES = {
+    "mel64_power_real": dict(num=64, radix2_exp=10, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                             window_type=WIN["hann"], slide_length=256, scale_type=SCALE["mel"],
+                             style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=0,
+                             x=("mix", 511, 12000), result_type=1),
+    "mel64_mag_complex": dict(num=64, radix2_exp=10, samplate=16000, low_fre=0.0, high_fre=8000.0,
+                              window_type=WIN["hann"], slide_length=256, scale_type=SCALE["mel"],
+                              style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=1,
+                              x=("mix", 512, 12000), result_type=0),
+    "linear_slice_power_complex": dict(num=100, radix2_exp=9, samplate=16000, low_fre=1000.0, high_fre=8000.0,
+                                       window_type=WIN["hann"], slide_length=128, scale_type=SCALE["linear"],
+                                       style_type=STYLE["slaney"], normal_type=NORMAL["none"], data_type=0,
+                                       x=("mix", 513, 6000), result_type=0),
+}
+
+
+def reassign_ctor(case):
+    return {k: case[k] for k in ("samplate", "window_type", "slide_length", "re_type", "thresh", "is_padding") if k in case}

@@ -149,6 +149,29 @@ def make_wsst():
     print("wsst.npz", os.path.getsize(os.path.join(HERE, "wsst.npz")) // 1024, "KiB")
 
 
+def make_reassign():
+    """reassign.npz: reassignment object and bftObj_new(isReassign = 1)"""
+    out = {}
+    for name, c in cases.REASSIGN_CASES.items():
+        o = ref.RefReassign(c["radix2_exp"], **cases.reassign_ctor(c))
+        assert o.status == 0
+        if "result_type" in c:
+            o.set_result_type(c["result_type"])
+        if "order" in c:
+            o.set_order(c["order"])
+        a = o.reassign(cases.make_input(c["x"], c["samplate"]))
+        out[f"{name}/re"], out[f"{name}/im"] = a[0], a[1]
+    for name, c in cases.BFT_REASSIGN_CASES.items():
+        kw = cases.ctor_kwargs(c)
+        o = ref.RefBFT(kw.pop("num"), kw.pop("radix2_exp"), is_reassign=1, **kw)
+        assert o.status == 0
+        o.set_result_type(c["result_type"])
+        re, im = o.bft(cases.make_input(c["x"], c["samplate"]))   # first call: the scratch is still zero
+        out[f"bft_{name}/re"], out[f"bft_{name}/im"] = re, im
+    np.savez_compressed(os.path.join(HERE, "reassign.npz"), **out)
+    print("reassign.npz", os.path.getsize(os.path.join(HERE, "reassign.npz")) // 1024, "KiB")
+
+
 def main():
     assert ref.available(), "build the reference oracle first: make -C oracle"
     bft_out = {}
@@ -225,3 +248,4 @@ if __name__ == "__main__":
         make_spectrogram()
         make_pwt()
         make_wsst()
+        make_reassign()

@@ -1,0 +1,136 @@
+"""GPU parity of the reassignment object and of bftObj_new(isReassign = 1).  As for the synchrosqueezed
+transform, the target cell of a coefficient is a ROUNDED function of float32 ratios; the criterion
+(tests/test_reassign_host.py::explained, pinned there against the reference itself): every cell
+agrees to 1e-5 of the peak except for the summed magnitude of the coefficients whose coordinates
+lie within their float32 uncertainty of a rounding boundary or of the power threshold (< 2 % of
+the coefficient mass; in practice a handful of cells differ).  For the BFT the same allowance is
+propagated through |.|^2 / |.| and the (non-negative) filter bank."""
+import os
+
+import numpy as np
+import pytest
+
+import audioflux_amd as af
+from oracle import ref, restate
+from tests import cases
+from tests.conftest import assert_parity
+from tests.test_reassign_host import explained, restated
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "reassign.npz"))
+
+
+def make(c):
+    o = af.Reassign(radix2_exp=c["radix2_exp"], samplate=c["samplate"], window_type=af.WindowType(c["window_type"]),
+                    slide_length=c["slide_length"], re_type=af.ReassignType(c.get("re_type", 0)),
+                    thresh=c.get("thresh", 0.001), is_padding=bool(c.get("is_padding", 0)))
+    if "order" in c:
+        o.set_order(c["order"])
+    return o
+
+
+@pytest.mark.parametrize("name", list(cases.REASSIGN_CASES))
+def test_reassign_matches_golden(name, gold):
+    c = cases.REASSIGN_CASES[name]
+    o = make(c)
+    x = cases.make_input(c["x"], c["samplate"])
+    amp = c.get("result_type", 0) == 1
+    if amp:
+        o.set_result_type(1)
+    a = o.reassign_raw(x)
+    want = gold[f"{name}/re"] if amp else gold[f"{name}/re"] + 1j * gold[f"{name}/im"]
+    assert a[0].shape == want.shape == (o.cal_time_length(len(x)), o.fft_length // 2 + 1)
+    if c.get("re_type") == cases.RETYPE["none"]:
+        assert_parity(a[0] + 1j * a[1], want, 1e-5, name)
+        return
+    Sh, vt, vf = restated(c, x)
+    assert_parity(a[2] + 1j * a[3], Sh, 1e-5, name + " stft output")
+    got = a[0] if amp else a[0] + 1j * a[1]
+    n_diff = explained(got, want, Sh, vt, vf, c.get("thresh", 0.001), name)
+    assert n_diff < 0.005 * want.size
+    # coefficients are moved, not created: total (signed) mass is that of the accepted sources
+    if not amp and c.get("order", 1) == 1:
+        sign = np.where(np.arange(Sh.shape[1]) % 2 == 1, -1.0, 1.0)[None, :]
+        assert abs(got.sum() - (Sh * sign).sum()) <= 1e-3 * np.abs(Sh).sum()
+
+
+def bft_allowance(c, x, result_type):
+    """(expected output, allowance) of the reassigned BFT from the float64 restatement"""
+    n = 1 << c["radix2_exp"]
+    rc = dict(radix2_exp=c["radix2_exp"], samplate=c["samplate"], window_type=c["window_type"],
+              slide_length=c["slide_length"], re_type=0)
+    Sh, vt, vf = restated(rc, x)
+    R = restate.reassign_scatter(Sh, vt, vf)
+    A, amb = restate.reassign_allowance(Sh, vt, vf, 0.001)
+    if c["scale_type"] == cases.SCALE["linear"]:
+        det = np.float32(c["samplate"]) / np.float32(n)
+        lo = int(np.round(np.float32(c["low_fre"]) / det))
+        B = np.zeros((c["num"], n // 2 + 1))
+        B[np.arange(c["num"]), lo + np.arange(c["num"])] = 1
+    else:
+        B, _, _ = restate.mel_bank(c["num"], n, c["samplate"], c["low_fre"], c["high_fre"], "slaney", "none")
+        B = B.astype(np.float64)
+    mag = c["data_type"] == 1
+    if result_type == 1:
+        val = np.abs(R) if mag else np.abs(R) ** 2
+        dval = A if mag else 2 * np.abs(R) * A + A * A
+    else:
+        val = R if mag else R * R
+        dval = A if mag else 2 * np.abs(R) * A + A * A
+    return val @ B.T, dval @ np.abs(B).T
+
+
+@pytest.mark.parametrize("name", list(cases.BFT_REASSIGN_CASES))
+def test_bft_with_reassignment_matches_golden(name, gold):
+    c = cases.BFT_REASSIGN_CASES[name]
+    x = cases.make_input(c["x"], c["samplate"])
+    o = af.BFT(c["num"], radix2_exp=c["radix2_exp"], samplate=c["samplate"], low_fre=c["low_fre"],
+               high_fre=c["high_fre"], window_type=af.WindowType(c["window_type"]), slide_length=c["slide_length"],
+               scale_type=af.SpectralFilterBankScaleType(c["scale_type"]), data_type=af.SpectralDataType(c["data_type"]),
+               is_reassign=True)
+    got = o.bft(x, result_type=c["result_type"]).T
+    want = gold[f"bft_{name}/re"]
+    if c["result_type"] == 0:
+        want = want + 1j * gold[f"bft_{name}/im"]
+    exp, allow = bft_allowance(c, x, c["result_type"])
+    scale = np.abs(want).max()
+    assert (np.abs(exp - want) <= allow + 2e-5 * scale).all(), "restatement does not explain the golden vector"
+    d = np.abs(got - want)
+    bad = d > allow + 1e-5 * scale
+    assert not bad.any(), f"{name}: {int(bad.sum())} cells beyond the propagated allowance (worst {d[bad].max() / scale:.2e})"
+    assert (d > 1e-5 * scale).mean() < 0.02
+    # a second call starts from zero again (the reference would accumulate onto its previous scratch)
+    assert np.array_equal(o.bft(x, result_type=c["result_type"]).T, got)
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_reassign_fresh_input_against_compiled_reference():
+    c = dict(radix2_exp=11, samplate=16000, window_type=1, slide_length=512, re_type=0)
+    x = cases.mix(520, 16000 * 3, 16000)
+    r = ref.RefReassign(11, samplate=16000, window_type=1, slide_length=512, re_type=0)
+    a = r.reassign(x)
+    want = a[0] + 1j * a[1]
+    g = make(c).reassign_raw(x)
+    Sh, vt, vf = restated(c, x)
+    n_diff = explained(g[0] + 1j * g[1], want, Sh, vt, vf, 0.001, "fresh input")
+    assert n_diff < 0.002 * want.size
+
+
+def test_device_batch_and_wrapper():
+    import torch
+    c = cases.REASSIGN_CASES["all_hann_1024"]
+    o = make(c)
+    xs = np.stack([cases.mix(530 + i, 9000, 16000) for i in range(3)])
+    host = [o.reassign_raw(x) for x in xs]
+    re, im, sre, sim = o.reassign_device(torch.from_numpy(xs).cuda(), with_stft=True)
+    torch.cuda.synchronize()
+    for i in range(3):
+        # float atomics: the order of additions inside one cell is not fixed -> compare at 1e-6, not bit for bit
+        assert_parity(re[i].cpu().numpy() + 1j * im[i].cpu().numpy(), host[i][0] + 1j * host[i][1], 1e-6, "batch")
+        assert np.array_equal(sre[i].cpu().numpy(), host[i][2])
+    m1, m2 = o.reassign(xs)
+    assert m1.shape == (3, 513, o.cal_time_length(9000)) and m1.dtype == np.complex64 and m2.shape == m1.shape
