@@ -103,8 +103,9 @@ def test_bft_with_reassignment_matches_golden(name, gold):
     bad = d > allow + 1e-5 * scale
     assert not bad.any(), f"{name}: {int(bad.sum())} cells beyond the propagated allowance (worst {d[bad].max() / scale:.2e})"
     assert (d > 1e-5 * scale).mean() < 0.02
-    # a second call starts from zero again (the reference would accumulate onto its previous scratch)
-    assert np.array_equal(o.bft(x, result_type=c["result_type"]).T, got)
+    # a second call starts from zero again (the reference would accumulate onto its previous scratch);
+    # float atomics: the order of additions inside a cell is not fixed, so equal to rounding only
+    assert_parity(o.bft(x, result_type=c["result_type"]).T, got, 1e-6, name + " second call")
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
