@@ -14,11 +14,12 @@ from .cwt import CWT
 from .pwt import PWT
 from .reassign import Reassign
 from .stft import STFT
+from .synsq import Synsq
 from .wsst import WSST
 from .spectrogram import (Bark, BarkSpectrogram, Chroma, Erb, ErbSpectrogram, Linear, Mel, MelSpectrogram,
                           Spectrogram, SpectrogramBase, SpectralFilterBankType)
 from .batch import mel_mfcc_device
 
-__all__ = ["BFT", "XXCC", "Cepstrogram", "CQT", "CWT", "PWT", "Reassign", "STFT", "WSST", "Spectrogram", "SpectrogramBase", "MelSpectrogram", "BarkSpectrogram", "ErbSpectrogram",
+__all__ = ["BFT", "XXCC", "Cepstrogram", "CQT", "CWT", "PWT", "Reassign", "STFT", "Synsq", "WSST", "Spectrogram", "SpectrogramBase", "MelSpectrogram", "BarkSpectrogram", "ErbSpectrogram",
            "Linear", "Mel", "Bark", "Erb", "Chroma", "SpectralFilterBankType", "mel_mfcc_device", "get_lib", "build", "runtime_status",
            "last_error", "LIB_PATH"]

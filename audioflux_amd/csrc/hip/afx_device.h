@@ -207,8 +207,11 @@ typedef struct {
     int mode;
     float fmin, fmax, logMin, logMax, thresh;
     const float *freNorm;
+    int phaseInput; /* 1: dRe holds the instantaneous frequency itself (synsqObj_synsq), dIm unused */
 } AfxWsstArgs;
 int afxk_wsst_squeeze(const AfxWsstArgs *a, void *stream);
+/* phase-difference frequency estimate of a complex matrix re/im [num][length] -> phase [num][length] */
+int afxk_synsq_phase(const float *re, const float *im, int num, long long length, float *phase, void *stream);
 
 /* time-frequency reassignment (afx_reassign.hip): planes are [batch][timeLength][F] */
 typedef struct {

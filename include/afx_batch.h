@@ -23,6 +23,7 @@
 #include "reassign_algorithm.h"
 #include "spectrogram_algorithm.h"
 #include "stft_algorithm.h"
+#include "synsq_algorithm.h"
 #include "wsst_algorithm.h"
 
 #ifdef __cplusplus

@@ -614,3 +614,31 @@ class RefReassign:
         if getattr(self, "obj", None):
             self.L.reassignObj_free(self.obj)
             self.obj = C.c_void_p(None)
+
+
+class RefSynsq:
+    """src/synsq_algorithm.h:12-31"""
+
+    def __init__(self, num, radix2_exp, samplate=None, order=None, thresh=None):
+        L = lib()
+        self.L = L
+        self.num, self.n = num, 1 << radix2_exp
+        self.obj = C.c_void_p(None)
+        L.synsqObj_new.restype = C.c_int
+        L.synsqObj_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, ip, ip, fp]
+        self.status = L.synsqObj_new(C.byref(self.obj), num, radix2_exp, _pi(samplate), _pi(order), _pf(thresh))
+        L.synsqObj_synsq.restype = None
+        L.synsqObj_synsq.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp, fp]
+        L.synsqObj_free.argtypes = [C.c_void_p]
+
+    def synsq(self, fre, scale_type, W):
+        fre = np.ascontiguousarray(fre, np.float32)
+        re, im = np.ascontiguousarray(W.real, np.float32), np.ascontiguousarray(W.imag, np.float32)
+        a, b = np.zeros_like(re), np.zeros_like(re)
+        self.L.synsqObj_synsq(self.obj, _f(fre), int(scale_type), _f(re), _f(im), _f(a), _f(b))
+        return a + 1j * b
+
+    def __del__(self):
+        if getattr(self, "obj", None):
+            self.L.synsqObj_free(self.obj)
+            self.obj = C.c_void_p(None)

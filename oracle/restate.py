@@ -743,3 +743,65 @@ def reassign_allowance(Sh, vt, vf, thresh, c_rel=1e-5):
             np.add.at(allow, (r[ok].astype(np.int64), c[ok].astype(np.int64)), mag[ok])
     np.add.at(allow, (own_t[edge], own_f[edge]), mag[edge])
     return allow, amb
+
+
+# --------------------------------------------------------------------------
+# synchrosqueezing of a given matrix -- src/synsq_algorithm.c:181-281
+# --------------------------------------------------------------------------
+def synsq_frequency(W):
+    """phase-difference frequency estimate [num, n] (cycles / sample): atan2(re, im) -- the
+    reference's argument order --, unwrap along time, first difference (column 0 -> 0, last column
+    repeats its neighbour), / 2 pi (:181-193)"""
+    return synsq_phase(W)[0]
+
+
+def synsq_phase(W):
+    """(frequency estimate, unwrapped angle): the reference keeps the UNWRAPPED angle in float32, so
+    the rounding of a phase difference grows with the accumulated angle (half an ulp of ~|angle|)"""
+    W = np.asarray(W, np.complex128)
+    ang = np.unwrap(np.arctan2(W.real, W.imag), axis=1)
+    d = np.zeros_like(ang)
+    d[:, 1:] = ang[:, 1:] - ang[:, :-1]
+    if W.shape[1] >= 2:
+        d[:, -1] = d[:, -2]
+    return d / (2 * np.pi), ang
+
+
+def synsq_coordinates(ph, fre, samplate, scale="octave"):
+    """continuous band coordinate of a frequency estimate (the maps of wsst_coordinates)"""
+    num = len(fre)
+    fmin, fmax = float(fre[0]) / samplate, float(fre[num - 1]) / samplate
+    with np.errstate(all="ignore"):
+        if scale in ("octave", "log"):
+            return (np.log2(np.abs(ph)) - np.log2(fmin)) * num / (np.log2(fmax) - np.log2(fmin))
+        if scale in ("linear", "linspace"):
+            return np.abs(ph - fmin) * num / (fmax - fmin)
+        c = np.asarray(fre, np.float64) / samplate
+        a = np.abs(ph)
+        k = np.clip(np.searchsorted(c, a, side="right") - 1, 0, num - 2)
+        v = k + (a - c[k]) / (c[k + 1] - c[k])
+        return np.where((a >= c[0]) & (a < c[-1]), v, np.nan)
+
+
+def synsq_allowance(W, ph, ang, fre, samplate, scale, thresh):
+    """per output cell: magnitude of the coefficients whose band is not determined at float32
+    accuracy: the rounded coordinate changes when the phase difference moves by +-eps, eps = two
+    float32 ulps of the unwrapped angle it is the difference of (>= 1e-6: atan2f itself), or |W|
+    is within 1e-5 of the threshold"""
+    W = np.asarray(W, np.complex128)
+    num, n = W.shape
+    mag = np.abs(W)
+    big = np.abs(ang)
+    big[:, 1:] = np.maximum(big[:, 1:], big[:, :-1])
+    d = np.maximum(1e-6, 2.4e-7 * big) / (2 * np.pi)
+    with np.errstate(all="ignore"):
+        r = [np.floor(synsq_coordinates(ph + s, fre, samplate, scale) + 0.5) for s in (-d, 0.0, d)]
+    amb = (r[0] != r[1]) | (r[2] != r[1])
+    amb &= ~(np.isnan(r[0]) & np.isnan(r[1]) & np.isnan(r[2]))
+    amb |= np.abs(mag - thresh) <= 1e-5 * max(thresh, 1e-30)
+    allow = np.zeros((num, n))
+    cols = np.broadcast_to(np.arange(n)[None, :], W.shape)
+    for rr in r:
+        ok = amb & np.isfinite(rr) & (rr >= 0) & (rr < num)
+        np.add.at(allow, (rr[ok].astype(np.int64), cols[ok]), mag[ok])
+    return allow, amb

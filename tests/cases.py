@@ -352,3 +352,33 @@ BFT_REASSIGN_CASES = {
 
 def reassign_ctor(case):
     return {k: case[k] for k in ("samplate", "window_type", "slide_length", "re_type", "thresh", "is_padding") if k in case}
+
+
+# synchrosqueezing of a given matrix: (num, radix2_exp, samplate, scale, band axis, seed)
+SYNSQ_CASES = {
+    "octave_48": dict(num=48, radix2_exp=11, samplate=16000, scale_type=SCALE["octave"], low=55.0, high=6000.0, seed=601),
+    "mel_32": dict(num=32, radix2_exp=10, samplate=16000, scale_type=SCALE["mel"], low=100.0, high=7000.0, seed=602),
+    "linspace_40": dict(num=40, radix2_exp=12, samplate=32000, scale_type=SCALE["linspace"], low=200.0, high=12000.0, seed=603),
+}
+
+
+def synsq_input(c):
+    """(band centres [num] float32 ascending, complex64 matrix [num, n]): every row a frequency-modulated
+    component around its band centre with a slowly varying amplitude, plus weak complex noise"""
+    num, n, sr = c["num"], 1 << c["radix2_exp"], c["samplate"]
+    rng = np.random.default_rng(c["seed"])
+    if c["scale_type"] == SCALE["linspace"]:
+        fre = np.linspace(c["low"], c["high"], num)
+    elif c["scale_type"] == SCALE["mel"]:
+        m = np.linspace(2595 * np.log10(1 + c["low"] / 700), 2595 * np.log10(1 + c["high"] / 700), num)
+        fre = 700 * (10 ** (m / 2595) - 1)
+    else:
+        fre = c["low"] * (c["high"] / c["low"]) ** (np.arange(num) / (num - 1))
+    t = np.arange(n)
+    rows = []
+    for i in range(num):
+        f_inst = fre[i] * (1 + 0.25 * np.sin(2 * np.pi * t / n * (1 + i % 3) + rng.uniform(0, 6.28)))
+        phase = 2 * np.pi * np.cumsum(f_inst) / sr
+        amp = 0.5 + 0.5 * np.cos(2 * np.pi * t / n * (2 + i % 5)) ** 2
+        rows.append(amp * np.exp(1j * phase) + 0.002 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+    return fre.astype(np.float32), np.stack(rows).astype(np.complex64)

@@ -172,6 +172,18 @@ def make_reassign():
     print("reassign.npz", os.path.getsize(os.path.join(HERE, "reassign.npz")) // 1024, "KiB")
 
 
+def make_synsq():
+    """synsq.npz: synchrosqueezing of synthetic matrices (whole columns at a time stride)"""
+    out = {}
+    for name, c in cases.SYNSQ_CASES.items():
+        fre, W = cases.synsq_input(c)
+        o = ref.RefSynsq(c["num"], c["radix2_exp"], samplate=c["samplate"])
+        assert o.status == 0
+        out[f"{name}/s"] = o.synsq(fre, c["scale_type"], W)[:, ::cases.cwt_stride(c)].astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, "synsq.npz"), **out)
+    print("synsq.npz", os.path.getsize(os.path.join(HERE, "synsq.npz")) // 1024, "KiB")
+
+
 def main():
     assert ref.available(), "build the reference oracle first: make -C oracle"
     bft_out = {}
@@ -249,3 +261,4 @@ if __name__ == "__main__":
         make_pwt()
         make_wsst()
         make_reassign()
+        make_synsq()
