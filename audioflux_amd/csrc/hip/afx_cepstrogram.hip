@@ -19,11 +19,7 @@
 
 namespace {
 
-// in-place DIF transform in LDS (afx_ldsfft.h); afterwards X[k] sits at bitrev_r(k)
-__device__ __forceinline__ void fft_dif(float2 *s, int r, const float2 *tw, int tid, int nth) {
-    afx_lds_fft_dif(s, r, tw, 1, tid, nth);
-}
-
+// the in-place DIF transform in LDS (afx_ldsfft.h) leaves X[k] at bitrev_r(k)
 __device__ __forceinline__ int brev(int k, int r) { return (int)(__brev((unsigned)k) >> (32 - r)); }
 
 __global__ void k_cepstrogram(AfxCepstrogramArgs a) {

@@ -98,3 +98,43 @@ def test_cfg5_cqt_chroma_gpu_share_duplicates_and_sampled_reference():
         rre, rim = rr.cqt(x[i].cpu().numpy())
         assert_parity(re[i].cpu().numpy() + 1j * im[i].cpu().numpy(), rre + 1j * rim, what="cfg5 cqt clip 61")
         assert_parity(ch[i].cpu().numpy(), rr.chroma(rre, rim), tol=5e-5, what="cfg5 chroma clip 61")
+
+
+def test_cfg2_spectrogram_object_equals_bft_and_stft_round_trip():
+    """the sibling objects at the cfg-2 scale: (a) the mel spectrogram object runs the BFT execution
+    plan, so on the full 1000-clip corpus its result equals bftObj's bit for bit; (b) STFT ->
+    inverse STFT (weighted overlap-add) returns the framed span of 256 whole clips to 1e-5;
+    (c) centre-padded frames: clip j and clip j advanced by one hop share their interior frames."""
+    import torch
+    clips, n, hop, nfft = 1000, 480000, 512, 2048
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = 0.1 * torch.randn((clips, n), device="cuda", generator=g)
+    bft = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+                 scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+    bft.set_result_type(1)
+    spec = af.MelSpectrogram(num=128, samplate=16000, low_fre=0.0, high_fre=8000.0, radix2_exp=11, slide_length=hop)
+    a, b = bft.bft_device(x), spec.spectrogram_device(x)
+    torch.cuda.synchronize()
+    assert a.shape == (clips, 934, 128) and torch.equal(a, b)
+    del a, b
+    s = af.STFT(radix2_exp=11, window_type=af.WindowType.HANN, slide_length=hop)
+    xs = x[:256]
+    re, im = s.stft_device(xs)
+    y = s.istft_device(re, im)
+    torch.cuda.synchronize()
+    m = y.shape[1]
+    err = (y[:, nfft:m - nfft] - xs[:, nfft:m - nfft]).abs().amax() / xs.abs().amax()
+    assert float(err) <= 1e-5, f"round trip {float(err):.2e}"
+    del re, im, y
+    s.enable_padding(True)
+    s.set_padding(af.PaddingPositionType.CENTER, af.PaddingModeType.REFLECT)
+    xa = xs[:64]
+    xb = torch.empty_like(xa)
+    xb[:, : n - hop] = xa[:, hop:]
+    xb[:, n - hop:] = 0.05
+    ra, ia = s.stft_device(xa)
+    rb, ib = s.stft_device(xb)
+    torch.cuda.synchronize()
+    t = ra.shape[1]
+    # frames whose support lies inside both clips (away from the reflected edges) are the same samples
+    assert torch.equal(rb[:, 2:t - 4], ra[:, 3:t - 3]) and torch.equal(ib[:, 2:t - 4], ia[:, 3:t - 3])
