@@ -103,7 +103,20 @@ def cpu_baseline(budget_s=25.0):
         rate = frames / wall
         tried.append(f"B={p}procs:{rate:.0f}")
         if rate > best["value"]:
-            best = {"value": rate, "cores": p, "how": f"B: {p} processes x 1 FFT thread", "frames": frames}
+            best = {"value": rate, "cores": p, "how": f"B: {p} processes x 1 FFT thread", "frames": frames,
+                    "procs": p}
+    # the sweep samples are short; re-time the best configuration on a sample sized for ~12 s of
+    # wall time (bounded: <= 96 clips per worker) and report that measurement
+    if "procs" in best and time.perf_counter() - t_start < budget_s:
+        p = best["procs"]
+        per_proc = best["value"] / p
+        n = int(max(8, min(96, 12.0 * per_proc / ((SR * CLIP_SECONDS - NFFT) // HOP + 1))))
+        with ctx.Pool(p) as pool:
+            res = pool.map(cpu_worker, [(3000 + i, n, 2) for i in range(p)])
+        wall = max(r[1] for r in res)
+        frames = sum(r[0] for r in res)
+        tried.append(f"final={p}procsx{n}clips:{frames / wall:.0f}")
+        best.update(value=frames / wall, frames=frames)
     return {"value": best["value"], "unit": "frames/s", "cores": best["cores"], "kind": "reference",
             "sample": f"{best['how']}, {best['frames']} frames of {CLIP_SECONDS} s @16 kHz clips "
                       f"(mel-128 + MFCC-13, n_fft 2048, hop 512); built-in radix-2 FFT + naive matmul "
