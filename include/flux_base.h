@@ -14,50 +14,50 @@ extern "C" {
 
 /* analysis window applied to each STFT frame (reference flux_base.h:14-36) */
 typedef enum {
-    Window_Rect = 0,
-    Window_Hann = 1,
-    Window_Hamm = 2,
-    Window_Blackman = 3,
-    Window_Kaiser = 4,
-    Window_Bartlett = 5,
-    Window_Triang = 6,
-    Window_Flattop = 7,
-    Window_Gauss = 8,
-    Window_Blackman_Harris = 9,
-    Window_Blackman_Nuttall = 10,
-    Window_Bartlett_Hann = 11,
-    Window_Bohman = 12,
-    Window_Tukey = 13
+    Window_Rect = 0,                          /* all ones */
+    Window_Hann = 1,                          /* 0.5 - 0.5 cos, periodic (length+1 symmetric window minus its last sample) */
+    Window_Hamm = 2,                          /* 0.54 - 0.46 cos, periodic */
+    Window_Blackman = 3,                      /* 3-term cosine sum, end samples forced to 0 */
+    Window_Kaiser = 4,                        /* beta 5, I0 by a 15-term series */
+    Window_Bartlett = 5,                      /* symmetric */
+    Window_Triang = 6,                        /* symmetric */
+    Window_Flattop = 7,                       /* 5-term cosine sum */
+    Window_Gauss = 8,                         /* alpha 2.5 */
+    Window_Blackman_Harris = 9,               /* 4-term, -92 dB */
+    Window_Blackman_Nuttall = 10,             /* 4-term */
+    Window_Bartlett_Hann = 11,                /* symmetric */
+    Window_Bohman = 12,                       /* symmetric */
+    Window_Tukey = 13                         /* tapered cosine, alpha 0.5 */
 } WindowType;
 
 /* what the filter bank is applied to (reference flux_base.h:49-53) */
 typedef enum {
-    SpectralData_Power = 0,
-    SpectralData_Mag = 1
+    SpectralData_Power = 0,                   /* |S|^2 (optionally ^normValue) feeds the bank */
+    SpectralData_Mag = 1                      /* |S| feeds the bank; normValue raises the bank's OUTPUT */
 } SpectralDataType;
 
 /* frequency axis of the band centres (reference flux_base.h:55-74) */
 typedef enum {
-    SpectralFilterBankScale_Linear = 0,
-    SpectralFilterBankScale_Linspace = 1,
-    SpectralFilterBankScale_Mel = 2,
-    SpectralFilterBankScale_Bark = 3,
-    SpectralFilterBankScale_Erb = 4,
-    SpectralFilterBankScale_Octave = 5,
-    SpectralFilterBankScale_Log = 6,
-    SpectralFilterBankScale_Deep = 7,
-    SpectralFilterBankScale_Chroma = 8,
-    SpectralFilterBankScale_LogChroma = 9,
-    SpectralFilterBankScale_DeepChroma = 10
+    SpectralFilterBankScale_Linear = 0,       /* bin slice [lowIndex, highIndex], no bank matrix */
+    SpectralFilterBankScale_Linspace = 1,     /* centres equally spaced in Hz */
+    SpectralFilterBankScale_Mel = 2,          /* 2595 log10(1 + f/700) */
+    SpectralFilterBankScale_Bark = 3,         /* Traunmueller with the low / high corrections */
+    SpectralFilterBankScale_Erb = 4,          /* 21.3654 log10(1 + 0.004368 f) */
+    SpectralFilterBankScale_Octave = 5,       /* binPerOctave steps per octave from the band of lowFre */
+    SpectralFilterBankScale_Log = 6,          /* equally spaced in log2(f / 440) */
+    SpectralFilterBankScale_Deep = 7,         /* spectrogram object only: salience model, refused (-4) */
+    SpectralFilterBankScale_Chroma = 8,       /* spectrogram object only: Gaussian STFT-chroma bank */
+    SpectralFilterBankScale_LogChroma = 9,    /* spectrogram object only: log bank folded onto chroma */
+    SpectralFilterBankScale_DeepChroma = 10   /* spectrogram object only: refused (-4) */
 } SpectralFilterBankScaleType;
 
 /* shape of each band (reference flux_base.h:76-93) */
 typedef enum {
-    SpectralFilterBankStyle_Slaney = 0,
-    SpectralFilterBankStyle_ETSI = 1,
-    SpectralFilterBankStyle_Gammatone = 2,
-    SpectralFilterBankStyle_Point = 3,
-    SpectralFilterBankStyle_Rect = 4,
+    SpectralFilterBankStyle_Slaney = 0,       /* triangles in Hz between neighbouring centres */
+    SpectralFilterBankStyle_ETSI = 1,         /* triangles in bins */
+    SpectralFilterBankStyle_Gammatone = 2,    /* 4th-order gammatone magnitude response: dense rows */
+    SpectralFilterBankStyle_Point = 3,        /* one unit weight at the centre bin */
+    SpectralFilterBankStyle_Rect = 4,         /* ones between the neighbouring centres */
     SpectralFilterBankStyle_Hann = 5,
     SpectralFilterBankStyle_Hamm = 6,
     SpectralFilterBankStyle_Blackman = 7,
