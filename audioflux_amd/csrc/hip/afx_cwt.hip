@@ -74,6 +74,7 @@ struct CwtGeom {
     const float2 *tw;  // W_L^m, m < L/2
     const float2 *fastTw;
     const int *support;  // [num][2] non-zero k2 range per scale, or NULL
+    const int *order;    // [num] scale handled by blockIdx.y (+ list base), or NULL = identity
     int num;           // scales (chunk stride of the per-scale buffers = num * L)
 };
 
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
-    const int j = blockIdx.y;
+    const int j = g.order ? g.order[blockIdx.y] : (int)blockIdx.y;
     // wave w of workgroup b owns rows k1 = 16 b + w + 4 it, it < ROWS_PER_WAVE
     const int k1base = blockIdx.x * (4 * ROWS_PER_WAVE) + wave;
     const float2 *xc = Xt + (long long)blockIdx.z * L;
@@ -322,22 +323,16 @@ __global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2
     }
 }
 
-__global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2 *__restrict__ B,
-                                                         float *__restrict__ outRe,
-                                                         float *__restrict__ outIm) {
-    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]
+// second half of the 256-point column transform, shared by the two column kernels: r[a] holds
+// B[16 a + g][c] of thread (c, g); radix-16, twiddle, exchange, radix-16, conj, 1/L, crop, store
+__device__ __forceinline__ void cols256_finish(const CwtGeom &g, v2 (&r)[16], v2 *ex, int c, int gq, int c0,
+                                               float *__restrict__ oRe, float *__restrict__ oIm) {
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
-    const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
-    const int c0 = blockIdx.x * 16, j = blockIdx.y;
-    const float2 *in = B + ((long long)blockIdx.z * g.num + j) * L + c0 + c;
-    v2 r[16];
     float2 t3[16];
 #pragma unroll
-    for (int a = 0; a < 16; ++a) r[a] = ld2(in + (long long)(16 * a + gq) * L2);
-#pragma unroll
     for (int p = 1; p < 16; ++p) t3[p] = g.fastTw[8 * 64 + 8 * 8 + 16 * p + gq];  // W_256^(g p)
-    __builtin_amdgcn_sched_barrier(0);  // all 31 loads in flight before the first butterfly
+    __builtin_amdgcn_sched_barrier(0);  // all loads in flight before the first butterfly
     dft16(r);  // r[rev4(p)] = sum_a B[16 a + g] W_16^(a p)
 #pragma unroll
     for (int p = 1; p < 16; ++p) r[rev4(p)] = cmul(r[rev4(p)], v2{t3[p].x, t3[p].y});
@@ -350,8 +345,6 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2
     dft16(r);  // r[rev4(q)] = Y[m2 = p + 16 q]
     const float invL = 1.f / (float)L;
     const long long D = g.dataLength, P = g.pad;
-    float *oRe = outRe + ((long long)blockIdx.z * g.num + j) * D;
-    float *oIm = outIm + ((long long)blockIdx.z * g.num + j) * D;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const long long n = (long long)(p + 16 * q) * L2 + c0 + c;
@@ -361,6 +354,87 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2
             oIm[n - P] = -a.y * invL;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2 *__restrict__ B,
+                                                         float *__restrict__ outRe,
+                                                         float *__restrict__ outIm) {
+    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
+    const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
+    const int c0 = blockIdx.x * 16;
+    const int j = g.order ? g.order[blockIdx.y] : (int)blockIdx.y;
+    const float2 *in = B + ((long long)blockIdx.z * g.num + j) * L + c0 + c;
+    v2 r[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) r[a] = ld2(in + (long long)(16 * a + gq) * L2);
+    const long long D = g.dataLength;
+    cols256_finish(g, r, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
+                   outIm + ((long long)blockIdx.z * g.num + j) * D);
+}
+
+// Narrow-band scales: every non-zero of the wavelet lies in R rows k2 in [lo, lo + R) of the
+// transposed spectrum (frequencies k = k1 + 256 k2), so the 512-point row transform of the first
+// pass is an R-term sum,
+//     B[k1][m1] = W_L^(m1 k1) * sum_{k2} conj(Xt[k1][k2] wavelet[k1][k2]) W_512^(k2 m1),
+// which this kernel evaluates on the fly for its 16 columns m1 and feeds straight into the column
+// transform: such a scale runs NO row pass and its 1 MB intermediate is neither written nor read
+// (HBM traffic per scale and chunk: 2.5 MB -> the 0.5 MB of output).  The R x 256 products are
+// staged in LDS with row-contiguous loads; they are the same for the 32 workgroups of a scale and
+// are served by L2.  The terms outside a wavelet's support that R rounds up to are exact zeros.
+template <int R>
+__global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const float2 *__restrict__ Xt,
+                                                            const float *__restrict__ bankT, int isDet,
+                                                            int listBase, float *__restrict__ outRe,
+                                                            float *__restrict__ outIm) {
+    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]
+    __shared__ v2 zs[256 * R];       // [k1][k2 - lo]
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
+    const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
+    const int c0 = blockIdx.x * 16, m1 = c0 + c;
+    const int j = g.order[listBase + blockIdx.y];
+    int lo = g.support[2 * j];
+    if (lo + R > L2) lo = L2 - R;
+    const float2 *xc = Xt + (long long)blockIdx.z * L + lo;
+    const float *bankj = bankT + (long long)j * L + lo;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int idx = tid + 256 * i, k2 = idx & (R - 1), k1 = idx / R;
+        const float2 xv = xc[k1 * L2 + k2];
+        const float b = bankj[k1 * L2 + k2];
+        // conj(X * wavelet) (cwt_algorithm.c:428-435): IFFT through a forward FFT
+        zs[idx] = isDet ? v2{-b * xv.y, -(b * xv.x)} : v2{b * xv.x, -(b * xv.y)};
+    }
+    v2 w5[R], wl[16];
+#pragma unroll
+    for (int k2 = 0; k2 < R; ++k2) {  // W_512^q = W_L^(256 q), q = (lo + k2) m1 mod 512
+        const int q = ((lo + k2) * m1) & (L2 - 1);
+        const float2 t = g.tw[256 * (q & 255)];
+        const float sgn = (q & 256) ? -1.f : 1.f;
+        w5[k2] = v2{t.x * sgn, t.y * sgn};
+    }
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {  // four-step twiddle W_L^(m1 k1), m1 k1 < L
+        const int m = m1 * (16 * a + gq);
+        const float2 t = g.tw[m & 65535];
+        const float sgn = (m >> 16) & 1 ? -1.f : 1.f;
+        wl[a] = v2{t.x * sgn, t.y * sgn};
+    }
+    __syncthreads();
+    v2 r[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const v2 *z = zs + (16 * a + gq) * R;
+        v2 acc = cmul(z[0], w5[0]);
+#pragma unroll
+        for (int k2 = 1; k2 < R; ++k2) acc += cmul(z[k2], w5[k2]);
+        r[a] = cmul(acc, wl[a]);
+    }
+    const long long D = g.dataLength;
+    cols256_finish(g, r, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
+                   outIm + ((long long)blockIdx.z * g.num + j) * D);
 }
 
 // ---- transforms that fit one CU's LDS (L <= 16384: the reference wrapper's default sizes) ----
@@ -429,6 +503,7 @@ CwtGeom make_geom(const AfxCwtPlanDims *d, const float *tw) {
     g.tw = reinterpret_cast<const float2 *>(tw);
     g.fastTw = reinterpret_cast<const float2 *>(d->fastTw);
     g.support = d->support;
+    g.order = d->order;
     g.num = 0;
     return g;
 }
@@ -485,22 +560,56 @@ extern "C" int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const 
 
 extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt,
                                 const float *bankT, int num, int isDet, int chunks, float *scratchB,
-                                float *outRe, float *outIm, void *stream) {
+                                float *outRe, float *outIm, int parts, void *stream) {
     if (chunks <= 0) return AFX_OK;
     if (chunks > 65535 || num > 65535) return AFX_ERR_UNSUPPORTED;
     CwtGeom g = make_geom(d, tw);
     g.num = num;
     const int L1 = 1 << d->r1, L2 = 1 << d->r2;
     if (d->fastTw && d->r1 == 8 && d->r2 == 9 && !getenv("AFX_NO_FUSED")) {
-        hipLaunchKernelGGL(k_cwt_inv_rows512, dim3(L1 / (4 * ROWS_PER_WAVE), num, chunks), dim3(256), 0, (hipStream_t)stream,
-                           g, reinterpret_cast<const float2 *>(Xt), bankT, isDet,
-                           reinterpret_cast<float2 *>(scratchB));
-        AFX_LAUNCH_CHECK("k_cwt_inv_rows512");
-        hipLaunchKernelGGL(k_cwt_inv_cols256, dim3(L2 / 16, num, chunks), dim3(256), 0, (hipStream_t)stream,
-                           g, reinterpret_cast<const float2 *>(scratchB), outRe, outIm);
-        AFX_LAUNCH_CHECK("k_cwt_inv_cols256");
+        const float2 *Xt2 = reinterpret_cast<const float2 *>(Xt);
+        float2 *B2 = reinterpret_cast<float2 *>(scratchB);
+        hipStream_t s = (hipStream_t)stream;
+        // wide scales: row pass -> intermediate -> column pass
+        const int nWide = d->order ? d->nWide : num;
+        if (nWide > 0 && (parts & AFX_CWT_WIDE)) {
+            hipLaunchKernelGGL(k_cwt_inv_rows512, dim3(L1 / (4 * ROWS_PER_WAVE), nWide, chunks), dim3(256), 0, s,
+                               g, Xt2, bankT, isDet, B2);
+            AFX_LAUNCH_CHECK("k_cwt_inv_rows512");
+            hipLaunchKernelGGL(k_cwt_inv_cols256, dim3(L2 / 16, nWide, chunks), dim3(256), 0, s, g, B2, outRe,
+                               outIm);
+            AFX_LAUNCH_CHECK("k_cwt_inv_cols256");
+        }
+        // narrow-band scales: column pass only, straight from the spectrum
+        if (d->order && (parts & AFX_CWT_NARROW)) {
+            int base = nWide;
+            if (d->nNarrow[0] > 0) {
+                hipLaunchKernelGGL(k_cwt_inv_cols256_nb<2>, dim3(L2 / 16, d->nNarrow[0], chunks), dim3(256), 0, s,
+                                   g, Xt2, bankT, isDet, base, outRe, outIm);
+                AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb<2>");
+            }
+            base += d->nNarrow[0];
+            if (d->nNarrow[1] > 0) {
+                hipLaunchKernelGGL(k_cwt_inv_cols256_nb<4>, dim3(L2 / 16, d->nNarrow[1], chunks), dim3(256), 0, s,
+                                   g, Xt2, bankT, isDet, base, outRe, outIm);
+                AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb<4>");
+            }
+            base += d->nNarrow[1];
+            if (d->nNarrow[2] > 0) {
+                hipLaunchKernelGGL(k_cwt_inv_cols256_nb<8>, dim3(L2 / 16, d->nNarrow[2], chunks), dim3(256), 0, s,
+                                   g, Xt2, bankT, isDet, base, outRe, outIm);
+                AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb<8>");
+            }
+            base += d->nNarrow[2];
+            if (d->nNarrow[3] > 0) {
+                hipLaunchKernelGGL(k_cwt_inv_cols256_nb<16>, dim3(L2 / 16, d->nNarrow[3], chunks), dim3(256), 0, s,
+                                   g, Xt2, bankT, isDet, base, outRe, outIm);
+                AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb<16>");
+            }
+        }
         return AFX_OK;
     }
+    if (!(parts & AFX_CWT_WIDE)) return AFX_OK;  // the size-generic kernels take every scale in the wide part
     const size_t ldsC = (size_t)L1 * d->tileCols * sizeof(float2), ldsR = (size_t)L2 * sizeof(float2);
     int st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_inv_cols), ldsC);
     if (st == AFX_OK) st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_inv_rows), ldsR);

@@ -178,6 +178,14 @@ typedef struct {
                           * [8][64] W_512^(lane d) | [8][8] W_64^(c d) | [16][16] W_256^(g p);
                           * NULL: size-generic kernels only                            */
     const int *support;  /* device [num][2]: k2 range of each wavelet's non-zeros (or NULL)  */
+    /* narrow-band scales (register-FFT plan only): a wavelet whose non-zeros lie in <= 16 rows
+     * k2 of the transposed spectrum needs no row pass and no intermediate -- the column kernel
+     * forms its operands from the spectrum directly (k_cwt_inv_cols256_nb).
+     * order: device [num] scale indices, the nWide wide scales first, then the scales of the
+     * classes R = 2, 4, 8, 16 (nNarrow[0..3] of them); NULL: every scale takes both passes */
+    const int *order;
+    int nWide;
+    int nNarrow[4];
 } AfxCwtPlanDims;
 #define AFX_CWT_FASTTW_FLOATS (2 * (8 * 64 + 8 * 8 + 16 * 16))
 /* `chunks` signals, chunk c at x + c*xStride -> Xt[c][L] complex (transposed layout:
@@ -185,10 +193,14 @@ typedef struct {
 int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x, long long xStride,
                      int chunks, float *scratchA, float *Xt, void *stream);
 /* Xt[chunks][L], bankT[num][L] (same layout) -> outRe/outIm [chunks][num][dataLength];
- * scratchB: chunks*num*L complex */
+ * scratchB: chunks*num*L complex (wide part only).  parts: AFX_CWT_WIDE = the scales that take
+ * the row pass + column pass (all of them when the plan has no narrow-band order),
+ * AFX_CWT_NARROW = the narrow-band scales (no scratch, any number of chunks per launch) */
+#define AFX_CWT_WIDE 1
+#define AFX_CWT_NARROW 2
 int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, const float *bankT,
                      int num, int isDet, int chunks, float *scratchB, float *outRe, float *outIm,
-                     void *stream);
+                     int parts, void *stream);
 
 /* transforms with L = 2^(r1+r2) <= 8192, entirely in LDS: x (NULL: re-use the spectra in X) ->
  * X[chunks][L] natural order -> outRe/outIm [chunks][num][dataLength]; bankNatural [num][L] */

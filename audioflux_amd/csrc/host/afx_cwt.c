@@ -37,6 +37,7 @@ struct OpaqueCWT {
     float *dFastTw;          /* twiddle tables of the register-FFT kernels (L = 2^17) */
     float *dBankN, *dBankDetN; /* natural-layout banks of the in-LDS path (L <= 16384), else NULL */
     int *dSupport;           /* [num][2]: k2 range holding every non-zero of the scale's wavelet */
+    int *dOrder;             /* [num]: wide scales first, then the narrow-band classes (afx_device.h) */
     float *dGA, *dGXt, *dGB; /* scratch of the batched calls: `group` chunks at a time */
     size_t capGA, capGXt, capGB;
     int haveSpectrum;
@@ -533,21 +534,27 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
              * rest (exact: those products are zeros in the reference too) */
             int *sup = (int *)malloc(sizeof(int) * 2 * (size_t)num);
             if (sup) {
-                for (int i = 0; i < num; i++) {
-                    long long kmin = -1, kmax = -1;
-                    const float *row = o->hBank + (size_t)i * fftLength;
-                    for (long long k = 0; k < fftLength; k++)
-                        if (row[k] != 0.f) {
-                            if (kmin < 0) kmin = k;
-                            kmax = k;
-                        }
-                    sup[2 * i] = kmin < 0 ? 0 : (int)(kmin >> o->dims.r1);
-                    sup[2 * i + 1] = kmin < 0 ? 0 : (int)(kmax >> o->dims.r1) + 1;
-                }
+                afx_cwt_support_host(o->hBank, num, fftLength, o->dims.r1, sup);
                 st = afxdev_malloc((void **)&o->dSupport, sizeof(int) * 2 * (size_t)num);
                 if (st == AFX_OK) st = afxdev_h2d(o->dSupport, sup, sizeof(int) * 2 * (size_t)num, o->stream);
                 if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
                 o->dims.support = o->dSupport;
+                /* narrow-band scales (<= maxR rows of the transposed spectrum hold every
+                 * non-zero) skip the row pass: list the wide scales first, then the classes
+                 * R = 2, 4, 8, 16 (afx_device.h).  AFX_CWT_NARROW=0 sends every scale through
+                 * both passes; AFX_CWT_NARROW_MAX bounds the widest class used. */
+                int *order = (int *)malloc(sizeof(int) * (size_t)num);
+                const char *en = getenv("AFX_CWT_NARROW"), *em = getenv("AFX_CWT_NARROW_MAX");
+                int maxR = em ? atoi(em) : AFX_CWT_NARROW_MAX_DEFAULT;
+                if (en && atoi(en) == 0) maxR = 0;
+                if (order && st == AFX_OK && maxR >= 2) {
+                    afx_cwt_classify_host(sup, num, maxR, order, &o->dims.nWide, o->dims.nNarrow);
+                    st = afxdev_malloc((void **)&o->dOrder, sizeof(int) * (size_t)num);
+                    if (st == AFX_OK) st = afxdev_h2d(o->dOrder, order, sizeof(int) * (size_t)num, o->stream);
+                    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+                    if (st == AFX_OK) o->dims.order = o->dOrder;
+                }
+                free(order);
                 free(sup);
             }
             if (st == AFX_OK) st = afxdev_malloc((void **)&o->dFastTw, sizeof(float) * AFX_CWT_FASTTW_FLOATS);
@@ -579,6 +586,43 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
     return 0;
 }
 
+/* Support of every wavelet in the transposed spectrum layout (frequency k = k1 + 2^r1 k2):
+ * sup[2i], sup[2i+1] = the range of rows k2 that holds all non-zeros of scale i ((0,0) for an
+ * all-zero row).  Host-only, exported for tests. */
+void afx_cwt_support_host(const float *bank, int num, long long fftLength, int r1, int *sup) {
+    for (int i = 0; i < num; i++) {
+        long long kmin = -1, kmax = -1;
+        const float *row = bank + (size_t)i * fftLength;
+        for (long long k = 0; k < fftLength; k++)
+            if (row[k] != 0.f) {
+                if (kmin < 0) kmin = k;
+                kmax = k;
+            }
+        sup[2 * i] = kmin < 0 ? 0 : (int)(kmin >> r1);
+        sup[2 * i + 1] = kmin < 0 ? 0 : (int)(kmax >> r1) + 1;
+    }
+}
+
+/* Execution order of the scales in the register-FFT inverse (afx_device.h): scales whose support
+ * spans more than maxR rows ("wide": row pass + column pass) first, then the narrow-band classes
+ * R = 2, 4, 8, 16 (support width <= R, > R/2), each in ascending scale order.  maxR is clamped
+ * to 16; maxR < 2 makes every scale wide. */
+void afx_cwt_classify_host(const int *sup, int num, int maxR, int *order, int *nWide, int nNarrow[4]) {
+    if (maxR > 16) maxR = 16;
+    int q = 0;
+    for (int cls = -1; cls < 4; cls++) {
+        int n = 0;
+        for (int i = 0; i < num; i++) {
+            const int w = sup[2 * i + 1] - sup[2 * i];
+            int c = -1;
+            if (w <= maxR && maxR >= 2) c = w <= 2 ? 0 : w <= 4 ? 1 : w <= 8 ? 2 : 3;
+            if (c == cls) order[q++] = i, n++;
+        }
+        if (cls < 0) *nWide = n;
+        else nNarrow[cls] = n;
+    }
+}
+
 float *cwtObj_getFreBandArr(CWTObj o) { return o ? o->freBandArr : NULL; }
 int *cwtObj_getBinBandArr(CWTObj o) { return o ? o->binBandArr : NULL; }
 
@@ -604,7 +648,8 @@ static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *
         st = afxk_cwt_small(&o->dims, o->dTw, dataArr ? o->dX : NULL, 0, 1, isDet ? o->dBankDetN : o->dBankN,
                             o->num, isDet, o->dXt, dRe, dIm, o->stream);
     else if (st == AFX_OK)
-        st = afxk_cwt_inverse(&o->dims, o->dTw, o->dXt, dBank, o->num, isDet, 1, o->dB, dRe, dIm, o->stream);
+        st = afxk_cwt_inverse(&o->dims, o->dTw, o->dXt, dBank, o->num, isDet, 1, o->dB, dRe, dIm,
+                              AFX_CWT_WIDE | AFX_CWT_NARROW, o->stream);
     if (st == AFX_OK && re) st = afxdev_d2h(re, dRe, outB, o->stream);
     if (st == AFX_OK && im) st = afxdev_d2h(im, dIm, outB, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
@@ -687,8 +732,13 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
             const int n = nf - c < group ? nf - c : group;
             st = afxk_cwt_inverse(&o->dims, o->dTw, o->dGXt + 2 * L * (size_t)c, dBank, o->num, isDet, n,
                                   o->dGB, dReal + (size_t)(c0 + c) * plane, dImag + (size_t)(c0 + c) * plane,
-                                  hipStream);
+                                  AFX_CWT_WIDE, hipStream);
         }
+        /* the narrow-band scales have no intermediate: all chunks of the forward batch at once */
+        if (st == AFX_OK)
+            st = afxk_cwt_inverse(&o->dims, o->dTw, o->dGXt, dBank, o->num, isDet, nf, NULL,
+                                  dReal + (size_t)c0 * plane, dImag + (size_t)c0 * plane, AFX_CWT_NARROW,
+                                  hipStream);
     }
     o->lastStream = hipStream;
     o->lastUsed = 1;
@@ -786,6 +836,7 @@ void cwtObj_free(CWTObj o) {
     afxdev_free(o->dBankN);
     afxdev_free(o->dBankDetN);
     afxdev_free(o->dSupport);
+    afxdev_free(o->dOrder);
     afxdev_free(o->dGA);
     afxdev_free(o->dGXt);
     afxdev_free(o->dGB);

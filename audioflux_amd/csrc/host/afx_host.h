@@ -68,6 +68,13 @@ struct OpaqueCWT;
 int afx_cwt_create_custom(struct OpaqueCWT **cwtObj, int num, int radix2Exp, int samplate, int isPadding,
                           const float *bank, const float *fre, const int *bin, const char *who);
 long long afx_cwt_fft_length(int radix2Exp, int isPadding);
+/* narrow-band scale planning of the register-FFT inverse (host-only, exported for tests):
+ * rows k2 of the transposed spectrum (k = k1 + 2^r1 k2) that hold each wavelet's non-zeros, and
+ * the execution order wide scales | classes R = 2, 4, 8, 16 (see afx_device.h) */
+void afx_cwt_support_host(const float *bank, int num, long long fftLength, int r1, int *sup);
+void afx_cwt_classify_host(const int *sup, int num, int maxR, int *order, int *nWide, int nNarrow[4]);
+/* widest narrow-band class used unless AFX_CWT_NARROW_MAX says otherwise (0: off) */
+#define AFX_CWT_NARROW_MAX_DEFAULT 0
 
 /* ---- afx_bandplan.c ----------------------------------------------------- */
 struct AfxBandPlanTag; /* AfxBandPlan is declared in afx_device.h */

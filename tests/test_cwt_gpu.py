@@ -46,3 +46,36 @@ def test_cwt_linearity_and_reuse():
     assert_parity(ws, wa - 3 * wb, 2e-6, "linearity")
     # short input is zero-padded by the wrapper, long input truncated (utils/util.py:98-111)
     assert o.cwt(a[:1000]).shape == (30, 2048) and o.cwt(np.concatenate([a, b])).shape == (30, 2048)
+
+
+@pytest.mark.parametrize("max_r", [2, 4, 8, 16])
+def test_cwt_narrow_band_scales_equal_two_pass(max_r, monkeypatch):
+    """L = 2^17 (BASELINE cfg 4): scales whose wavelet occupies <= max_r rows of the transposed
+    spectrum skip the row pass (k_cwt_inv_cols256_nb); every scale must agree with the two-pass
+    result, for the transform and for its time derivative, at 1e-5 of the scale's own peak."""
+    import torch
+
+    def build(mr):
+        monkeypatch.setenv("AFX_CWT_NARROW_MAX", str(mr))
+        o = af.CWT(num=84, radix2_exp=16, samplate=44100, low_fre=32.703, bin_per_octave=12,
+                   wavelet_type=af.WaveletContinueType.MORLET,
+                   scale_type=af.SpectralFilterBankScaleType.OCTAVE, is_padding=True)
+        o.enable_det(True)
+        return o
+
+    two_pass, narrow = build(0), build(max_r)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = 0.1 * torch.randn((3, 1 << 16), device="cuda", generator=g)
+    x[1] += torch.sin(torch.arange(1 << 16, device="cuda") * (2 * np.pi * 55.0 / 44100))  # energy in a narrow scale
+    for det in (False, True):
+        r0, i0 = two_pass.cwt_device(x, det=det)
+        r1, i1 = narrow.cwt_device(x, det=det)
+        torch.cuda.synchronize()
+        w0, w1 = torch.complex(r0, i0), torch.complex(r1, i1)
+        peak = w0.abs().amax(dim=2, keepdim=True)
+        err = ((w1 - w0).abs() / peak).amax(dim=2)  # [chunk, scale]
+        assert float(err.max()) <= 1e-5, (det, max_r, err.max(dim=0).values.cpu().numpy())
+    # the one-chunk host entry point takes the same plan
+    h0 = two_pass.cwt(x[1].cpu().numpy())
+    h1 = narrow.cwt(x[1].cpu().numpy())
+    assert_parity(h1, h0, TOL, f"host entry, max_r {max_r}")
