@@ -75,6 +75,7 @@ struct CwtGeom {
     const float2 *fastTw;
     const int *support;  // [num][2] non-zero k2 range per scale, or NULL
     const int *order;    // [num] scale handled by blockIdx.y (+ list base), or NULL = identity
+    const int *orderLo;  // [num][2] (scale, first support row) in the same order, narrow-band kernels
     int num;           // scales (chunk stride of the per-scale buffers = num * L)
 };
 
@@ -211,7 +212,7 @@ __device__ __forceinline__ v2 ld2(const float2 *p) {
     return r;
 }
 
-constexpr int ROWS_PER_WAVE = 4;
+constexpr int ROWS_PER_WAVE = 4;  // 1 and 2 measure the same (profiles/r01_cwt_narrowband.txt)
 
 __global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2 *__restrict__ Xt,
                                                          const float *__restrict__ bankT, int isDet,
@@ -325,14 +326,16 @@ __global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2
 
 // second half of the 256-point column transform, shared by the two column kernels: r[a] holds
 // B[16 a + g][c] of thread (c, g); radix-16, twiddle, exchange, radix-16, conj, 1/L, crop, store
-__device__ __forceinline__ void cols256_finish(const CwtGeom &g, v2 (&r)[16], v2 *ex, int c, int gq, int c0,
-                                               float *__restrict__ oRe, float *__restrict__ oIm) {
-    constexpr int L2 = 512;
-    constexpr long long L = 1LL << 17;
-    float2 t3[16];
+__device__ __forceinline__ void cols256_twiddles(const CwtGeom &g, int gq, float2 (&t3)[16]) {
 #pragma unroll
     for (int p = 1; p < 16; ++p) t3[p] = g.fastTw[8 * 64 + 8 * 8 + 16 * p + gq];  // W_256^(g p)
-    __builtin_amdgcn_sched_barrier(0);  // all loads in flight before the first butterfly
+}
+
+__device__ __forceinline__ void cols256_finish(const CwtGeom &g, v2 (&r)[16], const float2 (&t3)[16], v2 *ex,
+                                               int c, int gq, int c0, float *__restrict__ oRe,
+                                               float *__restrict__ oIm) {
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
     dft16(r);  // r[rev4(p)] = sum_a B[16 a + g] W_16^(a p)
 #pragma unroll
     for (int p = 1; p < 16; ++p) r[rev4(p)] = cmul(r[rev4(p)], v2{t3[p].x, t3[p].y});
@@ -344,14 +347,16 @@ __device__ __forceinline__ void cols256_finish(const CwtGeom &g, v2 (&r)[16], v2
     for (int gg = 0; gg < 16; ++gg) r[gg] = ex[(p * 16 + gg) * 16 + c];
     dft16(r);  // r[rev4(q)] = Y[m2 = p + 16 q]
     const float invL = 1.f / (float)L;
-    const long long D = g.dataLength, P = g.pad;
+    // time sample n = (p + 16 q) 512 + column; kept if pad <= n < pad + dataLength (one unsigned
+    // compare on n - pad: every quantity is below 2^17)
+    const int n0 = p * L2 + c0 + c - g.pad;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const long long n = (long long)(p + 16 * q) * L2 + c0 + c;
-        if (n >= P && n < P + D) {  // conj, 1/L, crop (cwt_algorithm.c:449-458)
+        const int n = n0 + q * (16 * L2);
+        if ((unsigned)n < (unsigned)g.dataLength) {  // conj, 1/L, crop (cwt_algorithm.c:449-458)
             const v2 a = r[rev4(q)];
-            oRe[n - P] = a.x * invL;
-            oIm[n - P] = -a.y * invL;
+            oRe[n] = a.x * invL;
+            oIm[n] = -a.y * invL;
         }
     }
 }
@@ -367,10 +372,13 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2
     const int j = g.order ? g.order[blockIdx.y] : (int)blockIdx.y;
     const float2 *in = B + ((long long)blockIdx.z * g.num + j) * L + c0 + c;
     v2 r[16];
+    float2 t3[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) r[a] = ld2(in + (long long)(16 * a + gq) * L2);
+    cols256_twiddles(g, gq, t3);
+    __builtin_amdgcn_sched_barrier(0);  // all 31 loads in flight before the first butterfly
     const long long D = g.dataLength;
-    cols256_finish(g, r, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
+    cols256_finish(g, r, t3, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
                    outIm + ((long long)blockIdx.z * g.num + j) * D);
 }
 
@@ -389,51 +397,62 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
                                                             int listBase, float *__restrict__ outRe,
                                                             float *__restrict__ outIm) {
     __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]
-    __shared__ v2 zs[256 * R];       // [k1][k2 - lo]
+    static_assert(256 * R <= 16 * 16 * 16, "the staged products share the exchange buffer");
+    v2 *zs = ex;                       // [k1][k2 - lo], consumed before the exchange starts
+    __shared__ v2 tlo[256], thi[512];  // W_L^m (m < 256), W_L^(256 q) (q < 512)
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
     const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
     const int c0 = blockIdx.x * 16, m1 = c0 + c;
-    const int j = g.order[listBase + blockIdx.y];
-    int lo = g.support[2 * j];
+    // (scale, first row of its support): one dependent read ahead of the operand loads
+    const int2 jl = reinterpret_cast<const int2 *>(g.orderLo)[listBase + blockIdx.y];
+    const int j = jl.x;
+    int lo = jl.y;
     if (lo + R > L2) lo = L2 - R;
     const float2 *xc = Xt + (long long)blockIdx.z * L + lo;
     const float *bankj = bankT + (long long)j * L + lo;
+    float2 xv[R], t3[16];
+    float bw[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int idx = tid + 256 * i, k2 = idx & (R - 1), k1 = idx / R;
-        const float2 xv = xc[k1 * L2 + k2];
-        const float b = bankj[k1 * L2 + k2];
-        // conj(X * wavelet) (cwt_algorithm.c:428-435): IFFT through a forward FFT
-        zs[idx] = isDet ? v2{-b * xv.y, -(b * xv.x)} : v2{b * xv.x, -(b * xv.y)};
+        xv[i] = xc[k1 * L2 + k2];
+        bw[i] = bankj[k1 * L2 + k2];
     }
+    // twiddles from two small LDS tables instead of scattered gathers over the 512 KB table
+    // (each would touch 64 cache lines per wave): W_L^m = W_L^(m & 255) * W_L^(256 (m >> 8))
+    const float2 ta = g.tw[256 * tid], tb = g.tw[tid];  // W_L^(256 i) = W_512^i; i >= 256: -W_512^(i - 256)
+    cols256_twiddles(g, gq, t3);
+    __builtin_amdgcn_sched_barrier(0);  // every global read of the workgroup is in flight from here
+    thi[tid] = v2{ta.x, ta.y};
+    thi[tid + 256] = v2{-ta.x, -ta.y};
+    tlo[tid] = v2{tb.x, tb.y};
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        // conj(X * wavelet) (cwt_algorithm.c:428-435): IFFT through a forward FFT
+        zs[tid + 256 * i] = isDet ? v2{-bw[i] * xv[i].y, -(bw[i] * xv[i].x)} : v2{bw[i] * xv[i].x, -(bw[i] * xv[i].y)};
+    }
+    __syncthreads();
     v2 w5[R], wl[16];
 #pragma unroll
-    for (int k2 = 0; k2 < R; ++k2) {  // W_512^q = W_L^(256 q), q = (lo + k2) m1 mod 512
-        const int q = ((lo + k2) * m1) & (L2 - 1);
-        const float2 t = g.tw[256 * (q & 255)];
-        const float sgn = (q & 256) ? -1.f : 1.f;
-        w5[k2] = v2{t.x * sgn, t.y * sgn};
-    }
+    for (int k2 = 0; k2 < R; ++k2) w5[k2] = thi[((lo + k2) * m1) & (L2 - 1)];  // W_512^((lo + k2) m1)
 #pragma unroll
     for (int a = 0; a < 16; ++a) {  // four-step twiddle W_L^(m1 k1), m1 k1 < L
         const int m = m1 * (16 * a + gq);
-        const float2 t = g.tw[m & 65535];
-        const float sgn = (m >> 16) & 1 ? -1.f : 1.f;
-        wl[a] = v2{t.x * sgn, t.y * sgn};
+        wl[a] = cmul(tlo[m & 255], thi[m >> 8]);
     }
-    __syncthreads();
     v2 r[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         const v2 *z = zs + (16 * a + gq) * R;
         v2 acc = cmul(z[0], w5[0]);
 #pragma unroll
-        for (int k2 = 1; k2 < R; ++k2) acc += cmul(z[k2], w5[k2]);
+        for (int k2 = 1; k2 < R; ++k2) acc = cfma(z[k2], w5[k2], acc);
         r[a] = cmul(acc, wl[a]);
     }
+    __syncthreads();  // every thread is done with zs before the exchange buffer is written
     const long long D = g.dataLength;
-    cols256_finish(g, r, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
+    cols256_finish(g, r, t3, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
                    outIm + ((long long)blockIdx.z * g.num + j) * D);
 }
 
@@ -504,6 +523,7 @@ CwtGeom make_geom(const AfxCwtPlanDims *d, const float *tw) {
     g.fastTw = reinterpret_cast<const float2 *>(d->fastTw);
     g.support = d->support;
     g.order = d->order;
+    g.orderLo = d->orderLo;
     g.num = 0;
     return g;
 }

@@ -184,6 +184,7 @@ typedef struct {
      * order: device [num] scale indices, the nWide wide scales first, then the scales of the
      * classes R = 2, 4, 8, 16 (nNarrow[0..3] of them); NULL: every scale takes both passes */
     const int *order;
+    const int *orderLo;  /* device [num][2]: (order[i], support[2 order[i]]) -- one read per workgroup */
     int nWide;
     int nNarrow[4];
 } AfxCwtPlanDims;

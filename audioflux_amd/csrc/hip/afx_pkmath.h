@@ -45,6 +45,15 @@ __device__ __forceinline__ v2 cmul(v2 a, v2 b) {
         : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-ay by + ., ay bx + .)
     return r;
 }
+// complex multiply-accumulate c + a * b: two packed fmas
+__device__ __forceinline__ v2 cfma(v2 a, v2 b, v2 c) {
+    v2 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+        : "=v"(t) : "v"(a), "v"(b), "v"(c));  // (ax bx + cx, ax by + cy)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-ay by + ., ay bx + .)
+    return r;
+}
 // w * (-i d):  real = w.x d.y + w.y d.x,  imag = w.y d.y - w.x d.x
 __device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
     v2 t, r;

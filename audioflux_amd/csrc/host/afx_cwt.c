@@ -549,10 +549,26 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
                 if (en && atoi(en) == 0) maxR = 0;
                 if (order && st == AFX_OK && maxR >= 2) {
                     afx_cwt_classify_host(sup, num, maxR, order, &o->dims.nWide, o->dims.nNarrow);
-                    st = afxdev_malloc((void **)&o->dOrder, sizeof(int) * (size_t)num);
-                    if (st == AFX_OK) st = afxdev_h2d(o->dOrder, order, sizeof(int) * (size_t)num, o->stream);
+                    /* device image: order[num] followed by the (scale, first support row) pairs */
+                    int *img = (int *)malloc(sizeof(int) * 3 * (size_t)num);
+                    if (!img) st = AFX_ERR_NOMEM;
+                    for (int i = 0; i < num && img; i++) {
+                        img[i] = order[i];
+                        img[num + 2 * i] = order[i];
+                        img[num + 2 * i + 1] = sup[2 * order[i]];
+                    }
+                    /* the pairs are read as int2: keep them 8-byte aligned */
+                    const size_t pairOff = ((size_t)num + 1) & ~(size_t)1;
+                    if (st == AFX_OK) st = afxdev_malloc((void **)&o->dOrder, sizeof(int) * (pairOff + 2 * (size_t)num));
+                    if (st == AFX_OK) st = afxdev_h2d(o->dOrder, img, sizeof(int) * (size_t)num, o->stream);
+                    if (st == AFX_OK)
+                        st = afxdev_h2d(o->dOrder + pairOff, img + num, sizeof(int) * 2 * (size_t)num, o->stream);
                     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
-                    if (st == AFX_OK) o->dims.order = o->dOrder;
+                    if (st == AFX_OK) {
+                        o->dims.order = o->dOrder;
+                        o->dims.orderLo = o->dOrder + pairOff;
+                    }
+                    free(img);
                 }
                 free(order);
                 free(sup);
@@ -705,25 +721,29 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
         return st;
     }
     /* Forward transforms of up to 32 chunks share one launch (a single chunk is only
-     * 2^r2/tileCols workgroups).  The inverse runs `group` chunks per launch; its per-scale
-     * intermediate is group * num * L complex (88 MB per chunk at num 84, L 2^17), and with
-     * group = 1 it is re-read while still resident in the 256 MB memory-side cache
-     * (measured: column pass 22.6 us per chunk at group 1, 32 us at group 4). */
-    /* ... i.e. about 88 MB of intermediate per launch pair whatever the transform length:
-     * one chunk at L = 2^17, 16 at the wrapper's default L = 2^13 (otherwise launch-bound) */
-    int group = (int)(96.0e6 / ((double)o->num * L * 8.0));
+     * 2^r2/tileCols workgroups).  The two-pass part of the inverse runs `group` chunks per launch:
+     * its intermediate is group * nTwoPass * L complex (1 MB per scale and chunk at L 2^17; the
+     * buffer is indexed by scale, so it is sized for all of them), and it is re-read while still
+     * resident in the 256 MB memory-side cache when about 96 MB are in flight per launch pair
+     * whatever the transform length: cfg 4 with all 84 scales on two passes: 1 chunk (column
+     * pass 22.6 us per chunk at group 1, 32 us at group 4); with the 40 wide scales the
+     * narrow-band plan leaves: 2 chunks (+9 %, profiles/r01_cwt_narrowband.txt); 16 chunks at
+     * the wrapper's default L = 2^13 (otherwise launch-bound). */
+    const int nTwoPass = o->dims.order ? o->dims.nWide : o->num; /* scales that write the intermediate */
+    int group = nTwoPass > 0 ? (int)(96.0e6 / ((double)nTwoPass * L * 8.0)) : chunks;
     if (group < 1) group = 1;
     {
         const char *e = getenv("AFX_CWT_GROUP");
         if (e && atoi(e) > 0) group = atoi(e);
-        while (group > 1 && (double)group * o->num * L * 8.0 > 4.0e9) group /= 2;
+        while (group > 1 && nTwoPass > 0 && (double)group * o->num * L * 8.0 > 4.0e9) group /= 2;
         if (group > chunks) group = chunks;
     }
     int fwdBatch = group > 32 ? group : 32;
     if (fwdBatch > chunks) fwdBatch = chunks;
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGA, &o->capGA, sizeof(float) * 2 * L * fwdBatch);
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGXt, &o->capGXt, sizeof(float) * 2 * L * fwdBatch);
-    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGB, &o->capGB, sizeof(float) * 2 * L * group * o->num);
+    if (st == AFX_OK && nTwoPass > 0)
+        st = afxdev_reserve((void **)&o->dGB, &o->capGB, sizeof(float) * 2 * L * group * o->num);
     for (int c0 = 0; c0 < chunks && st == AFX_OK; c0 += fwdBatch) {
         const int nf = chunks - c0 < fwdBatch ? chunks - c0 : fwdBatch;
         st = afxk_cwt_forward(&o->dims, o->dTw, dData + (long long)c0 * chunkStride, chunkStride, nf,

@@ -73,8 +73,9 @@ long long afx_cwt_fft_length(int radix2Exp, int isPadding);
  * the execution order wide scales | classes R = 2, 4, 8, 16 (see afx_device.h) */
 void afx_cwt_support_host(const float *bank, int num, long long fftLength, int r1, int *sup);
 void afx_cwt_classify_host(const int *sup, int num, int maxR, int *order, int *nWide, int nNarrow[4]);
-/* widest narrow-band class used unless AFX_CWT_NARROW_MAX says otherwise (0: off) */
-#define AFX_CWT_NARROW_MAX_DEFAULT 0
+/* widest narrow-band class used unless AFX_CWT_NARROW_MAX says otherwise (0: every scale takes
+ * both passes); 16 measured best on BASELINE cfg 4 (profiles/r01_cwt_narrowband.txt) */
+#define AFX_CWT_NARROW_MAX_DEFAULT 16
 
 /* ---- afx_bandplan.c ----------------------------------------------------- */
 struct AfxBandPlanTag; /* AfxBandPlan is declared in afx_device.h */
