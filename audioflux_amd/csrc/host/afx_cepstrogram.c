@@ -14,6 +14,7 @@ struct OpaqueCepstrogram {
     WindowType windowType;
     void *stream;
     float *dWindow, *dTwiddle;
+    float *dFastTab; /* twiddle tables of the N = 2048 wave kernel (NULL for other sizes) */
     float *dX, *dOut, *dSpec; /* grow-only scratch */
     size_t capX, capOut, capSpec;
     int cachedTime; /* frames of the spectrum kept in dSpec (for cepstrogram2) */
@@ -51,6 +52,17 @@ int cepstrogramObj_new(CepstrogramObj *cepstrogramObj, int radix2Exp, WindowType
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTwiddle, nb < 8 ? 8 : nb);
     if (st == AFX_OK) st = afxdev_h2d(o->dWindow, w, nb, o->stream);
     if (st == AFX_OK) st = afxdev_h2d(o->dTwiddle, tw, nb < 8 ? 8 : nb, o->stream);
+    if (st == AFX_OK && o->fftLength == 2048) {
+        float *ft = (float *)malloc(sizeof(float) * AFX_CEPSTROGRAM_FASTTAB_FLOATS);
+        if (!ft) st = AFX_ERR_NOMEM;
+        if (st == AFX_OK) {
+            afxk_cepstrogram_fast_tables(ft);
+            st = afxdev_malloc((void **)&o->dFastTab, sizeof(float) * AFX_CEPSTROGRAM_FASTTAB_FLOATS);
+        }
+        if (st == AFX_OK) st = afxdev_h2d(o->dFastTab, ft, sizeof(float) * AFX_CEPSTROGRAM_FASTTAB_FLOATS, o->stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(o->stream); /* ft is freed below */
+        free(ft);
+    }
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     free(w);
     free(tw);
@@ -93,6 +105,7 @@ static void run(CepstrogramObj o, int cepNum, const float *hData, int dataLength
     a.cepNum = cepNum;
     a.window = o->dWindow;
     a.twiddle = o->dTwiddle;
+    a.fastTab = o->dFastTab;
     a.specRe = o->dSpec;
     a.specIm = o->dSpec ? o->dSpec + (size_t)T * N : NULL;
     a.out1 = m1 ? o->dOut : NULL;
@@ -147,6 +160,7 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj o, int cepNum, const fl
     a.cepNum = cepNum < 0 ? 0 : cepNum;
     a.window = o->dWindow;
     a.twiddle = o->dTwiddle;
+    a.fastTab = o->dFastTab;
     a.out1 = dOut1;
     a.out2 = dOut2;
     a.out3 = dOut3;
@@ -216,6 +230,7 @@ void cepstrogramObj_free(CepstrogramObj o) {
     if (o->stream) afxdev_stream_sync(o->stream);
     afxdev_free(o->dWindow);
     afxdev_free(o->dTwiddle);
+    afxdev_free(o->dFastTab);
     afxdev_free(o->dX);
     afxdev_free(o->dOut);
     afxdev_free(o->dSpec);
