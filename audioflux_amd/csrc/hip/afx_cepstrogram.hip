@@ -93,28 +93,73 @@ __global__ void k_cepstrogram(AfxCepstrogramArgs a) {
     }
 }
 
-// ---- N = 2048: one wave per frame, four wave-level real transforms --------------------------
-// Every sequence of the chain is real, so each transform is the 1024-point complex transform of
-// afx_wavefft2048.h (registers + two LDS exchanges, no workgroup barrier) instead of a 2048-point
-// complex radix-2 transform in LDS with a barrier per stage pair:
-//   S = rfft(x w)                    -> L[k] = ln max(|S[k]|^2, 1e-16), k <= 1024
-//   L is real and even (L[2048 - k] = L[k]), so IFFT(L) = FFT(L) / N is real and even:
-//   c = Re rfft(L_even) / N          -> out1 = c[0..1024]
+// ---- N = 2048 and N = 4096: one wave per frame, wave-level real transforms -----------------
+// Every sequence of the chain is real, so each transform is built from the 1024-point complex
+// transform of afx_wavefft2048.h (registers + two LDS exchanges, no workgroup barrier) instead of
+// an N-point complex radix-2 transform in LDS with a barrier per stage pair:
+//   S = rfft(x w)                    -> L[k] = ln max(|S[k]|^2, 1e-16), k <= N/2
+//   L is real and even (L[N - k] = L[k]), so IFFT(L) = FFT(L) / N is real and even:
+//   c = Re rfft(L_even) / N          -> out1 = c[0..N/2]
 //   l, d = the two lifter sequences of c (cepstrogram_algorithm.c:258-263, :282-283; c[m] for
-//          m > 1024 is c[2048 - m]: the reference's own value there differs by rounding only)
+//          m > N/2 is c[N - m]: the reference's own value there differs by rounding only)
 //   out2 = Re rfft(l), out3 = Re rfft(d)
-// Between the transforms the spectrum / cepstrum goes through a 1025-float natural-order row in
-// the wave's exchange buffer.  HBM per frame: 4 hop in (frames overlap in L2), 12 (N/2 + 1) out.
-constexpr int CW = 8;  // waves per workgroup (2 per SIMD: the 20 KB of tables are shared)
+// For cepNum <= DIRECT_Q (the wrapper's default is 4) the lifter transforms are evaluated in
+// closed form instead: l = c on {0..q} and mirrored onto {N-q..N-1}, d = c on {q+1..N-q}, so
+//   out2[k] = c[0] + 2 sum_{m=1..q} c[m] cos(2 pi k m / N)
+//   out3[k] = L[k] - out2[k] + c[q] cos(2 pi k q / N)      (index N-q is in both sequences;
+//                                                            q = 0: out3 = L - c[0])
+// with cos(m theta_k) by rotating W_N^k (an error of ~m ulp; q <= 16) -- two transforms per frame.
+// Between the transforms the spectrum / cepstrum goes through an (N/2 + 1)-float natural-order
+// row in the wave's exchange buffer.  HBM per frame: 4 hop in (frames overlap in L2), 12 (N/2 + 1) out.
+// N = 4096 splits every transform into the 2048-point real transforms E, O of the even / odd
+// samples: X[k] = E[k] + W_4096^k O[k], X[2048 - k] = conj(E[k] - W_4096^k O[k]); it has the
+// closed-form lifters only (larger cepNum takes the size-generic kernel).
+constexpr int CW = 8;         // waves per workgroup, N = 2048 (2 per SIMD: the tables are shared)
+constexpr int CW4 = 8;        // N = 4096
+constexpr int DIRECT_Q = 16;  // largest cepNum of the closed-form lifters
 
 struct CepWArgs {
     const float *x;
     long long clipStride, totalFrames;
     int framesPerClip, hop, framesPerWave, aligned, cepNum;
-    const float2 *win2;  // [1024] (w[2n], w[2n+1])
-    const float2 *tab;   // afxw tables: tw1 | tw2 | tw3
+    const float *win;    // [N]
+    const float2 *tab;   // afxw tables: tw1 | tw2 | tw3 ( | W_4096^k, k <= 1024, for N = 4096)
     float *out1, *out2, *out3;
 };
+
+__device__ __forceinline__ float log_power(v2 z) {
+    float p = z.x * z.x + z.y * z.y;
+    if (p < 1e-16f) p = 1e-16f;  // cepstrogram_algorithm.c:219-229
+    return logf(p);
+}
+
+// closed-form lifter outputs of NB bins: w[i] = W_N^k of the bin, Lk[i] its log power;
+// c = the cepstrum row in LDS (c[0..q] are read, the same address in every lane)
+template <int NB>
+__device__ __forceinline__ void lifters_direct(const float *c, int q, const v2 (&w)[NB], const float (&Lk)[NB],
+                                               float (&env)[NB], float (&det)[NB]) {
+    v2 z[NB];
+    float acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        z[i] = v2{1.f, 0.f};
+        acc[i] = 0.f;
+    }
+    for (int m = 1; m <= q; ++m) {
+        const float cm = c[m];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            z[i] = cmul(z[i], w[i]);  // W_N^(k m): real part cos(2 pi k m / N)
+            acc[i] = fmaf(cm, z[i].x, acc[i]);
+        }
+    }
+    const float c0 = c[0], cq = q >= 1 ? c[q] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        env[i] = c0 + 2.f * acc[i];
+        det[i] = Lk[i] - env[i] + cq * z[i].x;
+    }
+}
 
 __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -124,8 +169,11 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v2 *ex = tabTw + afxw::TAB_F2 + wave * afxw::EX_F2;
     float *row = reinterpret_cast<float *>(ex);  // natural-order row between transforms (1025 floats)
-    for (int i = threadIdx.x; i < 1024; i += CW * 64) tabWin[i] = v2{a.win2[i].x, a.win2[i].y};
-    for (int i = threadIdx.x; i < afxw::TAB_F2; i += CW * 64) tabTw[i] = v2{a.tab[i].x, a.tab[i].y};
+    {
+        const float2 *win2 = reinterpret_cast<const float2 *>(a.win);
+        for (int i = threadIdx.x; i < 1024; i += CW * 64) tabWin[i] = v2{win2[i].x, win2[i].y};
+        for (int i = threadIdx.x; i < afxw::TAB_F2; i += CW * 64) tabTw[i] = v2{a.tab[i].x, a.tab[i].y};
+    }
     __syncthreads();
     const afxw::Tables tb = {tabTw, tabTw + afxw::TAB_TW1_F2, tabTw + afxw::TAB_TW1_F2 + afxw::TAB_TW2_F2};
 
@@ -149,7 +197,9 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
             for (int n1 = 0; n1 < 16; ++n1) raw[n1] = v2{px[2 * (64 * n1 + lane)], px[2 * (64 * n1 + lane) + 1]};
         }
     };
-    // spectrum values of one transform -> natural-order row; val(S[k]) for the bin itself and its partner
+    // one value per bin of a transform, in the lane layout of afxw::Bins: slot 8 s + j is bin
+    // k = lane + 64 s + 256 j, slot 16 + 8 s + j... see bin_of()
+    // -> natural-order row
     auto to_row = [&](const afxw::Bins &b, auto val) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -184,20 +234,42 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
         }
     };
     const int q = a.cepNum;
+    const bool direct = q <= DIRECT_Q;
     fetch(frame_ptr(f));
     for (; f < fEnd; ++f) {
         v2 v[16];
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = raw[n1] * tabWin[64 * n1 + lane];
-        if (f + 1 < fEnd) fetch(frame_ptr(f + 1));  // in flight under the four transforms
+        if (f + 1 < fEnd) fetch(frame_ptr(f + 1));  // in flight under the transforms
         afxw::Bins b;
-        // 1. spectrum -> log power row (cepstrogram_algorithm.c:219-229)
+        // 1. spectrum -> log power row
         afxw::rfft2048(v, ex, tb, lane, b);
-        to_row(b, [](v2 z) {
-            float p = z.x * z.x + z.y * z.y;
-            if (p < 1e-16f) p = 1e-16f;
-            return logf(p);
-        });
+        float Lk[20];  // slots: 8 s + j -> bin k, 8 s + 4 + j -> bin 1024 - k, 16..19 -> 128, 896, 384, 640
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Lk[8 * s + j] = log_power(b.x[s][j]);
+                Lk[8 * s + 4 + j] = log_power(b.y[s][j]);
+            }
+        Lk[16] = log_power(b.xc[0]);
+        Lk[17] = log_power(b.yc[0]);
+        Lk[18] = log_power(b.xc[1]);
+        Lk[19] = log_power(b.yc[1]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * s + 256 * j;
+                row[k] = Lk[8 * s + j];
+                row[1024 - k] = Lk[8 * s + 4 + j];
+            }
+        if (lane == 0) {
+            row[128] = Lk[16];
+            row[896] = Lk[17];
+            row[384] = Lk[18];
+            row[640] = Lk[19];
+        }
         wave_lds_order();
         // 2. real cepstrum: rfft of the even extension L[m] = L[2048 - m]
 #pragma unroll
@@ -209,9 +281,61 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
         afxw::rfft2048(v, ex, tb, lane, b);
         const float invN = 1.f / (float)N;
         if (a.out1) to_out(b, a.out1 + f * F, invN);
+        if (!a.out2 && !a.out3) continue;
         to_row(b, [invN](v2 z) { return z.x * invN; });
         wave_lds_order();
-        if (!a.out2 && !a.out3) continue;
+        if (direct) {
+            // 3'. closed-form lifters; W_2048^k = 2 tab3[k], W_2048^(1024 - k) = -conj(W_2048^k)
+            v2 w[20];
+            float env[20], det[20];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v2 t = tb.tw3[lane + 64 * s + 256 * j] * 2.f;
+                    w[8 * s + j] = t;
+                    w[8 * s + 4 + j] = v2{-t.x, t.y};
+                }
+            {
+                const v2 t0 = tb.tw3[128] * 2.f, t1 = tb.tw3[384] * 2.f;
+                w[16] = t0;
+                w[17] = v2{-t0.x, t0.y};
+                w[18] = t1;
+                w[19] = v2{-t1.x, t1.y};
+            }
+            lifters_direct<20>(row, q, w, Lk, env, det);
+            wave_lds_order();  // the row is read; the next frame's transform may overwrite it
+            float *o2 = a.out2 ? a.out2 + f * F : nullptr, *o3 = a.out3 ? a.out3 + f * F : nullptr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * s + 256 * j;
+                    if (o2) {
+                        o2[k] = env[8 * s + j];
+                        o2[1024 - k] = env[8 * s + 4 + j];
+                    }
+                    if (o3) {
+                        o3[k] = det[8 * s + j];
+                        o3[1024 - k] = det[8 * s + 4 + j];
+                    }
+                }
+            if (lane == 0) {
+                if (o2) {
+                    o2[128] = env[16];
+                    o2[896] = env[17];
+                    o2[384] = env[18];
+                    o2[640] = env[19];
+                }
+                if (o3) {
+                    o3[128] = det[16];
+                    o3[896] = det[17];
+                    o3[384] = det[18];
+                    o3[640] = det[19];
+                }
+            }
+            continue;
+        }
         // 3. lifters: l keeps c[0..q] and its mirror l[N-1-j] = c[j+1], j < q (:258-263);
         //    d keeps c[q+1 .. N-q] (:282-283)
         v2 vd[16];
@@ -236,10 +360,172 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
     }
 }
 
+// ---- N = 4096 ---------------------------------------------------------------------------------
+// Spectrum of a 4096-sample real sequence from the transforms of its even and odd samples.  For
+// every position of the afxw::Bins layout (k' = lane + 64 s + 256 j, its partner 1024 - k', and
+// the base-128 extras) four bins come out: k', 1024 - k', 1024 + k', 2048 - k'.  emit(slot, X)
+// receives the spectrum value itself (not conjugated); slots: 4 (4 s + j) + {0: k', 1: 2048 - k',
+// 2: 1024 - k', 3: 1024 + k'}, extras 32 + 4 i + {0..3} for k' = 128 + 256 i.
+template <typename Emit>
+__device__ __forceinline__ void combine4096(const afxw::Bins &e, const afxw::Bins &o, const v2 *w4, int lane,
+                                            Emit emit) {
+    auto position = [&](int slot, int kp, v2 xE, v2 xO, v2 yE, v2 yO) {
+        const v2 wk = w4[kp], wp = w4[1024 - kp];
+        const v2 t = cmul(xO, wk);                    // W^k' O[k']
+        const v2 u = cmul(yO, v2{wp.x, -wp.y});       // conj(W^(1024-k')) conj(O[1024-k'])
+        const v2 s0 = xE + t, d0 = xE - t, s1 = yE + u, d1 = yE - u;
+        emit(slot + 0, s0);                 // X[k']          = E + W O
+        emit(slot + 1, v2{d0.x, -d0.y});    // X[2048 - k']   = conj(E - W O)
+        emit(slot + 2, v2{s1.x, -s1.y});    // X[1024 - k']   = conj(yE + u)
+        emit(slot + 3, d1);                 // X[1024 + k']   = yE - u
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            position(4 * (4 * s + j), lane + 64 * s + 256 * j, e.x[s][j], o.x[s][j], e.y[s][j], o.y[s][j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) position(32 + 4 * i, 128 + 256 * i, e.xc[i], o.xc[i], e.yc[i], o.yc[i]);
+}
+
+// bin index of a slot of combine4096 for this lane
+__device__ __forceinline__ int bin4096(int slot, int lane) {
+    const int p = slot >> 2, r = slot & 3;
+    const int kp = p < 8 ? lane + 64 * (p >> 2) + 256 * (p & 3) : 128 + 256 * (p - 8);
+    return r == 0 ? kp : r == 1 ? 2048 - kp : r == 2 ? 1024 - kp : 1024 + kp;
+}
+
+__global__ __launch_bounds__(CW4 * 64) void k_cepstrogram_w4096(CepWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = 4096, F = 2049;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 *tabWin = reinterpret_cast<v4 *>(smem_raw);                // [1024] window quads
+    v2 *tabTw = reinterpret_cast<v2 *>(tabWin + 1024);
+    v2 *tabW4 = tabTw + afxw::TAB_F2;                             // W_4096^k, k <= 1024 (1032 slots)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2 *ex = tabW4 + 1032 + wave * afxw::EX_F2;
+    float *row = reinterpret_cast<float *>(ex);  // natural-order row between transforms (2049 floats)
+    {
+        const v4 *win4 = reinterpret_cast<const v4 *>(a.win);
+        for (int i = threadIdx.x; i < 1024; i += CW4 * 64) tabWin[i] = win4[i];
+        for (int i = threadIdx.x; i < afxw::TAB_F2 + 1025; i += CW4 * 64) tabTw[i] = v2{a.tab[i].x, a.tab[i].y};
+    }
+    __syncthreads();
+    const afxw::Tables tb = {tabTw, tabTw + afxw::TAB_TW1_F2, tabTw + afxw::TAB_TW1_F2 + afxw::TAB_TW2_F2};
+
+    const long long gw = (long long)blockIdx.x * CW4 + wave;
+    long long f = gw * a.framesPerWave, fEnd = f + a.framesPerWave;
+    if (fEnd > a.totalFrames) fEnd = a.totalFrames;
+    if (f >= fEnd) return;
+    auto frame_ptr = [&](long long fr) {
+        return a.framesPerClip > 0
+                   ? a.x + (fr / a.framesPerClip) * a.clipStride + (fr % a.framesPerClip) * (long long)a.hop
+                   : a.x + fr * (long long)a.hop;
+    };
+    const int q = a.cepNum;
+    for (; f < fEnd; ++f) {
+        const float *px = frame_ptr(f);
+        v2 ve[16], vo[16];
+        // even / odd samples of the windowed frame: lane holds x[4n .. 4n+3], n = 64 n1 + lane
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int n = 64 * n1 + lane;
+            v4 xv;
+            if (a.aligned) xv = reinterpret_cast<const v4 *>(px)[n];
+            else xv = v4{px[4 * n], px[4 * n + 1], px[4 * n + 2], px[4 * n + 3]};
+            const v4 wv = tabWin[n];
+            ve[n1] = v2{xv.x * wv.x, xv.z * wv.z};
+            vo[n1] = v2{xv.y * wv.y, xv.w * wv.w};
+        }
+        afxw::Bins be, bo;
+        // 1. spectrum -> log power (kept in registers for the closed-form details) -> row
+        afxw::rfft2048(ve, ex, tb, lane, be);
+        afxw::rfft2048(vo, ex, tb, lane, bo);
+        float Lk[40];
+        combine4096(be, bo, tabW4, lane, [&](int slot, v2 X) { Lk[slot] = log_power(X); });
+#pragma unroll
+        for (int slot = 0; slot < 32; ++slot) row[bin4096(slot, lane)] = Lk[slot];
+        if (lane == 0) {
+#pragma unroll
+            for (int slot = 32; slot < 40; ++slot) row[bin4096(slot, lane)] = Lk[slot];
+        }
+        wave_lds_order();
+        // 2. real cepstrum: transform of the even extension L[m] = L[4096 - m]
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int m = 4 * (64 * n1 + lane);
+            auto ext = [&](int i) { return row[i <= 2048 ? i : N - i]; };
+            ve[n1] = v2{ext(m), ext(m + 2)};
+            vo[n1] = v2{ext(m + 1), ext(m + 3)};
+        }
+        wave_lds_order();
+        afxw::rfft2048(ve, ex, tb, lane, be);
+        afxw::rfft2048(vo, ex, tb, lane, bo);
+        const float invN = 1.f / (float)N;
+        float ck[40];
+        combine4096(be, bo, tabW4, lane, [&](int slot, v2 X) { ck[slot] = X.x * invN; });
+        float *o1 = a.out1 ? a.out1 + f * F : nullptr;
+        // only c[0 .. q] is read back (by every lane): bins 0 .. 16 live in lanes 0 .. 16, slot 0
+        if (lane <= DIRECT_Q) row[lane] = ck[0];
+        if (o1) {
+#pragma unroll
+            for (int slot = 0; slot < 32; ++slot) o1[bin4096(slot, lane)] = ck[slot];
+            if (lane == 0) {
+#pragma unroll
+                for (int slot = 32; slot < 40; ++slot) o1[bin4096(slot, lane)] = ck[slot];
+            }
+        }
+        if (!a.out2 && !a.out3) {
+            wave_lds_order();
+            continue;
+        }
+        wave_lds_order();
+        // 3'. closed-form lifters, W_4096^k per slot: k', 2048 - k' -> -conj, 1024 -+ k' from the table
+        float *o2 = a.out2 ? a.out2 + f * F : nullptr, *o3 = a.out3 ? a.out3 + f * F : nullptr;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // two batches of 20 slots: register pressure
+            v2 w[20];
+            float lk[20], env[20], det[20];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                const int slot = i < 16 ? 16 * half + i : 32 + 4 * half + (i - 16);
+                const int p = slot >> 2, r = slot & 3;
+                const int kp = p < 8 ? lane + 64 * (p >> 2) + 256 * (p & 3) : 128 + 256 * (p - 8);
+                const v2 wk = tabW4[kp], wp = tabW4[1024 - kp];
+                // W^(2048 - k') = -conj(W^k'),  W^(1024 + k') = -conj(W^(1024 - k'))
+                w[i] = r == 0 ? wk : r == 1 ? v2{-wk.x, wk.y} : r == 2 ? wp : v2{-wp.x, wp.y};
+                lk[i] = Lk[slot];
+            }
+            lifters_direct<20>(row, q, w, lk, env, det);
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                const int slot = i < 16 ? 16 * half + i : 32 + 4 * half + (i - 16);
+                if (i < 16 || lane == 0) {
+                    const int k = bin4096(slot, lane);
+                    if (o2) o2[k] = env[i];
+                    if (o3) o3[k] = det[i];
+                }
+            }
+        }
+        wave_lds_order();  // the row is read; the next frame's transform may overwrite it
+    }
+}
+
 }  // namespace
 
-// host: twiddle tables of the N = 2048 wave kernel, tab[AFX_CEPSTROGRAM_FASTTAB_FLOATS]
-extern "C" void afxk_cepstrogram_fast_tables(float *tab) { afxw::fill_tables(tab); }
+// host: twiddle tables of the wave kernels, tab[AFX_CEPSTROGRAM_FASTTAB_FLOATS]; N = 4096 appends
+// W_4096^k, k <= 1024 (in double, rounded once)
+extern "C" void afxk_cepstrogram_fast_tables(float *tab, int fftLength) {
+    afxw::fill_tables(tab);
+    if (fftLength == 4096) {
+        const double PI = 3.14159265358979323846;
+        float *w4 = tab + 2 * afxw::TAB_F2;
+        for (int k = 0; k <= 1024; ++k) {
+            w4[2 * k] = (float)cos(-2.0 * PI * (double)k / 4096.0);
+            w4[2 * k + 1] = (float)sin(-2.0 * PI * (double)k / 4096.0);
+        }
+    }
+}
 
 extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
     if (a->radix2Exp < 1 || a->radix2Exp > 13) {
@@ -248,34 +534,47 @@ extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
     }
     if (a->timeLength <= 0) return AFX_OK;
     const int N = 1 << a->radix2Exp;
-    if (N == 2048 && a->x && !a->specRe && a->fastTab && 2 * a->cepNum + 2 < N && !getenv("AFX_NO_FUSED")) {
+    const bool wave2k = N == 2048 && 2 * a->cepNum + 2 < N, wave4k = N == 4096 && a->cepNum <= DIRECT_Q;
+    if ((wave2k || wave4k) && a->x && !a->specRe && a->fastTab && !getenv("AFX_NO_FUSED")) {
         CepWArgs w;
         w.x = a->x;
         w.clipStride = a->clipStride;
         w.totalFrames = a->timeLength;
         w.framesPerClip = a->framesPerClip;
         w.hop = a->hop;
-        // float2 loads need every frame start 8-byte aligned
-        w.aligned = ((reinterpret_cast<size_t>(a->x) & 7) == 0 && (a->hop & 1) == 0 &&
-                     (a->framesPerClip <= 0 || (a->clipStride & 1) == 0))
+        // vector loads (float2 / float4 per lane) need every frame start aligned to them
+        const int am = wave2k ? 1 : 3;
+        w.aligned = ((reinterpret_cast<size_t>(a->x) & (size_t)(4 * am + 3)) == 0 && (a->hop & am) == 0 &&
+                     (a->framesPerClip <= 0 || (a->clipStride & am) == 0))
                         ? 1
                         : 0;
         w.cepNum = a->cepNum;
-        w.win2 = reinterpret_cast<const float2 *>(a->window);
+        w.win = a->window;
         w.tab = reinterpret_cast<const float2 *>(a->fastTab);
         w.out1 = a->out1;
         w.out2 = a->out2;
         w.out3 = a->out3;
+        const int cw = wave2k ? CW : CW4;
         // enough waves for ~4 workgroups per CU, at most 16 frames per wave
-        long long fpw = w.totalFrames / (256LL * CW * 4);
+        long long fpw = w.totalFrames / (256LL * cw * 4);
         w.framesPerWave = fpw < 1 ? 1 : (fpw > 16 ? 16 : (int)fpw);
         const long long waves = (w.totalFrames + w.framesPerWave - 1) / w.framesPerWave;
-        const long long blocks = (waves + CW - 1) / CW;
-        const size_t lds = sizeof(float2) * (size_t)(1024 + afxw::TAB_F2 + CW * afxw::EX_F2);
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram_w2048),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_cepstrogram_w2048, dim3((unsigned)blocks), dim3(CW * 64), lds, (hipStream_t)stream, w);
-        AFX_LAUNCH_CHECK("k_cepstrogram_w2048");
+        const long long blocks = (waves + cw - 1) / cw;
+        if (wave2k) {
+            const size_t lds = sizeof(float2) * (size_t)(1024 + afxw::TAB_F2 + CW * afxw::EX_F2);
+            AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram_w2048),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_cepstrogram_w2048, dim3((unsigned)blocks), dim3(CW * 64), lds, (hipStream_t)stream,
+                               w);
+            AFX_LAUNCH_CHECK("k_cepstrogram_w2048");
+        } else {
+            const size_t lds = 16384 + sizeof(float2) * (size_t)(afxw::TAB_F2 + 1032 + CW4 * afxw::EX_F2);
+            AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram_w4096),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_cepstrogram_w4096, dim3((unsigned)blocks), dim3(CW4 * 64), lds, (hipStream_t)stream,
+                               w);
+            AFX_LAUNCH_CHECK("k_cepstrogram_w4096");
+        }
         return AFX_OK;
     }
     int threads = N / 2;

@@ -287,13 +287,13 @@ typedef struct {
     float *out1, *out2, *out3; /* device [T, N/2+1]; any may be NULL                */
     int framesPerClip;   /* > 0: timeLength counts the frames of several clips,      */
     long long clipStride;/*      frame f starts at x + (f / fpc) * clipStride + (f % fpc) * hop */
-    const float *fastTab;/* device tables of the N = 2048 wave kernel (afxk_cepstrogram_fast_tables),
-                          * or NULL: size-generic kernel only                           */
+    const float *fastTab;/* device tables of the wave kernels for N = 2048 / 4096
+                          * (afxk_cepstrogram_fast_tables), or NULL: size-generic kernel only */
 } AfxCepstrogramArgs;
 int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream);
-/* host: fills tab[AFX_CEPSTROGRAM_FASTTAB_FLOATS] for AfxCepstrogramArgs.fastTab */
-#define AFX_CEPSTROGRAM_FASTTAB_FLOATS (2 * (16 * 64 + 64 + 1024))
-void afxk_cepstrogram_fast_tables(float *tab);
+/* host: fills tab[AFX_CEPSTROGRAM_FASTTAB_FLOATS] for AfxCepstrogramArgs.fastTab (fftLength 2048 or 4096) */
+#define AFX_CEPSTROGRAM_FASTTAB_FLOATS (2 * (16 * 64 + 64 + 1024 + 1025))
+void afxk_cepstrogram_fast_tables(float *tab, int fftLength);
 
 /* specialised rectify + DCT for cepstra (afx_cepstrum.hip): out[rows, ccNum] =
  * pre(in)[rows, num] . dct[ccNum, num]^T */
