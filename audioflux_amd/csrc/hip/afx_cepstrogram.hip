@@ -114,9 +114,22 @@ __global__ void k_cepstrogram(AfxCepstrogramArgs a) {
 // N = 4096 splits every transform into the 2048-point real transforms E, O of the even / odd
 // samples: X[k] = E[k] + W_4096^k O[k], X[2048 - k] = conj(E[k] - W_4096^k O[k]); it has the
 // closed-form lifters only (larger cepNum takes the size-generic kernel).
-constexpr int CW = 8;         // waves per workgroup, N = 2048 (2 per SIMD: the tables are shared)
-constexpr int CW4 = 8;        // N = 4096
-constexpr int DIRECT_Q = 16;  // largest cepNum of the closed-form lifters
+#ifndef AFX_CEPS_CW   // compile-time experiment switches (tools/variants.sh, tools/gpu_ceps_ab.sh)
+#define AFX_CEPS_CW 8
+#endif
+#ifndef AFX_CEPS_CW4
+#define AFX_CEPS_CW4 8
+#endif
+#ifndef AFX_CEPS_NB
+#define AFX_CEPS_NB 20
+#endif
+#ifndef AFX_CEPS_FASTLOG
+#define AFX_CEPS_FASTLOG 0
+#endif
+constexpr int CW = AFX_CEPS_CW;    // waves per workgroup, N = 2048 (the tables are shared)
+constexpr int CW4 = AFX_CEPS_CW4;  // N = 4096
+constexpr int LNB = AFX_CEPS_NB;   // bins per batch of the closed-form lifters (divides 20)
+constexpr int DIRECT_Q = 16;       // largest cepNum of the closed-form lifters
 
 struct CepWArgs {
     const float *x;
@@ -130,7 +143,11 @@ struct CepWArgs {
 __device__ __forceinline__ float log_power(v2 z) {
     float p = z.x * z.x + z.y * z.y;
     if (p < 1e-16f) p = 1e-16f;  // cepstrogram_algorithm.c:219-229
+#if AFX_CEPS_FASTLOG
+    return __logf(p);
+#else
     return logf(p);
+#endif
 }
 
 // closed-form lifter outputs of NB bins: w[i] = W_N^k of the bin, Lk[i] its log power;
@@ -285,55 +302,36 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
         to_row(b, [invN](v2 z) { return z.x * invN; });
         wave_lds_order();
         if (direct) {
-            // 3'. closed-form lifters; W_2048^k = 2 tab3[k], W_2048^(1024 - k) = -conj(W_2048^k)
-            v2 w[20];
-            float env[20], det[20];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const v2 t = tb.tw3[lane + 64 * s + 256 * j] * 2.f;
-                    w[8 * s + j] = t;
-                    w[8 * s + 4 + j] = v2{-t.x, t.y};
-                }
-            {
-                const v2 t0 = tb.tw3[128] * 2.f, t1 = tb.tw3[384] * 2.f;
-                w[16] = t0;
-                w[17] = v2{-t0.x, t0.y};
-                w[18] = t1;
-                w[19] = v2{-t1.x, t1.y};
-            }
-            lifters_direct<20>(row, q, w, Lk, env, det);
-            wave_lds_order();  // the row is read; the next frame's transform may overwrite it
+            // 3'. closed-form lifters; W_2048^k = 2 tab3[k], W_2048^(1024 - k) = -conj(W_2048^k);
+            //     slots as in Lk[], LNB at a time (register pressure)
             float *o2 = a.out2 ? a.out2 + f * F : nullptr, *o3 = a.out3 ? a.out3 + f * F : nullptr;
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int b0 = 0; b0 < 20; b0 += LNB) {
+                v2 w[LNB];
+                float lk[LNB], env[LNB], det[LNB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = lane + 64 * s + 256 * j;
-                    if (o2) {
-                        o2[k] = env[8 * s + j];
-                        o2[1024 - k] = env[8 * s + 4 + j];
-                    }
-                    if (o3) {
-                        o3[k] = det[8 * s + j];
-                        o3[1024 - k] = det[8 * s + 4 + j];
-                    }
+                for (int i = 0; i < LNB; ++i) {
+                    const int slot = b0 + i;
+                    const int kb = slot < 16 ? lane + 64 * (slot >> 3) + 256 * (slot & 3) : 128 + 256 * ((slot - 16) >> 1);
+                    const bool partner = slot < 16 ? ((slot >> 2) & 1) : ((slot - 16) & 1);
+                    const v2 t = tb.tw3[kb] * 2.f;
+                    w[i] = partner ? v2{-t.x, t.y} : t;
+                    lk[i] = Lk[slot];
                 }
-            if (lane == 0) {
-                if (o2) {
-                    o2[128] = env[16];
-                    o2[896] = env[17];
-                    o2[384] = env[18];
-                    o2[640] = env[19];
-                }
-                if (o3) {
-                    o3[128] = det[16];
-                    o3[896] = det[17];
-                    o3[384] = det[18];
-                    o3[640] = det[19];
+                lifters_direct<LNB>(row, q, w, lk, env, det);
+#pragma unroll
+                for (int i = 0; i < LNB; ++i) {
+                    const int slot = b0 + i;
+                    const int kb = slot < 16 ? lane + 64 * (slot >> 3) + 256 * (slot & 3) : 128 + 256 * ((slot - 16) >> 1);
+                    const bool partner = slot < 16 ? ((slot >> 2) & 1) : ((slot - 16) & 1);
+                    const int k = partner ? 1024 - kb : kb;
+                    if (slot < 16 || lane == 0) {
+                        if (o2) o2[k] = env[i];
+                        if (o3) o3[k] = det[i];
+                    }
                 }
             }
+            wave_lds_order();  // the row is read; the next frame's transform may overwrite it
             continue;
         }
         // 3. lifters: l keeps c[0..q] and its mirror l[N-1-j] = c[j+1], j < q (:258-263);
@@ -483,12 +481,12 @@ __global__ __launch_bounds__(CW4 * 64) void k_cepstrogram_w4096(CepWArgs a) {
         // 3'. closed-form lifters, W_4096^k per slot: k', 2048 - k' -> -conj, 1024 -+ k' from the table
         float *o2 = a.out2 ? a.out2 + f * F : nullptr, *o3 = a.out3 ? a.out3 + f * F : nullptr;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {  // two batches of 20 slots: register pressure
-            v2 w[20];
-            float lk[20], env[20], det[20];
+        for (int b0 = 0; b0 < 40; b0 += LNB) {  // LNB slots at a time: register pressure
+            v2 w[LNB];
+            float lk[LNB], env[LNB], det[LNB];
 #pragma unroll
-            for (int i = 0; i < 20; ++i) {
-                const int slot = i < 16 ? 16 * half + i : 32 + 4 * half + (i - 16);
+            for (int i = 0; i < LNB; ++i) {
+                const int slot = b0 + i;
                 const int p = slot >> 2, r = slot & 3;
                 const int kp = p < 8 ? lane + 64 * (p >> 2) + 256 * (p & 3) : 128 + 256 * (p - 8);
                 const v2 wk = tabW4[kp], wp = tabW4[1024 - kp];
@@ -496,11 +494,11 @@ __global__ __launch_bounds__(CW4 * 64) void k_cepstrogram_w4096(CepWArgs a) {
                 w[i] = r == 0 ? wk : r == 1 ? v2{-wk.x, wk.y} : r == 2 ? wp : v2{-wp.x, wp.y};
                 lk[i] = Lk[slot];
             }
-            lifters_direct<20>(row, q, w, lk, env, det);
+            lifters_direct<LNB>(row, q, w, lk, env, det);
 #pragma unroll
-            for (int i = 0; i < 20; ++i) {
-                const int slot = i < 16 ? 16 * half + i : 32 + 4 * half + (i - 16);
-                if (i < 16 || lane == 0) {
+            for (int i = 0; i < LNB; ++i) {
+                const int slot = b0 + i;
+                if (slot < 32 || lane == 0) {
                     const int k = bin4096(slot, lane);
                     if (o2) o2[k] = env[i];
                     if (o3) o3[k] = det[i];
