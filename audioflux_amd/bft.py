@@ -89,6 +89,15 @@ class BFT:
         fn.argtypes = [c_void_p, c_float]
         fn(self._obj, float(norm_value))
 
+    def fused_plan_kind(self):
+        """Additive, diagnostic (include/afx_batch.h: bftObj_fusedPlanKind): 0 size-generic kernels,
+        1 fused n_fft-2048 kernel, 2 the same with rows cut into segments, 101 / 201 the fused
+        n_fft 1024 / 4096 kernels."""
+        fn = self._lib.bftObj_fusedPlanKind
+        fn.argtypes = [c_void_p]
+        fn.restype = c_int
+        return int(fn(self._obj))
+
     # -- transforms ---------------------------------------------------------
     def bft(self, data_arr, result_type=0):
         """data_arr (..., n) -> (..., num, time); complex64 if result_type == 0."""

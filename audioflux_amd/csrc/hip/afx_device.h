@@ -317,6 +317,12 @@ typedef struct {
     int rowB[64];
     float *wA;      /* host, [tapsA][64]                          */
     float *wB;      /* host, [tapsB][64]                          */
+    /* split plans (afx_bandplan_build_split): a slot holds a SEGMENT of a row, rowA/rowB are -1
+     * and bank row r is the sum of up to four slot results, in ascending bin order:
+     * segIdx[r] packs four slot indices, 8 bits each, lowest byte first -- lane l's A slot is
+     * l, its B slot 64 + l, 128 = none (contributes zero) */
+    int split;
+    unsigned segIdx[128];
 } AfxBandPlan;
 
 typedef struct {
@@ -337,6 +343,8 @@ int afxk_melfused_create(void **plan, int radix2Exp, const float *hWindow,
                          const AfxBandPlan *band, void *stream);
 int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 void afxk_melfused_destroy(void *plan);
+/* 0: no plan, 1: rows in whole slots, 2: split plan (row segments), +100 / +200: the n_fft 1024 / 4096 kernels */
+int afxk_melfused_kind(const void *plan);
 
 #ifdef __cplusplus
 }

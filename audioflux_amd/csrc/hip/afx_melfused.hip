@@ -164,7 +164,9 @@ __device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &k
 // SHIFT: consecutive frames of a clip overlap; with hop = 128*SHIFT samples the next
 // frame's register image is the current one moved down by SHIFT registers, so only SHIFT
 // new float2 per lane are fetched per frame (SHIFT = 0: every frame is fetched whole)
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX = false>
+// SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split): the slot results go
+// through 129 floats of the (by then dead) exchange buffer and lane l adds up rows l and l + 64
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX = false, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -194,6 +196,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     const int k1 = lane >> 2, m2 = lane & 3;
     const int startA = a.meta[lane], startB = a.meta[64 + lane];
     const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    // split plans: the (up to four) slots whose results make up rows lane and lane + 64
+    const unsigned seg0 = SPLIT ? (unsigned)a.meta[256 + lane] : 0u, seg1 = SPLIT ? (unsigned)a.meta[320 + lane] : 0u;
     const float4 *wrow = reinterpret_cast<const float4 *>(tabW + lane * WP);
     const int qm = (256 - lane) & 255;  // mirror base of q = lane (lane 0 mirrors itself)
 
@@ -537,14 +541,33 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
         }
-        if (GENERAL && !CPLX && a.postPow) {
+        if (GENERAL && !CPLX && !SPLIT && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
         }
         // ---- 5. store ---------------------------------------------------------------
         float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
-        if (rowA >= 0) orow[rowA] = accA;
-        if (rowB >= 0) orow[rowB] = accB;
+        if constexpr (SPLIT) {
+            // slot results -> LDS (behind the power row: that part of the exchange buffer is
+            // dead since stage 3), then every row is the sum of its segments in ascending bins
+            float *part = prow + PROW_F;
+            part[lane] = accA;
+            part[64 + lane] = accB;
+            if (lane == 0) part[128] = 0.f;
+            wave_lds_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned u = h ? seg1 : seg0;
+                float sum = part[u & 255u] + part[(u >> 8) & 255u];
+                sum += part[(u >> 16) & 255u];
+                sum += part[u >> 24];
+                if (GENERAL && !CPLX && a.postPow) sum = powf(sum, a.normValue);
+                if (lane + 64 * h < a.num) orow[lane + 64 * h] = sum;
+            }
+        } else {
+            if (rowA >= 0) orow[rowA] = accA;
+            if (rowB >= 0) orow[rowB] = accB;
+        }
         }  // pass
         wave_lds_sync();  // the next frame overwrites ex / prow
 
@@ -900,6 +923,7 @@ __global__ __launch_bounds__(PWAVES * 64, 2) void k_stft_mel_pair(KArgs a) {
 struct Plan {
     int variant;
     int num;
+    int split;  // slots hold row segments (AfxBandPlan.split)
     float2 *dWin2, *dTw1, *dTw2, *dTw3;
     float *dWLane;
     int *dMeta;
@@ -911,7 +935,7 @@ struct Variant {
 constexpr Variant kVariants[] = {{48, 16}, {72, 32}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX = false>
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX = false, bool SPLIT = false>
 int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -953,11 +977,11 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     static bool attrSet = false;
     if (!attrSet) {
         AFX_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX>),
+            reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX, SPLIT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet = true;
     }
-    hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX, SPLIT>), dim3((unsigned)blocks),
                        dim3(WAVES * 64), lds, (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_mel_banded");
     return AFX_OK;
@@ -1009,7 +1033,7 @@ int launch_pair(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     return AFX_OK;
 }
 
-template <int TA, int TB>
+template <int TA, int TB, bool SPLIT = false>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     // The GENERAL instantiation also serves plain |S|^2 (its map branches cost two scalar
     // compares per frame): with the hand-issued LDS reads the branch-free instantiation is
@@ -1017,19 +1041,19 @@ int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const bool shift4 = (a->hop == 512);  // hop = 128 * SHIFT
     if (a->specMap >= 3) {  // complex result: S (3) or S^2 (4), real and imaginary planes
         if (!a->outIm) return AFX_ERR_ARG;
-        return shift4 ? launch_variant<TA, TB, true, 4, true>(p, a, stream)
-                      : launch_variant<TA, TB, true, 0, true>(p, a, stream);
+        return shift4 ? launch_variant<TA, TB, true, 4, true, SPLIT>(p, a, stream)
+                      : launch_variant<TA, TB, true, 0, true, SPLIT>(p, a, stream);
     }
     // hop 512, float2-aligned frames, real results: two frames per wave
     const bool alignedFrames = ((a->clipStride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
-    if (shift4 && alignedFrames && a->dataLength >= 2048 && getenv("AFX_PAIR"))
+    if (!SPLIT && shift4 && alignedFrames && a->dataLength >= 2048 && getenv("AFX_PAIR"))
         return launch_pair<TA, TB>(p, a, stream);
     // register re-use of the overlapping frames for hop = 128 * SHIFT: N/8, N/4, N/2
     switch (a->hop) {
-        case 256: return launch_variant<TA, TB, true, 2>(p, a, stream);
-        case 512: return launch_variant<TA, TB, true, 4>(p, a, stream);
-        case 1024: return launch_variant<TA, TB, true, 8>(p, a, stream);
-        default: return launch_variant<TA, TB, true, 0>(p, a, stream);
+        case 256: return launch_variant<TA, TB, true, 2, false, SPLIT>(p, a, stream);
+        case 512: return launch_variant<TA, TB, true, 4, false, SPLIT>(p, a, stream);
+        case 1024: return launch_variant<TA, TB, true, 8, false, SPLIT>(p, a, stream);
+        default: return launch_variant<TA, TB, true, 0, false, SPLIT>(p, a, stream);
     }
 }
 
@@ -1065,6 +1089,13 @@ extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
     return -1;
 }
 
+extern "C" int afxk_melfused_kind(const void *plan) {
+    const Plan *p = static_cast<const Plan *>(plan);
+    if (!p) return 0;
+    if (p->variant >= 100) return p->variant >= 200 ? 201 : 101;
+    return p->split ? 2 : 1;
+}
+
 extern "C" void afxk_melfused_destroy(void *plan) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p) return;
@@ -1097,6 +1128,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     if (!p) return AFX_ERR_NOMEM;
     p->variant = variant;
     p->num = band->num;
+    p->split = band->split;
 
     // twiddle tables in double, rounded once
     float *tw1 = static_cast<float *>(malloc(sizeof(float) * 2 * 16 * 64));
@@ -1104,7 +1136,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     float *tw3 = static_cast<float *>(malloc(sizeof(float) * 2 * 1024));
     const int WP = TA + TB + 4;
     float *wL = static_cast<float *>(calloc((size_t)64 * WP, sizeof(float)));
-    int meta[256];
+    int meta[384];  // startA | startB | rowA | rowB | segIdx[0..63] | segIdx[64..127]
     int st = (tw1 && tw2 && tw3 && wL) ? AFX_OK : AFX_ERR_NOMEM;
     if (st == AFX_OK) {
         const double PI = 3.14159265358979323846;
@@ -1134,6 +1166,8 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
             meta[64 + l] = band->startB[l];
             meta[128 + l] = band->rowA[l];
             meta[192 + l] = band->rowB[l];
+            meta[256 + l] = (int)band->segIdx[l];
+            meta[320 + l] = (int)band->segIdx[64 + l];
         }
         st = upload(&p->dWin2, hWindow, sizeof(float) * NFFT, stream);
     }
@@ -1162,9 +1196,9 @@ extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *str
     if (p->variant >= 100) return afxk_mel1k_run(plan, a, stream);
     switch (p->variant) {
         case 0:
-            return launch<48, 16>(p, a, stream);
+            return p->split ? launch<48, 16, true>(p, a, stream) : launch<48, 16>(p, a, stream);
         case 1:
-            return launch<72, 32>(p, a, stream);
+            return p->split ? launch<72, 32, true>(p, a, stream) : launch<72, 32>(p, a, stream);
         default:
             return AFX_ERR_UNSUPPORTED;
     }

@@ -12,6 +12,8 @@ int afx_device_count(void) { return afxdev_device_count(); }
 int afx_set_device(int ordinal) { return afxdev_set_device(ordinal); }
 const char *afx_version(void) { return "audioflux_mi355x 0.1.0 gfx950"; }
 
+int bftObj_fusedPlanKind(BFTObj bft) { return bft ? afxk_melfused_kind(bft->fast) : 0; }
+
 int afx_bftXxccBatchDevice(BFTObj bft, XXCCObj xxcc, const float *dData, int batch,
                            int dataLength, long long clipStride, int ccNum,
                            CepstralRectifyType *rectifyType, float *dMel, float *dCc,

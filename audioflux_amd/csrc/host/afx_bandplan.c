@@ -170,3 +170,131 @@ int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p) {
     free(rb);
     return 0;
 }
+
+/* ---- split plans ---------------------------------------------------------------------------
+ * Banks whose rows are longer than the compiled tap variants (mel-40 / mel-64, bark and erb banks,
+ * higher sample rates) still have ~2 non-zeros per bin in total: their rows are cut into
+ * segments of at most tapsA (A slots) or tapsB (B slots) bins, every lane gets one A and one B
+ * segment, and the kernel adds a row's segment results in ascending bin order.  Segment starts are
+ * matched to LDS-bank residues like whole rows; because a segment may have to start a few bins
+ * early, the payload per slot is reduced until the padded segments fit the variant.
+ * Returns 0 and fills *p (split = 1) when the bank fits, 1 otherwise. */
+int afx_bandplan_build_split(const float *bank, int num, int F, int tapsA, int tapsB, AfxBandPlan *p) {
+    memset(p, 0, sizeof(*p));
+    if (!bank || num < 1 || num > 128 || tapsA < 4 || tapsB < 4) return 1;
+    RowBand *rb = (RowBand *)calloc((size_t)num, sizeof(RowBand));
+    RowBand *segA = (RowBand *)calloc(64, sizeof(RowBand)), *segB = (RowBand *)calloc(64, sizeof(RowBand));
+    if (!rb || !segA || !segB) {
+        free(rb);
+        free(segA);
+        free(segB);
+        return 1;
+    }
+    for (int m = 0; m < num; m++) {
+        const float *row = bank + (size_t)m * F;
+        int first = -1, last = -1;
+        for (int k = 0; k < F; k++)
+            if (row[k] != 0.f) {
+                if (first < 0) first = k;
+                last = k;
+            }
+        rb[m].row = m;
+        rb[m].start = first < 0 ? 0 : first;
+        rb[m].len = first < 0 ? 0 : last - first + 1;
+    }
+    int laneA[64], shiftA[64], laneB[64], shiftB[64];
+    /* segment lists per row: type (0 A, 1 B) and index into segA / segB, ascending bins */
+    unsigned char segType[128][4], segOf[128][4], segCnt[128];
+    int payA = tapsA, payB = tapsB, ok = 0, nA = 0, nB = 0;
+    for (int iter = 0; iter < 40 && !ok && payA >= 8 && payB >= 0; iter++) {
+        nA = nB = 0;
+        int feasible = 1;
+        for (int m = 0; m < num && feasible; m++) {
+            int rem = rb[m].len, pos = rb[m].start;
+            segCnt[m] = 0;
+            while (rem > 0) {
+                if (segCnt[m] == 4) {
+                    feasible = 0;
+                    break;
+                }
+                const int c = segCnt[m]++;
+                if (rem <= payB && nB < 64) {
+                    segB[nB].row = m, segB[nB].start = pos, segB[nB].len = rem;
+                    segType[m][c] = 1, segOf[m][c] = (unsigned char)nB++;
+                    rem = 0;
+                } else {
+                    if (nA == 64) {
+                        feasible = 0;
+                        break;
+                    }
+                    const int take = rem < payA ? rem : payA;
+                    segA[nA].row = m, segA[nA].start = pos, segA[nA].len = take;
+                    segType[m][c] = 0, segOf[m][c] = (unsigned char)nA++;
+                    pos += take, rem -= take;
+                }
+            }
+        }
+        if (!feasible) break; /* smaller payloads only make more segments */
+        int needA = nA ? assign_lanes(segA, nA, laneA, shiftA) : 1;
+        int needB = nB ? assign_lanes(segB, nB, laneB, shiftB) : 1;
+        /* the kernel reads the power row in pairs: a placement that left a start odd (the
+         * matcher's identity fallback) does not qualify */
+        for (int l = 0; l < 64; l++) {
+            if (nA && laneA[l] >= 0 && ((segA[laneA[l]].start - shiftA[l]) & 1)) needA = tapsA + 1;
+            if (nB && laneB[l] >= 0 && ((segB[laneB[l]].start - shiftB[l]) & 1)) needB = tapsB + 1;
+        }
+        if (needA <= tapsA && needB <= tapsB) ok = 1;
+        else {
+            if (needA > tapsA) payA -= 2;
+            if (needB > tapsB) payB -= 2;
+        }
+    }
+    if (ok) {
+        p->num = num;
+        p->split = 1;
+        p->tapsA = tapsA;
+        p->tapsB = tapsB;
+        p->wA = (float *)calloc((size_t)tapsA * 64, sizeof(float));
+        p->wB = (float *)calloc((size_t)tapsB * 64, sizeof(float));
+        if (!p->wA || !p->wB) {
+            afx_bandplan_free(p);
+            ok = 0;
+        }
+    }
+    if (ok) {
+        int slotOfA[64], slotOfB[64]; /* segment index -> lane */
+        for (int l = 0; l < 64; l++) {
+            p->rowA[l] = p->rowB[l] = -1;
+            p->startA[l] = 2 * (l & 31);
+            p->startB[l] = 2 * (l & 31);
+            if (nA && laneA[l] >= 0) {
+                const RowBand *g = &segA[laneA[l]];
+                for (int t = 0; t < g->len; t++)
+                    p->wA[(size_t)(t + shiftA[l]) * 64 + l] = bank[(size_t)g->row * F + g->start + t];
+                p->startA[l] = g->start - shiftA[l];
+                slotOfA[laneA[l]] = l;
+            }
+            if (nB && laneB[l] >= 0) {
+                const RowBand *g = &segB[laneB[l]];
+                for (int t = 0; t < g->len; t++)
+                    p->wB[(size_t)(t + shiftB[l]) * 64 + l] = bank[(size_t)g->row * F + g->start + t];
+                p->startB[l] = g->start - shiftB[l];
+                slotOfB[laneB[l]] = l;
+            }
+        }
+        for (int m = 0; m < 128; m++) {
+            unsigned packed = 0;
+            for (int c = 0; c < 4; c++) {
+                unsigned slot = 128;
+                if (m < num && c < segCnt[m])
+                    slot = segType[m][c] ? 64u + (unsigned)slotOfB[segOf[m][c]] : (unsigned)slotOfA[segOf[m][c]];
+                packed |= slot << (8 * c);
+            }
+            p->segIdx[m] = packed;
+        }
+    }
+    free(rb);
+    free(segA);
+    free(segB);
+    return ok ? 0 : 1;
+}

@@ -11,6 +11,7 @@
 #include "afx_objects.h"
 
 int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p);
+int afx_bandplan_build_split(const float *bank, int num, int F, int tapsA, int tapsB, AfxBandPlan *p);
 void afx_bandplan_free(AfxBandPlan *p);
 
 int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hBank) {
@@ -20,7 +21,17 @@ int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hB
     AfxBandPlan band;
     if (afx_bandplan_build(hBank, o->num, o->F, &band) != 0) return AFX_OK;
     int st = AFX_OK;
-    if (afxk_melfused_variant(o->radix2Exp, band.tapsA, band.tapsB) >= 0) {
+    int fits = afxk_melfused_variant(o->radix2Exp, band.tapsA, band.tapsB) >= 0;
+    if (!fits && o->radix2Exp == 11 && !getenv("AFX_NO_SPLIT")) {
+        /* rows longer than the compiled tap variants (mel-40 / -64, bark, erb, higher sample
+         * rates): cut them into segments, smallest variant first (afx_bandplan.c) */
+        static const int variants[2][2] = {{48, 16}, {72, 32}};
+        afx_bandplan_free(&band);
+        for (int v = 0; v < 2 && !fits; v++)
+            fits = afx_bandplan_build_split(hBank, o->num, o->F, variants[v][0], variants[v][1], &band) == 0;
+        if (!fits) return AFX_OK;
+    }
+    if (fits) {
         void *plan = NULL;
         st = afxk_melfused_create(&plan, o->radix2Exp, hWindow, &band, o->stream);
         if (st == AFX_OK) o->fast = (struct AfxMelFusedPlan *)plan;

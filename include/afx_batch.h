@@ -39,6 +39,12 @@ int afx_set_device(int ordinal);
 /* "audioflux_mi355x <version> gfx950" */
 const char *afx_version(void);
 
+/* which execution plan a BFT object (bftObj_new, or the one inside a spectrogram object) got:
+ * 0 = size-generic kernels, 1 = fused STFT -> filter-bank kernel (n_fft 2048) with whole rows per
+ * lane slot, 2 = the same kernel with rows cut into segments (banks whose rows exceed the compiled
+ * tap variants), 101 / 201 = the fused n_fft 1024 / 4096 kernels.  Diagnostic only. */
+int bftObj_fusedPlanKind(BFTObj bftObj);
+
 /* batch clips of dataLength samples, host pointers:
  * dataArr[batch*dataLength] -> mRealArr3[batch*T*num] (+ mImageArr3 when the
  * result type is complex).  Same as calling bftObj_bft per clip. */

@@ -13,7 +13,8 @@ from oracle import restate
 class Band(C.Structure):
     _fields_ = [("num", C.c_int), ("tapsA", C.c_int), ("tapsB", C.c_int),
                 ("startA", C.c_int * 64), ("startB", C.c_int * 64), ("rowA", C.c_int * 64),
-                ("rowB", C.c_int * 64), ("wA", C.POINTER(C.c_float)), ("wB", C.POINTER(C.c_float))]
+                ("rowB", C.c_int * 64), ("wA", C.POINTER(C.c_float)), ("wB", C.POINTER(C.c_float)),
+                ("split", C.c_int), ("segIdx", C.c_uint * 128)]
 
 
 @pytest.mark.parametrize("num,n,sr,style", [(128, 2048, 16000, "slaney"), (128, 2048, 32000, "slaney"),
@@ -54,3 +55,84 @@ def test_bandplan_rejects_wide_banks():
     bank = np.ones((200, 1025), np.float32)
     b = Band()
     assert lib.afx_bandplan_build(bank.ctypes.data_as(C.POINTER(C.c_float)), 200, 1025, C.byref(b)) == 1
+
+
+SCALE = {"mel": 2, "bark": 3, "erb": 4}
+
+
+def _bank(num, n, sr, scale):
+    lib = af.get_lib()
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.afx_auditory_bank.restype = None
+    lib.afx_auditory_bank.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_int, fp, fp, ip]
+    F = n // 2 + 1
+    bank = np.zeros((num, F), np.float32)
+    fre, bins = np.zeros(num + 2, np.float32), np.zeros(num + 2, np.int32)
+    lib.afx_auditory_bank(num, n, sr, SCALE[scale], 0, 0, 0.0, sr / 2, 12, bank.ctypes.data_as(fp),
+                          fre.ctypes.data_as(fp), bins.ctypes.data_as(ip))
+    return bank
+
+
+@pytest.mark.parametrize("scale,num,sr,variant", [
+    ("mel", 40, 16000, (48, 16)), ("mel", 64, 16000, (48, 16)), ("mel", 64, 44100, (48, 16)),
+    ("mel", 20, 22050, (72, 32)), ("bark", 64, 16000, (48, 16)), ("bark", 64, 44100, (72, 32)),
+    ("erb", 64, 16000, (48, 16)), ("erb", 40, 44100, (72, 32)), ("bark", 96, 48000, (72, 32)),
+])
+def test_split_plan_is_exact_and_conflict_free(scale, num, sr, variant):
+    """rows longer than the compiled tap variants are cut into segments (afx_bandplan_build_split):
+    emulating the kernel's stage 4 (slot dot products over the zero-padded power row) + stage 5
+    (a row = the sum of its <= 4 slots) reproduces bank . power, starts are even and give every
+    32-lane half-wave 32 distinct LDS bank pairs, and the smallest variant that fits is chosen"""
+    lib = af.get_lib()
+    n, F = 2048, 1025
+    bank = _bank(num, n, sr, scale)
+    fp = C.POINTER(C.c_float)
+    b = Band()
+    rc = lib.afx_bandplan_build(bank.ctypes.data_as(fp), num, F, C.byref(b))
+    assert rc == 0 and not ((b.tapsA <= 48 and b.tapsB <= 16) or (b.tapsA <= 72 and b.tapsB <= 32))
+    lib.afx_bandplan_free(C.byref(b))
+    chosen = None
+    for ta, tb in ((48, 16), (72, 32)):
+        b = Band()
+        if lib.afx_bandplan_build_split(bank.ctypes.data_as(fp), num, F, ta, tb, C.byref(b)) == 0:
+            chosen = (ta, tb)
+            break
+    assert chosen == variant
+    ta, tb = chosen
+    assert b.split == 1 and b.num == num and (b.tapsA, b.tapsB) == chosen
+    assert all(r == -1 for r in b.rowA) and all(r == -1 for r in b.rowB)
+    sA, sB = np.array(b.startA), np.array(b.startB)
+    for s, taps in ((sA, ta), (sB, tb)):
+        assert (s >= 0).all() and (s % 2 == 0).all() and (s + taps <= 1104).all()  # PROW_F of the kernel
+        for h in range(2):
+            assert len(set((s[h * 32:(h + 1) * 32] // 2) % 32)) == 32
+    wA = np.ctypeslib.as_array(b.wA, (ta, 64)).astype(np.float64)
+    wB = np.ctypeslib.as_array(b.wB, (tb, 64)).astype(np.float64)
+    power = np.zeros(1104)
+    power[:F] = np.random.default_rng(num + sr).random(F)
+    part = np.zeros(129)
+    for l in range(64):
+        part[l] = wA[:, l] @ power[sA[l]:sA[l] + ta]
+        part[64 + l] = wB[:, l] @ power[sB[l]:sB[l] + tb]
+    seg = np.array(b.segIdx, dtype=np.uint32)
+    got = np.array([sum(part[(seg[r] >> (8 * c)) & 255] for c in range(4)) for r in range(num)])
+    assert np.allclose(got, bank.astype(np.float64) @ power[:F], rtol=1e-12, atol=1e-12)
+    assert all(seg[r] == 0x80808080 for r in range(num, 128))  # rows beyond num: no slots
+    # a row's slots are listed in ascending bin order and every used slot belongs to one row
+    used = [int((seg[r] >> (8 * c)) & 255) for r in range(num) for c in range(4) if (seg[r] >> (8 * c)) & 255 != 128]
+    assert len(used) == len(set(used))
+    for r in range(num):
+        starts = [(sA[u] if u < 64 else sB[u - 64]) for u in [int((seg[r] >> (8 * c)) & 255) for c in range(4)] if u != 128]
+        assert starts == sorted(starts)
+    lib.afx_bandplan_free(C.byref(b))
+
+
+def test_split_plan_refuses_what_does_not_fit():
+    lib = af.get_lib()
+    fp = C.POINTER(C.c_float)
+    for scale, num, sr in (("mel", 13, 16000), ("bark", 128, 44100)):
+        bank = _bank(num, 2048, sr, scale)
+        for ta, tb in ((48, 16), (72, 32)):
+            b = Band()
+            assert lib.afx_bandplan_build_split(bank.ctypes.data_as(fp), num, 1025, ta, tb, C.byref(b)) == 1
+            assert b.wA is None or not b.wA  # nothing left allocated

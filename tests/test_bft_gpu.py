@@ -177,3 +177,58 @@ def test_bft_nfft4096_fused_kernel_matches_compiled_reference(scale):
                 o.set_data_norm_value(norm)
             got = o.bft(x, result_type=rt).T
             assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"scale{scale} hop{hop} rt{rt} dt{dt} norm{norm}")
+
+
+SPLIT_CASES = [  # (scale, num, samplate): banks whose rows exceed the fused kernel's tap variants
+    ("MEL", 40, 16000), ("MEL", 64, 32000), ("MEL", 20, 22050), ("BARK", 64, 16000), ("BARK", 80, 44100),
+    ("ERB", 64, 22050), ("ERB", 40, 44100),
+]
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("scale,num,sr", SPLIT_CASES)
+def test_bft_split_plan_matches_compiled_reference(scale, num, sr, monkeypatch):
+    """n_fft 2048 with long-row banks: the fused kernel runs a split plan (row segments per lane slot,
+    summed in ascending bin order) instead of falling back to the size-generic kernel -- real and
+    complex results, power / magnitude / norm exponent, the register-reuse (hop 512) and plain (hop 300)
+    instantiations; and the size-generic kernel (AFX_NO_SPLIT=1) agrees"""
+    st = getattr(af.SpectralFilterBankScaleType, scale)
+    noise = cases.noise(700 + num, sr * 2 + 77)
+    tonal = noise.copy()
+    tonal[sr // 2:sr] += (0.3 * np.sin(np.arange(sr - sr // 2) * 0.21)).astype(np.float32)
+    kw = dict(radix2_exp=11, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, scale_type=st)
+    for hop in (512, 300):
+        for rt, dt, norm in ((1, 0, 1.0), (1, 1, 1.0), (1, 0, 0.5), (0, 0, 1.0), (0, 1, 1.0)):
+            # complex results sum the spectrum itself: around a strong tone the band sums cancel to
+            # far below max|S|, and the float32 error of S (1e-7 of max|S| -- the reference's too:
+            # 2.5e-5 of the output peak for mel-20 with the tone) is all that is left; the tone
+            # therefore goes through the real-result modes only
+            x = tonal if rt == 1 else noise
+            r = ref.RefBFT(num, 11, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, window_type=1, slide_length=hop,
+                           scale_type=int(st), style_type=0, normal_type=0, data_type=dt)
+            r.set_result_type(rt)
+            if norm != 1.0:
+                r.set_norm(norm)
+            re, im = r.bft(x)
+            o = af.BFT(num, slide_length=hop, data_type=af.SpectralDataType(dt), **kw)
+            assert o.fused_plan_kind() == 2, (scale, num, sr)
+            if norm != 1.0:
+                o.set_data_norm_value(norm)
+            got = o.bft(x, result_type=rt).T
+            assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"{scale}-{num}@{sr} hop{hop} rt{rt} dt{dt} norm{norm}")
+    monkeypatch.setenv("AFX_NO_SPLIT", "1")
+    g = af.BFT(num, slide_length=512, data_type=af.SpectralDataType.POWER, **kw)
+    assert g.fused_plan_kind() == 0
+    monkeypatch.delenv("AFX_NO_SPLIT")
+    o = af.BFT(num, slide_length=512, data_type=af.SpectralDataType.POWER, **kw)
+    assert_parity(o.bft(tonal, result_type=1), g.bft(tonal, result_type=1), TOL, "split plan vs size-generic kernel")
+
+
+def test_fused_plan_kinds():
+    mk = lambda num, r, sr=16000, **k: af.BFT(num, radix2_exp=r, samplate=sr, low_fre=0.0, high_fre=sr / 2.0,
+                                              scale_type=af.SpectralFilterBankScaleType.MEL, **k)
+    assert mk(128, 11).fused_plan_kind() == 1
+    assert mk(40, 11).fused_plan_kind() == 2
+    assert mk(13, 11).fused_plan_kind() == 0   # rows of ~160 bins: more than four segments
+    assert mk(128, 10).fused_plan_kind() == 101
+    assert mk(128, 12).fused_plan_kind() == 201

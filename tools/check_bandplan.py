@@ -2,7 +2,7 @@ import ctypes as C, numpy as np
 from oracle import restate
 lib=C.CDLL('audioflux_amd/lib/libaudioflux_mi355x.so')
 class Band(C.Structure):
-    _fields_=[('num',C.c_int),('tapsA',C.c_int),('tapsB',C.c_int),('startA',C.c_int*64),('startB',C.c_int*64),('rowA',C.c_int*64),('rowB',C.c_int*64),('wA',C.POINTER(C.c_float)),('wB',C.POINTER(C.c_float))]
+    _fields_=[('num',C.c_int),('tapsA',C.c_int),('tapsB',C.c_int),('startA',C.c_int*64),('startB',C.c_int*64),('rowA',C.c_int*64),('rowB',C.c_int*64),('wA',C.POINTER(C.c_float)),('wB',C.POINTER(C.c_float)),('split',C.c_int),('segIdx',C.c_uint*128)]
 for (num,N,sr) in [(128,2048,16000),(128,2048,32000),(80,2048,16000),(64,2048,16000),(40,2048,16000),(128,2048,44100)]:
     bank,_,_=restate.mel_bank(num,N,sr,0,sr/2)
     F=N//2+1
