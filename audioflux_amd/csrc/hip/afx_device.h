@@ -343,7 +343,7 @@ int afxk_melfused_create(void **plan, int radix2Exp, const float *hWindow,
                          const AfxBandPlan *band, void *stream);
 int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 void afxk_melfused_destroy(void *plan);
-/* 0: no plan, 1: rows in whole slots, 2: split plan (row segments), +100 / +200: the n_fft 1024 / 4096 kernels */
+/* 0: no plan, 1: rows in whole slots, 2: split plan (row segments); 101: the n_fft 1024 kernel; 201 / 202: the n_fft 4096 kernel, whole rows / split plan */
 int afxk_melfused_kind(const void *plan);
 
 #ifdef __cplusplus

@@ -1077,6 +1077,7 @@ extern "C" int afxk_mel4k_variant(int tapsA, int tapsB);
 extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream);
 extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 extern "C" void afxk_mel4k_destroy(void *plan);
+extern "C" int afxk_mel4k_kind(const void *plan);
 
 extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
     if (getenv("AFX_NO_FUSED")) return -1;
@@ -1092,7 +1093,8 @@ extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
 extern "C" int afxk_melfused_kind(const void *plan) {
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return 0;
-    if (p->variant >= 100) return p->variant >= 200 ? 201 : 101;
+    if (p->variant >= 200) return afxk_mel4k_kind(plan);
+    if (p->variant >= 100) return 101;
     return p->split ? 2 : 1;
 }
 

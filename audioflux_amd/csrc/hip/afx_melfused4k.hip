@@ -75,7 +75,9 @@ __device__ __forceinline__ void split_pair_h(v2 A, v2 B, v2 w /* 0.5 W_2048^k */
     hq = v2{y.x, -y.y};
 }
 
-template <int TA, int TB, int SHIFT, bool CPLX>
+// SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split); lane l adds up rows l and
+// l + 64 from the slot results of other lanes (ds_bpermute: no LDS memory, no extra barrier)
+template <int TA, int TB, int SHIFT, bool CPLX, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -102,6 +104,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
     const int k1 = lane >> 2, m2 = lane & 3;
     const int startA = a.meta[lane], startB = a.meta[64 + lane];
     const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    // split plans: the (up to four) slots whose results make up rows lane and lane + 64
+    const unsigned seg0 = SPLIT ? (unsigned)a.meta[256 + lane] : 0u, seg1 = SPLIT ? (unsigned)a.meta[320 + lane] : 0u;
     const float4 *wrow = reinterpret_cast<const float4 *>(tabW + lane * WP);
     const int qm = (256 - lane) & 255;
 
@@ -335,13 +339,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
         }
-        if (!CPLX && a.postPow) {
+        if (!CPLX && !SPLIT && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
         }
         float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
-        if (rowA >= 0) orow[rowA] = accA;
-        if (rowB >= 0) orow[rowB] = accB;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned u = h ? seg1 : seg0;
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {  // ascending bin order
+                    const unsigned slot = (u >> (8 * c)) & 255u;  // lane | 64 (B slot) | 128 (none)
+                    const int src = (int)(slot & 63u) * 4;
+                    const float va = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(accA)));
+                    const float vb = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(accB)));
+                    sum += (slot & 128u) ? 0.f : ((slot & 64u) ? vb : va);
+                }
+                if (!CPLX && a.postPow) sum = powf(sum, a.normValue);
+                if (lane + 64 * h < a.num) orow[lane + 64 * h] = sum;
+            }
+        } else {
+            if (rowA >= 0) orow[rowA] = accA;
+            if (rowB >= 0) orow[rowB] = accB;
+        }
         }  // pass
         wave_lds_sync();
 
@@ -355,6 +377,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
 struct Plan {
     int variant;  // >= 200: this file
     int num;
+    int split;    // slots hold row segments (AfxBandPlan.split)
     float4 *dWin4;
     float2 *dTw1, *dTw2, *dTw3, *dTw4;
     float *dWLane;
@@ -369,7 +392,7 @@ static_assert(block_lds_bytes(96, 32) <= 160 * 1024 && block_lds_bytes(128, 64) 
                   block_lds_bytes(176, 8) <= 160 * 1024,
               "tables + weights + 8 wave images must fit the 160 KB LDS");
 
-template <int TA, int TB, int SHIFT, bool CPLX>
+template <int TA, int TB, int SHIFT, bool CPLX, bool SPLIT = false>
 int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -404,25 +427,25 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet = false;
     if (!attrSet) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k<TA, TB, SHIFT, CPLX>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k<TA, TB, SHIFT, CPLX, SPLIT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet = true;
     }
-    hipLaunchKernelGGL((k_stft_band_4k<TA, TB, SHIFT, CPLX>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_band_4k<TA, TB, SHIFT, CPLX, SPLIT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_band_4k");
     return AFX_OK;
 }
 
-template <int TA, int TB>
+template <int TA, int TB, bool SPLIT = false>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     if (a->specMap >= 3) {
         if (!a->outIm) return AFX_ERR_ARG;
-        return a->hop == 1024 ? launch_variant<TA, TB, 4, true>(p, a, stream)
-                              : launch_variant<TA, TB, 0, true>(p, a, stream);
+        return a->hop == 1024 ? launch_variant<TA, TB, 4, true, SPLIT>(p, a, stream)
+                              : launch_variant<TA, TB, 0, true, SPLIT>(p, a, stream);
     }
-    return a->hop == 1024 ? launch_variant<TA, TB, 4, false>(p, a, stream)
-                          : launch_variant<TA, TB, 0, false>(p, a, stream);
+    return a->hop == 1024 ? launch_variant<TA, TB, 4, false, SPLIT>(p, a, stream)
+                          : launch_variant<TA, TB, 0, false, SPLIT>(p, a, stream);
 }
 
 template <typename T>
@@ -438,6 +461,11 @@ extern "C" int afxk_mel4k_variant(int tapsA, int tapsB) {
     for (int i = 0; i < kNumVariants; ++i)
         if (tapsA <= kVariants[i].tapsA && tapsB <= kVariants[i].tapsB) return 200 + i;
     return -1;
+}
+
+extern "C" int afxk_mel4k_kind(const void *plan) {
+    const Plan *p = static_cast<const Plan *>(plan);
+    return !p ? 0 : (p->split ? 202 : 201);
 }
 
 extern "C" void afxk_mel4k_destroy(void *plan) {
@@ -462,13 +490,14 @@ extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBan
     if (!p) return AFX_ERR_NOMEM;
     p->variant = variant;
     p->num = band->num;
+    p->split = band->split;
     const int WP = TA + TB + 4;
     float *tw1 = static_cast<float *>(malloc(sizeof(float) * 2 * TAB_TW1_F2));
     float *tw2 = static_cast<float *>(malloc(sizeof(float) * 2 * TAB_TW2_F2));
     float *tw3 = static_cast<float *>(malloc(sizeof(float) * 2 * TAB_TW3_F2));
     float *tw4 = static_cast<float *>(calloc(2 * TAB_TW4_F2, sizeof(float)));
     float *wL = static_cast<float *>(calloc((size_t)64 * WP, sizeof(float)));
-    int meta[256];
+    int meta[384];  // startA | startB | rowA | rowB | segIdx[0..63] | segIdx[64..127]
     int st = (tw1 && tw2 && tw3 && tw4 && wL) ? AFX_OK : AFX_ERR_NOMEM;
     if (st == AFX_OK) {
         const double PI = 3.14159265358979323846;
@@ -501,6 +530,8 @@ extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBan
             meta[64 + l] = band->startB[l];
             meta[128 + l] = band->rowA[l];
             meta[192 + l] = band->rowB[l];
+            meta[256 + l] = (int)band->segIdx[l];
+            meta[320 + l] = (int)band->segIdx[64 + l];
         }
         float *w2 = static_cast<float *>(malloc(sizeof(float) * NFFT));
         if (!w2) st = AFX_ERR_NOMEM;
@@ -540,9 +571,9 @@ extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return AFX_ERR_ARG;
     switch (p->variant) {
-        case 200: return launch<96, 32>(p, a, stream);
-        case 201: return launch<128, 64>(p, a, stream);
-        case 202: return launch<176, 8>(p, a, stream);
+        case 200: return p->split ? launch<96, 32, true>(p, a, stream) : launch<96, 32>(p, a, stream);
+        case 201: return p->split ? launch<128, 64, true>(p, a, stream) : launch<128, 64>(p, a, stream);
+        case 202: return p->split ? launch<176, 8, true>(p, a, stream) : launch<176, 8>(p, a, stream);
         default: return AFX_ERR_UNSUPPORTED;
     }
 }

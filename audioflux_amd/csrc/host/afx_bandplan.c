@@ -178,8 +178,10 @@ int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p) {
  * segment, and the kernel adds a row's segment results in ascending bin order.  Segment starts are
  * matched to LDS-bank residues like whole rows; because a segment may have to start a few bins
  * early, the payload per slot is reduced until the padded segments fit the variant.
+ * rowCap = floats of the kernel's zero-padded power row: no slot may read beyond it.
  * Returns 0 and fills *p (split = 1) when the bank fits, 1 otherwise. */
-int afx_bandplan_build_split(const float *bank, int num, int F, int tapsA, int tapsB, AfxBandPlan *p) {
+int afx_bandplan_build_split(const float *bank, int num, int F, int tapsA, int tapsB, int rowCap,
+                             AfxBandPlan *p) {
     memset(p, 0, sizeof(*p));
     if (!bank || num < 1 || num > 128 || tapsA < 4 || tapsB < 4) return 1;
     RowBand *rb = (RowBand *)calloc((size_t)num, sizeof(RowBand));
@@ -242,6 +244,22 @@ int afx_bandplan_build_split(const float *bank, int num, int F, int tapsA, int t
         for (int l = 0; l < 64; l++) {
             if (nA && laneA[l] >= 0 && ((segA[laneA[l]].start - shiftA[l]) & 1)) needA = tapsA + 1;
             if (nB && laneB[l] >= 0 && ((segB[laneB[l]].start - shiftB[l]) & 1)) needB = tapsB + 1;
+            /* a short segment near the top of the spectrum must not read past the row's zero pad:
+             * start it 64 bins (one full residue cycle) earlier while its taps allow */
+            if (nA && laneA[l] >= 0) {
+                const RowBand *g = &segA[laneA[l]];
+                while (g->start - shiftA[l] + tapsA > rowCap && shiftA[l] + 64 + g->len <= tapsA &&
+                       g->start - shiftA[l] - 64 >= 0)
+                    shiftA[l] += 64;
+                if (g->start - shiftA[l] + tapsA > rowCap) needA = tapsA + 1;
+            }
+            if (nB && laneB[l] >= 0) {
+                const RowBand *g = &segB[laneB[l]];
+                while (g->start - shiftB[l] + tapsB > rowCap && shiftB[l] + 64 + g->len <= tapsB &&
+                       g->start - shiftB[l] - 64 >= 0)
+                    shiftB[l] += 64;
+                if (g->start - shiftB[l] + tapsB > rowCap) needB = tapsB + 1;
+            }
         }
         if (needA <= tapsA && needB <= tapsB) ok = 1;
         else {

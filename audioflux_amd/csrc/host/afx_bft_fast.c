@@ -11,7 +11,8 @@
 #include "afx_objects.h"
 
 int afx_bandplan_build(const float *bank, int num, int F, AfxBandPlan *p);
-int afx_bandplan_build_split(const float *bank, int num, int F, int tapsA, int tapsB, AfxBandPlan *p);
+int afx_bandplan_build_split(const float *bank, int num, int F, int tapsA, int tapsB, int rowCap,
+                             AfxBandPlan *p);
 void afx_bandplan_free(AfxBandPlan *p);
 
 int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hBank) {
@@ -22,13 +23,17 @@ int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hB
     if (afx_bandplan_build(hBank, o->num, o->F, &band) != 0) return AFX_OK;
     int st = AFX_OK;
     int fits = afxk_melfused_variant(o->radix2Exp, band.tapsA, band.tapsB) >= 0;
-    if (!fits && o->radix2Exp == 11 && !getenv("AFX_NO_SPLIT")) {
-        /* rows longer than the compiled tap variants (mel-40 / -64, bark, erb, higher sample
-         * rates): cut them into segments, smallest variant first (afx_bandplan.c) */
-        static const int variants[2][2] = {{48, 16}, {72, 32}};
+    if (!fits && (o->radix2Exp == 11 || o->radix2Exp == 12) && !getenv("AFX_NO_SPLIT")) {
+        /* rows longer than the compiled tap variants (mel-40 / -64 / -80, bark, erb, higher sample
+         * rates): cut them into segments, smallest variant first (afx_bandplan.c); the last number
+         * is the length of the kernel's zero-padded power row (PROW_F of afx_melfused{,4k}.hip) */
+        static const int v2k[2][3] = {{48, 16, 1104}, {72, 32, 1104}};
+        static const int v4k[3][3] = {{96, 32, 2176}, {128, 64, 2176}, {176, 8, 2176}};
+        const int (*v)[3] = o->radix2Exp == 11 ? v2k : v4k;
+        const int nv = o->radix2Exp == 11 ? 2 : 3;
         afx_bandplan_free(&band);
-        for (int v = 0; v < 2 && !fits; v++)
-            fits = afx_bandplan_build_split(hBank, o->num, o->F, variants[v][0], variants[v][1], &band) == 0;
+        for (int i = 0; i < nv && !fits; i++)
+            fits = afx_bandplan_build_split(hBank, o->num, o->F, v[i][0], v[i][1], v[i][2], &band) == 0;
         if (!fits) return AFX_OK;
     }
     if (fits) {

@@ -73,28 +73,34 @@ def _bank(num, n, sr, scale):
     return bank
 
 
-@pytest.mark.parametrize("scale,num,sr,variant", [
-    ("mel", 40, 16000, (48, 16)), ("mel", 64, 16000, (48, 16)), ("mel", 64, 44100, (48, 16)),
-    ("mel", 20, 22050, (72, 32)), ("bark", 64, 16000, (48, 16)), ("bark", 64, 44100, (72, 32)),
-    ("erb", 64, 16000, (48, 16)), ("erb", 40, 44100, (72, 32)), ("bark", 96, 48000, (72, 32)),
+VARIANTS = {2048: ((48, 16), (72, 32)), 4096: ((96, 32), (128, 64), (176, 8))}  # compiled tap variants
+ROW_CAP = {2048: 1104, 4096: 2176}  # floats of the kernels' zero-padded power rows (PROW_F)
+
+
+@pytest.mark.parametrize("n,scale,num,sr,variant", [
+    (2048, "mel", 40, 16000, (48, 16)), (2048, "mel", 64, 16000, (48, 16)), (2048, "mel", 64, 44100, (48, 16)),
+    (2048, "mel", 20, 22050, (72, 32)), (2048, "bark", 64, 16000, (48, 16)), (2048, "bark", 64, 44100, (72, 32)),
+    (2048, "erb", 64, 16000, (48, 16)), (2048, "erb", 40, 44100, (72, 32)), (2048, "bark", 96, 48000, (72, 32)),
+    (4096, "mel", 80, 32000, (96, 32)), (4096, "mel", 40, 16000, (96, 32)), (4096, "bark", 40, 32000, (176, 8)),
+    (4096, "bark", 64, 44100, (128, 64)), (4096, "erb", 64, 22050, (96, 32)),
 ])
-def test_split_plan_is_exact_and_conflict_free(scale, num, sr, variant):
+def test_split_plan_is_exact_and_conflict_free(n, scale, num, sr, variant):
     """rows longer than the compiled tap variants are cut into segments (afx_bandplan_build_split):
     emulating the kernel's stage 4 (slot dot products over the zero-padded power row) + stage 5
     (a row = the sum of its <= 4 slots) reproduces bank . power, starts are even and give every
     32-lane half-wave 32 distinct LDS bank pairs, and the smallest variant that fits is chosen"""
     lib = af.get_lib()
-    n, F = 2048, 1025
+    F, cap = n // 2 + 1, ROW_CAP[n]
     bank = _bank(num, n, sr, scale)
     fp = C.POINTER(C.c_float)
     b = Band()
     rc = lib.afx_bandplan_build(bank.ctypes.data_as(fp), num, F, C.byref(b))
-    assert rc == 0 and not ((b.tapsA <= 48 and b.tapsB <= 16) or (b.tapsA <= 72 and b.tapsB <= 32))
+    assert rc == 0 and not any(b.tapsA <= ta and b.tapsB <= tb for ta, tb in VARIANTS[n])
     lib.afx_bandplan_free(C.byref(b))
     chosen = None
-    for ta, tb in ((48, 16), (72, 32)):
+    for ta, tb in VARIANTS[n]:
         b = Band()
-        if lib.afx_bandplan_build_split(bank.ctypes.data_as(fp), num, F, ta, tb, C.byref(b)) == 0:
+        if lib.afx_bandplan_build_split(bank.ctypes.data_as(fp), num, F, ta, tb, cap, C.byref(b)) == 0:
             chosen = (ta, tb)
             break
     assert chosen == variant
@@ -103,12 +109,12 @@ def test_split_plan_is_exact_and_conflict_free(scale, num, sr, variant):
     assert all(r == -1 for r in b.rowA) and all(r == -1 for r in b.rowB)
     sA, sB = np.array(b.startA), np.array(b.startB)
     for s, taps in ((sA, ta), (sB, tb)):
-        assert (s >= 0).all() and (s % 2 == 0).all() and (s + taps <= 1104).all()  # PROW_F of the kernel
+        assert (s >= 0).all() and (s % 2 == 0).all() and (s + taps <= cap).all()  # no read past the power row
         for h in range(2):
             assert len(set((s[h * 32:(h + 1) * 32] // 2) % 32)) == 32
     wA = np.ctypeslib.as_array(b.wA, (ta, 64)).astype(np.float64)
     wB = np.ctypeslib.as_array(b.wB, (tb, 64)).astype(np.float64)
-    power = np.zeros(1104)
+    power = np.zeros(cap)
     power[:F] = np.random.default_rng(num + sr).random(F)
     part = np.zeros(129)
     for l in range(64):
@@ -132,7 +138,7 @@ def test_split_plan_refuses_what_does_not_fit():
     fp = C.POINTER(C.c_float)
     for scale, num, sr in (("mel", 13, 16000), ("bark", 128, 44100)):
         bank = _bank(num, 2048, sr, scale)
-        for ta, tb in ((48, 16), (72, 32)):
+        for ta, tb in VARIANTS[2048]:
             b = Band()
-            assert lib.afx_bandplan_build_split(bank.ctypes.data_as(fp), num, 1025, ta, tb, C.byref(b)) == 1
+            assert lib.afx_bandplan_build_split(bank.ctypes.data_as(fp), num, 1025, ta, tb, 1104, C.byref(b)) == 1
             assert b.wA is None or not b.wA  # nothing left allocated

@@ -179,16 +179,32 @@ def test_bft_nfft4096_fused_kernel_matches_compiled_reference(scale):
             assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"scale{scale} hop{hop} rt{rt} dt{dt} norm{norm}")
 
 
-SPLIT_CASES = [  # (scale, num, samplate): banks whose rows exceed the fused kernel's tap variants
-    ("MEL", 40, 16000), ("MEL", 64, 32000), ("MEL", 20, 22050), ("BARK", 64, 16000), ("BARK", 80, 44100),
-    ("ERB", 64, 22050), ("ERB", 40, 44100),
+def _bank32(num, n, sr, scale):
+    """the float32 bank the object uploads (bit-identical to the reference's, tests/test_host_setup.py)"""
+    import ctypes as C
+    lib = af.get_lib()
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.afx_auditory_bank.restype = None
+    lib.afx_auditory_bank.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_int, fp, fp, ip]
+    bank = np.zeros((num, n // 2 + 1), np.float32)
+    fre, bins = np.zeros(num + 2, np.float32), np.zeros(num + 2, np.int32)
+    lib.afx_auditory_bank(num, n, sr, scale, 0, 0, 0.0, sr / 2.0, 12, bank.ctypes.data_as(fp),
+                          fre.ctypes.data_as(fp), bins.ctypes.data_as(ip))
+    return bank
+
+
+SPLIT_CASES = [  # (radix2_exp, scale, num, samplate): banks whose rows exceed the fused kernels' tap variants
+    (11, "MEL", 40, 16000), (11, "MEL", 64, 32000), (11, "MEL", 20, 22050), (11, "BARK", 64, 16000),
+    (11, "BARK", 80, 44100), (11, "ERB", 64, 22050), (11, "ERB", 40, 44100),
+    (12, "MEL", 80, 32000), (12, "MEL", 40, 16000), (12, "BARK", 40, 32000), (12, "BARK", 64, 44100),
+    (12, "ERB", 64, 22050),
 ]
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("scale,num,sr", SPLIT_CASES)
-def test_bft_split_plan_matches_compiled_reference(scale, num, sr, monkeypatch):
-    """n_fft 2048 with long-row banks: the fused kernel runs a split plan (row segments per lane slot,
+@pytest.mark.parametrize("r2,scale,num,sr", SPLIT_CASES)
+def test_bft_split_plan_matches_compiled_reference(r2, scale, num, sr, monkeypatch):
+    """n_fft 2048 / 4096 with long-row banks: the fused kernel runs a split plan (row segments per lane slot,
     summed in ascending bin order) instead of falling back to the size-generic kernel -- real and
     complex results, power / magnitude / norm exponent, the register-reuse (hop 512) and plain (hop 300)
     instantiations; and the size-generic kernel (AFX_NO_SPLIT=1) agrees"""
@@ -196,31 +212,49 @@ def test_bft_split_plan_matches_compiled_reference(scale, num, sr, monkeypatch):
     noise = cases.noise(700 + num, sr * 2 + 77)
     tonal = noise.copy()
     tonal[sr // 2:sr] += (0.3 * np.sin(np.arange(sr - sr // 2) * 0.21)).astype(np.float32)
-    kw = dict(radix2_exp=11, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, scale_type=st)
-    for hop in (512, 300):
+    kw = dict(radix2_exp=r2, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, scale_type=st)
+    nfft = 1 << r2
+    for hop in (nfft // 4, 300):
         for rt, dt, norm in ((1, 0, 1.0), (1, 1, 1.0), (1, 0, 0.5), (0, 0, 1.0), (0, 1, 1.0)):
             # complex results sum the spectrum itself: around a strong tone the band sums cancel to
             # far below max|S|, and the float32 error of S (1e-7 of max|S| -- the reference's too:
             # 2.5e-5 of the output peak for mel-20 with the tone) is all that is left; the tone
             # therefore goes through the real-result modes only
             x = tonal if rt == 1 else noise
-            r = ref.RefBFT(num, 11, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, window_type=1, slide_length=hop,
+            r = ref.RefBFT(num, r2, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, window_type=1, slide_length=hop,
                            scale_type=int(st), style_type=0, normal_type=0, data_type=dt)
             r.set_result_type(rt)
             if norm != 1.0:
                 r.set_norm(norm)
             re, im = r.bft(x)
             o = af.BFT(num, slide_length=hop, data_type=af.SpectralDataType(dt), **kw)
-            assert o.fused_plan_kind() == 2, (scale, num, sr)
+            assert o.fused_plan_kind() == (2 if r2 == 11 else 202), (scale, num, sr)
             if norm != 1.0:
                 o.set_data_norm_value(norm)
             got = o.bft(x, result_type=rt).T
-            assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"{scale}-{num}@{sr} hop{hop} rt{rt} dt{dt} norm{norm}")
+            tol = TOL
+            if rt == 0:
+                # Complex results sum the spectrum itself (or its square) over the band.  Frames are
+                # not centred at the phase origin, so S[k] alternates in sign from bin to bin and a
+                # smooth band of 100-250 weights cancels to far below max|S|: what is left carries
+                # the float32 error of S (1e-7 of max|S|) -- the reference's own distance from a
+                # float64 evaluation reaches 3e-5 of the output peak here.  Bar: the larger of TOL
+                # and 3x that distance.
+                from oracle import restate
+                fr = restate.frames_of(x.astype(np.float64), nfft, hop) * restate.fft_window(1, nfft)[None, :]
+                S = np.fft.rfft(fr, axis=1)
+                f64 = (S if dt == 1 else S * S) @ _bank32(num, nfft, sr, int(st)).astype(np.float64).T
+                want = re + 1j * im
+                ref_err = max(np.abs(want - f64).max() / np.abs(f64).max(),
+                              np.linalg.norm(want - f64) / np.linalg.norm(f64))
+                tol = max(TOL, 3.0 * ref_err)
+                assert_parity(got, f64, tol, f"{scale}-{num}@{sr} hop{hop} rt{rt} dt{dt} vs float64")
+            assert_parity(got, re if rt == 1 else re + 1j * im, tol, f"{scale}-{num}@{sr} hop{hop} rt{rt} dt{dt} norm{norm}")
     monkeypatch.setenv("AFX_NO_SPLIT", "1")
-    g = af.BFT(num, slide_length=512, data_type=af.SpectralDataType.POWER, **kw)
+    g = af.BFT(num, slide_length=nfft // 4, data_type=af.SpectralDataType.POWER, **kw)
     assert g.fused_plan_kind() == 0
     monkeypatch.delenv("AFX_NO_SPLIT")
-    o = af.BFT(num, slide_length=512, data_type=af.SpectralDataType.POWER, **kw)
+    o = af.BFT(num, slide_length=nfft // 4, data_type=af.SpectralDataType.POWER, **kw)
     assert_parity(o.bft(tonal, result_type=1), g.bft(tonal, result_type=1), TOL, "split plan vs size-generic kernel")
 
 
@@ -232,3 +266,4 @@ def test_fused_plan_kinds():
     assert mk(13, 11).fused_plan_kind() == 0   # rows of ~160 bins: more than four segments
     assert mk(128, 10).fused_plan_kind() == 101
     assert mk(128, 12).fused_plan_kind() == 201
+    assert mk(80, 12, 32000).fused_plan_kind() == 202

@@ -1,4 +1,4 @@
-"""n_fft 2048 / hop 512 with banks whose rows exceed the fused kernel's tap variants: split plan
+"""n_fft 2048 / hop 512 and n_fft 4096 / hop 1024 with banks whose rows exceed the fused kernel's tap variants: split plan
 (default) vs the size-generic kernel (AFX_NO_SPLIT=1), 500 clips x 30 s @ 16 kHz, real power results"""
 import os
 import sys
@@ -9,9 +9,11 @@ import torch
 import audioflux_amd as af
 
 x = 0.1 * torch.randn((500, 480000), device="cuda")
-for scale, num, sr in (("MEL", 40, 16000), ("MEL", 64, 16000), ("MEL", 80, 22050), ("BARK", 64, 16000),
-                       ("ERB", 64, 16000), ("MEL", 64, 44100), ("MEL", 128, 16000)):
-    o = af.BFT(num, radix2_exp=11, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, slide_length=512,
+for r2, scale, num, sr in ((11, "MEL", 40, 16000), (11, "MEL", 64, 16000), (11, "MEL", 80, 22050),
+                           (11, "BARK", 64, 16000), (11, "ERB", 64, 16000), (11, "MEL", 64, 44100),
+                           (11, "MEL", 128, 16000), (12, "MEL", 80, 32000), (12, "MEL", 40, 16000),
+                           (12, "BARK", 64, 32000), (12, "ERB", 64, 22050), (12, "MEL", 128, 32000)):
+    o = af.BFT(num, radix2_exp=r2, samplate=sr, low_fre=0.0, high_fre=sr / 2.0, slide_length=(1 << r2) // 4,
                scale_type=getattr(af.SpectralFilterBankScaleType, scale), data_type=af.SpectralDataType.POWER)
     o.set_result_type(1)
     t = o.cal_time_length(480000)
@@ -26,4 +28,4 @@ for scale, num, sr in (("MEL", 40, 16000), ("MEL", 64, 16000), ("MEL", 80, 22050
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print(f"{scale}-{num} @ {sr}: plan kind {o.fused_plan_kind()}, {ms:.3f} ms, {500 * t / ms / 1e3:.1f} M frames/s")
+    print(f"n_fft {1 << r2} {scale}-{num} @ {sr}: plan kind {o.fused_plan_kind()}, {ms:.3f} ms, {500 * t / ms / 1e3:.1f} M frames/s")
