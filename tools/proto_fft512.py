@@ -60,6 +60,11 @@ def fft256(x):
 
 
 x = rng.standard_normal(512) + 1j * rng.standard_normal(512)
-print("fft512 err", np.abs(fft512(x) - np.fft.fft(x)).max())
+e512 = np.abs(fft512(x) - np.fft.fft(x)).max()
+print("fft512 err", e512)
+assert e512 < 1e-10
 x = rng.standard_normal(256) + 1j * rng.standard_normal(256)
-print("fft256 err", np.abs(fft256(x) - np.fft.fft(x)).max())
+e256 = np.abs(fft256(x) - np.fft.fft(x)).max()
+print("fft256 err", e256)
+assert e256 < 1e-10
+print("prototype OK")
