@@ -20,6 +20,9 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_ldsfft.h"
+#include "afx_wavefft2048.h"
+
+#include <mutex>
 
 namespace {
 
@@ -164,6 +167,196 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     }
 }
 
+// ---- n_fft 2048 / 4096 without a filter bank: one wave per frame ----------------------------
+// The STFT object (complex spectrum, all N bins as conjugate mirrors), the linear-scale spectrogram
+// (bin slices, every AFX_SPEC_* map) and the three transforms of the reassignment object store
+// 8-33 KB per frame and no workgroup needs to see a whole spectrum: each wave runs the register /
+// LDS transform of afx_wavefft2048.h on its own frames (n_fft 4096: even / odd samples + combine)
+// and stores its bins straight from registers -- lanes hold consecutive bins, so every store
+// instruction covers 256 contiguous bytes.  Frames that touch the clip's ends (padding modes) or
+// start unaligned are gathered sample by sample through the same index map as the generic kernel.
+constexpr int SW = 8;  // waves per workgroup
+
+// CPLX: mode AFX_SPEC_COMPLEX only (the stores are the spectrum itself); the general maps are
+// compiled for n_fft 2048 only (at 4096 their 40 unrolled bin slots exceed the unroller's budget
+// and the bins would be indexed dynamically, i.e. live in scratch)
+template <int R2, bool CPLX>
+__global__ __launch_bounds__(SW * 64) void k_stft_wave(AfxStftArgs a, const float2 *__restrict__ tab,
+                                                      int framesPerWave, int vecOk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = 1 << R2, M = N / 2;
+    constexpr int NTAB = afxw::TAB_F2 + (R2 == 12 ? 1032 : 0);
+    float *tabWin = reinterpret_cast<float *>(smem_raw);       // [N]
+    v2 *tabTw = reinterpret_cast<v2 *>(tabWin + N);            // afxw tables (| W_4096^k)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2 *ex = tabTw + NTAB + wave * afxw::EX_F2;
+    for (int i = threadIdx.x; i < N; i += SW * 64) tabWin[i] = a.window[i];
+    for (int i = threadIdx.x; i < afxw::TAB_F2 + (R2 == 12 ? 1025 : 0); i += SW * 64) tabTw[i] = v2{tab[i].x, tab[i].y};
+    __syncthreads();
+    const afxw::Tables tb = {tabTw, tabTw + afxw::TAB_TW1_F2, tabTw + afxw::TAB_TW1_F2 + afxw::TAB_TW2_F2};
+    const v2 *tabW4 = tabTw + afxw::TAB_F2;
+
+    const long long total = (long long)a.batch * a.timeLength;
+    const long long gw = (long long)blockIdx.x * SW + wave;
+    long long f = gw * framesPerWave, fEnd = f + framesPerWave;
+    if (fEnd > total) fEnd = total;
+    const bool two = (a.mode == AFX_SPEC_COMPLEX || a.mode == AFX_SPEC_SQUARE);
+    for (; f < fEnd; ++f) {
+        const int b = (int)(f / a.timeLength);
+        const int t = (int)(f - (long long)b * a.timeLength);
+        const float *x = a.x + (long long)b * a.clipStride;
+        const long long start = (long long)t * a.hop - a.padLeft;
+        const bool inside = start >= 0 && start + N <= a.dataLength;
+        const long long row = f * (long long)a.binCount;
+        // bin k of this frame (0 <= k <= N/2) and, for 0 < k < N/2, its mirror N - k = conj
+        auto emit = [&](int k, v2 X) {
+            float v0, v1;
+            const int j = k - a.binLo;
+            if (j >= 0 && j < a.binCount) {
+                if constexpr (CPLX) {
+                    a.outRe[row + j] = X.x;
+                    a.outIm[row + j] = X.y;
+                } else {
+                    map_bin(make_float2(X.x, X.y), a.mode, a.normValue, v0, v1);
+                    a.outRe[row + j] = v0;
+                    if (two) a.outIm[row + j] = v1;
+                }
+            }
+            const int j2 = N - k - a.binLo;
+            if (k > 0 && k < M && j2 >= 0 && j2 < a.binCount) {
+                if constexpr (CPLX) {
+                    a.outRe[row + j2] = X.x;
+                    a.outIm[row + j2] = -X.y;
+                } else {
+                    map_bin(make_float2(X.x, -X.y), a.mode, a.normValue, v0, v1);
+                    a.outRe[row + j2] = v0;
+                    if (two) a.outIm[row + j2] = v1;
+                }
+            }
+        };
+        if constexpr (R2 == 11) {
+            v2 v[16];
+            if (inside && vecOk) {
+                const v2 *p2 = reinterpret_cast<const v2 *>(x + start);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1] = p2[64 * n1 + lane];
+            } else {
+                // sample by sample through the padding index map, staged in the exchange buffer
+                float *stage = reinterpret_cast<float *>(ex);
+#pragma unroll 1
+                for (int i = 0; i < 32; ++i) stage[lane + 64 * i] = fetch(x, start + lane + 64 * i, a);
+                wave_lds_order();
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1] = reinterpret_cast<const v2 *>(stage)[64 * n1 + lane];
+                wave_lds_order();
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] *= reinterpret_cast<const v2 *>(tabWin)[64 * n1 + lane];
+            afxw::Bins bn;
+            afxw::rfft2048(v, ex, tb, lane, bn);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * s + 256 * j;
+                    emit(k, bn.x[s][j]);
+                    emit(1024 - k, v2{bn.y[s][j].x, -bn.y[s][j].y});
+                }
+            if (lane == 0) {
+                emit(128, bn.xc[0]);
+                emit(896, v2{bn.yc[0].x, -bn.yc[0].y});
+                emit(384, bn.xc[1]);
+                emit(640, v2{bn.yc[1].x, -bn.yc[1].y});
+            }
+        } else {
+            typedef float v4 __attribute__((ext_vector_type(4)));
+            // even samples, transform, then odd samples (re-read through L1/L2: holding both halves
+            // across the first transform costs 32 VGPRs and spills)
+            auto load_half = [&](int odd, v2 (&v)[16]) {
+                if (inside && vecOk) {
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const int n = 64 * n1 + lane;
+                        const v4 xv = reinterpret_cast<const v4 *>(x + start)[n];
+                        const v4 wv = reinterpret_cast<const v4 *>(tabWin)[n];
+                        v[n1] = odd ? v2{xv.y * wv.y, xv.w * wv.w} : v2{xv.x * wv.x, xv.z * wv.z};
+                    }
+                } else {
+                    // (windowed) samples 2 i + odd staged in the exchange buffer: 2048 floats
+                    float *stage = reinterpret_cast<float *>(ex);
+#pragma unroll 1
+                    for (int i = 0; i < 32; ++i) {
+                        const int m = 2 * (lane + 64 * i) + odd;
+                        stage[lane + 64 * i] = fetch(x, start + m, a) * tabWin[m];
+                    }
+                    wave_lds_order();
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) v[n1] = reinterpret_cast<const v2 *>(stage)[64 * n1 + lane];
+                    wave_lds_order();
+                }
+            };
+            afxw::Bins be, bo;
+            {
+                v2 v[16];
+                load_half(0, v);
+                afxw::rfft2048(v, ex, tb, lane, be);
+                load_half(1, v);
+                afxw::rfft2048(v, ex, tb, lane, bo);
+            }
+            afxw::combine4096(be, bo, tabW4, lane, [&](int slot, v2 X) {
+                if (slot < 32 || lane == 0) emit(afxw::bin4096(slot, lane), X);
+            });
+        }
+    }
+}
+
+// twiddle tables of the wave kernels, one device copy per device (never freed)
+const float2 *wave_tables() {
+    static std::mutex mu;
+    static float2 *dTab[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dTab[dev]) {
+        const size_t n = (size_t)afxw::TAB_F2 + 1025;
+        float *h = static_cast<float *>(calloc(2 * n, sizeof(float)));
+        if (!h) return nullptr;
+        afxw::fill_tables(h);
+        const double PI = 3.14159265358979323846;
+        for (int k = 0; k <= 1024; ++k) {
+            h[2 * (afxw::TAB_F2 + k)] = (float)cos(-2.0 * PI * (double)k / 4096.0);
+            h[2 * (afxw::TAB_F2 + k) + 1] = (float)sin(-2.0 * PI * (double)k / 4096.0);
+        }
+        float2 *d = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&d), 2 * n * sizeof(float)) == hipSuccess &&
+            hipMemcpy(d, h, 2 * n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess)
+            dTab[dev] = d;
+        else if (d) (void)hipFree(d);
+        free(h);
+    }
+    return dTab[dev];
+}
+
+template <int R2, bool CPLX>
+int launch_stft_wave(const AfxStftArgs *a, const float2 *tab, long long frames, void *stream) {
+    constexpr int N = 1 << R2;
+    const int vm = R2 == 11 ? 1 : 3;  // float2 / float4 loads: every interior frame start aligned to them
+    const int vecOk = ((reinterpret_cast<size_t>(a->x) & (size_t)(4 * vm + 3)) == 0 && (a->hop & vm) == 0 &&
+                       (a->padLeft & vm) == 0 && (a->clipStride & vm) == 0)
+                          ? 1
+                          : 0;
+    long long fpw = frames / (256LL * SW * 4);
+    fpw = fpw < 1 ? 1 : (fpw > 16 ? 16 : fpw);
+    const long long waves = (frames + fpw - 1) / fpw, blocks = (waves + SW - 1) / SW;
+    const size_t lds = sizeof(float) * N + sizeof(float2) * (size_t)(afxw::TAB_F2 + (R2 == 12 ? 1032 : 0) + SW * afxw::EX_F2);
+    AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_wave<R2, CPLX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_stft_wave<R2, CPLX>), dim3((unsigned)blocks), dim3(SW * 64), lds, (hipStream_t)stream, *a, tab,
+                       (int)fpw, vecOk);
+    AFX_LAUNCH_CHECK("k_stft_wave");
+    return AFX_OK;
+}
+
 }  // namespace
 
 extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
@@ -176,6 +369,17 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     if (frames > 0x7fffffffLL) {
         afxdev_set_error("stft: %lld frames in one launch", frames);
         return AFX_ERR_UNSUPPORTED;
+    }
+    // n_fft 2048: one wave per frame (191 vs 111 M frames/s for the full complex spectrum).  The
+    // n_fft 4096 instantiation (<12, true>: two transforms + combine, 40 bin slots per lane) needs
+    // 252 VGPRs + 620 B/lane of scratch and measured SLOWER than this kernel (38 vs 57 M frames/s):
+    // not dispatched.
+    const bool cplx = a->mode == AFX_SPEC_COMPLEX;
+    if (a->radix2Exp == 11 && !a->bandStart && !a->energy && a->binLo >= 0 && !getenv("AFX_NO_FUSED") &&
+        !getenv("AFX_NO_STFT_WAVE")) {
+        if (const float2 *tab = wave_tables())
+            return cplx ? launch_stft_wave<11, true>(a, tab, frames, stream)
+                        : launch_stft_wave<11, false>(a, tab, frames, stream);
     }
     const int N = 1 << a->radix2Exp;
     int threads = N / 4;

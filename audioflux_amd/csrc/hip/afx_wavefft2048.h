@@ -97,6 +97,41 @@ __device__ __forceinline__ void rfft2048(v2 (&v)[16], v2 *ex, const Tables &t, i
     wave_lds_order();  // every lane has its bins in registers: ex may be overwritten
 }
 
+// ---- N = 4096 ---------------------------------------------------------------------------------
+// Spectrum of a 4096-sample real sequence from the transforms of its even and odd samples.  For
+// every position of the afxw::Bins layout (k' = lane + 64 s + 256 j, its partner 1024 - k', and
+// the base-128 extras) four bins come out: k', 1024 - k', 1024 + k', 2048 - k'.  emit(slot, X)
+// receives the spectrum value itself (not conjugated); slots: 4 (4 s + j) + {0: k', 1: 2048 - k',
+// 2: 1024 - k', 3: 1024 + k'}, extras 32 + 4 i + {0..3} for k' = 128 + 256 i.
+template <typename Emit>
+__device__ __forceinline__ void combine4096(const Bins &e, const Bins &o, const v2 *w4, int lane,
+                                            Emit emit) {
+    auto position = [&](int slot, int kp, v2 xE, v2 xO, v2 yE, v2 yO) {
+        const v2 wk = w4[kp], wp = w4[1024 - kp];
+        const v2 t = cmul(xO, wk);                    // W^k' O[k']
+        const v2 u = cmul(yO, v2{wp.x, -wp.y});       // conj(W^(1024-k')) conj(O[1024-k'])
+        const v2 s0 = xE + t, d0 = xE - t, s1 = yE + u, d1 = yE - u;
+        emit(slot + 0, s0);                 // X[k']          = E + W O
+        emit(slot + 1, v2{d0.x, -d0.y});    // X[2048 - k']   = conj(E - W O)
+        emit(slot + 2, v2{s1.x, -s1.y});    // X[1024 - k']   = conj(yE + u)
+        emit(slot + 3, d1);                 // X[1024 + k']   = yE - u
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            position(4 * (4 * s + j), lane + 64 * s + 256 * j, e.x[s][j], o.x[s][j], e.y[s][j], o.y[s][j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) position(32 + 4 * i, 128 + 256 * i, e.xc[i], o.xc[i], e.yc[i], o.yc[i]);
+}
+
+// bin index of a slot of combine4096 for this lane
+__device__ __forceinline__ int bin4096(int slot, int lane) {
+    const int p = slot >> 2, r = slot & 3;
+    const int kp = p < 8 ? lane + 64 * (p >> 2) + 256 * (p & 3) : 128 + 256 * (p - 8);
+    return r == 0 ? kp : r == 1 ? 2048 - kp : r == 2 ? 1024 - kp : 1024 + kp;
+}
+
 // host: the three twiddle tables, evaluated in double and rounded once; tab[2 * TAB_F2] floats
 inline void fill_tables(float *tab) {
     const double PI = 3.14159265358979323846;

@@ -267,3 +267,24 @@ def test_fused_plan_kinds():
     assert mk(128, 10).fused_plan_kind() == 101
     assert mk(128, 12).fused_plan_kind() == 201
     assert mk(80, 12, 32000).fused_plan_kind() == 202
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("hop", [512, 300])
+def test_bft_linear_scale_n2048_every_result_mode(hop):
+    """linear scale at n_fft 2048 = a bin slice straight from the wave-per-frame STFT kernel: power,
+    magnitude, norm exponent, and the complex results S / S^2"""
+    x = cases.noise(41, 16000 * 2 + 5)
+    for rt, dt, norm in ((1, 0, 1.0), (1, 1, 1.0), (1, 0, 0.5), (1, 1, 2.0), (0, 0, 1.0), (0, 1, 1.0)):
+        r = ref.RefBFT(100, 11, samplate=16000, low_fre=1000.0, high_fre=8000.0, window_type=1, slide_length=hop,
+                       scale_type=0, style_type=0, normal_type=0, data_type=dt)
+        r.set_result_type(rt)
+        if norm != 1.0:
+            r.set_norm(norm)
+        re, im = r.bft(x)
+        o = af.BFT(100, radix2_exp=11, samplate=16000, low_fre=1000.0, high_fre=8000.0, slide_length=hop,
+                   scale_type=af.SpectralFilterBankScaleType.LINEAR, data_type=af.SpectralDataType(dt))
+        if norm != 1.0:
+            o.set_data_norm_value(norm)
+        got = o.bft(x, result_type=rt).T
+        assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"linear hop{hop} rt{rt} dt{dt} norm{norm}")

@@ -117,7 +117,7 @@ def test_custom_window_and_slide_length_switches():
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("r,hop", [(11, 512), (12, 1024), (13, 3000), (5, 8), (1, 1), (2, 1)])
+@pytest.mark.parametrize("r,hop", [(11, 512), (12, 1024), (11, 300), (12, 999), (13, 3000), (5, 8), (1, 1), (2, 1)])
 def test_stft_istft_match_compiled_reference_fresh_inputs(r, hop):
     n = 1 << r
     x = cases.noise(100 + r, max(6 * n + 17, 50))
@@ -171,3 +171,30 @@ def test_degenerate_inputs():
     assert_parity(re[0], np.fft.fft(np.where(np.arange(256) == 128, w, 0)).real, 1e-6, "one sample, centre pad")
     with pytest.raises(RuntimeError):
         af.STFT(radix2_exp=31)
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("r,hop", [(11, 512), (11, 301), (12, 1024), (12, 700)])
+def test_wave_kernel_every_padding_mode_and_the_generic_kernel(r, hop, monkeypatch):
+    """n_fft 2048 runs one wave per frame (k_stft_wave): interior frames by vector loads, frames touching
+    the clip's ends sample by sample through the padding index map -- every position x mode, against
+    the compiled reference (n_fft 4096: the size-generic kernel, same checks); and the size-generic
+    kernel (AFX_NO_STFT_WAVE=1) agrees"""
+    n = 1 << r
+    x = cases.noise(300 + r + hop, 5 * n + 123)
+    for pos in (0, 1, 2):
+        for mode in (0, 1, 2):
+            rr = ref.RefSTFT(r, 1, hop)
+            o = af.STFT(radix2_exp=r, window_type=af.WindowType.HANN, slide_length=hop)
+            rr.enable_padding(1)
+            rr.set_padding(pos, mode, 0.5, -0.25)
+            o.enable_padding(True)
+            o.set_padding(af.PaddingPositionType(pos), af.PaddingModeType(mode), 0.5, -0.25)
+            re, im = rr.stft(x)
+            gre, gim = o.stft_full(x)
+            assert_parity(gre + 1j * gim, re + 1j * im, TOL, f"r{r} hop{hop} pos{pos} mode{mode}")
+    o = af.STFT(radix2_exp=r, window_type=af.WindowType.HANN, slide_length=hop)
+    wre, wim = o.stft_full(x)
+    monkeypatch.setenv("AFX_NO_STFT_WAVE", "1")
+    gre, gim = o.stft_full(x)
+    assert_parity(wre + 1j * wim, gre + 1j * gim, TOL, "wave vs size-generic kernel")
