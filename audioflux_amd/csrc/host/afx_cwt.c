@@ -730,7 +730,8 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * narrow-band plan leaves: 2 chunks (+9 %, profiles/r01_cwt_narrowband.txt); 16 chunks at
      * the wrapper's default L = 2^13 (otherwise launch-bound). */
     const int nTwoPass = o->dims.order ? o->dims.nWide : o->num; /* scales that write the intermediate */
-    int group = nTwoPass > 0 ? (int)(96.0e6 / ((double)nTwoPass * L * 8.0)) : chunks;
+    /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
+    int group = nTwoPass > 0 ? (int)(96.0e6 / ((double)nTwoPass * L * 8.0)) : 32;
     if (group < 1) group = 1;
     {
         const char *e = getenv("AFX_CWT_GROUP");
