@@ -1,7 +1,7 @@
 """XXCC -- ctypes mirror of python/audioflux/feature/xxcc.py:60-230 over
 libaudioflux_mi355x.so (MFCC / BFCC / GTCC / CQCC from any spectrogram)."""
 import ctypes
-from ctypes import POINTER, c_float, c_int, c_longlong, c_void_p
+from ctypes import POINTER, c_int, c_longlong, c_void_p
 
 import numpy as np
 

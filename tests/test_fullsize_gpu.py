@@ -6,7 +6,6 @@ cfg 2: 1000 x 30 s @ 16 kHz, n_fft 2048, hop 512, mel-128 + MFCC-13 (934 000 fra
 cfg 4: CWT morlet 84 scales on 2^16-sample chunks @ 44.1 kHz, padded (L = 2^17)
 cfg 5: CQT 84 bins + chroma, 30 s @ 44.1 kHz clips (125 = one GPU's share of the 8-GPU run)
 """
-import numpy as np
 import pytest
 
 import audioflux_amd as af

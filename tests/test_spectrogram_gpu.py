@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import audioflux_amd as af
-from oracle import ref, restate
+from oracle import ref
 from tests import cases
 from tests.conftest import assert_parity
 
