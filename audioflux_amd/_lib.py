@@ -59,11 +59,41 @@ def get_lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.afx_last_error.restype = ctypes.c_char_p
         _lib.afx_version.restype = ctypes.c_char_p
+        _lib.afx_error_count.restype = ctypes.c_int
     return _lib
 
 
 def last_error():
     return get_lib().afx_last_error().decode(errors="replace")
+
+
+class _Checked:
+    """A `void` reference entry point (bftObj_bft, stftObj_stft, cwtObj_cwt, ...) cannot return a
+    status; the library records a failure inside one on the calling thread (afx_error_count(),
+    include/afx_batch.h).  This proxy samples the counter around the call and raises, so an
+    out-of-memory or launch failure never reaches the caller as a zero-filled "result"."""
+    __slots__ = ("_fn",)
+
+    def __init__(self, fn):
+        object.__setattr__(self, "_fn", fn)
+
+    def __setattr__(self, key, value):  # argtypes / restype go to the ctypes function
+        setattr(self._fn, key, value)
+
+    def __getattr__(self, key):
+        return getattr(self._fn, key)
+
+    def __call__(self, *args):
+        lib = get_lib()
+        before = lib.afx_error_count()
+        res = self._fn(*args)
+        if lib.afx_error_count() != before:
+            raise RuntimeError(f"{self._fn.__name__} failed: {last_error()}")
+        return res
+
+
+def checked(fn):
+    return fn if isinstance(fn, _Checked) else _Checked(fn)
 
 
 def check(status, what):

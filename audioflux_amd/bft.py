@@ -112,6 +112,7 @@ class BFT:
         re = np.zeros((clips.shape[0], t, self.num), np.float32)
         im = np.zeros((clips.shape[0], t, self.num), np.float32)
         fn = self._lib.bftObj_bft  # the reference entry point, one clip per call
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p, _util.c_float_p]
         temporal = []
@@ -129,6 +130,7 @@ class BFT:
 
     def _fetch_temporal(self, t):
         fn = self._lib.bftObj_getTemporalData
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, POINTER(_util.c_float_p)] * 1 + [POINTER(_util.c_float_p)] * 2
         e, r, z = _util.c_float_p(), _util.c_float_p(), _util.c_float_p()

@@ -41,6 +41,7 @@ class Cepstrogram:
         f = self.fft_length // 2 + 1
         outs = [np.zeros((clips.shape[0], t, f), np.float32) for _ in range(3)]
         fn = self._lib.cepstrogramObj_cepstrogram
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, c_int, _util.c_float_p, c_int] + [_util.c_float_p] * 3
         for i in range(clips.shape[0]):

@@ -55,6 +55,7 @@ class CQT:
     def set_scale(self, flag):
         fn = self._lib.cqtObj_setScale
         fn.argtypes = [c_void_p, c_int]
+        fn = _lib.checked(fn)
         fn.restype = None
         fn(self._obj, int(flag))
 
@@ -67,6 +68,7 @@ class CQT:
         re = np.zeros((clips.shape[0], t, self.num), np.float32)
         im = np.zeros_like(re)
         fn = self._lib.cqtObj_cqt
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p, _util.c_float_p]
         for i in range(clips.shape[0]):
@@ -84,6 +86,7 @@ class CQT:
         t = m.shape[-2]
         out = np.zeros((frames.shape[0], t, chroma_num), np.float32)
         fn = self._lib.cqtObj_chroma
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), _util.c_float_p,
                        _util.c_float_p, _util.c_float_p]
@@ -141,6 +144,7 @@ class CQT:
         t = m.shape[-2]
         out = np.zeros((frames.shape[0], t, cc_num), np.float32)
         fn = self._lib.cqtObj_cqcc
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, POINTER(c_int), _util.c_float_p]
         for i in range(frames.shape[0]):
@@ -159,6 +163,7 @@ class CQT:
         t = m.shape[-2]
         out = np.zeros((frames.shape[0], t, hc_num), np.float32)
         fn = self._lib.cqtObj_cqhc
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p]
         for i in range(frames.shape[0]):
@@ -176,6 +181,7 @@ class CQT:
         tone = np.zeros_like(frames)
         pitch = np.zeros_like(frames)
         fn = self._lib.cqtObj_deconv
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, _util.c_float_p, _util.c_float_p]
         for i in range(frames.shape[0]):

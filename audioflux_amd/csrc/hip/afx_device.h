@@ -30,7 +30,13 @@ int afxdev_ensure(void);              /* initialise HIP, select device      */
 const char *afxdev_last_error(void);
 void afxdev_set_error(const char *fmt, ...);
 int afxdev_device_count(void);
-int afxdev_set_device(int ordinal);   /* used by the multi-GPU launcher     */
+int afxdev_set_device(int ordinal);   /* process-wide default for new objects */
+int afxdev_current_device(void);      /* this thread's HIP device, -1 if none */
+int afxdev_bind_stream(void *stream); /* thread's device := the stream's device */
+#define AFX_MAX_DEVICES 16           /* power of two; per-device one-time flags */
+int afxdev_error_count(void);         /* failures reported on this thread so far */
+/* first statement of every compute entry point: the object's device becomes current */
+#define AFX_ENTER(o) do { if ((o) != NULL) (void)afxdev_bind_stream((o)->stream); } while (0)
 
 int afxdev_malloc(void **dptr, size_t bytes);
 void afxdev_free(void *dptr);
@@ -335,6 +341,12 @@ typedef struct {
     float normValue;
     float *out;     /* device [batch*timeLength, num]                       */
     float *outIm;   /* device, same shape; complex result modes only        */
+    /* optional fusions of the n_fft 2048 real-result kernel (afx_melfused2.hip); a run that cannot
+     * honour them returns AFX_ERR_UNSUPPORTED and the caller takes the separate kernels */
+    const float *dct; /* device [num, num] orthonormal DCT-II: cepstra of the rows in the same launch */
+    int ccNum;        /*   first ccNum coefficients of log10(max(row, 1e-8)); needs `out`              */
+    float *cc;        /*   device [batch*timeLength, ccNum]                                          */
+    float *energy, *rms, *zcr; /* device [batch*timeLength]: temporal features of the windowed frame */
 } AfxMelFusedArgs;
 
 /* variant index able to run (radix2Exp, tapsA, tapsB), or -1 */

@@ -184,8 +184,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     {
         const v2 *gTw1 = reinterpret_cast<const v2 *>(a.tw1);
         const v2 *gTw2 = reinterpret_cast<const v2 *>(a.tw2), *gTw3 = reinterpret_cast<const v2 *>(a.tw3);
-        for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = reinterpret_cast<const v2 *>(a.win2)[i];
-        for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = gTw1[i];
+        // pair layout for ds_read_b128: entry (n1, lane) of a [16][64] table sits at
+        // [(n1 >> 1)][lane][n1 & 1], so one 16-byte read returns the rows 2j and 2j + 1 of a lane
+        auto pairIdx = [](int i) { return ((i >> 7) << 7) + ((i & 63) << 1) + ((i >> 6) & 1); };
+        for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64)
+            tabWin[((AFX_V & 2) && !CPLX) ? pairIdx(i) : i] = reinterpret_cast<const v2 *>(a.win2)[i];
+        for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[((AFX_V & 4) && !CPLX) ? pairIdx(i) : i] = gTw1[i];
         for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = gTw3[i];
         for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
         if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = gTw2[threadIdx.x];
@@ -234,7 +238,27 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
     for (; f < fEnd; ++f) {
         v2 v[16];
         // ---- 1. window (samples were fetched during the previous frame) ---------------
-        if constexpr (HAND) {
+        if constexpr (HAND && (AFX_V & 2)) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const unsigned aw = lds_addr(tabWin + 2 * lane);
+            v4f wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) RD128(wv[j], aw, 1024 * j);
+            LDS_WAIT_N(4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                PIN(wv[j]);
+                v[2 * j] = raw[2 * j] * v2{wv[j].x, wv[j].y};
+                v[2 * j + 1] = raw[2 * j + 1] * v2{wv[j].z, wv[j].w};
+            }
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int j = 4; j < 8; ++j) {
+                PIN(wv[j]);
+                v[2 * j] = raw[2 * j] * v2{wv[j].x, wv[j].y};
+                v[2 * j + 1] = raw[2 * j + 1] * v2{wv[j].z, wv[j].w};
+            }
+        } else if constexpr (HAND) {
             const unsigned aw = lds_addr(tabWin + lane);
             v2 wv[16];
 #pragma unroll
@@ -279,7 +303,20 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
             for (int k = 1; k < 16; ++k) t1[k] = tabTw1[k * 64 + lane];
         }
         dft16(v);
-        if constexpr (HAND) {
+        if constexpr (HAND && (AFX_V & 4)) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const unsigned a1 = lds_addr(tabTw1 + 2 * lane);
+            v4f tq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) RD128(tq[j], a1, 1024 * j);
+            lds_wait();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                PIN(tq[j]);
+                t1[2 * j] = v2{tq[j].x, tq[j].y};
+                t1[2 * j + 1] = v2{tq[j].z, tq[j].w};
+            }
+        } else if constexpr (HAND) {
             // requested after the butterflies: held across them they cost 30 live VGPRs and spill
             const unsigned a1 = lds_addr(tabTw1 + lane);
 #pragma unroll
@@ -309,9 +346,26 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_banded(KArgs a) {
         // all twiddles are read in one batch before the butterflies (LDS reads interleaved with
         // the image writes would be serialised one round trip at a time: same array, may alias)
         dft16(v);
+        if constexpr (HAND && (AFX_V & 8)) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const unsigned a2 = lds_addr(tabTw2 + m2 * 16);
+            v4f tq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) RD128(tq[j], a2, 16 * j);
+            lds_wait();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) PIN(tq[j]);
+            ex[m2 * 260 + k1] = v[0];
+#pragma unroll
+            for (int j1 = 1; j1 < 16; ++j1) {
+                const v2 tw = (j1 & 1) ? v2{tq[j1 >> 1].z, tq[j1 >> 1].w} : v2{tq[j1 >> 1].x, tq[j1 >> 1].y};
+                ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], tw);
+            }
+        } else {
         ex[m2 * 260 + k1] = v[0];
 #pragma unroll
         for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], tabTw2[m2 * 16 + j1]);
+        }
         wave_lds_sync();
 
         // ---- 3. last radix-4 + real-input split -> spectrum values in registers -------
@@ -924,6 +978,7 @@ struct Plan {
     int variant;
     int num;
     int split;  // slots hold row segments (AfxBandPlan.split)
+    void *v2;   // real-result kernel of afx_melfused2.hip (this file keeps the complex-result modes)
     float2 *dWin2, *dTw1, *dTw2, *dTw3;
     float *dWLane;
     int *dMeta;
@@ -974,12 +1029,13 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.outIm = a->outIm;
     k.num = p->num;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
-    static bool attrSet = false;
-    if (!attrSet) {
+    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev]) {
         AFX_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void *>(k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX, SPLIT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet = true;
+        attrSet[attrDev] = true;
     }
     hipLaunchKernelGGL((k_stft_mel_banded<TA, TB, GENERAL, SHIFT, CPLX, SPLIT>), dim3((unsigned)blocks),
                        dim3(WAVES * 64), lds, (hipStream_t)stream, k);
@@ -1021,11 +1077,12 @@ int launch_pair(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.outIm = nullptr;
     k.num = p->num;
     constexpr size_t lds = (size_t)pair_block_lds_bytes(TA, TB);
-    static bool attrSet = false;
-    if (!attrSet) {
+    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev]) {
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_pair<TA, TB, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet = true;
+        attrSet[attrDev] = true;
     }
     hipLaunchKernelGGL((k_stft_mel_pair<TA, TB, true>), dim3((unsigned)blocks), dim3(PWAVES * 64), lds,
                        (hipStream_t)stream, k);
@@ -1065,6 +1122,11 @@ int upload(T **dptr, const void *src, size_t bytes, void *stream) {
 }
 
 }  // namespace
+
+// real-result modes at n_fft = 2048: afx_melfused2.hip
+extern "C" int afxk_mel2_create(void **plan, int variant, const float *hWindow, const AfxBandPlan *band, void *stream);
+extern "C" int afxk_mel2_run(void *plan, const AfxMelFusedArgs *a, void *stream);
+extern "C" void afxk_mel2_destroy(void *plan);
 
 // n_fft = 1024 lives in afx_melfused1k.hip; its plans carry variant numbers >= 100
 extern "C" int afxk_mel1k_variant(int tapsA, int tapsB);
@@ -1109,6 +1171,7 @@ extern "C" void afxk_melfused_destroy(void *plan) {
         afxk_mel1k_destroy(plan);
         return;
     }
+    afxk_mel2_destroy(p->v2);
     afxdev_free(p->dWin2);
     afxdev_free(p->dTw1);
     afxdev_free(p->dTw2);
@@ -1179,6 +1242,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     if (st == AFX_OK) st = upload(&p->dWLane, wL, sizeof(float) * (size_t)64 * WP, stream);
     if (st == AFX_OK) st = upload(&p->dMeta, meta, sizeof(meta), stream);
     if (st == AFX_OK) st = afxdev_stream_sync(stream);  // host staging buffers are freed below
+    if (st == AFX_OK) st = afxk_mel2_create(&p->v2, variant, hWindow, band, stream);
     free(tw1);
     free(tw2);
     free(tw3);
@@ -1196,6 +1260,8 @@ extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *str
     if (!p) return AFX_ERR_ARG;
     if (p->variant >= 200) return afxk_mel4k_run(plan, a, stream);
     if (p->variant >= 100) return afxk_mel1k_run(plan, a, stream);
+    if (a->specMap < 3 && !getenv("AFX_MEL_V1")) return afxk_mel2_run(p->v2, a, stream);
+    if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;
     switch (p->variant) {
         case 0:
             return p->split ? launch<48, 16, true>(p, a, stream) : launch<48, 16>(p, a, stream);

@@ -1,0 +1,738 @@
+// afx_melfused2.hip -- the headline kernel, round-2 form: framed STFT -> |S|^2 (or |S|,
+// |S|^2p) -> banded filter bank (-> log10 -> DCT-II cepstra), one 64-lane wave per 2048-sample
+// frame, real results.  Same algorithm and summation orders as k_stft_mel_banded
+// (afx_melfused.hip, which keeps the complex-result instantiations); what changed is how the
+// wave talks to the LDS and what it no longer computes twice:
+//
+//   * every constant table is laid out for 16-byte reads: window and W_1024 twiddles as
+//     [(n1 >> 1)][lane][n1 & 1] (one ds_read_b128 = two rows), W_64 rows contiguous, the
+//     W_2048 split twiddles per lane [s][lane][m]                       (46 -> 22 table reads)
+//   * exchange 1: row pitch 72 float2, writer lane 4 m1 + m2 stores at column
+//     8 (m1 >> 1) + 2 m2 + (m1 & 1): the reader takes (m1, m1 + 1) with one ds_read_b128;
+//     exchange 2: image V[q][m2] (m2 fastest; 16-byte halves swapped when bit 3 of q is set:
+//     conflict-free without padding), a lane's four radix-4 inputs are two ds_read_b128;
+//     rows are written two at a time with ds_write2_b64            (64 -> 32 exchange ops)
+//   * 513 conjugate pairs on 512 slots: lane 0's mirror side reads the self-mirrored base
+//     q = 128 instead of q = 0, its slots 2 / 3 become the pairs (128, 896) / (384, 640) and
+//     bin 512 is |Z[512]|^2 directly -- no lane runs the "centre" butterflies any more
+//     (28 VALU + 6 LDS reads per frame that only lane 0's results were kept of)
+//   * the power row goes out with ds_write2st64_b32 (bins k, k + 256 in one instruction), its
+//     zero pad sits behind the exchange images and is written once per launch
+//   * cepstra in the same launch (CC): every 16 frames the wave re-reads its own 16 mel rows
+//     (L2-resident), takes log10 and runs 32 v_mfma_f32_16x16x4_f32 against the DCT rows held
+//     in LDS -- the matrix pipe is otherwise idle in this kernel, the second launch and its
+//     478 MB re-read of mel from HBM disappear (xxcc_algorithm.c:124-155)
+//   * temporal features (TEMPORAL): energy / rms / zero-crossing rate of the windowed frame
+//     as wave reductions (temporal_algorithm.c:138-144), so isTemporal objects stay on this kernel
+//
+// Index algebra and LDS bank behaviour of every access class: tools/proto_fft1024_v2.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "afx_device.h"
+#include "afx_hipcheck.h"
+#include "afx_pkmath.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int NFFT = 2048;
+constexpr int MC = 1024;
+constexpr int WAVES = 12;                    // one workgroup per CU, 3 waves per SIMD
+constexpr int P1 = 72;                       // float2 per row of the exchange-1 image
+constexpr int PROW_OFF = 5120;               // byte offset of the power row in a wave's region
+constexpr int PROW_F = 1104;                 // 1025 bins + zero pad for the fixed-length band loops
+constexpr int WAVE_LDS = PROW_OFF + PROW_F * 4;  // 9536: pad [9220, 9536) lies behind both images
+static_assert(16 * P1 * 8 <= PROW_OFF + 1025 * 4, "exchange image must end before the zero pad");
+// table blob, byte offsets (built on the host by afxk_mel2_create, copied to LDS per workgroup)
+constexpr int T_WIN = 0;                     // [8][64] float4: (w[2n], w[2n+1]) of rows n1 = 2j, 2j + 1
+constexpr int T_TW1 = 8192;                  // [8][64] float4: W_1024^(lane k1), k1 = 2j, 2j + 1
+constexpr int T_TW2 = 16384;                 // [4][16] float2: W_64^(m2 j1)
+constexpr int T_TW3 = 16896;                 // [2][64][4] float2: 0.5 W_2048^bin of slot (s, lane, m)
+constexpr int T_BAND = 20992;                // [64][WP] floats: lane-major band weights, A then B taps
+__host__ __device__ constexpr int wpitch(int ta, int tb) { return ta + tb + 4; }
+__host__ __device__ constexpr int tab_bytes(int ta, int tb) { return T_BAND + 64 * wpitch(ta, tb) * 4; }
+constexpr int DCT_PITCH = 36;                // floats per lane of the DCT operand table (9 x 16 B: conflict-free b128)
+__host__ __device__ constexpr int block_lds_bytes(int ta, int tb, bool cc) {
+    return tab_bytes(ta, tb) + (cc ? 64 * DCT_PITCH * 4 : 0) + WAVES * WAVE_LDS;
+}
+
+struct KArgs2 {
+    const float *x;
+    long long clipStride;
+    long long totalFrames;
+    int timeLength, hop;
+    int framesPerWave;
+    int aligned;           // frame starts are 8-byte aligned -> float2 loads
+    const float4 *tab;     // table blob
+    const int *meta;       // [6][64]: startA, startB, rowA, rowB, segIdx lo / hi
+    int specMap, postPow;
+    float normValue;
+    float *out;            // [totalFrames, num]
+    int num;
+    // CC
+    const float *dct;      // device [num, num] orthonormal DCT-II (row = coefficient)
+    int ccNum;
+    float *cc;             // [totalFrames, ccNum]
+    // TEMPORAL
+    float *energy, *rms, *zcr;  // [totalFrames]
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
+#define RD64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+// two rows with one instruction; offsets in units of 8 bytes (<= 255)
+#define WR2_64(addr, d0, d1, o0, o1) \
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
+// two dwords 64-dword units apart; offsets in units of 256 bytes (<= 255)
+#define WR2ST_32(addr, d0, d1, o0, o1) \
+    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
+#define PIN(x) asm volatile("" : "+v"(x))
+#define LDS_WAIT_N(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+
+// Orders this wave's LDS stores before its later LDS loads of other lanes' data: DS operations of
+// one wave execute in issue order, lgkmcnt(0) drains them, the wave barrier pins the compiler.
+// Deliberately NOT a fence (that would also drain vmcnt: the prefetch and the previous stores).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ v2 lo2(v4f q) { return v2{q.x, q.y}; }
+__device__ __forceinline__ v2 hi2(v4f q) { return v2{q.z, q.w}; }
+
+// |X|^2 of the conjugate pair (k, 1024-k) from A = Z[k], B = Z[1024-k], w = 0.5 W_2048^k
+__device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w, float &pk, float &pq) {
+    const v2 e2 = pk_add_conj(A, B);   // 2 E
+    const v2 d = pk_sub_conj(A, B);    // 2 i O
+    const v2 wo = cmul_mi(d, w);       // W O
+    const v2 x = e2 * 0.5f + wo;       // X[k]
+    const v2 y = e2 * 0.5f - wo;       // conj(X[1024-k])
+    pk = x.x * x.x + x.y * x.y;
+    pq = y.x * y.x + y.y * y.y;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// SHIFT: hop = 128 * SHIFT samples -> the next frame's register image is this one moved down by
+//   SHIFT registers, only SHIFT new float2 per lane are fetched (0: every frame fetched whole)
+// SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split)
+// CC: cepstra of the rows in the same launch (num = 128, ccNum <= 16, log10 rectification)
+// TEMPORAL: energy / rms / zcr of the windowed frame
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL>
+__global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr int WP = wpitch(TA, TB);
+    constexpr int TABB = tab_bytes(TA, TB);
+    constexpr int DCTB = CC ? 64 * DCT_PITCH * 4 : 0;
+    unsigned char *wreg = smem + TABB + DCTB + wave * WAVE_LDS;
+    float *prow = reinterpret_cast<float *>(wreg + PROW_OFF);
+
+    // ---- workgroup-shared tables -> LDS (once) -------------------------------------------
+    {
+        float4 *s4 = reinterpret_cast<float4 *>(smem);
+        for (int i = threadIdx.x; i < TABB / 16; i += WAVES * 64) s4[i] = a.tab[i];
+        if constexpr (CC) {
+            // B operand of the cepstrum MFMAs: lane (coefficient fi = lane & 15, k-slot g = lane >> 4)
+            // holds dct[fi][16 u + 4 g + c] at [lane][4 u + c]
+            float *tabD = reinterpret_cast<float *>(smem + TABB);
+            for (int i = threadIdx.x; i < 64 * 32; i += WAVES * 64) {
+                const int l = i >> 5, e = i & 31;
+                const int fi = l & 15, g = l >> 4;
+                tabD[l * DCT_PITCH + e] =
+                    fi < a.ccNum ? a.dct[(long long)fi * a.num + 16 * (e >> 2) + 4 * g + (e & 3)] : 0.f;
+            }
+        }
+        for (int i = 1025 + lane; i < PROW_F; i += 64) prow[i] = 0.f;  // zero pad, never overwritten
+    }
+    __syncthreads();
+
+    // ---- per-lane constants (loop-invariant LDS byte addresses) -----------------------------
+    const int k1 = lane >> 2, m2 = lane & 3;
+    const unsigned T0 = lds_addr(smem), W0 = lds_addr(wreg);
+    const unsigned aWin = T0 + T_WIN + 16 * lane;                      // + 1024 j; W_1024 at + T_TW1
+    const unsigned aTw2 = T0 + T_TW2 + 128 * m2;                       // + 16 j
+    const unsigned aE1w = W0 + 8 * (8 * (k1 >> 1) + 2 * m2 + (k1 & 1));  // writer m1 = lane >> 2; row k: + 576 k
+    const unsigned aE1r = W0 + 576 * k1 + 16 * m2;                     // pair jj: + 64 jj
+    const unsigned aE2w = W0 + 32 * k1 + 16 * ((m2 >> 1) ^ ((k1 >> 3) & 1)) + 8 * (m2 & 1);  // j1: + 512 j1
+    const int b3l = (lane >> 3) & 1;
+    const unsigned aAlo = W0 + 32 * lane + 16 * b3l, aAhi = W0 + 32 * lane + 16 * (1 - b3l);  // s = 1: + 2048
+    const int qm0 = lane == 0 ? 128 : 256 - lane, qm1 = 192 - lane;
+    const unsigned aB0lo = W0 + 32 * qm0 + 16 * ((qm0 >> 3) & 1), aB0hi = W0 + 32 * qm0 + 16 * (1 - ((qm0 >> 3) & 1));
+    const unsigned aB1lo = W0 + 32 * qm1 + 16 * ((qm1 >> 3) & 1), aB1hi = W0 + 32 * qm1 + 16 * (1 - ((qm1 >> 3) & 1));
+    const unsigned aT3lo = T0 + T_TW3 + 32 * lane + 16 * b3l, aT3hi = T0 + T_TW3 + 32 * lane + 16 * (1 - b3l);
+    const unsigned R = W0 + PROW_OFF;
+    const unsigned aP01 = R + 4 * lane;                                // bins k, k + 256 | 64 + k ... by offsets
+    const unsigned aP23 = R + 4 * (lane == 0 ? 128 : lane + 512);      // (k + 512, k + 768) | lane 0: (128, 384)
+    const unsigned aQs1 = R + 4 * (192 - lane);                        // 1024 - bin of s = 1 slots; s = 0 slots 1, 0 at + 9, + 13
+    const unsigned aQ23 = R + 4 * (lane == 0 ? 640 : 256 - lane);      // s = 0 slots 3, 2 | lane 0: (640, 896)
+    const bool lane0 = (lane == 0);
+
+    const int startA = a.meta[lane], startB = a.meta[64 + lane];
+    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const unsigned seg0 = SPLIT ? (unsigned)a.meta[256 + lane] : 0u, seg1 = SPLIT ? (unsigned)a.meta[320 + lane] : 0u;
+    const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
+    const unsigned awr = T0 + T_BAND + 4 * WP * lane;
+
+    const long long gw = (long long)blockIdx.x * WAVES + wave;
+    long long f = gw * a.framesPerWave;
+    long long fEnd = f + a.framesPerWave;
+    if (fEnd > a.totalFrames) fEnd = a.totalFrames;
+    if (f >= fEnd) return;
+    int clip = (int)(f / a.timeLength);
+    int t = (int)(f - (long long)clip * a.timeLength);
+    int ccN = 0;  // frames of this wave whose cepstra are still to be formed
+
+    // raw samples of the frame about to be transformed: raw[n1] = (x[2n], x[2n+1]), n = 64 n1 + lane
+    v2 raw[16];
+    auto fetch = [&](const float *px, int first) {
+        if (a.aligned) {
+            const v2 *p2 = reinterpret_cast<const v2 *>(px);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1)
+                if (n1 >= first) raw[n1] = p2[64 * n1 + lane];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1)
+                if (n1 >= first) {
+                    const int n = 64 * n1 + lane;
+                    raw[n1] = v2{px[2 * n], px[2 * n + 1]};
+                }
+        }
+    };
+    fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
+
+    // ---- cepstra of `cnt` (<= 16) consecutive rows fb.. of this wave: C[16 frames, 16 coefficients] =
+    //      log10(max(rows, 1e-8)) . D^T with v_mfma_f32_16x16x4_f32.  Lane (fi = lane & 15, g = lane >> 4)
+    //      loads float4 row[fb + fi][16 u + 4 g ..] (k-slot g of MFMA (u, c) stands for band 16 u + 4 g + c),
+    //      the matching DCT elements come from the LDS table.  Called one frame AFTER the 16th row was
+    //      stored, so the s_waitcnt finds those stores long complete; reads bypass the CU's L1.
+    auto cc_block = [&](long long fb, int cnt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores -> L2 (vmcnt counts stores on gfx9)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // keep this block's per-lane values out of the frame loop's registers
+        const int fi = ln & 15, g = ln >> 4;
+        const long long r = fb + (fi < cnt ? fi : cnt - 1);  // tail: duplicate the last row, not stored
+        const v4f *src = reinterpret_cast<const v4f *>(a.out + r * 128) + g;
+        const unsigned ad = T0 + TABB + 4 * DCT_PITCH * ln;
+        v4f acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        constexpr float LOG10_2 = 0.30102999566398120f;
+        // two halves of the 128 bands: 32 + 16 live registers instead of 64 + 16 (the frame loop
+        // keeps the next frame's 32 prefetch registers alive across this block)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v4f av[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)  // sc1: served by the L2, never by this CU's L1
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(av[u]) : "v"(src + 4 * (4 * h + u)) : "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) RD128(dv[u], ad, 16 * (4 * h + u));
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) PIN(av[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) PIN(dv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // log10f(max(x, 1e-8)) (xxcc_algorithm.c:131-137) as v_log_f32 * log10(2); four
+                    // independent accumulator chains (a dependent f32 MFMA waits 40 cycles)
+                    const float lg = __log2f(fmaxf(av[u][c], 1e-8f)) * LOG10_2;
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(lg, dv[u][c], acc[c], 0, 0, 0);
+                }
+            }
+        }
+        const v4f sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        // C layout: column (coefficient) = lane & 15, row (frame) = 4 (lane >> 4) + reg
+        if (fi < a.ccNum) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr = 4 * g + reg;
+                if (rr < cnt) a.cc[(fb + rr) * a.ccNum + fi] = sum[reg];
+            }
+        }
+        ccN -= cnt;
+    };
+
+    for (; f < fEnd; ++f) {
+        v2 v[16];
+        // ---- 1. window: 8 x 16 bytes per lane, the first half is used while the second lands ----
+        {
+            v4f wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) RD128(wv[j], aWin, T_WIN + 1024 * j);
+            LDS_WAIT_N(4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                PIN(wv[j]);
+                v[2 * j] = raw[2 * j] * lo2(wv[j]);
+                v[2 * j + 1] = raw[2 * j + 1] * hi2(wv[j]);
+            }
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int j = 4; j < 8; ++j) {
+                PIN(wv[j]);
+                v[2 * j] = raw[2 * j] * lo2(wv[j]);
+                v[2 * j + 1] = raw[2 * j + 1] * hi2(wv[j]);
+            }
+        }
+        // ---- 1b. start fetching the next frame: in flight under the whole transform ---------
+        if (f + 1 < fEnd) {
+            int tn = t + 1, cn = clip;
+            if (tn == a.timeLength) {
+                tn = 0;
+                ++cn;
+            }
+            const float *pn = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
+            if (SHIFT > 0 && tn != 0) {
+#pragma unroll
+                for (int n1 = 0; n1 + SHIFT < 16; ++n1) raw[n1] = raw[n1 + SHIFT];
+                fetch(pn, 16 - SHIFT);
+            } else {
+                fetch(pn, 0);
+            }
+        }
+        // ---- 1c. temporal features of the windowed frame (temporal_algorithm.c:138-144) -------
+        if constexpr (TEMPORAL) {
+            // sample order: n = 64 n1 + lane, (x, y) = samples 2n, 2n + 1; the sample before 2n is the
+            // y of the previous lane (n1 unchanged) or, for lane 0, the y of lane 63 at n1 - 1
+            float e = 0.f, z = 0.f;
+            float prevTop = 0.f;  // y of lane 63 at n1 - 1, wave-uniform
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                e = fmaf(v[n1].x, v[n1].x, e);
+                e = fmaf(v[n1].y, v[n1].y, e);
+                float py = __shfl_up(v[n1].y, 1, 64);
+                if (lane0) py = prevTop;
+                const bool first = (n1 == 0) && lane0;  // sample 0 has no predecessor
+                if (!first && v[n1].x * py < 0.f) z += 1.f;
+                if (v[n1].y * v[n1].x < 0.f) z += 1.f;
+                prevTop = __shfl(v[n1].y, 63, 64);
+            }
+            e = wave_sum(e);
+            z = wave_sum(z);
+            if (lane0) {
+                a.energy[f] = e;
+                a.rms[f] = sqrtf(e / (float)NFFT);
+                a.zcr[f] = (float)((double)z / (double)NFFT);
+            }
+        }
+
+        // ---- 2a. radix-16 over n1, twiddle W_1024^(lane k1), transpose through LDS -----------
+        dft16(v);
+        {
+            v4f tq[8];  // requested after the butterflies: held across them they would spill
+#pragma unroll
+            for (int j = 0; j < 8; ++j) RD128(tq[j], aWin, T_TW1 + 1024 * j);
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) PIN(tq[j]);
+            v2 o[16];
+            o[0] = v[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) o[k] = cmul(v[rev4(k)], (k & 1) ? hi2(tq[k >> 1]) : lo2(tq[k >> 1]));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned b = aE1w + 2304 * g;  // rows 4g .. 4g+3, 576 bytes = 72 units apart
+                WR2_64(b, o[4 * g], o[4 * g + 1], 0, 72);
+                WR2_64(b, o[4 * g + 2], o[4 * g + 3], 144, 216);
+            }
+        }
+        wave_lds_sync();
+        {
+            v4f rq[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) RD128(rq[jj], aE1r, 64 * jj);
+            wave_lds_sync();
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                PIN(rq[jj]);
+                v[2 * jj] = lo2(rq[jj]);
+                v[2 * jj + 1] = hi2(rq[jj]);
+            }
+        }
+
+        // ---- 2b. radix-16 over m1, twiddle W_64^(m2 j1) -> image V[q = k1 + 16 j1][m2] --------
+        dft16(v);
+        {
+            v4f tq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) RD128(tq[j], aTw2, 16 * j);
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) PIN(tq[j]);
+            v2 o[16];
+            o[0] = v[0];
+#pragma unroll
+            for (int j1 = 1; j1 < 16; ++j1) o[j1] = cmul(v[rev4(j1)], (j1 & 1) ? hi2(tq[j1 >> 1]) : lo2(tq[j1 >> 1]));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned b = aE2w + 2048 * g;  // j1 = 4g .. 4g+3, 512 bytes = 64 units apart
+                WR2_64(b, o[4 * g], o[4 * g + 1], 0, 64);
+                WR2_64(b, o[4 * g + 2], o[4 * g + 3], 128, 192);
+            }
+        }
+        wave_lds_sync();
+
+        // ---- 3. last radix-4 + real-input split -> spectrum values in registers --------------
+        float pk[2][4], pq[2][4], p512;
+        {
+            v4f zalo[2], zahi[2], zblo[2], zbhi[2], wlo[2], whi[2];
+            RD128(zalo[0], aAlo, 0);
+            RD128(zahi[0], aAhi, 0);
+            RD128(zblo[0], aB0lo, 0);
+            RD128(zbhi[0], aB0hi, 0);
+            RD128(wlo[0], aT3lo, 0);
+            RD128(whi[0], aT3hi, 0);
+            RD128(zalo[1], aAlo, 2048);
+            RD128(zahi[1], aAhi, 2048);
+            RD128(zblo[1], aB1lo, 0);
+            RD128(zbhi[1], aB1hi, 0);
+            RD128(wlo[1], aT3lo, 2048);
+            RD128(whi[1], aT3hi, 2048);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s == 0) LDS_WAIT_N(6);
+                else LDS_WAIT_N(0);
+                PIN(zalo[s]); PIN(zahi[s]); PIN(zblo[s]); PIN(zbhi[s]); PIN(wlo[s]); PIN(whi[s]);
+                v2 za0 = lo2(zalo[s]), za1 = hi2(zalo[s]), za2 = lo2(zahi[s]), za3 = hi2(zahi[s]);
+                v2 zb0 = lo2(zblo[s]), zb1 = hi2(zblo[s]), zb2 = lo2(zbhi[s]), zb3 = hi2(zbhi[s]);
+                dft4(za0, za1, za2, za3);  // Z[q + 256 j]
+                dft4(zb0, zb1, zb2, zb3);  // Z[q' + 256 j], q' the mirror base (lane 0, s = 0: 128)
+                v2 A0 = za0, A1 = za1, A2 = za2, A3 = za3;
+                v2 B0 = zb3, B1 = zb2, B2 = zb1, B3 = zb0;  // partner of Z[q + 256 j] is Z[q' + 256 (3 - j)]
+                if (s == 0) {
+                    // lane 0: q = 0 mirrors itself and q' = 128 mirrors itself:
+                    // (Z0, Z0) -> bins 0, 1024; (Z256, Z768); (Z128, Z896); (Z384, Z640); bin 512 below
+                    p512 = za2.x * za2.x + za2.y * za2.y;
+                    A2 = lane0 ? zb0 : za2;
+                    A3 = lane0 ? zb1 : za3;
+                    B0 = lane0 ? za0 : zb3;
+                    B1 = lane0 ? za3 : zb2;
+                    B2 = lane0 ? zb3 : zb1;
+                    B3 = lane0 ? zb2 : zb0;
+                }
+                split_pair(A0, B0, lo2(wlo[s]), pk[s][0], pq[s][0]);
+                split_pair(A1, B1, hi2(wlo[s]), pk[s][1], pq[s][1]);
+                split_pair(A2, B2, lo2(whi[s]), pk[s][2], pq[s][2]);
+                split_pair(A3, B3, hi2(whi[s]), pk[s][3], pq[s][3]);
+            }
+        }
+        if (a.specMap == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pk[i >> 2][i & 3] = sqrtf(pk[i >> 2][i & 3]);
+                pq[i >> 2][i & 3] = sqrtf(pq[i >> 2][i & 3]);
+            }
+            p512 = sqrtf(p512);
+        } else if (a.specMap == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pk[i >> 2][i & 3] = powf(pk[i >> 2][i & 3], a.normValue);
+                pq[i >> 2][i & 3] = powf(pq[i >> 2][i & 3], a.normValue);
+            }
+            p512 = powf(p512, a.normValue);
+        }
+        // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
+        WR2ST_32(aP01, pk[0][0], pk[0][1], 0, 4);
+        WR2ST_32(aP23, pk[0][2], pk[0][3], 0, 4);
+        WR2ST_32(aP01, pk[1][0], pk[1][1], 1, 5);
+        WR2ST_32(aP01, pk[1][2], pk[1][3], 9, 13);
+        WR2ST_32(aQs1, pq[0][1], pq[0][0], 9, 13);
+        WR2ST_32(aQ23, pq[0][3], pq[0][2], 0, 4);
+        WR2ST_32(aQs1, pq[1][3], pq[1][2], 0, 4);
+        WR2ST_32(aQs1, pq[1][1], pq[1][0], 8, 12);
+        if (lane0) prow[512] = p512;
+        wave_lds_sync();
+
+        // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset
+        //         ds_read_b64 (conflict-free by the plan's bank-aware lane assignment); the NEXT
+        //         block of four quads is requested before this block's values are waited for --------
+        float accA, accB;
+        {
+            constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 4, NB = (QT + BLK - 1) / BLK;
+            v2 sA = {0.f, 0.f}, sB = {0.f, 0.f};
+            v4f w[2][BLK];
+            v2 p0[2][BLK], p1[2][BLK];
+            auto request = [&](int blk, v4f (&wq)[BLK], v2 (&q0v)[BLK], v2 (&q1v)[BLK]) {
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const int q = blk * BLK + i;
+                    if (q >= QT) continue;
+                    RD128(wq[i], awr, 16 * q);
+                    if (q < QA) {
+                        RD64(q0v[i], apa, 16 * q);
+                        RD64(q1v[i], apa, 16 * q + 8);
+                    } else {
+                        RD64(q0v[i], apb, 16 * (q - QA));
+                        RD64(q1v[i], apb, 16 * (q - QA) + 8);
+                    }
+                }
+            };
+            request(0, w[0], p0[0], p1[0]);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int cur = blk & 1;
+                const int nextQuads = (blk + 1 < NB) ? ((QT - (blk + 1) * BLK) < BLK ? (QT - (blk + 1) * BLK) : BLK) : 0;
+                if (blk + 1 < NB) request(blk + 1, w[cur ^ 1], p0[cur ^ 1], p1[cur ^ 1]);
+                if (nextQuads == 4) LDS_WAIT_N(12);
+                else if (nextQuads == 3) LDS_WAIT_N(9);
+                else if (nextQuads == 2) LDS_WAIT_N(6);
+                else if (nextQuads == 1) LDS_WAIT_N(3);
+                else LDS_WAIT_N(0);
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    if (blk * BLK + i >= QT) continue;
+                    PIN(w[cur][i]);
+                    PIN(p0[cur][i]);
+                    PIN(p1[cur][i]);
+                    const int q = blk * BLK + i;
+                    if (q < QA) {
+                        sA += lo2(w[cur][i]) * p0[cur][i];
+                        sA += hi2(w[cur][i]) * p1[cur][i];
+                    } else {
+                        sB += lo2(w[cur][i]) * p0[cur][i];
+                        sB += hi2(w[cur][i]) * p1[cur][i];
+                    }
+                }
+            }
+            accA = sA.x + sA.y;
+            accB = sB.x + sB.y;
+        }
+        if (!SPLIT && a.postPow) {
+            accA = powf(accA, a.normValue);
+            accB = powf(accB, a.normValue);
+        }
+        // ---- 5. store (first the cepstra of the 16 rows stored before this one, if that many wait) ----
+        if constexpr (CC) {
+            if (ccN == 16) cc_block(f - 16, 16);
+        }
+        float *orow = a.out + f * a.num;
+        if constexpr (SPLIT) {
+            // slot results -> LDS (start of the wave's region: the image there is dead since stage 3),
+            // then every row is the sum of its segments in ascending bins
+            float *part = reinterpret_cast<float *>(wreg);
+            part[lane] = accA;
+            part[64 + lane] = accB;
+            if (lane0) part[128] = 0.f;
+            wave_lds_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned u = h ? seg1 : seg0;
+                float sum = part[u & 255u] + part[(u >> 8) & 255u];
+                sum += part[(u >> 16) & 255u];
+                sum += part[u >> 24];
+                if (a.postPow) sum = powf(sum, a.normValue);
+                if (lane + 64 * h < a.num) orow[lane + 64 * h] = sum;
+            }
+        } else {
+            if (rowA >= 0) orow[rowA] = accA;
+            if (rowB >= 0) orow[rowB] = accB;
+        }
+        if constexpr (CC) {
+            ++ccN;
+            if (f + 1 == fEnd) cc_block(f + 1 - ccN, ccN);  // the wave's last rows (drains its last stores)
+        }
+        wave_lds_sync();  // the next frame overwrites the images / the power row
+
+        if (++t == a.timeLength) {
+            t = 0;
+            ++clip;
+        }
+    }
+}
+
+struct Plan2 {
+    int variant, num, split;
+    float4 *dTab;
+    int *dMeta;
+};
+struct Variant {
+    int tapsA, tapsB;
+};
+constexpr Variant kVariants[] = {{48, 16}, {72, 32}};
+
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL>
+int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    if (total <= 0) return AFX_OK;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // one 12-wave workgroup is resident per CU; two rounds of workgroups keep the tail short while each
+    // wave still streams a long contiguous run of frames (and re-uses 3/4 of every frame from registers)
+    long long waves = (long long)cus * WAVES * 2;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 16) fpw = 16;
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+
+    KArgs2 k;
+    memset(&k, 0, sizeof(k));
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.aligned = ((a->clipStride & 1) == 0) && ((a->hop & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
+    k.tab = p->dTab;
+    k.meta = p->dMeta;
+    k.specMap = a->specMap;
+    k.postPow = a->postPow;
+    k.normValue = a->normValue;
+    k.out = a->out;
+    k.num = p->num;
+    k.dct = a->dct;
+    k.ccNum = a->ccNum;
+    k.cc = a->cc;
+    k.energy = a->energy;
+    k.rms = a->rms;
+    k.zcr = a->zcr;
+    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB, CC);
+    static_assert(lds <= 163840, "workgroup LDS budget");
+    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev]) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet[attrDev] = true;
+    }
+    hipLaunchKernelGGL((k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_mel_v2");
+    return AFX_OK;
+}
+
+template <int TA, int TB, bool SPLIT, bool CC, bool TEMPORAL>
+int launch_hop(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
+    // register re-use of the overlapping frames for hop = 128 * SHIFT: N/8, N/4, N/2
+    switch (a->hop) {
+        case 256: return launch_variant<TA, TB, 2, SPLIT, CC, TEMPORAL>(p, a, stream);
+        case 512: return launch_variant<TA, TB, 4, SPLIT, CC, TEMPORAL>(p, a, stream);
+        case 1024: return launch_variant<TA, TB, 8, SPLIT, CC, TEMPORAL>(p, a, stream);
+        default: return launch_variant<TA, TB, 0, SPLIT, CC, TEMPORAL>(p, a, stream);
+    }
+}
+
+template <int TA, int TB>
+int launch(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
+    const bool cc = a->cc != nullptr, tmp = a->energy != nullptr;
+    if (cc && tmp) return AFX_ERR_UNSUPPORTED;  // callers run the cepstra separately for temporal objects
+    if (cc) {
+        if (p->split || p->num != 128 || a->ccNum < 1 || a->ccNum > 16 || !a->dct || !a->out) return AFX_ERR_UNSUPPORTED;
+        if (block_lds_bytes(TA, TB, true) > 163840) return AFX_ERR_UNSUPPORTED;
+        if constexpr (block_lds_bytes(TA, TB, true) <= 163840) return launch_hop<TA, TB, false, true, false>(p, a, stream);
+        return AFX_ERR_UNSUPPORTED;
+    }
+    if (tmp) {
+        if (!a->rms || !a->zcr) return AFX_ERR_ARG;
+        return p->split ? launch_hop<TA, TB, true, false, true>(p, a, stream)
+                        : launch_hop<TA, TB, false, false, true>(p, a, stream);
+    }
+    return p->split ? launch_hop<TA, TB, true, false, false>(p, a, stream)
+                    : launch_hop<TA, TB, false, false, false>(p, a, stream);
+}
+
+}  // namespace
+
+extern "C" void afxk_mel2_destroy(void *plan) {
+    Plan2 *p = static_cast<Plan2 *>(plan);
+    if (!p) return;
+    afxdev_free(p->dTab);
+    afxdev_free(p->dMeta);
+    free(p);
+}
+
+// variant: index into {48+16, 72+32} taps (afxk_melfused_variant for radix2Exp 11)
+extern "C" int afxk_mel2_create(void **plan, int variant, const float *hWindow, const AfxBandPlan *band, void *stream) {
+    *plan = nullptr;
+    if (variant < 0 || variant > 1) return AFX_ERR_UNSUPPORTED;
+    const int TA = kVariants[variant].tapsA, TB = kVariants[variant].tapsB;
+    const int WP = wpitch(TA, TB);
+    const size_t bytes = (size_t)tab_bytes(TA, TB);
+    Plan2 *p = static_cast<Plan2 *>(calloc(1, sizeof(Plan2)));
+    float *tab = static_cast<float *>(calloc(bytes, 1));
+    if (!p || !tab) {
+        free(p);
+        free(tab);
+        return AFX_ERR_NOMEM;
+    }
+    p->variant = variant;
+    p->num = band->num;
+    p->split = band->split;
+    const double PI = 3.14159265358979323846;
+    // window and W_1024^(lane k1) in pair layout: entry (n1, lane) at float2 index 128 (n1 >> 1) + 2 lane + (n1 & 1)
+    float *win = tab + T_WIN / 4, *tw1 = tab + T_TW1 / 4, *tw2 = tab + T_TW2 / 4, *tw3 = tab + T_TW3 / 4;
+    for (int n1 = 0; n1 < 16; ++n1)
+        for (int l = 0; l < 64; ++l) {
+            const int at = 2 * (128 * (n1 >> 1) + 2 * l + (n1 & 1));
+            const int n = 64 * n1 + l;
+            win[at] = hWindow[2 * n];
+            win[at + 1] = hWindow[2 * n + 1];
+            const double ang = -2.0 * PI * (double)(n1 * l) / MC;  // twiddles in double, rounded once
+            tw1[at] = (float)cos(ang);
+            tw1[at + 1] = (float)sin(ang);
+        }
+    for (int m = 0; m < 4; ++m)
+        for (int j = 0; j < 16; ++j) {
+            const double ang = -2.0 * PI * (double)(m * j) / 64.0;
+            tw2[2 * (m * 16 + j)] = (float)cos(ang);
+            tw2[2 * (m * 16 + j) + 1] = (float)sin(ang);
+        }
+    // 0.5 W_2048^bin of the P-bin of slot (s, lane, m); 16-byte halves swapped when bit 3 of lane is set
+    for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < 64; ++l)
+            for (int m = 0; m < 4; ++m) {
+                int bin = l + 64 * s + 256 * m;
+                if (s == 0 && l == 0 && m >= 2) bin = m == 2 ? 128 : 384;  // lane 0 carries the self-mirrored base
+                const double ang = -2.0 * PI * (double)bin / NFFT;
+                const int at = 2 * (4 * (64 * s + l) + 2 * ((m >> 1) ^ ((l >> 3) & 1)) + (m & 1));
+                tw3[at] = (float)(0.5 * cos(ang));
+                tw3[at + 1] = (float)(0.5 * sin(ang));
+            }
+    float *wL = tab + T_BAND / 4;
+    for (int l = 0; l < 64; ++l) {
+        for (int t = 0; t < band->tapsA; ++t) wL[(size_t)l * WP + t] = band->wA[(size_t)t * 64 + l];
+        for (int t = 0; t < band->tapsB; ++t) wL[(size_t)l * WP + TA + t] = band->wB[(size_t)t * 64 + l];
+    }
+    int meta[384];
+    for (int l = 0; l < 64; ++l) {
+        meta[l] = band->startA[l];
+        meta[64 + l] = band->startB[l];
+        meta[128 + l] = band->rowA[l];
+        meta[192 + l] = band->rowB[l];
+        meta[256 + l] = (int)band->segIdx[l];
+        meta[320 + l] = (int)band->segIdx[64 + l];
+    }
+    int st = afxdev_malloc(reinterpret_cast<void **>(&p->dTab), bytes);
+    if (st == AFX_OK) st = afxdev_h2d(p->dTab, tab, bytes, stream);
+    if (st == AFX_OK) st = afxdev_malloc(reinterpret_cast<void **>(&p->dMeta), sizeof(meta));
+    if (st == AFX_OK) st = afxdev_h2d(p->dMeta, meta, sizeof(meta), stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(stream);  // host staging buffers are freed below
+    free(tab);
+    if (st != AFX_OK) {
+        afxk_mel2_destroy(p);
+        return st;
+    }
+    *plan = p;
+    return AFX_OK;
+}
+
+// real-result modes only (specMap 0, 1, 2); AFX_ERR_UNSUPPORTED when the requested fusion
+// (cepstra / temporal features) does not apply to this plan
+extern "C" int afxk_mel2_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
+    const Plan2 *p = static_cast<const Plan2 *>(plan);
+    if (!p || a->specMap >= 3) return AFX_ERR_ARG;
+    return p->variant == 0 ? launch<48, 16>(p, a, stream) : launch<72, 32>(p, a, stream);
+}

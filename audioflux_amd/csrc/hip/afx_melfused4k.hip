@@ -425,11 +425,12 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.outIm = a->outIm;
     k.num = p->num;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
-    static bool attrSet = false;
-    if (!attrSet) {
+    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev]) {
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k<TA, TB, SHIFT, CPLX, SPLIT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet = true;
+        attrSet[attrDev] = true;
     }
     hipLaunchKernelGGL((k_stft_band_4k<TA, TB, SHIFT, CPLX, SPLIT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
@@ -568,6 +569,7 @@ extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBan
 }
 
 extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
+    if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;  // fusions exist at n_fft 2048 only
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return AFX_ERR_ARG;
     switch (p->variant) {

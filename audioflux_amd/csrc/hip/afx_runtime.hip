@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 #include "afx_device.h"
@@ -12,9 +13,24 @@
 
 namespace {
 thread_local char g_err[512] = "";
+thread_local int t_err_count = 0;
 std::once_flag g_once;
 int g_init_status = AFX_ERR_NODEVICE;
 char g_init_why[256] = "HIP runtime not initialised";
+int g_device_count = 0;
+// HIP's current device is PER THREAD: the library's device (AFX_DEVICE, afx_set_device) is a
+// process-wide default that every thread adopts on its first call, and every object is tied to
+// the device its stream was created on (afxdev_bind_stream at each entry point).
+std::atomic<int> g_default_device{0};
+
+bool device_is_gfx950(int dev, char *why, size_t n) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return true;  // cannot tell: let launches decide
+    if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) return true;
+    // kernels are built for gfx950 only; anything else cannot run them
+    snprintf(why, n, "device %d is %s, this library targets gfx950", dev, prop.gcnArchName);
+    return false;
+}
 }  // namespace
 
 extern "C" void afxdev_set_error(const char *fmt, ...) {
@@ -22,12 +38,14 @@ extern "C" void afxdev_set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    ++t_err_count;
     if (getenv("AFX_QUIET") == nullptr) fprintf(stderr, "[audioflux_mi355x] %s\n", g_err);
 }
 
 extern "C" const char *afxdev_last_error(void) { return g_err; }
+extern "C" int afxdev_error_count(void) { return t_err_count; }
 
-extern "C" int afxdev_ensure(void) {
+static int init_status(void) {
     std::call_once(g_once, [] {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -36,6 +54,7 @@ extern "C" int afxdev_ensure(void) {
             g_init_status = AFX_ERR_NODEVICE;
             return;
         }
+        g_device_count = n;
         int dev = 0;
         if (const char *s = getenv("AFX_DEVICE")) dev = atoi(s);
         if (dev < 0 || dev >= n) dev = 0;
@@ -45,22 +64,35 @@ extern "C" int afxdev_ensure(void) {
             g_init_status = AFX_ERR_NODEVICE;
             return;
         }
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-                // kernels are built for gfx950 only; anything else cannot run them
-                snprintf(g_init_why, sizeof(g_init_why), "device %d is %s, this library targets gfx950", dev,
-                         prop.gcnArchName);
-                g_init_status = AFX_ERR_NODEVICE;
-                return;
-            }
+        if (!device_is_gfx950(dev, g_init_why, sizeof(g_init_why))) {
+            g_init_status = AFX_ERR_NODEVICE;
+            return;
         }
+        g_default_device.store(dev);
         g_init_status = AFX_OK;
     });
     if (g_init_status != AFX_OK) {
         afxdev_set_error("no usable MI355X (gfx950) HIP device (%s): this backend has no CPU fallback", g_init_why);
     }
     return g_init_status;
+}
+
+// Called first by every constructor (and by afx_runtime_status): initialise once, then -- per
+// thread, outside the call_once -- make the library's default device current, so that a new
+// object's stream, plan constants and scratch all land there whichever thread builds it.
+extern "C" int afxdev_ensure(void) {
+    int st = init_status();
+    if (st != AFX_OK) return st;
+    const int want = g_default_device.load();
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != want) {
+        hipError_t e = hipSetDevice(want);
+        if (e != hipSuccess) {
+            afxdev_set_error("hipSetDevice(%d): %s", want, hipGetErrorString(e));
+            return AFX_ERR_NODEVICE;
+        }
+    }
+    return AFX_OK;
 }
 
 extern "C" int afxdev_device_count(void) {
@@ -72,13 +104,46 @@ extern "C" int afxdev_device_count(void) {
 extern "C" int afxdev_set_device(int ordinal) {
     int st = afxdev_ensure();
     if (st != AFX_OK) return st;
+    if (ordinal < 0 || ordinal >= g_device_count) {
+        afxdev_set_error("afx_set_device(%d): %d device(s) visible", ordinal, g_device_count);
+        return AFX_ERR_ARG;
+    }
+    char why[256];
+    if (!device_is_gfx950(ordinal, why, sizeof(why))) {
+        afxdev_set_error("%s", why);
+        return AFX_ERR_NODEVICE;
+    }
     AFX_HIP(hipSetDevice(ordinal));
+    g_default_device.store(ordinal);  // objects created from now on (by any thread) live there
+    return AFX_OK;
+}
+
+extern "C" int afxdev_current_device(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
+// Make the device that owns `stream` (an object's own stream, created by its constructor) the
+// calling thread's current device.  Called at every compute entry point: allocations, table
+// lookups and launches of the call then all refer to the object's device, whatever the thread
+// (or torch, or another object) selected before.
+extern "C" int afxdev_bind_stream(void *stream) {
+    if (!stream) return afxdev_ensure();
+    hipDevice_t d = 0;
+    hipError_t e = hipStreamGetDevice((hipStream_t)stream, &d);
+    if (e != hipSuccess) {
+        afxdev_set_error("hipStreamGetDevice: %s", hipGetErrorString(e));
+        return AFX_ERR_HIP;
+    }
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != (int)d) AFX_HIP(hipSetDevice((int)d));
     return AFX_OK;
 }
 
 extern "C" int afxdev_malloc(void **dptr, size_t bytes) {
     *dptr = nullptr;
-    int st = afxdev_ensure();
+    int st = init_status();  // on the CURRENT device: the constructor's or the bound object's
     if (st != AFX_OK) return st;
     if (bytes == 0) bytes = 4;
     hipError_t e = hipMalloc(dptr, bytes);
@@ -128,7 +193,7 @@ extern "C" int afxdev_d2d(void *dst, const void *src, size_t bytes, void *stream
 
 extern "C" int afxdev_stream_create(void **stream) {
     *stream = nullptr;
-    int st = afxdev_ensure();
+    int st = init_status();
     if (st != AFX_OK) return st;
     hipStream_t s;
     AFX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));

@@ -8,6 +8,7 @@
 
 int afx_runtime_status(void) { return afxdev_ensure(); }
 const char *afx_last_error(void) { return afxdev_last_error(); }
+int afx_error_count(void) { return afxdev_error_count(); }
 int afx_device_count(void) { return afxdev_device_count(); }
 int afx_set_device(int ordinal) { return afxdev_set_device(ordinal); }
 const char *afx_version(void) { return "audioflux_mi355x 0.1.0 gfx950"; }
@@ -19,6 +20,7 @@ int afx_bftXxccBatchDevice(BFTObj bft, XXCCObj xxcc, const float *dData, int bat
                            CepstralRectifyType *rectifyType, float *dMel, float *dCc,
                            void *hipStream) {
     if (!bft || !xxcc || !dData || !dCc) return AFX_ERR_ARG;
+    AFX_ENTER(bft);
     if (!bft->resultType || xxcc->num != bft->num || ccNum < 1 || ccNum > xxcc->num) {
         afxdev_set_error("afx_bftXxccBatchDevice: needs a real-result BFT and an XXCC of the same num");
         return AFX_ERR_ARG;
@@ -28,7 +30,7 @@ int afx_bftXxccBatchDevice(BFTObj bft, XXCCObj xxcc, const float *dData, int bat
     if (T <= 0 || batch <= 0) return AFX_OK;
     const long long frames = (long long)batch * T;
 
-    /* fused single-kernel path when the plan supports it */
+    /* one launch (STFT -> bank -> log10 -> DCT-II, afx_melfused2.hip) when the plan supports it */
     int used = 0;
     int st = afx_bft_try_fast_cc(bft, xxcc, dData, batch, dataLength, clipStride, ccNum,
                                  rectifyType, dMel, dCc, stream, &used);

@@ -433,10 +433,11 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
         return afxk_stft(&a, stream);
     }
 
-    /* fused register-resident kernel for the hot configurations */
-    if (!dTemporal) {
+    /* fused register-resident kernel for the hot configurations (temporal features ride along
+     * in the n_fft 2048 real-result kernel) */
+    {
         int used = 0;
-        int st = afx_bft_try_fast(o, dData, batch, dataLength, clipStride, dRe, dIm, stream, &used);
+        int st = afx_bft_try_fast(o, dData, batch, dataLength, clipStride, dRe, dIm, dTemporal, stream, &used);
         if (st != AFX_OK || used) return st;
     }
 
@@ -502,6 +503,7 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
 
 int bftObj_bftBatchDevice(BFTObj o, const float *dData, int batch, int dataLength,
                           long long clipStride, float *dReal, float *dImag, void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dData || !dReal) return AFX_ERR_ARG;
     if (!o->resultType && !dImag) return AFX_ERR_ARG;
     return afx_bft_run_device(o, dData, batch, dataLength, clipStride, dReal, dImag, NULL,
@@ -510,6 +512,7 @@ int bftObj_bftBatchDevice(BFTObj o, const float *dData, int batch, int dataLengt
 
 int bftObj_bftBatch(BFTObj o, const float *dataArr, int batch, int dataLength, float *mRealArr3,
                     float *mImageArr3) {
+    AFX_ENTER(o);
     if (!o || !dataArr || dataLength <= 0 || batch <= 0 || !mRealArr3) return AFX_ERR_ARG;
     const int T = bftObj_calTimeLength(o, dataLength);
     if (T <= 0) return AFX_OK;
@@ -554,6 +557,7 @@ int bftObj_bftBatch(BFTObj o, const float *dataArr, int batch, int dataLength, f
 }
 
 void bftObj_bft(BFTObj o, float *dataArr, int dataLength, float *mRealArr3, float *mImageArr3) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("bftObj_bft: NULL object");
         return;

@@ -45,31 +45,47 @@ int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hB
     return st;
 }
 
+/* argument block of a real- or complex-result run of the fused kernels */
+static void fast_args(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
+                      long long clipStride, float *dRe, float *dIm, AfxMelFusedArgs *a) {
+    memset(a, 0, sizeof(*a));
+    a->x = dData;
+    a->clipStride = clipStride;
+    a->batch = batch;
+    a->dataLength = dataLength;
+    a->timeLength = (dataLength - o->fftLength) / o->slideLength + 1;
+    a->hop = o->slideLength;
+    a->normValue = o->normValue;
+    a->out = dRe;
+    a->outIm = dIm;
+    if (!o->resultType) {
+        /* complex result (bft_algorithm.c:457-485): the spectrum itself for MAG, its complex
+         * square for POWER; the norm exponent plays no part */
+        a->specMap = (o->dataType == SpectralData_Power) ? 4 : 3;
+    } else if (o->dataType == SpectralData_Mag) {
+        a->specMap = 1;
+        a->postPow = (o->normValue != 1);
+    } else {
+        a->specMap = (o->dataType == SpectralData_Power && o->normValue != 1) ? 2 : 0;
+    }
+}
+
+/* dTemporal: 3 planes of batch*T floats (energy | rms | zcr) or NULL.  Temporal features ride
+ * along in the n_fft 2048 real-result kernel; anything else reports "not used" for them. */
 int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
-                     long long clipStride, float *dRe, float *dIm, void *stream, int *used) {
+                     long long clipStride, float *dRe, float *dIm, float *dTemporal, void *stream,
+                     int *used) {
     *used = 0;
     if (!o->fast) return AFX_OK;
     if (!o->resultType && !dIm) return AFX_OK;
     AfxMelFusedArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = dData;
-    a.clipStride = clipStride;
-    a.batch = batch;
-    a.dataLength = dataLength;
-    a.timeLength = (dataLength - o->fftLength) / o->slideLength + 1;
-    a.hop = o->slideLength;
-    a.normValue = o->normValue;
-    a.out = dRe;
-    a.outIm = dIm;
-    if (!o->resultType) {
-        /* complex result (bft_algorithm.c:457-485): the spectrum itself for MAG, its complex
-         * square for POWER; the norm exponent plays no part */
-        a.specMap = (o->dataType == SpectralData_Power) ? 4 : 3;
-    } else if (o->dataType == SpectralData_Mag) {
-        a.specMap = 1;
-        a.postPow = (o->normValue != 1);
-    } else {
-        a.specMap = (o->dataType == SpectralData_Power && o->normValue != 1) ? 2 : 0;
+    fast_args(o, dData, batch, dataLength, clipStride, dRe, dIm, &a);
+    if (dTemporal) {
+        const long long frames = (long long)batch * a.timeLength;
+        if (!o->resultType) return AFX_OK;
+        a.energy = dTemporal;
+        a.rms = dTemporal + frames;
+        a.zcr = dTemporal + 2 * frames;
     }
     int st = afxk_melfused_run(o->fast, &a, stream);
     if (st == AFX_ERR_UNSUPPORTED) return AFX_OK; /* e.g. complex results at n_fft 4096: generic kernels */
@@ -77,14 +93,33 @@ int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dat
     return st;
 }
 
+/* STFT -> bank -> log10 -> DCT-II in ONE launch (afx_melfused2.hip): applies to real-result
+ * objects on the n_fft 2048 whole-row plan with num = 128, ccNum <= 16 and the log rectification
+ * (xxcc_algorithm.c:124-155).  dMel may be NULL: the rows then go to the object's scratch (the
+ * kernel re-reads every 16 of them from L2 to form the cepstra). */
 int afx_bft_try_fast_cc(struct OpaqueBFT *o, struct OpaqueXXCC *x, const float *dData, int batch,
                         int dataLength, long long clipStride, int ccNum,
                         CepstralRectifyType *rectifyType, float *dMel, float *dCc, void *stream,
                         int *used) {
-    (void)o; (void)x; (void)dData; (void)batch; (void)dataLength; (void)clipStride; (void)ccNum;
-    (void)rectifyType; (void)dMel; (void)dCc; (void)stream;
-    *used = 0; /* cepstra are produced by the DCT GEMM right after the fused mel kernel */
-    return AFX_OK;
+    *used = 0;
+    if (!o->fast || !o->resultType || o->isTemporal || getenv("AFX_NO_FUSED_CC")) return AFX_OK;
+    if (rectifyType && *rectifyType != CepstralRectify_Log) return AFX_OK;
+    if (x->num != o->num || ccNum < 1 || ccNum > 16) return AFX_OK;
+    AfxMelFusedArgs a;
+    fast_args(o, dData, batch, dataLength, clipStride, dMel, NULL, &a);
+    if (!a.out) {
+        int st = afxdev_reserve((void **)&o->dOut, &o->capOut,
+                                sizeof(float) * (size_t)batch * a.timeLength * o->num);
+        if (st != AFX_OK) return st;
+        a.out = o->dOut;
+    }
+    a.dct = x->dDct;
+    a.ccNum = ccNum;
+    a.cc = dCc;
+    int st = afxk_melfused_run(o->fast, &a, stream);
+    if (st == AFX_ERR_UNSUPPORTED) return AFX_OK;
+    if (st == AFX_OK) *used = 1;
+    return st;
 }
 
 void afx_bft_free_fast(struct OpaqueBFT *o) {

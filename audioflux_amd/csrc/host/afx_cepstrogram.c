@@ -139,6 +139,7 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj o, int cepNum, const fl
                                           int batch, int dataLength, long long clipStride,
                                           float *dOut1, float *dOut2, float *dOut3,
                                           void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dData || batch <= 0 || dataLength <= 0 || clipStride < 0) {
         afxdev_set_error("cepstrogramObj_cepstrogramBatchDevice: bad argument");
         return AFX_ERR_ARG;
@@ -175,6 +176,7 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj o, int cepNum, const fl
 
 void cepstrogramObj_cepstrogram(CepstrogramObj o, int cepNum, float *dataArr, int dataLength,
                                 float *mDataArr1, float *mDataArr2, float *mDataArr3) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cepstrogramObj_cepstrogram: NULL object");
         return;
@@ -188,6 +190,7 @@ void cepstrogramObj_cepstrogram(CepstrogramObj o, int cepNum, float *dataArr, in
 
 void cepstrogramObj_cepstrogram2(CepstrogramObj o, int cepNum, float *mRealArr, float *mImageArr,
                                  int nLength, float *mDataArr1, float *mDataArr2, float *mDataArr3) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cepstrogramObj_cepstrogram2: NULL object");
         return;

@@ -420,6 +420,7 @@ static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, 
 }
 
 void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float *mImageArr) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cqtObj_cqt: NULL object");
         return;
@@ -445,6 +446,7 @@ void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float
 /* clips already in HBM, results left in HBM (include/afx_batch.h) */
 int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLength,
                           long long clipStride, float *dReal, float *dImag, void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dData || !dReal || !dImag || batch <= 0 || dataLength <= 0 || clipStride < dataLength) {
         afxdev_set_error("cqtObj_cqtBatchDevice: bad argument");
         return AFX_ERR_ARG;
@@ -468,6 +470,7 @@ int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLengt
 
 int cqtObj_cqtBatch(CQTObj o, const float *dataArr, int batch, int dataLength, float *mRealArr,
                     float *mImageArr) {
+    AFX_ENTER(o);
     if (!o || !dataArr || !mRealArr || !mImageArr || batch <= 0 || dataLength <= 0) {
         afxdev_set_error("cqtObj_cqtBatch: bad argument");
         return AFX_ERR_ARG;
@@ -562,6 +565,7 @@ static int chroma_prepare(CQTObj o, int *chromaNum, SpectralDataType *dataType,
 void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
                    ChromaDataNormalType *normType, float *mRealArr, float *mImageArr,
                    float *mDataArr) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cqtObj_chroma: NULL object");
         return;
@@ -587,6 +591,7 @@ void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
 int cqtObj_chromaBatchDevice(CQTObj o, int *chromaNum, SpectralDataType *dataType,
                              ChromaDataNormalType *normType, const float *dReal,
                              const float *dImag, long long rows, float *dData, void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dReal || !dImag || !dData || rows <= 0) {
         afxdev_set_error("cqtObj_chromaBatchDevice: bad argument");
         return AFX_ERR_ARG;
@@ -606,6 +611,7 @@ int cqtObj_chromaBatchDevice(CQTObj o, int *chromaNum, SpectralDataType *dataTyp
 
 void cqtObj_cqcc(CQTObj o, float *mDataArr1, int ccNum, CepstralRectifyType *rectifyType,
                  float *mDataArr2) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cqtObj_cqcc: NULL object");
         return;
@@ -652,6 +658,7 @@ static int deconv_prepare(CQTObj o) {
 }
 
 void cqtObj_cqhc(CQTObj o, float *mDataArr1, int hcNum, float *mDataArr2) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cqtObj_cqhc: NULL object");
         return;
@@ -684,6 +691,7 @@ void cqtObj_cqhc(CQTObj o, float *mDataArr1, int hcNum, float *mDataArr2) {
 
 /* mDataArr1 [T,num] magnitudes -> mDataArr2 timbre (formant), mDataArr3 pitch, both [T,num] */
 void cqtObj_deconv(CQTObj o, float *mDataArr1, float *mDataArr2, float *mDataArr3) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cqtObj_deconv: NULL object");
         return;

@@ -676,6 +676,7 @@ static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *
 }
 
 void cwtObj_cwt(CWTObj o, float *dataArr, float *mRealArr3, float *mImageArr3) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cwtObj_cwt: NULL object");
         return;
@@ -773,12 +774,14 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
 
 int cwtObj_cwtBatchDevice(CWTObj o, const float *dData, int chunks, long long chunkStride,
                           float *dReal, float *dImag, void *hipStream) {
+    AFX_ENTER(o);
     return cwt_batch_device(o, dData, chunks, chunkStride, o ? o->dBankT : NULL, 0, dReal, dImag,
                             hipStream, "cwtObj_cwtBatchDevice");
 }
 
 int cwtObj_cwtDetBatchDevice(CWTObj o, const float *dData, int chunks, long long chunkStride,
                              float *dReal, float *dImag, void *hipStream) {
+    AFX_ENTER(o);
     return cwt_batch_device(o, dData, chunks, chunkStride, o ? o->dBankDetT : NULL, 1, dReal, dImag,
                             hipStream, "cwtObj_cwtDetBatchDevice");
 }
@@ -786,6 +789,7 @@ int cwtObj_cwtDetBatchDevice(CWTObj o, const float *dData, int chunks, long long
 /* host pointers: dataArr[chunks][2^r] -> mRealArr3/mImageArr3 [chunks][num][2^r]; chunks are
  * streamed through the object's one-chunk staging buffers */
 int cwtObj_cwtBatch(CWTObj o, const float *dataArr, int chunks, float *mRealArr3, float *mImageArr3) {
+    AFX_ENTER(o);
     if (!o || !dataArr || !mRealArr3 || !mImageArr3 || chunks <= 0) {
         afxdev_set_error("cwtObj_cwtBatch: bad argument");
         return AFX_ERR_ARG;
@@ -801,6 +805,7 @@ int cwtObj_cwtBatch(CWTObj o, const float *dataArr, int chunks, float *mRealArr3
 }
 
 void cwtObj_enableDet(CWTObj o, int flag) {
+    AFX_ENTER(o);
     if (!o || !flag || o->dBankDetT) return;
     /* bank times the angular frequency (cwt_algorithm.c:485-528) */
     const long long L = o->fftLength;
@@ -835,6 +840,7 @@ void cwtObj_enableDet(CWTObj o, int flag) {
 }
 
 void cwtObj_cwtDet(CWTObj o, float *dataArr, float *mRealArr3, float *mImageArr3) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("cwtObj_cwtDet: NULL object");
         return;

@@ -127,7 +127,8 @@ int afx_bft_create(const AfxBftPlan *p, struct OpaqueBFT **bftObj);
 /* fused-kernel hooks (afx_melfused.hip) */
 int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hBank);
 int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
-                     long long clipStride, float *dRe, float *dIm, void *stream, int *used);
+                     long long clipStride, float *dRe, float *dIm, float *dTemporal, void *stream,
+                     int *used);
 int afx_bft_try_fast_cc(struct OpaqueBFT *o, struct OpaqueXXCC *x, const float *dData, int batch,
                         int dataLength, long long clipStride, int ccNum,
                         CepstralRectifyType *rectifyType, float *dMel, float *dCc, void *stream,

@@ -120,6 +120,7 @@ static int stft_planes(ReassignObj o, int which, const float *dData, int batch, 
 int reassignObj_reassignBatchDevice(ReassignObj o, const float *dData, int batch, int dataLength,
                                     long long clipStride, float *dReal1, float *dImag1, float *dReal2,
                                     float *dImag2, void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dData || !dReal1 || batch <= 0 || dataLength <= 0) return AFX_ERR_ARG;
     if (!o->resultType && !dImag1) return AFX_ERR_ARG;
     const int T = reassignObj_calTimeLength(o, dataLength);
@@ -182,6 +183,7 @@ int reassignObj_reassignBatchDevice(ReassignObj o, const float *dData, int batch
 
 void reassignObj_reassign(ReassignObj o, float *dataArr, int dataLength, float *mRealArr1,
                           float *mImageArr1, float *mRealArr2, float *mImageArr2) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("reassignObj_reassign: NULL object");
         return;

@@ -454,6 +454,7 @@ static int chroma_tail(SpectrogramObj o, const float *dBase, long long rows, flo
 
 int spectrogramObj_spectrogramBatchDevice(SpectrogramObj o, const float *dData, int batch, int dataLength,
                                           long long clipStride, float *dSpect, void *hipStream) {
+    AFX_ENTER(o ? o->core : NULL);
     if (!o || !dData || !dSpect || batch <= 0 || dataLength <= 0) return AFX_ERR_ARG;
     const int T = bftObj_calTimeLength(o->core, dataLength);
     if (T <= 0) return AFX_OK;
@@ -473,6 +474,7 @@ int spectrogramObj_spectrogramBatchDevice(SpectrogramObj o, const float *dData, 
 
 void spectrogramObj_spectrogram(SpectrogramObj o, float *dataArr, int dataLength, float *mSpectArr,
                                 float *mPhaseArr) {
+    AFX_ENTER(o ? o->core : NULL);
     if (!o) {
         afxdev_set_error("spectrogramObj_spectrogram: NULL object");
         return;
@@ -525,6 +527,7 @@ void spectrogramObj_spectrogram(SpectrogramObj o, float *dataArr, int dataLength
 
 void spectrogramObj_spectrogram1(SpectrogramObj o, float *mRealArr, float *mImageArr, int nLength,
                                  int mLength, float *mSpectArr, float *mPhaseArr) {
+    AFX_ENTER(o ? o->core : NULL);
     if (!o) {
         afxdev_set_error("spectrogramObj_spectrogram1: NULL object");
         return;
@@ -592,35 +595,42 @@ static void run_xxcc(SpectrogramObj o, float *mDataArr1, int ccNum, CepstralRect
 }
 
 void spectrogramObj_mfcc(SpectrogramObj o, float *mDataArr1, int ccNum, float *mDataArr2) {
+    AFX_ENTER(o ? o->core : NULL);
     if (o && o->scale == SpectralFilterBankScale_Mel) run_xxcc(o, mDataArr1, ccNum, NULL, mDataArr2, "spectrogramObj_mfcc");
 }
 
 void spectrogramObj_gtcc(SpectrogramObj o, float *mDataArr1, int ccNum, float *mDataArr2) {
+    AFX_ENTER(o ? o->core : NULL);
     if (o && o->style == SpectralFilterBankStyle_Gammatone) run_xxcc(o, mDataArr1, ccNum, NULL, mDataArr2, "spectrogramObj_gtcc");
 }
 
 void spectrogramObj_bfcc(SpectrogramObj o, float *mDataArr1, int ccNum, float *mDataArr2) {
+    AFX_ENTER(o ? o->core : NULL);
     if (o && o->scale == SpectralFilterBankScale_Bark) run_xxcc(o, mDataArr1, ccNum, NULL, mDataArr2, "spectrogramObj_bfcc");
 }
 
 void spectrogramObj_xxcc(SpectrogramObj o, float *mDataArr1, int ccNum, CepstralRectifyType *rectifyType,
                          float *mDataArr2) {
+    AFX_ENTER(o ? o->core : NULL);
     run_xxcc(o, mDataArr1, ccNum, rectifyType, mDataArr2, "spectrogramObj_xxcc");
 }
 
 void spectrogramObj_mfccStandard(SpectrogramObj o, float *mDataArr1, int *deltaWindowLength,
                                  CepstralEnergyType *energyType, CepstralRectifyType *rectifyType,
                                  float *mDataArr2) {
+    AFX_ENTER(o ? o->core : NULL);
     (void)o; (void)mDataArr1; (void)deltaWindowLength; (void)energyType; (void)rectifyType; (void)mDataArr2;
 }
 
 void spectrogramObj_xxccStandard(SpectrogramObj o, float *mDataArr1, int *deltaWindowLength,
                                  CepstralEnergyType *energyType, CepstralRectifyType *rectifyType,
                                  float *mDataArr2) {
+    AFX_ENTER(o ? o->core : NULL);
     (void)o; (void)mDataArr1; (void)deltaWindowLength; (void)energyType; (void)rectifyType; (void)mDataArr2;
 }
 
 void spectrogramObj_deconv(SpectrogramObj o, float *mDataArr1, float *mDataArr2, float *mDataArr3) {
+    AFX_ENTER(o ? o->core : NULL);
     if (!o) {
         afxdev_set_error("spectrogramObj_deconv: NULL object");
         return;

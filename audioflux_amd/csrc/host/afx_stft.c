@@ -178,6 +178,7 @@ static void fill_args(STFTObj o, AfxStftArgs *a, const float *dData, int batch, 
 
 int stftObj_stftBatchDevice(STFTObj o, const float *dData, int batch, int dataLength,
                             long long clipStride, float *dReal, float *dImag, void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dData || !dReal || !dImag || batch <= 0 || dataLength <= 0) return AFX_ERR_ARG;
     int T, tail, valid = dataLength;
     if (o->isPad) {
@@ -262,6 +263,7 @@ static void fail(STFTObj o, int st, const char *who) {
 }
 
 void stftObj_stft(STFTObj o, float *dataArr, int dataLength, float *mRealArr, float *mImageArr) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("stftObj_stft: NULL object");
         return;
@@ -318,6 +320,7 @@ static int sync_synthesis(STFTObj o, int methodType, void *stream) {
 int stftObj_istftBatchDevice(STFTObj o, const float *dReal, const float *dImag, int batch,
                              int nLength, int type, float *dData, long long dataStride,
                              void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dReal || !dImag || !dData || batch <= 0 || nLength <= 0) return AFX_ERR_ARG;
     /* the frame scratch belongs to the object: drain the previous stream on a switch */
     if (o->lastStreamSet && o->lastStream != hipStream) {
@@ -350,6 +353,7 @@ int stftObj_istftBatchDevice(STFTObj o, const float *dReal, const float *dImag, 
 
 void stftObj_istft(STFTObj o, float *mRealArr, float *mImageArr, int nLength, int type,
                    float *dataArr) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("stftObj_istft: NULL object");
         return;

@@ -47,6 +47,7 @@ int synsqObj_new(SynsqObj *synsqObj, int num, int radix2Exp, int *samplate, int 
 
 void synsqObj_synsq(SynsqObj o, float *freArr, SpectralFilterBankScaleType scaleType, float *mRealArr1,
                     float *mImageArr1, float *mRealArr2, float *mImageArr2) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("synsqObj_synsq: NULL object");
         return;

@@ -91,6 +91,7 @@ void wsstObj_setOrder(WSSTObj o, int order) {
 
 int wsstObj_wsstBatchDevice(WSSTObj o, const float *dData, int chunks, long long chunkStride, float *dReal1,
                             float *dImag1, float *dReal2, float *dImag2, void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dData || !dReal1 || !dImag1 || chunks <= 0) return AFX_ERR_ARG;
     const size_t plane = (size_t)o->num * o->fftLength * (size_t)chunks;
     /* W goes straight to the caller's second pair when it is wanted, else to scratch */
@@ -128,6 +129,7 @@ int wsstObj_wsstBatchDevice(WSSTObj o, const float *dData, int chunks, long long
 
 void wsstObj_wsst(WSSTObj o, float *dataArr, float *mRealArr1, float *mImageArr1, float *mRealArr2,
                   float *mImageArr2) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("wsstObj_wsst: NULL object");
         return;

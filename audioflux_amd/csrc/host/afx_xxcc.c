@@ -55,6 +55,7 @@ static int rectify_to_map(const CepstralRectifyType *rectifyType) {
 
 int xxccObj_xxccDevice(XXCCObj o, const float *dIn, long long rows, int ccNum,
                        CepstralRectifyType *rectifyType, float *dOut, void *hipStream) {
+    AFX_ENTER(o);
     if (!o || !dIn || !dOut) return AFX_ERR_ARG;
     if (ccNum > o->num || ccNum < 1) return AFX_ERR_ARG;
     if (afxk_cepstrum_supported(dIn, o->num, ccNum) && !getenv("AFX_NO_FUSED"))
@@ -78,6 +79,7 @@ static int run_cc(XXCCObj o, const float *hIn, int ccNum, CepstralRectifyType *r
 
 void xxccObj_xxcc(XXCCObj o, float *mDataArr1, int ccNum, CepstralRectifyType *rectifyType,
                   float *mDataArr2) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("xxccObj_xxcc: NULL object");
         return;
@@ -97,6 +99,7 @@ void xxccObj_xxcc(XXCCObj o, float *mDataArr1, int ccNum, CepstralRectifyType *r
  * as xxccObj_setTimeLength(rows) + xxccObj_xxcc, with a status (include/afx_batch.h) */
 int xxccObj_xxccBatch(XXCCObj o, const float *mDataArr1, long long rows, int ccNum,
                       CepstralRectifyType *rectifyType, float *mDataArr2) {
+    AFX_ENTER(o);
     if (!o || !mDataArr1 || !mDataArr2 || rows <= 0 || rows > 2147483647LL || ccNum > o->num || ccNum < 1) {
         afxdev_set_error("xxccObj_xxccBatch: bad argument");
         return AFX_ERR_ARG;
@@ -119,6 +122,7 @@ void xxccObj_xxccStandard(XXCCObj o, float *mDataArr1, int ccNum, float *energyA
                           int *deltaWindowLength, CepstralEnergyType *energyType,
                           CepstralRectifyType *rectifyType, float *mCoeArr, float *mDeltaArr1,
                           float *mDeltaArr2) {
+    AFX_ENTER(o);
     if (!o) {
         afxdev_set_error("xxccObj_xxccStandard: NULL object");
         return;

@@ -74,6 +74,7 @@ class CWT:
         re = np.zeros((clips.shape[0], self.num, self.fft_length), np.float32)
         im = np.zeros_like(re)
         fn = getattr(self._lib, name)
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, _util.c_float_p, _util.c_float_p]
         for i in range(clips.shape[0]):
@@ -88,6 +89,7 @@ class CWT:
     def enable_det(self, flag=True):
         fn = self._lib.cwtObj_enableDet
         fn.argtypes = [c_void_p, c_int]
+        fn = _lib.checked(fn)
         fn.restype = None
         fn(self._obj, int(flag))
 

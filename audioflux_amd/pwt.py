@@ -68,6 +68,7 @@ class PWT:
         re = np.zeros((clips.shape[0], self.num, self.fft_length), np.float32)
         im = np.zeros_like(re)
         fn = getattr(self._lib, name)
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, _util.c_float_p, _util.c_float_p]
         for i in range(clips.shape[0]):

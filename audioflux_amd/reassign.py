@@ -57,6 +57,7 @@ class Reassign:
         t, f = self.cal_time_length(x.shape[0]), self.fft_length // 2 + 1
         a = [np.zeros((t, f), np.float32) for _ in range(4)]
         fn = self._lib.reassignObj_reassign
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int] + [_util.c_float_p] * 4
         fn(self._obj, _util.fptr(x), x.shape[0], *[_util.fptr(v) for v in a])

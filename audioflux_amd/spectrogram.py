@@ -132,6 +132,7 @@ class SpectrogramBase:
             raise ValueError("Only LINEAR bank type has phase arr")
         clips, lead = _util.flatten_leading(x, 1)
         fn = self._lib.spectrogramObj_spectrogram
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p, _util.c_float_p]
         specs, phases = [], []
@@ -155,6 +156,7 @@ class SpectrogramBase:
         spec = np.zeros((t, self.num), np.float32)
         ph = np.zeros((t, self.num), np.float32) if is_phase_arr else None
         fn = self._lib.spectrogramObj_spectrogram1
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, _util.c_float_p, c_int, c_int, _util.c_float_p, _util.c_float_p]
         fn(self._obj, _util.fptr(re), _util.fptr(im), t, m, _util.fptr(spec), _util.fptr(ph) if is_phase_arr else None)
@@ -183,6 +185,7 @@ class SpectrogramBase:
         m = np.ascontiguousarray(_util.as_f32(m_data_arr).T)
         out = np.zeros((m.shape[0], cc_num), np.float32)
         fn = getattr(self._lib, name)
+        fn = _lib.checked(fn)
         fn.restype = None
         if rectify is None:
             fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p]

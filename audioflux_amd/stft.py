@@ -54,6 +54,7 @@ class STFT:
                     value1=0.0, value2=0.0):
         """only honoured after enable_padding(True), as in the reference"""
         fn = self._lib.stftObj_setPadding
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_float), POINTER(c_float)]
         fn(self._obj, _util.opt_int(int(position_type)), _util.opt_int(int(mode_type)),
@@ -95,6 +96,7 @@ class STFT:
         re = np.zeros((t, self.fft_length), np.float32)
         im = np.zeros((t, self.fft_length), np.float32)
         fn = self._lib.stftObj_stft
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p, _util.c_float_p]
         fn(self._obj, _util.fptr(x), x.shape[-1], _util.fptr(re), _util.fptr(im))
@@ -128,6 +130,7 @@ class STFT:
         n = self.cal_data_length(t)
         out = np.zeros((clips.shape[0], n), np.float32)
         fn = self._lib.stftObj_istft
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, _util.c_float_p, c_int, c_int, _util.c_float_p]
         for i in range(clips.shape[0]):

@@ -35,6 +35,7 @@ class Synsq:
         re, im = np.ascontiguousarray(m.real, np.float32), np.ascontiguousarray(m.imag, np.float32)
         a, b = np.zeros_like(re), np.zeros_like(re)
         fn = self._lib.synsqObj_synsq
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int] + [_util.c_float_p] * 4
         fn(self._obj, _util.fptr(fre), int(filter_bank_type), _util.fptr(re), _util.fptr(im), _util.fptr(a),

@@ -65,6 +65,7 @@ class WSST:
         assert x.shape == (self.fft_length,)
         a = [np.zeros((self.num, self.fft_length), np.float32) for _ in range(4)]
         fn = self._lib.wsstObj_wsst
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p] + [_util.c_float_p] * 5
         fn(self._obj, _util.fptr(x), *[_util.fptr(v) for v in a])

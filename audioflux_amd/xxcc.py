@@ -26,6 +26,7 @@ class XXCC:
     def set_time_length(self, time_length):
         fn = self._lib.xxccObj_setTimeLength
         fn.argtypes = [c_void_p, c_int]
+        fn = _lib.checked(fn)
         fn.restype = None
         fn(self._obj, int(time_length))
         self.time_length = time_length
@@ -42,6 +43,7 @@ class XXCC:
         t = m.shape[-2]
         out = np.zeros((frames.shape[0], t, cc_num), np.float32)
         fn = self._lib.xxccObj_xxcc
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, POINTER(c_int), _util.c_float_p]
         self.set_time_length(t)
@@ -67,6 +69,7 @@ class XXCC:
         n_out = cc_num + (1 if energy_type == CepstralEnergyType.APPEND else 0)
         outs = [np.zeros((frames.shape[0], t, n_out), np.float32) for _ in range(3)]
         fn = self._lib.xxccObj_xxccStandard
+        fn = _lib.checked(fn)
         fn.restype = None
         fn.argtypes = [c_void_p, _util.c_float_p, c_int, _util.c_float_p, POINTER(c_int),
                        POINTER(c_int), POINTER(c_int), _util.c_float_p, _util.c_float_p,

@@ -34,8 +34,18 @@ extern "C" {
 /* 0 when a gfx950 device is usable; negative otherwise (no CPU fallback exists) */
 int afx_runtime_status(void);
 const char *afx_last_error(void);
+/* Number of failures reported on the CALLING THREAD so far.  The reference's compute entry points
+ * are `void` (bftObj_bft, stftObj_stft, cwtObj_cwt, ...): a HIP failure inside one (out of memory,
+ * launch error) cannot be returned, so it is recorded -- message in afx_last_error(), one line on
+ * stderr -- and this counter advances.  A caller that samples it before and after a void call knows
+ * whether the (pre-zeroed) outputs are results; the audioflux_amd wrappers raise RuntimeError. */
+int afx_error_count(void);
 int afx_device_count(void);
-/* bind the calling thread / subsequently created objects to a device ordinal */
+/* Device ordinal for objects created FROM NOW ON, by any thread (HIP's current device is per
+ * thread: every constructor makes this device current first).  An existing object stays on the
+ * device it was built on: each compute entry point makes the object's device current for the
+ * calling thread (its stream's device), so objects on different devices can be mixed in one
+ * process and used from any thread -- one object by one thread at a time, like the reference. */
 int afx_set_device(int ordinal);
 /* "audioflux_mi355x <version> gfx950" */
 const char *afx_version(void);

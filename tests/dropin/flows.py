@@ -175,9 +175,13 @@ def flow_cqt(af, x, y):
     out = {"cqt": q, "fre": o.get_fre_band_arr(), "fft_length": np.array(o.get_fft_length()),
            "T": np.array(o.cal_time_length(len(y)))}
     out["chroma"] = o.chroma(q)
-    out["cqcc"] = o.cqcc(np.abs(q).astype(np.float32))
-    out["cqhc"] = o.cqhc(np.abs(q).astype(np.float32))
-    dec = o.deconv(np.abs(q).astype(np.float32))
+    # the log-domain consumers chain from the CQT of the NOISE clip: on the tonal clip most bins sit at
+    # the 1e-3 noise floor and log10 turns the 1e-6-of-peak float32 differences there into 5e-5 of the
+    # cepstral peak (conditioning of the chain, not of cqcc; cqcc on equal inputs is in tests/test_cqt_gpu.py)
+    qa = np.abs(o.cqt(x)).astype(np.float32)
+    out["cqcc"] = o.cqcc(qa)
+    out["cqhc"] = o.cqhc(qa)
+    dec = o.deconv(qa)
     for i, a in enumerate(dec):
         out[f"deconv{i}"] = np.asarray(a)
     return out

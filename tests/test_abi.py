@@ -100,3 +100,40 @@ def test_single_hip_runtime_in_process():
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
+
+
+def test_void_entry_point_failures_are_counted_and_raised():
+    """the reference's compute entry points are void; a failure inside one must not reach
+    the caller as a zero-filled result.  afx_error_count() advances on the calling thread and the
+    wrappers' call proxy raises."""
+    from audioflux_amd import _lib
+    lib = af.get_lib()
+    lib.afx_error_count.restype = ctypes.c_int
+    before = lib.afx_error_count()
+    fn = lib.bftObj_bft
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    fn(None, None, 0, None, None)  # NULL object: reported, not crashed
+    assert lib.afx_error_count() == before + 1
+    assert "NULL object" in af.last_error()
+    with pytest.raises(RuntimeError, match="bftObj_bft failed"):
+        _lib.checked(fn)(None, None, 0, None, None)
+    # a call that succeeds (NULL-safe free) does not raise through the proxy
+    free = lib.bftObj_free
+    free.restype = None
+    free.argtypes = [ctypes.c_void_p]
+    _lib.checked(free)(None)
+
+
+def test_every_void_compute_call_of_the_wrappers_is_checked():
+    """no `restype = None` compute call in audioflux_amd/*.py bypasses the proxy (destructors excepted)"""
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "audioflux_amd", "*.py")):
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            if line.strip().endswith(".restype = None"):
+                ctx = "\n".join(lines[max(0, i - 4):i + 1])
+                if "Obj_free" in ctx or "_lib.checked(" in ctx or "class _Checked" in ctx:
+                    continue
+                bad.append(f"{os.path.basename(path)}:{i + 1}")
+    assert bad == [], bad

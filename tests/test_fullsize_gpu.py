@@ -38,8 +38,10 @@ def test_cfg2_full_corpus_shift_property_and_sampled_reference():
     #     overlapping frames at every position)
     assert torch.equal(mel[1::2, : t - 1], mel[0::2, 1:])
     assert torch.equal(cc[1::2, : t - 1], cc[0::2, 1:])
-    # (a') MFCC of the fused call == the separate cepstral call on the mel it wrote
-    assert torch.equal(cc, xx.xxcc_device(mel, 13))
+    # (a') MFCC of the one-launch call vs the separate cepstral kernel on the mel it wrote: same DCT rows,
+    #      log10 by v_log_f32 * log10(2) there, log10f here -- 1e-6 of the peak over the whole corpus
+    sep = xx.xxcc_device(mel, 13)
+    assert float((cc - sep).abs().amax() / sep.abs().amax()) <= 1e-6
     # (b) compiled reference on clips sampled across the batch (first, last, middle, an odd one)
     if ref.available():
         for i in (0, 999, 500, 777):
