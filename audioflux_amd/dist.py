@@ -36,34 +36,127 @@ def shard_range(n_items, rank, world):
 
 
 class FeatureGather:
-    """Gathers equally-shaped per-rank feature slabs [clips_local, T, C] to `dst`.
-    Asynchronous: start() enqueues the collective behind the producing stream,
-    wait() returns the [world*clips_local, T, C] tensor on dst (None elsewhere)."""
+    """Gathers per-rank feature slabs [clips_local, ...] to `dst`, clip-major (rank r's clips follow
+    rank r-1's).  Asynchronous: start() enqueues the collective on the CURRENT stream (callers put it
+    on a side stream behind the producing one), wait() returns the gathered tensor on dst (None
+    elsewhere).  Ranks may hold different clip counts (shard_range gives ceil-sized blocks, the last
+    ranks get fewer): every slab is padded to `clips_max` rows for the equal-chunk collective and the
+    result is trimmed -- `clips_max` / `counts` are fixed at construction or learnt once by an
+    all_gather of the counts.  `always_collective` runs the same RCCL code path at world size 1
+    (communicator creation, stream ordering), which is what the single-GPU box can exercise."""
 
-    def __init__(self, dst=0, group=None):
+    def __init__(self, dst=0, group=None, counts=None, always_collective=False):
         self.dst, self.group = dst, group
-        self.work, self.out = None, None
+        self.counts = list(counts) if counts is not None else None
+        self.always = always_collective
+        self.work, self.out, self.pad = None, None, None
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _learn_counts(self, slab):
+        world = self._world()
+        mine = torch.tensor([slab.shape[0]], dtype=torch.int64, device=slab.device)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine, group=self.group)
+        self.counts = [int(g.item()) for g in got]
 
     def start(self, slab):
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+        world = self._world()
+        if world == 1 and not (self.always and dist.is_initialized()):
             self.out, self.work = slab, None
             return
+        if self.counts is None:
+            self._learn_counts(slab)
+        assert len(self.counts) == world and slab.shape[0] == self.counts[dist.get_rank(self.group)], \
+            "FeatureGather: slab rows differ from the announced per-rank counts"
+        cmax = max(self.counts)
+        send = slab
+        if slab.shape[0] != cmax:  # short last shard: pad for the equal-chunk collective
+            if self.pad is None or self.pad.shape[1:] != slab.shape[1:] or self.pad.dtype != slab.dtype:
+                self.pad = torch.zeros((cmax,) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
+            self.pad[: slab.shape[0]].copy_(slab)
+            send = self.pad
         rank = dist.get_rank(self.group)
         if rank == self.dst:
-            if self.out is None or self.out.shape[0] != world * slab.shape[0] or self.out.shape[1:] != slab.shape[1:]:
-                self.out = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]),
-                                       dtype=slab.dtype, device=slab.device)
+            shape = (world * cmax,) + tuple(slab.shape[1:])
+            if self.out is None or tuple(self.out.shape) != shape or self.out.dtype != slab.dtype:
+                self.out = torch.empty(shape, dtype=slab.dtype, device=slab.device)
             chunks = list(self.out.chunk(world, dim=0))
         else:
             chunks = None
-        self.work = dist.gather(slab, chunks, dst=self.dst, group=self.group, async_op=True)
+        self.work = dist.gather(send.contiguous(), chunks, dst=self.dst, group=self.group, async_op=True)
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
             self.work = None
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1 or dist.get_rank(self.group) == self.dst:
+        world = self._world()
+        if world == 1 and not (self.always and dist.is_initialized()):
             return self.out
-        return None
+        if self.out is None or dist.get_rank(self.group) != self.dst:
+            return None
+        if self.counts is None or all(c == self.counts[0] for c in self.counts):
+            return self.out
+        cmax = max(self.counts)  # trim the padding rows of the short shards
+        return torch.cat([self.out[r * cmax: r * cmax + c] for r, c in enumerate(self.counts)], dim=0)
+
+
+class NativeGather:
+    """The same exchange through the library's own C-ABI export (include/afx_batch.h: afx_comm_*,
+    afx_gather = ncclGather over RCCL / xGMI, bound at run time) -- what a C / C++ host of the
+    library uses; torch.distributed only carries the 128-byte bootstrap id here (any launcher
+    side channel does).  Slabs must have the same shape on every rank."""
+
+    def __init__(self, dst=0, group=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._check = _lib.get_lib(), _lib.check
+        self.dst = dst
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            self._check(self._lib.afx_comm_get_unique_id(ident), "afx_comm_get_unique_id")
+        if world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        self._comm = ctypes.c_void_p(None)
+        self._lib.afx_comm_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p]
+        self._check(self._lib.afx_comm_create(ctypes.byref(self._comm), world, rank, ident), "afx_comm_create")
+        self._lib.afx_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_void_p]
+        self._lib.afx_comm_free.argtypes = [ctypes.c_void_p]
+        self._lib.afx_comm_free.restype = None
+        self.world, self.rank, self.out = world, rank, None
+
+    def start(self, slab, stream=None):
+        """asynchronous on `stream` (default: torch's current stream)"""
+        assert slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous()
+        s = stream if stream is not None else torch.cuda.current_stream(slab.device)
+        recv = None
+        if self.rank == self.dst:
+            shape = (self.world * slab.shape[0],) + tuple(slab.shape[1:])
+            if self.out is None or tuple(self.out.shape) != shape:
+                self.out = torch.empty(shape, dtype=slab.dtype, device=slab.device)
+            recv = self.out.data_ptr()
+        self._check(self._lib.afx_gather(self._comm, slab.data_ptr(), slab.numel(), recv, self.dst, s.cuda_stream),
+                    "afx_gather")
+
+    def wait(self):
+        """stream-ordered like every device call of the library: the result is valid for work
+        enqueued behind the gather on its stream (synchronise that stream to read it on the host)"""
+        return self.out if self.rank == self.dst else None
+
+    def close(self):
+        if self._comm:
+            self._lib.afx_comm_free(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,22 +1,31 @@
 #!/usr/bin/env python
-"""bench.py -- audio frames/sec for batched STFT -> mel-128 -> MFCC-13
-(n_fft = 2048, hop = 512) on synthetic 16 kHz mono clips, BASELINE.json's metric.
+"""bench.py -- BASELINE.json's metric: audio frames/sec for batched STFT -> mel-128 -> MFCC-13
+(n_fft = 2048, hop = 512) on synthetic 16 kHz mono clips (--config 2, the default and the line the
+driver records), plus the two other measured configurations of BASELINE.json in the same JSON
+shape: --config 4 (CWT morlet, 84 scales, 1000 x 10 s @ 44.1 kHz) and --config 5 (CQT 84 bins +
+chroma, 30 s @ 44.1 kHz clips, 125 clips per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config 2|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: `--clips` clips (default 1000,
-BASELINE cfg 2) of 30 s per GPU, inputs already resident in HBM, features (mel and
-MFCC) left in HBM; with N > 1 each rank owns its own batch (weak scaling) and the MFCC
-slab is gathered to rank 0 over RCCL, overlapped with the next step.  Timing: barrier +
-torch.cuda.synchronize() on both sides of exactly K steps, max over ranks.  Rank 0
+A "step" is one pass of the hot path over one batch per GPU, inputs already resident in HBM,
+features left in HBM; with N > 1 each rank owns its own batch (weak scaling: clips are independent,
+no data-path collective) and the feature slab named by --gather goes to rank 0 over RCCL on a side
+stream, overlapped with the next step (cfg 4: replicas only -- its output exceeds every link).
+Timing: barrier + torch.cuda.synchronize() on both sides of exactly K steps, max over ranks.  Rank 0
 prints ONE JSON line.
 
-`roofline` is for the dominant kernel of the step, timed live with HIP events on the
-stream it is launched on (torch's current stream is handed to the library);
+`roofline`: cfg 2 is ONE kernel launch per step (k_stft_mel_v2: STFT -> |S|^2 -> mel bank -> log10 ->
+DCT-II); it is timed live with HIP events on the stream it is launched on (torch's current stream is
+handed to the library).  `achieved` = SURVEY 8d's algorithmic bytes per unit x units per launch /
+that duration; `sustained_ms` repeats the step back to back for >= 1 s (sustained clocks, where the
+K-step region of a short run sees boost clocks); `traffic` = HBM bytes per launch from the round's
+own rocprofv3 --pmc passes of this command (profiles/r02_bench_cfg<N>_pmc.json, written by
+tools/prof_traffic.py), null when that file is absent.  After the timed region clip 0 of the
+benchmarked outputs is checked against the oracle (1e-5 peak / L2).
 `cpu_baseline` times the reference's own C path (oracle/_ref, built-in FFT + naive
-double-accumulating matmul) on the host cores for a bounded sample of the same workload.
+double-accumulating matmul: no FFTW/MKL in this image) on the host cores for a bounded sample.
 """
 import argparse
 import json
@@ -30,38 +39,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SR, NFFT, HOP, NMEL, NCC = 16000, 2048, 512, 128, 13
-CLIP_SECONDS = 30
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-BYTES_PER_FRAME = 4 * HOP + 4 * NMEL + 4 * NCC  # each sample read once, each output written once
-BYTES_PER_FRAME_MEL_KERNEL = 4 * HOP + 4 * NMEL   # what the dominant kernel itself must move
 
 
-def cpu_worker(args):
-    """one host process: reference mel+MFCC over `n` clips (objects pre-built, one warm-up)"""
-    seed, n, threads = args
-    if threads > 0:
-        os.environ["OMP_NUM_THREADS"] = str(threads)
-    else:
-        os.environ.pop("OMP_NUM_THREADS", None)
-    from oracle import ref
-    length = SR * CLIP_SECONDS
-    x = (0.1 * np.random.default_rng(seed).standard_normal((n, length))).astype(np.float32)
-    bft = ref.RefBFT(NMEL, 11, samplate=SR, low_fre=0.0, high_fre=SR / 2.0, window_type=1,
-                     slide_length=HOP, scale_type=2, style_type=0, normal_type=0, data_type=0)
-    bft.set_result_type(1)
-    cc = ref.RefXXCC(NMEL)
-    re, _ = bft.bft(x[0])
-    cc.xxcc(re, NCC, 0)  # warm-up
-    t0 = time.perf_counter()
-    frames = 0
-    for i in range(n):
-        re, _ = bft.bft(x[i])
-        cc.xxcc(re, NCC, 0)
-        frames += re.shape[0]
-    return frames, time.perf_counter() - t0
-
-
+# =================================================================================================
+# host-side CPU baselines (compiled reference, oracle/_ref) -- rank 0, N = 1 only
 def _effective_cpus():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # cgroup v2 CPU quota, if any
@@ -73,14 +55,71 @@ def _effective_cpus():
     return n
 
 
-def cpu_baseline(budget_s=25.0):
-    """reference CPU path (oracle/_ref: the reference's own C, built-in radix-2 FFT + naive
-    double-accumulating matmul, no FFTW/MKL) on this box's host cores -- BASELINE.md section 3:
+def cpu_worker_cfg2(args):
+    """one host process: reference mel+MFCC over `n` clips (objects pre-built, one warm-up)"""
+    seed, n, threads = args
+    if threads > 0:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+    else:
+        os.environ.pop("OMP_NUM_THREADS", None)
+    from oracle import ref
+    x = (0.1 * np.random.default_rng(seed).standard_normal((n, 480000))).astype(np.float32)
+    bft = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1,
+                     slide_length=512, scale_type=2, style_type=0, normal_type=0, data_type=0)
+    bft.set_result_type(1)
+    cc = ref.RefXXCC(128)
+    re, _ = bft.bft(x[0])
+    cc.xxcc(re, 13, 0)  # warm-up
+    t0 = time.perf_counter()
+    units = 0
+    for i in range(n):
+        re, _ = bft.bft(x[i])
+        cc.xxcc(re, 13, 0)
+        units += re.shape[0]
+    return units, time.perf_counter() - t0
+
+
+def cpu_worker_cfg4(args):
+    """reference CWT on `n` chunks of 2^16 samples; returns (chunks, seconds)"""
+    seed, n, threads = args
+    if threads > 0:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle import ref
+    r = ref.RefCWT(num=84, radix2_exp=16, samplate=44100, low_fre=32.703, bin_per_octave=12,
+                   wavelet_type=1, scale_type=5, is_padding=1)
+    x = (0.1 * np.random.default_rng(seed).standard_normal((n + 1, 65536))).astype(np.float32)
+    r.cwt(x[0])
+    t0 = time.perf_counter()
+    for i in range(n):
+        r.cwt(x[1 + i])
+    return n, time.perf_counter() - t0
+
+
+def cpu_worker_cfg5(args):
+    """reference CQT + chroma on `n` clips of 30 s @ 44.1 kHz; returns (top-octave frames, seconds)"""
+    seed, n, threads = args
+    if threads > 0:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle import ref
+    r = ref.RefCQT(num=84, samplate=44100, min_fre=32.703, bin_per_octave=12, normal_type=1)
+    x = (0.1 * np.random.default_rng(seed).standard_normal((n + 1, 1323000))).astype(np.float32)
+    r.chroma(*r.cqt(x[0]))  # (a shorter warm-up clip makes the reference corrupt its heap)
+    t0 = time.perf_counter()
+    frames = 0
+    for i in range(n):
+        re, im = r.cqt(x[1 + i])
+        r.chroma(re, im)
+        frames += re.shape[0]
+    return frames, time.perf_counter() - t0
+
+
+def cpu_baseline(worker, unit, per_proc, what, budget_s=25.0):
+    """reference CPU path on this box's host cores -- BASELINE.md section 3:
     (A) as shipped: one process, default OpenMP (frame loop on omp_get_max_threads()/2 threads,
         src/stft_algorithm.c:95-100; the matmul is serial);
-    (B) all cores: P worker processes with one FFT thread each (OMP_NUM_THREADS=2), clips
-        sharded; P is swept because hosts differ (SMT, cgroup quotas) and the best aggregate
-        is reported.  Bounded sample, objects pre-built, one warm-up call per worker."""
+    (B) all cores: P worker processes with one FFT thread each (OMP_NUM_THREADS=2), units sharded;
+        P is swept because hosts differ (SMT, cgroup quotas) and the best aggregate is reported.
+    Bounded sample, objects pre-built, one warm-up call per worker."""
     from oracle import ref
     if not ref.available():
         return None
@@ -89,39 +128,209 @@ def cpu_baseline(budget_s=25.0):
     ncpu = _effective_cpus()
     ctx = mp.get_context("spawn")
     with ctx.Pool(1) as pool:  # (A) in a fresh process so OMP defaults apply
-        fa, ta = pool.map(cpu_worker, [(1000, 8, 0)])[0]
-    best = {"value": fa / ta, "cores": ncpu, "how": "A: 1 process, default OpenMP", "frames": fa}
-    tried = [f"A=1proc:{fa / ta:.0f}"]
-    sizes = sorted({p for p in (8, 16, 32, 64, 128, 256, ncpu) if p <= ncpu})
-    for p in sizes:
+        fa, ta = pool.map(worker, [(1000, per_proc[0], 0)])[0]
+    best = {"value": fa / ta, "cores": ncpu, "how": "A: 1 process, default OpenMP", "units": fa}
+    tried = [f"A=1proc:{fa / ta:.4g}"]
+    for p in sorted({p for p in (8, 16, 32, 64, 128, 256, ncpu) if p <= ncpu}):
         if time.perf_counter() - t_start > budget_s:
             break
         with ctx.Pool(p) as pool:
-            res = pool.map(cpu_worker, [(2000 + i, 4, 2) for i in range(p)])
+            res = pool.map(worker, [(2000 + i, per_proc[1], 2) for i in range(p)])
         wall = max(r[1] for r in res)  # workers run concurrently; the slowest bounds the job
-        frames = sum(r[0] for r in res)
-        rate = frames / wall
-        tried.append(f"B={p}procs:{rate:.0f}")
+        rate = sum(r[0] for r in res) / wall
+        tried.append(f"B={p}procs:{rate:.4g}")
         if rate > best["value"]:
-            best = {"value": rate, "cores": p, "how": f"B: {p} processes x 1 FFT thread", "frames": frames,
-                    "procs": p}
-    # the sweep samples are short; re-time the best configuration on a sample sized for ~12 s of
-    # wall time (bounded: <= 96 clips per worker) and report that measurement
-    if "procs" in best and time.perf_counter() - t_start < budget_s:
+            best = {"value": rate, "cores": p, "how": f"B: {p} processes x 1 FFT thread",
+                    "units": sum(r[0] for r in res), "procs": p}
+    # the sweep samples are short; re-time the best configuration on a sample sized for ~12 s
+    if "procs" in best and per_proc[2] > per_proc[1] and time.perf_counter() - t_start < budget_s:
         p = best["procs"]
-        per_proc = best["value"] / p
-        n = int(max(8, min(96, 12.0 * per_proc / ((SR * CLIP_SECONDS - NFFT) // HOP + 1))))
         with ctx.Pool(p) as pool:
-            res = pool.map(cpu_worker, [(3000 + i, n, 2) for i in range(p)])
+            res = pool.map(worker, [(3000 + i, per_proc[2], 2) for i in range(p)])
         wall = max(r[1] for r in res)
-        frames = sum(r[0] for r in res)
-        tried.append(f"final={p}procsx{n}clips:{frames / wall:.0f}")
-        best.update(value=frames / wall, frames=frames)
-    return {"value": best["value"], "unit": "frames/s", "cores": best["cores"], "kind": "reference",
-            "sample": f"{best['how']}, {best['frames']} frames of {CLIP_SECONDS} s @16 kHz clips "
-                      f"(mel-128 + MFCC-13, n_fft 2048, hop 512); built-in radix-2 FFT + naive matmul "
-                      f"(no FFTW/MKL); visible cpus {ncpu}; sweep frames/s: " + " ".join(tried),
+        units = sum(r[0] for r in res)
+        tried.append(f"final={p}procsx{per_proc[2]}:{units / wall:.4g}")
+        best.update(value=units / wall, units=units)
+    return {"value": best["value"], "unit": unit, "cores": best["cores"], "kind": "reference",
+            "sample": f"{best['how']}, {best['units']} {unit.split('/')[0]} of {what}; built-in radix-2 FFT + "
+                      f"naive matmul (no FFTW/MKL); visible cpus {ncpu}; sweep {unit}: " + " ".join(tried),
             "wall_s": round(time.perf_counter() - t_start, 1)}
+
+
+# =================================================================================================
+# workloads
+def _parity(got, want):
+    got = np.asarray(got)
+    want = np.asarray(want)
+    den = np.abs(want).max() or 1.0
+    peak = float(np.abs(got - want).max() / den)
+    l2 = float(np.linalg.norm((got - want).ravel()) / (np.linalg.norm(want.ravel()) or 1.0))
+    return max(peak, l2)
+
+
+class Cfg2:
+    """batched STFT -> mel-128 -> MFCC-13, 1000 x 30 s @ 16 kHz per GPU, n_fft 2048, hop 512"""
+    config = 2
+    metric = "audio frames/sec (mel+MFCC, n_fft=2048 hop=512)"
+    unit = "frames/s"
+    default_clips = 1000
+    bytes_per_unit = 4 * 512 + 4 * 128 + 4 * 13  # SURVEY 8d: each sample once, each output once
+    kernel = ("k_stft_mel_v2 (framed FFT -> |S|^2 -> banded mel bank -> log10 -> DCT-II, "
+              "one launch per step)")
+    gather_choices = ("mfcc", "mel")
+
+    def __init__(self, torch, af, dev, rank, clips):
+        self.torch, self.af, self.clips = torch, af, clips
+        n = 16000 * 30
+        gen = torch.Generator(device=dev).manual_seed(1 + rank)
+        self.x = 0.1 * torch.randn((clips, n), generator=gen, device=dev, dtype=torch.float32)
+        self.bft = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+                          scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+        self.bft.set_result_type(1)
+        self.xx = af.XXCC(128)
+        self.T = self.bft.cal_time_length(n)
+        self.units = clips * self.T
+        self.mel = torch.empty((clips, self.T, 128), device=dev, dtype=torch.float32)
+        self.cc = [torch.empty((clips, self.T, 13), device=dev, dtype=torch.float32) for _ in range(2)]
+        self.workload = (f"batched STFT->mel128->MFCC13, {clips} x 30 s @16 kHz per GPU, n_fft=2048 hop=512 "
+                         f"(BASELINE cfg 2)")
+        self.outputs = "mel[clips,T,128] + mfcc[clips,T,13] f32 in HBM"
+
+    def step(self, i):
+        self.af.mel_mfcc_device(self.bft, self.xx, self.x, 13, out_mel=self.mel, out_cc=self.cc[i & 1])
+
+    def slab(self, i, which):
+        return self.cc[i & 1] if which == "mfcc" else self.mel
+
+    def check(self, i):
+        from oracle import ref
+        if not ref.available():
+            return None
+        rmel, rcc = ref.mel_mfcc(self.x[:1].cpu().numpy())
+        return max(_parity(self.mel[0].cpu().numpy(), rmel[0]), _parity(self.cc[i & 1][0].cpu().numpy(), rcc[0]))
+
+    def cpu(self):
+        return cpu_baseline(cpu_worker_cfg2, "frames/s", (8, 4, 96), "30 s @16 kHz clips (mel-128 + MFCC-13, "
+                            "n_fft 2048, hop 512)")
+
+
+class Cfg4:
+    """CWT morlet, 84 scales, 1000 x 10 s @ 44.1 kHz = 7000 chunks of 2^16 samples (padded, L = 2^17)"""
+    config = 4
+    metric = "CWT chunks/sec (morlet, 84 scales, 2^16-sample chunks @44.1 kHz, padded L=2^17)"
+    unit = "chunks/s"
+    default_clips = 1000
+    bytes_per_unit = 65536 * (4 + 8 * 84)  # 676 B per input sample
+    kernel = ("all launches of one step: k_cwt_fwd_* (1/84 of the work), k_cwt_inv_rows512 + k_cwt_inv_cols256 "
+              "(wide scales), k_cwt_inv_cols256_nb<R> (narrow-band scales)")
+    gather_choices = ()
+    GROUP = 32  # chunks per device call: the [84, 2^16] complex outputs (44 MB per chunk) are ring-buffered
+
+    def __init__(self, torch, af, dev, rank, clips):
+        self.torch, self.af, self.clips = torch, af, clips
+        self.o = af.CWT(num=84, radix2_exp=16, samplate=44100, low_fre=32.703, bin_per_octave=12,
+                        wavelet_type=af.WaveletContinueType.MORLET,
+                        scale_type=af.SpectralFilterBankScaleType.OCTAVE, is_padding=True)
+        gen = torch.Generator(device=dev).manual_seed(3 + rank)
+        # every clip = 7 chunks of 65536 samples, the last one zero padded (441 000 = 6 x 65536 + 47 784)
+        x = torch.zeros((clips, 7 * 65536), device=dev, dtype=torch.float32)
+        x[:, :441000] = 0.1 * torch.randn((clips, 441000), generator=gen, device=dev, dtype=torch.float32)
+        self.x = x.view(clips * 7, 65536)
+        self.units = clips * 7
+        g = min(self.GROUP, self.units)
+        self.ring = [(torch.empty((g, 84, 65536), device=dev), torch.empty((g, 84, 65536), device=dev))
+                     for _ in range(2)]
+        self.workload = (f"CWT morlet 84 scales, {clips} x 10 s @44.1 kHz per GPU = {self.units} chunks of 2^16 "
+                         f"samples, padded (L=2^17) (BASELINE cfg 4)")
+        self.outputs = f"[84, 65536] complex per chunk, ring-buffered in HBM ({g} chunks per call)"
+
+    def step(self, i):
+        g = self.ring[0][0].shape[0]
+        k = 0
+        for c0 in range(0, self.units, g):
+            n = min(g, self.units - c0)
+            re, im = self.ring[k & 1]
+            self.o.cwt_device(self.x[c0:c0 + n], re[:n], im[:n])
+            k += 1
+        self.last = (k - 1) & 1, self.units - n, n
+
+    def check(self, i):
+        from oracle import ref
+        if not ref.available():
+            return None
+        slot, c0, n = self.last
+        r = ref.RefCWT(num=84, radix2_exp=16, samplate=44100, low_fre=32.703, bin_per_octave=12,
+                       wavelet_type=1, scale_type=5, is_padding=1)
+        rre, rim = r.cwt(self.x[c0].cpu().numpy())
+        re, im = self.ring[slot]
+        return _parity(re[0].cpu().numpy() + 1j * im[0].cpu().numpy(), rre + 1j * rim)
+
+    def cpu(self):
+        return cpu_baseline(cpu_worker_cfg4, "chunks/s", (2, 1, 2), "2^16-sample chunks (84 morlet scales, padded)")
+
+
+class Cfg5:
+    """CQT 84 bins (12 / octave) + chroma-12, 30 s @ 44.1 kHz clips, 125 clips per GPU"""
+    config = 5
+    metric = "CQT top-octave frames/sec (84 bins, 12/octave, + chroma, 30 s @44.1 kHz clips)"
+    unit = "frames/s"
+    default_clips = 125
+    bytes_per_unit = 4 * 128 + 8 * 84 + 4 * 12  # hop 128 samples in, 84 complex + 12 chroma out
+    kernel = ("all launches of one step: 7 x k_cqt_octave_mfma_w (one per octave), 6 x k_cqt_decimate, "
+              "k_cqt_chroma")
+    gather_choices = ("chroma", "cqt")
+
+    def __init__(self, torch, af, dev, rank, clips):
+        self.torch, self.af, self.clips = torch, af, clips
+        n = 1323000
+        self.o = af.CQT(num=84, samplate=44100, low_fre=32.703, bin_per_octave=12,
+                        normal_type=af.SpectralFilterBankNormalType.AREA)
+        gen = torch.Generator(device=dev).manual_seed(4 + rank)
+        self.x = 0.1 * torch.randn((clips, n), generator=gen, device=dev, dtype=torch.float32)
+        self.T = self.o.cal_time_length(n)
+        self.units = clips * self.T
+        self.re = torch.empty((clips, self.T, 84), device=dev)
+        self.im = torch.empty_like(self.re)
+        self.ch = [torch.empty((clips, self.T, 12), device=dev) for _ in range(2)]
+        self.workload = (f"CQT 84 bins (12/octave) + chroma-12, {clips} x 30 s @44.1 kHz per GPU "
+                         f"(BASELINE cfg 5)")
+        self.outputs = "cqt[clips,T,84] complex (split planes) + chroma[clips,T,12] f32 in HBM"
+
+    def step(self, i):
+        self.o.cqt_device(self.x, self.re, self.im)
+        self.o.chroma_device(self.re, self.im, out=self.ch[i & 1])
+
+    def slab(self, i, which):
+        return self.ch[i & 1] if which == "chroma" else self.re
+
+    def check(self, i):
+        from oracle import ref
+        if not ref.available():
+            return None
+        r = ref.RefCQT(num=84, samplate=44100, min_fre=32.703, bin_per_octave=12, normal_type=1)
+        rre, rim = r.cqt(self.x[0].cpu().numpy())
+        rch = r.chroma(rre, rim)
+        return max(_parity(self.re[0].cpu().numpy() + 1j * self.im[0].cpu().numpy(), rre + 1j * rim),
+                   _parity(self.ch[i & 1][0].cpu().numpy(), rch))
+
+    def cpu(self):
+        return cpu_baseline(cpu_worker_cfg5, "frames/s", (1, 1, 1), "30 s @44.1 kHz clips (CQT-84 + chroma-12)")
+
+
+WORKLOADS = {2: Cfg2, 4: Cfg4, 5: Cfg5}
+
+
+def pmc_traffic(config, clips):
+    """HBM bytes per step from the round's rocprofv3 --pmc passes of this command
+    (tools/prof_traffic.py): 2 x FETCH_SIZE (gfx950 tallies wide coalesced reads at half,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB, scaled to this run's clip count"""
+    path = os.path.join(ROOT, "profiles", f"r02_bench_cfg{config}_pmc.json")
+    try:
+        rec = json.load(open(path))
+        per_step = (2.0 * rec["fetch_kib_per_step"] + rec["write_kib_per_step"]) * 1024.0
+        return per_step * clips / rec["clips"], os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
@@ -129,9 +338,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips", type=int, default=1000, help="clips per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (0: the configuration's own)")
+    ap.add_argument("--gather", default="", help="comma list of feature slabs gathered to rank 0 when N > 1 "
+                    "(cfg 2: mfcc[,mel]; cfg 5: chroma[,cqt]); default: the first one")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--clock-warmup", type=float, default=0.5, help="seconds of untimed steps before the W warm-up "
+                    "steps: the device ramps its clocks over tens of ms after idling, and W steps of ~1.5 ms end "
+                    "long before that (0 disables; reported as config.clock_warmup_s)")
     a = ap.parse_args()
 
     import torch
@@ -145,58 +362,55 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    os.environ.setdefault("AFX_DEVICE", str(local))
-    get = af.get_lib()
-    get.afx_set_device(local)
+    af._lib.check(af.get_lib().afx_set_device(local), "afx_set_device")
 
-    length = SR * CLIP_SECONDS
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)
-    x = 0.1 * torch.randn((a.clips, length), generator=gen, device=dev, dtype=torch.float32)
+    W = WORKLOADS[a.config]
+    clips = a.clips or W.default_clips
+    w = W(torch, af, dev, rank, clips)
+    which = [g for g in (a.gather.split(",") if a.gather else list(W.gather_choices[:1])) if g]
+    for g in which:
+        assert g in W.gather_choices, f"--gather {g}: config {a.config} offers {W.gather_choices}"
+    gathers = ([afd.FeatureGather(dst=0, counts=[clips] * world) for _ in which]
+               if (world > 1 and not a.no_gather) else [])
+    comm = torch.cuda.Stream(device=dev) if gathers else None
 
-    bft = af.BFT(NMEL, radix2_exp=11, samplate=SR, low_fre=0.0, high_fre=SR / 2.0, slide_length=HOP,
-                 scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
-    bft.set_result_type(1)
-    xx = af.XXCC(NMEL)
-    T = bft.cal_time_length(length)
-    frames_per_step = a.clips * T
-    mel = torch.empty((a.clips, T, NMEL), device=dev, dtype=torch.float32)
-    ccs = [torch.empty((a.clips, T, NCC), device=dev, dtype=torch.float32) for _ in range(2)]
-    gather = afd.FeatureGather(dst=0) if (world > 1 and not a.no_gather) else None
-    comm = torch.cuda.Stream(device=dev) if gather else None
-
-    ev_pairs = []
+    ev = []
 
     def step(i, timed):
-        cc = ccs[i & 1]
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        e2 = torch.cuda.Event(enable_timing=True)
-        # the two launches of afx_bftXxccBatchDevice, issued separately so that HIP events
-        # on the launch stream bracket the dominant kernel alone
         e0.record()
-        bft.bft_device(x, out_real=mel)          # k_stft_mel_banded: STFT -> |S|^2 -> mel bank
+        w.step(i)
         e1.record()
-        xx.xxcc_device(mel, NCC, out=cc)         # k_cepstrum_mfma: log10 -> DCT-II -> 13 coeffs
-        e2.record()
         if timed:
-            ev_pairs.append((e0, e1, e2))
-        if gather:
-            # MFCC slab of this step goes to rank 0 while the next step computes
-            gather.wait()
+            ev.append((e0, e1))
+        if gathers:
+            # the slabs of this step go to rank 0 while the next step computes (double-buffered
+            # sources; the previous gather has had a whole step to finish)
+            for g in gathers:
+                g.wait()
             comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm):
-                gather.start(cc)
+                for g, name in zip(gathers, which):
+                    g.start(w.slab(i, name))
 
     def fence():
-        if gather:
-            gather.wait()
+        for g in gathers:
+            g.wait()
+        if comm is not None:
             torch.cuda.current_stream().wait_stream(comm)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.clock_warmup > 0:  # untimed, like the W steps below: brings the clocks to their loaded state
+        tw, i = time.perf_counter(), 0
+        while time.perf_counter() - tw < a.clock_warmup:
+            step(i, False)
+            i += 1
+            if i % 8 == 0:
+                torch.cuda.synchronize()
     for i in range(a.warmup):
         step(i, False)
     fence()
@@ -209,42 +423,58 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if ev else None
 
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in ev_pairs])) if ev_pairs else None
-    cep_ms = float(np.mean([e1.elapsed_time(e2) for _, e1, e2 in ev_pairs])) if ev_pairs else None
+    # ---- outside the timed region ----------------------------------------------------------------
+    sustained_ms = None
+    if world == 1 and not a.no_sustained:
+        n, s0, s1 = 0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        s0.record()
+        while True:
+            w.step(n)
+            n += 1
+            if n % 8 == 0:
+                torch.cuda.synchronize()
+                if time.perf_counter() - t1 >= 1.0:
+                    break
+        s1.record()
+        torch.cuda.synchronize()
+        sustained_ms = s0.elapsed_time(s1) / n
+    err = None
+    if rank == 0 and not a.no_check:
+        err = w.check(max(a.steps - 1, 0) if sustained_ms is None else n - 1)
+        assert err is None or err <= 1e-5, f"benchmarked output differs from the oracle: {err:.3e}"
 
     if rank == 0:
-        total_frames = frames_per_step * world * a.steps
-        value = total_frames / elapsed
-        achieved = frames_per_step * BYTES_PER_FRAME_MEL_KERNEL / (kern_ms * 1e-3) / 1e9 if kern_ms else None
+        value = w.units * world * a.steps / elapsed
+        achieved = w.units * W.bytes_per_unit / (kern_ms * 1e-3) / 1e9 if kern_ms else None
+        traffic, traffic_src = pmc_traffic(a.config, clips)
+        par = f"clips sharded x{world}"
+        if gathers:
+            par += f", RCCL gather of {'+'.join(which)} to rank 0 (side stream, overlapped)"
+        elif world > 1:
+            par += ", replicas only (no gather)"
         out = {
-            "metric": "audio frames/sec (mel+MFCC, n_fft=2048 hop=512)",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "metric": W.metric, "value": value, "unit": W.unit, "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"batched STFT->mel{NMEL}->MFCC{NCC}, {a.clips} x {CLIP_SECONDS} s "
-                                   f"@16 kHz per GPU, n_fft={NFFT} hop={HOP} (BASELINE cfg 2)",
-                       "clips_per_gpu": a.clips, "frames_per_step_per_gpu": frames_per_step,
-                       "outputs": "mel[clips,T,128] + mfcc[clips,T,13] f32 in HBM",
-                       "parallelism": f"clips sharded x{world}" + (", RCCL gather of MFCC to rank 0" if gather else "")},
+            "config": {"workload": w.workload, "clips_per_gpu": clips, "units_per_step_per_gpu": w.units,
+                       "outputs": w.outputs, "parallelism": par, "clock_warmup_s": a.clock_warmup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         # HBM bytes per launch from rocprofv3 PMC passes of this same command
-                         # (profiles/r01_final_rocprofv3_bench_summary.txt): 2*FETCH_SIZE (gfx950 counts
-                         # wide coalesced reads at half) + WRITE_SIZE, in KiB -> bytes; scales with clips
-                         "traffic": (2 * 955752 + 467001) * 1024 * (a.clips / 1000.0),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_final_*",
-                         "kernel": "k_stft_mel_banded (framed FFT -> |S|^2 -> banded mel bank), "
-                                   "one launch per step",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": BYTES_PER_FRAME_MEL_KERNEL,
-                         "frames_per_launch": frames_per_step,
-                         "second_kernel": {"name": "k_cepstrum_mfma (log10 + DCT-II)", "kernel_ms": cep_ms,
-                                           "algorithmic_bytes_per_frame": 4 * NMEL + 4 * NCC},
-                         "step_algorithmic_bytes_per_frame": BYTES_PER_FRAME},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": W.kernel, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_unit": W.bytes_per_unit, "units_per_launch": w.units,
+                         "sustained_ms": sustained_ms,
+                         "sustained_value": (w.units / (sustained_ms * 1e-3)) if sustained_ms else None,
+                         "sustained_frac": (w.units * W.bytes_per_unit / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         if sustained_ms else None},
+            "oracle_check": {"clip0_max_rel_err": err, "bar": 1e-5},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = w.cpu()
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

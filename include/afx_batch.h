@@ -156,6 +156,25 @@ int stftObj_istftBatchDevice(STFTObj stftObj, const float *dReal, const float *d
                              int nLength, int type, float *dData, long long dataStride,
                              void *hipStream);
 
+/* ---- the exchange step (multi-GPU): feature slabs -> root over RCCL / xGMI -------------------
+ * One process per GPU, clips sharded contiguously (rank r owns clips [r*ceil(B/G), ...)): the
+ * transforms need no collective, the gathered tensor is the ranks' slabs back to back.  RCCL is
+ * bound at run time (dlopen of librccl.so.1; a copy already mapped by the process is shared), so
+ * single-GPU deployments never load it.  Bootstrap: rank 0 calls afx_comm_get_unique_id and
+ * hands the 128 bytes to the other ranks by whatever the launcher offers (MPI, a file, the
+ * torch.distributed store: audioflux_amd/dist.py), then every rank calls afx_comm_create.
+ * afx_gather is asynchronous on `hipStream` like ncclGather (rccl.h:745): `count` floats from
+ * dSend on every rank, worldSize*count floats into dRecv on `root` (dRecv is ignored elsewhere).
+ * All return 0 or a negative status (-4: RCCL not installed). */
+#define AFX_COMM_ID_BYTES 128
+typedef struct AfxComm *AfxCommObj;
+int afx_comm_get_unique_id(void *id /* out: AFX_COMM_ID_BYTES */);
+int afx_comm_create(AfxCommObj *comm, int worldSize, int rank, const void *id);
+int afx_comm_world_size(AfxCommObj comm);
+int afx_comm_rank(AfxCommObj comm);
+int afx_gather(AfxCommObj comm, const float *dSend, long long count, float *dRecv, int root, void *hipStream);
+void afx_comm_free(AfxCommObj comm);
+
 #ifdef __cplusplus
 }
 #endif

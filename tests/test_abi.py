@@ -133,7 +133,7 @@ def test_every_void_compute_call_of_the_wrappers_is_checked():
         for i, line in enumerate(lines):
             if line.strip().endswith(".restype = None"):
                 ctx = "\n".join(lines[max(0, i - 4):i + 1])
-                if "Obj_free" in ctx or "_lib.checked(" in ctx or "class _Checked" in ctx:
+                if "Obj_free" in ctx or "_free." in ctx or "_lib.checked(" in ctx or "class _Checked" in ctx:
                     continue
                 bad.append(f"{os.path.basename(path)}:{i + 1}")
     assert bad == [], bad

@@ -166,3 +166,59 @@ def test_cwt_register_fft_path_L131072():
     wa, wb = o.cwt(x[0]), o.cwt(y)
     ws = o.cwt((x[0] - 2 * y).astype(np.float32))
     assert np.abs(ws - (wa - 2 * wb)).max() <= 2e-5 * np.abs(ws).max()
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_one_launch_mel_mfcc_variants_against_reference():
+    """afx_bftXxccBatchDevice on the one-launch path of k_stft_mel_v2 (cepstra of every 16 rows of a
+    wave by MFMA): clip lengths whose frame counts leave partial 16-row blocks, every ccNum <= 16,
+    with and without the mel output, several hops; the separate-kernel route (cubic-root
+    rectification, ccNum > 16) must give reference results too."""
+    torch = _torch()
+    rng = np.random.default_rng(77)
+    for hop, n, clips in ((512, 2048 + 512 * 36 + 5, 5), (512, 2048 + 512 * 15, 3), (300, 16000, 2), (1024, 40000, 4)):
+        x = (0.1 * rng.standard_normal((clips, n))).astype(np.float32)
+        x[0, : n // 2] = 0.0  # silent frames: the 1e-8 floor of the rectification
+        xd = torch.from_numpy(x).cuda()
+        bft = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+                     scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+        bft.set_result_type(1)
+        xx = af.XXCC(128)
+        rb = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1, slide_length=hop,
+                        scale_type=2, style_type=0, normal_type=0, data_type=0)
+        rb.set_result_type(1)
+        rc = ref.RefXXCC(128)
+        rmel = np.stack([rb.bft(x[i])[0] for i in range(clips)])
+        for cc_num, want_mel, rect in ((13, True, 0), (16, False, 0), (1, True, 0), (7, False, 0), (20, True, 0), (13, True, 1)):
+            mel, cc = af.mel_mfcc_device(bft, xx, xd, cc_num, rectify_type=af.CepstralRectifyType(rect),
+                                         want_mel=want_mel)
+            torch.cuda.synchronize()
+            want = np.stack([rc.xxcc(rmel[i], cc_num, rect) for i in range(clips)])
+            assert_parity(cc.cpu().numpy(), want, what=f"mfcc hop{hop} cc{cc_num} mel{want_mel} rect{rect}")
+            if want_mel:
+                assert_parity(mel.cpu().numpy(), rmel, what=f"mel hop{hop}")
+
+
+def test_objects_are_usable_from_other_threads():
+    """HIP's current device is per thread: an object built on one thread computes on another, and a
+    thread that never touched the library builds its own (device binding per entry point)"""
+    import threading
+    x = (0.1 * np.random.default_rng(5).standard_normal(30000)).astype(np.float32)
+    o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+               scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+    want = o.bft(x, result_type=1)
+    out = {}
+
+    def worker():
+        out["shared"] = o.bft(x, result_type=1)
+        mine = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+                      scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+        out["own"] = mine.bft(x, result_type=1)
+        c = af.CQT(num=84, samplate=32000)
+        out["cqt"] = c.cqt(x)
+
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    assert np.array_equal(out["shared"], want) and np.array_equal(out["own"], want)
+    assert np.array_equal(out["cqt"], af.CQT(num=84, samplate=32000).cqt(x))

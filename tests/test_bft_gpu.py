@@ -288,3 +288,28 @@ def test_bft_linear_scale_n2048_every_result_mode(hop):
             o.set_data_norm_value(norm)
         got = o.bft(x, result_type=rt).T
         assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"linear hop{hop} rt{rt} dt{dt} norm{norm}")
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("hop", [512, 300])
+def test_temporal_features_ride_in_the_fused_kernel(hop):
+    """isTemporal objects at n_fft 2048 stay on k_stft_mel_v2 (energy / rms / zcr as wave reductions,
+    temporal_algorithm.c:138-144) -- whole-row and split plans, register re-use and plain fetch."""
+    x = cases.tones(12, 16000 * 2 + 301, 16000) + 0.05 * cases.noise(70, 16000 * 2 + 301)
+    for num, scale in ((128, 2), (64, 3)):  # mel-128: whole rows; bark-64: split plan
+        r = ref.RefBFT(num, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1,
+                       slide_length=hop, scale_type=scale, style_type=0, normal_type=0, data_type=0, is_temporal=1)
+        r.set_result_type(1)
+        re, _ = r.bft(x)
+        we, wr, wz = r.temporal(re.shape[0])
+        o = af.BFT(num, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+                   scale_type=af.SpectralFilterBankScaleType(scale), data_type=af.SpectralDataType.POWER,
+                   is_temporal=True)
+        assert o.fused_plan_kind() in (1, 2)
+        got = o.bft(x, result_type=1).T
+        e, rms, z = o.get_temporal_data()
+        assert_parity(got, re, TOL, f"temporal spec num{num} hop{hop}")
+        assert_parity(e, we, TOL, "energy")
+        assert_parity(rms, wr, TOL, "rms")
+        # a sign change decided by a product at float32 rounding may differ: at most one count per frame
+        assert np.abs(z - wz).max() <= 1.0 / 2048 + 1e-9 and (z != wz).mean() <= 0.02, np.abs(z - wz).max()

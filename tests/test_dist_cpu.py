@@ -19,14 +19,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_clips=6):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from audioflux_amd import dist as afd
     import torch.distributed as dist
     r, _, w = afd.init_from_env(backend="gloo")
-    n_clips, t, c = 6, 5, 3
+    t, c = 5, 3
     start, stop = afd.shard_range(n_clips, r, w)
     # "features" of clip i are filled with i so the gathered layout is checkable
     slab = torch.stack([torch.full((t, c), float(i)) for i in range(start, stop)])
@@ -53,11 +53,12 @@ def test_shard_range_partitions_everything():
 
 
 @pytest.mark.timeout(120)
-def test_gather_world2_gloo():
+@pytest.mark.parametrize("n_clips", [6, 7])  # 7: ceil-sized blocks 4 + 3, the short shard is padded / trimmed
+def test_gather_world2_gloo(n_clips):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, n_clips)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=90) for _ in procs)

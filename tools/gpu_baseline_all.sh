@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 (time timeout 600 python -m pytest tests -q -m gpu) > $OUT/pytest.log 2>&1
 echo "pytest -m gpu rc=$? $(grep -E 'passed|failed' $OUT/pytest.log | tail -n 1)" | tee $OUT/status.txt
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json
-for t in "bench_aux.py --cwt-chunks 32 --cqt-clips 32" bench_cepstrogram.py bench_split.py bench_stft.py \
+for t in bench_cepstrogram.py bench_split.py bench_stft.py \
          "bench_nfft.py 10 256" "bench_nfft.py 12 1024" bench_complex.py bench_cwt_small.py bench_next.py; do
   echo "== tools/$t" >> $OUT/rates.txt
   timeout 300 python tools/$t 2>&1 | grep -vE "^\s*$|Warning|warn" | tail -n 14 >> $OUT/rates.txt

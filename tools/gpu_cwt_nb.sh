@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_cwt_gpu.py tests/test_pwt_gpu.py tests/test_wsst_gpu.py tests/test_synsq_gpu.py \
     tests/test_fullsize_gpu.py -x -q -m gpu -k "cwt or pwt or wsst or synsq" > $OUT/pytest.log 2>&1
 echo "pytest CWT consumers (default plan) rc=$? $(tail -n 1 $OUT/pytest.log)" | tee -a $OUT/status.txt
-run() { echo "$1: $(env $1 timeout 300 python tools/bench_aux.py --only cwt --cwt-chunks 32 --steps 5 --warmup 2 2>&1 | tail -n 1 | cut -c80-160)" | tee -a $OUT/bench.txt; }
+run() { echo "$1: $(env $1 timeout 300 python bench.py --config 4 --clips 5 --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-sustained 2>&1 | tail -n 1 | cut -c1-160)" | tee -a $OUT/bench.txt; }
 for rnd in 1 2; do
   run "AFX_CWT_NARROW_MAX=0 AFX_CWT_GROUP=1"
   run "AFX_CWT_NARROW_MAX=0"
@@ -20,7 +20,7 @@ for rnd in 1 2; do
 done
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o trace -- \
-      python $GRAFT_REPO_ROOT/tools/bench_aux.py --only cwt --cwt-chunks 32 --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/$OUT/trace.log 2>&1
+      python $GRAFT_REPO_ROOT/bench.py --config 4 --clips 5 --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-sustained > $GRAFT_REPO_ROOT/$OUT/trace.log 2>&1
 cd "$GRAFT_REPO_ROOT"
 python tools/prof_summary.py $(find $OUT -name '*.db' | sort) > $OUT/summary.txt 2>&1
 tail -n 1 $OUT/trace.log >> $OUT/summary.txt
