@@ -7,11 +7,19 @@
 //   below the power threshold the coordinate stays (t_i, f_j); clip to the grid   (:772-822)
 //   target cell = rounded position of (t', f') on the (frame, bin) grid           (:312-320)
 // k_reassign_index stores the two target indices (-1: dropped), k_reassign_order applies the
-// reference's "order" iteration of the frequency index (:340-358), and k_reassign_scatter adds
-// every coefficient, sign-flipped on odd bins (:378-381), to its target cell.  A target cell
-// collects sources from several frames and bins, so the scatter uses float atomics in HBM; the
-// order of the float32 additions differs from the reference's loop order by ~1e-7 of the sum.
+// reference's "order" iteration of the frequency index (:340-358); every coefficient, sign-flipped
+// on odd bins (:378-381), is then added to its target cell.  A target cell collects sources from
+// several frames and bins.  The reference adds them in its loop order (frames outer, bins inner,
+// :360-414); so does this file, WITHOUT atomics: (target cell, source index) pairs are sorted by
+// target with a stable device radix sort (rocPRIM; ties keep the ascending source order), and one
+// thread per target cell walks its run and sums sequentially -- the float32 additions happen in
+// the reference's order, the result is deterministic run to run and bit-identical to the
+// reference's accumulation whenever the transforms and target indices agree.
 #include <hip/hip_runtime.h>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
@@ -71,26 +79,48 @@ __global__ void k_reassign_order(const int *cur, int *next, int T, int F) {
     if (v >= 0 && v < F) next[base + e] = cur[base + (long long)i * F + v];
 }
 
-__global__ void k_reassign_scatter(AfxReassignArgs a) {
+// sort key of source e of clip c (local to a sort chunk): cLocal * cells + target cell, or all ones
+// when the coefficient is dropped (sorted behind every cell)
+__global__ void k_reassign_keys(AfxReassignArgs a, int clip0, unsigned long long *keys) {
     const int F = a.F, T = a.timeLength;
+    const long long cells = (long long)T * F;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long long)T * F) return;
-    const int j = (int)(e % F);
-    const long long base = (long long)blockIdx.y * T * F;
+    if (e >= cells) return;
+    const long long base = (long long)(clip0 + blockIdx.y) * cells;
     const int i1 = a.timeIdx[base + e], j1 = a.freIdx[base + e];
-    if (i1 < 0 || i1 >= T || j1 < 0 || j1 >= F) return;
-    float v1 = a.hRe[base + e], v2 = a.hIm[base + e];
-    if (j & 1) {
-        v1 = -v1;
-        v2 = -v2;
+    const bool ok = !(i1 < 0 || i1 >= T || j1 < 0 || j1 >= F);
+    keys[(long long)blockIdx.y * cells + e] =
+        ok ? (unsigned long long)((long long)blockIdx.y * cells + (long long)i1 * F + j1) : ~0ull;
+}
+
+// one thread per sorted position; the thread at the first position of a run of equal keys owns the
+// target cell and adds the run's sources in order (ascending source index = the reference's loop order)
+__global__ void k_reassign_sum(AfxReassignArgs a, int clip0, long long n, const unsigned long long *keys,
+                               const unsigned *src) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const unsigned long long key = keys[p];
+    if (key == ~0ull || (p > 0 && keys[p - 1] == key)) return;
+    const int F = a.F;
+    const long long cells = (long long)a.timeLength * F;
+    const long long clipBase = (long long)clip0 * cells;  // key / src are local to the chunk starting at clip0
+    float sr = 0.f, si = 0.f;
+    for (long long q = p; q < n && keys[q] == key; ++q) {
+        const long long e = src[q];  // chunk-local source index: cLocal * cells + i * F + j
+        float v1 = a.hRe[clipBase + e], v2 = a.hIm[clipBase + e];
+        if ((e % cells % F) & 1) {
+            v1 = -v1;
+            v2 = -v2;
+        }
+        if (!a.resultType) {
+            sr += v1;
+            si += v2;
+        } else {
+            sr += sqrtf(v1 * v1 + v2 * v2);
+        }
     }
-    const long long o = base + (long long)i1 * F + j1;
-    if (!a.resultType) {
-        atomicAdd(a.outRe + o, v1);
-        atomicAdd(a.outIm + o, v2);
-    } else {
-        atomicAdd(a.outRe + o, sqrtf(v1 * v1 + v2 * v2));
-    }
+    a.outRe[clipBase + (long long)key] += sr;  // the caller's (zeroed) accumulator, one writer per cell
+    if (!a.resultType) a.outIm[clipBase + (long long)key] += si;
 }
 
 }  // namespace
@@ -123,7 +153,50 @@ extern "C" int afxk_reassign(const AfxReassignArgs *a, int order, int *idxScratc
                                    (hipStream_t)stream));
         }
     }
-    hipLaunchKernelGGL(k_reassign_scatter, grid, dim3(256), 0, (hipStream_t)stream, b);
-    AFX_LAUNCH_CHECK("k_reassign_scatter");
+    // ordered accumulation, chunks of clips of at most ~32 M coefficients per sort
+    const long long maxN = 32LL << 20;
+    int per = (int)(maxN / cells);
+    if (per < 1) per = 1;
+    if (per > a->batch) per = a->batch;
+    if ((long long)per * cells > 0xffffffffLL) {
+        afxdev_set_error("reassign: %lld cells per clip exceed the 32-bit source index", cells);
+        return AFX_ERR_UNSUPPORTED;
+    }
+    const long long nMax = (long long)per * cells;
+    hipStream_t hs = (hipStream_t)stream;
+    unsigned long long *keysIn = nullptr, *keysOut = nullptr;
+    unsigned *srcOut = nullptr;
+    void *tmp = nullptr;
+    size_t tmpBytes = 0;
+    rocprim::counting_iterator<unsigned> srcIn(0);
+    // 64-bit keys span [0, per * cells): only the bits in use are sorted
+    unsigned endBit = 1;
+    while (endBit < 64 && (1ull << endBit) < (unsigned long long)nMax) ++endBit;
+    AFX_HIP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keysIn, keysOut, srcIn, srcOut, (size_t)nMax, 0u, 64u, hs));
+    AFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&keysIn), sizeof(unsigned long long) * nMax, hs));
+    AFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&keysOut), sizeof(unsigned long long) * nMax, hs));
+    AFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&srcOut), sizeof(unsigned) * nMax, hs));
+    AFX_HIP(hipMallocAsync(&tmp, tmpBytes ? tmpBytes : 4, hs));
+    int st = AFX_OK;
+    for (int c0 = 0; c0 < a->batch && st == AFX_OK; c0 += per) {
+        const int nc = (a->batch - c0 < per) ? a->batch - c0 : per;
+        const long long n = (long long)nc * cells;
+        hipLaunchKernelGGL(k_reassign_keys, dim3((unsigned)blocks, (unsigned)nc), dim3(256), 0, hs, b, c0, keysIn);
+        // dropped coefficients carry the all-ones key: all 64 bits take part so that they sort last
+        hipError_t e = rocprim::radix_sort_pairs(tmp, tmpBytes, keysIn, keysOut, srcIn, srcOut, (size_t)n, 0u, 64u, hs);
+        if (e != hipSuccess) {
+            afxdev_set_error("reassign: rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
+            st = AFX_ERR_HIP;
+            break;
+        }
+        hipLaunchKernelGGL(k_reassign_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, b, c0, n, keysOut, srcOut);
+    }
+    (void)endBit;
+    (void)hipFreeAsync(keysIn, hs);
+    (void)hipFreeAsync(keysOut, hs);
+    (void)hipFreeAsync(srcOut, hs);
+    (void)hipFreeAsync(tmp, hs);
+    if (st != AFX_OK) return st;
+    AFX_LAUNCH_CHECK("k_reassign_sum");
     return AFX_OK;
 }
