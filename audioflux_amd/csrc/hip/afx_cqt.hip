@@ -449,6 +449,7 @@ struct Taps32 {
 // then right taps j = 1..31 at x[2i + j]) as one fma chain.
 constexpr int DEC_OUT = 1024, DEC_LDS = DEC_OUT + 40;
 
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ x, int srcLen,
                                                       long long xStride, float *__restrict__ y,
                                                       int dstLen, long long yStride, Taps32 tp,
@@ -461,8 +462,15 @@ __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ 
     y += (long long)blockIdx.y * yStride;
     for (int k = tid; k < DEC_LDS; k += 256) {
         const long long s = 2LL * (i0 - 16 + k);
-        XE[k] = (s >= 0 && s < srcLen) ? x[s] : 0.f;
-        XO[k] = (s + 1 >= 0 && s + 1 < srcLen) ? x[s + 1] : 0.f;
+        if (PAIRS && s >= 0 && s + 1 < srcLen) {
+            // 8-byte aligned rows: the even / odd sample pair is one coalesced load
+            const float2 v = *reinterpret_cast<const float2 *>(x + s);
+            XE[k] = v.x;
+            XO[k] = v.y;
+        } else {
+            XE[k] = (s >= 0 && s < srcLen) ? x[s] : 0.f;
+            XO[k] = (s + 1 >= 0 && s + 1 < srcLen) ? x[s + 1] : 0.f;
+        }
     }
     __syncthreads();
     // outputs i = i0 + 4 tid + q; LDS index of x[2 (i + d)] is 4 tid + q + d + 16
@@ -506,7 +514,8 @@ __global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re
     float *p = reinterpret_cast<float *>(smem_raw);          // [CH_FRAMES][num]
     float *cv = p + CH_FRAMES * num;                          // [CH_FRAMES][chromaNum]
     float *nrm = cv + CH_FRAMES * chromaNum;                  // [CH_FRAMES]
-    unsigned char *fl = reinterpret_cast<unsigned char *>(nrm + CH_FRAMES);  // [chromaNum][num]
+    int *cnt = reinterpret_cast<int *>(nrm + CH_FRAMES);      // [chromaNum] bins per chroma class
+    unsigned char *fl = reinterpret_cast<unsigned char *>(cnt + chromaNum);  // [chromaNum][num] bin lists
     const int tid = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * CH_FRAMES;
     const int nf = rows - f0 < CH_FRAMES ? (int)(rows - f0) : CH_FRAMES;
@@ -519,15 +528,23 @@ __global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re
         if (isMag) v = sqrtf(v);
         p[e] = v;
     }
-    for (int e = tid; e < chromaNum * num; e += 256) fl[e] = fold[e];
+    // the 0/1 matrix as per-chroma lists of bins (ascending, the order of the matrix product): a chroma
+    // class collects num / chromaNum bins, scanning all num flags per (frame, class) costs 12x the adds
+    for (int c = tid; c < chromaNum; c += 256) {
+        unsigned char *lst = fl + c * num;  // overwritten in place: list entries never pass the scan position
+        int n = 0;
+        for (int j = 0; j < num; ++j)
+            if (fold[c * num + j]) lst[n++] = (unsigned char)j;
+        cnt[c] = n;
+    }
     __syncthreads();
     for (int it = tid; it < nf * chromaNum; it += 256) {
         const int f = it / chromaNum, c = it - f * chromaNum;
         const float *row = p + f * num;
-        const unsigned char *fr = fl + c * num;
+        const unsigned char *lst = fl + c * num;
+        const int n = cnt[c];
         float v = 0.f;
-        for (int j = 0; j < num; ++j)
-            if (fr[j]) v += row[j];
+        for (int q = 0; q < n; ++q) v += row[lst[q]];
         cv[it] = v;
     }
     __syncthreads();
@@ -684,9 +701,15 @@ extern "C" int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, 
     if (dstLen <= 0 || batch <= 0) return AFX_OK;
     Taps32 tp;
     for (int i = 0; i < 32; ++i) tp.h[i] = taps32[i];
-    hipLaunchKernelGGL(k_cqt_decimate, dim3((unsigned)((dstLen + DEC_OUT - 1) / DEC_OUT), (unsigned)batch),
-                       dim3(256), 0, (hipStream_t)stream, x, srcLen, xStride, y, dstLen, yStride, tp,
-                       sqrtRatio);
+    const dim3 grid((unsigned)((dstLen + DEC_OUT - 1) / DEC_OUT), (unsigned)batch);
+    // even / odd sample pairs as float2 loads when every clip row starts 8-byte aligned
+    const bool pairs = (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (xStride % 2 == 0 || batch == 1);
+    if (pairs)
+        hipLaunchKernelGGL(k_cqt_decimate<true>, grid, dim3(256), 0, (hipStream_t)stream, x, srcLen, xStride, y,
+                           dstLen, yStride, tp, sqrtRatio);
+    else
+        hipLaunchKernelGGL(k_cqt_decimate<false>, grid, dim3(256), 0, (hipStream_t)stream, x, srcLen, xStride, y,
+                           dstLen, yStride, tp, sqrtRatio);
     AFX_LAUNCH_CHECK("k_cqt_decimate");
     return AFX_OK;
 }
@@ -715,8 +738,9 @@ extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows,
                                const unsigned char *fold, int chromaNum, int isMag, int normType,
                                float *out, void *stream) {
     if (rows <= 0) return AFX_OK;
+    if (num > 255) return AFX_ERR_UNSUPPORTED;  // bin lists are bytes
     const size_t lds = sizeof(float) * ((size_t)CH_FRAMES * num + (size_t)CH_FRAMES * chromaNum + CH_FRAMES) +
-                       (size_t)chromaNum * num;
+                       sizeof(int) * (size_t)chromaNum + (size_t)chromaNum * num;
     if (lds > 150 * 1024) return AFX_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma),

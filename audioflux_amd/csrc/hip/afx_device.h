@@ -77,7 +77,8 @@ typedef struct {
     int mode;              /* AFX_SPEC_*                                      */
     float normValue;
     int binLo;             /* first bin stored                                */
-    int binCount;          /* bins stored per frame (row pitch of the output) */
+    int binCount;          /* bins stored per frame                           */
+    long long outPitch;    /* floats between output rows; 0: binCount         */
     float *outRe;          /* device [batch*timeLength, binCount]             */
     float *outIm;          /* device, modes COMPLEX/SQUARE only               */
     float *energy;         /* optional device [batch*timeLength] (or NULL)    */

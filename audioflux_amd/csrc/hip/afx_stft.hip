@@ -126,7 +126,7 @@ __global__ void k_stft_generic(AfxStftArgs a) {
     // 3. un-pack the requested bins, map them, store (or keep for the filter bank)
     const bool band = a.bandStart != nullptr;
     const bool two = (a.mode == AFX_SPEC_COMPLEX || a.mode == AFX_SPEC_SQUARE);
-    const long long row = frame * (long long)a.binCount;
+    const long long row = frame * (a.outPitch ? a.outPitch : (long long)a.binCount);
     for (int j = tid; j < a.binCount; j += nth) {
         int k = a.binLo + j;  // 0 <= k <= M, or up to N-1 with fullSpectrum
         const bool mirror = k > M;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(SW * 64) void k_stft_wave(AfxStftArgs a, const floa
         const float *x = a.x + (long long)b * a.clipStride;
         const long long start = (long long)t * a.hop - a.padLeft;
         const bool inside = start >= 0 && start + N <= a.dataLength;
-        const long long row = f * (long long)a.binCount;
+        const long long row = f * (a.outPitch ? a.outPitch : (long long)a.binCount);
         // bin k of this frame (0 <= k <= N/2) and, for 0 < k < N/2, its mirror N - k = conj
         auto emit = [&](int k, v2 X) {
             float v0, v1;

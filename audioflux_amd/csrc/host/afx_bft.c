@@ -22,9 +22,13 @@
 
 /* largest [frames, F] spectrum scratch one launch may use; larger batches are
  * processed in clip chunks (the fused kernel needs no such scratch) */
-static size_t scratch_budget_bytes(void) {
+/* spectrum scratch of the dense-bank route per chunk.  Measured on cfg 2 (tools/bench_dense.py,
+ * profiles/r02_dense_gemm.txt): 96 MB chunks (spectrum resident in the Infinity Cache between the
+ * two kernels) give grids of < 1 workgroup per CU and 115 M frames/s; 1 GB chunks 171 M frames/s
+ * with the GEMM at 107 TFLOP/s -- launch width beats cache residency here */
+static size_t dense_chunk_bytes(void) {
     const char *s = getenv("AFX_SCRATCH_MB");
-    size_t mb = 2048;
+    size_t mb = 1024;
     if (s && atoi(s) > 0) mb = (size_t)atoi(s);
     return mb << 20;
 }
@@ -211,10 +215,19 @@ int afx_bft_create(const AfxBftPlan *p, BFTObj *bftObj) {
     if (st == AFX_OK)
         st = afxdev_h2d(o->dTwiddle, hTw, sizeof(float) * (fftLength / 2 > 0 ? fftLength : 2),
                         o->stream);
+    o->bankPitch = (o->F + 3) & ~3;
     if (st == AFX_OK && hBank) {
-        st = afxdev_malloc((void **)&o->dBank, sizeof(float) * (size_t)num * o->F);
+        float *padded = (float *)calloc((size_t)num * o->bankPitch, sizeof(float));
+        if (!padded) st = AFX_ERR_NOMEM;
+        if (st == AFX_OK) {
+            for (int r = 0; r < num; r++)
+                memcpy(padded + (size_t)r * o->bankPitch, hBank + (size_t)r * o->F, sizeof(float) * o->F);
+            st = afxdev_malloc((void **)&o->dBank, sizeof(float) * (size_t)num * o->bankPitch);
+        }
         if (st == AFX_OK)
-            st = afxdev_h2d(o->dBank, hBank, sizeof(float) * (size_t)num * o->F, o->stream);
+            st = afxdev_h2d(o->dBank, padded, sizeof(float) * (size_t)num * o->bankPitch, o->stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(o->stream); /* the staging copy is freed below */
+        free(padded);
     }
     if (st == AFX_OK && hBank) {
         /* row spans of the bank: [first non-zero, last non-zero] of every row.  Used when the
@@ -369,11 +382,11 @@ static int run_reassigned(BFTObj o, const float *dData, int batch, int dataLengt
     }
     st = afxk_spec_map(rRe, rIm, frames, F, 0, F, specMode, o->normValue, mRe, complexOut ? mIm : NULL, stream);
     if (st == AFX_OK)
-        st = afxk_gemm_nt(mRe, F, o->dBank, F, dRe, o->num, frames, o->num, F, AFX_MAP_NONE, post, o->normValue,
-                          stream);
+        st = afxk_gemm_nt(mRe, F, o->dBank, o->bankPitch, dRe, o->num, frames, o->num, F, AFX_MAP_NONE, post,
+                          o->normValue, stream);
     if (st == AFX_OK && complexOut)
-        st = afxk_gemm_nt(mIm, F, o->dBank, F, dIm, o->num, frames, o->num, F, AFX_MAP_NONE, AFX_MAP_NONE, 1.f,
-                          stream);
+        st = afxk_gemm_nt(mIm, F, o->dBank, o->bankPitch, dIm, o->num, frames, o->num, F, AFX_MAP_NONE, AFX_MAP_NONE,
+                          1.f, stream);
     return st;
 }
 
@@ -464,10 +477,13 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
         return afxk_stft(&a, stream);
     }
 
-    /* dense bank (gammatone): spectrum scratch in HBM + MFMA GEMM, chunked over clips */
+    /* dense bank (gammatone): spectrum scratch + MFMA GEMM, chunked over clips.  The scratch rows
+     * are pitched to 4 floats (16-byte aligned rows for the GEMM's dwordx4 loads); chunk size:
+     * AFX_SCRATCH_MB, default 1024 (dense_chunk_bytes) */
     const int planes = complexOut ? 2 : 1;
-    const size_t perClip = (size_t)T * o->F * sizeof(float) * planes;
-    long long chunk = (long long)(scratch_budget_bytes() / (perClip ? perClip : 1));
+    const int pitch = o->bankPitch;
+    const size_t perClip = (size_t)T * pitch * sizeof(float) * planes;
+    long long chunk = (long long)(dense_chunk_bytes() / (perClip ? perClip : 1));
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
     int st = afxdev_reserve((void **)&o->dSpec, &o->capSpec, perClip * (size_t)chunk);
@@ -480,8 +496,9 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
         a.batch = nb;
         a.binLo = 0;
         a.binCount = o->F;
+        a.outPitch = pitch;
         a.outRe = o->dSpec;
-        a.outIm = complexOut ? o->dSpec + frames * o->F : NULL;
+        a.outIm = complexOut ? o->dSpec + frames * pitch : NULL;
         if (dTemporal) {
             a.energy = dTemporal + b0 * T;
             a.rms = dTemporal + framesAll + b0 * T;
@@ -489,11 +506,11 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
         }
         st = afxk_stft(&a, stream);
         if (st != AFX_OK) return st;
-        st = afxk_gemm_nt(a.outRe, o->F, o->dBank, o->F, dRe + b0 * T * o->num, o->num, frames,
+        st = afxk_gemm_nt(a.outRe, pitch, o->dBank, pitch, dRe + b0 * T * o->num, o->num, frames,
                           o->num, o->F, AFX_MAP_NONE, post, o->normValue, stream);
         if (st != AFX_OK) return st;
         if (complexOut) {
-            st = afxk_gemm_nt(a.outIm, o->F, o->dBank, o->F, dIm + b0 * T * o->num, o->num, frames,
+            st = afxk_gemm_nt(a.outIm, pitch, o->dBank, pitch, dIm + b0 * T * o->num, o->num, frames,
                               o->num, o->F, AFX_MAP_NONE, AFX_MAP_NONE, 1.f, stream);
             if (st != AFX_OK) return st;
         }

@@ -34,6 +34,8 @@ struct OpaqueBFT {
     /* device constants */
     void *stream;
     float *dWindow, *dTwiddle, *dBank;
+    int bankPitch; /* floats per row of dBank: F rounded up to 4 (zero padded) so that the MFMA GEMM
+                    * loads 16-byte aligned rows */
     /* banded (row span) view of the bank for the in-kernel filter-bank epilogue of the
      * size-generic STFT kernel; NULL when the bank is too dense for it */
     int *dBandMeta;   /* [3][num]: start, len, offset */

@@ -569,7 +569,7 @@ void spectrogramObj_spectrogram1(SpectrogramObj o, float *mRealArr, float *mImag
         float *dBase = (o->scale == SpectralFilterBankScale_LogChroma) ? o->dTmp : o->dOut;
         st = afxk_spec_map(dRe, dIm, T, N, 0, F, mode, o->core->normValue, dS, NULL, stream);
         if (st == AFX_OK)
-            st = afxk_gemm_nt(dS, F, o->core->dBank, F, dBase, o->coreRows, T, o->coreRows, F, AFX_MAP_NONE,
+            st = afxk_gemm_nt(dS, F, o->core->dBank, o->core->bankPitch, dBase, o->coreRows, T, o->coreRows, F, AFX_MAP_NONE,
                               post, o->core->normValue, stream);
         if (st == AFX_OK && is_chroma_like(o->scale)) st = chroma_tail(o, dBase, T, o->dOut, stream);
     }

@@ -313,3 +313,36 @@ def test_temporal_features_ride_in_the_fused_kernel(hop):
         assert_parity(rms, wr, TOL, "rms")
         # a sign change decided by a product at float32 rounding may differ: at most one count per frame
         assert np.abs(z - wz).max() <= 1.0 / 2048 + 1e-9 and (z != wz).mean() <= 0.02, np.abs(z - wz).max()
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("rt,dt", [(1, 0), (1, 1), (0, 0)])
+def test_dense_bank_at_the_headline_shape(rt, dt):
+    """Dense (gammatone) bank at n_fft 2048 / 128 bands: STFT wave kernel -> pitched [T,F] scratch ->
+    128 x 128 MFMA GEMM (k_gemm_nt128), chunked; real power / magnitude and complex results against the
+    reference's double-accumulating __mdot1 (flux_vector.c:55-86) on several clips (more than one chunk
+    with AFX_SCRATCH_MB=1)."""
+    xs = np.stack([cases.noise(80 + i, 16000 * 2 + 50) for i in range(3)])
+    r = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1, slide_length=512,
+                   scale_type=4, style_type=2, normal_type=0, data_type=dt)
+    r.set_result_type(rt)
+    o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+               scale_type=af.SpectralFilterBankScaleType.ERB, style_type=af.SpectralFilterBankStyleType.GAMMATONE,
+               data_type=af.SpectralDataType(dt))
+    assert o.fused_plan_kind() == 0  # dense bank: no banded plan
+    old = os.environ.get("AFX_SCRATCH_MB")
+    try:
+        for mb in (None, "1"):
+            if mb:
+                os.environ["AFX_SCRATCH_MB"] = mb
+            got = o.bft_batch(xs, result_type=rt)
+            for i in range(3):
+                re, im = r.bft(xs[i])
+                want = re if rt == 1 else re + 1j * im
+                g = got[i] if rt == 1 else got[i]
+                assert_parity(g, want, TOL, f"gammatone rt{rt} dt{dt} clip{i} scratch{mb}")
+    finally:
+        if old is None:
+            os.environ.pop("AFX_SCRATCH_MB", None)
+        else:
+            os.environ["AFX_SCRATCH_MB"] = old
