@@ -30,8 +30,10 @@ typedef struct OpaqueBFT *BFTObj;
  *   slideLength   hop, default fftLength/4
  *   filterScaleType/StyleType/NormalType  defaults Linear / Slaney / None
  *   dataType      default SpectralData_Power
- *   isReassign    default 0 (1 is rejected by this backend: returns -2)
- *   isTemporal    default 0; 1 also computes per-frame energy/rms/zcr
+ *   isReassign    default 0; 1: the time-frequency reassigned spectrum replaces the STFT
+ *                 (reassign_algorithm.c:203-414; ordered, deterministic accumulation)
+ *   isTemporal    default 0; 1 also computes per-frame energy/rms/zcr (in the same kernel
+ *                 launch at n_fft 2048 with real results)
  * returns 0 ok, -100 bad radix2Exp, 1 bad scale type, -1 bad num/frequency
  *         range, <= -2 backend/HIP failure (never leaves *bftObj dangling). */
 int bftObj_new(BFTObj *bftObj, int num, int radix2Exp,

@@ -32,10 +32,14 @@ void cepstrogramObj_cepstrogram(CepstrogramObj cepstrogramObj, int cepNum,
                                 float *dataArr, int dataLength,
                                 float *mDataArr1, float *mDataArr2, float *mDataArr3);
 
-/* Spectrum-input variant.  The reference copies its cached spectrum INTO the
- * caller's arrays instead of the other way round (cepstrogram_algorithm.c:
- * 214-215), i.e. it re-uses the spectrum of the previous cepstrogram call and
- * overwrites mRealArr/mImageArr with it; that behaviour is reproduced. */
+/* Spectrum-input variant -- WARNING, upstream quirk kept bit for bit: the reference's memcpy
+ * runs the wrong way round (cepstrogram_algorithm.c:214-215).  The spectrum the CALLER passes
+ * in mRealArr / mImageArr is NEVER USED: both arrays are OVERWRITTEN with the spectrum cached by
+ * the previous cepstrogramObj_cepstrogram call (zeros if there was none) and the cepstra are
+ * computed from that cache.  A drop-in must behave identically, so this backend does; callers
+ * that want "cepstra of my spectrum" must not use this entry point -- run
+ * cepstrogramObj_cepstrogram on the signal instead.  (The reference's Python wrapper does not
+ * bind it.) */
 void cepstrogramObj_cepstrogram2(CepstrogramObj cepstrogramObj, int cepNum,
                                  float *mRealArr, float *mImageArr, int nLength,
                                  float *mDataArr1, float *mDataArr2, float *mDataArr3);
