@@ -38,28 +38,29 @@ __device__ __forceinline__ v2 pk_sub_conj(v2 a, v2 b) {
     return r;
 }
 // complex product a * b
+// (both instructions in ONE asm statement: the compiler pads every inline-asm VALU result with an
+// s_nop before its first use -- it cannot see that the hardware interlocks the dependence)
 __device__ __forceinline__ v2 cmul(v2 a, v2 b) {
     v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (ax bx, ax by)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-ay by + ., ay bx + .)
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                  // (ax bx, ax by)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"              // (-ay by + ., ay bx + .)
+        : "=&v"(t), "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 // complex multiply-accumulate c + a * b: two packed fmas
 __device__ __forceinline__ v2 cfma(v2 a, v2 b, v2 c) {
     v2 t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
-        : "=v"(t) : "v"(a), "v"(b), "v"(c));  // (ax bx + cx, ax by + cy)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-ay by + ., ay bx + .)
+    asm("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                          // (ax bx + cx, ax by + cy)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"              // (-ay by + ., ay bx + .)
+        : "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 // w * (-i d):  real = w.x d.y + w.y d.x,  imag = w.y d.y - w.x d.x
 __device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
     v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(d), "v"(w));  // (dy wx, dy wy)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"
-        : "=v"(r) : "v"(d), "v"(w), "v"(t));  // (dx wy + ., -dx wx + .)
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                  // (dy wx, dy wy)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"              // (dx wy + ., -dx wx + .)
+        : "=&v"(t), "=v"(r) : "v"(d), "v"(w));
     return r;
 }
 // (-i) a = (a.y, -a.x) as one multiply by the constant pair (1, -1)
