@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests.conftest import l2_rel, peak_rel
+from tests.conftest import l2_rel, parity_log, peak_rel
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -89,9 +89,7 @@ def both(tmp_path_factory):
 
 
 # bars other than plain 1e-5 peak + L2 (DESIGN section 2 table lists them with the measured values)
-TOL = {
-    ("cepstrogram", "det"): 3e-5,       # details: reference itself ~1e-5 from float64 there
-}
+TOL = {}  # every flow output meets plain 1e-5 (measured worst: cepstrogram details 5.7e-6)
 # outputs that are a scatter onto ROUNDED coordinates (WSST / synsq / reassign): a coefficient whose
 # float32 coordinate sits on a .5 boundary lands in the neighbouring cell in any implementation whose
 # transform is not bit-identical; the explained-difference proof is tests/test_{wsst,synsq,reassign}_gpu.py.
@@ -131,7 +129,9 @@ def test_flow_matches_stock(both, flow):
             off = np.abs(got - want) > 1e-5 * peak
             moved = np.abs(got - want).sum() / np.abs(want).sum()
             report.append(f"{k}: {off.mean():.2e} of cells differ, displaced mass {moved:.2e}")
-            assert off.mean() <= 0.02 and moved <= 0.05, (flow, k, off.mean(), moved)
+            parity_log(f"dropin {flow}/{k}", float(off.mean()), 1e-3, "fraction of cells beyond 1e-5 (scatter onto rounded coordinates)",
+                       {"displaced_mass": float(moved), "displaced_mass_bar": 1e-4})
+            assert off.mean() <= 1e-3 and moved <= 1e-4, (flow, k, off.mean(), moved)  # measured <= 2.5e-4 / 2.1e-5
             continue
         if (flow, k) == ("stft", "istft"):
             # edge samples divide by a window sum near the reference's clamp (tests/conftest.py); interior at 1e-5
@@ -139,5 +139,6 @@ def test_flow_matches_stock(both, flow):
         tol = TOL.get((flow, k), 1e-5)
         p, l = peak_rel(got, want), l2_rel(got, want)
         report.append(f"{k}: peak {p:.2e} l2 {l:.2e}")
+        parity_log(f"dropin {flow}/{k}", max(p, l), tol)
         assert p <= tol and l <= tol, f"{flow}/{k}: peak-rel {p:.3e}, l2-rel {l:.3e} > {tol}"
     print(flow, "; ".join(report))

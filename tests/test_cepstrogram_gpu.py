@@ -6,13 +6,13 @@ import pytest
 
 import audioflux_amd as af
 from tests import cases
-from tests.conftest import assert_parity
+from tests.conftest import assert_parity, parity_log
 
 pytestmark = pytest.mark.gpu
 # cepstrum / envelope: 1e-5.  details: the reference's own float32 result is 0.7-1.1e-5
 # (peak-relative) away from a float64 evaluation of the same formulas on these inputs
 # (tests/test_oracle.py), so two float32 implementations can differ by ~sqrt(2) of that.
-TOL = {"cep": 1e-5, "env": 1e-5, "det": 3e-5}
+TOL = {"cep": 1e-5, "env": 1e-5, "det": 2e-5}  # details: worst measured 1.8e-5 (the reference itself is ~1e-5 from float64 there)
 
 
 @pytest.mark.parametrize("name", list(cases.CEPS_CASES))
@@ -40,7 +40,7 @@ def test_envelope_plus_details_reconstruct_log_spectrum():
     k = np.arange(n // 2 + 1)
     # c is even, so c[N-q] = c[q] = cep[:, q]
     extra = cep[:, q:q + 1] * np.cos(2 * np.pi * k * (n - q) / n)[None, :]
-    assert_parity(env + det, logS + extra, 1e-4, "lifter partition")
+    assert_parity(env + det, logS + extra, 1e-5, "lifter partition")
 
 
 def test_wave_kernel_2048_matches_golden_through_device_call(golden_dir):
@@ -107,6 +107,9 @@ def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_n
             for tag, other in (("reference", want[k]), ("float64", f64[k])):
                 p_err = np.abs(got - other).max() / peak
                 l_err = np.linalg.norm(got - other) / l2
+                parity_log(f"cepstrogram wave {name} r{r} hop{hop} q{cep_num} clip{i} vs {tag}", max(p_err, l_err),
+                           max(TOL[name], 6.0 * max(ref_p, ref_l)), "max(TOL, 6 x reference-vs-float64)",
+                           {"reference_vs_float64": float(max(ref_p, ref_l))})
                 assert p_err <= max(TOL[name], 6.0 * ref_p) and l_err <= max(TOL[name], 6.0 * ref_l), (
                     f"clip {i} {name} hop {hop} q {cep_num} vs {tag}: peak-rel {p_err:.2e} (reference vs float64 "
                     f"{ref_p:.2e}), l2-rel {l_err:.2e} ({ref_l:.2e})")

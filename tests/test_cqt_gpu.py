@@ -37,7 +37,7 @@ def test_cqt_chroma_cqcc_match_golden(name, golden_dir):
             ch = o.chroma(q, cn, af.SpectralDataType(dt), af.ChromaDataNormalType(nt))
             # MIN normalisation divides by the smallest chroma value of the frame, which
             # amplifies the (1e-6 level) relative error of that one value
-            tol = 5e-5 if cname == "six_min" else TOL
+            tol = 4.5e-5 if cname == "six_min" else TOL  # divides by the frame MINIMUM; measured 2.2e-5
             assert_parity(ch.T, gold[f"{name}/chroma_{cname}"], tol, f"{name}/chroma_{cname}")
     cc = o.cqcc(np.abs(q), 13)
     assert_parity(cc.T, gold[f"{name}/cqcc"], TOL, f"{name}/cqcc")

@@ -40,7 +40,13 @@ def explained(got, want, Sh, vt, vf, thresh, what):
     assert not bad.any(), f"{what}: {int(bad.sum())} cells differ beyond what boundary coefficients explain " \
                           f"(worst {d[bad].max() / scale:.3e})"
     frac = np.abs(Sh[amb]).sum() / np.abs(Sh).sum()
-    assert frac < 0.02, f"{what}: {frac:.4f} of the coefficient mass is undetermined -- criterion too loose"
+    from tests.conftest import parity_log
+    parity_log(f"reassign explained-difference: {what}", float((d > 1e-5 * scale).mean()), 0.005,
+               "fraction of cells beyond 1e-5 (all explained by boundary coefficients)",
+               {"undetermined_mass": float(frac), "undetermined_mass_bar": 0.01,
+                "worst_unexplained_excess": float(np.maximum(d - allow, 0).max() / scale)})
+    assert frac < 0.01, \
+        f"{what}: {frac:.4f} of the coefficient mass is undetermined -- criterion too loose"
     return int((d > 1e-5 * scale).sum())
 
 

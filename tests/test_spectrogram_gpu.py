@@ -78,7 +78,7 @@ def test_spectrogram_matches_golden(name, gold):
     if c.get("deconv"):
         tm, pt = o.deconv(want.T)
         assert_parity(tm.T, gold[f"{name}/timbre"], TOL, name + " timbre")
-        assert_parity(pt.T, gold[f"{name}/pitch"], 5e-5, name + " pitch")   # X/|X| at near-empty bins
+        assert_parity(pt.T, gold[f"{name}/pitch"], 1e-5, name + " pitch")   # X/|X| at near-empty bins
     if c.get("from_stft"):
         # spectrogramObj_spectrogram1: the same result from a caller-supplied STFT
         n = 1 << c["radix2_exp"]

@@ -28,7 +28,13 @@ def explained(got, want, W, v, thresh, what):
                           f"(worst {d[bad].max() / scale:.3e})"
     strong = np.abs(W) > thresh
     frac = np.abs(W[amb]).sum() / max(np.abs(W[strong]).sum(), 1e-30)
-    assert frac < 0.05, f"{what}: {frac:.3f} of the coefficient mass is undetermined -- criterion too loose"
+    from tests.conftest import parity_log
+    parity_log(f"wsst explained-difference: {what}", float((d > 1e-5 * scale).mean()), 0.05,
+               "fraction of cells beyond 1e-5 (all explained by boundary coefficients)",
+               {"undetermined_mass": float(frac), "undetermined_mass_bar": 0.04,
+                "worst_unexplained_excess": float(np.maximum(d - allow, 0).max() / scale)})
+    assert frac < 0.04, \
+        f"{what}: {frac:.3f} of the coefficient mass is undetermined -- criterion too loose"
     return int((d > 1e-5 * scale).sum())
 
 
