@@ -46,7 +46,7 @@ def test_cqt_chroma_cqcc_match_golden(name, golden_dir):
     assert_parity(o.cqhc(mag, 20).T, gold[f"{name}/cqhc"], TOL, f"{name}/cqhc")
     tone, pitch = o.deconv(mag)
     assert_parity(tone.T, gold[f"{name}/timbre"], TOL, f"{name}/timbre")
-    assert_parity(pitch.T, gold[f"{name}/pitch"], 2e-5, f"{name}/pitch")
+    assert_parity(pitch.T, gold[f"{name}/pitch"], 1e-5, f"{name}/pitch")
 
 
 def test_cqt_tone_lands_on_its_bin():
