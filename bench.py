@@ -28,6 +28,7 @@ benchmarked outputs is checked against the oracle (1e-5 peak / L2).
 double-accumulating matmul: no FFTW/MKL in this image) on the host cores for a bounded sample.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -317,6 +318,40 @@ class Cfg5:
         return cpu_baseline(cpu_worker_cfg5, "frames/s", (1, 1, 1), "30 s @44.1 kHz clips (CQT-84 + chroma-12)")
 
 
+class DryRun:
+    """AFX_BENCH_DRYRUN=1: a CPU stand-in for the kernels (tests/test_dist_cpu.py runs this file under
+    torch.distributed.run with the gloo backend): the distributed control flow of a bench run -- clip
+    ownership, double-buffered slabs, the side-stream gather, fences, the max-over-ranks clock, the
+    JSON line -- executes unchanged; every clip's "features" carry its global index."""
+    config = 2
+    metric, unit = "dry run (no device)", "frames/s"
+    default_clips = 4
+    bytes_per_unit = 2612
+    kernel = "none (CPU stand-in)"
+    gather_choices = ("mfcc", "mel")
+
+    def __init__(self, torch, af, dev, rank, clips):
+        self.torch, self.clips, self.rank = torch, clips, rank
+        self.T, self.units = 7, clips * 7
+        self.mel = torch.zeros((clips, self.T, 128))
+        self.cc = [torch.zeros((clips, self.T, 13)) for _ in range(2)]
+        self.workload, self.outputs = f"dry run, {clips} clips per rank", "CPU tensors"
+
+    def step(self, i):
+        ids = self.torch.arange(self.rank * self.clips, (self.rank + 1) * self.clips, dtype=self.torch.float32)
+        self.cc[i & 1][:] = (ids * 1000 + i)[:, None, None]   # clip id and step, checkable after the gather
+        self.mel[:] = ids[:, None, None]
+
+    def slab(self, i, which):
+        return self.cc[i & 1] if which == "mfcc" else self.mel
+
+    def check(self, i):
+        return None
+
+    def cpu(self):
+        return None
+
+
 WORKLOADS = {2: Cfg2, 4: Cfg4, 5: Cfg5}
 
 
@@ -357,14 +392,32 @@ def main():
     import audioflux_amd as af
     from audioflux_amd import dist as afd
 
-    rank, local, world = afd.init_from_env()
+    dry = os.environ.get("AFX_BENCH_DRYRUN") == "1"  # CPU stand-in for the kernels, gloo backend (tests)
+    rank, local, world = afd.init_from_env(backend="gloo" if dry else None)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    af._lib.check(af.get_lib().afx_set_device(local), "afx_set_device")
+    if dry:
+        dev = torch.device("cpu")
 
-    W = WORKLOADS[a.config]
+        class Event:  # stand-in for torch.cuda.Event
+            def __init__(self, enable_timing=True):
+                self.t = 0.0
+
+            def record(self):
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return (other.t - self.t) * 1e3
+
+        def sync():
+            pass
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        af._lib.check(af.get_lib().afx_set_device(local), "afx_set_device")
+        Event, sync = torch.cuda.Event, torch.cuda.synchronize
+
+    W = DryRun if dry else WORKLOADS[a.config]
     clips = a.clips or W.default_clips
     w = W(torch, af, dev, rank, clips)
     which = [g for g in (a.gather.split(",") if a.gather else list(W.gather_choices[:1])) if g]
@@ -372,13 +425,13 @@ def main():
         assert g in W.gather_choices, f"--gather {g}: config {a.config} offers {W.gather_choices}"
     gathers = ([afd.FeatureGather(dst=0, counts=[clips] * world) for _ in which]
                if (world > 1 and not a.no_gather) else [])
-    comm = torch.cuda.Stream(device=dev) if gathers else None
+    comm = torch.cuda.Stream(device=dev) if (gathers and not dry) else None
 
     ev = []
 
     def step(i, timed):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        e0 = Event(enable_timing=True)
+        e1 = Event(enable_timing=True)
         e0.record()
         w.step(i)
         e1.record()
@@ -389,8 +442,9 @@ def main():
             # sources; the previous gather has had a whole step to finish)
             for g in gathers:
                 g.wait()
-            comm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm):
+            if comm is not None:
+                comm.wait_stream(torch.cuda.current_stream())
+            with (torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()):
                 for g, name in zip(gathers, which):
                     g.start(w.slab(i, name))
 
@@ -399,18 +453,22 @@ def main():
             g.wait()
         if comm is not None:
             torch.cuda.current_stream().wait_stream(comm)
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    if a.clock_warmup > 0:  # untimed, like the W steps below: brings the clocks to their loaded state
+    if a.clock_warmup > 0 and not dry:
+        # untimed, like the W steps below: brings the clocks to their loaded state.  Compute only --
+        # the ranks run different numbers of steps in a fixed wall time, and every collective must be
+        # entered the same number of times by all of them
         tw, i = time.perf_counter(), 0
         while time.perf_counter() - tw < a.clock_warmup:
-            step(i, False)
+            w.step(i)
             i += 1
             if i % 8 == 0:
-                torch.cuda.synchronize()
+                sync()
+        sync()
     for i in range(a.warmup):
         step(i, False)
     fence()
@@ -427,7 +485,7 @@ def main():
 
     # ---- outside the timed region ----------------------------------------------------------------
     sustained_ms = None
-    if world == 1 and not a.no_sustained:
+    if world == 1 and not a.no_sustained and not dry:
         n, s0, s1 = 0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t1 = time.perf_counter()
         s0.record()
@@ -441,6 +499,12 @@ def main():
         s1.record()
         torch.cuda.synchronize()
         sustained_ms = s0.elapsed_time(s1) / n
+    if dry and gathers and rank == 0:
+        # the gathered slab of the last step: rank r's clips follow rank r-1's, every clip carries its id
+        got = gathers[0].wait()
+        last = a.steps - 1
+        want = torch.arange(world * clips, dtype=torch.float32) * 1000 + last
+        assert got.shape == (world * clips, w.T, 13) and bool((got[:, 0, 0] == want).all()), "gathered slab order"
     err = None
     if rank == 0 and not a.no_check:
         err = w.check(max(a.steps - 1, 0) if sustained_ms is None else n - 1)

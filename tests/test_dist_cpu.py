@@ -66,3 +66,28 @@ def test_gather_world2_gloo(n_clips):
         p.join(30)
         assert p.exitcode == 0
     assert res == {"gather": True, "none": True}
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("gather", ["mfcc", "mfcc,mel"])
+def test_bench_control_flow_world2_gloo(gather):
+    """bench.py itself under `torch.distributed.run --nproc-per-node 2` with the kernels replaced by a CPU
+    stand-in (AFX_BENCH_DRYRUN=1, gloo): the launch line the driver uses, clip ownership, the
+    double-buffered side-stream gather(s), fences, the max-over-ranks clock and the JSON contract; rank 0
+    checks the order of the gathered slab."""
+    import json
+    import subprocess
+    env = dict(os.environ, AFX_BENCH_DRYRUN="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--gather", gather]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
+    assert d["config"]["units_per_step_per_gpu"] * 2 * 3 / (d["ms_per_step"] * 3e-3) == pytest.approx(d["value"], rel=1e-6)
+    assert "RCCL gather of " + "+".join(gather.split(",")) in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d  # N > 1: no CPU baseline leg
