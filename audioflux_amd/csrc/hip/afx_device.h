@@ -47,6 +47,7 @@ int afxdev_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int afxdev_stream_create(void **stream);
 void afxdev_stream_destroy(void *stream);
 int afxdev_stream_sync(void *stream);
+int afxdev_stream_wait_stream(void *waiter, void *signaler); /* device-side join: waiter waits for signaler's work so far */
 
 /* grow-only scratch helper: (re)allocates *dptr when *capacity < bytes */
 int afxdev_reserve(void **dptr, size_t *capacity, size_t bytes);

@@ -201,6 +201,20 @@ extern "C" int afxdev_stream_create(void **stream) {
     return AFX_OK;
 }
 
+// `waiter` waits (on the device) for everything enqueued on `signaler` so far
+extern "C" int afxdev_stream_wait_stream(void *waiter, void *signaler) {
+    hipEvent_t ev;
+    AFX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaler);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev);  // released by the runtime once the recorded work has completed
+    if (e != hipSuccess) {
+        afxdev_set_error("stream wait: %s", hipGetErrorString(e));
+        return AFX_ERR_HIP;
+    }
+    return AFX_OK;
+}
+
 extern "C" void afxdev_stream_destroy(void *stream) {
     if (stream) (void)hipStreamDestroy((hipStream_t)stream);
 }

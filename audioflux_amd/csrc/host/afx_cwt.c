@@ -32,6 +32,8 @@ struct OpaqueCWT {
     float *hBank;      /* host copy, natural layout [num][L] (kept for the det bank) */
     AfxCwtPlanDims dims;
     void *stream;
+    void *stream2;           /* side stream of the batched device call: narrow-band scales */
+    void *chain[3];          /* side streams of the extra two-pass chains */
     float *dTw, *dBankT, *dBankDetT;
     float *dX, *dA, *dXt, *dB, *dOut; /* scratch of the one-chunk calls */
     float *dFastTw;          /* twiddle tables of the register-FFT kernels (L = 2^17) */
@@ -732,7 +734,8 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * the wrapper's default L = 2^13 (otherwise launch-bound). */
     const int nTwoPass = o->dims.order ? o->dims.nWide : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
-    int group = nTwoPass > 0 ? (int)(96.0e6 / ((double)nTwoPass * L * 8.0)) : 32;
+    const int overlap = !(getenv("AFX_CWT_OVERLAP") && atoi(getenv("AFX_CWT_OVERLAP")) == 0);
+    int group = nTwoPass > 0 ? (int)((overlap ? 48.0e6 : 96.0e6) / ((double)nTwoPass * L * 8.0)) : 32;
     if (group < 1) group = 1;
     {
         const char *e = getenv("AFX_CWT_GROUP");
@@ -744,23 +747,61 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
     if (fwdBatch > chunks) fwdBatch = chunks;
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGA, &o->capGA, sizeof(float) * 2 * L * fwdBatch);
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dGXt, &o->capGXt, sizeof(float) * 2 * L * fwdBatch);
+    const size_t gbFloats = (size_t)2 * L * group * o->num;
+    /* independent two-pass chains in flight (each with its own intermediate): 2 measured best on cfg 4
+     * with one chunk per launch pair (26.8 k vs 25.5 k chunks/s on one chain of two chunks) */
+    int chains = (overlap && nTwoPass > 0) ? 2 : 1;
+    if (getenv("AFX_CWT_CHAINS") && atoi(getenv("AFX_CWT_CHAINS")) >= 1) chains = atoi(getenv("AFX_CWT_CHAINS"));
+    if (chains > 4) chains = 4;
+    if (nTwoPass == 0) chains = 1;
     if (st == AFX_OK && nTwoPass > 0)
-        st = afxdev_reserve((void **)&o->dGB, &o->capGB, sizeof(float) * 2 * L * group * o->num);
+        st = afxdev_reserve((void **)&o->dGB, &o->capGB, sizeof(float) * gbFloats * chains);
+    /* The narrow-band scales (no intermediate; bound by their instruction stream) run on a side stream
+     * beside the two-pass launches of the wide scales (bound by the intermediate's round trip, and
+     * short launches with < 2 waves per SIMD): both depend only on the forward transform of the
+     * batch.  Joined before the next forward batch overwrites the spectra.  AFX_CWT_OVERLAP=0: one stream. */
+    void *side = NULL, *pipe = NULL; /* narrow-band side stream */
+    if (nTwoPass > 0 && nTwoPass < o->num && overlap) {
+        side = o->stream != hipStream ? o->stream : o->stream2;
+        if (!side) {
+            st = afxdev_stream_create(&o->stream2);
+            side = o->stream2;
+        }
+    }
+    for (int i = 0; i + 1 < chains && st == AFX_OK; i++)
+        if (!o->chain[i]) st = afxdev_stream_create(&o->chain[i]);
+    (void)pipe;
     for (int c0 = 0; c0 < chunks && st == AFX_OK; c0 += fwdBatch) {
         const int nf = chunks - c0 < fwdBatch ? chunks - c0 : fwdBatch;
         st = afxk_cwt_forward(&o->dims, o->dTw, dData + (long long)c0 * chunkStride, chunkStride, nf,
                               o->dGA, o->dGXt, hipStream);
-        for (int c = 0; c < nf && st == AFX_OK; c += group) {
-            const int n = nf - c < group ? nf - c : group;
-            st = afxk_cwt_inverse(&o->dims, o->dTw, o->dGXt + 2 * L * (size_t)c, dBank, o->num, isDet, n,
-                                  o->dGB, dReal + (size_t)(c0 + c) * plane, dImag + (size_t)(c0 + c) * plane,
-                                  AFX_CWT_WIDE, hipStream);
+        for (int i = 0; i + 1 < chains && st == AFX_OK; i++) st = afxdev_stream_wait_stream(o->chain[i], hipStream);
+        if (st == AFX_OK && side) {
+            st = afxdev_stream_wait_stream(side, hipStream);
+            if (st == AFX_OK)
+                st = afxk_cwt_inverse(&o->dims, o->dTw, o->dGXt, dBank, o->num, isDet, nf, NULL,
+                                      dReal + (size_t)c0 * plane, dImag + (size_t)c0 * plane, AFX_CWT_NARROW, side);
         }
+        /* two-pass launches of consecutive chunk groups alternate between the caller's stream and a
+         * second side stream, each with its own intermediate: the row pass of one group overlaps the
+         * column pass of the other (each launch alone leaves most CUs under two waves per SIMD) */
+        int k = 0;
+        for (int c = 0; c < nf && st == AFX_OK; c += group, ++k) {
+            const int n = nf - c < group ? nf - c : group;
+            const int ch = k % chains;
+            void *s = ch ? o->chain[ch - 1] : hipStream;
+            float *gb = o->dGB + (size_t)ch * gbFloats;
+            st = afxk_cwt_inverse(&o->dims, o->dTw, o->dGXt + 2 * L * (size_t)c, dBank, o->num, isDet, n,
+                                  gb, dReal + (size_t)(c0 + c) * plane, dImag + (size_t)(c0 + c) * plane,
+                                  AFX_CWT_WIDE, s);
+        }
+        for (int i = 0; i + 1 < chains && st == AFX_OK; i++) st = afxdev_stream_wait_stream(hipStream, o->chain[i]);
         /* the narrow-band scales have no intermediate: all chunks of the forward batch at once */
-        if (st == AFX_OK)
+        if (st == AFX_OK && !side)
             st = afxk_cwt_inverse(&o->dims, o->dTw, o->dGXt, dBank, o->num, isDet, nf, NULL,
                                   dReal + (size_t)c0 * plane, dImag + (size_t)c0 * plane, AFX_CWT_NARROW,
                                   hipStream);
+        if (st == AFX_OK && side) st = afxdev_stream_wait_stream(hipStream, side);
     }
     o->lastStream = hipStream;
     o->lastUsed = 1;
@@ -852,6 +893,10 @@ void cwtObj_cwtDet(CWTObj o, float *dataArr, float *mRealArr3, float *mImageArr3
 void cwtObj_free(CWTObj o) {
     if (!o) return;
     if (o->stream) afxdev_stream_sync(o->stream);
+    if (o->stream2) afxdev_stream_sync(o->stream2);
+    for (int i = 0; i < 3; i++)
+        if (o->chain[i]) afxdev_stream_sync(o->chain[i]);
+    if (o->lastUsed && o->lastStream) afxdev_stream_sync(o->lastStream); /* the caller's stream may still run our kernels */
     afxdev_free(o->dTw);
     afxdev_free(o->dBankT);
     afxdev_free(o->dBankDetT);
@@ -868,6 +913,8 @@ void cwtObj_free(CWTObj o) {
     afxdev_free(o->dGXt);
     afxdev_free(o->dGB);
     afxdev_free(o->dOut);
+    afxdev_stream_destroy(o->stream2);
+    for (int i = 0; i < 3; i++) afxdev_stream_destroy(o->chain[i]);
     afxdev_stream_destroy(o->stream);
     free(o->freBandArr);
     free(o->binBandArr);
