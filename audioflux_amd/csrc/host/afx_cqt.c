@@ -32,6 +32,7 @@ struct OpaqueCQT {
     int timeLength;          /* frames of the last cqt call */
     /* device */
     void *stream;
+    void *stream2;           /* side stream of the device call when the caller's stream IS `stream` */
     float *dTwiddle, *dKTaps, *dScaleOn, *dScaleOff;
     int *dKStart, *dKLen, *dKOff;
     float *dTimeKernel;      /* [groups][N][colTiles*32]: time-domain image of the spectral kernels */
@@ -364,11 +365,29 @@ static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, 
     const int T = dataLength / o->slideLength + 1;
     const long long pitch = ((long long)dataLength / 2 + 3) & ~3LL;
     int st = AFX_OK;
+    /* The decimation chain (signal of octave k from octave k+1: memory / latency bound) does not depend on
+     * the octave products (matrix-core bound): it runs ahead on a side stream, every level in its own
+     * slice of dSig[0] (pitch, pitch/2, ... samples per clip: < 2 pitch in all), and the octave kernel of a
+     * level waits only for the decimation that produced its input.  AFX_CQT_OVERLAP=0: one stream, in order. */
+    const int overlap = o->octaveNum > 1 && !(getenv("AFX_CQT_OVERLAP") && atoi(getenv("AFX_CQT_OVERLAP")) == 0);
+    void *side = NULL;
+    if (overlap) {
+        side = o->stream != stream ? o->stream : o->stream2;
+        if (!side) {
+            st = afxdev_stream_create(&o->stream2);
+            side = o->stream2;
+        }
+        if (st != AFX_OK) return st;
+    }
     if (o->octaveNum > 1) {
-        /* buffer 0 holds the first decimation (pitch samples per clip), buffer 1 the second */
-        st = afxdev_reserve((void **)&o->dSig[0], &o->capSig[0], sizeof(float) * (size_t)pitch * batch);
-        if (st == AFX_OK && o->octaveNum > 2)
-            st = afxdev_reserve((void **)&o->dSig[1], &o->capSig[1], sizeof(float) * (size_t)pitch * batch);
+        /* level offsets inside dSig[0]: level 1 at 0, level k at sum of the pitches before it */
+        size_t total = 0;
+        long long p = pitch;
+        for (int k = 1; k < o->octaveNum; k++) {
+            total += (size_t)p * batch;
+            p = ((p / 2) + 3) & ~3LL;
+        }
+        st = afxdev_reserve((void **)&o->dSig[0], &o->capSig[0], sizeof(float) * total);
     }
     if (st != AFX_OK) return st;
 
@@ -391,10 +410,22 @@ static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, 
 
     const float *cur = dX;
     long long curStride = xStride;
-    int nextBuf = 0, len = dataLength, hop = o->slideLength;
+    int len = dataLength, hop = o->slideLength;
+    long long levelPitch = pitch;
+    size_t levelOff = 0;
+    /* the side stream starts behind everything the caller's stream has enqueued: the input is ready and
+     * the previous call's octave kernels no longer read the signal slices */
+    if (side) st = afxdev_stream_wait_stream(side, stream);
     for (int oct = o->octaveNum - 1; oct >= 0 && st == AFX_OK; oct--) {
         const int k = o->octaveNum - 1 - oct; /* decimations so far */
         const int frames = len / hop + 1;
+        /* the next level's signal first (side stream when overlapping), then this level's product */
+        const int next = (int)floorf(len * 0.5f); /* resampleObj_calDataLength */
+        float *dNext = o->dSig[0] ? o->dSig[0] + levelOff : NULL;
+        if (oct > 0)
+            st = afxk_cqt_decimate(cur, len, curStride, dNext, next, levelPitch, batch, o->taps, sqrtf(0.5f),
+                                   side ? side : stream);
+        if (st != AFX_OK) break;
         a.x = cur;
         a.xStride = curStride;
         a.hop = hop;
@@ -407,12 +438,13 @@ static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, 
                                    : NULL;
         st = afxk_cqt_octave(&a, stream);
         if (st != AFX_OK || oct == 0) break;
-        const int next = (int)floorf(len * 0.5f); /* resampleObj_calDataLength */
-        st = afxk_cqt_decimate(cur, len, curStride, o->dSig[nextBuf], next, pitch, batch, o->taps,
-                               sqrtf(0.5f), stream);
-        cur = o->dSig[nextBuf];
-        curStride = pitch;
-        nextBuf ^= 1;
+        /* the next octave kernel reads dNext: wait for the decimation enqueued above (and only for it:
+         * later ones are not enqueued yet) */
+        if (side) st = afxdev_stream_wait_stream(stream, side);
+        cur = dNext;
+        curStride = levelPitch;
+        levelOff += (size_t)levelPitch * batch;
+        levelPitch = ((levelPitch / 2) + 3) & ~3LL;
         len = next;
         hop /= 2;
     }
@@ -713,6 +745,7 @@ void cqtObj_deconv(CQTObj o, float *mDataArr1, float *mDataArr2, float *mDataArr
 
 void cqtObj_free(CQTObj o) {
     if (!o) return;
+    if (o->stream2) afxdev_stream_sync(o->stream2); /* side stream of the device call */
     if (o->stream) afxdev_stream_sync(o->stream);
     afxdev_free(o->dTwiddle);
     afxdev_free(o->dKTaps);
@@ -730,6 +763,7 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dIn);
     afxdev_free(o->dDct);
     afxdev_free(o->dDevTw);
+    afxdev_stream_destroy(o->stream2);
     afxdev_stream_destroy(o->stream);
     free(o->freBandArr);
     free(o->sLenArr);
