@@ -109,3 +109,38 @@ void afx_fft_ref32(int r, const float *re1, const float *im1, float *re2, float 
     free(wc);
     free(ws);
 }
+
+/* ---- on-wire format of gathered features ------------------------------------
+ * NumPy .npy, format version 1.0: magic, header dict {'descr': '<f4', 'fortran_order': False,
+ * 'shape': (...)}, padded with spaces to a multiple of 64 bytes, then the C-ordered float32 data.
+ * Any consumer reads it with numpy.load / memory-maps it; no reference counterpart (the reference
+ * leaves persistence to its Python callers). */
+#include <stdio.h>
+#include <string.h>
+
+int afx_write_npy_f32(const char *path, const float *data, int ndim, const long long *shape) {
+    if (!path || !data || ndim < 1 || ndim > 8 || !shape) return -6;
+    char dict[256];
+    int n = snprintf(dict, sizeof(dict), "{'descr': '<f4', 'fortran_order': False, 'shape': (");
+    size_t count = 1;
+    for (int i = 0; i < ndim; i++) {
+        if (shape[i] < 0) return -6;
+        count *= (size_t)shape[i];
+        n += snprintf(dict + n, sizeof(dict) - (size_t)n, i + 1 < ndim ? "%lld, " : (ndim == 1 ? "%lld," : "%lld"), shape[i]);
+    }
+    n += snprintf(dict + n, sizeof(dict) - (size_t)n, "), }");
+    /* 10 bytes of preamble + header, newline-terminated, total a multiple of 64 */
+    int headerLen = n + 1;
+    const int pad = (64 - (10 + headerLen) % 64) % 64;
+    headerLen += pad;
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    const unsigned char pre[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char)(headerLen & 255),
+                                   (unsigned char)(headerLen >> 8)};
+    int ok = fwrite(pre, 1, 10, f) == 10 && fwrite(dict, 1, (size_t)n, f) == (size_t)n;
+    for (int i = 0; ok && i < pad; i++) ok = fputc(' ', f) != EOF;
+    ok = ok && fputc('\n', f) != EOF;
+    ok = ok && fwrite(data, sizeof(float), count, f) == count;
+    if (fclose(f) != 0) ok = 0;
+    return ok ? 0 : -1;
+}

@@ -102,6 +102,18 @@ class FeatureGather:
         return torch.cat([self.out[r * cmax: r * cmax + c] for r, c in enumerate(self.counts)], dim=0)
 
 
+def save_npy(path, tensor):
+    """Write a (gathered) float32 feature tensor as .npy through the library's own writer
+    (include/afx_batch.h: afx_write_npy_f32 -- the on-wire format a C / C++ host uses too)."""
+    import ctypes
+    from . import _lib
+    t = tensor.detach().to("cpu", torch.float32).contiguous()
+    lib = _lib.get_lib()
+    lib.afx_write_npy_f32.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
+    dims = (ctypes.c_longlong * t.dim())(*t.shape)
+    _lib.check(lib.afx_write_npy_f32(str(path).encode(), t.data_ptr(), t.dim(), dims), "afx_write_npy_f32")
+
+
 class NativeGather:
     """The same exchange through the library's own C-ABI export (include/afx_batch.h: afx_comm_*,
     afx_gather = ncclGather over RCCL / xGMI, bound at run time) -- what a C / C++ host of the

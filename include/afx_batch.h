@@ -156,6 +156,11 @@ int stftObj_istftBatchDevice(STFTObj stftObj, const float *dReal, const float *d
                              int nLength, int type, float *dData, long long dataStride,
                              void *hipStream);
 
+/* On-wire format of (gathered) feature tensors: NumPy .npy v1.0, little-endian float32, C order
+ * (readable with numpy.load / mmap by any consumer).  Host pointer; returns 0, -1 on an I/O error,
+ * -6 on bad arguments. */
+int afx_write_npy_f32(const char *path, const float *data, int ndim, const long long *shape);
+
 /* ---- the exchange step (multi-GPU): feature slabs -> root over RCCL / xGMI -------------------
  * One process per GPU, clips sharded contiguously (rank r owns clips [r*ceil(B/G), ...)): the
  * transforms need no collective, the gathered tensor is the ranks' slabs back to back.  RCCL is

@@ -137,3 +137,20 @@ def test_every_void_compute_call_of_the_wrappers_is_checked():
                     continue
                 bad.append(f"{os.path.basename(path)}:{i + 1}")
     assert bad == [], bad
+
+
+def test_npy_writer_round_trip(tmp_path):
+    """afx_write_npy_f32: the on-wire format of gathered features is a plain .npy numpy.load reads back"""
+    import numpy as np
+    lib = af.get_lib()
+    lib.afx_write_npy_f32.restype = ctypes.c_int
+    lib.afx_write_npy_f32.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
+    for shape in ((5,), (3, 7), (4, 934, 13), (2, 1, 3, 2)):
+        a = np.random.default_rng(len(shape)).standard_normal(shape).astype(np.float32)
+        p = str(tmp_path / f"f{len(shape)}.npy").encode()
+        dims = (ctypes.c_longlong * len(shape))(*shape)
+        assert lib.afx_write_npy_f32(p, a.ctypes.data, len(shape), dims) == 0
+        b = np.load(p.decode())
+        assert b.dtype == np.float32 and b.shape == shape and np.array_equal(a, b)
+        assert os.path.getsize(p.decode()) % 4 == 0 and (os.path.getsize(p.decode()) - a.nbytes) % 64 == 0
+    assert lib.afx_write_npy_f32(None, None, 1, None) == -6
