@@ -642,6 +642,10 @@ static int launch_cqt_mfma_w(const AfxCqtOctaveArgs *a, int SH, int sigWords, in
 static int try_cqt_mfma_w(const AfxCqtOctaveArgs *a, void *stream) {
     const int N = 1 << a->radix2Exp;
     if (a->colTiles != 1 || (N != 256 && N != 512) || getenv("AFX_CQT_KSPLIT")) return AFX_ERR_UNSUPPORTED;
+    // top octave of the default ladder (hop = N/4 = 128): its 18 KB signal windows leave this kernel 4 waves
+    // per CU; the K-split kernel (4 waves share one window, 16 waves per CU) measures 2 % faster on the whole
+    // cfg-5 step (3.82 -> 3.74 ms).  AFX_CQT_W_TOP=1 restores the wave-private kernel.
+    if (N == 512 && a->hop * 4 == N && !getenv("AFX_CQT_W_TOP")) return AFX_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a->x) % 16) || (a->xStride % 4)) return AFX_ERR_UNSUPPORTED;
     int SH = 0;
     while (SH < 30 && !((a->hop >> SH) & 1)) ++SH;
