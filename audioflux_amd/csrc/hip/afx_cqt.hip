@@ -441,13 +441,15 @@ struct Taps32 {
     float h[32];
 };
 
-// 1024 outputs per workgroup, 4 consecutive outputs per thread.  The input window is staged
-// in LDS split into even and odd samples (XE[k] = x[2 (i0-16+k)], XO[k] = x[2 (i0-16+k) + 1],
-// zero outside the signal: a dropped tap and a zero tap add the same), so that x[2i -/+ j] for
-// consecutive outputs are consecutive words and each thread gets its 36 + 36 operands with 18
-// ds_read_b128.  Taps are applied in the reference's order (left taps j = 0..31 at x[2i - j],
-// then right taps j = 1..31 at x[2i + j]) as one fma chain.
-constexpr int DEC_OUT = 1024, DEC_LDS = DEC_OUT + 40;
+// 1024 outputs per workgroup, 4 consecutive outputs per thread.  The input window is staged in LDS split
+// into even and odd samples, XE[k] = x[2 (i0-15+k)] and XO[k] = x[2 (i0-16+k) + 1] (zero outside the signal:
+// a dropped tap and a zero tap add the same), so that x[2i -/+ j] for consecutive outputs are consecutive
+// words and the first word a thread needs of either array sits at a 16-byte boundary: its 34 + 35 operands
+// are 9 + 9 ds_read_b128 (a window whose first word is unused gets narrowed by the compiler into unaligned
+// ds_read2 pieces at half the LDS rate).  Taps are applied in the reference's order (left taps j = 0..31 at
+// x[2i - j], then right taps j = 1..31 at x[2i + j]) as one fma chain; the four results leave as one
+// 16-byte store.
+constexpr int DEC_OUT = 1024, DEC_LDS = DEC_OUT + 36;
 
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ x, int srcLen,
@@ -460,43 +462,84 @@ __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ 
     const int i0 = blockIdx.x * DEC_OUT;
     x += (long long)blockIdx.y * xStride;
     y += (long long)blockIdx.y * yStride;
-    for (int k = tid; k < DEC_LDS; k += 256) {
-        const long long s = 2LL * (i0 - 16 + k);
-        if (PAIRS && s >= 0 && s + 1 < srcLen) {
-            // 8-byte aligned rows: the even / odd sample pair is one coalesced load
-            const float2 v = *reinterpret_cast<const float2 *>(x + s);
-            XE[k] = v.x;
-            XO[k] = v.y;
-        } else {
-            XE[k] = (s >= 0 && s < srcLen) ? x[s] : 0.f;
-            XO[k] = (s + 1 >= 0 && s + 1 < srcLen) ? x[s + 1] : 0.f;
+    auto at = [&](long long s) { return (s >= 0 && s < srcLen) ? x[s] : 0.f; };
+    if (PAIRS) {
+        // s_k = 2 (i0 - 15 + k): XE[k] = x[s_k], XO[k] = x[s_k - 1].  For odd k, s_k is a multiple of 4 (i0 is)
+        // and one 16-byte load gives XE[k], XO[k+1], XE[k+1], XO[k+2]
+        for (int q = tid; q <= (DEC_LDS - 2) / 2; q += 256) {
+            if (q == 0) {
+                const long long s0 = 2LL * (i0 - 15);
+                XE[0] = at(s0);
+                XO[0] = at(s0 - 1);
+                XO[1] = at(s0 + 1);
+            } else {
+                const int k = 2 * q - 1;
+                const long long s = 2LL * (i0 - 15 + k);
+                float4 v;
+                if (s >= 0 && s + 3 < srcLen) {
+                    v = *reinterpret_cast<const float4 *>(x + s);
+                } else {
+                    v = make_float4(at(s), at(s + 1), at(s + 2), at(s + 3));
+                }
+                XE[k] = v.x;
+                XE[k + 1] = v.z;
+                if (k + 1 < DEC_LDS) XO[k + 1] = v.y;
+                if (k + 2 < DEC_LDS) XO[k + 2] = v.w;
+            }
+        }
+    } else {
+        for (int k = tid; k < DEC_LDS; k += 256) {
+            const long long s = 2LL * (i0 - 15 + k);
+            XE[k] = at(s);
+            XO[k] = at(s - 1);
         }
     }
     __syncthreads();
-    // outputs i = i0 + 4 tid + q; LDS index of x[2 (i + d)] is 4 tid + q + d + 16
+    // outputs i = i0 + 4 tid + q; x[2 (i + d)] is XE[4 tid + q + d + 15], x[2 (i + d) + 1] is XO[4 tid + q + d + 16]
+    // (hand-issued: hipcc splits these float4 reads into ds_read2_b32 / ds_read2_b64 pieces -- half the LDS rate
+    // and 2-way bank conflicts, SQ_LDS_BANK_CONFLICT was 65 % of the kernel's LDS cycles)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 ev[9], ov[9];
+    const unsigned ae = (unsigned)(size_t)XE + 16u * tid, ao = (unsigned)(size_t)XO + 16u * tid;
+#define DEC_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+    DEC_RD(ev[0], ae, 0);   DEC_RD(ov[0], ao, 0);   DEC_RD(ev[1], ae, 16);  DEC_RD(ov[1], ao, 16);
+    DEC_RD(ev[2], ae, 32);  DEC_RD(ov[2], ao, 32);  DEC_RD(ev[3], ae, 48);  DEC_RD(ov[3], ao, 48);
+    DEC_RD(ev[4], ae, 64);  DEC_RD(ov[4], ao, 64);  DEC_RD(ev[5], ae, 80);  DEC_RD(ov[5], ao, 80);
+    DEC_RD(ev[6], ae, 96);  DEC_RD(ov[6], ao, 96);  DEC_RD(ev[7], ae, 112); DEC_RD(ov[7], ao, 112);
+    DEC_RD(ev[8], ae, 128); DEC_RD(ov[8], ao, 128);
+#undef DEC_RD
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float E[36], O[36];
 #pragma unroll
     for (int b = 0; b < 9; ++b) {
-        const float4 e = *reinterpret_cast<const float4 *>(&XE[4 * tid + 4 * b]);
-        const float4 o = *reinterpret_cast<const float4 *>(&XO[4 * tid + 4 * b]);
-        E[4 * b] = e.x; E[4 * b + 1] = e.y; E[4 * b + 2] = e.z; E[4 * b + 3] = e.w;
-        O[4 * b] = o.x; O[4 * b + 1] = o.y; O[4 * b + 2] = o.z; O[4 * b + 3] = o.w;
+        // the asm results are only defined after the wait above: pin the uses behind it
+        asm volatile("" : "+v"(ev[b]), "+v"(ov[b]));
+        E[4 * b] = ev[b].x; E[4 * b + 1] = ev[b].y; E[4 * b + 2] = ev[b].z; E[4 * b + 3] = ev[b].w;
+        O[4 * b] = ov[b].x; O[4 * b + 1] = ov[b].y; O[4 * b + 2] = ov[b].z; O[4 * b + 3] = ov[b].w;
     }
+    float r[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int i = i0 + 4 * tid + q;
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {  // x[2i - j]: even j -> XE[i - j/2], odd j -> XO[i - (j+1)/2]
-            const float v = (j & 1) ? O[q + 16 - (j + 1) / 2] : E[q + 16 - j / 2];
+        for (int j = 0; j < 32; ++j) {  // x[2i - j]: even j -> x[2 (i - j/2)], odd j -> x[2 (i - (j+1)/2) + 1]
+            const float v = (j & 1) ? O[q + 16 - (j + 1) / 2] : E[q + 15 - j / 2];
             acc = __fmaf_rn(tp.h[j], v, acc);
         }
 #pragma unroll
-        for (int j = 1; j < 32; ++j) {  // x[2i + j]: even j -> XE[i + j/2], odd j -> XO[i + (j-1)/2]
-            const float v = (j & 1) ? O[q + 16 + (j - 1) / 2] : E[q + 16 + j / 2];
+        for (int j = 1; j < 32; ++j) {  // x[2i + j]: even j -> x[2 (i + j/2)], odd j -> x[2 (i + (j-1)/2) + 1]
+            const float v = (j & 1) ? O[q + 16 + (j - 1) / 2] : E[q + 15 + j / 2];
             acc = __fmaf_rn(tp.h[j], v, acc);
         }
-        if (i < dstLen) y[i] = acc / sqrtRatio;
+        r[q] = acc / sqrtRatio;
+    }
+    const int i = i0 + 4 * tid;
+    if (PAIRS && i + 3 < dstLen) {  // (PAIRS: the launcher checked that y rows are 16-byte aligned)
+        *reinterpret_cast<float4 *>(y + i) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i + q < dstLen) y[i + q] = r[q];
     }
 }
 
@@ -678,7 +721,9 @@ extern "C" int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream) {
     if (a->timeLength <= 0) return AFX_OK;
     const int N = 1 << a->radix2Exp;
     if (a->timeKernel && a->colTiles >= 1 && a->colTiles <= 3) {
-        int st = try_cqt_mfma_w(a, stream);
+        int st = afxk_cqt_octave_f16(a, stream);
+        if (st != AFX_ERR_UNSUPPORTED) return st;
+        st = try_cqt_mfma_w(a, stream);
         if (st != AFX_ERR_UNSUPPORTED) return st;
         if (a->colTiles == 1) st = dispatch_cqt_mfma<1>(a, stream);
         else if (a->colTiles == 2) st = dispatch_cqt_mfma<2>(a, stream);
@@ -706,8 +751,9 @@ extern "C" int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, 
     Taps32 tp;
     for (int i = 0; i < 32; ++i) tp.h[i] = taps32[i];
     const dim3 grid((unsigned)((dstLen + DEC_OUT - 1) / DEC_OUT), (unsigned)batch);
-    // even / odd sample pairs as float2 loads when every clip row starts 8-byte aligned
-    const bool pairs = (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (xStride % 2 == 0 || batch == 1);
+    // 16-byte loads and stores when every clip row of x and y starts 16-byte aligned
+    const bool pairs = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (xStride % 4 == 0 || batch == 1) &&
+                       (reinterpret_cast<uintptr_t>(y) % 16 == 0) && (yStride % 4 == 0 || batch == 1);
     if (pairs)
         hipLaunchKernelGGL(k_cqt_decimate<true>, grid, dim3(256), 0, (hipStream_t)stream, x, srcLen, xStride, y,
                            dstLen, yStride, tp, sqrtRatio);

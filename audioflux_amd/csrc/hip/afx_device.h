@@ -268,8 +268,13 @@ typedef struct {
     const float *timeKernel; /* device [N][colTiles*32] time-domain kernels of this octave,
                               * columns [Re 0..rows-1 | Im 0..rows-1]; NULL: FFT path      */
     int colTiles;
+    const unsigned short *timeKernelH; /* device [2][N/16][64][8] f16 (hi, lo) words of the scaled image in
+                              * MFMA fragment order (afx_cqt_f16.hip); NULL: float32 kernels     */
+    const float *colMul;     /* device [32]: 2^-s_j of the image columns                          */
 } AfxCqtOctaveArgs;
 int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
+/* f16 matrix-core variant; AFX_ERR_UNSUPPORTED when the plan / alignment is outside its scope */
+int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream);
 /* batch clips: x + b*xStride -> y + b*yStride */
 int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, int dstLen,
                       long long yStride, int batch, const float *taps32, float sqrtRatio,

@@ -37,6 +37,9 @@ struct OpaqueCQT {
     int *dKStart, *dKLen, *dKOff;
     float *dTimeKernel;      /* [groups][N][colTiles*32]: time-domain image of the spectral kernels */
     int colTiles;            /* 0: the matrix-core path is not available for this plan */
+    unsigned short *dTimeKernelH; /* [groups][2 words][N/16 steps][64 lanes][8]: the image as f16 (hi, lo) words of
+                              * its power-of-two scaled columns, in MFMA fragment order (afx_cqt_f16.hip) */
+    float *dColMul;          /* [groups][32]: 2^-s_j undoing the column scaling */
     unsigned char *dFold;
     int foldChromaNum;
     float *dX;               /* staged input of the host-pointer calls */
@@ -58,6 +61,60 @@ struct OpaqueCQT {
 static void fail(CQTObj o, int st, const char *who) {
     o->status = st;
     fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+}
+
+/* float32 -> IEEE binary16, round to nearest even (gcc 11 on x86-64 has no _Float16) */
+static unsigned short cqt_f32_to_f16(float f) {
+    union { float f; unsigned u; } v;
+    v.f = f;
+    const unsigned sign = (v.u >> 16) & 0x8000u, ax = v.u & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return (unsigned short)(sign | (ax > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (ax >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u); /* >= 65520 rounds to infinity */
+    if (ax < 0x38800000u) {                                         /* below 2^-14: subnormal, step 2^-24 */
+        const float t = fabsf(f) * 16777216.0f;
+        return (unsigned short)(sign | (unsigned)lrintf(t));        /* default rounding mode: nearest even */
+    }
+    unsigned h = (((ax >> 23) - 112u) << 10) | ((ax & 0x7fffffu) >> 13);
+    const unsigned rem = ax & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (unsigned short)(sign | h);
+}
+
+static float cqt_f16_to_f32(unsigned short h) {
+    const int e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(1024 + m), e - 25);
+    return (h & 0x8000) ? -v : v;
+}
+
+/* One group's image G [N][32] -> (hi, lo) f16 words of the columns scaled to a peak in [2^13, 2^14), in the
+ * fragment order of v_mfma_f32_32x32x16_f16's B operand: word w, step ks, lane l (column j = l & 31, half
+ * g = l >> 5), element e holds row k = 16 ks + 8 g + e.  colMul[j] = 2^-s_j. */
+void afx_cqt_time_kernel_f16(const float *G, int N, unsigned short *out, float *colMul) {
+    const int KS = N / 16;
+    for (int j = 0; j < 32; j++) {
+        float peak = 0.f;
+        for (int k = 0; k < N; k++) peak = fmaxf(peak, fabsf(G[(size_t)k * 32 + j]));
+        int s = 0;
+        if (peak > 0.f && isfinite(peak)) {
+            int ex;
+            (void)frexpf(peak, &ex); /* peak = m 2^ex, m in [0.5, 1) */
+            s = 14 - ex;             /* peak 2^s in [2^13, 2^14) */
+            if (s > 100) s = 100;
+            if (s < -100) s = -100;
+        }
+        colMul[j] = ldexpf(1.f, -s);
+        for (int k = 0; k < N; k++) {
+            const float v = ldexpf(G[(size_t)k * 32 + j], s); /* exact */
+            const unsigned short hi = cqt_f32_to_f16(v);
+            const unsigned short lo = cqt_f32_to_f16(v - cqt_f16_to_f32(hi));
+            const int ks = k / 16, g = (k % 16) / 8, e = k % 8, l = 32 * g + j;
+            out[(((size_t)0 * KS + ks) * 64 + l) * 8 + e] = hi;
+            out[(((size_t)1 * KS + ks) * 64 + l) * 8 + e] = lo;
+        }
+    }
 }
 
 int cqtObj_new(CQTObj *cqtObj, int num, int samplate, float minFre, int *isContinue) {
@@ -325,6 +382,23 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     if (o->colTiles) {
         UP(o->dTimeKernel, timeKernel, timeKernelBytes);
     }
+    if (o->colTiles == 1 && N == 512 && !getenv("AFX_CQT_F32")) {
+        /* f16 (hi, lo) words of the image for the f16 matrix-core kernel (afx_cqt_f16.hip) */
+        const int groups = rowsTotal / bpo;
+        const size_t perGroup = (size_t)2 * (N / 16) * 64 * 8;
+        unsigned short *kh = (unsigned short *)calloc((size_t)groups * perGroup, sizeof(unsigned short));
+        float *cm = (float *)calloc((size_t)groups * 32, sizeof(float));
+        if (kh && cm) {
+            for (int g = 0; g < groups; g++)
+                afx_cqt_time_kernel_f16(timeKernel + (size_t)g * N * 32, N, kh + (size_t)g * perGroup, cm + (size_t)g * 32);
+            UP(o->dTimeKernelH, kh, sizeof(unsigned short) * (size_t)groups * perGroup);
+            UP(o->dColMul, cm, sizeof(float) * (size_t)groups * 32);
+            /* the uploads above are asynchronous on o->stream: synced below before the host copies are freed */
+            if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+        }
+        free(kh);
+        free(cm);
+    }
 #undef UP
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     free(tw);
@@ -436,6 +510,9 @@ static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, 
         a.colTiles = o->colTiles;
         a.timeKernel = o->colTiles ? o->dTimeKernel + (size_t)(o->vFlag ? oct : 0) * o->fftLength * o->colTiles * 32
                                    : NULL;
+        a.timeKernelH = o->dTimeKernelH ? o->dTimeKernelH + (size_t)(o->vFlag ? oct : 0) * 2 * (o->fftLength / 16) * 64 * 8
+                                        : NULL;
+        a.colMul = o->dColMul ? o->dColMul + (size_t)(o->vFlag ? oct : 0) * 32 : NULL;
         st = afxk_cqt_octave(&a, stream);
         if (st != AFX_OK || oct == 0) break;
         /* the next octave kernel reads dNext: wait for the decimation enqueued above (and only for it:
@@ -756,6 +833,8 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dScaleOff);
     afxdev_free(o->dFold);
     afxdev_free(o->dTimeKernel);
+    afxdev_free(o->dTimeKernelH);
+    afxdev_free(o->dColMul);
     afxdev_free(o->dX);
     afxdev_free(o->dSig[0]);
     afxdev_free(o->dSig[1]);

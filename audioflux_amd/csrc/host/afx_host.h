@@ -57,6 +57,11 @@ void afx_fft_ref32(int radix2Exp, const float *re1, const float *im1, float *re2
 /* afx_cqt.c: 0/1 folding matrix [chromaNum, num] of log-spaced bins onto chroma classes
  * (src/filterbank/chroma_filterBank.c:176-264); calloc'ed, caller frees */
 unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre);
+/* afx_cqt.c: one octave group's time-domain image G [N][32] -> IEEE binary16 (hi, lo) words of its columns
+ * scaled by 2^s_j to a peak in [2^13, 2^14) (round to nearest even; lo = f16(v - hi)), in the B-fragment order
+ * of v_mfma_f32_32x32x16_f16: out[word][N/16 steps][64 lanes][8], lane l = 32 g + j holds rows
+ * 16 ks + 8 g + e of column j; colMul[32] = 2^-s_j (afx_cqt_f16.hip) */
+void afx_cqt_time_kernel_f16(const float *G, int N, unsigned short *out, float *colMul);
 /* afx_spectrogram.c: Gaussian STFT-chroma bank [num, fftLength/2+1]
  * (src/filterbank/chroma_filterBank.c:13-174, default octave centre 5 / width 2) */
 float *afx_chroma_stft_bank(int num, int fftLength, int samplate);

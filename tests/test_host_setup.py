@@ -74,3 +74,42 @@ def test_dct_and_twiddle_tables():
     t = np.ctypeslib.as_array(N.afx_twiddle_table(2048), (1024, 2)).astype(np.float64)
     w = np.exp(-2j * np.pi * np.arange(1024) / 2048)
     assert np.abs(t[:, 0] + 1j * t[:, 1] - w).max() < 1e-7
+
+
+def test_cqt_f16_fragment_words_match_numpy():
+    """afx_cqt_time_kernel_f16 (host side of afx_cqt_f16.hip): round-to-nearest-even binary16 (hi, lo) words of the
+    power-of-two scaled image columns, in MFMA B-fragment order, bit for bit against numpy.float16"""
+    import ctypes
+
+    from audioflux_amd import _lib
+    lib = _lib.get_lib()
+    fn = lib.afx_cqt_time_kernel_f16
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(11)
+    N = 512
+    G = (rng.standard_normal((N, 32)) * 10.0 ** rng.uniform(-9, -1, (1, 32))).astype(np.float32)
+    G[:, 24:] = 0.0                                   # padding columns
+    G[5, 3] = 0.0
+    G[7, 2] = np.float32(1e-30)                       # far below the column peak: subnormal / zero words
+    G[9:40, 1] *= np.float32(2.0 ** -13)              # values whose hi word is an f16 subnormal
+    out = np.zeros((2, N // 16, 64, 8), np.uint16)
+    cm = np.zeros(32, np.float32)
+    fn(G.ctypes.data, N, out.ctypes.data, cm.ctypes.data)
+    for j in range(32):
+        pk = np.abs(G[:, j]).max()
+        s = 14 - int(np.frexp(pk)[1]) if pk > 0 else 0
+        assert cm[j] == np.ldexp(np.float32(1), -s)
+        v = np.ldexp(G[:, j], s).astype(np.float32)
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float32)).astype(np.float16)
+        k = np.arange(N)
+        got_hi = out[0, k // 16, 32 * ((k % 16) // 8) + j, k % 8]
+        got_lo = out[1, k // 16, 32 * ((k % 16) // 8) + j, k % 8]
+        # +0 / -0 words compare equal as values; everything else bit for bit
+        assert np.array_equal(got_hi.view(np.float16), hi) and np.array_equal(got_lo.view(np.float16), lo), j
+        nz = hi != 0
+        assert np.array_equal(got_hi[nz], hi.view(np.uint16)[nz])
+        # hi + lo carries the float32 value to 2^-21 of itself (2^-25 absolute in the subnormal range)
+        err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - v)
+        assert np.all(err <= np.maximum(np.abs(v) * 2.0 ** -21, 2.0 ** -25))
