@@ -137,6 +137,30 @@ class CQT:
                       out.data_ptr(), s.cuda_stream), "cqtObj_chromaBatchDevice")
         return out
 
+    def cqt_chroma_device(self, x, chroma_num=12, data_type=SpectralDataType.POWER, norm_type=ChromaDataNormalType.MAX,
+                          out_real=None, out_imag=None, out=None, stream=None):
+        """Additive (cqtObj_cqtChromaBatchDevice): cqt_device + chroma_device as one call, pass by pass over
+        the clips -> (real, imag, chroma) HIP tensors; same results as the two calls."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        b, n = x.shape
+        t = self.cal_time_length(n)
+        if out_real is None:
+            out_real = torch.empty((b, t, self.num), dtype=torch.float32, device=x.device)
+        if out_imag is None:
+            out_imag = torch.empty_like(out_real)
+        if out is None:
+            out = torch.empty((b, t, chroma_num), dtype=torch.float32, device=x.device)
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        fn = self._lib.cqtObj_cqtChromaBatchDevice
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, POINTER(c_int),
+                       POINTER(c_int), POINTER(c_int), c_void_p, c_void_p]
+        _lib.check(fn(self._obj, x.data_ptr(), b, n, x.stride(0), out_real.data_ptr(), out_imag.data_ptr(),
+                      _util.opt_int(chroma_num), _util.opt_int(int(data_type)), _util.opt_int(int(norm_type)),
+                      out.data_ptr(), s.cuda_stream), "cqtObj_cqtChromaBatchDevice")
+        return out_real, out_imag, out
+
     def cqcc(self, m_data_arr, cc_num=13, rectify_type=CepstralRectifyType.LOG):
         """real (..., num, time) magnitudes of the LAST cqt call -> (..., cc_num, time)"""
         m = _util.as_f32(np.swapaxes(np.abs(np.asarray(m_data_arr)), -1, -2))

@@ -55,7 +55,8 @@ struct CqF16 {
     static constexpr int CS = COPIES == 1 ? ((RAW + 15) & ~15)
                                           : ((RAW + 255) & ~255) + (COPIES == 4 ? 64 : 128);  // copy stride
     static constexpr int PART = COPIES * CS;         // bytes of one word plane (xh or xl)
-    static constexpr int WAVE_BYTES = 2 * PART;
+    // the transposed epilogue reuses the region: [32 frames][2 planes][4 pieces][4 floats] = 4 KB
+    static constexpr int WAVE_BYTES = 2 * PART > 4096 ? 2 * PART : 4096;
     static constexpr int B_BYTES = 2 * KS * 64 * 16; // both word planes of the image
     // byte offset of sample s inside copy c (s >= 0; multiple of 4 where it is used for stores)
     __host__ __device__ static constexpr int at(int s, int c) {
@@ -75,18 +76,30 @@ __device__ __forceinline__ float dpp_f(float v, int ctrl) {
     }
 }
 
-__device__ __forceinline__ unsigned pack_h2(float a, float b) {
-    h2 v = {(_Float16)a, (_Float16)b};  // round to nearest even
-    return __builtin_bit_cast(unsigned, v);
+// (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
+// fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).
+// One asm statement: VALU->VALU dependences are interlocked, and hipcc's own form of this costs 7 instructions.
+__device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigned &hi, unsigned &lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(x0), "v"(x1), "s"(up));
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 constexpr int RSRC_RAW = 0x00020000;  // raw buffer, 32-bit data format (cdna_hip_programming.md T8)
 
-template <int H, int EXP = 0>
+// R12: 12 bins per octave (the default ladder) -> the tile's results are transposed through LDS and leave as four
+// 12-byte-per-lane stores (one lane = 3 consecutive bins of one frame and plane); otherwise 32 dword stores.
+// TIMING: per-phase s_memtime sums to dbg (AFX_CQT_EXP=3; tools only).
+template <int H, bool R12, bool TIMING>
 // hop 128: 19 KB of window planes per wave leave room for four waves (one per SIMD, up to 512 VGPRs)
 __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtOctaveArgs a, int tilesPerClip, unsigned long long *dbg) {
     using C = CqF16<H>;
+    constexpr int NSTORE = R12 ? 4 : 32;  // memory stores per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, nth = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), waves = nth >> 6;
@@ -108,16 +121,24 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
     __syncthreads();
 
     // Output: per clip one raw buffer per plane, T x num floats; rows past timeLength and the padding columns
-    // fall out of range and are dropped by the bounds check, so every tile issues the same 32 stores
+    // fall out of range and are dropped by the bounds check, so every tile issues the same NSTORE stores
     // (the compiler can then count them: waiting for the prefetched window does not wait for stores).
     const bool colOk = i < 2 * a.rows, colIm = i >= a.rows;
     const int colOff = a.colBase + (colOk ? (colIm ? i - a.rows : i) : 0);
     const float colMul = a.colMul[i] * (a.octScale / a.scale[colOff]);  // 2^-s_j sqrt(2^k) / sqrt(len_j)
     const unsigned OOR = 0x80000000u;
+    const unsigned planeBytes = (unsigned)a.timeLength * (unsigned)a.num * 4u;
+    const unsigned rowBytes = (unsigned)a.num * 4u;
+    // generic epilogue: lane = column, 16 rows
     const unsigned laneOff = (unsigned)(4 * g * a.num + colOff) * 4u;
     const unsigned voffRe = (colOk && !colIm) ? laneOff : OOR;
     const unsigned voffIm = (colOk && colIm) ? laneOff : OOR;
-    const unsigned planeBytes = (unsigned)a.timeLength * (unsigned)a.num * 4u;
+    // transposed epilogue (R12): the lane's 16 values go to epi[frame][plane][piece][word] ...
+    const int jj = i < 12 ? i : i - 12;
+    unsigned char *epiW = sig + (i < 24 ? (i >= 12 ? 64 : 0) + (jj / 3) * 16 + (jj % 3) * 4 : (i - 24) * 16 + 12) + 4 * g * 128;
+    // ... and leave as: store q, lane L -> frame 16 (q >> 1) + (L >> 2), plane q & 1, bins 3 (L & 3) .. + 2
+    const unsigned char *epiR = sig + (lane >> 2) * 128 + (lane & 3) * 16;
+    const unsigned voff12 = (unsigned)(lane >> 2) * rowBytes + (unsigned)(a.colBase + 3 * (lane & 3)) * 4u;
     // A fragment base of this lane: row i of copy i mod COPIES, first step
     const int cpy = i % C::COPIES;
     const unsigned char *aHi = sig + cpy * C::CS + C::at(i * H + 8 * g, cpy);
@@ -142,19 +163,19 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
     };
     int t = blockIdx.x * waves + wave;  // wave-uniform (SGPR)
     if (t < totalTiles) fetch(t);
-    // 32 out-of-range (dropped) stores behind the first window: the loop is then entered with the same
-    // count of memory operations in flight as on its back edge (window loads, then a tile's 32 stores), and
-    // the compiler's wait for the window becomes vmcnt(32 + ...) instead of a wait for the previous tile's
-    // stores to be acknowledged (measured: the f16 octave kernels spent two thirds of their time there)
+    // NSTORE out-of-range (dropped) stores behind the first window: the loop is then entered with the same
+    // count of memory operations in flight as on its back edge (window loads, then a tile's stores), and
+    // the compiler's wait for the window becomes vmcnt(NSTORE + ...) instead of a wait for the previous tile's
+    // stores to be acknowledged
     {
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.outRe, 0, 4, RSRC_RAW);
 #pragma unroll
-        for (int r = 0; r < (EXP == 1 ? 2 : 32); ++r) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, OOR + 4u * r, 0, 0);  // distinct: not merged
+        for (int r = 0; r < NSTORE; ++r) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, OOR + 4u * r, 0, 0);  // distinct: not merged
     }
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = EXP == 3 ? __builtin_readcyclecounter() : 0, ntile = 0;
-    const unsigned long long c0 = tprev, r0 = EXP == 3 ? __builtin_amdgcn_s_memrealtime() : 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = TIMING ? __builtin_readcyclecounter() : 0, ntile = 0;
+    const unsigned long long c0 = tprev, r0 = TIMING ? __builtin_amdgcn_s_memrealtime() : 0;
     auto stamp = [&](int k) {
-        if (EXP == 3) {
+        if (TIMING) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long now = __builtin_readcyclecounter();
             ph[k] += now - tprev;
@@ -164,8 +185,8 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
     };
     for (; t < totalTiles; t += stride) {
         const int clip = t / tilesPerClip, t0 = (t - clip * tilesPerClip) * 32;
-        stamp(0);  // loop overhead / previous epilogue issue
-        if (EXP == 3) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); stamp(1); }  // window arrival
+        stamp(0);  // loop overhead
+        if (TIMING) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory"); stamp(1); }  // window arrival
         // ---- tile exponent: peak of the window -> [2^13, 2^14)
         float peak = 0.f;
 #pragma unroll
@@ -189,18 +210,15 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
         const float up = __uint_as_float((unsigned)(e + 127) << 23);      // 2^e
         const float down = __uint_as_float((unsigned)(127 - e) << 23);    // 2^-e
         // ---- window -> (xh, xl) planes (every copy)
-        wave_lds_order();  // the fragment reads of the previous tile are done
+        wave_lds_order();  // the fragment / epilogue reads of the previous tile are done
 #pragma unroll
         for (int u = 0; u < C::NV; ++u) {
             const int s = 4 * (lane + 64 * u);
             if (s < C::S) {
                 const float4 v = __builtin_bit_cast(float4, wnd[u]);
-                const float x0 = v.x * up, x1 = v.y * up, x2 = v.z * up, x3 = v.w * up;
-                const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2v = (_Float16)x2, h3 = (_Float16)x3;
-                const h2 ha = {h0, h1}, hb = {h2v, h3};
-                const unsigned hi0 = __builtin_bit_cast(unsigned, ha), hi1 = __builtin_bit_cast(unsigned, hb);
-                const unsigned lo0 = pack_h2(x0 - (float)h0, x1 - (float)h1);
-                const unsigned lo1 = pack_h2(x2 - (float)h2v, x3 - (float)h3);
+                unsigned hi0, hi1, lo0, lo1;
+                split_pair(v.x, v.y, up, hi0, lo0);
+                split_pair(v.z, v.w, up, hi1, lo1);
                 const int base = C::MARGIN + 2 * s + (C::PAD ? 16 * (s / H) : 0);
 #pragma unroll
                 for (int c = 0; c < C::COPIES; ++c) {
@@ -240,13 +258,9 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 2 < C::KS) load(ks + 2, (ks + 2) % 3);
             const int sl = ks % 3;
-            if (EXP != 2) {
             hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bh[sl], hh, 0, 0, 0);
             hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bl[sl], hl, 0, 0, 0);
             lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl], bh[sl], lh, 0, 0, 0);
-            } else {  // experiment: operands consumed without the matrix pipe
-                hh[0] += (float)ah[sl][0] + (float)bh[sl][0] + (float)al[sl][0] + (float)bl[sl][0];
-            }
             if (ks + 2 < C::KS) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
@@ -257,26 +271,39 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (EXP == 3) { asm volatile("s_nop 0" ::: "memory"); stamp(4); ++ntile; }  // K loop
+        if (TIMING) { asm volatile("s_nop 0" ::: "memory"); stamp(4); ++ntile; }  // K loop
         // ---- D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
         {
             const long long po = (long long)clip * a.outStride;
             const __amdgpu_buffer_rsrc_t rRe = __builtin_amdgcn_make_buffer_rsrc(a.outRe + po, 0, (int)planeBytes, RSRC_RAW);
             const __amdgpu_buffer_rsrc_t rIm = __builtin_amdgcn_make_buffer_rsrc(a.outIm + po, 0, (int)planeBytes, RSRC_RAW);
             const float mul = down * colMul;
-            const unsigned rowBytes = (unsigned)a.num * 4u;
             const unsigned tileOff = (unsigned)t0 * rowBytes;
+            if (R12) {
+                wave_lds_order();  // the last fragment reads are done: the window region is free
 #pragma unroll
-            for (int r = 0; r < (EXP == 1 ? 1 : 16); ++r) {
-                const unsigned ro = tileOff + (unsigned)((r & 3) + 8 * (r >> 2)) * rowBytes;  // scalar
-                const unsigned v = __float_as_uint((hh[r] + (hl[r] + lh[r])) * mul);
-                __builtin_amdgcn_raw_buffer_store_b32(v, rRe, voffRe + ro, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(v, rIm, voffIm + ro, 0, 0);
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float *>(epiW + ((r & 3) + 8 * (r >> 2)) * 128) = (hh[r] + (hl[r] + lh[r])) * mul;
+                wave_lds_order();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(epiR + (q >> 1) * 2048 + (q & 1) * 64);
+                    const u32x3 v3 = {v.x, v.y, v.z};
+                    __builtin_amdgcn_raw_buffer_store_b96(v3, (q & 1) ? rIm : rRe, voff12 + tileOff + (unsigned)(q >> 1) * 16u * rowBytes, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned ro = tileOff + (unsigned)((r & 3) + 8 * (r >> 2)) * rowBytes;  // scalar
+                    const unsigned v = __float_as_uint((hh[r] + (hl[r] + lh[r])) * mul);
+                    __builtin_amdgcn_raw_buffer_store_b32(v, rRe, voffRe + ro, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(v, rIm, voffIm + ro, 0, 0);
+                }
             }
         }
-        stamp(5);  // store issue
+        stamp(5);  // epilogue
     }
-    if (EXP == 3 && dbg && lane == 0) {
+    if (TIMING && dbg && lane == 0) {
         unsigned long long *d = dbg + (size_t)(blockIdx.x * waves + wave) * 8;
         for (int k = 0; k < 6; ++k) d[k] = ph[k];
         d[6] = ntile;
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
     }
 }
 
-template <int H, int EXP = 0>
+template <int H, bool R12, bool TIMING>
 int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
     using C = CqF16<H>;
     int waves = (160 * 1024 - C::B_BYTES) / C::WAVE_BYTES;
@@ -294,7 +321,7 @@ int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
     if (waves >= 4) waves &= ~3;  // the same number of waves on every SIMD
     if (waves < 1) return AFX_ERR_UNSUPPORTED;
     const size_t lds = (size_t)C::B_BYTES + (size_t)waves * C::WAVE_BYTES;
-    const void *fn = reinterpret_cast<const void *>(k_cqt_octave_f16<H, EXP>);
+    const void *fn = reinterpret_cast<const void *>(k_cqt_octave_f16<H, R12, TIMING>);
     AFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tilesPerClip = (a->timeLength + 31) / 32;
     const long long total = (long long)tilesPerClip * (a->batch > 0 ? a->batch : 1);
@@ -304,15 +331,14 @@ int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
     AfxCqtOctaveArgs b = *a;
     if (b.batch <= 0) b.batch = 1;
     unsigned long long *dbg = nullptr;
-    if (EXP == 3) {
+    if (TIMING) {
         AFX_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * 8 * wgs * waves));
         AFX_HIP(hipMemset(dbg, 0, sizeof(unsigned long long) * 8 * wgs * waves));
     }
-    hipLaunchKernelGGL((k_cqt_octave_f16<H, EXP>), dim3((unsigned)wgs), dim3(64 * waves), lds, (hipStream_t)stream, b,
+    hipLaunchKernelGGL((k_cqt_octave_f16<H, R12, TIMING>), dim3((unsigned)wgs), dim3(64 * waves), lds, (hipStream_t)stream, b,
                        tilesPerClip, dbg);
     AFX_LAUNCH_CHECK("k_cqt_octave_f16");
-    if (EXP == 3) {
-        static int shown = 0;
+    if (TIMING) {
         AFX_HIP(hipStreamSynchronize((hipStream_t)stream));
         const size_t n = (size_t)8 * wgs * waves;
         unsigned long long *h = (unsigned long long *)malloc(sizeof(unsigned long long) * n);
@@ -323,42 +349,40 @@ int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
             nt += (double)h[w * 8 + 6];
             mhz += (double)h[w * 8 + 7] / 10.0;
         }
-        fprintf(stderr, "cqt_f16<%d> shader clock over the tile loops: %.0f MHz\n", H, mhz / ((double)wgs * waves));
-        if (shown++ < 4)
-            fprintf(stderr, "cqt_f16<%d> phases, cycles(100 MHz ticks?) per tile: loop %.0f window-wait %.0f convert %.0f prefetch %.0f kloop %.0f stores %.0f  (tiles %.0f, waves %d)\n",
-                    H, ph[0] / nt, ph[1] / nt, ph[2] / nt, ph[3] / nt, ph[4] / nt, ph[5] / nt, nt, waves);
+        fprintf(stderr, "cqt_f16<%d> %d waves/CU, %.0f MHz; shader cycles per tile: loop %.0f window-wait %.0f convert %.0f "
+                "prefetch %.0f kloop %.0f epilogue %.0f\n", H, waves, mhz / ((double)wgs * waves), ph[0] / nt, ph[1] / nt,
+                ph[2] / nt, ph[3] / nt, ph[4] / nt, ph[5] / nt);
         free(h);
         AFX_HIP(hipFree(dbg));
     }
     return AFX_OK;
 }
 
+template <int H>
+int dispatch_f16(const AfxCqtOctaveArgs *a, void *stream) {
+    const char *ex = getenv("AFX_CQT_EXP");
+    const bool r12 = a->rows == 12 && !getenv("AFX_CQT_STORE32");
+    if (ex && atoi(ex) == 3) return r12 ? launch_f16<H, true, true>(a, stream) : launch_f16<H, false, true>(a, stream);
+    return r12 ? launch_f16<H, true, false>(a, stream) : launch_f16<H, false, false>(a, stream);
+}
+
 }  // namespace
 
-// N = 512, one column tile, power-of-two hop <= 128, 16-byte aligned clip rows; anything else returns
+// N = 512, one column tile, power-of-two hop <= 128; anything else returns
 // AFX_ERR_UNSUPPORTED and the caller (afxk_cqt_octave) takes the float32 kernels.
 extern "C" int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
     if (!a->timeKernelH || !a->colMul || a->colTiles != 1 || a->radix2Exp != 9) return AFX_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(a->x) % 16) || (a->xStride % 4)) return AFX_ERR_UNSUPPORTED;
+    // (no alignment condition on the clip rows: buffer loads need dword alignment only)
     // 32-bit byte offsets inside one clip's signal and one clip's output plane
     if (a->validLength > (1 << 28) || (long long)a->timeLength * a->num > (1LL << 28)) return AFX_ERR_UNSUPPORTED;
-    if (const char *ex = getenv("AFX_CQT_EXP")) {  // timing experiments (results are wrong)
-        const int x = atoi(ex);
-        if (a->hop == 16 && x == 1) return launch_f16<16, 1>(a, stream);
-        if (a->hop == 16 && x == 2) return launch_f16<16, 2>(a, stream);
-        if (a->hop == 128 && x == 1) return launch_f16<128, 1>(a, stream);
-        if (a->hop == 128 && x == 2) return launch_f16<128, 2>(a, stream);
-        if (a->hop == 16 && x == 3) return launch_f16<16, 3>(a, stream);
-        if (a->hop == 128 && x == 3) return launch_f16<128, 3>(a, stream);
-    }
     switch (a->hop) {
-        case 128: return launch_f16<128>(a, stream);
-        case 64: return launch_f16<64>(a, stream);
-        case 32: return launch_f16<32>(a, stream);
-        case 16: return launch_f16<16>(a, stream);
-        case 8: return launch_f16<8>(a, stream);
-        case 4: return launch_f16<4>(a, stream);
-        case 2: return launch_f16<2>(a, stream);
+        case 128: return dispatch_f16<128>(a, stream);
+        case 64: return dispatch_f16<64>(a, stream);
+        case 32: return dispatch_f16<32>(a, stream);
+        case 16: return dispatch_f16<16>(a, stream);
+        case 8: return dispatch_f16<8>(a, stream);
+        case 4: return dispatch_f16<4>(a, stream);
+        case 2: return dispatch_f16<2>(a, stream);
         default: return AFX_ERR_UNSUPPORTED;
     }
 }

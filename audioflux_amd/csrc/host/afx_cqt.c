@@ -552,6 +552,22 @@ void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float
     if (st != AFX_OK) fail(o, st, "cqtObj_cqt");
 }
 
+/* Clips per pass of the octave ladder.  Every octave kernel writes its 12 of the num columns of each output
+ * row (48-byte pieces of 336-byte rows), so a row is completed by seven launches; when the pass's output
+ * (2 planes x clips x T x num floats) stays within reach of the memory-side cache those pieces merge before
+ * they reach HBM, beyond it the partial-line writes throttle the store path (measured on cfg 5: 125 clips in one
+ * pass = 868 MB, octave kernels 1.3-2x slower per clip than at 64 clips).  Default: passes of <= 384 MB of output;
+ * AFX_CQT_CHUNK=<clips> overrides. */
+static int cqt_chunk_clips(CQTObj o, int T) {
+    const char *e = getenv("AFX_CQT_CHUNK");
+    if (e && atoi(e) > 0) return atoi(e) > 32768 ? 32768 : atoi(e);
+    const double perClip = 8.0 * (double)T * o->num;
+    long long c = (long long)(384.0 * 1024 * 1024 / (perClip > 0 ? perClip : 1));
+    if (c < 8) c = 8;
+    if (c > 32768) c = 32768;
+    return (int)c;
+}
+
 /* clips already in HBM, results left in HBM (include/afx_batch.h) */
 int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLength,
                           long long clipStride, float *dReal, float *dImag, void *hipStream) {
@@ -564,8 +580,9 @@ int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLengt
     const int T = dataLength / o->slideLength + 1;
     /* scratch is shared between calls: order this call after the previous one's stream */
     if (o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
-    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += 32768) {
-        const int nb = batch - b0 < 32768 ? batch - b0 : 32768;
+    const int chunk = cqt_chunk_clips(o, T);
+    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
+        const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride,
                             dReal + (long long)b0 * T * o->num, dImag + (long long)b0 * T * o->num,
                             hipStream);
@@ -715,6 +732,37 @@ int cqtObj_chromaBatchDevice(CQTObj o, int *chromaNum, SpectralDataType *dataTyp
     } else if (st != AFX_ERR_ARG) {
         fail(o, st, "cqtObj_chromaBatchDevice");
     }
+    return st;
+}
+
+/* CQT and its chroma in one call (include/afx_batch.h): pass by pass, so that the chroma kernel reads the
+ * pass's CQT rows while they are still cached */
+int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dataLength, long long clipStride,
+                                float *dReal, float *dImag, int *chromaNum, SpectralDataType *dataType,
+                                ChromaDataNormalType *normType, float *dChroma, void *hipStream) {
+    AFX_ENTER(o);
+    if (!o || !dData || !dReal || !dImag || !dChroma || batch <= 0 || dataLength <= 0 || clipStride < dataLength) {
+        afxdev_set_error("cqtObj_cqtChromaBatchDevice: bad argument");
+        return AFX_ERR_ARG;
+    }
+    int cn, isMag, nrm;
+    int st = chroma_prepare(o, chromaNum, dataType, normType, &cn, &isMag, &nrm);
+    if (st == AFX_ERR_ARG) return st;
+    const int T = dataLength / o->slideLength + 1;
+    if (st == AFX_OK && o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
+    const int chunk = cqt_chunk_clips(o, T);
+    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
+        const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+        float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;
+        st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im, hipStream);
+        if (st == AFX_OK)
+            st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, cn, isMag, nrm,
+                                 dChroma + (long long)b0 * T * cn, hipStream);
+    }
+    o->lastStream = hipStream;
+    o->lastUsed = 1;
+    o->timeLength = T;
+    if (st != AFX_OK) fail(o, st, "cqtObj_cqtChromaBatchDevice");
     return st;
 }
 

@@ -298,8 +298,11 @@ class Cfg5:
         self.outputs = "cqt[clips,T,84] complex (split planes) + chroma[clips,T,12] f32 in HBM"
 
     def step(self, i):
-        self.o.cqt_device(self.x, self.re, self.im)
-        self.o.chroma_device(self.re, self.im, out=self.ch[i & 1])
+        if os.environ.get("AFX_BENCH_CQT_SPLIT") == "1":  # the two separate calls (A/B)
+            self.o.cqt_device(self.x, self.re, self.im)
+            self.o.chroma_device(self.re, self.im, out=self.ch[i & 1])
+        else:
+            self.o.cqt_chroma_device(self.x, out_real=self.re, out_imag=self.im, out=self.ch[i & 1])
 
     def slab(self, i, which):
         return self.ch[i & 1] if which == "chroma" else self.re

@@ -110,6 +110,13 @@ int cqtObj_chromaBatchDevice(CQTObj cqtObj, int *chromaNum, SpectralDataType *da
                              ChromaDataNormalType *normType, const float *dReal,
                              const float *dImag, long long rows, float *dData, void *hipStream);
 
+/* cqtObj_cqtBatchDevice followed by cqtObj_chromaBatchDevice on its output, as one call: the clips go through
+ * the octave ladder in passes (AFX_CQT_CHUNK clips, default <= 384 MB of output) and each pass's chroma is taken
+ * while its CQT rows are still cached.  dChroma [batch][T, chromaNum]; results identical to the two calls. */
+int cqtObj_cqtChromaBatchDevice(CQTObj cqtObj, const float *dData, int batch, int dataLength, long long clipStride,
+                                float *dReal, float *dImag, int *chromaNum, SpectralDataType *dataType,
+                                ChromaDataNormalType *normType, float *dChroma, void *hipStream);
+
 /* ---- cepstrogram ----------------------------------------------------------------------
  * batch clips -> dOut1/dOut2/dOut3 [batch][T, N/2+1] (cepstrum, envelope, details; any may
  * be NULL).  Same as calling cepstrogramObj_cepstrogram (cepstrogram_algorithm.h) per clip. */

@@ -1,6 +1,8 @@
 """Batched / HBM-resident entry points of include/afx_batch.h for CWT, CQT(+chroma),
 cepstrogram and xxcc: identical to looping the legacy one-clip call (bit-exact, same
 kernels), and within tolerance of the compiled reference on sampled clips."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,6 +88,18 @@ def test_cqt_batch_device_equals_loop_and_reference():
         rre, rim = r.cqt(x[2])
         assert_parity(got[2].T, rre + 1j * rim, what="cqt batch vs reference")
         assert_parity(gch[2].T, r.chroma(rre, rim), what="chroma batch vs reference")
+    # the fused call, in one pass and in passes of 3 clips: same bits as the two calls
+    for chunk in (None, "3"):
+        if chunk:
+            os.environ["AFX_CQT_CHUNK"] = chunk
+        try:
+            re3, im3, ch3 = o.cqt_chroma_device(xd)
+            re4, im4 = o.cqt_device(xd)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("AFX_CQT_CHUNK", None)
+        assert torch.equal(re3, re) and torch.equal(im3, im) and torch.equal(ch3, ch), f"fused call, chunk {chunk}"
+        assert torch.equal(re4, re) and torch.equal(im4, im), f"cqt_device in passes, chunk {chunk}"
     # ragged tail + padded row stride
     wide = torch.zeros((3, n + 77), dtype=torch.float32, device="cuda")
     wide[:, :n - 13] = xd[:3, :n - 13]
