@@ -805,3 +805,67 @@ def synsq_allowance(W, ph, ang, fre, samplate, scale, thresh):
         ok = amb & np.isfinite(rr) & (rr >= 0) & (rr < num)
         np.add.at(allow, (rr[ok].astype(np.int64), cols[ok]), mag[ok])
     return allow, amb
+
+
+# ---- model of the split-f16 octave product (audioflux_amd/csrc/hip/afx_cqt_f16.hip) ----------------
+def _f16_words(a):
+    """(hi, lo) binary16 words of float32 values: hi = f16(a), lo = f16(a - hi), as float32 arrays"""
+    a = np.asarray(a, f32)
+    hi = a.astype(np.float16)
+    lo = (a - hi.astype(f32)).astype(np.float16)
+    return hi.astype(f32), lo.astype(f32)
+
+
+def cqt_octave_f16_model(xp, T, hop, n, Kf):
+    """One octave Q[T, bpo] as k_cqt_octave_f16 forms it: the time-domain image G_j[m] = sum_k K_j[k]
+    e^{-2 pi i k m / n} of the thresholded spectral kernels (rounded to float32, columns scaled by 2^s_j to a
+    peak in [2^13, 2^14) and split into f16 words), times 32-frame tiles of the zero-padded signal xp (float32,
+    scaled by 2^e per tile from the tile's peak and split into f16 words); three products xh gh + xh gl + xl gh
+    accumulated in float32.  Test infrastructure: pins the numerics of that formulation on the CPU."""
+    bpo = Kf.shape[0]
+    m = np.arange(n)
+    k = np.arange(Kf.shape[1])
+    G = (Kf[:, :, None] * np.exp(-2j * np.pi * k[None, :, None] * m[None, None, :] / n)).sum(axis=1)  # [bpo, n]
+    Gc = np.concatenate([G.real, G.imag], axis=0).T.astype(f32)                                           # [n, 2 bpo]
+    s = np.zeros(2 * bpo, np.int64)
+    for j in range(2 * bpo):
+        pk = np.abs(Gc[:, j]).max()
+        s[j] = 14 - np.frexp(pk)[1] if pk > 0 else 0
+    gh, gl = _f16_words(np.ldexp(Gc, s[None, :]))
+    out = np.zeros((T, bpo), complex)
+    xp = np.asarray(xp, f32)
+    for t0 in range(0, T, 32):
+        rows = min(32, T - t0)
+        w = xp[t0 * hop: t0 * hop + 31 * hop + n]  # the tile's window (zero padded by the caller)
+        pk = np.abs(w).max()
+        e = min(13 - (int(np.frexp(pk)[1]) - 1), 126) if pk >= 2.0 ** -126 else 0
+        idx = np.arange(n)[None, :] + hop * np.arange(rows)[:, None]
+        xh, xl = _f16_words(np.ldexp(w, e)[idx])
+        acc = (xh @ gh).astype(f32) + ((xh @ gl).astype(f32) + (xl @ gh).astype(f32))
+        acc = np.ldexp(acc, -e) * np.ldexp(f32(1), -s)[None, :]
+        out[t0:t0 + rows] = acc[:, :bpo] + 1j * acc[:, bpo:]
+    return out
+
+
+def cqt_f16_model(x, num=84, samplate=32000, min_fre=32.703196, bpo=12, window_type=1, normal="none",
+                  hop=None, is_scale=True):
+    """restate.cqt with every octave product formed by cqt_octave_f16_model (float32 signal chain)"""
+    fre, n, lens, K = cqt_plan(num, samplate, min_fre, bpo, window_type, normal)
+    octaves = num // bpo
+    hop = hop or n // 4
+    x = np.asarray(x, np.float64)
+    T = len(x) // hop + 1
+    out = np.zeros((T, num), complex)
+    h = hop
+    for k, o in enumerate(range(octaves - 1, -1, -1)):
+        frames = len(x) // h + 1
+        valid = len(x) - (len(x) % h if frames > 1 else 0)
+        xp = np.concatenate([np.zeros(n // 2), x[:valid], np.zeros(n // 2 + n + 32 * h)])
+        Q = cqt_octave_f16_model(xp, T, h, n, K) * np.sqrt(2.0 ** k)
+        if is_scale:
+            Q = Q / np.sqrt(lens[o * bpo:(o + 1) * bpo])[None, :]
+        out[:, o * bpo:(o + 1) * bpo] = Q
+        if o > 0:
+            x = decimate2(x)
+            h //= 2
+    return out

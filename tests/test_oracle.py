@@ -139,3 +139,19 @@ def test_restatement_matches_golden_cwt(name, wavelet, gb, golden_dir):
     got = restate.cwt(x, gold[f"{name}/fre"][::-1], c["samplate"], wavelet, gb[0], gb[1],
                       bool(c["is_padding"]))[:, ::cases.cwt_stride(c)]
     assert_parity(got, gold[f"{name}/re"] + 1j * gold[f"{name}/im"], 1e-5, name)
+
+
+@pytest.mark.parametrize("name", ["c84_32k_area", "c84_44k_none_noscale", "c48_16k_area"])
+def test_split_f16_octave_product_model_matches_golden_cqt(name, golden_dir):
+    """the formulation of k_cqt_octave_f16 (time-domain image of the thresholded kernels, both operands as
+    (hi, lo) f16 words under power-of-two scaling, three products, float32 accumulation), modelled in numpy,
+    meets the reference's golden CQT at the same 1e-5 as the float64 restatement -- and sits within 2e-6 of it"""
+    gold = np.load(os.path.join(golden_dir, "cqt.npz"))
+    c = cases.CQT_CASES[name]
+    x = cases.make_input(c["x"], c["samplate"])
+    args = (x, c["num"], c["samplate"], float(np.float32(c["min_fre"])), 12, c["window_type"],
+            "area" if c["normal_type"] == 1 else "none", None, bool(c["is_scale"]))
+    q = restate.cqt_f16_model(*args)
+    want = gold[f"{name}/re"] + 1j * gold[f"{name}/im"]
+    assert_parity(q, want, 1e-5, name + " (f16 model)")
+    assert_parity(q, restate.cqt(*args), 2e-6, name + " (f16 model vs float64 restatement)")

@@ -11,6 +11,9 @@
     with the same k as B element e of lane half g, and the (hi, lo) f16 split with power-of-two scaling meets
     float32-level accuracy (the three-product sum against a float64 product).
 
+  * the transposed 12-bin epilogue (accumulator layout -> LDS -> four 12-byte stores per lane) and the index algebra
+    of k_cqt_decimate's even / odd staging (afx_cqt.hip) are restated lane by lane as well.
+
 Exits non-zero on any mismatch; prints OK."""
 import sys
 
@@ -36,7 +39,7 @@ class Cfg:
         else:
             self.CS = ((self.RAW + 255) & ~255) + (64 if self.COPIES == 4 else 128)
         self.PART = self.COPIES * self.CS
-        self.WAVE_BYTES = 2 * self.PART
+        self.WAVE_BYTES = max(2 * self.PART, 4096)  # the transposed epilogue reuses the region (4 KB)
         self.B_BYTES = 2 * KS * 64 * 16
 
     def at(self, s, c):
@@ -67,7 +70,7 @@ def check_hop(H):
     assert waves >= 4, (H, waves)
     assert c.B_BYTES + waves * c.WAVE_BYTES <= 160 * 1024
     # the window as int16 "sample ids" (hi plane; the lo plane is the same map + PART)
-    lds = np.full(c.WAVE_BYTES // 2, -1, np.int64)  # one entry per f16 word
+    lds = np.full(c.PART, -1, np.int64)  # one entry per f16 word of the two planes
     for u in range(c.NV):
         for lane in range(64):
             s = 4 * (lane + 64 * u)
@@ -164,7 +167,89 @@ def check_numerics():
     return worst
 
 
+def check_epilogue():
+    """R12 epilogue: accumulator layout -> LDS [frame][plane][piece][4] -> four 12-byte stores per lane"""
+    rng = np.random.default_rng(2)
+    D = rng.standard_normal((32, 32))  # tile result [frame][column], columns 0..11 re, 12..23 im, 24..31 padding
+    lds = np.full(4096 // 4, np.nan)
+    for lane in range(64):
+        i, g = lane & 31, lane >> 5
+        jj = i if i < 12 else i - 12
+        if i < 24:
+            base = (64 if i >= 12 else 0) + (jj // 3) * 16 + (jj % 3) * 4
+        else:
+            base = (i - 24) * 16 + 12  # padding columns land in the unused fourth word of a piece
+        base += 4 * g * 128
+        for r in range(16):
+            row = (r & 3) + 8 * (r >> 2) + 4 * g  # D layout of v_mfma_f32_32x32x*: col = lane & 31
+            a = base + ((r & 3) + 8 * (r >> 2)) * 128
+            assert a % 4 == 0 and a + 4 <= 4096
+            if i < 24:
+                assert np.isnan(lds[a // 4]), "two lanes write one word"
+            lds[a // 4] = D[row, i]
+    rows_bytes = 84 * 4
+    seen = set()
+    for q in range(4):
+        for lane in range(64):
+            a = (lane >> 2) * 128 + (lane & 3) * 16 + (q >> 1) * 2048 + (q & 1) * 64
+            v = lds[a // 4: a // 4 + 3]
+            frame, plane, piece = 16 * (q >> 1) + (lane >> 2), q & 1, lane & 3
+            want = D[frame, plane * 12 + 3 * piece: plane * 12 + 3 * piece + 3]
+            assert np.array_equal(v, want), (q, lane)
+            # byte offset inside the clip's plane (colBase = 0, t0 = 0): voff12 + (q >> 1) 16 rowBytes
+            off = (lane >> 2) * rows_bytes + 3 * (lane & 3) * 4 + (q >> 1) * 16 * rows_bytes
+            assert off == frame * rows_bytes + 3 * piece * 4
+            seen.add((frame, plane, piece))
+    assert len(seen) == 32 * 2 * 4
+
+
+def check_decimator():
+    """k_cqt_decimate (afx_cqt.hip): staging XE[k] = x[2 (i0-15+k)], XO[k] = x[2 (i0-16+k) + 1] by 16-byte groups,
+    operands E[q + 15 -/+ .], O[q + 16 -/+ .] -> the reference's tap order"""
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal(32)
+    DEC_OUT, DEC_LDS = 1024, 1060
+    for src_len, blocks in ((5000, 3), (2049, 2), (40, 1)):
+        x = rng.standard_normal(src_len)
+        dst_len = src_len // 2
+        at = lambda s: x[s] if 0 <= s < src_len else 0.0
+        for blk in range(blocks):
+            i0 = blk * DEC_OUT
+            XE, XO = np.full(DEC_LDS, np.nan), np.full(DEC_LDS, np.nan)
+            for q in range(0, (DEC_LDS - 2) // 2 + 1):
+                if q == 0:
+                    s0 = 2 * (i0 - 15)
+                    XE[0], XO[0], XO[1] = at(s0), at(s0 - 1), at(s0 + 1)
+                else:
+                    k = 2 * q - 1
+                    s = 2 * (i0 - 15 + k)
+                    assert s % 4 == 0  # one 16-byte load
+                    v = [at(s), at(s + 1), at(s + 2), at(s + 3)]
+                    XE[k], XE[k + 1] = v[0], v[2]
+                    if k + 1 < DEC_LDS:
+                        XO[k + 1] = v[1]
+                    if k + 2 < DEC_LDS:
+                        XO[k + 2] = v[3]
+            for tid in (0, 1, 7, 255):
+                E, O = XE[4 * tid: 4 * tid + 36], XO[4 * tid: 4 * tid + 36]
+                for q in range(4):
+                    i = i0 + 4 * tid + q
+                    if i >= dst_len:
+                        continue
+                    acc = 0.0
+                    for j in range(32):
+                        acc += h[j] * (O[q + 16 - (j + 1) // 2] if j & 1 else E[q + 15 - j // 2])
+                    for j in range(1, 32):
+                        acc += h[j] * (O[q + 16 + (j - 1) // 2] if j & 1 else E[q + 15 + j // 2])
+                    want = sum(h[j] * at(2 * i - j) for j in range(32)) + sum(h[j] * at(2 * i + j) for j in range(1, 32))
+                    assert np.isfinite(acc) and abs(acc - want) < 1e-12, (src_len, blk, tid, q)
+
+
 def main():
+    check_epilogue()
+    print("transposed epilogue: every (frame, plane, 3-bin piece) leaves exactly once with the right values")
+    check_decimator()
+    print("decimator staging / operand indices reproduce y[i] = sum h_j x[2i - j] + sum h_j x[2i + j]")
     for H in (128, 64, 32, 16, 8, 4, 2):
         waves, wb = check_hop(H)
         print(f"hop {H:3d}: {waves} waves per CU, {wb} bytes of window planes per wave, fragments conflict-free")
