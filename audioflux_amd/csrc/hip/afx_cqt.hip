@@ -639,6 +639,99 @@ __global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re
     }
 }
 
+// ---- chroma, second formulation (AFX_CQT_CHROMA_V2=1; not yet measured on hardware, off by default) --------
+// k_cqt_chroma spends most of its time before the first barrier: chromaNum threads scan the num flags of their
+// row of the 0/1 matrix in global memory, one dependent byte load at a time, while the other threads wait.
+// Here the per-class bin lists are built once per launch on the host side of this file and travel as a kernel
+// argument; a thread owns (frame = tid & 63, classes wave, wave + 4, ...), so the class -- and with it the list
+// walked -- is uniform per wave (scalar loads of the kernel argument), and the |Q|^2 rows sit in LDS at an odd
+// pitch so that the 64 frames of a read fall on distinct banks.  Same sums in the same (ascending bin) order.
+struct ChromaLists {
+    unsigned short start[65];   // class c owns bins[start[c] .. start[c + 1])
+    unsigned char bins[256];
+};
+
+__global__ __launch_bounds__(256) void k_cqt_chroma_v2(const float *__restrict__ re, const float *__restrict__ im,
+                                                       long long rows, int num, ChromaLists L, int chromaNum,
+                                                       int isMag, int normType, float *__restrict__ out, int vec4) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int pitch = num | 1;                                // odd: frames of one bin on distinct banks
+    float *p = reinterpret_cast<float *>(smem_raw);           // [CH_FRAMES][pitch]
+    float *cv = p + CH_FRAMES * pitch;                        // [CH_FRAMES][chromaNum]
+    const int tid = threadIdx.x;
+    const long long f0 = (long long)blockIdx.x * CH_FRAMES;
+    const int nf = rows - f0 < CH_FRAMES ? (int)(rows - f0) : CH_FRAMES;
+    const float *pr = re + f0 * num, *pi = im + f0 * num;
+    auto pw = [&](float a, float b) {
+        float v = __fmaf_rn(a, a, b * b);
+        if (isMag) v = sqrtf(v);
+        return v;
+    };
+    if (vec4) {
+        const float4 *pr4 = reinterpret_cast<const float4 *>(pr), *pi4 = reinterpret_cast<const float4 *>(pi);
+        const int n4 = nf * num / 4, q4 = num / 4;
+        for (int e0 = tid; e0 < n4; e0 += 4 * 256) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + 256 * u, n4 - 1);
+                a[u] = pr4[e];
+                b[u] = pi4[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < n4) {
+                    const int f = e / q4, j = 4 * (e - f * q4);
+                    float *d = p + f * pitch + j;
+                    d[0] = pw(a[u].x, b[u].x);
+                    d[1] = pw(a[u].y, b[u].y);
+                    d[2] = pw(a[u].z, b[u].z);
+                    d[3] = pw(a[u].w, b[u].w);
+                }
+            }
+        }
+    } else {
+        for (int e = tid; e < nf * num; e += 256) {
+            const int f = e / num, j = e - f * num;
+            p[f * pitch + j] = pw(pr[e], pi[e]);
+        }
+    }
+    __syncthreads();
+    {
+        const int f = tid & (CH_FRAMES - 1);
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const float *row = p + f * pitch;
+        for (int c = wave; c < chromaNum; c += 4) {           // uniform per wave
+            const int b0 = L.start[c], b1 = L.start[c + 1];
+            float v = 0.f;
+            for (int q = b0; q < b1; ++q) v += row[L.bins[q]];
+            if (f < nf) cv[f * chromaNum + c] = v;
+        }
+    }
+    __syncthreads();
+    // per-frame normalisation (__mnormalize) and store: thread (frame, class) reads its frame's chromaNum values
+    float *po = out + f0 * chromaNum;
+    for (int it = tid; it < nf * chromaNum; it += 256) {
+        const int f = it / chromaNum;
+        float v = cv[it];
+        if (normType != 0) {
+            const float *c = cv + f * chromaNum;
+            float red = normType == 2 ? 3.4e38f : 0.f;
+            for (int k = 0; k < chromaNum; ++k) {             // 1 max, 2 min, 3 P2, 4 P1, in k_cqt_chroma's order
+                const float av = fabsf(c[k]);
+                if (normType == 1) red = fmaxf(red, av);
+                else if (normType == 2) red = fminf(red, av);
+                else if (normType == 3) red += av * av;
+                else red += av;
+            }
+            if (normType == 3) red = sqrtf(red);
+            if (red != 0.f) v = v / red;
+        }
+        po[it] = v;
+    }
+}
+
 }  // namespace
 
 
@@ -806,8 +899,8 @@ extern "C" int afxk_cqt_deconv(const float *in, long long rows, int num, int rad
 }
 
 extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
-                               const unsigned char *fold, int chromaNum, int isMag, int normType,
-                               float *out, void *stream) {
+                               const unsigned char *fold, const unsigned char *foldHost, int chromaNum, int isMag,
+                               int normType, float *out, void *stream) {
     if (rows <= 0) return AFX_OK;
     if (num > 255) return AFX_ERR_UNSUPPORTED;  // bin lists are bytes
     const size_t lds = sizeof(float) * ((size_t)CH_FRAMES * num + (size_t)CH_FRAMES * chromaNum + CH_FRAMES) +
@@ -817,6 +910,26 @@ extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows,
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int vec4 = (num % 4 == 0) && (reinterpret_cast<uintptr_t>(re) % 16 == 0) && (reinterpret_cast<uintptr_t>(im) % 16 == 0);
+    if (getenv("AFX_CQT_CHROMA_V2") && foldHost && chromaNum <= 64) {
+        // bin lists from the host copy of the 0/1 matrix (every bin belongs to at most one class: <= num entries)
+        ChromaLists L;
+        int n = 0;
+        for (int c = 0; c < chromaNum; ++c) {
+            L.start[c] = (unsigned short)n;
+            for (int j = 0; j < num && n < 256; ++j)
+                if (foldHost[(size_t)c * num + j]) L.bins[n++] = (unsigned char)j;
+        }
+        for (int c = chromaNum; c <= 64; ++c) L.start[c] = (unsigned short)n;
+        for (int q = n; q < 256; ++q) L.bins[q] = 0;
+        const size_t lds2 = sizeof(float) * ((size_t)CH_FRAMES * (num | 1) + (size_t)CH_FRAMES * chromaNum);
+        if (lds2 > 48 * 1024)
+            AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma_v2),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_cqt_chroma_v2, dim3((unsigned)((rows + CH_FRAMES - 1) / CH_FRAMES)), dim3(256), lds2,
+                           (hipStream_t)stream, re, im, rows, num, L, chromaNum, isMag, normType, out, vec4);
+        AFX_LAUNCH_CHECK("k_cqt_chroma_v2");
+        return AFX_OK;
+    }
     hipLaunchKernelGGL(k_cqt_chroma, dim3((unsigned)((rows + CH_FRAMES - 1) / CH_FRAMES)), dim3(256),
                        lds, (hipStream_t)stream, re, im, rows, num, fold, chromaNum, isMag, normType, out, vec4);
     AFX_LAUNCH_CHECK("k_cqt_chroma");

@@ -285,9 +285,11 @@ int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, i
 int afxk_cqt_deconv(const float *in, long long rows, int num, int radix2Exp, const float *twiddle,
                     const int *hcIdx, int hcNum, float *outTimbre, float *outPitch, float *outHc,
                     void *stream);
+/* fold: device 0/1 matrix [chromaNum][num]; foldHost: the same on the host (may be NULL; used by the
+ * AFX_CQT_CHROMA_V2 kernel, which takes the per-class bin lists as a kernel argument) */
 int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
-                    const unsigned char *fold, int chromaNum, int isMag, int normType, float *out,
-                    void *stream);
+                    const unsigned char *fold, const unsigned char *foldHost, int chromaNum, int isMag,
+                    int normType, float *out, void *stream);
 
 /* cepstrogram (afx_cepstrogram.hip): one clip, timeLength frames */
 typedef struct {

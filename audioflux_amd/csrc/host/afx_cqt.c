@@ -41,6 +41,7 @@ struct OpaqueCQT {
                               * its power-of-two scaled columns, in MFMA fragment order (afx_cqt_f16.hip) */
     float *dColMul;          /* [groups][32]: 2^-s_j undoing the column scaling */
     unsigned char *dFold;
+    unsigned char *hFold;    /* host copy of the 0/1 folding matrix (bin lists of the AFX_CQT_CHROMA_V2 kernel) */
     int foldChromaNum;
     float *dX;               /* staged input of the host-pointer calls */
     size_t capX;
@@ -674,7 +675,8 @@ static int chroma_prepare(CQTObj o, int *chromaNum, SpectralDataType *dataType,
         st = afxdev_malloc((void **)&o->dFold, (size_t)cn * o->num);
         if (st == AFX_OK) st = afxdev_h2d(o->dFold, fold, (size_t)cn * o->num, o->stream);
         if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
-        free(fold);
+        free(o->hFold);
+        o->hFold = fold;
         if (st == AFX_OK) o->foldChromaNum = cn;
     }
     int nrm = 0;
@@ -707,7 +709,7 @@ void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
     if (st == AFX_OK) st = afxdev_h2d(dRe, mRealArr, inB, o->stream);
     if (st == AFX_OK) st = afxdev_h2d(dIm, mImageArr, inB, o->stream);
     if (st == AFX_OK)
-        st = afxk_cqt_chroma(dRe, dIm, T, o->num, o->dFold, cn, isMag, nrm, dC, o->stream);
+        st = afxk_cqt_chroma(dRe, dIm, T, o->num, o->dFold, o->hFold, cn, isMag, nrm, dC, o->stream);
     if (st == AFX_OK) st = afxdev_d2h(mDataArr, dC, sizeof(float) * (size_t)T * cn, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) fail(o, st, "cqtObj_chroma");
@@ -725,7 +727,7 @@ int cqtObj_chromaBatchDevice(CQTObj o, int *chromaNum, SpectralDataType *dataTyp
     int cn, isMag, nrm;
     int st = chroma_prepare(o, chromaNum, dataType, normType, &cn, &isMag, &nrm);
     if (st == AFX_OK)
-        st = afxk_cqt_chroma(dReal, dImag, rows, o->num, o->dFold, cn, isMag, nrm, dData, hipStream);
+        st = afxk_cqt_chroma(dReal, dImag, rows, o->num, o->dFold, o->hFold, cn, isMag, nrm, dData, hipStream);
     if (st == AFX_OK) {
         o->lastStream = hipStream;
         o->lastUsed = 1;
@@ -756,7 +758,7 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
         float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;
         st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im, hipStream);
         if (st == AFX_OK)
-            st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, cn, isMag, nrm,
+            st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, o->hFold, cn, isMag, nrm,
                                  dChroma + (long long)b0 * T * cn, hipStream);
     }
     o->lastStream = hipStream;
@@ -880,6 +882,7 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dScaleOn);
     afxdev_free(o->dScaleOff);
     afxdev_free(o->dFold);
+    free(o->hFold);
     afxdev_free(o->dTimeKernel);
     afxdev_free(o->dTimeKernelH);
     afxdev_free(o->dColMul);
