@@ -277,8 +277,9 @@ class Cfg5:
     unit = "frames/s"
     default_clips = 125
     bytes_per_unit = 4 * 128 + 8 * 84 + 4 * 12  # hop 128 samples in, 84 complex + 12 chroma out
-    kernel = ("all launches of one step: 7 x k_cqt_octave_mfma_w (one per octave), 6 x k_cqt_decimate, "
-              "k_cqt_chroma")
+    kernel = ("all launches of one step, per pass of the clips: 7 x k_cqt_octave_f16 (one per octave), "
+              "6 x k_cqt_decimate, k_cqt_chroma")
+    dtype = "f32 (octave products: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ("chroma", "cqt")
 
     def __init__(self, torch, af, dev, rank, clips):
@@ -525,7 +526,7 @@ def main():
         out = {
             "metric": W.metric, "value": value, "unit": W.unit, "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": getattr(w, "dtype", "f32"), "data": "synthetic",
             "config": {"workload": w.workload, "clips_per_gpu": clips, "units_per_step_per_gpu": w.units,
                        "outputs": w.outputs, "parallelism": par, "clock_warmup_s": a.clock_warmup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
