@@ -1,0 +1,39 @@
+#!/bin/bash
+# First GPU call of a round: (1) the whole `pytest -m gpu` suite with the parity log, (2) the three bench lines,
+# (3) A/B of the candidates that were written without hardware access at the end of round 2 and ship switched off:
+#     AFX_CQT_CHROMA_V2=1 (k_cqt_chroma_v2: host-built bin lists, wave-uniform class walk) -- parity tests of the
+#     CQT first, then the cfg-5 step with and without it, and its kernel trace.
+# -> gpurun_out/round_start_<tag>/ ; every step under its own timeout.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round_start.sh r03'
+set -u
+TAG=${1:-r}
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/round_start_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+rm -f $OUT/parity.jsonl
+(time AFX_PARITY_LOG=$PWD/$OUT/parity.jsonl timeout 900 python -m pytest tests -q -m gpu -x) > $OUT/pytest.log 2>&1
+echo "pytest -m gpu rc=$? $(grep -aE '[0-9]+ passed|failed' $OUT/pytest.log | tail -n 1)" | tee $OUT/status.txt
+python tools/parity_table.py $OUT/parity.jsonl > $OUT/parity_table.md 2>&1
+for c in 2 5 4; do timeout 300 python bench.py --config $c > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; done
+# candidates
+(AFX_CQT_CHROMA_V2=1 timeout 400 python -m pytest tests/test_cqt_gpu.py tests/test_batch_gpu.py tests/dropin -q -m gpu -x) > $OUT/pytest_chroma_v2.log 2>&1
+echo "chroma v2 tests rc=$? $(grep -aE '[0-9]+ passed|failed' $OUT/pytest_chroma_v2.log | tail -n 1)" | tee -a $OUT/status.txt
+for v in 0 1; do
+  if [ $v = 1 ]; then export AFX_CQT_CHROMA_V2=1; else unset AFX_CQT_CHROMA_V2; fi
+  timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_chroma_v2_$v.json 2> $OUT/bench_cfg5_chroma_v2_$v.err
+  AFX_CQT_OVERLAP=0 timeout 200 bash tools/prof_cmd.sh rs_${TAG}_chroma$v "" python bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
+  cp gpurun_out/prof_rs_${TAG}_chroma$v/summary.txt $OUT/trace_cfg5_chroma_v2_$v.txt 2>/dev/null
+done
+unset AFX_CQT_CHROMA_V2
+cat $OUT/status.txt
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$OUT/bench_cfg*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], "value %.4g %s ms/step %.4f frac %.4f" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"]))
+    except Exception as e:
+        print(f.split("/")[-1], "no line:", e)
+PY
+grep -h "k_cqt_chroma" $OUT/trace_cfg5_chroma_v2_*.txt | cut -c1-120
