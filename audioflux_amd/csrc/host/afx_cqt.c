@@ -556,16 +556,21 @@ void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float
 /* Clips per pass of the octave ladder.  Every octave kernel writes its 12 of the num columns of each output
  * row (48-byte pieces of 336-byte rows), so a row is completed by seven launches; when the pass's output
  * (2 planes x clips x T x num floats) stays within reach of the memory-side cache those pieces merge before
- * they reach HBM, beyond it the partial-line writes throttle the store path (measured on cfg 5: 125 clips in one
- * pass = 868 MB, octave kernels 1.3-2x slower per clip than at 64 clips).  Default: passes of <= 384 MB of output;
- * AFX_CQT_CHUNK=<clips> overrides. */
-static int cqt_chunk_clips(CQTObj o, int T) {
+ * they reach HBM, beyond it the partial-line writes throttle the store path (measured on cfg 5, 125 clips:
+ * one pass of 868 MB 2.07 ms per step, passes of 64 / 50 / 42 / 32 / 16 clips 1.86 / 1.93 / 1.98 / 2.06 / 2.40 ms,
+ * profiles/r02_cqt_f16_steps.txt).  Default: the fewest passes of <= 448 MB of output each, of equal size
+ * (125 clips of cfg 5 -> 63 + 62); AFX_CQT_CHUNK=<clips> overrides. */
+static int cqt_chunk_clips(CQTObj o, int T, int batch) {
     const char *e = getenv("AFX_CQT_CHUNK");
     if (e && atoi(e) > 0) return atoi(e) > 32768 ? 32768 : atoi(e);
     const double perClip = 8.0 * (double)T * o->num;
-    long long c = (long long)(384.0 * 1024 * 1024 / (perClip > 0 ? perClip : 1));
+    long long c = (long long)(448.0 * 1024 * 1024 / (perClip > 0 ? perClip : 1));
     if (c < 8) c = 8;
     if (c > 32768) c = 32768;
+    if (batch > c) { /* equal passes instead of full ones and a small remainder */
+        const long long passes = (batch + c - 1) / c;
+        c = (batch + passes - 1) / passes;
+    }
     return (int)c;
 }
 
@@ -581,7 +586,7 @@ int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLengt
     const int T = dataLength / o->slideLength + 1;
     /* scratch is shared between calls: order this call after the previous one's stream */
     if (o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
-    const int chunk = cqt_chunk_clips(o, T);
+    const int chunk = cqt_chunk_clips(o, T, batch);
     for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride,
@@ -752,7 +757,7 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
     if (st == AFX_ERR_ARG) return st;
     const int T = dataLength / o->slideLength + 1;
     if (st == AFX_OK && o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
-    const int chunk = cqt_chunk_clips(o, T);
+    const int chunk = cqt_chunk_clips(o, T, batch);
     for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;

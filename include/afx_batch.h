@@ -111,7 +111,7 @@ int cqtObj_chromaBatchDevice(CQTObj cqtObj, int *chromaNum, SpectralDataType *da
                              const float *dImag, long long rows, float *dData, void *hipStream);
 
 /* cqtObj_cqtBatchDevice followed by cqtObj_chromaBatchDevice on its output, as one call: the clips go through
- * the octave ladder in passes (AFX_CQT_CHUNK clips, default <= 384 MB of output) and each pass's chroma is taken
+ * the octave ladder in passes (AFX_CQT_CHUNK clips; default: the fewest equal passes of <= 448 MB of output) and each pass's chroma is taken
  * while its CQT rows are still cached.  dChroma [batch][T, chromaNum]; results identical to the two calls. */
 int cqtObj_cqtChromaBatchDevice(CQTObj cqtObj, const float *dData, int batch, int dataLength, long long clipStride,
                                 float *dReal, float *dImag, int *chromaNum, SpectralDataType *dataType,
