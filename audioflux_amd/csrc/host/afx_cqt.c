@@ -560,10 +560,10 @@ void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float
  * one pass of 868 MB 2.07 ms per step, passes of 64 / 50 / 42 / 32 / 16 clips 1.86 / 1.93 / 1.98 / 2.06 / 2.40 ms,
  * profiles/r02_cqt_f16_steps.txt).  Default: the fewest passes of <= 448 MB of output each, of equal size
  * (125 clips of cfg 5 -> 63 + 62); AFX_CQT_CHUNK=<clips> overrides. */
-static int cqt_chunk_clips(CQTObj o, int T, int batch) {
+int afx_cqt_pass_clips(long long rowFloats, int batch) {
     const char *e = getenv("AFX_CQT_CHUNK");
     if (e && atoi(e) > 0) return atoi(e) > 32768 ? 32768 : atoi(e);
-    const double perClip = 8.0 * (double)T * o->num;
+    const double perClip = 8.0 * (double)rowFloats;
     long long c = (long long)(448.0 * 1024 * 1024 / (perClip > 0 ? perClip : 1));
     if (c < 8) c = 8;
     if (c > 32768) c = 32768;
@@ -573,6 +573,8 @@ static int cqt_chunk_clips(CQTObj o, int T, int batch) {
     }
     return (int)c;
 }
+
+static int cqt_chunk_clips(CQTObj o, int T, int batch) { return afx_cqt_pass_clips((long long)T * o->num, batch); }
 
 /* clips already in HBM, results left in HBM (include/afx_batch.h) */
 int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLength,

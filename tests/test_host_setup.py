@@ -113,3 +113,29 @@ def test_cqt_f16_fragment_words_match_numpy():
         # hi + lo carries the float32 value to 2^-21 of itself (2^-25 absolute in the subnormal range)
         err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - v)
         assert np.all(err <= np.maximum(np.abs(v) * 2.0 ** -21, 2.0 ** -25))
+
+
+def test_cqt_pass_sizes(monkeypatch):
+    """afx_cqt_pass_clips: the fewest equal passes of <= 448 MB of output; AFX_CQT_CHUNK overrides"""
+    import ctypes
+
+    from audioflux_amd import _lib
+    fn = _lib.get_lib().afx_cqt_pass_clips
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_longlong, ctypes.c_int]
+    monkeypatch.delenv("AFX_CQT_CHUNK", raising=False)
+    row = 10336 * 84                       # BASELINE cfg 5: 30 s @ 44.1 kHz, 84 bins
+    cap = int(448 * 1024 * 1024 / (8.0 * row))
+    assert cap == 67
+    assert fn(row, 125) == 63              # two passes, 63 + 62
+    assert fn(row, 67) == 67 and fn(row, 68) == 34 and fn(row, 1) == 67
+    assert fn(row, 1000) == 67             # 15 passes of <= 67
+    for batch in (1, 7, 67, 68, 125, 134, 135, 1000, 32768):
+        c = fn(row, batch)
+        passes = -(-batch // c)
+        assert c <= cap and passes == -(-batch // cap)   # as few passes as the cap allows ...
+        if batch > cap:
+            assert passes * c - batch < passes            # ... of equal size: short by less than one clip per pass
+    assert fn(10, 5) >= 5                                # tiny rows: one pass
+    monkeypatch.setenv("AFX_CQT_CHUNK", "3")
+    assert fn(row, 125) == 3
