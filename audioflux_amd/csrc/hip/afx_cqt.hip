@@ -646,13 +646,8 @@ __global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re
 // argument; a thread owns (frame = tid & 63, classes wave, wave + 4, ...), so the class -- and with it the list
 // walked -- is uniform per wave (scalar loads of the kernel argument), and the |Q|^2 rows sit in LDS at an odd
 // pitch so that the 64 frames of a read fall on distinct banks.  Same sums in the same (ascending bin) order.
-struct ChromaLists {
-    unsigned short start[65];   // class c owns bins[start[c] .. start[c + 1])
-    unsigned char bins[256];
-};
-
 __global__ __launch_bounds__(256) void k_cqt_chroma_v2(const float *__restrict__ re, const float *__restrict__ im,
-                                                       long long rows, int num, ChromaLists L, int chromaNum,
+                                                       long long rows, int num, AfxChromaLists L, int chromaNum,
                                                        int isMag, int normType, float *__restrict__ out, int vec4) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int pitch = num | 1;                                // odd: frames of one bin on distinct banks
@@ -899,7 +894,7 @@ extern "C" int afxk_cqt_deconv(const float *in, long long rows, int num, int rad
 }
 
 extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
-                               const unsigned char *fold, const unsigned char *foldHost, int chromaNum, int isMag,
+                               const unsigned char *fold, const AfxChromaLists *lists, int chromaNum, int isMag,
                                int normType, float *out, void *stream) {
     if (rows <= 0) return AFX_OK;
     if (num > 255) return AFX_ERR_UNSUPPORTED;  // bin lists are bytes
@@ -910,17 +905,8 @@ extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows,
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int vec4 = (num % 4 == 0) && (reinterpret_cast<uintptr_t>(re) % 16 == 0) && (reinterpret_cast<uintptr_t>(im) % 16 == 0);
-    if (getenv("AFX_CQT_CHROMA_V2") && foldHost && chromaNum <= 64) {
-        // bin lists from the host copy of the 0/1 matrix (every bin belongs to at most one class: <= num entries)
-        ChromaLists L;
-        int n = 0;
-        for (int c = 0; c < chromaNum; ++c) {
-            L.start[c] = (unsigned short)n;
-            for (int j = 0; j < num && n < 256; ++j)
-                if (foldHost[(size_t)c * num + j]) L.bins[n++] = (unsigned char)j;
-        }
-        for (int c = chromaNum; c <= 64; ++c) L.start[c] = (unsigned short)n;
-        for (int q = n; q < 256; ++q) L.bins[q] = 0;
+    if (getenv("AFX_CQT_CHROMA_V2") && lists && chromaNum <= 64) {
+        const AfxChromaLists L = *lists;
         const size_t lds2 = sizeof(float) * ((size_t)CH_FRAMES * (num | 1) + (size_t)CH_FRAMES * chromaNum);
         if (lds2 > 48 * 1024)
             AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma_v2),

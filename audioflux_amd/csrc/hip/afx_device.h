@@ -285,10 +285,16 @@ int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, i
 int afxk_cqt_deconv(const float *in, long long rows, int num, int radix2Exp, const float *twiddle,
                     const int *hcIdx, int hcNum, float *outTimbre, float *outPitch, float *outHc,
                     void *stream);
-/* fold: device 0/1 matrix [chromaNum][num]; foldHost: the same on the host (may be NULL; used by the
- * AFX_CQT_CHROMA_V2 kernel, which takes the per-class bin lists as a kernel argument) */
+/* the 0/1 folding matrix as per-class bin lists: class c owns bins[start[c] .. start[c+1]) in ascending order
+ * (the order of the matrix product); chromaNum <= 64, num <= 255 (afx_cqt.c: afx_chroma_lists) */
+typedef struct AfxChromaLists_ {
+    unsigned short start[65];
+    unsigned char bins[256];
+} AfxChromaLists;
+/* fold: device 0/1 matrix [chromaNum][num]; lists: the same as bin lists (host struct, may be NULL; used by the
+ * AFX_CQT_CHROMA_V2 kernel, which takes it as a kernel argument) */
 int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
-                    const unsigned char *fold, const unsigned char *foldHost, int chromaNum, int isMag,
+                    const unsigned char *fold, const AfxChromaLists *lists, int chromaNum, int isMag,
                     int normType, float *out, void *stream);
 
 /* cepstrogram (afx_cepstrogram.hip): one clip, timeLength frames */

@@ -41,7 +41,8 @@ struct OpaqueCQT {
                               * its power-of-two scaled columns, in MFMA fragment order (afx_cqt_f16.hip) */
     float *dColMul;          /* [groups][32]: 2^-s_j undoing the column scaling */
     unsigned char *dFold;
-    unsigned char *hFold;    /* host copy of the 0/1 folding matrix (bin lists of the AFX_CQT_CHROMA_V2 kernel) */
+    AfxChromaLists foldLists; /* the folding matrix as per-class bin lists (AFX_CQT_CHROMA_V2 kernel) */
+    int haveLists;
     int foldChromaNum;
     float *dX;               /* staged input of the host-pointer calls */
     size_t capX;
@@ -660,6 +661,24 @@ unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre) {
     return tmp;
 }
 
+/* 0/1 folding matrix -> per-class bin lists (ascending bins: the order of the matrix product); -1 when the
+ * matrix does not fit the list form (more than 64 classes, more than 256 entries) */
+int afx_chroma_lists(const unsigned char *fold, int chromaNum, int num, AfxChromaLists *out) {
+    if (!fold || !out || chromaNum < 1 || chromaNum > 64 || num < 1 || num > 255) return -1;
+    int n = 0;
+    memset(out, 0, sizeof(*out));
+    for (int c = 0; c < chromaNum; c++) {
+        out->start[c] = (unsigned short)n;
+        for (int j = 0; j < num; j++) {
+            if (!fold[(size_t)c * num + j]) continue;
+            if (n >= 256) return -1;
+            out->bins[n++] = (unsigned char)j;
+        }
+    }
+    for (int c = chromaNum; c <= 64; c++) out->start[c] = (unsigned short)n;
+    return 0;
+}
+
 /* resolve the optional chroma parameters; upload the folding matrix when chromaNum changed */
 static int chroma_prepare(CQTObj o, int *chromaNum, SpectralDataType *dataType,
                           ChromaDataNormalType *normType, int *cnOut, int *isMag, int *nrmOut) {
@@ -682,8 +701,8 @@ static int chroma_prepare(CQTObj o, int *chromaNum, SpectralDataType *dataType,
         st = afxdev_malloc((void **)&o->dFold, (size_t)cn * o->num);
         if (st == AFX_OK) st = afxdev_h2d(o->dFold, fold, (size_t)cn * o->num, o->stream);
         if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
-        free(o->hFold);
-        o->hFold = fold;
+        o->haveLists = fold && afx_chroma_lists(fold, cn, o->num, &o->foldLists) == 0;
+        free(fold);
         if (st == AFX_OK) o->foldChromaNum = cn;
     }
     int nrm = 0;
@@ -716,7 +735,7 @@ void cqtObj_chroma(CQTObj o, int *chromaNum, SpectralDataType *dataType,
     if (st == AFX_OK) st = afxdev_h2d(dRe, mRealArr, inB, o->stream);
     if (st == AFX_OK) st = afxdev_h2d(dIm, mImageArr, inB, o->stream);
     if (st == AFX_OK)
-        st = afxk_cqt_chroma(dRe, dIm, T, o->num, o->dFold, o->hFold, cn, isMag, nrm, dC, o->stream);
+        st = afxk_cqt_chroma(dRe, dIm, T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag, nrm, dC, o->stream);
     if (st == AFX_OK) st = afxdev_d2h(mDataArr, dC, sizeof(float) * (size_t)T * cn, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) fail(o, st, "cqtObj_chroma");
@@ -734,7 +753,7 @@ int cqtObj_chromaBatchDevice(CQTObj o, int *chromaNum, SpectralDataType *dataTyp
     int cn, isMag, nrm;
     int st = chroma_prepare(o, chromaNum, dataType, normType, &cn, &isMag, &nrm);
     if (st == AFX_OK)
-        st = afxk_cqt_chroma(dReal, dImag, rows, o->num, o->dFold, o->hFold, cn, isMag, nrm, dData, hipStream);
+        st = afxk_cqt_chroma(dReal, dImag, rows, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag, nrm, dData, hipStream);
     if (st == AFX_OK) {
         o->lastStream = hipStream;
         o->lastUsed = 1;
@@ -765,7 +784,7 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
         float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;
         st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im, hipStream);
         if (st == AFX_OK)
-            st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, o->hFold, cn, isMag, nrm,
+            st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag, nrm,
                                  dChroma + (long long)b0 * T * cn, hipStream);
     }
     o->lastStream = hipStream;
@@ -889,7 +908,6 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dScaleOn);
     afxdev_free(o->dScaleOff);
     afxdev_free(o->dFold);
-    free(o->hFold);
     afxdev_free(o->dTimeKernel);
     afxdev_free(o->dTimeKernelH);
     afxdev_free(o->dColMul);

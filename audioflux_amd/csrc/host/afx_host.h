@@ -62,6 +62,9 @@ unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre);
  * of v_mfma_f32_32x32x16_f16: out[word][N/16 steps][64 lanes][8], lane l = 32 g + j holds rows
  * 16 ks + 8 g + e of column j; colMul[32] = 2^-s_j (afx_cqt_f16.hip) */
 void afx_cqt_time_kernel_f16(const float *G, int N, unsigned short *out, float *colMul);
+/* afx_cqt.c: 0/1 folding matrix -> per-class bin lists (afx_device.h: AfxChromaLists); 0 on success */
+struct AfxChromaLists_;
+int afx_chroma_lists(const unsigned char *fold, int chromaNum, int num, struct AfxChromaLists_ *out);
 /* afx_cqt.c: clips per pass of the batched CQT calls for clips of rowFloats = T * num output floats per plane:
  * the fewest equal passes of <= 448 MB of output (AFX_CQT_CHUNK=<clips> overrides) */
 int afx_cqt_pass_clips(long long rowFloats, int batch);

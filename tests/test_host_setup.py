@@ -139,3 +139,36 @@ def test_cqt_pass_sizes(monkeypatch):
     assert fn(10, 5) >= 5                                # tiny rows: one pass
     monkeypatch.setenv("AFX_CQT_CHUNK", "3")
     assert fn(row, 125) == 3
+
+
+def test_chroma_lists_equal_the_folding_matrix():
+    """afx_chroma_lists (argument of the switched-off k_cqt_chroma_v2): per-class ascending bin lists of the 0/1 matrix
+    of afx_chroma_fold -- summing a row's bins in list order is the matrix product"""
+    import ctypes
+
+    from audioflux_amd import _lib
+    lib = _lib.get_lib()
+
+    class Lists(ctypes.Structure):
+        _fields_ = [("start", ctypes.c_ushort * 65), ("bins", ctypes.c_ubyte * 256)]
+    fold_fn = lib.afx_chroma_fold
+    fold_fn.restype = ctypes.POINTER(ctypes.c_ubyte)
+    fold_fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+    lists_fn = lib.afx_chroma_lists
+    lists_fn.restype = ctypes.c_int
+    lists_fn.argtypes = [ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int, ctypes.c_int, ctypes.POINTER(Lists)]
+    rng = np.random.default_rng(3)
+    for cn, num, bpo, fmin in ((12, 84, 12, 32.703), (6, 84, 12, 32.703), (12, 48, 12, 65.4), (24, 168, 24, 27.5), (12, 84, 12, 55.0)):
+        fp = fold_fn(cn, num, bpo, fmin)
+        fold = np.ctypeslib.as_array(fp, shape=(cn * num,)).reshape(cn, num).copy()
+        L = Lists()
+        assert lists_fn(fp, cn, num, ctypes.byref(L)) == 0
+        start, bins = np.array(L.start[:]), np.array(L.bins[:])
+        assert start[0] == 0 and np.all(np.diff(start[:cn + 1]) >= 0) and np.all(start[cn:] == start[cn])
+        assert start[cn] == fold.sum()
+        p = rng.standard_normal(num).astype(np.float32)
+        for c in range(cn):
+            mine = bins[start[c]:start[c + 1]]
+            assert np.array_equal(mine, np.flatnonzero(fold[c])), (cn, num, c)
+            assert np.isclose(p[mine].sum(), (fold[c] * p).sum())
+    assert lists_fn(fp, 65, 84, ctypes.byref(L)) == -1 and lists_fn(None, 12, 84, ctypes.byref(L)) == -1
