@@ -13,12 +13,19 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 rm -f $OUT/parity.jsonl
 (time AFX_PARITY_LOG=$PWD/$OUT/parity.jsonl timeout 900 python -m pytest tests -q -m gpu -x) > $OUT/pytest.log 2>&1
-echo "pytest -m gpu rc=$? $(grep -aE '[0-9]+ passed|failed' $OUT/pytest.log | tail -n 1)" | tee $OUT/status.txt
+RC=$?
+echo "pytest -m gpu rc=$RC $(grep -aE '[0-9]+ passed|failed' $OUT/pytest.log | tail -n 1)" | tee $OUT/status.txt
+if [ $RC -ne 0 ]; then  # a failure or a hang in the shipped kernels: do not spend GPU time on anything else
+  tail -n 40 $OUT/pytest.log
+  exit 1
+fi
 python tools/parity_table.py $OUT/parity.jsonl > $OUT/parity_table.md 2>&1
 for c in 2 5 4; do timeout 300 python bench.py --config $c > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; done
 # candidates
-(AFX_CQT_CHROMA_V2=1 timeout 400 python -m pytest tests/test_cqt_gpu.py tests/test_batch_gpu.py tests/dropin -q -m gpu -x) > $OUT/pytest_chroma_v2.log 2>&1
-echo "chroma v2 tests rc=$? $(grep -aE '[0-9]+ passed|failed' $OUT/pytest_chroma_v2.log | tail -n 1)" | tee -a $OUT/status.txt
+(AFX_CQT_CHROMA_V2=1 timeout 300 python -m pytest tests/test_cqt_gpu.py tests/test_batch_gpu.py tests/dropin -q -m gpu -x) > $OUT/pytest_chroma_v2.log 2>&1
+RC=$?
+echo "chroma v2 tests rc=$RC $(grep -aE '[0-9]+ passed|failed' $OUT/pytest_chroma_v2.log | tail -n 1)" | tee -a $OUT/status.txt
+if [ $RC -ne 0 ]; then tail -n 30 $OUT/pytest_chroma_v2.log; cat $OUT/status.txt; exit 0; fi
 for v in 0 1; do
   if [ $v = 1 ]; then export AFX_CQT_CHROMA_V2=1; else unset AFX_CQT_CHROMA_V2; fi
   timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_chroma_v2_$v.json 2> $OUT/bench_cfg5_chroma_v2_$v.err
