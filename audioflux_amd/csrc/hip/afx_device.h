@@ -275,6 +275,25 @@ typedef struct {
 int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
 /* f16 matrix-core variant; AFX_ERR_UNSUPPORTED when the plan / alignment is outside its scope */
 int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream);
+/* all seven octaves of the default plan (+ chroma) in one launch (afx_cqt_all.hip; AFX_CQT_FUSED=1, off by
+ * default): level l = the signal decimated l times, hop 128 >> l, octave 6 - l */
+typedef struct {
+    const float *x[7];        /* device: signal of level l                                   */
+    long long xStride[7];     /* samples between consecutive clips of level l                */
+    int validLength[7];       /* samples framed at level l                                   */
+    float octScale[7];        /* sqrt(2^l)                                                   */
+    const unsigned short *imageH; /* the shared f16 (hi, lo) image, fragment order           */
+    const float *colMul;      /* [32] 2^-s_j of its columns                                  */
+    const float *scale;       /* [num] sqrt(len_j) or ones                                   */
+    int num, timeLength, batch;
+    long long outStride;
+    float *outRe, *outIm;     /* [batch][T, num]                                             */
+    float *chroma;            /* [batch][T, 12] or NULL                                      */
+    long long chromaStride;
+    int isMag, normType;
+    unsigned char cls[84];    /* chroma class of every bin (with chroma != NULL)             */
+} AfxCqtAllArgs;
+int afxk_cqt_all_f16(const AfxCqtAllArgs *a, void *stream);
 /* batch clips: x + b*xStride -> y + b*yStride */
 int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, int dstLen,
                       long long yStride, int batch, const float *taps32, float sqrtRatio,

@@ -436,11 +436,82 @@ void cqtObj_setScale(CQTObj o, int flag) {
 /* The octave recursion on HBM-resident clips: dX + b*xStride (b < batch, dataLength
  * samples each) -> dRe/dIm [batch][T, num].  dSig[0/1] hold the decimated signals of all
  * clips (pitch = dataLength/2 samples).  Asynchronous on `stream`. */
+/* AFX_CQT_FUSED=1 (off by default; written without hardware access at the end of round 2):
+ * the six decimations first, then ONE launch for the seven octave products (+ the chroma when dChroma != NULL and
+ * lists gives every bin exactly one of 12 classes).  AFX_ERR_UNSUPPORTED: the caller takes the per-octave path. */
+static int cqt_run_device_fused(CQTObj o, const float *dX, int batch, int dataLength, long long xStride,
+                                float *dRe, float *dIm, float *dChroma, int cn, int isMag, int nrm, void *stream) {
+    if (!getenv("AFX_CQT_FUSED") || o->octaveNum != 7 || o->binPerOctave != 12 || o->num != 84 || o->vFlag ||
+        o->fftLength != 512 || o->slideLength != 128 || !o->dTimeKernelH || !o->dColMul)
+        return AFX_ERR_UNSUPPORTED;
+    AfxCqtAllArgs a;
+    memset(&a, 0, sizeof(a));
+    if (dChroma) {
+        if (cn != 12 || !o->haveLists) return AFX_ERR_UNSUPPORTED;
+        memset(a.cls, 255, sizeof(a.cls));
+        for (int c = 0; c < 12; c++)
+            for (int q = o->foldLists.start[c]; q < o->foldLists.start[c + 1]; q++) {
+                const int j = o->foldLists.bins[q];
+                if (j >= 84 || a.cls[j] != 255) return AFX_ERR_UNSUPPORTED; /* a bin in two classes */
+                a.cls[j] = (unsigned char)c;
+            }
+        for (int j = 0; j < 84; j++)
+            if (a.cls[j] == 255) return AFX_ERR_UNSUPPORTED; /* a bin in no class: not a partition */
+    }
+    const int T = dataLength / o->slideLength + 1;
+    const long long pitch = ((long long)dataLength / 2 + 3) & ~3LL;
+    size_t total = 0;
+    long long p = pitch;
+    for (int k = 1; k < 7; k++) {
+        total += (size_t)p * batch;
+        p = ((p / 2) + 3) & ~3LL;
+    }
+    int st = afxdev_reserve((void **)&o->dSig[0], &o->capSig[0], sizeof(float) * total);
+    const float *cur = dX;
+    long long curStride = xStride, levelPitch = pitch;
+    size_t levelOff = 0;
+    int len = dataLength, hop = o->slideLength;
+    for (int l = 0; l < 7 && st == AFX_OK; l++) {
+        const int frames = len / hop + 1;
+        a.x[l] = cur;
+        a.xStride[l] = curStride;
+        a.validLength[l] = len - (frames > 1 ? len % hop : 0); /* stft_algorithm.c:838-843 */
+        a.octScale[l] = l == 0 ? 1.f : sqrtf((float)(1 << l));
+        if (l == 6) break;
+        const int next = (int)floorf(len * 0.5f);
+        float *dNext = o->dSig[0] + levelOff;
+        st = afxk_cqt_decimate(cur, len, curStride, dNext, next, levelPitch, batch, o->taps, sqrtf(0.5f), stream);
+        cur = dNext;
+        curStride = levelPitch;
+        levelOff += (size_t)levelPitch * batch;
+        levelPitch = ((levelPitch / 2) + 3) & ~3LL;
+        len = next;
+        hop /= 2;
+    }
+    if (st != AFX_OK) return st;
+    a.imageH = o->dTimeKernelH;
+    a.colMul = o->dColMul;
+    a.scale = o->isScale ? o->dScaleOn : o->dScaleOff;
+    a.num = o->num;
+    a.timeLength = T;
+    a.batch = batch;
+    a.outStride = (long long)T * o->num;
+    a.outRe = dRe;
+    a.outIm = dIm;
+    a.chroma = dChroma;
+    a.chromaStride = (long long)T * 12;
+    a.isMag = isMag;
+    a.normType = nrm;
+    return afxk_cqt_all_f16(&a, stream);
+}
+
 static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, long long xStride,
                           float *dRe, float *dIm, void *stream) {
     const int T = dataLength / o->slideLength + 1;
     const long long pitch = ((long long)dataLength / 2 + 3) & ~3LL;
-    int st = AFX_OK;
+    int st = cqt_run_device_fused(o, dX, batch, dataLength, xStride, dRe, dIm, NULL, 0, 0, 0, stream);
+    if (st != AFX_ERR_UNSUPPORTED) return st;
+    st = AFX_OK;
     /* The decimation chain (signal of octave k from octave k+1: memory / latency bound) does not depend on
      * the octave products (matrix-core bound): it runs ahead on a side stream, every level in its own
      * slice of dSig[0] (pitch, pitch/2, ... samples per clip: < 2 pitch in all), and the octave kernel of a
@@ -782,6 +853,9 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
     for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;
+        st = cqt_run_device_fused(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im,
+                                  dChroma + (long long)b0 * T * cn, cn, isMag, nrm, hipStream);
+        if (st != AFX_ERR_UNSUPPORTED) continue; /* one launch did both (or failed) */
         st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im, hipStream);
         if (st == AFX_OK)
             st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag, nrm,
