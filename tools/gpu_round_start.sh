@@ -2,7 +2,8 @@
 # First GPU call of a round: (1) the whole `pytest -m gpu` suite with the parity log, (2) the three bench lines,
 # (3) A/B of the candidates that were written without hardware access at the end of round 2 and ship switched off:
 #     AFX_CQT_CHROMA_V2=1 (k_cqt_chroma_v2: host-built bin lists, wave-uniform class walk) -- parity tests of the
-#     CQT first, then the cfg-5 step with and without it, and its kernel trace.
+#     CQT first, then the cfg-5 step with and without it, and its kernel trace; AFX_CQT_FUSED=1 (k_cqt_all_f16:
+#     seven octaves + chroma in one launch) the same way.
 # -> gpurun_out/round_start_<tag>/ ; every step under its own timeout.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round_start.sh r03'
 set -u
@@ -33,6 +34,23 @@ for v in 0 1; do
   cp gpurun_out/prof_rs_${TAG}_chroma$v/summary.txt $OUT/trace_cfg5_chroma_v2_$v.txt 2>/dev/null
 done
 unset AFX_CQT_CHROMA_V2
+# AFX_CQT_FUSED=1 (k_cqt_all_f16: seven octaves + chroma in one launch): smallest parity test first, short timeout
+(AFX_CQT_FUSED=1 timeout 120 python -m pytest tests/test_cqt_gpu.py -q -m gpu -x) > $OUT/pytest_fused.log 2>&1
+RC=$?
+echo "fused tests (cqt) rc=$RC $(grep -aE '[0-9]+ passed|failed' $OUT/pytest_fused.log | tail -n 1)" | tee -a $OUT/status.txt
+if [ $RC -eq 0 ]; then
+  (AFX_CQT_FUSED=1 timeout 300 python -m pytest tests/test_batch_gpu.py tests/dropin -q -m gpu -x) >> $OUT/pytest_fused.log 2>&1
+  RC=$?
+  echo "fused tests (batch, dropin) rc=$RC $(grep -aE '[0-9]+ passed|failed' $OUT/pytest_fused.log | tail -n 1)" | tee -a $OUT/status.txt
+fi
+if [ $RC -eq 0 ]; then
+  AFX_CQT_FUSED=1 timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_fused.json 2> $OUT/bench_cfg5_fused.err
+  AFX_CQT_FUSED=1 AFX_CQT_CHUNK=125 timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_fused_onepass.json 2> $OUT/bench_cfg5_fused_onepass.err
+  AFX_CQT_FUSED=1 timeout 200 bash tools/prof_cmd.sh rs_${TAG}_fused "" python bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
+  cp gpurun_out/prof_rs_${TAG}_fused/summary.txt $OUT/trace_cfg5_fused.txt 2>/dev/null
+else
+  tail -n 30 $OUT/pytest_fused.log
+fi
 cat $OUT/status.txt
 python - <<PY
 import json, glob
