@@ -172,3 +172,26 @@ def test_chroma_lists_equal_the_folding_matrix():
             assert np.array_equal(mine, np.flatnonzero(fold[c])), (cn, num, c)
             assert np.isclose(p[mine].sum(), (fold[c] * p).sum())
     assert lists_fn(fp, 65, 84, ctypes.byref(L)) == -1 and lists_fn(None, 12, 84, ctypes.byref(L)) == -1
+    # the switched-off all-octave kernel adds |Q|^2 to a per-frame accumulator octave by octave, bin by bin (class
+    # of bin j from these lists): for a partition into 12 classes that is k_cqt_chroma's float32 summation order
+    fp = fold_fn(12, 84, 12, 32.703)
+    assert lists_fn(fp, 12, 84, ctypes.byref(L)) == 0
+    start, bins = np.array(L.start[:]), np.array(L.bins[:])
+    cls = np.full(84, 255)
+    for c in range(12):
+        for q in range(start[c], start[c + 1]):
+            assert cls[bins[q]] == 255
+            cls[bins[q]] = c
+    assert np.all(cls < 12)
+    pw = (rng.standard_normal(84).astype(np.float32)) ** 2
+    per_class = np.zeros(12, np.float32)
+    for c in range(12):
+        v = np.float32(0)
+        for q in range(start[c], start[c + 1]):
+            v = np.float32(v + pw[bins[q]])
+        per_class[c] = v
+    acc = np.zeros(12, np.float32)
+    for octave in range(7):
+        for j in range(12):
+            acc[cls[12 * octave + j]] = np.float32(acc[cls[12 * octave + j]] + pw[12 * octave + j])
+    assert np.array_equal(acc, per_class)
