@@ -46,6 +46,15 @@ fi
 if [ $RC -eq 0 ]; then
   AFX_CQT_FUSED=1 timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_fused.json 2> $OUT/bench_cfg5_fused.err
   AFX_CQT_FUSED=1 AFX_CQT_CHUNK=125 timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_fused_onepass.json 2> $OUT/bench_cfg5_fused_onepass.err
+  # decimations of pass p + 1 on the side stream under the launch of pass p: its own parity run first
+  (AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2 timeout 200 python -m pytest tests/test_batch_gpu.py -q -m gpu -x -k cqt) > $OUT/pytest_fused2.log 2>&1
+  RC2=$?
+  echo "fused mode 2 tests rc=$RC2 $(grep -aE '[0-9]+ passed|failed' $OUT/pytest_fused2.log | tail -n 1)" | tee -a $OUT/status.txt
+  if [ $RC2 -eq 0 ]; then
+    for ch in 63 32 16; do
+      AFX_CQT_FUSED=2 AFX_CQT_CHUNK=$ch timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_fused2_chunk$ch.json 2> $OUT/bench_cfg5_fused2_chunk$ch.err
+    done
+  fi
   AFX_CQT_FUSED=1 timeout 200 bash tools/prof_cmd.sh rs_${TAG}_fused "" python bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
   cp gpurun_out/prof_rs_${TAG}_fused/summary.txt $OUT/trace_cfg5_fused.txt 2>/dev/null
 else
