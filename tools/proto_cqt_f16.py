@@ -201,6 +201,13 @@ def check_epilogue():
             assert off == frame * rows_bytes + 3 * piece * 4
             seen.add((frame, plane, piece))
     assert len(seen) == 32 * 2 * 4
+    # k_cqt_all_f16 (afx_cqt_all.hip): lane f < 32 takes frame f's 12 (re, im) pairs from the same image for the
+    # chroma accumulator: four 16-byte reads per plane at f 128 + 16 p (re) and f 128 + 64 + 16 p (im)
+    for f in range(32):
+        for p in range(4):
+            re = lds[(f * 128 + 16 * p) // 4: (f * 128 + 16 * p) // 4 + 3]
+            im = lds[(f * 128 + 64 + 16 * p) // 4: (f * 128 + 64 + 16 * p) // 4 + 3]
+            assert np.array_equal(re, D[f, 3 * p: 3 * p + 3]) and np.array_equal(im, D[f, 12 + 3 * p: 12 + 3 * p + 3])
 
 
 def check_decimator():
