@@ -43,11 +43,21 @@ def parity_log(what, measured, bar, kind="peak/l2", extra=None):
         f.write(json.dumps(rec) + "\n")
 
 
+# AFX_HOSTSTUB=1 (tests/test_hoststub.py): the suite runs against the sanitizer build of the host objects with a
+# stand-in device layer -- results are meaningless there, only the host code paths matter
+HOSTSTUB = os.environ.get("AFX_HOSTSTUB") == "1"
+if HOSTSTUB:
+    sys.modules["torch"] = None  # no device: tests that need torch tensors end with ImportError (and torch does not
+    #                              survive an LD_PRELOADed sanitizer runtime)
+
+
 def assert_parity(got, want, tol=1e-5, what=""):
     """north_star tolerance: 1e-5 relative, taken peak-relative and L2-relative
     per output tensor (element-wise relative error is meaningless at near-empty
     bins: the reference itself is 1e-4 off float64 there)"""
     assert np.shape(got) == np.shape(want), f"{what}: shape {np.shape(got)} vs {np.shape(want)}"
+    if HOSTSTUB:
+        return
     assert np.all(np.isfinite(got)), f"{what}: non-finite values"
     p, l = peak_rel(got, want), l2_rel(got, want)
     parity_log(what, max(p, l), tol)
@@ -72,6 +82,8 @@ def assert_istft_parity(got, want, gain_norm, what=""):
     samples where the window sum is near the reference's 1e-6 clamp.  Bar: 1e-5 of the peak where
     that number is <= 30, 3e-7 x condition number elsewhere (any float32 implementation, the
     reference included, is that far from the exact result there)"""
+    if HOSTSTUB:
+        return
     gain, norm = gain_norm
     cond = np.asarray(gain) / np.asarray(norm)
     scale = np.abs(want).max()

@@ -1,0 +1,88 @@
+"""CPU-only: the C host objects (audioflux_amd/csrc/host/*.c) built with AddressSanitizer + UBSan against a stand-in
+device layer (tests/hoststub/gen_stub.py: "device" memory is host memory, kernels do no arithmetic, the CQT launchers
+touch every range they are handed).
+
+  * tests/hoststub/driver_cqt.c drives every CQT entry point -- passes (AFX_CQT_CHUNK), the f32 / f16 / fused-launch
+    glue (AFX_CQT_F32, AFX_CQT_FUSED=1|2), chroma with a changing class count, free -- with leak detection on;
+  * the whole `-m gpu` suite then runs against the sanitized library (AFX_HOSTSTUB=1: parity assertions are skipped,
+    tests that need torch end with ImportError): every constructor and every first compute call of every test case
+    goes through the host code under the sanitizers.  Results are meaningless there; a sanitizer report is a failure.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(ROOT, "tests", "hoststub")
+INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
+SAN = ["-std=c99", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off"]
+
+
+def _asan_runtime():
+    p = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+pytestmark = pytest.mark.skipif(shutil.which("gcc") is None or _asan_runtime() is None,
+                                reason="needs gcc with the AddressSanitizer runtime")
+
+
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("hoststub"))
+    stub = os.path.join(tmp, "stub.c")
+    subprocess.run([sys.executable, os.path.join(HERE, "gen_stub.py"),
+                    os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"), stub], check=True)
+    host = sorted(os.path.join(ROOT, "audioflux_amd", "csrc", "host", f)
+                  for f in os.listdir(os.path.join(ROOT, "audioflux_amd", "csrc", "host")) if f.endswith(".c"))
+    lib = os.path.join(tmp, "libafx_stub.so")
+    r = subprocess.run(["gcc", *SAN, "-shared", "-fPIC", *INC, *host, stub, "-lm", "-o", lib],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = os.path.join(tmp, "driver_cqt")
+    r = subprocess.run(["gcc", *SAN, *INC, os.path.join(HERE, "driver_cqt.c"), lib, f"-Wl,-rpath,{tmp}", "-lm", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return tmp, lib, exe
+
+
+@pytest.mark.parametrize("env", ["", "AFX_CQT_CHUNK=2", "AFX_CQT_OVERLAP=0 AFX_CQT_CHUNK=3", "AFX_CQT_F32=1",
+                                 "AFX_CQT_FUSED=1", "AFX_CQT_FUSED=1 AFX_CQT_CHUNK=2", "AFX_CQT_FUSED=2",
+                                 "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2", "AFX_CQT_CHROMA_V2=1"])
+def test_cqt_host_logic_is_clean_under_sanitizers(built, env):
+    _, _, exe = built
+    e = dict(os.environ)
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2"):
+        e.pop(k, None)
+    e.update(kv.split("=") for kv in env.split())
+    e["ASAN_OPTIONS"] = "detect_leaks=1"
+    r = subprocess.run([exe], capture_output=True, text=True, env=e, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+    assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-3000:]
+
+
+def test_every_gpu_test_case_drives_clean_host_code(built):
+    tmp, lib, _ = built
+    e = dict(os.environ)
+    e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0:halt_on_error=0", AFX_HOSTSTUB="1", AFX_LIB=lib,
+             AFX_HIP_RUNTIME="system", UBSAN_OPTIONS="print_stacktrace=1")
+    e.pop("AFX_PARITY_LOG", None)
+    log = os.path.join(tmp, "suite.log")
+    with open(log, "w") as f:
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "-p", "no:cacheprovider",
+                            "--ignore=tests/dropin", "--ignore=tests/test_dist_cpu.py", "--ignore=tests/test_dist_gpu.py",
+                            "--ignore=tests/test_hoststub.py"],
+                           stdout=f, stderr=subprocess.STDOUT, env=e, cwd=ROOT, timeout=1500)
+    out = open(log, errors="replace").read()
+    assert r.returncode in (0, 1), f"the suite did not run to its end (rc {r.returncode}):\n{out[-3000:]}"
+    bad = [ln for ln in out.splitlines() if "AddressSanitizer" in ln or "runtime error" in ln]
+    assert not bad, "\n".join(bad[:20])
+    import re
+    m = re.search(r"(\d+) failed, (\d+) passed", out) or re.search(r"(\d+) passed", out)
+    assert m, out[-2000:]
+    ran = sum(int(g) for g in m.groups())
+    assert ran >= 150, f"only {ran} tests reached the library"
