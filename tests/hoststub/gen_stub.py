@@ -94,12 +94,223 @@ int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num, c
     touch_write(out, rows * chromaNum, 3.f);
     return AFX_OK;
 }
+
+/* ---- the other launchers: footprints as documented in afx_device.h */
+static void touch_rw(float *p, long long n) { for (long long i = 0; i < n; i++) p[i] = p[i] * 0.5f + 1.f; }
+static void touch_rows_w(float *p, long long rows, long long width, long long pitch, float v) {
+    for (long long r = 0; r < rows; r++) touch_write(p + r * pitch, width, v);
+}
+static void touch_rows_r(const float *p, long long rows, long long width, long long pitch) {
+    for (long long r = 0; r < rows; r++) touch_read(p + r * pitch, width);
+}
+int afxk_stft(const AfxStftArgs *a, void *stream) {
+    (void)stream;
+    const long long N = 1LL << a->radix2Exp, rows = (long long)a->batch * a->timeLength;
+    for (int b = 0; b < a->batch; b++) touch_read(a->x + b * a->clipStride, a->dataLength);
+    if (a->window) touch_read(a->window, N);
+    touch_read(a->twiddle, N);
+    const long long width = a->bandW ? a->bandNum : a->binCount, pitch = a->outPitch ? a->outPitch : width;
+    if (a->bandW) { touch_read((const float *)a->bandStart, a->bandNum); touch_read((const float *)a->bandLen, a->bandNum); }
+    touch_rows_w(a->outRe, rows, width, pitch, 1.f);
+    if (a->outIm && (a->mode == AFX_SPEC_COMPLEX || a->mode == AFX_SPEC_SQUARE)) touch_rows_w(a->outIm, rows, width, pitch, 2.f);
+    if (a->energy) touch_write(a->energy, rows, 1.f);
+    if (a->rms) touch_write(a->rms, rows, 1.f);
+    if (a->zcr) touch_write(a->zcr, rows, 1.f);
+    return AFX_OK;
+}
+int afxk_istft(const AfxIstftArgs *a, void *stream) {
+    (void)stream;
+    const long long N = 1LL << a->radix2Exp, rows = (long long)a->batch * a->timeLength;
+    touch_read(a->re, rows * N);
+    touch_read(a->im, rows * N);
+    touch_read(a->twiddle, N);
+    touch_read(a->win1, N);
+    touch_read(a->win2, N);
+    touch_write(a->frames, rows * N, 0.f);
+    for (int b = 0; b < a->batch; b++) touch_rw(a->out + b * a->outStride, (long long)(a->timeLength - 1) * a->hop + N);
+    return AFX_OK;
+}
+int afxk_spec_map(const float *re, const float *im, long long rows, int rowPitch, int binLo, int binCount, int mode,
+                  float normValue, float *out, float *out2, void *stream) {
+    (void)normValue; (void)stream;
+    touch_rows_r(re + binLo, rows, binCount, rowPitch);
+    touch_rows_r(im + binLo, rows, binCount, rowPitch);
+    touch_write(out, rows * binCount, 1.f);
+    if (out2 && (mode == AFX_SPEC_COMPLEX || mode == AFX_SPEC_SQUARE)) touch_write(out2, rows * binCount, 2.f);
+    return AFX_OK;
+}
+int afxk_row_post(float *data, long long rows, int n, int doPow, float powArg, int normType, void *stream) {
+    (void)doPow; (void)powArg; (void)normType; (void)stream;
+    touch_rw(data, rows * n);
+    return AFX_OK;
+}
+int afxk_gemm_nt(const float *A, long long lda, const float *B, int ldb, float *C, long long ldc, long long M, int N, int K,
+                 int pre, int post, float postArg, void *stream) {
+    (void)pre; (void)post; (void)postArg; (void)stream;
+    touch_rows_r(A, M, K, lda);
+    touch_rows_r(B, N, K, ldb);
+    touch_rows_w(C, M, N, ldc, 1.f);
+    return AFX_OK;
+}
+int afxk_xxcc_standard(const float *cc, const float *energy, long long rows, int ccNum, int energyType, int deltaLen,
+                       float *coe, float *delta1, float *delta2, void *stream) {
+    (void)deltaLen; (void)stream;
+    const int outLen = ccNum + (energyType == 1);
+    touch_read(cc, rows * ccNum);
+    if (energyType != 2 && energy) touch_read(energy, rows);
+    touch_write(coe, rows * outLen, 1.f);
+    if (delta1) touch_write(delta1, rows * outLen, 1.f);
+    if (delta2) touch_write(delta2, rows * outLen, 1.f);
+    return AFX_OK;
+}
+int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x, long long xStride, int chunks,
+                     float *scratchA, float *Xt, void *stream) {
+    (void)tw; (void)stream;
+    const long long L = 1LL << (d->r1 + d->r2);
+    for (int c = 0; c < chunks; c++) touch_read(x + c * xStride, d->dataLength);
+    touch_write(scratchA, 2 * L * chunks, 0.f);
+    touch_write(Xt, 2 * L * chunks, 1.f);
+    return AFX_OK;
+}
+int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, const float *bankT, int num, int isDet,
+                     int chunks, float *scratchB, float *outRe, float *outIm, int parts, void *stream) {
+    (void)tw; (void)isDet; (void)stream;
+    const long long L = 1LL << (d->r1 + d->r2);
+    touch_read(Xt, 2 * L * chunks);
+    touch_read(bankT, (long long)num * L);
+    if (parts & AFX_CWT_WIDE) touch_write(scratchB, 2 * L * chunks * (d->order ? d->nWide : num), 0.f);
+    touch_write(outRe, (long long)chunks * num * d->dataLength, 1.f);
+    touch_write(outIm, (long long)chunks * num * d->dataLength, 2.f);
+    return AFX_OK;
+}
+int afxk_cwt_small(const AfxCwtPlanDims *d, const float *tw, const float *x, long long xStride, int chunks,
+                   const float *bankNatural, int num, int isDet, float *X, float *outRe, float *outIm, void *stream) {
+    (void)tw; (void)isDet; (void)stream;
+    const long long L = 1LL << (d->r1 + d->r2);
+    if (x) { for (int c = 0; c < chunks; c++) touch_read(x + c * xStride, d->dataLength); touch_write(X, 2 * L * chunks, 1.f); }
+    else touch_read(X, 2 * L * chunks);
+    touch_read(bankNatural, (long long)num * L);
+    touch_write(outRe, (long long)chunks * num * d->dataLength, 1.f);
+    touch_write(outIm, (long long)chunks * num * d->dataLength, 2.f);
+    return AFX_OK;
+}
+int afxk_wsst_squeeze(const AfxWsstArgs *a, void *stream) {
+    (void)stream;
+    const long long n = (long long)a->batch * a->num * a->length;
+    touch_read(a->wRe, n);
+    touch_read(a->wIm, n);
+    touch_read(a->dRe, n);
+    if (!a->phaseInput) touch_read(a->dIm, n);
+    if (a->mode == 2) touch_read(a->freNorm, a->num);
+    touch_rw(a->outRe, n);
+    touch_rw(a->outIm, n);
+    return AFX_OK;
+}
+int afxk_synsq_phase(const float *re, const float *im, int num, long long length, float *phase, void *stream) {
+    (void)stream;
+    touch_read(re, num * length);
+    touch_read(im, num * length);
+    touch_write(phase, num * length, 0.f);
+    return AFX_OK;
+}
+int afxk_reassign(const AfxReassignArgs *a, int order, int *idxScratch, void *stream) {
+    (void)order; (void)idxScratch; (void)stream;
+    const long long n = (long long)a->batch * a->timeLength * a->F;
+    touch_read(a->hRe, n);
+    touch_read(a->hIm, n);
+    if (a->doFre) { touch_read(a->dhRe, n); touch_read(a->dhIm, n); }
+    if (a->doTime) { touch_read(a->thRe, n); touch_read(a->thIm, n); }
+    touch_read(a->freArr, a->F);
+    touch_write((float *)a->timeIdx, n, 0.f);
+    touch_write((float *)a->freIdx, n, 0.f);
+    touch_rw(a->outRe, n);
+    if (a->outIm) touch_rw(a->outIm, n);
+    return AFX_OK;
+}
+int afxk_cqt_deconv(const float *in, long long rows, int num, int radix2Exp, const float *twiddle, const int *hcIdx,
+                    int hcNum, float *outTimbre, float *outPitch, float *outHc, void *stream) {
+    (void)stream;
+    touch_read(in, rows * num);
+    touch_read(twiddle, 1LL << radix2Exp);
+    if (outTimbre) touch_write(outTimbre, rows * num, 1.f);
+    if (outPitch) touch_write(outPitch, rows * num, 1.f);
+    if (outHc) { touch_read((const float *)hcIdx, hcNum); touch_write(outHc, rows * hcNum, 1.f); }
+    return AFX_OK;
+}
+int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
+    (void)stream;
+    const long long N = 1LL << a->radix2Exp, T = a->timeLength;
+    if (a->x) {
+        if (a->framesPerClip > 0) {
+            for (long long f = 0; f < T; f += a->framesPerClip)
+                touch_read(a->x + (f / a->framesPerClip) * a->clipStride,
+                           (long long)((T - f < a->framesPerClip ? T - f : a->framesPerClip) - 1) * a->hop + N);
+        } else {
+            touch_read(a->x, (T - 1) * a->hop + N);
+        }
+        if (a->specRe) touch_write(a->specRe, T * N, 1.f);
+        if (a->specIm) touch_write(a->specIm, T * N, 1.f);
+    } else {
+        touch_read(a->specRe, T * N);
+        touch_read(a->specIm, T * N);
+    }
+    touch_read(a->window, N);
+    touch_read(a->twiddle, N);
+    if (a->out1) touch_write(a->out1, T * (N / 2 + 1), 1.f);
+    if (a->out2) touch_write(a->out2, T * (N / 2 + 1), 1.f);
+    if (a->out3) touch_write(a->out3, T * (N / 2 + 1), 1.f);
+    return AFX_OK;
+}
+int afxk_cepstrum_supported(const float *in, int num, int ccNum) { (void)in; return num <= 128 && ccNum <= 32; }
+int afxk_cepstrum(const float *in, long long rows, int num, const float *dct, int ccNum, int pre, float *out, void *stream) {
+    (void)pre; (void)stream;
+    touch_read(in, rows * num);
+    touch_read(dct, (long long)ccNum * num);
+    touch_write(out, rows * ccNum, 1.f);
+    return AFX_OK;
+}
+typedef struct { int num, radix2Exp; } StubPlan;
+int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
+    return (radix2Exp >= 10 && radix2Exp <= 12 && tapsA <= 72 && tapsB <= 32) ? 0 : -1;
+}
+int afxk_melfused_create(void **plan, int radix2Exp, const float *hWindow, const AfxBandPlan *band, void *stream) {
+    (void)stream;
+    touch_read(hWindow, 1LL << radix2Exp);
+    touch_read(band->wA, (long long)band->tapsA * 64);
+    if (band->tapsB > 0) touch_read(band->wB, (long long)band->tapsB * 64);
+    StubPlan *p = (StubPlan *)malloc(sizeof(StubPlan));
+    if (!p) return AFX_ERR_NOMEM;
+    p->num = band->num;
+    p->radix2Exp = radix2Exp;
+    *plan = p;
+    return AFX_OK;
+}
+int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
+    (void)stream;
+    const StubPlan *p = (const StubPlan *)plan;
+    const long long rows = (long long)a->batch * a->timeLength;
+    if ((a->cc || a->energy) && p->radix2Exp != 11) return AFX_ERR_UNSUPPORTED;
+    for (int b = 0; b < a->batch; b++) touch_read(a->x + b * a->clipStride, a->dataLength);
+    if (a->out) touch_write(a->out, rows * p->num, 1.f);
+    if (a->outIm && a->specMap >= 3) touch_write(a->outIm, rows * p->num, 2.f);
+    if (a->cc) { touch_read(a->dct, (long long)p->num * p->num); touch_write(a->cc, rows * a->ccNum, 1.f); }
+    if (a->energy) touch_write(a->energy, rows, 1.f);
+    if (a->rms) touch_write(a->rms, rows, 1.f);
+    if (a->zcr) touch_write(a->zcr, rows, 1.f);
+    return AFX_OK;
+}
+void afxk_melfused_destroy(void *plan) { free(plan); }
+int afxk_melfused_kind(const void *plan) { return plan ? 1 : 0; }
 '''
 
 DONE = {"afxdev_ensure", "afxdev_last_error", "afxdev_set_error", "afxdev_error_count", "afxdev_malloc", "afxdev_free",
         "afxdev_memset", "afxdev_h2d", "afxdev_d2h", "afxdev_d2d", "afxdev_stream_create", "afxdev_stream_destroy",
         "afxdev_reserve", "afxk_cqt_decimate", "afxk_cqt_octave", "afxk_cqt_octave_f16", "afxk_cqt_all_f16",
-        "afxk_cqt_chroma"}
+        "afxk_cqt_chroma", "afxk_stft", "afxk_istft", "afxk_spec_map", "afxk_row_post", "afxk_gemm_nt",
+        "afxk_xxcc_standard", "afxk_cwt_forward", "afxk_cwt_inverse", "afxk_cwt_small", "afxk_wsst_squeeze",
+        "afxk_synsq_phase", "afxk_reassign", "afxk_cqt_deconv", "afxk_cepstrogram", "afxk_cepstrum_supported",
+        "afxk_cepstrum", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run", "afxk_melfused_destroy",
+        "afxk_melfused_kind"}
 
 
 def main(header, out):

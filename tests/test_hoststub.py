@@ -68,12 +68,12 @@ def test_cqt_host_logic_is_clean_under_sanitizers(built, env):
 def test_every_gpu_test_case_drives_clean_host_code(built):
     tmp, lib, _ = built
     e = dict(os.environ)
-    e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0:halt_on_error=0", AFX_HOSTSTUB="1", AFX_LIB=lib,
+    e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0", AFX_HOSTSTUB="1", AFX_LIB=lib,
              AFX_HIP_RUNTIME="system", UBSAN_OPTIONS="print_stacktrace=1")
     e.pop("AFX_PARITY_LOG", None)
     log = os.path.join(tmp, "suite.log")
     with open(log, "w") as f:
-        r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "-p", "no:cacheprovider",
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider",
                             "--ignore=tests/dropin", "--ignore=tests/test_dist_cpu.py", "--ignore=tests/test_dist_gpu.py",
                             "--ignore=tests/test_hoststub.py"],
                            stdout=f, stderr=subprocess.STDOUT, env=e, cwd=ROOT, timeout=1500)
