@@ -42,27 +42,45 @@ def built(tmp_path_factory):
     r = subprocess.run(["gcc", *SAN, "-shared", "-fPIC", *INC, *host, stub, "-lm", "-o", lib],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    exe = os.path.join(tmp, "driver_cqt")
-    r = subprocess.run(["gcc", *SAN, *INC, os.path.join(HERE, "driver_cqt.c"), lib, f"-Wl,-rpath,{tmp}", "-lm", "-o", exe],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return tmp, lib, exe
+    exes = {}
+    for name in ("driver_cqt", "driver_batch"):
+        exes[name] = os.path.join(tmp, name)
+        r = subprocess.run(["gcc", *SAN, *INC, os.path.join(HERE, name + ".c"), lib, f"-Wl,-rpath,{tmp}", "-lm", "-o",
+                            exes[name]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    return tmp, lib, exes
+
+
+def _run_driver(exe, env, knobs):
+    e = dict(os.environ)
+    for k in knobs:
+        e.pop(k, None)
+    e.update(kv.split("=") for kv in env.split())
+    e["ASAN_OPTIONS"] = "detect_leaks=1"
+    r = subprocess.run([exe], capture_output=True, text=True, env=e, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+    assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-3000:]
 
 
 @pytest.mark.parametrize("env", ["", "AFX_CQT_CHUNK=2", "AFX_CQT_OVERLAP=0 AFX_CQT_CHUNK=3", "AFX_CQT_F32=1",
                                  "AFX_CQT_FUSED=1", "AFX_CQT_FUSED=1 AFX_CQT_CHUNK=2", "AFX_CQT_FUSED=2",
                                  "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2", "AFX_CQT_CHROMA_V2=1"])
 def test_cqt_host_logic_is_clean_under_sanitizers(built, env):
-    _, _, exe = built
-    e = dict(os.environ)
-    for k in ("AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2"):
-        e.pop(k, None)
-    e.update(kv.split("=") for kv in env.split())
-    e["ASAN_OPTIONS"] = "detect_leaks=1"
-    r = subprocess.run([exe], capture_output=True, text=True, env=e, timeout=600)
-    out = r.stdout + r.stderr
-    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
-    assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-3000:]
+    _run_driver(built[2]["driver_cqt"], env,
+                ("AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2"))
+
+
+@pytest.mark.parametrize("env", ["", "AFX_SCRATCH_MB=1", "AFX_NO_FUSED_CC=1", "AFX_NO_FUSED=1", "AFX_CWT_GROUP=2",
+                                 "AFX_CWT_OVERLAP=0", "AFX_CWT_CHAINS=3 AFX_CWT_GROUP=1", "AFX_CWT_NARROW_MAX=0"])
+def test_device_pointer_entry_points_are_clean_under_sanitizers(built, env):
+    """tests/hoststub/driver_batch.c: the ...BatchDevice calls of include/afx_batch.h (which the Python GPU tests reach
+    through torch tensors) with exactly-sized buffers: mel + MFCC in one call, dense-bank route in several chunks,
+    temporal features, complex results, STFT / inverse STFT, spectrogram object, cepstrogram, reassignment, CWT at
+    2^12 and 2^16 (chunk groups, chains, narrow-band plan on / off, padded), PWT, WSST"""
+    _run_driver(built[2]["driver_batch"], env,
+                ("AFX_SCRATCH_MB", "AFX_NO_FUSED_CC", "AFX_NO_FUSED", "AFX_CWT_GROUP", "AFX_CWT_OVERLAP", "AFX_CWT_CHAINS",
+                 "AFX_CWT_NARROW_MAX"))
 
 
 def test_every_gpu_test_case_drives_clean_host_code(built):
