@@ -642,9 +642,9 @@ __global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re
 // ---- chroma, second formulation (AFX_CQT_CHROMA_V2=1; not yet measured on hardware, off by default) --------
 // k_cqt_chroma spends most of its time before the first barrier: chromaNum threads scan the num flags of their
 // row of the 0/1 matrix in global memory, one dependent byte load at a time, while the other threads wait.
-// Here the per-class bin lists are built once per launch on the host side of this file and travel as a kernel
-// argument; a thread owns (frame = tid & 63, classes wave, wave + 4, ...), so the class -- and with it the list
-// walked -- is uniform per wave (scalar loads of the kernel argument), and the |Q|^2 rows sit in LDS at an odd
+// Here the per-class bin lists are built on the host (afx_cqt.c: afx_chroma_lists, CPU-tested) and travel as a kernel
+// argument, copied to LDS once per workgroup; a thread owns (frame = tid & 63, classes wave, wave + 4, ...), so the class -- and with it the list
+// walked -- is uniform per wave (broadcast LDS reads), and the |Q|^2 rows sit in LDS at an odd
 // pitch so that the 64 frames of a read fall on distinct banks.  Same sums in the same (ascending bin) order.
 __global__ __launch_bounds__(256) void k_cqt_chroma_v2(const float *__restrict__ re, const float *__restrict__ im,
                                                        long long rows, int num, AfxChromaLists L, int chromaNum,
@@ -692,15 +692,21 @@ __global__ __launch_bounds__(256) void k_cqt_chroma_v2(const float *__restrict__
             p[f * pitch + j] = pw(pr[e], pi[e]);
         }
     }
+    // the lists: kernel argument -> LDS, one byte per thread and trip (indexing the argument itself in the walk below
+    // compiles to a dependent global load per bin)
+    unsigned char *sL = reinterpret_cast<unsigned char *>(cv + CH_FRAMES * chromaNum);
+    for (int b = tid; b < (int)sizeof(AfxChromaLists); b += 256) sL[b] = reinterpret_cast<const unsigned char *>(&L)[b];
     __syncthreads();
     {
+        const unsigned short *sStart = reinterpret_cast<const unsigned short *>(sL);
+        const unsigned char *sBins = sL + sizeof(L.start);
         const int f = tid & (CH_FRAMES - 1);
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const float *row = p + f * pitch;
         for (int c = wave; c < chromaNum; c += 4) {           // uniform per wave
-            const int b0 = L.start[c], b1 = L.start[c + 1];
+            const int b0 = sStart[c], b1 = sStart[c + 1];
             float v = 0.f;
-            for (int q = b0; q < b1; ++q) v += row[L.bins[q]];
+            for (int q = b0; q < b1; ++q) v += row[sBins[q]];
             if (f < nf) cv[f * chromaNum + c] = v;
         }
     }
@@ -907,7 +913,8 @@ extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows,
     const int vec4 = (num % 4 == 0) && (reinterpret_cast<uintptr_t>(re) % 16 == 0) && (reinterpret_cast<uintptr_t>(im) % 16 == 0);
     if (getenv("AFX_CQT_CHROMA_V2") && lists && chromaNum <= 64) {
         const AfxChromaLists L = *lists;
-        const size_t lds2 = sizeof(float) * ((size_t)CH_FRAMES * (num | 1) + (size_t)CH_FRAMES * chromaNum);
+        const size_t lds2 = sizeof(float) * ((size_t)CH_FRAMES * (num | 1) + (size_t)CH_FRAMES * chromaNum) +
+                            ((sizeof(AfxChromaLists) + 15) & ~(size_t)15);
         if (lds2 > 48 * 1024)
             AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma_v2),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
