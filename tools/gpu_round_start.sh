@@ -21,7 +21,9 @@ if [ $RC -ne 0 ]; then  # a failure or a hang in the shipped kernels: do not spe
   exit 1
 fi
 python tools/parity_table.py $OUT/parity.jsonl > $OUT/parity_table.md 2>&1
-for c in 2 5 4; do timeout 300 python bench.py --config $c > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; done
+# a step that runs into its timeout (rc 124) means a hung kernel: every later step would hang too -- stop
+guard() { local rc=$?; if [ $rc -eq 124 ]; then echo "TIMEOUT in: $1 -- stopping" | tee -a $OUT/status.txt; cat $OUT/status.txt; exit 1; fi; }
+for c in 2 5 4; do timeout 300 python bench.py --config $c > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; guard "bench cfg $c"; done
 # candidates
 (AFX_CQT_CHROMA_V2=1 timeout 300 python -m pytest tests/test_cqt_gpu.py tests/test_batch_gpu.py tests/dropin -q -m gpu -x) > $OUT/pytest_chroma_v2.log 2>&1
 RC=$?
@@ -30,6 +32,7 @@ if [ $RC -ne 0 ]; then tail -n 30 $OUT/pytest_chroma_v2.log; cat $OUT/status.txt
 for v in 0 1; do
   if [ $v = 1 ]; then export AFX_CQT_CHROMA_V2=1; else unset AFX_CQT_CHROMA_V2; fi
   timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_chroma_v2_$v.json 2> $OUT/bench_cfg5_chroma_v2_$v.err
+  guard "bench cfg 5, chroma v2 = $v"
   AFX_CQT_OVERLAP=0 timeout 200 bash tools/prof_cmd.sh rs_${TAG}_chroma$v "" python bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
   cp gpurun_out/prof_rs_${TAG}_chroma$v/summary.txt $OUT/trace_cfg5_chroma_v2_$v.txt 2>/dev/null
 done
@@ -45,6 +48,7 @@ if [ $RC -eq 0 ]; then
 fi
 if [ $RC -eq 0 ]; then
   AFX_CQT_FUSED=1 timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_fused.json 2> $OUT/bench_cfg5_fused.err
+  guard "bench cfg 5 fused"
   AFX_CQT_FUSED=1 AFX_CQT_CHUNK=125 timeout 200 python bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_fused_onepass.json 2> $OUT/bench_cfg5_fused_onepass.err
   # decimations of pass p + 1 on the side stream under the launch of pass p: its own parity run first
   (AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2 timeout 200 python -m pytest tests/test_batch_gpu.py -q -m gpu -x -k cqt) > $OUT/pytest_fused2.log 2>&1
