@@ -25,12 +25,13 @@ static float bessel_i0(float a) {
     return sum;
 }
 
-static float g_kaiser_beta = 5.0f; /* overridden only inside afx_window_kaiser */
+#define AFX_KAISER_BETA 5.0f /* window_calFFTWindow's Kaiser family; afx_window_kaiser passes its own */
 
 typedef struct {
     int n;          /* symmetric length being generated                 */
     int half;       /* samples computed from the formula                */
     float den_i0;   /* kaiser                                           */
+    float beta;     /* kaiser (no global state: constructors run concurrently on different threads) */
     float step;     /* bohman linspace step                             */
     int gauss_half; /* gauss: halfLen of its own mirrored construction  */
 } WinCtx;
@@ -72,7 +73,7 @@ static float half_value(WindowType type, const WinCtx *c, int i) {
             return v;
         }
         case Window_Kaiser: { /* :696-716, beta 5 */
-            const float a = g_kaiser_beta;
+            const float a = c->beta;
             float u = (float)(2.0 * i / d - 1);
             float b = a * sqrtf(1 - u * u);
             return bessel_i0(b) / c->den_i0;
@@ -107,9 +108,10 @@ static float half_value(WindowType type, const WinCtx *c, int i) {
 }
 
 /* symmetric window of length n into out[n] */
-static void fill_symmetric(WindowType type, int n, float *out) {
+static void fill_symmetric(WindowType type, int n, float *out, float kaiserBeta) {
     WinCtx c;
     c.n = n;
+    c.beta = kaiserBeta;
     c.den_i0 = 0;
     c.step = 0;
     c.gauss_half = 0;
@@ -134,7 +136,7 @@ static void fill_symmetric(WindowType type, int n, float *out) {
         }
         return;
     }
-    if (type == Window_Kaiser) c.den_i0 = bessel_i0(g_kaiser_beta);
+    if (type == Window_Kaiser) c.den_i0 = bessel_i0(c.beta);
     if (type == Window_Bohman) c.step = (1.f - (-1.f)) / (n - 1 > 0 ? n - 1 : 1);
     if (type == Window_Gauss) {
         /* the gauss family computes one extra sample for even n (flux_window.c:533-538) */
@@ -148,7 +150,7 @@ static void fill_symmetric(WindowType type, int n, float *out) {
     for (int i = n - 1; i >= half; i--) out[i] = out[n - 1 - i];
 }
 
-float *afx_window_create(WindowType type, int length, int periodic) {
+static float *window_create_beta(WindowType type, int length, int periodic, float kaiserBeta) {
     if (length <= 0) return NULL;
     float *w = (float *)calloc((size_t)length + 2, sizeof(float));
     if (!w) return NULL;
@@ -162,10 +164,14 @@ float *afx_window_create(WindowType type, int length, int periodic) {
         free(w);
         return NULL;
     }
-    fill_symmetric(type, n, tmp);
+    fill_symmetric(type, n, tmp, kaiserBeta);
     for (int i = 0; i < length; i++) w[i] = tmp[i];
     free(tmp);
     return w;
+}
+
+float *afx_window_create(WindowType type, int length, int periodic) {
+    return window_create_beta(type, length, periodic, AFX_KAISER_BETA);
 }
 
 float *afx_window_fft(WindowType type, int length) {
@@ -182,9 +188,5 @@ float *afx_window_fft(WindowType type, int length) {
 /* symmetric Kaiser window with an explicit beta (window_createKaiser(length, 0, &beta),
  * flux_window.c:112-127); used by the resampler table */
 float *afx_window_kaiser(int length, float beta) {
-    const float saved = g_kaiser_beta;
-    if (beta > 0) g_kaiser_beta = beta;
-    float *w = afx_window_create(Window_Kaiser, length, 0);
-    g_kaiser_beta = saved;
-    return w;
+    return window_create_beta(Window_Kaiser, length, 0, beta > 0 ? beta : AFX_KAISER_BETA);
 }
