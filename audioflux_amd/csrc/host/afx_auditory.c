@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "afx_device.h"
 #include "afx_host.h"
 
 /* ---- frequency <-> scale maps (auditory_filterBank.c:1024-1190) --------- */
@@ -139,11 +140,16 @@ static void normalise_rows(float *bank, int num, int F, SpectralFilterBankNormal
 /* ---- styles -------------------------------------------------------------- */
 
 /* triangles in Hz on the FFT grid (auditory_filterBank.c:435-500) */
-static void style_slaney(int num, int fftLength, int samplate, SpectralFilterBankNormalType normal,
+static int style_slaney(int num, int fftLength, int samplate, SpectralFilterBankNormalType normal,
                          const float *fre, const int *bin, float *bank) {
     const int F = fftLength / 2 + 1;
     float *grid = afx_linspace(0, samplate - samplate / (float)fftLength, fftLength, 0);
     float *width = (float *)calloc((size_t)num + 1, sizeof(float));
+    if (!grid || !width) {
+        free(grid);
+        free(width);
+        return AFX_ERR_NOMEM;
+    }
     for (int i = 0; i < num + 1; i++) width[i] = fre[i + 1] - fre[i];
     for (int i = 0; i < num; i++) {
         for (int j = bin[i]; j <= bin[i + 1] - 1 && j < F; j++) {
@@ -156,6 +162,7 @@ static void style_slaney(int num, int fftLength, int samplate, SpectralFilterBan
     normalise_rows(bank, num, F, normal, fre);
     free(grid);
     free(width);
+    return AFX_OK;
 }
 
 /* triangles in bins (auditory_filterBank.c:373-426) */
@@ -177,7 +184,7 @@ static void style_etsi(int num, int fftLength, SpectralFilterBankNormalType norm
 }
 
 /* point / rect / window-shaped bands (auditory_filterBank.c:210-337) */
-static void style_window(int num, int fftLength, SpectralFilterBankStyleType style,
+static int style_window(int num, int fftLength, SpectralFilterBankStyleType style,
                          SpectralFilterBankNormalType normal, const float *fre, const int *bin,
                          float *bank) {
     const int F = fftLength / 2 + 1;
@@ -201,6 +208,7 @@ static void style_window(int num, int fftLength, SpectralFilterBankStyleType sty
         } else {
             if (cur > left) { /* rising half of a symmetric window of 2(cur-left)+1 */
                 float *w = afx_window_create(wt, 2 * (cur - left) + 1, 0);
+                if (!w) return AFX_ERR_NOMEM;
                 for (int j = left, k = 0; j <= cur && j < F; j++, k++)
                     if (j >= 0) row[j] = w[k];
                 free(w);
@@ -208,6 +216,7 @@ static void style_window(int num, int fftLength, SpectralFilterBankStyleType sty
             if (right > cur) { /* falling half, starting one past the peak */
                 int n = 2 * (right - cur) + 1;
                 float *w = afx_window_create(wt, n, 0);
+                if (!w) return AFX_ERR_NOMEM;
                 for (int j = cur + 1, k = n / 2 + 1; j <= right && j < F; j++, k++)
                     if (j >= 0) row[j] = w[k];
                 free(w);
@@ -215,17 +224,19 @@ static void style_window(int num, int fftLength, SpectralFilterBankStyleType sty
         }
     }
     normalise_rows(bank, num, F, normal, fre);
+    return AFX_OK;
 }
 
 /* 4th-order gammatone magnitude responses (auditory_filterBank.c:509-591,
  * coefficients :696-925, cascade response dsp/filterDesign_freqz.c:12-138) */
-static void style_gammatone(int num, int fftLength, int samplate,
+static int style_gammatone(int num, int fftLength, int samplate,
                             SpectralFilterBankNormalType normal, const float *fre, float *bank) {
     const int F = fftLength / 2 + 1;
     const float t = (float)(1.0 / samplate);
     const float pv = sqrtf(3 + powf(2, 1.5)), nv = sqrtf(3 - powf(2, 1.5));
     const float end = (float)(2 * M_PI);
     float *omega = afx_linspace(0, end - end / fftLength, fftLength, 0);
+    if (!omega) return AFX_ERR_NOMEM;
 
     for (int b = 0; b < num; b++) {
         const float f = fre[b];
@@ -313,9 +324,10 @@ static void style_gammatone(int num, int fftLength, int samplate,
         for (int j = 1; j < F - 1; j++) row[j] *= 2;
     }
     free(omega);
+    return AFX_OK;
 }
 
-void afx_auditory_bank(int num, int fftLength, int samplate, SpectralFilterBankScaleType scale,
+int afx_auditory_bank(int num, int fftLength, int samplate, SpectralFilterBankScaleType scale,
                        SpectralFilterBankStyleType style, SpectralFilterBankNormalType normal,
                        float lowFre, float highFre, int binPerOctave, float *bank, float *freOut,
                        int *binOut) {
@@ -367,11 +379,21 @@ void afx_auditory_bank(int num, int fftLength, int samplate, SpectralFilterBankS
      *    to FFT bins (auditory_filterBank.c:594-677) */
     float *fre = afx_linspace(fwd(lowFre, ref), fwd(highFre, ref), count, 0);
     int *bin = (int *)calloc((size_t)num + 2, sizeof(int));
+    if (!fre || !bin) {
+        free(fre);
+        free(bin);
+        return AFX_ERR_NOMEM;
+    }
     for (int i = 0; i < count; i++) fre[i] = inv(fre[i], ref);
     if (style != SpectralFilterBankStyle_Slaney) {
         for (int i = 0; i < count; i++) bin[i] = (int)roundf(fftLength * fre[i] / samplate);
     } else { /* first grid point strictly above the edge frequency */
         float *grid = afx_linspace(0, samplate - samplate / (float)fftLength, fftLength, 0);
+        if (!grid) {
+            free(fre);
+            free(bin);
+            return AFX_ERR_NOMEM;
+        }
         for (int i = 0; i < num + 2; i++) {
             for (int j = 0; j < fftLength; j++) {
                 if (grid[j] > fre[i]) {
@@ -384,18 +406,19 @@ void afx_auditory_bank(int num, int fftLength, int samplate, SpectralFilterBankS
     }
 
     /* 2. the bank itself */
+    int st = AFX_OK;
     switch (style) {
         case SpectralFilterBankStyle_Slaney:
-            style_slaney(num, fftLength, samplate, normal, fre, bin, bank);
+            st = style_slaney(num, fftLength, samplate, normal, fre, bin, bank);
             break;
         case SpectralFilterBankStyle_ETSI:
             style_etsi(num, fftLength, normal, fre, bin, bank);
             break;
         case SpectralFilterBankStyle_Gammatone:
-            style_gammatone(num, fftLength, samplate, normal, fre, bank);
+            st = style_gammatone(num, fftLength, samplate, normal, fre, bank);
             break;
         default:
-            style_window(num, fftLength, style, normal, fre, bin, bank);
+            st = style_window(num, fftLength, style, normal, fre, bin, bank);
             break;
     }
 
@@ -403,4 +426,5 @@ void afx_auditory_bank(int num, int fftLength, int samplate, SpectralFilterBankS
     if (binOut) memcpy(binOut, bin + offset, sizeof(int) * (size_t)num);
     free(fre);
     free(bin);
+    return st;
 }

@@ -201,8 +201,8 @@ int afx_bft_create(const AfxBftPlan *p, BFTObj *bftObj) {
                 /* caller-built [num, F] matrix (the STFT-chroma bank of the spectrogram object) */
                 memcpy(hBank, p->customBank, sizeof(float) * (size_t)num * o->F);
             } else {
-                afx_auditory_bank(num, fftLength, sr, scale, p->style, p->normal, low, high, bpo, hBank,
-                                  o->freBandArr, o->binBandArr);
+                st = afx_auditory_bank(num, fftLength, sr, scale, p->style, p->normal, low, high, bpo, hBank,
+                                       o->freBandArr, o->binBandArr);
             }
         }
     }

@@ -781,6 +781,11 @@ int cqtObj_cqtBatch(CQTObj o, const float *dataArr, int batch, int dataLength, f
 unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre) {
     unsigned char *tmp = (unsigned char *)calloc((size_t)chromaNum * num, 1);
     unsigned char *out = (unsigned char *)calloc((size_t)chromaNum * num, 1);
+    if (!tmp || !out) {
+        free(tmp);
+        free(out);
+        return NULL;
+    }
     int n = bpo / chromaNum;
     const int offset = (int)ceilf((float)(n / 2.0));
     const int sub = n - offset;
@@ -847,6 +852,7 @@ static int chroma_prepare(CQTObj o, int *chromaNum, SpectralDataType *dataType,
     int st = AFX_OK;
     if (cn != o->foldChromaNum) {
         unsigned char *fold = afx_chroma_fold(cn, o->num, o->binPerOctave, o->minFre);
+        if (!fold) return AFX_ERR_NOMEM;
         if (o->lastUsed) afxdev_stream_sync(o->lastStream); /* a launch may still read the old one */
         afxdev_free(o->dFold);
         o->dFold = NULL;

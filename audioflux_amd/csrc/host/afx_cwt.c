@@ -85,7 +85,7 @@ static long double gammal_ref(long double x) {
 }
 
 /* natural-layout bank [num][L] (cwt_filterBank.c:85-290) */
-static void build_bank(struct OpaqueCWT *o, float *bank) {
+static int build_bank(struct OpaqueCWT *o, float *bank) {
     const int num = o->num, D = o->dataLength, sr = o->samplate;
     const long long L = o->fftLength;
     float low = o->lowFre, high = o->highFre, ref = 0;
@@ -129,6 +129,7 @@ static void build_bank(struct OpaqueCWT *o, float *bank) {
         default: a = low; b = high; break;
     }
     float *f = afx_linspace(a, b, num + 2, 0);
+    if (!f) return AFX_ERR_NOMEM;
     for (int i = 0; i < num + 2; i++) {
         switch (o->scaleType) {
             case SpectralFilterBankScale_Linear: f[i] = f[i] * ref; break;
@@ -155,9 +156,15 @@ static void build_bank(struct OpaqueCWT *o, float *bank) {
 
     /* angular frequency grid and scales, highest frequency first (:218-236) */
     float *w = (float *)calloc((size_t)L, sizeof(float));
+    float *s = (float *)calloc((size_t)num, sizeof(float));
+    if (!w || !s) {
+        free(f);
+        free(w);
+        free(s);
+        return AFX_ERR_NOMEM;
+    }
     for (long long i = 0; i <= L / 2; i++) w[i] = (float)(i * 2 * M_PI / L);
     for (long long i = L / 2 + 1, j = L / 2 - 1; i < L && j >= 0; i++, j--) w[i] = -w[j];
-    float *s = (float *)calloc((size_t)num, sizeof(float));
     for (int i = num, j = 0; i >= 1; i--, j++) {
         float v = f[i];
         if (v < 1e-6) v = 1e-6f;
@@ -248,6 +255,7 @@ static void build_bank(struct OpaqueCWT *o, float *bank) {
     free(f);
     free(w);
     free(s);
+    return AFX_OK;
 }
 
 /* device-free entry used by the CPU tests: the same bank cwtObj_new uploads, natural
@@ -273,7 +281,12 @@ int afx_cwt_bank_host(int num, int dataLength, int samplate, int padLength, int 
     o.freBandArr = (float *)calloc((size_t)num + 2, sizeof(float));
     o.binBandArr = (int *)calloc((size_t)num + 2, sizeof(int));
     if (!o.freBandArr || !o.binBandArr) return AFX_ERR_NOMEM;
-    build_bank(&o, bank);
+    const int bst = build_bank(&o, bank);
+    if (bst != AFX_OK) {
+        free(o.freBandArr);
+        free(o.binBandArr);
+        return bst;
+    }
     if (freBandArr) memcpy(freBandArr, o.freBandArr, sizeof(float) * (size_t)num);
     if (binBandArr) memcpy(binBandArr, o.binBandArr, sizeof(int) * (size_t)num);
     free(o.freBandArr);
@@ -500,11 +513,11 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
             memcpy(o->freBandArr, customFre, sizeof(float) * (size_t)num);
             memcpy(o->binBandArr, customBin, sizeof(int) * (size_t)num);
         } else {
-            build_bank(o, o->hBank);
+            st = build_bank(o, o->hBank);
         }
-        bankT = to_transposed(o->hBank, num, o->dims.r1, o->dims.r2, NULL);
+        if (st == AFX_OK) bankT = to_transposed(o->hBank, num, o->dims.r1, o->dims.r2, NULL);
         tw = afx_twiddle_table((int)fftLength);
-        if (!bankT || !tw) st = AFX_ERR_NOMEM;
+        if (st == AFX_OK && (!bankT || !tw)) st = AFX_ERR_NOMEM;
     }
     const size_t L = (size_t)fftLength;
     if (st == AFX_OK) st = afxdev_stream_create(&o->stream);

@@ -26,8 +26,8 @@ float *afx_window_fft(WindowType type, int length);
 float *afx_window_kaiser(int length, float beta);
 
 /* ---- afx_auditory.c ---------------------------------------------------- */
-/* fills bank[num*(fftLength/2+1)] (must be zeroed), fre[num], bin[num] */
-void afx_auditory_bank(int num, int fftLength, int samplate,
+/* fills bank[num*(fftLength/2+1)] (must be zeroed), fre[num], bin[num]; 0 or AFX_ERR_NOMEM */
+int afx_auditory_bank(int num, int fftLength, int samplate,
                        SpectralFilterBankScaleType scale,
                        SpectralFilterBankStyleType style,
                        SpectralFilterBankNormalType normal,

@@ -64,10 +64,11 @@ int afx_pwt_bank_host(int num, long long L, int samplate, SpectralFilterBankScal
     }
     float *half = (float *)calloc((size_t)num * F, sizeof(float));
     if (!half) return AFX_ERR_NOMEM;
-    afx_auditory_bank(num, N, samplate, scale, style, normal, low, high, bpo, half, fre, bin);
-    for (int i = 0; i < num; i++) memcpy(bank + (size_t)i * N, half + (size_t)i * F, sizeof(float) * (size_t)F);
+    const int st = afx_auditory_bank(num, N, samplate, scale, style, normal, low, high, bpo, half, fre, bin);
+    for (int i = 0; st == AFX_OK && i < num; i++)
+        memcpy(bank + (size_t)i * N, half + (size_t)i * F, sizeof(float) * (size_t)F);
     free(half);
-    return AFX_OK;
+    return st;
 }
 
 int pwtObj_new(PWTObj *pwtObj, int num, int radix2Exp, int *samplate, float *lowFre, float *highFre,

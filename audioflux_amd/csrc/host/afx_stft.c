@@ -424,7 +424,10 @@ int afx_test_stft_stream(int radix2Exp, int slideLength, int isPad, const float 
         const float *chunk = data + off;
         const int n = chunkLens[c];
         int valid = n, headTail = 0, skip = 0;
-        if (stftObj_calTimeLength(&s, n) < 0) return AFX_ERR_ARG;
+        if (stftObj_calTimeLength(&s, n) < 0) {
+            free(s.tailDataArr);
+            return AFX_ERR_ARG;
+        }
         const int T = afx_stft_deal_data(&s, chunk, n, &valid, &headTail, &skip);
         timeLens[c] = T;
         curLens[c] = 0;

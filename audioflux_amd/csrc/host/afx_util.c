@@ -1,6 +1,7 @@
 /* afx_util.c -- small host helpers (linspace, twiddle and DCT tables). */
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "afx_host.h"
 
@@ -81,6 +82,13 @@ void afx_fft_ref32(int r, const float *re1, const float *im1, float *re2, float 
     const int n = 1 << r, half = n / 2;
     float *wc = (float *)malloc(sizeof(float) * (size_t)(half > 0 ? half : 1));
     float *ws = (float *)malloc(sizeof(float) * (size_t)(half > 0 ? half : 1));
+    if (!wc || !ws) { /* out of memory: a zero spectrum (every kernel entry falls under the threshold) */
+        free(wc);
+        free(ws);
+        memset(re2, 0, sizeof(float) * (size_t)n);
+        memset(im2, 0, sizeof(float) * (size_t)n);
+        return;
+    }
     for (int i = 0; i < half; i++) {
         wc[i] = cosf((float)(2 * M_PI * i / n));
         ws[i] = -sinf((float)(2 * M_PI * i / n));
@@ -116,7 +124,6 @@ void afx_fft_ref32(int r, const float *re1, const float *im1, float *re2, float 
  * Any consumer reads it with numpy.load / memory-maps it; no reference counterpart (the reference
  * leaves persistence to its Python callers). */
 #include <stdio.h>
-#include <string.h>
 
 int afx_write_npy_f32(const char *path, const float *data, int ndim, const long long *shape) {
     if (!path || !data || ndim < 1 || ndim > 8 || !shape) return -6;
