@@ -14,9 +14,9 @@ SPECIAL = r'''
 #include <string.h>
 #include "afx_device.h"
 
-static char g_err[512];
-static int g_errs;
-volatile float afx_stub_sink;
+static _Thread_local char g_err[512];
+static _Thread_local int g_errs;
+_Thread_local volatile float afx_stub_sink;
 static void touch_read(const float *p, long long n) { float s = 0; for (long long i = 0; i < n; i++) s += p[i]; afx_stub_sink = s; }
 static void touch_write(float *p, long long n, float v) { for (long long i = 0; i < n; i++) p[i] = v; }
 

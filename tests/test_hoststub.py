@@ -104,3 +104,32 @@ def test_every_gpu_test_case_drives_clean_host_code(built):
     assert m, out[-2000:]
     ran = sum(int(g) for g in m.groups())
     assert ran >= 150, f"only {ran} tests reached the library"
+
+
+def _tsan_runtime():
+    p = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.mark.skipif(_tsan_runtime() is None, reason="needs gcc with the ThreadSanitizer runtime")
+def test_concurrent_objects_are_race_free(tmp_path):
+    """tests/hoststub/driver_threads.c under ThreadSanitizer: six threads build, use and free Kaiser-window BFT objects
+    and CQT objects (whose resampler table is a Kaiser window with another beta) at the same time; every thread also
+    compares its window with a single-threaded one.  (afx_window.c once kept the beta in a temporarily overwritten
+    global: TSan reports that version.)"""
+    tmp = str(tmp_path)
+    stub = os.path.join(tmp, "stub.c")
+    subprocess.run([sys.executable, os.path.join(HERE, "gen_stub.py"),
+                    os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"), stub], check=True)
+    host = sorted(os.path.join(ROOT, "audioflux_amd", "csrc", "host", f)
+                  for f in os.listdir(os.path.join(ROOT, "audioflux_amd", "csrc", "host")) if f.endswith(".c"))
+    exe = os.path.join(tmp, "driver_threads")
+    r = subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=thread", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                        *INC, *host, stub, os.path.join(HERE, "driver_threads.c"), "-lm", "-lpthread", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+    assert "ThreadSanitizer" not in out, out[-3000:]
+
