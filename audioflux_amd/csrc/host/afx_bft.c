@@ -92,6 +92,7 @@ int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *low
     if (binPerOctave && *binPerOctave >= 4 && *binPerOctave <= 48) bpo = *binPerOctave;
     if (windowType) win = *windowType;
     hop = fftLength / 4;
+    if (hop < 1) hop = 1; /* fftLength 2: the reference's default of 0 divides by zero in its frame count */
     if (slideLength && *slideLength > 0) hop = *slideLength;
 
     if (scale == SpectralFilterBankScale_Linear) {

@@ -41,7 +41,7 @@ int cepstrogramObj_new(CepstrogramObj *cepstrogramObj, int radix2Exp, WindowType
     o->radix2Exp = radix2Exp;
     o->fftLength = 1 << radix2Exp;
     o->windowType = windowType ? *windowType : Window_Rect;
-    o->slideLength = o->fftLength / 4;
+    o->slideLength = o->fftLength / 4 > 0 ? o->fftLength / 4 : 1; /* fftLength 2: the reference divides by its default of 0 */
     if (slideLength && *slideLength > 0) o->slideLength = *slideLength;
     float *w = afx_window_fft(o->windowType, o->fftLength);
     float *tw = afx_twiddle_table(o->fftLength);

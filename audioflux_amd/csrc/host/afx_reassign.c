@@ -52,7 +52,7 @@ int reassignObj_new(ReassignObj *reassignObj, int radix2Exp, int *samplate, Wind
     o->samplate = (samplate && *samplate > 0) ? *samplate : 32000;
     o->isPadding = isPadding ? *isPadding : 0;
     o->windowType = windowType ? *windowType : Window_Hann;
-    o->slideLength = (slideLength && *slideLength > 0) ? *slideLength : o->fftLength / 4;
+    o->slideLength = (slideLength && *slideLength > 0) ? *slideLength : (o->fftLength / 4 > 0 ? o->fftLength / 4 : 1);
     o->thresh = (thresh && *thresh >= 0) ? *thresh : 0.001f;
     const int N = o->fftLength;
     float *win = (float *)malloc(sizeof(float) * 3 * (size_t)N);

@@ -248,6 +248,7 @@ static int new_impl(SpectrogramObj *spectrogramObj, int num, int *samplate, floa
     if (windowType) win = *windowType;
     if (deep && win > Window_Hamm) win = Window_Hamm;
     hop = fftLength / 4;
+    if (hop < 1) hop = 1; /* fftLength 2 */
     if (slideLength && *slideLength > 0) hop = *slideLength;
     if (isContinue) cont = *isContinue;
 

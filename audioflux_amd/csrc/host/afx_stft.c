@@ -35,7 +35,8 @@ int stftObj_new(STFTObj *stftObj, int radix2Exp, WindowType *windowType, int *sl
     o->radix2Exp = radix2Exp;
     o->fftLength = 1 << radix2Exp;
     o->windowType = windowType ? *windowType : Window_Rect;
-    o->slideLength = o->fftLength / 4;
+    o->slideLength = o->fftLength / 4 > 0 ? o->fftLength / 4 : 1; /* fftLength 2: the reference's default of 0 divides by
+                                                                   * zero in its frame count (stft_algorithm.c:251) */
     if (slideLength && *slideLength > 0) o->slideLength = *slideLength;
     o->isContinue = isContinue ? *isContinue : 0;
     o->positionType = PaddingPosition_Center;

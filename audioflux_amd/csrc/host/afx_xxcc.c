@@ -24,6 +24,11 @@ int xxccObj_new(XXCCObj *xxccObj, int num) {
         printf("num is error!!!\n");
         return -1;
     }
+    if (num > 16384) { /* the [num, num] DCT matrix is built here: no filter bank of the path has more rows than
+                        * fftLength / 2 + 1 <= 8193; a larger num would sit in cos() for minutes and ask for > 1 GB */
+        afxdev_set_error("xxccObj_new: num %d exceeds 16384", num);
+        return AFX_ERR_UNSUPPORTED;
+    }
     int st = afxdev_ensure();
     if (st != AFX_OK) return st;
     XXCCObj o = (XXCCObj)calloc(1, sizeof(struct OpaqueXXCC));

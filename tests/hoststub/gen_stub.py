@@ -24,7 +24,11 @@ int afxdev_ensure(void) { return AFX_OK; }
 const char *afxdev_last_error(void) { return g_err; }
 void afxdev_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); g_errs++; }
 int afxdev_error_count(void) { return g_errs; }
-int afxdev_malloc(void **dptr, size_t bytes) { *dptr = malloc(bytes ? bytes : 1); return *dptr ? AFX_OK : AFX_ERR_NOMEM; }
+/* (a request beyond 16 GiB fails like hipMalloc would on a full device: the constructor must hand the status on) */
+int afxdev_malloc(void **dptr, size_t bytes) {
+    *dptr = bytes > ((size_t)1 << 34) ? NULL : malloc(bytes ? bytes : 1);
+    return *dptr ? AFX_OK : AFX_ERR_NOMEM;
+}
 void afxdev_free(void *dptr) { free(dptr); }
 int afxdev_memset(void *dptr, int value, size_t bytes, void *stream) { (void)stream; memset(dptr, value, bytes); return AFX_OK; }
 int afxdev_h2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memcpy(dst, src, bytes); return AFX_OK; }
@@ -35,7 +39,7 @@ void afxdev_stream_destroy(void *stream) { free(stream); }
 int afxdev_reserve(void **dptr, size_t *capacity, size_t bytes) {
     if (*dptr && *capacity >= bytes) return AFX_OK;
     free(*dptr);
-    *dptr = malloc(bytes ? bytes : 1);  /* exactly what was asked for: an overrun is an ASan report */
+    *dptr = bytes > ((size_t)1 << 34) ? NULL : malloc(bytes ? bytes : 1);  /* exactly what was asked for: an overrun is an ASan report */
     *capacity = *dptr ? bytes : 0;
     return *dptr ? AFX_OK : AFX_ERR_NOMEM;
 }

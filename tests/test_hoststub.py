@@ -106,6 +106,23 @@ def test_every_gpu_test_case_drives_clean_host_code(built):
     assert ran >= 150, f"only {ran} tests reached the library"
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_constructor_arguments_fuzz(built, seed):
+    """tests/hoststub/fuzz_ctor.py: random valid / borderline / invalid constructor arguments for every object through
+    raw ctypes against the sanitized host code: a handle and status 0, or a refusal -- never a crash or a sanitizer
+    report.  (It found: the default hop fftLength / 4 = 0 at fftLength 2 dividing by zero in the frame count, as in the
+    reference; xxccObj_new building a [num, num] DCT for any num.)"""
+    tmp, lib, _ = built
+    e = dict(os.environ)
+    e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0", AFX_LIB=lib, AFX_FUZZ_SEED=str(seed),
+             UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_ctor.py"), "40"], capture_output=True, text=True, env=e,
+                       timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "constructed" in out and "\nOK" in out, out[-3000:]
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
+
+
 def _tsan_runtime():
     p = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
     return p if os.path.isabs(p) and os.path.exists(p) else None
