@@ -17,8 +17,8 @@ extern "C" {
 
 typedef struct OpaqueXXCC *XXCCObj;
 
-/* num = bands of the input spectrogram (>= 2).  returns 0, -1 on bad num,
- * <= -2 on backend failure.  replaces xxcc_algorithm.c:32-62 */
+/* num = bands of the input spectrogram (>= 2; this backend: <= 16384, -4 beyond -- the [num, num] DCT matrix is
+ * built here).  returns 0, -1 on bad num, <= -2 on backend failure.  replaces xxcc_algorithm.c:32-62 */
 int xxccObj_new(XXCCObj *xxccObj, int num);
 
 /* number of frames the next xxcc call will process.  replaces xxcc_algorithm.c:64-89 */

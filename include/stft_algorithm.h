@@ -20,7 +20,7 @@ extern "C" {
 typedef struct OpaqueSTFT *STFTObj;
 
 /* radix2Exp 1..30 (this backend: <= 14); windowType NULL -> Rect; slideLength NULL/<=0 ->
- * fftLength/4; isContinue NULL -> 0.  returns 0, -100 bad radix2Exp, <= -2 backend failure.
+ * fftLength/4 (1 at fftLength 2, where the reference's default of 0 divides by zero); isContinue NULL -> 0.  returns 0, -100 bad radix2Exp, <= -2 backend failure.
  * replaces stft_algorithm.c:80-161 */
 int stftObj_new(STFTObj *stftObj, int radix2Exp, WindowType *windowType, int *slideLength,
                 int *isContinue);
