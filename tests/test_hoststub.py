@@ -123,6 +123,21 @@ def test_constructor_arguments_fuzz(built, seed):
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_compute_call_edges_fuzz(built, seed):
+    """tests/hoststub/fuzz_calls.py: zero / one-sample / shorter-than-a-frame inputs, batch 0, overlapping clip strides,
+    NULL outputs, padding and streaming switches on ordinary BFT / STFT / CQT / XXCC objects"""
+    tmp, lib, _ = built
+    e = dict(os.environ)
+    e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0", AFX_LIB=lib, AFX_FUZZ_SEED=str(seed),
+             UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_calls.py"), "40"], capture_output=True, text=True, env=e,
+                       timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "accepted" in out and "\nOK" in out, out[-3000:]
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
+
+
 def _tsan_runtime():
     p = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
     return p if os.path.isabs(p) and os.path.exists(p) else None
