@@ -40,7 +40,7 @@ def main():
         r2 = pick(8, 10, 11)
         N = 1 << r2
         num = pick(13, 40, 128)
-        hop = pick(1, N // 4, N, N + 3)
+        hop = pick(1, N // 4, N, N + 3, 3 * N)
         # ---- BFT
         h = vp()
         assert lib.bftObj_new(C.byref(h), num, r2, C.byref(C.c_int(16000)), None, None, None, None, C.byref(C.c_int(hop)), None, None,
@@ -62,8 +62,8 @@ def main():
         assert lib.stftObj_new(C.byref(s), r2, None, C.byref(C.c_int(hop)), C.byref(C.c_int(pick(0, 1)))) == 0
         lib.stftObj_enablePadding(s, pick(0, 1))
         lib.stftObj_setPadding(s, C.byref(C.c_int(pick(0, 1, 2))), C.byref(C.c_int(pick(0, 1, 2))), None, None)
-        for _call in range(2):
-            n = pick(0, 1, N - 1, N, 2 * N + 5)
+        for _call in range(6):  # a stream: the kept tail (also the "negative" tail of hop > fftLength) carries over
+            n = pick(0, 1, 7, hop, N - 1, N, N + hop - 1, 2 * N + 5, 4 * N + 1)
             T = max(lib.stftObj_calTimeLength(s, n), 0)
             x, re, im = arr(n), arr(T * N), arr(T * N)
             lib.stftObj_stft(s, ptr(x), n, ptr(re), ptr(im))
