@@ -12,10 +12,13 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/round_start_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# what the f16 CQT kernels assume of the hardware (per-dword bounds checks of raw buffer accesses, MFMA layout)
+(timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/buffer_oob.hip -o /tmp/buffer_oob && timeout 60 /tmp/buffer_oob) > $OUT/buffer_oob.txt 2>&1
+echo "buffer_oob rc=$? $(grep -c ' ok$' $OUT/buffer_oob.txt)/3 ok" | tee $OUT/status.txt
 rm -f $OUT/parity.jsonl
 (time AFX_PARITY_LOG=$PWD/$OUT/parity.jsonl timeout 900 python -m pytest tests -q -m gpu -x) > $OUT/pytest.log 2>&1
 RC=$?
-echo "pytest -m gpu rc=$RC $(grep -aE '[0-9]+ passed|failed' $OUT/pytest.log | tail -n 1)" | tee $OUT/status.txt
+echo "pytest -m gpu rc=$RC $(grep -aE '[0-9]+ passed|failed' $OUT/pytest.log | tail -n 1)" | tee -a $OUT/status.txt
 if [ $RC -ne 0 ]; then  # a failure or a hang in the shipped kernels: do not spend GPU time on anything else
   tail -n 40 $OUT/pytest.log
   exit 1
