@@ -98,6 +98,46 @@ def main():
         lib.xxccObj_setTimeLength(c, rows)
         lib.xxccObj_xxcc(c, ptr(m), cc, None, ptr(out))
         lib.xxccObj_free(c)
+        # ---- cepstrogram: cepNum at and beyond its range, inputs shorter than a frame
+        ce = vp()
+        assert lib.cepstrogramObj_new(C.byref(ce), r2, None, C.byref(C.c_int(hop))) == 0
+        lib.cepstrogramObj_calTimeLength.restype = C.c_int
+        n = pick(0, 1, N - 1, N, 3 * N + 1)
+        T = max(lib.cepstrogramObj_calTimeLength(ce, n), 0)
+        F = N // 2 + 1
+        x, o1, o2, o3 = arr(n), arr(T * F), arr(T * F), arr(T * F)
+        lib.cepstrogramObj_cepstrogram(ce, pick(-1, 0, 1, 4, F, F + 5), ptr(x), n, ptr(o1), ptr(o2), ptr(o3))
+        lib.cepstrogramObj_free(ce)
+        # ---- mel spectrogram object as a stream of chunks
+        sg = vp()
+        cont = C.c_int(pick(0, 1))
+        assert lib.spectrogramObj_newMel(C.byref(sg), 40, 16000, r2, C.byref(cont)) == 0
+        lib.spectrogramObj_calTimeLength.restype = C.c_int
+        for _call in range(4):
+            n = pick(0, 1, N // 4, N - 1, N, 2 * N + 3)
+            T = max(lib.spectrogramObj_calTimeLength(sg, n), 0)
+            x, m, ph = arr(n), arr(T * 40), arr(T * 40)
+            lib.spectrogramObj_spectrogram(sg, ptr(x), n, ptr(m), ptr(ph))
+        lib.spectrogramObj_free(sg)
+        # ---- reassignment, every reassign type, inputs around one frame
+        ra = vp()
+        assert lib.reassignObj_new(C.byref(ra), r2, None, None, C.byref(C.c_int(min(hop, N))), C.byref(C.c_int(pick(0, 1, 2, 3))),
+                                   None, C.byref(C.c_int(pick(0, 1))), None) == 0
+        lib.reassignObj_calTimeLength.restype = C.c_int
+        lib.reassignObj_setResultType(ra, pick(0, 1))
+        n = pick(0, 1, N - 1, N, N + 1, 2 * N + 9)
+        T = max(lib.reassignObj_calTimeLength(ra, n), 0)
+        x = arr(n)
+        b1, b2, b3, b4 = (arr(T * F) for _ in range(4))
+        lib.reassignObj_reassign(ra, ptr(x), n, ptr(b1), ptr(b2), ptr(b3), ptr(b4))
+        lib.reassignObj_free(ra)
+        # ---- CWT at the in-LDS size with NULL outputs now and then
+        cw = vp()
+        cr2 = pick(6, 10, 12)
+        assert lib.cwtObj_new(C.byref(cw), 24, cr2, None, None, None, None, None, None, None, None, C.byref(C.c_int(pick(0, 1)))) == 0
+        x, a1, a2 = arr(1 << cr2), arr(24 << cr2), arr(24 << cr2)
+        lib.cwtObj_cwt(cw, ptr(x), ptr(a1), ptr(a2))
+        lib.cwtObj_free(cw)
     print(f"calls accepted {done}, refused {refused}")
     print("OK")
 
