@@ -166,6 +166,11 @@ int afxk_gemm_nt(const float *A, long long lda, const float *B, int ldb,
                  float *C, long long ldc, long long M, int N, int K,
                  int pre, int post, float postArg, void *stream);
 
+/* the same product with every operand as three bf16 words on the bf16 matrix cores (afx_gemm_bf16.hip;
+ * AFX_GEMM_BF16=1, off by default); pre is AFX_MAP_NONE; AFX_ERR_UNSUPPORTED for unaligned operands */
+int afxk_gemm_nt128_bf16(const float *A, long long lda, const float *B, int ldb, float *C, long long ldc,
+                         long long M, int N, int K, int post, float postArg, void *stream);
+
 /* "standard" cepstra post-pass (xxcc_algorithm.c:244-292): per frame, put
  * ln(max(energy,1e-8)) in front of / in place of coefficient 0 and take the
  * causal smoothing-derivative FIR (util_delta, util/flux_util.c:803-815) along

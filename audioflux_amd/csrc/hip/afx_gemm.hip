@@ -261,6 +261,10 @@ extern "C" int afxk_gemm_nt(const float *A, long long lda, const float *B, int l
     // spectrum and its bank copy to a pitch of 4 floats): the 128 x 128 double-buffered kernel
     if (N > 32 && pre == AFX_MAP_NONE && lda % 4 == 0 && ldb % 4 == 0 &&
         reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0 && !getenv("AFX_GEMM_V1")) {
+        if (getenv("AFX_GEMM_BF16")) {  // three-bf16-word operands on the bf16 matrix cores (afx_gemm_bf16.hip; off by default)
+            const int st = afxk_gemm_nt128_bf16(A, lda, B, ldb, C, ldc, M, N, K, post, postArg, stream);
+            if (st != AFX_ERR_UNSUPPORTED) return st;
+        }
         const long long g = (M + TM - 1) / TM;
         const int gnn = (N + TN - 1) / TN;
         if (g <= 0x7fffffffLL && gnn <= 65535) {

@@ -67,6 +67,17 @@ if [ $RC -eq 0 ]; then
 else
   tail -n 30 $OUT/pytest_fused.log
 fi
+# AFX_GEMM_BF16=1 (k_gemm_nt128_bf16x3: dense filter-bank GEMM on three bf16 words per operand)
+(AFX_GEMM_BF16=1 timeout 200 python -m pytest tests/test_bft_gpu.py tests/test_spectrogram_gpu.py -q -m gpu -x -k "dense or gammatone or chroma") > $OUT/pytest_gemm_bf16.log 2>&1
+RC=$?
+echo "bf16 GEMM tests rc=$RC $(grep -aE '[0-9]+ passed|failed' $OUT/pytest_gemm_bf16.log | tail -n 1)" | tee -a $OUT/status.txt
+if [ $RC -eq 0 ]; then
+  timeout 120 python tools/bench_dense.py > $OUT/dense_f32.txt 2>&1; guard "bench_dense f32"
+  AFX_GEMM_BF16=1 timeout 120 python tools/bench_dense.py > $OUT/dense_bf16.txt 2>&1; guard "bench_dense bf16"
+  tail -n 4 $OUT/dense_f32.txt $OUT/dense_bf16.txt
+else
+  tail -n 25 $OUT/pytest_gemm_bf16.log
+fi
 cat $OUT/status.txt
 python - <<PY
 import json, glob
