@@ -12,7 +12,7 @@
 // and the product keeps the six terms down to 2^-24 of the leading one,
 //     a_h b_h + (a_h b_m + a_m b_h) + (a_m b_m + a_h b_l + a_l b_h),
 // accumulated in float32 by the matrix core: six MFMAs of 32 cycles per 16 k-steps = 192 cycles against 512 on the
-// f32 pipe.  numpy model (oracle-free): elementwise relative error 8.5e-7, the f32 GEMM's 9.4e-7.
+// f32 pipe.  numpy model: elementwise relative error 8.5e-7, the f32 GEMM's 9.4e-7.
 //
 // Tiling as k_gemm_nt128: 128 x 128 outputs per workgroup, four waves own 64 x 64 quadrants (2 x 2 MFMA tiles each),
 // K in steps of 16 (one MFMA k-step), double-buffered LDS.  The loader converts while it stages: a thread takes four
