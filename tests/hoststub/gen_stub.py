@@ -3,7 +3,8 @@
 objects can run under AddressSanitizer / UBSan without a GPU.  "Device" memory is malloc'ed host memory, streams
 are dummies, and the kernel launchers do no arithmetic -- but the ones of the CQT path READ every input range and
 WRITE every output range they are handed, so that a level buffer that is too small or a pointer that is off shows
-up as a sanitizer report.  Test infrastructure (tests/test_hoststub.py), never linked into the product."""
+up as a sanitizer report.  --functional-cqt leaves the CQT launchers out: tests/hoststub/cqt_functional.c, which
+computes, supplies them.  Test infrastructure (tests/test_hoststub.py), never linked into the product."""
 import re
 import sys
 
@@ -317,13 +318,23 @@ DONE = {"afxdev_ensure", "afxdev_last_error", "afxdev_set_error", "afxdev_error_
         "afxk_melfused_kind"}
 
 
-def main(header, out):
+CQT_MARK = "/* ---- CQT launchers: touch what the real kernels touch */"
+REST_MARK = "/* ---- the other launchers: footprints as documented in afx_device.h */"
+
+
+def main(header, out, functional_cqt=False):
+    """functional_cqt: leave the CQT launchers out (tests/hoststub/cqt_functional.c, which computes, supplies them)"""
+    special = SPECIAL
+    if functional_cqt:
+        head, rest = SPECIAL.split(CQT_MARK)
+        _, tail = rest.split(REST_MARK)
+        special = head + REST_MARK + tail
     src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = re.findall(r"^((?:const\s+)?[A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(afx[dk][a-z]*_[A-Za-z0-9_]+)\s*\(([^;{}]*?)\)\s*;",
                         src, flags=re.M | re.S)
-    body = [SPECIAL, "\n/* ---- everything else: accepted, nothing done */\n"]
+    body = [special, "\n/* ---- everything else: accepted, nothing done */\n"]
     for ret, name, args in protos:
         if name in DONE:
             continue
@@ -345,4 +356,4 @@ def main(header, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], "--functional-cqt" in sys.argv[3:])

@@ -7,6 +7,8 @@ touch every range they are handed).
   * the whole `-m gpu` suite then runs against the sanitized library (AFX_HOSTSTUB=1: parity assertions are skipped,
     tests that need torch end with ImportError): every constructor and every first compute call of every test case
     goes through the host code under the sanitizers.  Results are meaningless there; a sanitizer report is a failure.
+  * tests/hoststub/cqt_functional.c replaces the CQT launchers by double-precision loops that do what afx_device.h
+    says the kernels do: the CQT host code then has to reproduce the reference's golden vectors on every launch path.
 """
 import os
 import shutil
@@ -136,6 +138,51 @@ def test_compute_call_edges_fuzz(built, seed):
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "accepted" in out and "\nOK" in out, out[-3000:]
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
+
+
+@pytest.fixture(scope="module")
+def functional(tmp_path_factory):
+    """the host objects + tests/hoststub/cqt_functional.c (CQT launchers that COMPUTE, in double-precision loops, what
+    afx_device.h says the kernels do) + the stand-in for the rest of the device layer, under ASan / UBSan"""
+    tmp = str(tmp_path_factory.mktemp("functional"))
+    stub = os.path.join(tmp, "stub.c")
+    subprocess.run([sys.executable, os.path.join(HERE, "gen_stub.py"),
+                    os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"), stub, "--functional-cqt"], check=True)
+    host = sorted(os.path.join(ROOT, "audioflux_amd", "csrc", "host", f)
+                  for f in os.listdir(os.path.join(ROOT, "audioflux_amd", "csrc", "host")) if f.endswith(".c"))
+    lib = os.path.join(tmp, "libafx_functional.so")
+    r = subprocess.run(["gcc", *SAN, "-shared", "-fPIC", *INC, *host, stub, os.path.join(HERE, "cqt_functional.c"), "-lm",
+                        "-o", lib], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return lib
+
+
+@pytest.mark.parametrize("env,path", [("", "octave_f16"), ("AFX_CQT_CHUNK=2", "octave_f16"), ("AFX_CQT_F32=1", "octave_f32"),
+                                      ("AFX_NO_FUSED=1", "octave_f32"), ("AFX_CQT_FUSED=1", "all"),
+                                      ("AFX_CQT_FUSED=1 AFX_CQT_CHUNK=1", "all"), ("AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2", "all"),
+                                      ("AFX_CQT_FUSED=2", "all")])
+def test_cqt_host_glue_meets_the_golden_vectors_with_functional_launchers(functional, env, path):
+    """tests/hoststub/functional_cqt.py: the reference's golden CQT / chroma vectors through the C host code with the
+    kernels replaced by their contracts.  Every launch path's arguments (f16 image words and column multipliers,
+    float32 image, spectral kernels, the level table / class table of the all-octave launch, passes with a row stride
+    that is not a multiple of four) must reproduce the reference to 1e-5 -- including AFX_CQT_FUSED, whose kernel has not
+    been on hardware yet: its host half is pinned here.  `path` = the launcher the default 84-bin plan must have used."""
+    e = dict(os.environ)
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_NO_FUSED"):
+        e.pop(k, None)
+    if env:
+        e.update(kv.split("=") for kv in env.split())
+    e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0", AFX_LIB=functional, UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "functional_cqt.py"), "c84_32k_area", "c84_44k_none_noscale",
+                        "c48_16k_area", "c72_24bpo_hop200"], capture_output=True, text=True, env=e, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "\nOK" in out, out[-3000:]
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
+    import re
+    m = re.search(r"c84_32k_area launches: octave_f16 (\d+) octave_f32 (\d+) all (\d+) chroma (\d+)", out)
+    assert m, out[-2000:]
+    n = dict(zip(("octave_f16", "octave_f32", "all", "chroma"), map(int, m.groups())))
+    assert n[path] > 0 and all(n[k] == 0 for k in ("octave_f16", "octave_f32", "all") if k != path), n
 
 
 def _tsan_runtime():
