@@ -66,6 +66,8 @@ if [ $RC -eq 0 ]; then
   cp gpurun_out/prof_rs_${TAG}_fused/summary.txt $OUT/trace_cfg5_fused.txt 2>/dev/null
 else
   tail -n 30 $OUT/pytest_fused.log
+  # a candidate that ran into its timeout has most likely hung the device: nothing after it would run
+  if [ $RC -eq 124 ]; then echo "TIMEOUT in the fused CQT tests -- stopping" | tee -a $OUT/status.txt; cat $OUT/status.txt; exit 0; fi
 fi
 # AFX_GEMM_BF16=1 (k_gemm_nt128_bf16x3: dense filter-bank GEMM on three bf16 words per operand)
 (AFX_GEMM_BF16=1 timeout 200 python -m pytest tests/test_bft_gpu.py tests/test_spectrogram_gpu.py -q -m gpu -x -k "dense or gammatone or chroma") > $OUT/pytest_gemm_bf16.log 2>&1
