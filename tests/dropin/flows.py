@@ -325,8 +325,26 @@ def run_cpu(workdir, out):
     np.savez(out, meta=np.array(json.dumps(meta)))
 
 
+def run_cqt_functional(workdir, out):
+    """CPU: AFX_LIB = the host objects linked with tests/hoststub/cqt_functional.c (CQT launchers that compute);
+    the CQT / chroma flows through the wrapper, stock library vs that build (tests/test_hoststub.py)"""
+    stage(workdir)
+    af = import_wrapper(workdir)
+    x, y = signals()
+    res = {}
+    for tag, ext in (("stock", None), ("mi355x", "mi355x")):
+        af.fftlib.set_fft_lib(lib_ext=ext)
+        o = af.CQT(num=84, samplate=32000)
+        q = o.cqt(y)
+        res[f"{tag}/cqt"], res[f"{tag}/chroma"] = q, o.chroma(q)
+        res[f"{tag}/fre"], res[f"{tag}/T"] = o.get_fre_band_arr(), np.array(o.cal_time_length(len(y)))
+        q2, _ = af.cqt(x, samplate=32000)
+        res[f"{tag}/core_cqt_abs"], res[f"{tag}/core_chroma"] = q2, af.chroma_cqt(x, samplate=32000)
+    np.savez(out, **res)
+
+
 if __name__ == "__main__":
     workdir, out = sys.argv[1], sys.argv[2]
     mode = sys.argv[3] if len(sys.argv) > 3 else "gpu"
-    (run_gpu if mode == "gpu" else run_cpu)(workdir, out)
+    {"gpu": run_gpu, "cpu": run_cpu, "cqt_functional": run_cqt_functional}[mode](workdir, out)
     print("flows done:", mode)

@@ -154,6 +154,12 @@ def functional(tmp_path_factory):
     r = subprocess.run(["gcc", *SAN, "-shared", "-fPIC", *INC, *host, stub, os.path.join(HERE, "cqt_functional.c"), "-lm",
                         "-o", lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    # the same without the sanitizers, for processes that cannot run under an LD_PRELOADed ASan runtime (the
+    # reference's Python wrapper imports matplotlib: C++ exceptions before libstdc++ is loaded)
+    r = subprocess.run(["gcc", "-std=c99", "-O2", "-ffp-contract=off", "-shared", "-fPIC", *INC, *host, stub,
+                        os.path.join(HERE, "cqt_functional.c"), "-lm", "-o", lib.replace(".so", "_plain.so")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     return lib
 
 
@@ -183,6 +189,37 @@ def test_cqt_host_glue_meets_the_golden_vectors_with_functional_launchers(functi
     assert m, out[-2000:]
     n = dict(zip(("octave_f16", "octave_f32", "all", "chroma"), map(int, m.groups())))
     assert n[path] > 0 and all(n[k] == 0 for k in ("octave_f16", "octave_f32", "all") if k != path), n
+
+
+@pytest.mark.parametrize("env", ["", "AFX_CQT_FUSED=1"])
+def test_reference_wrapper_drives_the_cqt_host_code_on_the_cpu(functional, tmp_path, env):
+    """tests/dropin/flows.py cqt_functional: the reference's own unmodified Python wrapper (set_fft_lib) on the host
+    objects + functional CQT launchers, against the stock library through the same wrapper: CQT, chroma, frequency
+    table, frame count.  (The GPU version of this, every flow on the real kernels, is tests/dropin/test_dropin.py.)"""
+    import numpy as np
+    dropin = os.path.join(ROOT, "tests", "dropin")
+    sys.path.insert(0, dropin)
+    import flows
+    if not (os.path.exists(flows.STOCK) and (os.path.exists(flows.WRAPPER_ZIP) or os.path.isdir("/root/reference/python/audioflux"))):
+        pytest.skip("needs oracle/_ref (make -C oracle)")
+    e = dict(os.environ)
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED"):
+        e.pop(k, None)
+    if env:
+        e.update(kv.split("=") for kv in env.split())
+    e.update(AFX_LIB=functional.replace(".so", "_plain.so"))
+    out = str(tmp_path / "flows.npz")
+    r = subprocess.run([sys.executable, os.path.join(dropin, "flows.py"), str(tmp_path / "pkg"), out, "cqt_functional"],
+                       capture_output=True, text=True, env=e, timeout=900, cwd=str(tmp_path))
+    log = r.stdout + r.stderr
+    assert r.returncode == 0 and "flows done" in log, log[-3000:]
+    d = np.load(out)
+    assert np.array_equal(d["stock/T"], d["mi355x/T"]) and np.array_equal(d["stock/fre"], d["mi355x/fre"])
+    for k in ("cqt", "chroma", "core_cqt_abs", "core_chroma"):
+        want, got = d[f"stock/{k}"], d[f"mi355x/{k}"]
+        assert got.shape == want.shape and got.dtype == want.dtype, k
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 1e-5, (k, err)
 
 
 def _tsan_runtime():
