@@ -268,6 +268,13 @@ int afx_bft_create(const AfxBftPlan *p, BFTObj *bftObj) {
         }
         free(meta);
     }
+    if (st == AFX_OK && p->isReassign && r < 2) {
+        /* reassignObj_new takes radix2Exp 1 for "unset" and builds a 2^12 transform (reassign_algorithm.c:125-127),
+         * while this object's arrays are sized for fftLength 2: the reference writes past them.  Refused. */
+        afxdev_set_error("bftObj_new: isReassign with radix2Exp 1 is undefined in the reference (its reassignment "
+                         "object falls back to 2^12); refused");
+        st = AFX_ERR_UNSUPPORTED;
+    }
     if (st == AFX_OK && p->isReassign) {
         /* __bftObj_init (bft_algorithm.c:332-340): reassignment of both axes, default threshold */
         ReassignType reType = Reassign_All;

@@ -31,7 +31,8 @@ typedef struct OpaqueBFT *BFTObj;
  *   filterScaleType/StyleType/NormalType  defaults Linear / Slaney / None
  *   dataType      default SpectralData_Power
  *   isReassign    default 0; 1: the time-frequency reassigned spectrum replaces the STFT
- *                 (reassign_algorithm.c:203-414; ordered, deterministic accumulation)
+ *                 (reassign_algorithm.c:203-414; ordered, deterministic accumulation); with radix2Exp 1
+ *                 refused (-4): the reference's reassignment object then runs at 2^12 and overruns
  *   isTemporal    default 0; 1 also computes per-frame energy/rms/zcr (in the same kernel
  *                 launch at n_fft 2048 with real results)
  * returns 0 ok, -100 bad radix2Exp, 1 bad scale type, -1 bad num/frequency

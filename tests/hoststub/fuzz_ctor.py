@@ -15,15 +15,25 @@ rng = np.random.default_rng(int(os.environ.get("AFX_FUZZ_SEED", "1")))
 P = C.POINTER
 
 
+VERBOSE = os.environ.get("AFX_FUZZ_VERBOSE")  # print every argument drawn (to reproduce a finding by hand)
+
+
 def opt(val, ctype):
     """an optional pointer argument: NULL one time in three"""
     if rng.integers(0, 3) == 0:
+        if VERBOSE:
+            print("  opt NULL", flush=True)
         return None
+    if VERBOSE:
+        print("  opt", val, flush=True)
     return C.byref(ctype(val))
 
 
 def pick(*vals):
-    return vals[rng.integers(0, len(vals))]
+    v = vals[rng.integers(0, len(vals))]
+    if VERBOSE:
+        print("  pick", v, flush=True)
+    return v
 
 
 def irange(lo, hi):

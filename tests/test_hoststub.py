@@ -108,12 +108,14 @@ def test_every_gpu_test_case_drives_clean_host_code(built):
     assert ran >= 150, f"only {ran} tests reached the library"
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 35])
 def test_constructor_arguments_fuzz(built, seed):
     """tests/hoststub/fuzz_ctor.py: random valid / borderline / invalid constructor arguments for every object through
     raw ctypes against the sanitized host code: a handle and status 0, or a refusal -- never a crash or a sanitizer
     report.  (It found: the default hop fftLength / 4 = 0 at fftLength 2 dividing by zero in the frame count, as in the
-    reference; xxccObj_new building a [num, num] DCT for any num.)"""
+    reference; xxccObj_new building a [num, num] DCT for any num; seed 35: bftObj_new(radix2Exp 1, isReassign 1), whose
+    reassignment object silently falls back to 2^12 -- as in the reference -- and wrote 15905 x 2049 results into
+    planes sized for fftLength 2.  AFX_FUZZ_VERBOSE=1 prints every argument drawn.)"""
     tmp, lib, _ = built
     e = dict(os.environ)
     e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0", AFX_LIB=lib, AFX_FUZZ_SEED=str(seed),
