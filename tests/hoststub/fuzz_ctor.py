@@ -57,6 +57,10 @@ def f32(n):
     return (0.1 * rng.standard_normal(max(n, 1))).astype(np.float32)
 
 
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
 def fuzz_bft():
     h = C.c_void_p()
     num, r2 = pick(0, 1, 2, 13, 40, 128, 129, 600, 5000), pick(0, 1, 5, 8, 10, 11, 12, 15, 31)
@@ -139,12 +143,29 @@ def fuzz_stft():
 
 def fuzz_misc():
     h = C.c_void_p()
-    st = lib.xxccObj_new(C.byref(h), pick(-1, 0, 1, 13, 128, 100000))
+    xn = pick(-1, 0, 1, 13, 128, 100000)
+    st = lib.xxccObj_new(C.byref(h), xn)
     if status(st, h):
+        if xn <= 128:
+            T, cc = pick(1, 7, 300), pick(1, 13, xn, xn + 1)
+            lib.xxccObj_setTimeLength(h, T)
+            m, out = np.abs(f32(T * xn)) + 1e-3, np.zeros(T * max(cc, 1), np.float32)
+            lib.xxccObj_xxcc(h, vp(m), cc, opt(irange(-1, 3), C.c_int), vp(out))
         lib.xxccObj_free(h)
     h = C.c_void_p()
-    st = lib.cepstrogramObj_new(C.byref(h), pick(0, 1, 8, 11, 12, 16, 31), opt(irange(-1, 13), C.c_int), opt(pick(-1, 0, 1, 256), C.c_int))
+    cr = pick(0, 1, 8, 11, 12, 16, 31)
+    st = lib.cepstrogramObj_new(C.byref(h), cr, opt(irange(-1, 13), C.c_int), opt(pick(-1, 0, 1, 256), C.c_int))
     if status(st, h):
+        n = pick(1, 300, 5000)
+        lib.cepstrogramObj_calTimeLength.restype = C.c_int
+        T = lib.cepstrogramObj_calTimeLength(h, n)
+        assert 0 <= T < 10 ** 7
+        F = (1 << cr) // 2 + 1
+        if T * F <= 1 << 22:
+            x = f32(n)
+            o1, o2, o3 = (np.zeros(max(T, 1) * F, np.float32) for _ in range(3))
+            lib.cepstrogramObj_cepstrogram(h, pick(-1, 0, 1, 4, F, F + 5), vp(x), n, vp(o1), vp(o2) if pick(0, 1) else None,
+                                           vp(o3) if pick(0, 1) else None)
         lib.cepstrogramObj_free(h)
     h = C.c_void_p()
     st = lib.spectrogramObj_new(C.byref(h), pick(0, 1, 40, 128, 3000), opt(pick(0, 16000, 32000), C.c_int), opt(pick(-1.0, 0.0, 27.5), C.c_float),
@@ -152,6 +173,15 @@ def fuzz_misc():
                                 opt(irange(-1, 13), C.c_int), opt(pick(-1, 0, 128, 99999), C.c_int), opt(irange(0, 1), C.c_int),
                                 opt(irange(-1, 3), C.c_int), opt(irange(-1, 11), C.c_int), opt(irange(-1, 12), C.c_int), opt(irange(-1, 3), C.c_int))
     if status(st, h):
+        lib.spectrogramObj_getBandNum.restype = C.c_int
+        lib.spectrogramObj_calTimeLength.restype = C.c_int
+        n = pick(1, 600, 20000)
+        bn, T = lib.spectrogramObj_getBandNum(h), lib.spectrogramObj_calTimeLength(h, n)
+        assert 0 <= bn < 10 ** 6 and 0 <= T < 10 ** 7
+        if T * max(bn, 1) <= 1 << 22:
+            x = f32(n)
+            sp, ph = np.zeros(max(T * bn, 1), np.float32), np.zeros(max(T * bn, 1), np.float32)
+            lib.spectrogramObj_spectrogram(h, vp(x), n, vp(sp), vp(ph) if pick(0, 1) else None)
         lib.spectrogramObj_free(h)
     h = C.c_void_p()
     pn, pr = pick(0, 2, 84, 3000), pick(0, 6, 12, 14, 20)
@@ -161,6 +191,10 @@ def fuzz_misc():
                         opt(pick(0.0, 8000.0), C.c_float), opt(pick(0, 12), C.c_int), opt(irange(-1, 8), C.c_int), opt(irange(-1, 12), C.c_int),
                         opt(irange(-1, 3), C.c_int), opt(irange(0, 1), C.c_int))
     if status(st, h):
+        L = 1 << pr
+        if L * pn <= 1 << 22:
+            x, re, im = f32(L), np.zeros(pn * L, np.float32), np.zeros(pn * L, np.float32)
+            lib.pwtObj_pwt(h, vp(x), vp(re), vp(im))
         lib.pwtObj_free(h)
     h = C.c_void_p()
     wn, wr = pick(0, 2, 84, 3000), pick(0, 6, 12, 14, 20)
@@ -170,17 +204,41 @@ def fuzz_misc():
                          opt(pick(0.0, 8000.0), C.c_float), opt(pick(0, 12), C.c_int), opt(irange(-1, 9), C.c_int), opt(irange(-1, 8), C.c_int),
                          opt(pick(0.0, 6.0), C.c_float), opt(pick(0.0, 2.0), C.c_float), opt(pick(-1.0, 0.0, 0.001), C.c_float), opt(irange(0, 1), C.c_int))
     if status(st, h):
+        L = 1 << wr
+        if L * wn <= 1 << 20:
+            x = f32(L)
+            a, b, c, d = (np.zeros(wn * L, np.float32) for _ in range(4))
+            two = pick(0, 1)
+            lib.wsstObj_wsst(h, vp(x), vp(a), vp(b), vp(c) if two else None, vp(d) if two else None)
         lib.wsstObj_free(h)
     h = C.c_void_p()
-    st = lib.reassignObj_new(C.byref(h), pick(0, 1, 9, 11, 15, 31), opt(pick(0, 16000), C.c_int), opt(irange(-1, 13), C.c_int),
+    rr = pick(0, 1, 9, 11, 15, 31)
+    st = lib.reassignObj_new(C.byref(h), rr, opt(pick(0, 16000), C.c_int), opt(irange(-1, 13), C.c_int),
                              opt(pick(-1, 0, 64, 99999), C.c_int), opt(irange(-1, 4), C.c_int), opt(pick(-1.0, 0.0, 0.001), C.c_float),
                              opt(irange(0, 1), C.c_int), opt(irange(0, 1), C.c_int))
     if status(st, h):
+        n = pick(1, 3000, 20000)
+        lib.reassignObj_calTimeLength.restype = C.c_int
+        T = lib.reassignObj_calTimeLength(h, n)
+        assert 0 <= T < 10 ** 7
+        F = (1 << (rr if 1 < rr < 31 else 12)) // 2 + 1  # radix2Exp <= 1 means "default" to this constructor
+        if T * F <= 1 << 22:
+            lib.reassignObj_setResultType(h, pick(0, 1))
+            x = f32(n)
+            a, b, c, d = (np.zeros(max(T, 1) * F, np.float32) for _ in range(4))
+            two = pick(0, 1)
+            lib.reassignObj_reassign(h, vp(x), n, vp(a), vp(b), vp(c) if two else None, vp(d) if two else None)
         lib.reassignObj_free(h)
     h = C.c_void_p()
-    st = lib.synsqObj_new(C.byref(h), pick(0, 1, 84, 100000), pick(0, 1, 12, 20, 31), opt(pick(0, 32000), C.c_int), opt(irange(-1, 3), C.c_int),
+    sn, sr2 = pick(0, 1, 84, 100000), pick(0, 1, 12, 20, 31)
+    st = lib.synsqObj_new(C.byref(h), sn, sr2, opt(pick(0, 32000), C.c_int), opt(irange(-1, 3), C.c_int),
                           opt(pick(-1.0, 0.0, 0.001), C.c_float))
     if status(st, h):
+        L = 1 << sr2
+        if L * sn <= 1 << 20:
+            fre = np.sort(np.abs(f32(sn)) * 1e4 + 20).astype(np.float32)
+            a, b, c, d = (f32(sn * L) for _ in range(4))
+            lib.synsqObj_synsq(h, vp(fre), irange(0, 8), vp(a), vp(b), vp(c), vp(d))
         lib.synsqObj_free(h)
 
 
