@@ -552,6 +552,33 @@ extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    // one workgroup per frame; HIP rejects 2^32 or more threads in one dimension: beyond that, several launches of
+    // whole clips (or, for one long clip, of whole frames)
+    const long long maxFrames = ((1LL << 32) - 1) / threads;
+    if (a->timeLength > maxFrames) {
+        const long long F = N / 2 + 1;
+        long long per = maxFrames;
+        if (a->framesPerClip > 0) {
+            if (a->framesPerClip > maxFrames) {
+                afxdev_set_error("cepstrogram: %d frames per clip in one launch", a->framesPerClip);
+                return AFX_ERR_UNSUPPORTED;
+            }
+            per = maxFrames / a->framesPerClip * a->framesPerClip;
+        }
+        for (long long f0 = 0; f0 < a->timeLength; f0 += per) {
+            AfxCepstrogramArgs s = *a;
+            s.timeLength = (int)(a->timeLength - f0 < per ? a->timeLength - f0 : per);
+            if (a->x) s.x = a->x + (a->framesPerClip > 0 ? f0 / a->framesPerClip * a->clipStride : f0 * a->hop);
+            if (a->specRe) s.specRe = a->specRe + f0 * N;
+            if (a->specIm) s.specIm = a->specIm + f0 * N;
+            if (a->out1) s.out1 = a->out1 + f0 * F;
+            if (a->out2) s.out2 = a->out2 + f0 * F;
+            if (a->out3) s.out3 = a->out3 + f0 * F;
+            hipLaunchKernelGGL(k_cepstrogram, dim3((unsigned)s.timeLength), dim3(threads), lds, (hipStream_t)stream, s);
+            AFX_LAUNCH_CHECK("k_cepstrogram");
+        }
+        return AFX_OK;
+    }
     hipLaunchKernelGGL(k_cepstrogram, dim3((unsigned)a->timeLength), dim3(threads), lds,
                        (hipStream_t)stream, *a);
     AFX_LAUNCH_CHECK("k_cepstrogram");

@@ -69,6 +69,26 @@ extern "C" int afxk_istft(const AfxIstftArgs *a, void *stream) {
     }
     const long long frames = (long long)a->batch * a->timeLength;
     if (frames <= 0) return AFX_OK;
+    // k_istft_frames: one workgroup of <= 256 threads per frame (HIP rejects 2^32 or more threads in one dimension);
+    // k_istft_ola: one grid row per clip (65 535).  Larger batches go out as several launches of whole clips.
+    const long long maxFrames = ((1LL << 32) - 1) / 256;
+    if ((frames > maxFrames || a->batch > 65535) && a->batch > 1 && a->timeLength <= maxFrames) {
+        long long clipsPer = maxFrames / a->timeLength;
+        if (clipsPer > 65535) clipsPer = 65535;
+        const long long rowFloats = 1LL << a->radix2Exp;
+        for (long long b0 = 0; b0 < a->batch; b0 += clipsPer) {
+            AfxIstftArgs s = *a;
+            const long long row0 = b0 * a->timeLength;
+            s.batch = (int)(a->batch - b0 < clipsPer ? a->batch - b0 : clipsPer);
+            s.re = a->re + row0 * rowFloats;
+            s.im = a->im + row0 * rowFloats;
+            s.frames = a->frames + row0 * rowFloats;
+            s.out = a->out + b0 * a->outStride;
+            const int st = afxk_istft(&s, stream);
+            if (st != AFX_OK) return st;
+        }
+        return AFX_OK;
+    }
     if (frames > 0x7fffffffLL || a->batch > 65535) {
         afxdev_set_error("istft: %lld frames / %d clips in one launch", frames, a->batch);
         return AFX_ERR_UNSUPPORTED;

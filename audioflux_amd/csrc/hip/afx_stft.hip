@@ -396,6 +396,30 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_generic),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    // One workgroup per frame, and HIP rejects a launch with 2^32 or more threads in one dimension (16.7 M frames
+    // of 256 threads -- 4 477 clips of 30 s at n_fft 512 / hop 128, 8.6 GB of mel output): such a batch goes out as
+    // several launches of whole clips.  (A single clip beyond the limit still fails in the launch check below.)
+    const long long maxFrames = ((1LL << 32) - 1) / threads;
+    if (frames > maxFrames && a->batch > 1 && a->timeLength <= maxFrames) {
+        const int clipsPer = (int)(maxFrames / a->timeLength);
+        // floats between output rows, as the kernel indexes them: banded rows are packed, bin rows may be pitched
+        const long long pitch = a->bandW ? a->bandNum : (a->outPitch ? a->outPitch : (long long)a->binCount);
+        for (int b0 = 0; b0 < a->batch; b0 += clipsPer) {
+            AfxStftArgs s = *a;
+            const long long row0 = (long long)b0 * a->timeLength;
+            s.batch = a->batch - b0 < clipsPer ? a->batch - b0 : clipsPer;
+            s.x = a->x + (long long)b0 * a->clipStride;
+            s.outRe = a->outRe + row0 * pitch;
+            if (a->outIm) s.outIm = a->outIm + row0 * pitch;
+            if (a->energy) s.energy = a->energy + row0;
+            if (a->rms) s.rms = a->rms + row0;
+            if (a->zcr) s.zcr = a->zcr + row0;
+            hipLaunchKernelGGL(k_stft_generic, dim3((unsigned)((long long)s.batch * s.timeLength)), dim3(threads), lds,
+                               (hipStream_t)stream, s);
+            AFX_LAUNCH_CHECK("k_stft_generic");
+        }
+        return AFX_OK;
+    }
     hipLaunchKernelGGL(k_stft_generic, dim3((unsigned)frames), dim3(threads), lds,
                        (hipStream_t)stream, *a);
     AFX_LAUNCH_CHECK("k_stft_generic");

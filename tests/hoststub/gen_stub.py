@@ -18,8 +18,22 @@ SPECIAL = r'''
 static _Thread_local char g_err[512];
 static _Thread_local int g_errs;
 _Thread_local volatile float afx_stub_sink;
-static void touch_read(const float *p, long long n) { float s = 0; for (long long i = 0; i < n; i++) s += p[i]; afx_stub_sink = s; }
-static void touch_write(float *p, long long n, float v) { for (long long i = 0; i < n; i++) p[i] = v; }
+/* -DAFX_STUB_DRY: "device" allocations are address ranges without memory behind them and nothing is touched -- the
+ * host code can then be driven at sizes that fill a 288 GB device (tests/hoststub/driver_scale.c: size arithmetic
+ * under UBSan + clang's integer checks) */
+#ifdef AFX_STUB_DRY
+#define DRY 1
+#else
+#define DRY 0
+#endif
+static void touch_read(const float *p, long long n) { if (DRY) return; float s = 0; for (long long i = 0; i < n; i++) s += p[i]; afx_stub_sink = s; }
+static void touch_write(float *p, long long n, float v) { if (DRY) return; for (long long i = 0; i < n; i++) p[i] = v; }
+static void *dry_alloc(size_t bytes) {
+    static unsigned long long next = 1ull << 44;
+    void *p = (void *)(size_t)next;
+    next += (bytes + 4095) & ~4095ull;
+    return p;
+}
 
 int afxdev_ensure(void) { return AFX_OK; }
 const char *afxdev_last_error(void) { return g_err; }
@@ -27,18 +41,20 @@ void afxdev_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsn
 int afxdev_error_count(void) { return g_errs; }
 /* (a request beyond 16 GiB fails like hipMalloc would on a full device: the constructor must hand the status on) */
 int afxdev_malloc(void **dptr, size_t bytes) {
+    if (DRY) { *dptr = bytes > ((size_t)288 << 30) ? NULL : dry_alloc(bytes); return *dptr ? AFX_OK : AFX_ERR_NOMEM; }
     *dptr = bytes > ((size_t)1 << 34) ? NULL : malloc(bytes ? bytes : 1);
     return *dptr ? AFX_OK : AFX_ERR_NOMEM;
 }
-void afxdev_free(void *dptr) { free(dptr); }
-int afxdev_memset(void *dptr, int value, size_t bytes, void *stream) { (void)stream; memset(dptr, value, bytes); return AFX_OK; }
-int afxdev_h2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memcpy(dst, src, bytes); return AFX_OK; }
-int afxdev_d2h(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memcpy(dst, src, bytes); return AFX_OK; }
-int afxdev_d2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return AFX_OK; }
+void afxdev_free(void *dptr) { if (!DRY) free(dptr); }
+int afxdev_memset(void *dptr, int value, size_t bytes, void *stream) { (void)stream; if (!DRY) memset(dptr, value, bytes); return AFX_OK; }
+int afxdev_h2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; if (!DRY) memcpy(dst, src, bytes); return AFX_OK; }
+int afxdev_d2h(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; if (!DRY) memcpy(dst, src, bytes); return AFX_OK; }
+int afxdev_d2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; if (!DRY) memmove(dst, src, bytes); return AFX_OK; }
 int afxdev_stream_create(void **stream) { *stream = malloc(8); return *stream ? AFX_OK : AFX_ERR_NOMEM; }
 void afxdev_stream_destroy(void *stream) { free(stream); }
 int afxdev_reserve(void **dptr, size_t *capacity, size_t bytes) {
     if (*dptr && *capacity >= bytes) return AFX_OK;
+    if (DRY) { *dptr = bytes > ((size_t)288 << 30) ? NULL : dry_alloc(bytes); *capacity = *dptr ? bytes : 0; return *dptr ? AFX_OK : AFX_ERR_NOMEM; }
     free(*dptr);
     *dptr = bytes > ((size_t)1 << 34) ? NULL : malloc(bytes ? bytes : 1);  /* exactly what was asked for: an overrun is an ASan report */
     *capacity = *dptr ? bytes : 0;
@@ -53,6 +69,7 @@ int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, i
     return AFX_OK;
 }
 static void cqt_octave_touch(const AfxCqtOctaveArgs *a) {
+    if (DRY) return;
     const int batch = a->batch > 0 ? a->batch : 1;
     for (int b = 0; b < batch; b++) {
         touch_read(a->x + b * a->xStride, a->validLength);
@@ -93,7 +110,7 @@ int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num, c
     touch_read(re, rows * num);
     touch_read(im, rows * num);
     long long s = 0;
-    for (int i = 0; i < chromaNum * num; i++) s += fold[i];
+    for (int i = 0; !DRY && i < chromaNum * num; i++) s += fold[i];
     if (lists) s += lists->start[chromaNum];
     afx_stub_sink = (float)s;
     touch_write(out, rows * chromaNum, 3.f);
@@ -101,11 +118,13 @@ int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num, c
 }
 
 /* ---- the other launchers: footprints as documented in afx_device.h */
-static void touch_rw(float *p, long long n) { for (long long i = 0; i < n; i++) p[i] = p[i] * 0.5f + 1.f; }
+static void touch_rw(float *p, long long n) { if (DRY) return; for (long long i = 0; i < n; i++) p[i] = p[i] * 0.5f + 1.f; }
 static void touch_rows_w(float *p, long long rows, long long width, long long pitch, float v) {
+    if (DRY) return;
     for (long long r = 0; r < rows; r++) touch_write(p + r * pitch, width, v);
 }
 static void touch_rows_r(const float *p, long long rows, long long width, long long pitch) {
+    if (DRY) return;
     for (long long r = 0; r < rows; r++) touch_read(p + r * pitch, width);
 }
 int afxk_stft(const AfxStftArgs *a, void *stream) {

@@ -224,6 +224,109 @@ def test_reference_wrapper_drives_the_cqt_host_code_on_the_cpu(functional, tmp_p
         assert err <= 1e-5, (k, err)
 
 
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (UBSan integer checks)")
+def test_size_arithmetic_at_288_gb_scale(tmp_path):
+    """tests/hoststub/driver_scale.c: every device-pointer entry point at the BASELINE sizes, 20x, and batch sizes whose
+    element counts pass 2^31 / 2^32, against the stand-in device layer in DRY mode (address ranges without memory,
+    launchers do nothing), built with clang -fsanitize=undefined,integer: no wrapped product, truncating conversion or
+    sign change on the way to an allocation size or a pointer offset.  (The GPU tests run at one device's share.)"""
+    tmp = str(tmp_path)
+    stub = os.path.join(tmp, "stub.c")
+    subprocess.run([sys.executable, os.path.join(HERE, "gen_stub.py"),
+                    os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"), stub], check=True)
+    host = sorted(os.path.join(ROOT, "audioflux_amd", "csrc", "host", f)
+                  for f in os.listdir(os.path.join(ROOT, "audioflux_amd", "csrc", "host")) if f.endswith(".c"))
+    exe = os.path.join(tmp, "driver_scale")
+    r = subprocess.run([CLANG, "-std=gnu11", "-g", "-O1", "-DAFX_STUB_DRY", "-fsanitize=undefined,integer", "-fno-omit-frame-pointer",
+                        "-ffp-contract=off", *INC, *host, stub, os.path.join(HERE, "driver_scale.c"), "-lm", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "\nOK" in r.stdout, out[-3000:]
+    assert "runtime error" not in out, "\n".join(ln for ln in out.splitlines() if "runtime error" in ln)[:3000]
+
+
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def launch_audit(tmp_path_factory):
+    """the product's REAL host side -- C objects and the launchers of csrc/hip/*.hip, compiled --cuda-host-only -- with
+    UBSan + clang's integer checks, linked against tests/hoststub/fake_hip.cpp (a HIP runtime that checks every
+    launch configuration instead of launching) and tests/hoststub/driver_scale.c"""
+    if not (os.path.exists(CLANG) and os.path.exists(HIPCC)):
+        pytest.skip("needs hipcc / clang")
+    from concurrent.futures import ThreadPoolExecutor
+    tmp = str(tmp_path_factory.mktemp("audit"))
+    san = ["-g", "-O1", "-fsanitize=undefined,integer", "-fno-omit-frame-pointer"]
+    hipdir, hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "hip"), os.path.join(ROOT, "audioflux_amd", "csrc", "host")
+    jobs = []
+    for f in sorted(os.listdir(hipdir)):
+        if f.endswith(".hip"):
+            jobs.append([HIPCC, "--cuda-host-only", "--offload-arch=gfx950", *san, *INC, "-c", os.path.join(hipdir, f), "-o",
+                         os.path.join(tmp, f[:-4] + "_hip.o")])
+    for f in sorted(os.listdir(hostdir)):
+        if f.endswith(".c"):
+            jobs.append([CLANG, "-std=gnu11", *san, "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o",
+                         os.path.join(tmp, f[:-2] + "_c.o")])
+    jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(HERE, "driver_scale.c"), "-o", os.path.join(tmp, "driver.o")])
+    jobs.append([CLANG + "++", "-std=c++17", *san, "-I/opt/rocm/include", "-c", os.path.join(HERE, "fake_hip.cpp"), "-o",
+                 os.path.join(tmp, "fake_hip.o")])
+    with ThreadPoolExecutor(8) as ex:
+        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+            assert r.returncode == 0, r.stderr[-3000:]
+    objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))
+    # every kernel translation unit refers to its (absent) device code object by a hashed symbol
+    syms = subprocess.run(["nm", "-u", *objs], capture_output=True, text=True).stdout
+    import re
+    with open(os.path.join(tmp, "fatbins.c"), "w") as f:
+        for name in sorted(set(re.findall(r"__hip_fatbin_[0-9a-f]+", syms))):
+            f.write(f"const char {name}[16] = {{0}};\n")
+    r = subprocess.run([CLANG, "-c", os.path.join(tmp, "fatbins.c"), "-o", os.path.join(tmp, "fatbins.o")], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = os.path.join(tmp, "launch_audit")
+    r = subprocess.run([CLANG + "++", *san, *objs, os.path.join(tmp, "fatbins.o"), "-lm", "-lpthread", "-ldl", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.mark.parametrize("env,expect", [("", "k_stft_mel_v2"), ("AFX_NO_FUSED=1", "k_stft_generic"),
+                                        ("AFX_CQT_F32=1", "k_cqt_octave_mfma"), ("AFX_CQT_FUSED=1", "k_cqt_all_f16"),
+                                        ("AFX_CQT_FUSED=2", "k_cqt_all_f16"), ("AFX_CQT_CHROMA_V2=1", "k_cqt_chroma_v2"),
+                                        ("AFX_GEMM_BF16=1", "bf16x3"), ("AFX_CWT_NARROW_MAX=0", "k_cwt_inv_rows512"),
+                                        ("AFX_NO_FUSED_CC=1", "k_cepstrum_mfma"), ("AFX_SCRATCH_MB=64", "k_gemm_nt128")])
+def test_launch_audit(launch_audit, env, expect):
+    """every device-pointer entry point at the BASELINE sizes (must succeed), 20x, and far beyond the device's memory,
+    through the real launchers: no launch configuration outside the HIP limits (block size, grid dimensions, dynamic
+    LDS vs the raised attribute and the 160 KB of a CU), no UBSan / integer-check report in the launch arithmetic, and
+    the kernel the switch is about was reached -- including the kernels that have not been on hardware yet.  Launches
+    with 2^32 or more threads in one dimension are rejected by the stand-in runtime as HIP rejects them; they may only
+    come from batches whose buffers exceed the device (the size-generic STFT / cepstrogram / inverse-STFT launchers
+    split such batches into launches of whole clips -- found here: 4 477 clips of 30 s at n_fft 512 / hop 128 used to
+    fail)."""
+    e = dict(os.environ)
+    for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_GEMM_BF16", "AFX_CWT_NARROW_MAX",
+              "AFX_NO_FUSED_CC", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK"):
+        e.pop(k, None)
+    if env:
+        e.update(kv.split("=") for kv in env.split())
+    e.update(AFX_QUIET="1", AFX_AUDIT_EXPECT=expect)
+    r = subprocess.run([launch_audit], capture_output=True, text=True, env=e, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "\nOK" in r.stdout, out[-3000:]
+    assert "runtime error:" not in out and "VIOLATION" not in out, "\n".join(
+        ln for ln in out.splitlines() if "runtime error:" in ln or "VIOLATION" in ln)[:3000]
+    # what HIP would reject comes only from the sizes beyond the device (the last entries of the size tables)
+    rejected = [ln for ln in r.stdout.splitlines() if "refused (-3)" in ln]
+    assert all(" at 2000000:" in ln or " at 400000:" in ln or " at 3000000:" in ln for ln in rejected), rejected
+
+
 def _tsan_runtime():
     p = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
     return p if os.path.isabs(p) and os.path.exists(p) else None
