@@ -273,13 +273,15 @@ def launch_audit(tmp_path_factory):
         if f.endswith(".c"):
             jobs.append([CLANG, "-std=gnu11", *san, "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o",
                          os.path.join(tmp, f[:-2] + "_c.o")])
-    jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(HERE, "driver_scale.c"), "-o", os.path.join(tmp, "driver.o")])
+    drivers = ("driver_scale", "driver_batch", "driver_cqt")
+    for d in drivers:
+        jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(HERE, d + ".c"), "-o", os.path.join(tmp, d + ".drv")])
     jobs.append([CLANG + "++", "-std=c++17", *san, "-I/opt/rocm/include", "-c", os.path.join(HERE, "fake_hip.cpp"), "-o",
                  os.path.join(tmp, "fake_hip.o")])
     with ThreadPoolExecutor(8) as ex:
         for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
             assert r.returncode == 0, r.stderr[-3000:]
-    objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))
+    objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))  # (the drivers are *.drv)
     # every kernel translation unit refers to its (absent) device code object by a hashed symbol
     syms = subprocess.run(["nm", "-u", *objs], capture_output=True, text=True).stdout
     import re
@@ -289,11 +291,13 @@ def launch_audit(tmp_path_factory):
     r = subprocess.run([CLANG, "-c", os.path.join(tmp, "fatbins.c"), "-o", os.path.join(tmp, "fatbins.o")], capture_output=True,
                        text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    exe = os.path.join(tmp, "launch_audit")
-    r = subprocess.run([CLANG + "++", *san, *objs, os.path.join(tmp, "fatbins.o"), "-lm", "-lpthread", "-ldl", "-o", exe],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return exe
+    exes = {}
+    for d in drivers:
+        exes[d] = os.path.join(tmp, "audit_" + d)
+        r = subprocess.run([CLANG + "++", *san, *objs, os.path.join(tmp, d + ".drv"), os.path.join(tmp, "fatbins.o"), "-lm", "-lpthread",
+                            "-ldl", "-o", exes[d]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    return exes
 
 
 @pytest.mark.parametrize("env,expect", [("", "k_stft_mel_v2"), ("AFX_NO_FUSED=1", "k_stft_generic"),
@@ -317,7 +321,7 @@ def test_launch_audit(launch_audit, env, expect):
     if env:
         e.update(kv.split("=") for kv in env.split())
     e.update(AFX_QUIET="1", AFX_AUDIT_EXPECT=expect)
-    r = subprocess.run([launch_audit], capture_output=True, text=True, env=e, timeout=900)
+    r = subprocess.run([launch_audit["driver_scale"]], capture_output=True, text=True, env=e, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "\nOK" in r.stdout, out[-3000:]
     assert "runtime error:" not in out and "VIOLATION" not in out, "\n".join(
@@ -325,6 +329,30 @@ def test_launch_audit(launch_audit, env, expect):
     # what HIP would reject comes only from the sizes beyond the device (the last entries of the size tables)
     rejected = [ln for ln in r.stdout.splitlines() if "refused (-3)" in ln]
     assert all(" at 2000000:" in ln or " at 400000:" in ln or " at 3000000:" in ln for ln in rejected), rejected
+
+
+@pytest.mark.parametrize("driver,env", [("driver_batch", ""), ("driver_batch", "AFX_SCRATCH_MB=1"), ("driver_batch", "AFX_NO_FUSED=1"),
+                                        ("driver_batch", "AFX_NO_FUSED_CC=1"), ("driver_batch", "AFX_CWT_CHAINS=3 AFX_CWT_GROUP=1"),
+                                        ("driver_batch", "AFX_GEMM_BF16=1"), ("driver_cqt", ""), ("driver_cqt", "AFX_CQT_F32=1"),
+                                        ("driver_cqt", "AFX_NO_FUSED=1"), ("driver_cqt", "AFX_CQT_FUSED=1"),
+                                        ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_CHROMA_V2=1")])
+def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
+    """the configurations of tests/hoststub/driver_batch.c / driver_cqt.c (mel / gammatone / 40-band / temporal banks,
+    STFT and inverse, spectrogram, cepstrogram at two sizes, reassignment, CWT at 2^12 and 2^16 padded and not, PWT,
+    WSST; CQT plans of 84 and 48 bins, short clips, odd strides, 12 and 6 chroma classes) through the real launchers
+    and the checking HIP stand-in"""
+    e = dict(os.environ)
+    for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_GEMM_BF16", "AFX_CWT_CHAINS", "AFX_CWT_GROUP",
+              "AFX_NO_FUSED_CC", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK"):
+        e.pop(k, None)
+    if env:
+        e.update(kv.split("=") for kv in env.split())
+    e.update(AFX_QUIET="1")
+    r = subprocess.run([launch_audit[driver]], capture_output=True, text=True, env=e, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+    assert "runtime error:" not in out and "VIOLATION" not in out and "rejected as HIP" not in out, "\n".join(
+        ln for ln in out.splitlines() if "runtime error:" in ln or "VIOLATION" in ln or "rejected" in ln)[:3000]
 
 
 def _tsan_runtime():
