@@ -262,7 +262,7 @@ def launch_audit(tmp_path_factory):
         pytest.skip("needs hipcc / clang")
     from concurrent.futures import ThreadPoolExecutor
     tmp = str(tmp_path_factory.mktemp("audit"))
-    san = ["-g", "-O1", "-fsanitize=undefined,integer", "-fno-omit-frame-pointer"]
+    san = ["-g", "-O1", "-fPIC", "-fsanitize=undefined,integer", "-fno-omit-frame-pointer"]
     hipdir, hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "hip"), os.path.join(ROOT, "audioflux_amd", "csrc", "host")
     jobs = []
     for f in sorted(os.listdir(hipdir)):
@@ -288,7 +288,7 @@ def launch_audit(tmp_path_factory):
     with open(os.path.join(tmp, "fatbins.c"), "w") as f:
         for name in sorted(set(re.findall(r"__hip_fatbin_[0-9a-f]+", syms))):
             f.write(f"const char {name}[16] = {{0}};\n")
-    r = subprocess.run([CLANG, "-c", os.path.join(tmp, "fatbins.c"), "-o", os.path.join(tmp, "fatbins.o")], capture_output=True,
+    r = subprocess.run([CLANG, "-fPIC", "-c", os.path.join(tmp, "fatbins.c"), "-o", os.path.join(tmp, "fatbins.o")], capture_output=True,
                        text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     exes = {}
@@ -297,6 +297,13 @@ def launch_audit(tmp_path_factory):
         r = subprocess.run([CLANG + "++", *san, *objs, os.path.join(tmp, d + ".drv"), os.path.join(tmp, "fatbins.o"), "-lm", "-lpthread",
                             "-ldl", "-o", exes[d]], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
+    # the same objects as a shared library for the ctypes fuzzers (UBSan runtime as a shared object beside it)
+    rt = os.path.dirname(subprocess.run([CLANG, "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], capture_output=True,
+                                        text=True).stdout.strip())
+    exes["lib"] = os.path.join(tmp, "libafx_audit.so")
+    r = subprocess.run([CLANG + "++", "-shared", *san, "-shared-libsan", *objs, os.path.join(tmp, "fatbins.o"), "-lm", "-lpthread", "-ldl",
+                        f"-Wl,-rpath,{rt}", "-o", exes["lib"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     return exes
 
 
@@ -351,6 +358,20 @@ def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
     r = subprocess.run([launch_audit[driver]], capture_output=True, text=True, env=e, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+    assert "runtime error:" not in out and "VIOLATION" not in out and "rejected as HIP" not in out, "\n".join(
+        ln for ln in out.splitlines() if "runtime error:" in ln or "VIOLATION" in ln or "rejected" in ln)[:3000]
+
+
+@pytest.mark.parametrize("script,seed", [("fuzz_ctor.py", 5), ("fuzz_calls.py", 5)])
+def test_fuzzers_through_the_real_launchers(launch_audit, script, seed):
+    """the constructor / compute-call fuzzers against the launch-audit build: odd sizes, empty inputs, hops longer than
+    a frame ... must not produce an empty grid, an oversized block, an LDS request beyond its attribute or an integer
+    report in a launcher (40 seeds of each were run when this was written: none)"""
+    e = dict(os.environ)
+    e.update(AFX_QUIET="1", AFX_LIB=launch_audit["lib"], AFX_FUZZ_SEED=str(seed))
+    r = subprocess.run([sys.executable, os.path.join(HERE, script), "25"], capture_output=True, text=True, env=e, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "\nOK" in out, out[-3000:]
     assert "runtime error:" not in out and "VIOLATION" not in out and "rejected as HIP" not in out, "\n".join(
         ln for ln in out.splitlines() if "runtime error:" in ln or "VIOLATION" in ln or "rejected" in ln)[:3000]
 
