@@ -56,12 +56,21 @@ static int run(int samplate, int num, int n, int clips, long long stride) {
     return 0;
 }
 
+/* present only in the launch-audit build (tests/hoststub/fake_hip.cpp) */
+extern int fakehip_races(void) __attribute__((weak));
+extern int fakehip_violations(void) __attribute__((weak));
+
 int main(void) {
     /* default plan (84 bins: the f16 / fused paths), an unaligned row stride, a short clip, a 48-bin plan */
     if (run(44100, 84, 30000, 5, 30000)) return 1;
     if (run(44100, 84, 29987, 3, 30077)) return 1;
     if (run(44100, 84, 700, 2, 700)) return 1;
     if (run(16000, 48, 9000, 4, 9000)) return 1;
+    if (fakehip_races && (fakehip_races() || fakehip_violations())) {
+        fprintf(stderr, "%d unordered conflicting launches, %d launch configurations outside the HIP limits\n", fakehip_races(),
+                fakehip_violations());
+        return 1;
+    }
     printf("OK\n");
     return 0;
 }

@@ -8,6 +8,13 @@
 //     must come back from the launcher as a status), nothing zero;
 //   * dynamic LDS <= 64 KB, or <= what hipFuncSetAttribute(MaxDynamicSharedMemorySize) raised it to for that kernel,
 //     and never above the 160 KB of a gfx950 CU.
+// It also keeps the HAPPENS-BEFORE relation of the streams (launch order per stream, hipEventRecord /
+// hipStreamWaitEvent edges, host synchronisation) and, for the CQT kernels -- whose argument lists it decodes -- the
+// address ranges every launch reads and writes: two launches that touch overlapping ranges, at least one writing,
+// without an ordering between them are reported as "FAKEHIP RACE".  That checks the multi-stream schedules of
+// afx_cqt.c (decimations on a side stream, the double-buffered level signals of AFX_CQT_FUSED=2) on the CPU;
+// FAKEHIP_ORDER=1 switches this on; FAKEHIP_DROP_WAIT=<k> ignores the k-th hipStreamWaitEvent (the detector's own
+// test).
 // With it the launch arithmetic of every kernel -- including the ones that have not been on hardware yet
 // (AFX_CQT_FUSED, AFX_CQT_CHROMA_V2, AFX_GEMM_BF16) -- runs at the BASELINE sizes and far beyond them without a
 // GPU.  It says nothing about what the kernels compute.  Test infrastructure, never linked into the product.
@@ -21,14 +28,30 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
+
+#include "afx_device.h"
 
 namespace {
 // constructed on first use: clang's registration hooks run from static constructors of the kernel translation units
+typedef std::map<const void *, unsigned long long> VClock;  // stream -> operations of it that are known to be complete
+struct Access {
+    uintptr_t lo, hi;
+    bool write;
+    const void *stream;
+    unsigned long long stamp;
+    std::string what;
+};
 struct State {
     std::mutex mu;
     std::map<const void *, std::string> names;
     std::map<const void *, int> maxDynLds;
     std::map<std::string, unsigned long long> launches;
+    std::map<const void *, VClock> streams, events;
+    VClock host;
+    std::vector<Access> log;
+    std::map<std::string, int> raceKinds;
+    int waits = 0, races = 0;
 };
 State &st() {
     static State *s = new State;
@@ -57,6 +80,94 @@ void *dry_alloc(size_t bytes) {
     return p;
 }
 
+void merge(VClock &into, const VClock &from) {
+    for (const auto &kv : from) {
+        unsigned long long &v = into[kv.first];
+        if (kv.second > v) v = kv.second;
+    }
+}
+
+// a new operation on `stream` (caller holds the lock): its clock, with its own stamp
+VClock &begin_op(const void *stream, unsigned long long *stamp) {
+    VClock &v = st().streams[stream];
+    merge(v, st().host);
+    *stamp = ++v[stream];
+    return v;
+}
+
+// FAKEHIP_ORDER=1 switches the range bookkeeping on (quadratic in the number of launches: for the small drivers)
+bool order_on() {
+    static const bool on = getenv("FAKEHIP_ORDER") != nullptr;
+    return on;
+}
+
+void touch(const VClock &vc, const void *stream, unsigned long long stamp, const std::string &what, const void *p, long long floats,
+           bool write) {
+    if (!p || floats <= 0 || !order_on()) return;
+    State &S = st();
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + 4ull * (unsigned long long)floats;
+    for (const Access &a : S.log) {
+        if (a.hi <= lo || hi <= a.lo || !(a.write || write)) continue;
+        if (a.stream == stream) continue;  // same stream: in order
+        auto it = vc.find(a.stream);
+        if (it != vc.end() && it->second >= a.stamp) continue;  // ordered by an event or a host synchronisation
+        ++S.races;
+        const std::string kind = a.what + (a.write ? " (write)" : " (read)") + "  <->  " + what + (write ? " (write)" : " (read)");
+        if (S.raceKinds[kind]++ == 0) fprintf(stderr, "FAKEHIP RACE %s: overlapping ranges, no ordering between the streams\n", kind.c_str());
+    }
+    if (S.log.size() > 200000) S.log.erase(S.log.begin(), S.log.begin() + 100000);
+    S.log.push_back(Access{lo, hi, write, stream, stamp, what});
+}
+
+const char *short_name(const std::string &mangled) {
+    static const char *known[] = {"k_cqt_decimate", "k_cqt_octave_f16", "k_cqt_octave_mfma_w", "k_cqt_octave_mfma", "k_cqt_octave",
+                                  "k_cqt_all_f16", "k_cqt_chroma_v2", "k_cqt_chroma"};
+    for (const char *k : known)
+        if (mangled.find(k) != std::string::npos) return k;
+    return nullptr;
+}
+
+// the CQT kernels' argument lists (afx_cqt.hip, afx_cqt_f16.hip, afx_cqt_all.hip) -> the ranges a launch reads / writes
+void record_accesses(const std::string &mangled, dim3 g, void **args, const void *stream) {
+    const char *k = order_on() ? short_name(mangled) : nullptr;
+    if (!k) return;
+    unsigned long long stamp;
+    const VClock vc = begin_op(stream, &stamp);
+    const std::string name = k;
+    if (name == "k_cqt_decimate") {
+        const float *x = *static_cast<const float **>(args[0]);
+        const int srcLen = *static_cast<int *>(args[1]), dstLen = *static_cast<int *>(args[4]);
+        const long long xs = *static_cast<long long *>(args[2]), ys = *static_cast<long long *>(args[5]);
+        float *y = *static_cast<float **>(args[3]);
+        for (unsigned b = 0; b < g.y; ++b) {
+            touch(vc, stream, stamp, name, x + b * xs, srcLen, false);
+            touch(vc, stream, stamp, name, y + b * ys, dstLen, true);
+        }
+    } else if (name.rfind("k_cqt_octave", 0) == 0) {
+        const AfxCqtOctaveArgs &a = *static_cast<const AfxCqtOctaveArgs *>(args[0]);
+        for (int b = 0; b < (a.batch > 0 ? a.batch : 1); ++b) {
+            touch(vc, stream, stamp, name, a.x + b * a.xStride, a.validLength, false);
+            touch(vc, stream, stamp, name, a.outRe + b * a.outStride, (long long)a.timeLength * a.num, true);
+            touch(vc, stream, stamp, name, a.outIm + b * a.outStride, (long long)a.timeLength * a.num, true);
+        }
+    } else if (name == "k_cqt_all_f16") {
+        const AfxCqtAllArgs &a = *static_cast<const AfxCqtAllArgs *>(args[0]);
+        for (int b = 0; b < a.batch; ++b) {
+            for (int l = 0; l < 7; ++l) touch(vc, stream, stamp, name, a.x[l] + b * a.xStride[l], a.validLength[l], false);
+            touch(vc, stream, stamp, name, a.outRe + b * a.outStride, (long long)a.timeLength * a.num, true);
+            touch(vc, stream, stamp, name, a.outIm + b * a.outStride, (long long)a.timeLength * a.num, true);
+            if (a.chroma) touch(vc, stream, stamp, name, a.chroma + b * a.chromaStride, (long long)a.timeLength * 12, true);
+        }
+    } else {  // k_cqt_chroma, k_cqt_chroma_v2: (re, im, rows, num, fold | lists, chromaNum, isMag, normType, out, vec4)
+        const float *re = *static_cast<const float **>(args[0]), *im = *static_cast<const float **>(args[1]);
+        const long long rows = *static_cast<long long *>(args[2]);
+        const int num = *static_cast<int *>(args[3]), cn = *static_cast<int *>(args[5]);
+        touch(vc, stream, stamp, name, re, rows * num, false);
+        touch(vc, stream, stamp, name, im, rows * num, false);
+        touch(vc, stream, stamp, name, *static_cast<float **>(args[8]), rows * cn, true);
+    }
+}
+
 void violation(const std::string &name, const char *what, dim3 g, dim3 b, size_t lds) {
     ++g_violations;
     fprintf(stderr, "FAKEHIP VIOLATION %s: %s (grid %u x %u x %u, block %u x %u x %u, dynamic LDS %zu)\n", name.c_str(), what,
@@ -68,6 +179,7 @@ extern "C" {
 // ---- what the audit driver reads
 int fakehip_violations(void) { return g_violations; }
 int fakehip_rejected(void) { return g_rejected; }
+int fakehip_races(void) { return st().races; }
 void fakehip_report(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (const auto &kv : g_launches) printf("  launched %8llu x %s\n", kv.second, kv.first.c_str());
@@ -108,11 +220,12 @@ hipError_t __hipPopCallConfiguration(dim3 *gridDim, dim3 *blockDim, size_t *shar
     return hipSuccess;
 }
 
-hipError_t hipLaunchKernel(const void *f, dim3 g, dim3 b, void **, size_t lds, hipStream_t) {
+hipError_t hipLaunchKernel(const void *f, dim3 g, dim3 b, void **args, size_t lds, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_names.find(f);
     const std::string name = it == g_names.end() ? std::string("<unregistered kernel>") : it->second;
     ++g_launches[name];
+    record_accesses(name, g, args, stream);
     if (it == g_names.end()) violation(name, "launch of a function that was never registered", g, b, lds);
     const unsigned long long threads = (unsigned long long)b.x * b.y * b.z;
     if (threads == 0 || threads > 1024) violation(name, "block size outside 1..1024", g, b, lds);
@@ -177,18 +290,52 @@ hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t) { return hipMallo
 hipError_t hipFree(void *) { return hipSuccess; }
 hipError_t hipFreeAsync(void *, hipStream_t) { return hipSuccess; }
 hipError_t hipMemcpy(void *, const void *, size_t, hipMemcpyKind) { return hipSuccess; }
-hipError_t hipMemcpyAsync(void *, const void *, size_t, hipMemcpyKind, hipStream_t) { return hipSuccess; }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    unsigned long long stamp;
+    const VClock vc = begin_op(stream, &stamp);
+    if (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToDevice) touch(vc, stream, stamp, "copy", dst, (long long)(bytes / 4), true);
+    if (kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice) touch(vc, stream, stamp, "copy", src, (long long)(bytes / 4), false);
+    return hipSuccess;
+}
 hipError_t hipMemset(void *, int, size_t) { return hipSuccess; }
-hipError_t hipMemsetAsync(void *, int, size_t, hipStream_t) { return hipSuccess; }
+hipError_t hipMemsetAsync(void *dst, int, size_t bytes, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    unsigned long long stamp;
+    const VClock vc = begin_op(stream, &stamp);
+    touch(vc, stream, stamp, "memset", dst, (long long)(bytes / 4), true);
+    return hipSuccess;
+}
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    merge(st().host, st().streams[s]);
+    return hipSuccess;
+}
 hipError_t hipStreamGetDevice(hipStream_t, hipDevice_t *d) { *d = 0; return hipSuccess; }
 int hipGetStreamDeviceId(hipStream_t) { return 0; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const char *drop = getenv("FAKEHIP_DROP_WAIT");
+    if (++st().waits == (drop ? atoi(drop) : -1)) return hipSuccess;  // the detector's own test: this edge is lost
+    merge(st().streams[s], st().events[e]);
+    return hipSuccess;
+}
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = reinterpret_cast<hipEvent_t>(malloc(8)); return hipSuccess; }
-hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    st().events.erase(e);
+    free(e);
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    VClock &v = st().streams[s];
+    merge(v, st().host);
+    st().events[e] = v;
+    return hipSuccess;
+}
 hipError_t hipGetLastError(void) {
     const hipError_t e = t_lastError;
     t_lastError = hipSuccess;

@@ -276,7 +276,7 @@ def launch_audit(tmp_path_factory):
     drivers = ("driver_scale", "driver_batch", "driver_cqt")
     for d in drivers:
         jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(HERE, d + ".c"), "-o", os.path.join(tmp, d + ".drv")])
-    jobs.append([CLANG + "++", "-std=c++17", *san, "-I/opt/rocm/include", "-c", os.path.join(HERE, "fake_hip.cpp"), "-o",
+    jobs.append([CLANG + "++", "-std=c++17", *san, "-I/opt/rocm/include", *INC, "-c", os.path.join(HERE, "fake_hip.cpp"), "-o",
                  os.path.join(tmp, "fake_hip.o")])
     with ThreadPoolExecutor(8) as ex:
         for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
@@ -342,24 +342,44 @@ def test_launch_audit(launch_audit, env, expect):
                                         ("driver_batch", "AFX_NO_FUSED_CC=1"), ("driver_batch", "AFX_CWT_CHAINS=3 AFX_CWT_GROUP=1"),
                                         ("driver_batch", "AFX_GEMM_BF16=1"), ("driver_cqt", ""), ("driver_cqt", "AFX_CQT_F32=1"),
                                         ("driver_cqt", "AFX_NO_FUSED=1"), ("driver_cqt", "AFX_CQT_FUSED=1"),
-                                        ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_CHROMA_V2=1")])
+                                        ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=1"),
+                                        ("driver_cqt", "AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_OVERLAP=0"),
+                                        ("driver_cqt", "AFX_CQT_CHROMA_V2=1")])
 def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
     """the configurations of tests/hoststub/driver_batch.c / driver_cqt.c (mel / gammatone / 40-band / temporal banks,
     STFT and inverse, spectrogram, cepstrogram at two sizes, reassignment, CWT at 2^12 and 2^16 padded and not, PWT,
     WSST; CQT plans of 84 and 48 bins, short clips, odd strides, 12 and 6 chroma classes) through the real launchers
-    and the checking HIP stand-in"""
+    and the checking HIP stand-in.  For the CQT kernels the stand-in also decodes the argument lists and keeps the
+    happens-before relation of the streams: a launch that reads or writes a range another stream's launch writes,
+    without an event or synchronisation between them, is a "FAKEHIP RACE" (the side-stream decimations of the default
+    path, the double-buffered level signals of AFX_CQT_FUSED=2)."""
     e = dict(os.environ)
     for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_GEMM_BF16", "AFX_CWT_CHAINS", "AFX_CWT_GROUP",
-              "AFX_NO_FUSED_CC", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK"):
+              "AFX_NO_FUSED_CC", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "FAKEHIP_DROP_WAIT"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
-    e.update(AFX_QUIET="1")
+    e.update(AFX_QUIET="1", FAKEHIP_ORDER="1")
     r = subprocess.run([launch_audit[driver]], capture_output=True, text=True, env=e, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
-    assert "runtime error:" not in out and "VIOLATION" not in out and "rejected as HIP" not in out, "\n".join(
-        ln for ln in out.splitlines() if "runtime error:" in ln or "VIOLATION" in ln or "rejected" in ln)[:3000]
+    assert "runtime error:" not in out and "VIOLATION" not in out and "rejected as HIP" not in out and "RACE" not in out, "\n".join(
+        ln for ln in out.splitlines() if "runtime error:" in ln or "VIOLATION" in ln or "rejected" in ln or "RACE" in ln)[:3000]
+
+
+@pytest.mark.parametrize("env,pair", [("", "k_cqt_decimate (write)  <->  k_cqt_octave_f16 (read)"),
+                                      ("AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2", "k_cqt_decimate (write)  <->  k_cqt_all_f16 (read)")])
+def test_the_stream_order_check_sees_a_lost_wait(launch_audit, env, pair):
+    """the detector's own test: with the second hipStreamWaitEvent of the run ignored (FAKEHIP_DROP_WAIT=2: "the octave
+    product waits for the decimation that produced its input") the same driver must end in a race report"""
+    e = dict(os.environ)
+    for k in ("AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_NO_FUSED"):
+        e.pop(k, None)
+    if env:
+        e.update(kv.split("=") for kv in env.split())
+    e.update(AFX_QUIET="1", FAKEHIP_ORDER="1", FAKEHIP_DROP_WAIT="2")
+    r = subprocess.run([launch_audit["driver_cqt"]], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 1 and "FAKEHIP RACE " + pair in r.stderr, (r.stdout + r.stderr)[-3000:]
 
 
 @pytest.mark.parametrize("script,seed", [("fuzz_ctor.py", 5), ("fuzz_calls.py", 5)])
