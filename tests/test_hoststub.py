@@ -260,43 +260,9 @@ def launch_audit(tmp_path_factory):
     launch configuration instead of launching) and tests/hoststub/driver_scale.c"""
     if not (os.path.exists(CLANG) and os.path.exists(HIPCC)):
         pytest.skip("needs hipcc / clang")
-    from concurrent.futures import ThreadPoolExecutor
     tmp = str(tmp_path_factory.mktemp("audit"))
     san = ["-g", "-O1", "-fPIC", "-fsanitize=undefined,integer", "-fno-omit-frame-pointer"]
-    hipdir, hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "hip"), os.path.join(ROOT, "audioflux_amd", "csrc", "host")
-    jobs = []
-    for f in sorted(os.listdir(hipdir)):
-        if f.endswith(".hip"):
-            jobs.append([HIPCC, "--cuda-host-only", "--offload-arch=gfx950", *san, *INC, "-c", os.path.join(hipdir, f), "-o",
-                         os.path.join(tmp, f[:-4] + "_hip.o")])
-    for f in sorted(os.listdir(hostdir)):
-        if f.endswith(".c"):
-            jobs.append([CLANG, "-std=gnu11", *san, "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o",
-                         os.path.join(tmp, f[:-2] + "_c.o")])
-    drivers = ("driver_scale", "driver_batch", "driver_cqt")
-    for d in drivers:
-        jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(HERE, d + ".c"), "-o", os.path.join(tmp, d + ".drv")])
-    jobs.append([CLANG + "++", "-std=c++17", *san, "-I/opt/rocm/include", *INC, "-c", os.path.join(HERE, "fake_hip.cpp"), "-o",
-                 os.path.join(tmp, "fake_hip.o")])
-    with ThreadPoolExecutor(8) as ex:
-        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
-            assert r.returncode == 0, r.stderr[-3000:]
-    objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))  # (the drivers are *.drv)
-    # every kernel translation unit refers to its (absent) device code object by a hashed symbol
-    syms = subprocess.run(["nm", "-u", *objs], capture_output=True, text=True).stdout
-    import re
-    with open(os.path.join(tmp, "fatbins.c"), "w") as f:
-        for name in sorted(set(re.findall(r"__hip_fatbin_[0-9a-f]+", syms))):
-            f.write(f"const char {name}[16] = {{0}};\n")
-    r = subprocess.run([CLANG, "-fPIC", "-c", os.path.join(tmp, "fatbins.c"), "-o", os.path.join(tmp, "fatbins.o")], capture_output=True,
-                       text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    exes = {}
-    for d in drivers:
-        exes[d] = os.path.join(tmp, "audit_" + d)
-        r = subprocess.run([CLANG + "++", *san, *objs, os.path.join(tmp, d + ".drv"), os.path.join(tmp, "fatbins.o"), "-lm", "-lpthread",
-                            "-ldl", "-o", exes[d]], capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-3000:]
+    exes, objs = _build_with_fake_hip(tmp, san, ("driver_scale", "driver_batch", "driver_cqt"))
     # the same objects as a shared library for the ctypes fuzzers (UBSan runtime as a shared object beside it)
     rt = os.path.dirname(subprocess.run([CLANG, "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], capture_output=True,
                                         text=True).stdout.strip())
@@ -394,6 +360,51 @@ def test_fuzzers_through_the_real_launchers(launch_audit, script, seed):
     assert r.returncode == 0 and "\nOK" in out, out[-3000:]
     assert "runtime error:" not in out and "VIOLATION" not in out and "rejected as HIP" not in out, "\n".join(
         ln for ln in out.splitlines() if "runtime error:" in ln or "VIOLATION" in ln or "rejected" in ln)[:3000]
+
+
+def _build_with_fake_hip(tmp, san, drivers):
+    """host C objects + the real launchers (--cuda-host-only) + tests/hoststub/fake_hip.cpp + one executable per driver"""
+    from concurrent.futures import ThreadPoolExecutor
+    import re
+    hipdir, hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "hip"), os.path.join(ROOT, "audioflux_amd", "csrc", "host")
+    jobs = [[HIPCC, "--cuda-host-only", "--offload-arch=gfx950", *san, *INC, "-c", os.path.join(hipdir, f), "-o",
+             os.path.join(tmp, f[:-4] + "_hip.o")] for f in sorted(os.listdir(hipdir)) if f.endswith(".hip")]
+    jobs += [[CLANG, "-std=gnu11", *san, "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o",
+              os.path.join(tmp, f[:-2] + "_c.o")] for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
+    jobs += [[CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(HERE, d + ".c"), "-o", os.path.join(tmp, d + ".drv")] for d in drivers]
+    jobs.append([CLANG + "++", "-std=c++17", *san, "-I/opt/rocm/include", *INC, "-c", os.path.join(HERE, "fake_hip.cpp"), "-o",
+                 os.path.join(tmp, "fake_hip.o")])
+    with ThreadPoolExecutor(8) as ex:
+        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+            assert r.returncode == 0, r.stderr[-3000:]
+    objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))
+    syms = subprocess.run(["nm", "-u", *objs], capture_output=True, text=True).stdout
+    with open(os.path.join(tmp, "fatbins.c"), "w") as f:
+        for name in sorted(set(re.findall(r"__hip_fatbin_[0-9a-f]+", syms))):
+            f.write(f"const char {name}[16] = {{0}};\n")
+    r = subprocess.run([CLANG, "-fPIC", "-c", os.path.join(tmp, "fatbins.c"), "-o", os.path.join(tmp, "fatbins.o")], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exes = {}
+    for d in drivers:
+        exes[d] = os.path.join(tmp, "audit_" + d)
+        r = subprocess.run([CLANG + "++", *san, *objs, os.path.join(tmp, d + ".drv"), os.path.join(tmp, "fatbins.o"), "-lm", "-lpthread",
+                            "-ldl", "-o", exes[d]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    return exes, objs
+
+
+@pytest.mark.skipif(not (os.path.exists(CLANG) and os.path.exists(HIPCC)), reason="needs hipcc / clang")
+def test_concurrent_objects_are_race_free_through_the_real_launchers(tmp_path):
+    """tests/hoststub/driver_threads.c (six threads building, using and freeing BFT and CQT objects) with the real
+    launchers under clang's ThreadSanitizer: the launcher-level statics (per-device attribute flags, lazily built
+    tables) as well as the host objects"""
+    exes, _ = _build_with_fake_hip(str(tmp_path), ["-g", "-O1", "-fsanitize=thread", "-fno-omit-frame-pointer"], ("driver_threads",))
+    e = dict(os.environ, AFX_QUIET="1")
+    r = subprocess.run([exes["driver_threads"]], capture_output=True, text=True, env=e, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+    assert "ThreadSanitizer" not in out, out[-3000:]
 
 
 def _tsan_runtime():
