@@ -50,6 +50,7 @@ struct State {
     std::map<const void *, VClock> streams, events;
     VClock host;
     std::vector<Access> log;
+    std::map<uintptr_t, std::vector<char>> uploads;  // small host-to-device copies, kept: index lists the decoders need
     std::map<std::string, int> raceKinds;
     int waits = 0, races = 0;
 };
@@ -119,8 +120,28 @@ void touch(const VClock &vc, const void *stream, unsigned long long stamp, const
     S.log.push_back(Access{lo, hi, write, stream, stamp, what});
 }
 
+// what was uploaded to [p, p + bytes), or nullptr
+const void *uploaded(const void *p, size_t bytes) {
+    State &S = st();
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    auto it = S.uploads.upper_bound(a);
+    if (it == S.uploads.begin()) return nullptr;
+    --it;
+    if (a + bytes > it->first + it->second.size()) return nullptr;
+    return it->second.data() + (a - it->first);
+}
+
+// afx_cwt.hip: struct CwtGeom (kept in step by hand; a mismatch shows up as wild ranges, i.e. as reported races)
+struct CwtGeomView {
+    int r1, r2, dataLength, pad, C;
+    const void *tw, *fastTw;
+    const int *support, *order, *orderLo;
+    int num;
+};
+
 const char *short_name(const std::string &mangled) {
-    static const char *known[] = {"k_cqt_decimate", "k_cqt_octave_f16", "k_cqt_octave_mfma_w", "k_cqt_octave_mfma", "k_cqt_octave",
+    static const char *known[] = {"k_cwt_fwd_cols", "k_cwt_fwd_rows", "k_cwt_inv_rows512", "k_cwt_inv_cols256_nb", "k_cwt_inv_cols256",
+                                  "k_cqt_decimate", "k_cqt_octave_f16", "k_cqt_octave_mfma_w", "k_cqt_octave_mfma", "k_cqt_octave",
                                   "k_cqt_all_f16", "k_cqt_chroma_v2", "k_cqt_chroma"};
     for (const char *k : known)
         if (mangled.find(k) != std::string::npos) return k;
@@ -134,7 +155,60 @@ void record_accesses(const std::string &mangled, dim3 g, void **args, const void
     unsigned long long stamp;
     const VClock vc = begin_op(stream, &stamp);
     const std::string name = k;
-    if (name == "k_cqt_decimate") {
+    if (name.rfind("k_cwt_", 0) == 0) {
+        // the four-step CWT kernels (afx_cwt.hip): chunk = blockIdx.y (forward) / blockIdx.z (inverse), scale slot =
+        // blockIdx.y of the inverse kernels, scale = order[slot] (wide) or orderLo[listBase + slot].x (narrow-band)
+        const CwtGeomView &q = *static_cast<const CwtGeomView *>(args[0]);
+        const long long L = 1LL << (q.r1 + q.r2), D = q.dataLength;
+        if (name == "k_cwt_fwd_cols") {
+            const float *x = *static_cast<const float **>(args[1]);
+            const long long xs = *static_cast<long long *>(args[2]);
+            float *A = *static_cast<float **>(args[3]);
+            for (unsigned c = 0; c < g.y; ++c) {
+                touch(vc, stream, stamp, name, x + c * xs, D, false);
+                touch(vc, stream, stamp, name, A + 2 * L * c, 2 * L, true);
+            }
+        } else if (name == "k_cwt_fwd_rows") {
+            const float *A = *static_cast<const float **>(args[1]);
+            float *Xt = *static_cast<float **>(args[2]);
+            for (unsigned c = 0; c < g.y; ++c) {
+                touch(vc, stream, stamp, name, A + 2 * L * c, 2 * L, false);
+                touch(vc, stream, stamp, name, Xt + 2 * L * c, 2 * L, true);
+            }
+        } else {
+            const bool nb = name == "k_cwt_inv_cols256_nb", rows = name == "k_cwt_inv_rows512";
+            const int listBase = nb ? *static_cast<int *>(args[4]) : 0;
+            const float *in = *static_cast<const float **>(args[1]);  // Xt (rows512, nb) or B (cols256)
+            float *B = rows ? *static_cast<float **>(args[4]) : nullptr;
+            float *outRe = rows ? nullptr : *static_cast<float **>(args[nb ? 5 : 2]);
+            float *outIm = rows ? nullptr : *static_cast<float **>(args[nb ? 6 : 3]);
+            for (unsigned slot = 0; slot < g.y; ++slot) {
+                long long j = slot;
+                if (nb) {
+                    const int *e = static_cast<const int *>(uploaded(q.orderLo + 2 * (listBase + slot), 8));
+                    if (!e) { ++st().races; fprintf(stderr, "FAKEHIP RACE check: %s reads an index list that was never uploaded\n", k); return; }
+                    j = e[0];
+                } else if (q.order) {
+                    const int *e = static_cast<const int *>(uploaded(q.order + slot, 4));
+                    if (!e) { ++st().races; fprintf(stderr, "FAKEHIP RACE check: %s reads an index list that was never uploaded\n", k); return; }
+                    j = e[0];
+                }
+                if (j < 0 || j >= q.num) { ++st().races; fprintf(stderr, "FAKEHIP RACE check: %s scale %lld of %d\n", k, j, q.num); return; }
+                for (unsigned c = 0; c < g.z; ++c) {
+                    const long long row = (long long)c * q.num + j;
+                    if (rows) {
+                        touch(vc, stream, stamp, name, in + 2 * L * c, 2 * L, false);
+                        touch(vc, stream, stamp, name, B + 2 * L * row, 2 * L, true);
+                    } else {
+                        if (nb) touch(vc, stream, stamp, name, in + 2 * L * c, 2 * L, false);
+                        else touch(vc, stream, stamp, name, in + 2 * L * row, 2 * L, false);
+                        touch(vc, stream, stamp, name, outRe + D * row, D, true);
+                        touch(vc, stream, stamp, name, outIm + D * row, D, true);
+                    }
+                }
+            }
+        }
+    } else if (name == "k_cqt_decimate") {
         const float *x = *static_cast<const float **>(args[0]);
         const int srcLen = *static_cast<int *>(args[1]), dstLen = *static_cast<int *>(args[4]);
         const long long xs = *static_cast<long long *>(args[2]), ys = *static_cast<long long *>(args[5]);
@@ -289,11 +363,18 @@ hipError_t hipMalloc(void **p, size_t bytes) { *p = dry_alloc(bytes ? bytes : 1)
 hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t) { return hipMalloc(p, bytes); }
 hipError_t hipFree(void *) { return hipSuccess; }
 hipError_t hipFreeAsync(void *, hipStream_t) { return hipSuccess; }
-hipError_t hipMemcpy(void *, const void *, size_t, hipMemcpyKind) { return hipSuccess; }
+hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (kind == hipMemcpyHostToDevice && bytes <= (1u << 20) && order_on())
+        st().uploads[reinterpret_cast<uintptr_t>(dst)] = std::vector<char>(static_cast<const char *>(src), static_cast<const char *>(src) + bytes);
+    return hipSuccess;
+}
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     unsigned long long stamp;
     const VClock vc = begin_op(stream, &stamp);
+    if (kind == hipMemcpyHostToDevice && bytes <= (1u << 20) && order_on())
+        st().uploads[reinterpret_cast<uintptr_t>(dst)] = std::vector<char>(static_cast<const char *>(src), static_cast<const char *>(src) + bytes);
     if (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToDevice) touch(vc, stream, stamp, "copy", dst, (long long)(bytes / 4), true);
     if (kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice) touch(vc, stream, stamp, "copy", src, (long long)(bytes / 4), false);
     return hipSuccess;

@@ -306,7 +306,8 @@ def test_launch_audit(launch_audit, env, expect):
 
 @pytest.mark.parametrize("driver,env", [("driver_batch", ""), ("driver_batch", "AFX_SCRATCH_MB=1"), ("driver_batch", "AFX_NO_FUSED=1"),
                                         ("driver_batch", "AFX_NO_FUSED_CC=1"), ("driver_batch", "AFX_CWT_CHAINS=3 AFX_CWT_GROUP=1"),
-                                        ("driver_batch", "AFX_GEMM_BF16=1"), ("driver_cqt", ""), ("driver_cqt", "AFX_CQT_F32=1"),
+                                        ("driver_batch", "AFX_GEMM_BF16=1"), ("driver_batch", "AFX_CWT_GROUP=2"),
+                                        ("driver_batch", "AFX_CWT_NARROW_MAX=0"), ("driver_batch", "AFX_CWT_OVERLAP=0"), ("driver_cqt", ""), ("driver_cqt", "AFX_CQT_F32=1"),
                                         ("driver_cqt", "AFX_NO_FUSED=1"), ("driver_cqt", "AFX_CQT_FUSED=1"),
                                         ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=1"),
                                         ("driver_cqt", "AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_OVERLAP=0"),
@@ -318,7 +319,9 @@ def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
     and the checking HIP stand-in.  For the CQT kernels the stand-in also decodes the argument lists and keeps the
     happens-before relation of the streams: a launch that reads or writes a range another stream's launch writes,
     without an event or synchronisation between them, is a "FAKEHIP RACE" (the side-stream decimations of the default
-    path, the double-buffered level signals of AFX_CQT_FUSED=2)."""
+    path, the double-buffered level signals of AFX_CQT_FUSED=2); the same for the four-step CWT kernels, whose scale
+    lists it reads from the retained uploads (forward batch -> narrow-band scales on a side stream + two-pass chunk
+    groups alternating over the chain streams, each with its own intermediate)."""
     e = dict(os.environ)
     for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_GEMM_BF16", "AFX_CWT_CHAINS", "AFX_CWT_GROUP",
               "AFX_NO_FUSED_CC", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "FAKEHIP_DROP_WAIT"):
@@ -346,6 +349,22 @@ def test_the_stream_order_check_sees_a_lost_wait(launch_audit, env, pair):
     e.update(AFX_QUIET="1", FAKEHIP_ORDER="1", FAKEHIP_DROP_WAIT="2")
     r = subprocess.run([launch_audit["driver_cqt"]], capture_output=True, text=True, env=e, timeout=900)
     assert r.returncode == 1 and "FAKEHIP RACE " + pair in r.stderr, (r.stdout + r.stderr)[-3000:]
+
+
+def test_the_stream_order_check_sees_a_lost_wait_in_the_cwt_schedule(launch_audit):
+    """as above for the CWT chains: one of the first dozen wait edges of tests/hoststub/driver_batch.c orders a chain's
+    row pass behind the forward transform -- without it the run must report that pair"""
+    e = dict(os.environ)
+    for k in ("AFX_CWT_CHAINS", "AFX_CWT_GROUP", "AFX_CWT_OVERLAP", "AFX_CWT_NARROW_MAX", "AFX_NO_FUSED"):
+        e.pop(k, None)
+    seen = []
+    for k in range(1, 13):
+        e.update(AFX_QUIET="1", FAKEHIP_ORDER="1", FAKEHIP_DROP_WAIT=str(k))
+        r = subprocess.run([launch_audit["driver_batch"]], capture_output=True, text=True, env=e, timeout=900)
+        seen += [ln for ln in r.stderr.splitlines() if "FAKEHIP RACE k_cwt_fwd_rows (write)  <->  k_cwt_inv_" in ln]
+        if seen:
+            break
+    assert seen, "no dropped wait edge produced a forward -> inverse race report"
 
 
 @pytest.mark.parametrize("script,seed", [("fuzz_ctor.py", 5), ("fuzz_calls.py", 5)])
