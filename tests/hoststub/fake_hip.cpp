@@ -13,6 +13,7 @@
 // address ranges every launch reads and writes: two launches that touch overlapping ranges, at least one writing,
 // without an ordering between them are reported as "FAKEHIP RACE".  That checks the multi-stream schedules of
 // afx_cqt.c (decimations on a side stream, the double-buffered level signals of AFX_CQT_FUSED=2) on the CPU;
+// A decoded range that starts inside one of the library's own allocations and ends past it is a "FAKEHIP OVERRUN".
 // FAKEHIP_ORDER=1 switches this on; FAKEHIP_DROP_WAIT=<k> ignores the k-th hipStreamWaitEvent (the detector's own
 // test).
 // With it the launch arithmetic of every kernel -- including the ones that have not been on hardware yet
@@ -50,6 +51,7 @@ struct State {
     std::map<const void *, VClock> streams, events;
     VClock host;
     std::vector<Access> log;
+    std::map<uintptr_t, size_t> allocs;  // device allocations of the library: base -> bytes
     std::map<uintptr_t, std::vector<char>> uploads;  // small host-to-device copies, kept: index lists the decoders need
     std::map<std::string, int> raceKinds;
     int waits = 0, races = 0;
@@ -76,8 +78,9 @@ void *dry_alloc(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (bytes > DEVICE_BYTES) return nullptr;
     void *p = reinterpret_cast<void *>(static_cast<uintptr_t>(g_next));
-    g_next += (bytes + 4095) & ~4095ull;
+    g_next += ((bytes + 4095) & ~4095ull) + 4096;  // a guard page between allocations: an overrun never lands in the next one
     g_allocated += bytes;
+    st().allocs[reinterpret_cast<uintptr_t>(p)] = bytes;
     return p;
 }
 
@@ -107,6 +110,17 @@ void touch(const VClock &vc, const void *stream, unsigned long long stamp, const
     if (!p || floats <= 0 || !order_on()) return;
     State &S = st();
     const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + 4ull * (unsigned long long)floats;
+    {   // a range that starts inside one of the library's own allocations must end inside it
+        auto al = S.allocs.upper_bound(lo);
+        if (al != S.allocs.begin()) {
+            --al;
+            if (lo < al->first + al->second + 4096 && hi > al->first + al->second) {
+                ++S.races;
+                fprintf(stderr, "FAKEHIP OVERRUN %s %s %llu bytes past an allocation of %zu\n", what.c_str(), write ? "writes" : "reads",
+                        (unsigned long long)(hi - (al->first + al->second)), al->second);
+            }
+        }
+    }
     for (const Access &a : S.log) {
         if (a.hi <= lo || hi <= a.lo || !(a.write || write)) continue;
         if (a.stream == stream) continue;  // same stream: in order
