@@ -65,12 +65,21 @@ __device__ __forceinline__ float dpp_mov(float v, int ctrl) {
 }
 
 __device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigned &hi, unsigned &lo) {
+#ifndef AFX_HOST_EMULATION
     asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
         "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
         "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
         : "=&v"(hi), "=&v"(lo)
         : "v"(x0), "v"(x1), "s"(up));
+#else  // tests/emu (the kernel compiled for the host): the same four roundings in C
+    const _Float16 h0 = (_Float16)(x0 * up), h1 = (_Float16)(x1 * up);
+    const _Float16 l0 = (_Float16)(x0 * up - (float)h0), l1 = (_Float16)(x1 * up - (float)h1);
+    unsigned short b[4];
+    __builtin_memcpy(&b[0], &h0, 2), __builtin_memcpy(&b[1], &h1, 2), __builtin_memcpy(&b[2], &l0, 2), __builtin_memcpy(&b[3], &l1, 2);
+    hi = (unsigned)b[0] | ((unsigned)b[1] << 16);
+    lo = (unsigned)b[2] | ((unsigned)b[3] << 16);
+#endif
 }
 
 // per-lane constants of the kernel
@@ -284,10 +293,12 @@ __global__ __launch_bounds__(256) void k_cqt_all_f16(AfxCqtAllArgs a, int tilesP
     }
     for (; blk < totalBlocks; blk += stride) {
         const int clip = blk / tilesPerClip, t0 = (blk - clip * tilesPerClip) * 32;
-        if (CHROMA && L.lane < 32) {
-            wave_lds_order();
-            float4 *z = reinterpret_cast<float4 *>(L.acc + L.lane * 12);
-            z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CHROMA) {
+            wave_lds_order();  // (outside the lane condition: the host emulation of tests/emu makes it a rendezvous of the wave)
+            if (L.lane < 32) {
+                float4 *z = reinterpret_cast<float4 *>(L.acc + L.lane * 12);
+                z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         tile<2, CHROMA>(a, L, clip, t0, w2, [&] { fetch_window<4>(a, L, clip, t0, w4); });
         tile<4, CHROMA>(a, L, clip, t0, w4, [&] { fetch_window<8>(a, L, clip, t0, w8); });

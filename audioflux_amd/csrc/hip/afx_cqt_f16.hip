@@ -80,12 +80,21 @@ __device__ __forceinline__ float dpp_f(float v, int ctrl) {
 // fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).
 // One asm statement: VALU->VALU dependences are interlocked, and hipcc's own form of this costs 7 instructions.
 __device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigned &hi, unsigned &lo) {
+#ifndef AFX_HOST_EMULATION
     asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
         "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
         "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
         : "=&v"(hi), "=&v"(lo)
         : "v"(x0), "v"(x1), "s"(up));
+#else  // tests/emu (the kernel compiled for the host): the same four roundings in C
+    const _Float16 h0 = (_Float16)(x0 * up), h1 = (_Float16)(x1 * up);
+    const _Float16 l0 = (_Float16)(x0 * up - (float)h0), l1 = (_Float16)(x1 * up - (float)h1);
+    unsigned short b[4];
+    __builtin_memcpy(&b[0], &h0, 2), __builtin_memcpy(&b[1], &h1, 2), __builtin_memcpy(&b[2], &l0, 2), __builtin_memcpy(&b[3], &l1, 2);
+    hi = (unsigned)b[0] | ((unsigned)b[1] << 16);
+    lo = (unsigned)b[2] | ((unsigned)b[3] << 16);
+#endif
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -186,7 +195,9 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
     for (; t < totalTiles; t += stride) {
         const int clip = t / tilesPerClip, t0 = (t - clip * tilesPerClip) * 32;
         stamp(0);  // loop overhead
+#ifndef AFX_HOST_EMULATION
         if (TIMING) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory"); stamp(1); }  // window arrival
+#endif
         // ---- tile exponent: peak of the window -> [2^13, 2^14)
         float peak = 0.f;
 #pragma unroll
@@ -271,7 +282,9 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifndef AFX_HOST_EMULATION
         if (TIMING) { asm volatile("s_nop 0" ::: "memory"); stamp(4); ++ntile; }  // K loop
+#endif
         // ---- D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
         {
             const long long po = (long long)clip * a.outStride;

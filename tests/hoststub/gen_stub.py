@@ -341,8 +341,9 @@ CQT_MARK = "/* ---- CQT launchers: touch what the real kernels touch */"
 REST_MARK = "/* ---- the other launchers: footprints as documented in afx_device.h */"
 
 
-def main(header, out, functional_cqt=False):
-    """functional_cqt: leave the CQT launchers out (tests/hoststub/cqt_functional.c, which computes, supplies them)"""
+def main(header, out, functional_cqt=False, omit=()):
+    """functional_cqt: leave the CQT launchers out (tests/hoststub/cqt_functional.c, which computes, supplies them);
+    omit: further launchers somebody else defines (tests/emu: kernels emulated on the host)"""
     special = SPECIAL
     if functional_cqt:
         head, rest = SPECIAL.split(CQT_MARK)
@@ -355,7 +356,7 @@ def main(header, out, functional_cqt=False):
                         src, flags=re.M | re.S)
     body = [special, "\n/* ---- everything else: accepted, nothing done */\n"]
     for ret, name, args in protos:
-        if name in DONE:
+        if name in DONE or name in omit:
             continue
         ret = " ".join(ret.split())
         args = " ".join(args.split())
@@ -375,4 +376,5 @@ def main(header, out, functional_cqt=False):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], "--functional-cqt" in sys.argv[3:])
+    main(sys.argv[1], sys.argv[2], "--functional-cqt" in sys.argv[3:],
+         [a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("--omit=")])

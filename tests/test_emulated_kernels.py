@@ -1,0 +1,102 @@
+"""CPU-only: DEVICE code of the wave kernels, compiled for the host and run one thread per lane (tests/emu).
+
+tests/emu/hip/hip_runtime.h emulates the slice of HIP / gfx950 the f16 CQT kernels and the bf16 GEMM use -- the MFMA
+operand / result layouts, DPP, readlane, raw buffer loads and stores with their bounds behaviour, LDS with the wave /
+workgroup rendezvous -- and the kernels' .hip files are included unchanged (their two inline-assembly helpers have a C
+twin under AFX_HOST_EMULATION).  The library under test is the C host code + the real launchers of those files + the
+emulated kernels (+ contract-level stand-ins for the rest of the CQT path, tests/hoststub/cqt_functional.c):
+
+  * k_cqt_octave_f16 -- measured and parity-tested on the MI355X -- reproduces the golden CQT here too (1.1e-6; on the
+    device 1.2e-6): that calibrates the emulation;
+  * k_cqt_all_f16 (AFX_CQT_FUSED, seven octaves + chroma in one launch) and k_gemm_nt128_bf16x3 (AFX_GEMM_BF16) were
+    written without hardware access and have never run on a device: their device code meets the golden vectors /
+    a float64 product here, tails and all.
+
+What this cannot show: timing, register pressure, the hardware's own accumulation order inside an MFMA.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+STUB = os.path.join(ROOT, "tests", "hoststub")
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
+
+
+@pytest.fixture(scope="module")
+def emulated(tmp_path_factory):
+    from concurrent.futures import ThreadPoolExecutor
+    tmp = str(tmp_path_factory.mktemp("emu"))
+    stub = os.path.join(tmp, "stub.c")
+    subprocess.run([sys.executable, os.path.join(STUB, "gen_stub.py"), os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"),
+                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16"], check=True)
+    hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "host")
+    jobs = [["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o",
+             os.path.join(tmp, f[:-2] + "_c.o")] for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
+    jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
+    jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-DAFX_EMULATED_F16", "-Wno-unused-function", *INC, "-c",
+                 os.path.join(STUB, "cqt_functional.c"), "-o", os.path.join(tmp, "cqt_functional.o")])
+    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16"):
+        jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o",
+                     os.path.join(tmp, f + ".o")])
+    with ThreadPoolExecutor(8) as ex:
+        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+            assert r.returncode == 0, r.stderr[-3000:]
+    lib = os.path.join(tmp, "libafx_emulated.so")
+    objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))
+    r = subprocess.run([CLANG + "++", "-shared", *objs, "-lm", "-lpthread", "-o", lib], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return lib
+
+
+def _run(lib, script, args, env=""):
+    e = dict(os.environ)
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED", "AFX_CQT_CHROMA_V2", "AFX_CQT_EXP", "AFX_CQT_STORE32"):
+        e.pop(k, None)
+    if env:
+        e.update(kv.split("=") for kv in env.split())
+    e.update(AFX_LIB=lib, AFX_QUIET="1")
+    r = subprocess.run([sys.executable, os.path.join(EMU, script), *args], capture_output=True, text=True, env=e, timeout=1500)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "\nOK" in r.stdout, out[-3000:]
+    return r.stdout
+
+
+def _launches(out):
+    import re
+    m = re.search(r"emulated octave_f16 (\d+), emulated all_f16 (\d+); contract-level octave_f32 (\d+), chroma (\d+)", out)
+    assert m, out[-2000:]
+    return tuple(map(int, m.groups()))
+
+
+def test_octave_kernel_emulated_meets_the_golden_vectors(emulated):
+    """calibration: k_cqt_octave_f16 (all seven hop instantiations, the 12-byte transposed stores) -- the kernel the
+    device runs by default -- through the emulation"""
+    out = _run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max"])
+    f16, fused, f32, chroma = _launches(out)
+    assert f16 == 14 and fused == 0 and f32 == 0 and chroma == 1, out[-500:]  # two calls x 7 octaves, one chroma launch
+
+
+@pytest.mark.parametrize("env,case,chromas", [("AFX_CQT_FUSED=1", "c84_32k_area", ["power_max", "mag_p2"]),
+                                              ("AFX_CQT_FUSED=2 AFX_CQT_CHUNK=1", "c84_32k_area", ["p1"]),
+                                              ("AFX_CQT_FUSED=1", "c84_44k_none_noscale", ["none", "power_max"])])
+def test_all_octave_kernel_emulated_meets_the_golden_vectors(emulated, env, case, chromas):
+    """k_cqt_all_f16 (never on hardware): CQT and chroma of the golden cases from ONE emulated launch per pass -- level
+    walk, next-level prefetch, per-level multipliers, chroma accumulation and normalisation, tail tiles (235 frames),
+    an odd row stride; no octave or chroma launch besides it"""
+    out = _run(emulated, "emulated_cqt.py", [case, *chromas], env)
+    f16, fused, f32, chroma = _launches(out)
+    assert fused > 0 and f16 == 0 and f32 == 0 and chroma == 0, out[-500:]
+
+
+def test_bf16x3_gemm_emulated_matches_float64(emulated):
+    """k_gemm_nt128_bf16x3 (never on hardware): loader / three-word split / 24 MFMAs per k-step / epilogue with every
+    tail, elementwise against float64 on operands spanning ten decades"""
+    out = _run(emulated, "emulated_gemm.py", [])
+    assert out.count("elementwise relative error") == 3
