@@ -501,6 +501,7 @@ __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ 
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 ev[9], ov[9];
     const unsigned ae = (unsigned)(size_t)XE + 16u * tid, ao = (unsigned)(size_t)XO + 16u * tid;
+#ifndef AFX_HOST_EMULATION
 #define DEC_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
     DEC_RD(ev[0], ae, 0);   DEC_RD(ov[0], ao, 0);   DEC_RD(ev[1], ae, 16);  DEC_RD(ov[1], ao, 16);
     DEC_RD(ev[2], ae, 32);  DEC_RD(ov[2], ao, 32);  DEC_RD(ev[3], ae, 48);  DEC_RD(ov[3], ao, 48);
@@ -509,11 +510,20 @@ __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ 
     DEC_RD(ev[8], ae, 128); DEC_RD(ov[8], ao, 128);
 #undef DEC_RD
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else  // tests/emu (the kernel compiled for the host): the same 9 + 9 sixteen-byte reads
+    (void)ae, (void)ao;
+    for (int b = 0; b < 9; ++b) {
+        ev[b] = *reinterpret_cast<const f4 *>(XE + 4 * tid + 4 * b);
+        ov[b] = *reinterpret_cast<const f4 *>(XO + 4 * tid + 4 * b);
+    }
+#endif
     float E[36], O[36];
 #pragma unroll
     for (int b = 0; b < 9; ++b) {
+#ifndef AFX_HOST_EMULATION
         // the asm results are only defined after the wait above: pin the uses behind it
         asm volatile("" : "+v"(ev[b]), "+v"(ov[b]));
+#endif
         E[4 * b] = ev[b].x; E[4 * b + 1] = ev[b].y; E[4 * b + 2] = ev[b].z; E[4 * b + 3] = ev[b].w;
         O[4 * b] = ov[b].x; O[4 * b + 1] = ov[b].y; O[4 * b + 2] = ov[b].z; O[4 * b + 3] = ov[b].w;
     }

@@ -138,6 +138,31 @@ static inline emu_f32x16 emu_mfma_32x32x16_f16(emu_h8 a, emu_h8 b, emu_f32x16 c)
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16_f16((a), (b), (c))
 
+// v_mfma_f32_32x32x2_f32: A operand lane l = row l & 31, k = l >> 5; B operand lane l = column l & 31, k = l >> 5
+static inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c) {
+    unsigned *x = emu::exchange();
+    const int l = emu::lane();
+    memcpy(x + l * 32, &a, 4);
+    memcpy(x + l * 32 + 1, &b, 4);
+    emu::wave_barrier();
+    const int col = l & 31, g = l >> 5;
+    emu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(__uint_as_float(x[(row + 32 * k) * 32]), __uint_as_float(x[(col + 32 * k) * 32 + 1]), acc);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2_f32((a), (b), (c))
+static inline unsigned __brev(unsigned v) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+
 // v_mfma_f32_32x32x16_bf16: the same operand / result layout with bf16 words
 typedef __bf16 emu_bf8 __attribute__((ext_vector_type(8)));
 static inline float emu_bf16_value(unsigned short w) { return __uint_as_float((unsigned)w << 16); }

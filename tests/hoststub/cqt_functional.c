@@ -95,7 +95,6 @@ static double *image_from_words(const unsigned short *words, const float *colMul
 
 static int hop_is_f16(int hop) { return hop == 128 || hop == 64 || hop == 32 || hop == 16 || hop == 8 || hop == 4 || hop == 2; }
 
-#ifndef AFX_EMULATED_F16 /* tests/emu supplies the two f16 launchers: the kernels' device code, emulated on the host */
 int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
     (void)stream;
     if (!a->timeKernelH || !a->colMul || a->colTiles != 1 || a->radix2Exp != 9 || !hop_is_f16(a->hop)) return AFX_ERR_UNSUPPORTED;
@@ -107,8 +106,6 @@ int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
     free(G);
     return AFX_OK;
 }
-
-#endif
 
 int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream) {
     const int st = afxk_cqt_octave_f16(a, stream);
@@ -195,7 +192,6 @@ int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num, c
     return AFX_OK;
 }
 
-#ifndef AFX_EMULATED_F16
 /* level l = signal decimated l times, hop 128 >> l, octave 6 - l, one shared image */
 int afxk_cqt_all_f16(const AfxCqtAllArgs *a, void *stream) {
     (void)stream;
@@ -212,4 +208,3 @@ int afxk_cqt_all_f16(const AfxCqtAllArgs *a, void *stream) {
                         a->normType, a->chroma + b * a->chromaStride);
     return AFX_OK;
 }
-#endif

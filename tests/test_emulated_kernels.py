@@ -3,14 +3,15 @@
 tests/emu/hip/hip_runtime.h emulates the slice of HIP / gfx950 the f16 CQT kernels and the bf16 GEMM use -- the MFMA
 operand / result layouts, DPP, readlane, raw buffer loads and stores with their bounds behaviour, LDS with the wave /
 workgroup rendezvous -- and the kernels' .hip files are included unchanged (their two inline-assembly helpers have a C
-twin under AFX_HOST_EMULATION).  The library under test is the C host code + the real launchers of those files + the
-emulated kernels (+ contract-level stand-ins for the rest of the CQT path, tests/hoststub/cqt_functional.c):
+twin under AFX_HOST_EMULATION; afx_cqt.hip's two static LDS arrays become host statics).  The library under test is
+the C host code + the real launchers of those files + their kernels, emulated: every launch of the CQT path.
 
-  * k_cqt_octave_f16 -- measured and parity-tested on the MI355X -- reproduces the golden CQT here too (1.1e-6; on the
-    device 1.2e-6): that calibrates the emulation;
-  * k_cqt_all_f16 (AFX_CQT_FUSED, seven octaves + chroma in one launch) and k_gemm_nt128_bf16x3 (AFX_GEMM_BF16) were
-    written without hardware access and have never run on a device: their device code meets the golden vectors /
-    a float64 product here, tails and all.
+  * the shipped kernels -- k_cqt_decimate, k_cqt_octave_f16, k_cqt_chroma, and the f32 matrix-core octave kernels, all
+    measured and parity-tested on the MI355X -- reproduce the golden CQT / chroma here too (1.1e-6; on the device
+    1.2e-6): that calibrates the emulation;
+  * k_cqt_all_f16 (AFX_CQT_FUSED, seven octaves + chroma in one launch), k_cqt_chroma_v2 (AFX_CQT_CHROMA_V2) and
+    k_gemm_nt128_bf16x3 (AFX_GEMM_BF16) were written without hardware access and have never run on a device: their
+    device code meets the golden vectors / a float64 product here, tails and all.
 
 What this cannot show: timing, register pressure, the hardware's own accumulation order inside an MFMA.
 """
@@ -31,20 +32,34 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (
 
 @pytest.fixture(scope="module")
 def emulated(tmp_path_factory):
+    """C host objects + the launchers AND kernels of afx_cqt.hip, afx_cqt_f16.hip, afx_cqt_all.hip, afx_gemm_bf16.hip compiled
+    for the host (every CQT launch is emulated device code) + the stand-in for the rest of the device layer"""
+    import re
     from concurrent.futures import ThreadPoolExecutor
     tmp = str(tmp_path_factory.mktemp("emu"))
     stub = os.path.join(tmp, "stub.c")
     subprocess.run([sys.executable, os.path.join(STUB, "gen_stub.py"), os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"),
                     stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16"], check=True)
+    # afx_cqt.hip keeps two arrays in static LDS: on the host, storage shared by the lanes' threads
+    src = open(os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_cqt.hip")).read()
+    patched, n = re.subn(r"(?m)^(\s*)__shared__ ", r"\1static ", src)
+    assert n == 2, n
+    with open(os.path.join(tmp, "afx_cqt_host.hip"), "w") as f:
+        f.write(patched)
+    with open(os.path.join(tmp, "cqt_emulated_main.cpp"), "w") as f:
+        f.write('#include "hip/hip_runtime.h"\nnamespace {\nalignas(16) unsigned char smem_raw[160 * 1024];\n}\n'
+                f'#include "{tmp}/afx_cqt_host.hip"\n')
     hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "host")
     jobs = [["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o",
              os.path.join(tmp, f[:-2] + "_c.o")] for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
-    jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
-    jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-DAFX_EMULATED_F16", "-Wno-unused-function", *INC, "-c",
-                 os.path.join(STUB, "cqt_functional.c"), "-o", os.path.join(tmp, "cqt_functional.o")])
+    # (the stand-in's own afxk_cqt_deconv steps aside: afx_cqt.hip brings the real launcher)
+    jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", "-Dafxk_cqt_deconv=afxk_cqt_deconv_standin", *INC, "-c", stub, "-o",
+                 os.path.join(tmp, "stub.o")])
     for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16"):
         jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o",
                      os.path.join(tmp, f + ".o")])
+    jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
+                 os.path.join(tmp, "cqt_emulated_main.o")])
     with ThreadPoolExecutor(8) as ex:
         for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
             assert r.returncode == 0, r.stderr[-3000:]
@@ -57,7 +72,8 @@ def emulated(tmp_path_factory):
 
 def _run(lib, script, args, env=""):
     e = dict(os.environ)
-    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED", "AFX_CQT_CHROMA_V2", "AFX_CQT_EXP", "AFX_CQT_STORE32"):
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED", "AFX_CQT_CHROMA_V2", "AFX_CQT_EXP", "AFX_CQT_STORE32",
+              "AFX_CQT_OVERLAP"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
@@ -70,17 +86,23 @@ def _run(lib, script, args, env=""):
 
 def _launches(out):
     import re
-    m = re.search(r"emulated octave_f16 (\d+), emulated all_f16 (\d+); contract-level octave_f32 (\d+), chroma (\d+)", out)
+    m = re.search(r"emulated octave_f16 (\d+), emulated all_f16 (\d+);.*\n\s+emulated decimate (\d+), chroma (\d+), chroma_v2 (\d+), "
+                  r"octave_mfma \(f32\) (\d+)", out)
     assert m, out[-2000:]
-    return tuple(map(int, m.groups()))
+    return dict(zip(("octave_f16", "all_f16", "decimate", "chroma", "chroma_v2", "octave_f32"), map(int, m.groups())))
 
 
-def test_octave_kernel_emulated_meets_the_golden_vectors(emulated):
-    """calibration: k_cqt_octave_f16 (all seven hop instantiations, the 12-byte transposed stores) -- the kernel the
-    device runs by default -- through the emulation"""
-    out = _run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max"])
-    f16, fused, f32, chroma = _launches(out)
-    assert f16 == 14 and fused == 0 and f32 == 0 and chroma == 1, out[-500:]  # two calls x 7 octaves, one chroma launch
+def test_shipped_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
+    """calibration: the kernels the device runs by default -- k_cqt_decimate, k_cqt_octave_f16 (all seven hop
+    instantiations, the 12-byte transposed stores), k_cqt_chroma -- through the emulation"""
+    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min"]))
+    assert n["octave_f16"] == 21 and n["decimate"] == 18 and n["chroma"] == 2 and n["all_f16"] + n["chroma_v2"] + n["octave_f32"] == 0, n
+
+
+def test_f32_matrix_core_octave_kernels_emulated(emulated):
+    """calibration of the f32 MFMA model: k_cqt_octave_mfma / _mfma_w (AFX_CQT_F32=1; measured on the device in round 1)"""
+    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_44k_none_noscale", "power_max"], "AFX_CQT_F32=1"))
+    assert n["octave_f32"] == 14 and n["octave_f16"] == 0, n
 
 
 @pytest.mark.parametrize("env,case,chromas", [("AFX_CQT_FUSED=1", "c84_32k_area", ["power_max", "mag_p2"]),
@@ -90,9 +112,15 @@ def test_all_octave_kernel_emulated_meets_the_golden_vectors(emulated, env, case
     """k_cqt_all_f16 (never on hardware): CQT and chroma of the golden cases from ONE emulated launch per pass -- level
     walk, next-level prefetch, per-level multipliers, chroma accumulation and normalisation, tail tiles (235 frames),
     an odd row stride; no octave or chroma launch besides it"""
-    out = _run(emulated, "emulated_cqt.py", [case, *chromas], env)
-    f16, fused, f32, chroma = _launches(out)
-    assert fused > 0 and f16 == 0 and f32 == 0 and chroma == 0, out[-500:]
+    n = _launches(_run(emulated, "emulated_cqt.py", [case, *chromas], env))
+    assert n["all_f16"] > 0 and n["decimate"] > 0 and n["octave_f16"] + n["octave_f32"] + n["chroma"] + n["chroma_v2"] == 0, n
+
+
+def test_chroma_v2_emulated_meets_the_golden_vectors(emulated):
+    """k_cqt_chroma_v2 (AFX_CQT_CHROMA_V2; never on hardware -- an earlier version of it hung the device): 12 and 6
+    classes, max and min normalisation, on the emulated CQT rows"""
+    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min", "mag_p2"], "AFX_CQT_CHROMA_V2=1"))
+    assert n["chroma_v2"] == 3 and n["chroma"] == 0, n
 
 
 def test_bf16x3_gemm_emulated_matches_float64(emulated):
