@@ -231,6 +231,10 @@ static inline emu_u32x4 emu_load_b128(const __amdgpu_buffer_rsrc_t &r, int voff,
 
 // ---- afx_pkmath.h: packed-math helpers written in gfx950 assembly; the CQT kernels use only this one
 #define AFX_PKMATH_H
+#ifdef AFX_EMU_NO_LDS_ORDER  // the race check's own test: with the ordering points gone ThreadSanitizer must complain
+static inline void wave_lds_order() {}
+#else
 static inline void wave_lds_order() { emu::wave_barrier(); }
+#endif
 
 #endif

@@ -101,13 +101,13 @@ def test_shipped_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
 
 def test_f32_matrix_core_octave_kernels_emulated(emulated):
     """calibration of the f32 MFMA model: k_cqt_octave_mfma / _mfma_w (AFX_CQT_F32=1; measured on the device in round 1)"""
-    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_44k_none_noscale", "power_max"], "AFX_CQT_F32=1"))
+    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max"], "AFX_CQT_F32=1"))
     assert n["octave_f32"] == 14 and n["octave_f16"] == 0, n
 
 
 @pytest.mark.parametrize("env,case,chromas", [("AFX_CQT_FUSED=1", "c84_32k_area", ["power_max", "mag_p2"]),
                                               ("AFX_CQT_FUSED=2 AFX_CQT_CHUNK=1", "c84_32k_area", ["p1"]),
-                                              ("AFX_CQT_FUSED=1", "c84_44k_none_noscale", ["none", "power_max"])])
+                                              ("AFX_CQT_FUSED=1", "c84_44k_none_noscale", ["none"])])
 def test_all_octave_kernel_emulated_meets_the_golden_vectors(emulated, env, case, chromas):
     """k_cqt_all_f16 (never on hardware): CQT and chroma of the golden cases from ONE emulated launch per pass -- level
     walk, next-level prefetch, per-level multipliers, chroma accumulation and normalisation, tail tiles (235 frames),
@@ -119,8 +119,8 @@ def test_all_octave_kernel_emulated_meets_the_golden_vectors(emulated, env, case
 def test_chroma_v2_emulated_meets_the_golden_vectors(emulated):
     """k_cqt_chroma_v2 (AFX_CQT_CHROMA_V2; never on hardware -- an earlier version of it hung the device): 12 and 6
     classes, max and min normalisation, on the emulated CQT rows"""
-    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min", "mag_p2"], "AFX_CQT_CHROMA_V2=1"))
-    assert n["chroma_v2"] == 3 and n["chroma"] == 0, n
+    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min"], "AFX_CQT_CHROMA_V2=1"))
+    assert n["chroma_v2"] == 2 and n["chroma"] == 0, n
 
 
 def test_bf16x3_gemm_emulated_matches_float64(emulated):
@@ -128,3 +128,72 @@ def test_bf16x3_gemm_emulated_matches_float64(emulated):
     tail, elementwise against float64 on operands spanning ten decades"""
     out = _run(emulated, "emulated_gemm.py", [])
     assert out.count("elementwise relative error") == 3
+
+
+@pytest.fixture(scope="module")
+def emulated_tsan(tmp_path_factory):
+    """the same objects under clang's ThreadSanitizer with two small C drivers (tests/emu/driver_emu_small.c, _gemm.c); a
+    second build of the f16 octave kernel with its LDS ordering points removed (the check's own test)"""
+    import re
+    from concurrent.futures import ThreadPoolExecutor
+    tmp = str(tmp_path_factory.mktemp("emu_tsan"))
+    san = ["-O1", "-gline-tables-only", "-fsanitize=thread", "-fno-omit-frame-pointer"]
+    stub = os.path.join(tmp, "stub.c")
+    subprocess.run([sys.executable, os.path.join(STUB, "gen_stub.py"), os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"),
+                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16"], check=True)
+    src = open(os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_cqt.hip")).read()
+    with open(os.path.join(tmp, "afx_cqt_host.hip"), "w") as f:
+        f.write(re.sub(r"(?m)^(\s*)__shared__ ", r"\1static ", src))
+    with open(os.path.join(tmp, "cqt_emulated_main.cpp"), "w") as f:
+        f.write('#include "hip/hip_runtime.h"\nnamespace {\nalignas(16) unsigned char smem_raw[160 * 1024];\n}\n'
+                f'#include "{tmp}/afx_cqt_host.hip"\n')
+    hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "host")
+    jobs = [[CLANG, "-std=gnu11", *san, "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o", os.path.join(tmp, f[:-2] + "_c.o")]
+            for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
+    jobs.append([CLANG, "-std=gnu11", *san, "-Dafxk_cqt_deconv=afxk_cqt_deconv_standin", *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
+    for d in ("driver_emu_small", "driver_emu_gemm"):
+        jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(EMU, d + ".c"), "-o", os.path.join(tmp, d + ".drv")])
+    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16"):
+        jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o", os.path.join(tmp, f + ".o")])
+    jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
+                 os.path.join(tmp, "cqt_emulated_main.o")])
+    jobs.append([CLANG + "++", "-std=c++17", *san, "-DAFX_EMU_NO_LDS_ORDER", f"-I{EMU}", *INC, "-c", os.path.join(EMU, "cqt_emulated_f16.cpp"),
+                 "-o", os.path.join(tmp, "cqt_emulated_f16.neg")])
+    with ThreadPoolExecutor(8) as ex:
+        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+            assert r.returncode == 0, r.stderr[-3000:]
+    objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))
+    exes = {}
+    for name, drv, swap in (("small", "driver_emu_small.drv", None), ("gemm", "driver_emu_gemm.drv", None),
+                            ("negative", "driver_emu_small.drv", "cqt_emulated_f16")):
+        use = [o for o in objs if not (swap and o.endswith(swap + ".o"))] + ([os.path.join(tmp, swap + ".neg")] if swap else [])
+        exes[name] = os.path.join(tmp, "emu_tsan_" + name)
+        r = subprocess.run([CLANG + "++", *san, *use, os.path.join(tmp, drv), "-lm", "-lpthread", "-o", exes[name]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    return exes
+
+
+@pytest.mark.parametrize("exe,env", [("small", ""), ("small", "AFX_CQT_FUSED=1"), ("small", "AFX_CQT_CHROMA_V2=1"), ("small", "AFX_CQT_F32=1"),
+                                     ("small", "AFX_CQT_STORE32=1"), ("gemm", "")])
+def test_emulated_kernels_have_no_lds_races(emulated_tsan, exe, env):
+    """the lanes of an emulated kernel are host threads that meet only at the kernel's own cross-lane operations and
+    LDS-ordering points (wave_lds_order, __syncthreads): under ThreadSanitizer an LDS word written by one lane and read
+    by another without such a point in between is a data race -- a missing ordering point in the kernel, which on the
+    device shows up only when the compiler or the hardware reorders the two accesses.  None in the shipped kernels, none
+    in k_cqt_all_f16 / k_cqt_chroma_v2 / k_gemm_nt128_bf16x3."""
+    e = dict(os.environ)
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED", "AFX_CQT_CHROMA_V2", "AFX_CQT_EXP", "AFX_CQT_STORE32"):
+        e.pop(k, None)
+    if env:
+        e.update(kv.split("=") for kv in env.split())
+    e.update(AFX_QUIET="1")
+    r = subprocess.run([emulated_tsan[exe]], capture_output=True, text=True, env=e, timeout=1500)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+    assert "ThreadSanitizer" not in out, out[-3000:]
+
+
+def test_the_lds_race_check_sees_missing_ordering_points(emulated_tsan):
+    """with k_cqt_octave_f16's wave_lds_order() calls compiled out the same run is full of reports"""
+    r = subprocess.run([emulated_tsan["negative"]], capture_output=True, text=True, env=dict(os.environ, AFX_QUIET="1"), timeout=1500)
+    assert "WARNING: ThreadSanitizer: data race" in r.stderr and "k_cqt_octave_f16" in r.stderr, (r.stdout + r.stderr)[-2000:]

@@ -108,7 +108,7 @@ def test_every_gpu_test_case_drives_clean_host_code(built):
     assert ran >= 150, f"only {ran} tests reached the library"
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 35])
+@pytest.mark.parametrize("seed", [1, 35])
 def test_constructor_arguments_fuzz(built, seed):
     """tests/hoststub/fuzz_ctor.py: random valid / borderline / invalid constructor arguments for every object through
     raw ctypes against the sanitized host code: a handle and status 0, or a refusal -- never a crash or a sanitizer
@@ -127,7 +127,7 @@ def test_constructor_arguments_fuzz(built, seed):
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
 
 
-@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("seed", [1])
 def test_compute_call_edges_fuzz(built, seed):
     """tests/hoststub/fuzz_calls.py: zero / one-sample / shorter-than-a-frame inputs, batch 0, overlapping clip strides,
     NULL outputs, padding and streaming switches on ordinary BFT / STFT / CQT / XXCC objects"""
