@@ -73,6 +73,11 @@ static inline hipError_t hipMalloc(T **p, size_t n) { *p = static_cast<T *>(call
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }  // few "CUs": few workgroups
 
 // ---- launch: workgroups one after the other, one thread per lane
 namespace emu {
@@ -107,7 +112,11 @@ static inline int emu_mov_dpp(int v, int ctrl) {
 #define __builtin_amdgcn_readfirstlane(v) emu_readlane((v), 0)
 #define __builtin_amdgcn_mov_dpp(v, ctrl, rowmask, bankmask, bc) emu_mov_dpp((v), (ctrl))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#ifdef AFX_EMU_NO_LDS_ORDER  // the race check's own test: with the ordering points gone ThreadSanitizer must complain
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+#else
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
+#endif
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_memrealtime() 0ull
@@ -229,12 +238,44 @@ static inline emu_u32x4 emu_load_b128(const __amdgpu_buffer_rsrc_t &r, int voff,
             emu_buf_store((r), _o + 12, _v.w);                                             \
     } while (0)
 
-// ---- afx_pkmath.h: packed-math helpers written in gfx950 assembly; the CQT kernels use only this one
-#define AFX_PKMATH_H
-#ifdef AFX_EMU_NO_LDS_ORDER  // the race check's own test: with the ordering points gone ThreadSanitizer must complain
-static inline void wave_lds_order() {}
-#else
-static inline void wave_lds_order() { emu::wave_barrier(); }
-#endif
+// ---- wave shuffles, fast-math intrinsics
+template <class T>
+static inline T emu_shfl_from(T v, int src) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+    int u;
+    memcpy(&u, &v, 4);
+    u = emu_readlane(u, src);
+    T r;
+    memcpy(&r, &u, 4);
+    return r;
+}
+template <class T>
+static inline T __shfl(T v, int src, int = 64) { return emu_shfl_from(v, src & 63); }
+template <class T>
+static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl_from(v, emu::lane() ^ mask); }
+template <class T>
+static inline T __shfl_up(T v, int delta, int = 64) { return emu_shfl_from(v, emu::lane() >= delta ? emu::lane() - delta : emu::lane()); }
+#define __log2f(x) log2f(x)
+
+// v_mfma_f32_16x16x4_f32: A operand lane l = row l & 15, k = l >> 4; B operand lane l = column l & 15, k = l >> 4;
+// D register r of lane l = row 4 (l >> 4) + r, column l & 15
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+static inline emu_f32x4 emu_mfma_16x16x4_f32(float a, float b, emu_f32x4 c) {
+    unsigned *x = emu::exchange();
+    const int l = emu::lane();
+    memcpy(x + l * 32, &a, 4);
+    memcpy(x + l * 32 + 1, &b, 4);
+    emu::wave_barrier();
+    emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(__uint_as_float(x[(row + 16 * k) * 32]), __uint_as_float(x[(col + 16 * k) * 32 + 1]), acc);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_16x16x4_f32((a), (b), (c))
 
 #endif

@@ -6,9 +6,9 @@ workgroup rendezvous -- and the kernels' .hip files are included unchanged (thei
 twin under AFX_HOST_EMULATION; afx_cqt.hip's two static LDS arrays become host statics).  The library under test is
 the C host code + the real launchers of those files + their kernels, emulated: every launch of the CQT path.
 
-  * the shipped kernels -- k_cqt_decimate, k_cqt_octave_f16, k_cqt_chroma, and the f32 matrix-core octave kernels, all
-    measured and parity-tested on the MI355X -- reproduce the golden CQT / chroma here too (1.1e-6; on the device
-    1.2e-6): that calibrates the emulation;
+  * the shipped kernels -- the headline k_stft_mel_v2 (BASELINE cfg 1: mel 1.8e-7, MFCC 2.0e-7 of the golden vectors, the
+    device's own figures), k_cqt_decimate, k_cqt_octave_f16, k_cqt_chroma and the f32 matrix-core octave kernels, all
+    measured and parity-tested on the MI355X -- reproduce the golden vectors here too: that calibrates the emulation;
   * k_cqt_all_f16 (AFX_CQT_FUSED, seven octaves + chroma in one launch), k_cqt_chroma_v2 (AFX_CQT_CHROMA_V2) and
     k_gemm_nt128_bf16x3 (AFX_GEMM_BF16) were written without hardware access and have never run on a device: their
     device code meets the golden vectors / a float64 product here, tails and all.
@@ -26,6 +26,9 @@ EMU = os.path.join(ROOT, "tests", "emu")
 STUB = os.path.join(ROOT, "tests", "hoststub")
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
 INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
+
+STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
+                                                     "afxk_melfused_destroy", "afxk_melfused_kind")]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
 
@@ -52,10 +55,9 @@ def emulated(tmp_path_factory):
     hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "host")
     jobs = [["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o",
              os.path.join(tmp, f[:-2] + "_c.o")] for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
-    # (the stand-in's own afxk_cqt_deconv steps aside: afx_cqt.hip brings the real launcher)
-    jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", "-Dafxk_cqt_deconv=afxk_cqt_deconv_standin", *INC, "-c", stub, "-o",
-                 os.path.join(tmp, "stub.o")])
-    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16"):
+    # (the stand-in's own versions of the launchers that the emulated translation units bring step aside)
+    jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *STANDIN_RENAMES, *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
+    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16", "mel_emulated_v2"):
         jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o",
                      os.path.join(tmp, f + ".o")])
     jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
@@ -97,6 +99,16 @@ def test_shipped_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
     instantiations, the 12-byte transposed stores), k_cqt_chroma -- through the emulation"""
     n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min"]))
     assert n["octave_f16"] == 21 and n["decimate"] == 18 and n["chroma"] == 2 and n["all_f16"] + n["chroma_v2"] + n["octave_f32"] == 0, n
+
+
+def test_headline_kernel_emulated_meets_the_golden_vectors(emulated):
+    """k_stft_mel_v2 (afx_melfused2.hip; 624-654 M frames/s on the device): BASELINE cfg 1 -- golden mel spectrogram and
+    MFCC-13 of the reference -- from ONE emulated launch (wave FFT, band plan, log10 + DCT-II on the f32 matrix cores),
+    two clips with an odd row stride; mel alone equals mel beside the cepstra bit for bit.  On the device: 1.8e-7 /
+    2.6e-7; here 1.8e-7 / 2.0e-7.  (This kernel's cross-lane LDS exchanges rely on a wave's DS operations executing in
+    issue order: the emulation makes every DS read a rendezvous of the wave.)"""
+    out = _run(emulated, "emulated_bft.py", [])
+    assert "emulated k_stft_mel_v2 2" in out, out[-500:]
 
 
 def test_f32_matrix_core_octave_kernels_emulated(emulated):
@@ -150,10 +162,10 @@ def emulated_tsan(tmp_path_factory):
     hostdir = os.path.join(ROOT, "audioflux_amd", "csrc", "host")
     jobs = [[CLANG, "-std=gnu11", *san, "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o", os.path.join(tmp, f[:-2] + "_c.o")]
             for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
-    jobs.append([CLANG, "-std=gnu11", *san, "-Dafxk_cqt_deconv=afxk_cqt_deconv_standin", *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
+    jobs.append([CLANG, "-std=gnu11", *san, *STANDIN_RENAMES, *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
     for d in ("driver_emu_small", "driver_emu_gemm"):
         jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(EMU, d + ".c"), "-o", os.path.join(tmp, d + ".drv")])
-    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16"):
+    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16", "mel_emulated_v2"):
         jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o", os.path.join(tmp, f + ".o")])
     jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
                  os.path.join(tmp, "cqt_emulated_main.o")])
