@@ -238,6 +238,17 @@ static inline emu_u32x4 emu_load_b128(const __amdgpu_buffer_rsrc_t &r, int voff,
             emu_buf_store((r), _o + 12, _v.w);                                             \
     } while (0)
 
+// ds_bpermute_b32: lane l receives the value of lane (byte address / 4) & 63
+static inline int emu_ds_bpermute(int addr, int v) {
+    unsigned *x = emu::exchange();
+    x[emu::lane() * 32] = (unsigned)v;
+    emu::wave_barrier();
+    const int r = (int)x[((addr >> 2) & 63) * 32];
+    emu::wave_barrier();
+    return r;
+}
+#define __builtin_amdgcn_ds_bpermute(addr, v) emu_ds_bpermute((addr), (v))
+
 // ---- wave shuffles, fast-math intrinsics
 template <class T>
 static inline T emu_shfl_from(T v, int src) {

@@ -1,0 +1,7 @@
+// the DEVICE code of audioflux_amd/csrc/hip/afx_melfused1k.hip (k_stft_band_1k (n_fft 1024)) compiled for the host against
+// tests/emu/hip/hip_runtime.h
+#include "hip/hip_runtime.h"
+namespace {
+alignas(16) unsigned char smem[160 * 1024];
+}
+#include "../../audioflux_amd/csrc/hip/afx_melfused1k.hip"

@@ -11,7 +11,8 @@ the C host code + the real launchers of those files + their kernels, emulated: e
     measured and parity-tested on the MI355X -- reproduce the golden vectors here too: that calibrates the emulation;
   * k_cqt_all_f16 (AFX_CQT_FUSED, seven octaves + chroma in one launch), k_cqt_chroma_v2 (AFX_CQT_CHROMA_V2) and
     k_gemm_nt128_bf16x3 (AFX_GEMM_BF16) were written without hardware access and have never run on a device: their
-    device code meets the golden vectors / a float64 product here, tails and all.
+    device code meets the golden vectors / a float64 product here, tails and all;
+  * the rest of the fused STFT family (n_fft 1024, 4096, 2048 complex) runs its golden cases the same way.
 
 What this cannot show: timing, register pressure, the hardware's own accumulation order inside an MFMA.
 """
@@ -29,6 +30,9 @@ INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audio
 
 STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
                                                      "afxk_melfused_destroy", "afxk_melfused_kind")]
+
+EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
+             "mel_emulated_melfused1k", "mel_emulated_melfused4k")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
 
@@ -57,7 +61,7 @@ def emulated(tmp_path_factory):
              os.path.join(tmp, f[:-2] + "_c.o")] for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
     # (the stand-in's own versions of the launchers that the emulated translation units bring step aside)
     jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *STANDIN_RENAMES, *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
-    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16", "mel_emulated_v2"):
+    for f in EMU_UNITS:
         jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o",
                      os.path.join(tmp, f + ".o")])
     jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
@@ -109,6 +113,15 @@ def test_headline_kernel_emulated_meets_the_golden_vectors(emulated):
     issue order: the emulation makes every DS read a rendezvous of the wave.)"""
     out = _run(emulated, "emulated_bft.py", [])
     assert "emulated k_stft_mel_v2 2" in out, out[-500:]
+
+
+def test_fused_stft_kernels_emulated_meet_the_golden_vectors(emulated):
+    """the other fused STFT -> filter-bank kernels, through the product's own dispatcher: n_fft 2048 complex results
+    (k_stft_mel_cplx), n_fft 1024 (k_stft_band_1k: mel-80 magnitudes with area normalisation, mel-64 with temporal
+    features), n_fft 4096 (k_stft_band_4k: 60 octave bands), and the ragged-tail clip on the headline kernel"""
+    out = _run(emulated, "emulated_bft_cases.py", ["cfg1_mel_complex", "tones_mel_mag_area", "mel_temporal", "octave_hann_style", "ragged_tail"])
+    for k in ("k_stft_mel_cplx", "k_stft_band_1k", "k_stft_band_4k", "k_stft_mel_v2"):
+        assert k in out, out
 
 
 def test_f32_matrix_core_octave_kernels_emulated(emulated):
@@ -163,9 +176,9 @@ def emulated_tsan(tmp_path_factory):
     jobs = [[CLANG, "-std=gnu11", *san, "-ffp-contract=off", *INC, "-c", os.path.join(hostdir, f), "-o", os.path.join(tmp, f[:-2] + "_c.o")]
             for f in sorted(os.listdir(hostdir)) if f.endswith(".c")]
     jobs.append([CLANG, "-std=gnu11", *san, *STANDIN_RENAMES, *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
-    for d in ("driver_emu_small", "driver_emu_gemm"):
+    for d in ("driver_emu_small", "driver_emu_gemm", "driver_emu_bft"):
         jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(EMU, d + ".c"), "-o", os.path.join(tmp, d + ".drv")])
-    for f in ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16", "mel_emulated_v2"):
+    for f in EMU_UNITS:
         jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o", os.path.join(tmp, f + ".o")])
     jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
                  os.path.join(tmp, "cqt_emulated_main.o")])
@@ -176,7 +189,7 @@ def emulated_tsan(tmp_path_factory):
             assert r.returncode == 0, r.stderr[-3000:]
     objs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".o"))
     exes = {}
-    for name, drv, swap in (("small", "driver_emu_small.drv", None), ("gemm", "driver_emu_gemm.drv", None),
+    for name, drv, swap in (("small", "driver_emu_small.drv", None), ("gemm", "driver_emu_gemm.drv", None), ("bft", "driver_emu_bft.drv", None),
                             ("negative", "driver_emu_small.drv", "cqt_emulated_f16")):
         use = [o for o in objs if not (swap and o.endswith(swap + ".o"))] + ([os.path.join(tmp, swap + ".neg")] if swap else [])
         exes[name] = os.path.join(tmp, "emu_tsan_" + name)
@@ -186,13 +199,14 @@ def emulated_tsan(tmp_path_factory):
 
 
 @pytest.mark.parametrize("exe,env", [("small", ""), ("small", "AFX_CQT_FUSED=1"), ("small", "AFX_CQT_CHROMA_V2=1"), ("small", "AFX_CQT_F32=1"),
-                                     ("small", "AFX_CQT_STORE32=1"), ("gemm", "")])
+                                     ("small", "AFX_CQT_STORE32=1"), ("gemm", ""), ("bft", "")])
 def test_emulated_kernels_have_no_lds_races(emulated_tsan, exe, env):
     """the lanes of an emulated kernel are host threads that meet only at the kernel's own cross-lane operations and
     LDS-ordering points (wave_lds_order, __syncthreads): under ThreadSanitizer an LDS word written by one lane and read
     by another without such a point in between is a data race -- a missing ordering point in the kernel, which on the
     device shows up only when the compiler or the hardware reorders the two accesses.  None in the shipped kernels, none
-    in k_cqt_all_f16 / k_cqt_chroma_v2 / k_gemm_nt128_bf16x3."""
+    in k_cqt_all_f16 / k_cqt_chroma_v2 / k_gemm_nt128_bf16x3; "bft": the fused STFT -> filter-bank kernels of n_fft 1024 /
+    4096 / 2048-complex (tests/emu/driver_emu_bft.c)."""
     e = dict(os.environ)
     for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED", "AFX_CQT_CHROMA_V2", "AFX_CQT_EXP", "AFX_CQT_STORE32"):
         e.pop(k, None)
