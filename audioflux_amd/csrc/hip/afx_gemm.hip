@@ -122,7 +122,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float *__restrict__ A, lo
 //   * the tail of K (1025 = 64 x 16 + 1) is masked element-wise: the pad words of the scratch rows
 //     are not initialised
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef AFX_HOST_EMULATION
 #define GR32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#else  // tests/emu (the kernel compiled for the host): the same read through the pointer the address came from
+#define GR32(dst, addr, off) __builtin_memcpy(&(dst), reinterpret_cast<const char *>(addr##_p) + (off), 4)
+#endif
 constexpr int TM = 128, TN = 128, TK = 16, LP = TM + 4;
 static_assert(TK == 16, "the k-step pipeline below is written out for 8 steps");
 
@@ -195,6 +199,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt128(const float *__restrict__
         // full LDS round trip in front of every group of four MFMAs); partial waits: LDS returns in order
         float av[4][2], bv[4][2];
         const unsigned aa = (unsigned)(size_t)ap, ba = (unsigned)(size_t)bp;
+#ifdef AFX_HOST_EMULATION
+        const float *aa_p = ap, *ba_p = bp;
+        (void)aa, (void)ba;
+#endif
 #define AFX_GEMM_REQ(S)                                   \
     do {                                                  \
         GR32(av[(S) & 3][0], aa, 8 * (S) * LP);           \
@@ -202,12 +210,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt128(const float *__restrict__
         GR32(bv[(S) & 3][0], ba, 8 * (S) * LP);           \
         GR32(bv[(S) & 3][1], ba, 8 * (S) * LP + 128);     \
     } while (0)
+#ifndef AFX_HOST_EMULATION
+#define AFX_GEMM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+#define AFX_GEMM_PIN(a0, a1, b0, b1) asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1))
+#else
+#define AFX_GEMM_WAIT(n) ((void)0)
+#define AFX_GEMM_PIN(a0, a1, b0, b1) ((void)0)
+#endif
 #define AFX_GEMM_STEP(S, WAITN)                                                                          \
     do {                                                                                                 \
         if ((S) + 3 < TK / 2) AFX_GEMM_REQ(((S) + 3 < TK / 2 ? (S) + 3 : 0));                            \
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(WAITN) : "memory");                                   \
+        AFX_GEMM_WAIT(WAITN);                                                                            \
         float a0 = av[(S) & 3][0], a1 = av[(S) & 3][1], b0 = bv[(S) & 3][0], b1 = bv[(S) & 3][1];        \
-        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));                                       \
+        AFX_GEMM_PIN(a0, a1, b0, b1);                                                                    \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);                    \
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);                    \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);                    \

@@ -51,6 +51,13 @@ if HOSTSTUB:
     #                              survive an LD_PRELOADed sanitizer runtime)
 
 
+# AFX_EMULATED=1 (tests/test_emulated_kernels.py): the suite runs against the library whose kernels are the device code
+# compiled for the host (tests/emu) -- no torch, but results are real: parity assertions stay on
+EMULATED = os.environ.get("AFX_EMULATED") == "1"
+if EMULATED:
+    sys.modules["torch"] = None
+
+
 def assert_parity(got, want, tol=1e-5, what=""):
     """north_star tolerance: 1e-5 relative, taken peak-relative and L2-relative
     per output tensor (element-wise relative error is meaningless at near-empty

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Builds <dir>/libafx_emulated_max.so: the C host objects + EVERY kernel file that compiles against the host emulation
+(tests/emu/hip/hip_runtime.h) -- launchers and device code -- + the stand-in device layer for the rest (afx_reassign.hip:
+rocPRIM sort; afx_runtime / afx_comm: no kernels).  With it the `-m gpu` parity tests that use host arrays run on the CPU:
+
+    python tests/emu/build_emulated_max.py /tmp/emu
+    AFX_EMULATED=1 AFX_HIP_RUNTIME=system AFX_LIB=/tmp/emu/libafx_emulated_max.so python -m pytest tests/test_cqt_gpu.py -m gpu -q
+
+(AFX_EMULATED=1: tests/conftest.py takes torch away -- tests that need device tensors end with ModuleNotFoundError -- and
+keeps the parity assertions on.)  Measured at the end of round 2: test_cqt_gpu 6/6, test_stft_gpu 32/33, test_bft_gpu
+43/44, test_spectrogram_gpu 22/23, test_xxcc_gpu 8/10, test_pwt_gpu 8/9, test_synsq_gpu 3/3, test_cwt_gpu 9/13 (the
+remaining failures there need torch, except the cepstrogram wave kernels and the CWT narrow-band comparison, which the
+emulation does not reproduce yet).  Minutes per file: one host thread per lane."""
+import os, re, subprocess, sys
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+E = os.path.abspath(sys.argv[1])
+os.makedirs(E, exist_ok=True)
+CL = "/opt/rocm/lib/llvm/bin/clang"
+INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
+hipdir = f"{ROOT}/audioflux_amd/csrc/hip"
+UNITS = ["afx_cqt", "afx_cqt_f16", "afx_cqt_all", "afx_gemm_bf16", "afx_melfused2", "afx_melfused", "afx_melfused1k", "afx_melfused4k",
+         "afx_gemm", "afx_cepstrogram", "afx_cepstrum", "afx_cwt", "afx_stft", "afx_istft", "afx_spectral", "afx_xxcc", "afx_wsst"]
+renames = set()
+jobs = []
+for u in UNITS:
+    src = open(f"{hipdir}/{u}.hip").read()
+    renames.update(re.findall(r'extern "C"\s+[\w\s\*]+?\b(afxk_\w+)\s*\([^;{]*\)\s*\{', src))
+    with open(f"{E}/{u}_host.hip", "w") as f:
+        f.write(re.sub(r"(?m)^(\s*)__shared__ ", r"\1static ", src))
+    with open(f"{E}/emu_{u}.cpp", "w") as f:
+        f.write('#include "hip/hip_runtime.h"\nnamespace {\nalignas(16) unsigned char smem[160 * 1024];\nalignas(16) unsigned char smem_raw[160 * 1024];\nalignas(16) float s[40 * 1024];\n}\n'
+                'static unsigned char *const afx_emu_lds = smem;\nstatic inline void afx_emu_ds() { emu::wave_barrier(); }\n'
+                f'#include "{E}/{u}_host.hip"\n')
+    jobs.append([CL + "++", "-std=c++17", "-O2", "-g", "-fPIC", "-Wno-unused", f"-I{ROOT}/tests/emu", *INC, "-c", f"{E}/emu_{u}.cpp", "-o", f"{E}/emu_{u}.o"])
+jobs.append([CL + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{ROOT}/tests/emu", *INC, "-c", f"{ROOT}/tests/emu/emu_engine.cpp", "-o", f"{E}/emu_engine.o"])
+subprocess.run([sys.executable, f"{ROOT}/tests/hoststub/gen_stub.py", f"{hipdir}/afx_device.h", f"{E}/stub.c", "--functional-cqt"], check=True)
+stubsrc = open(f"{E}/stub.c").read()
+present = [n for n in sorted(renames) if re.search(r"\b" + n + r"\s*\(", stubsrc)]
+print("launchers emulated:", len(renames), "; stand-in versions renamed:", len(present))
+jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *[f"-D{n}=standin_{n}" for n in present], *INC, "-c", f"{E}/stub.c", "-o", f"{E}/stub.o"])
+for f in sorted(os.listdir(f"{ROOT}/audioflux_amd/csrc/host")):
+    if f.endswith(".c"):
+        jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *INC, "-c", f"{ROOT}/audioflux_amd/csrc/host/{f}", "-o", f"{E}/{f[:-2]}_c.o"])
+with ThreadPoolExecutor(12) as ex:
+    for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+        if r.returncode: print(" ".join(r.args[-3:]), r.stderr[-1500:]); sys.exit(1)
+objs = sorted(f"{E}/{f}" for f in os.listdir(E) if f.endswith(".o"))
+r = subprocess.run([CL + "++", "-shared", *objs, "-lm", "-lpthread", "-o", f"{E}/libafx_emulated_max.so"], capture_output=True, text=True)
+print(r.stderr[-3000:]); sys.exit(r.returncode)

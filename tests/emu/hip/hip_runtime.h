@@ -46,6 +46,7 @@ extern thread_local EmuIdx threadIdx, blockIdx, blockDim, gridDim;
 struct alignas(8) float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(8) int2 { int x, y; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
@@ -264,6 +265,8 @@ template <class T>
 static inline T __shfl(T v, int src, int = 64) { return emu_shfl_from(v, src & 63); }
 template <class T>
 static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl_from(v, emu::lane() ^ mask); }
+template <class T>
+static inline T __shfl_down(T v, int delta, int = 64) { return emu_shfl_from(v, emu::lane() + delta < 64 ? emu::lane() + delta : emu::lane()); }
 template <class T>
 static inline T __shfl_up(T v, int delta, int = 64) { return emu_shfl_from(v, emu::lane() >= delta ? emu::lane() - delta : emu::lane()); }
 #define __log2f(x) log2f(x)
