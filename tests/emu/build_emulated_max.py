@@ -8,9 +8,9 @@ rocPRIM sort; afx_runtime / afx_comm: no kernels).  With it the `-m gpu` parity 
 
 (AFX_EMULATED=1: tests/conftest.py takes torch away -- tests that need device tensors end with ModuleNotFoundError -- and
 keeps the parity assertions on.)  Measured at the end of round 2: test_cqt_gpu 6/6, test_stft_gpu 32/33, test_bft_gpu
-43/44, test_spectrogram_gpu 22/23, test_xxcc_gpu 8/10, test_pwt_gpu 8/9, test_synsq_gpu 3/3, test_cwt_gpu 9/13 (the
-remaining failures there need torch, except the cepstrogram wave kernels and the CWT narrow-band comparison, which the
-emulation does not reproduce yet).  Minutes per file: one host thread per lane."""
+43/44, test_spectrogram_gpu 22/23, test_xxcc_gpu 8/10, test_pwt_gpu 8/9, test_synsq_gpu 3/3, test_cwt_gpu 9/13,
+test_cepstrogram_gpu 4/19 -- every failure is the missing torch import of a test that hands device tensors to the
+library; no parity assertion fails.  Minutes per file: one host thread per lane."""
 import os, re, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
