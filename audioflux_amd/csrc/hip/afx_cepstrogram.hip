@@ -502,7 +502,7 @@ extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
     if (a->timeLength <= 0) return AFX_OK;
     const int N = 1 << a->radix2Exp;
     const bool wave2k = N == 2048 && 2 * a->cepNum + 2 < N, wave4k = N == 4096 && a->cepNum <= DIRECT_Q;
-    if ((wave2k || wave4k) && a->x && !a->specRe && a->fastTab && !getenv("AFX_NO_FUSED")) {
+    if ((wave2k || wave4k) && a->x && !a->specRe && a->fastTab && !afxdev_no_fused()) {
         CepWArgs w;
         w.x = a->x;
         w.clipStride = a->clipStride;

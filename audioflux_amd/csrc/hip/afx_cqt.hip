@@ -555,78 +555,41 @@ __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ 
 
 constexpr int CH_FRAMES = 64;  // frames per workgroup
 
-// |Q|^2 (or |Q|) of CH_FRAMES frames is staged in LDS with fully coalesced loads, every
-// (frame, chroma bin) pair then folds its bins in ascending order (the 0/1 matrix product of
-// cqt_algorithm.c:553-560) and the frame's chroma vector is normalised in place.
-__global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re,
-                                                    const float *__restrict__ im, long long rows,
-                                                    int num, const unsigned char *__restrict__ fold,
-                                                    int chromaNum, int isMag, int normType,
-                                                    float *__restrict__ out, int vec4) {
+// ---- chroma (cqt_algorithm.c:484-597): |Q|^2 (or |Q|) -> 0/1 fold matrix product -> per-frame normalisation ----
+// Size-generic form (num > 255 bins or > 64 classes, e.g. 36 bins / octave x 8 octaves): thread (frame, class)
+// scans its row of the 0/1 matrix and adds the flagged bins in ascending order -- the order of the matrix
+// product, so the same bits as the list kernel below -- then the frame's chroma vector is normalised in LDS.
+__global__ __launch_bounds__(256) void k_cqt_chroma_scan(const float *__restrict__ re, const float *__restrict__ im,
+                                                         long long rows, int num,
+                                                         const unsigned char *__restrict__ fold, int chromaNum,
+                                                         int isMag, int normType, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *p = reinterpret_cast<float *>(smem_raw);          // [CH_FRAMES][num]
-    float *cv = p + CH_FRAMES * num;                          // [CH_FRAMES][chromaNum]
-    float *nrm = cv + CH_FRAMES * chromaNum;                  // [CH_FRAMES]
-    int *cnt = reinterpret_cast<int *>(nrm + CH_FRAMES);      // [chromaNum] bins per chroma class
-    unsigned char *fl = reinterpret_cast<unsigned char *>(cnt + chromaNum);  // [chromaNum][num] bin lists
+    float *cv = reinterpret_cast<float *>(smem_raw);          // [CH_FRAMES][chromaNum]
     const int tid = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * CH_FRAMES;
     const int nf = rows - f0 < CH_FRAMES ? (int)(rows - f0) : CH_FRAMES;
-    const float *pr = re + f0 * num, *pi = im + f0 * num;
-    // explicit fma: left to the compiler, the unrolled body and the remainder of a loop contract
-    // differently and the value of a frame would depend on its position in the batch
-    auto pw = [&](float a, float b) {
-        float v = __fmaf_rn(a, a, b * b);
-        if (isMag) v = sqrtf(v);
-        return v;
-    };
-    if (vec4) {
-        // 16-byte loads, a trip's loads of both planes in flight together (a load-use-store loop pays one memory
-        // latency per element: the kernel ran at 2.5 TB/s)
-        const float4 *pr4 = reinterpret_cast<const float4 *>(pr), *pi4 = reinterpret_cast<const float4 *>(pi);
-        float4 *p4 = reinterpret_cast<float4 *>(p);
-        const int n4 = nf * num / 4;
-        for (int e0 = tid; e0 < n4; e0 += 4 * 256) {
-            float4 a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + 256 * u, n4 - 1);
-                a[u] = pr4[e];
-                b[u] = pi4[e];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e0 + 256 * u < n4)
-                    p4[e0 + 256 * u] = make_float4(pw(a[u].x, b[u].x), pw(a[u].y, b[u].y), pw(a[u].z, b[u].z), pw(a[u].w, b[u].w));
-        }
-    } else {
-        for (int e = tid; e < nf * num; e += 256) p[e] = pw(pr[e], pi[e]);
-    }
-    // the 0/1 matrix as per-chroma lists of bins (ascending, the order of the matrix product): a chroma
-    // class collects num / chromaNum bins, scanning all num flags per (frame, class) costs 12x the adds
-    for (int c = tid; c < chromaNum; c += 256) {
-        unsigned char *lst = fl + c * num;  // overwritten in place: list entries never pass the scan position
-        int n = 0;
-        for (int j = 0; j < num; ++j)
-            if (fold[c * num + j]) lst[n++] = (unsigned char)j;
-        cnt[c] = n;
-    }
-    __syncthreads();
     for (int it = tid; it < nf * chromaNum; it += 256) {
         const int f = it / chromaNum, c = it - f * chromaNum;
-        const float *row = p + f * num;
-        const unsigned char *lst = fl + c * num;
-        const int n = cnt[c];
+        const float *pr = re + (f0 + f) * num, *pi = im + (f0 + f) * num;
+        const unsigned char *fl = fold + (long long)c * num;
         float v = 0.f;
-        for (int q = 0; q < n; ++q) v += row[lst[q]];
+        for (int j = 0; j < num; ++j)
+            if (fl[j]) {
+                float p = __fmaf_rn(pr[j], pr[j], pi[j] * pi[j]);
+                if (isMag) p = sqrtf(p);
+                v += p;
+            }
         cv[it] = v;
     }
     __syncthreads();
-    if (normType != 0) {  // 1 max, 2 min, 3 P2, 4 P1 over the frame's chroma vector (__mnormalize)
-        if (tid < nf) {
-            const float *c = cv + tid * chromaNum;
+    float *po = out + f0 * chromaNum;
+    for (int it = tid; it < nf * chromaNum; it += 256) {
+        const int f = it / chromaNum;
+        float v = cv[it];
+        if (normType != 0) {
+            const float *c = cv + f * chromaNum;
             float red = normType == 2 ? 3.4e38f : 0.f;
-            for (int k = 0; k < chromaNum; ++k) {
+            for (int k = 0; k < chromaNum; ++k) {             // 1 max, 2 min, 3 P2, 4 P1 (__mnormalize)
                 const float av = fabsf(c[k]);
                 if (normType == 1) red = fmaxf(red, av);
                 else if (normType == 2) red = fminf(red, av);
@@ -634,29 +597,20 @@ __global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re
                 else red += av;
             }
             if (normType == 3) red = sqrtf(red);
-            nrm[tid] = red;
-        }
-        __syncthreads();
-    }
-    float *po = out + f0 * chromaNum;
-    for (int it = tid; it < nf * chromaNum; it += 256) {
-        float v = cv[it];
-        if (normType != 0) {
-            const float red = nrm[it / chromaNum];
             if (red != 0.f) v = v / red;
         }
         po[it] = v;
     }
 }
 
-// ---- chroma, second formulation (AFX_CQT_CHROMA_V2=1; not yet measured on hardware, off by default) --------
-// k_cqt_chroma spends most of its time before the first barrier: chromaNum threads scan the num flags of their
-// row of the 0/1 matrix in global memory, one dependent byte load at a time, while the other threads wait.
-// Here the per-class bin lists are built on the host (afx_cqt.c: afx_chroma_lists, CPU-tested) and travel as a kernel
-// argument, copied to LDS once per workgroup; a thread owns (frame = tid & 63, classes wave, wave + 4, ...), so the class -- and with it the list
-// walked -- is uniform per wave (broadcast LDS reads), and the |Q|^2 rows sit in LDS at an odd
-// pitch so that the 64 frames of a read fall on distinct banks.  Same sums in the same (ascending bin) order.
-__global__ __launch_bounds__(256) void k_cqt_chroma_v2(const float *__restrict__ re, const float *__restrict__ im,
+// The default form.  The per-class bin lists are built on the host (afx_cqt.c: afx_chroma_lists, CPU-tested) and
+// travel as a kernel argument, copied to LDS once per workgroup; |Q|^2 of CH_FRAMES frames is staged in LDS with
+// coalesced 16-byte loads at an odd row pitch (the 64 frames of a read fall on distinct banks); a thread owns
+// (frame = tid & 63, classes wave, wave + 4, ...), so the class -- and with it the list walked -- is uniform per
+// wave (broadcast LDS reads).  Sums in ascending bin order = the 0/1 matrix product of cqt_algorithm.c:553-560.
+// Round 3, measured at 125 clips (profiles/r03_round_start.txt): 149 us per pass against 206 us for the round-2
+// kernel, which built the lists per workgroup by scanning the matrix in global memory (removed).
+__global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re, const float *__restrict__ im,
                                                        long long rows, int num, AfxChromaLists L, int chromaNum,
                                                        int isMag, int normType, float *__restrict__ out, int vec4) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -809,11 +763,11 @@ static int launch_cqt_mfma_w(const AfxCqtOctaveArgs *a, int SH, int sigWords, in
 
 static int try_cqt_mfma_w(const AfxCqtOctaveArgs *a, void *stream) {
     const int N = 1 << a->radix2Exp;
-    if (a->colTiles != 1 || (N != 256 && N != 512) || getenv("AFX_CQT_KSPLIT")) return AFX_ERR_UNSUPPORTED;
+    if (a->colTiles != 1 || (N != 256 && N != 512)) return AFX_ERR_UNSUPPORTED;
     // top octave of the default ladder (hop = N/4 = 128): its 18 KB signal windows leave this kernel 4 waves
     // per CU; the K-split kernel (4 waves share one window, 16 waves per CU) measures 2 % faster on the whole
-    // cfg-5 step (3.82 -> 3.74 ms).  AFX_CQT_W_TOP=1 restores the wave-private kernel.
-    if (N == 512 && a->hop * 4 == N && !getenv("AFX_CQT_W_TOP")) return AFX_ERR_UNSUPPORTED;
+    // cfg-5 step (3.82 -> 3.74 ms, round 2).
+    if (N == 512 && a->hop * 4 == N) return AFX_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a->x) % 16) || (a->xStride % 4)) return AFX_ERR_UNSUPPORTED;
     int SH = 0;
     while (SH < 30 && !((a->hop >> SH) & 1)) ++SH;
@@ -913,28 +867,36 @@ extern "C" int afxk_cqt_chroma(const float *re, const float *im, long long rows,
                                const unsigned char *fold, const AfxChromaLists *lists, int chromaNum, int isMag,
                                int normType, float *out, void *stream) {
     if (rows <= 0) return AFX_OK;
-    if (num > 255) return AFX_ERR_UNSUPPORTED;  // bin lists are bytes
-    const size_t lds = sizeof(float) * ((size_t)CH_FRAMES * num + (size_t)CH_FRAMES * chromaNum + CH_FRAMES) +
-                       sizeof(int) * (size_t)chromaNum + (size_t)chromaNum * num;
-    if (lds > 150 * 1024) return AFX_ERR_UNSUPPORTED;
-    if (lds > 48 * 1024)
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int vec4 = (num % 4 == 0) && (reinterpret_cast<uintptr_t>(re) % 16 == 0) && (reinterpret_cast<uintptr_t>(im) % 16 == 0);
-    if (getenv("AFX_CQT_CHROMA_V2") && lists && chromaNum <= 64) {
+    if (num < 1 || chromaNum < 1) return AFX_ERR_ARG;
+    const long long blocks = (rows + CH_FRAMES - 1) / CH_FRAMES;
+    if (blocks > 0x7fffffffLL) {
+        afxdev_set_error("cqt chroma: %lld rows in one launch", rows);
+        return AFX_ERR_UNSUPPORTED;
+    }
+    if (lists && chromaNum <= 64 && num <= 255) {
+        const int vec4 = (num % 4 == 0) && (reinterpret_cast<uintptr_t>(re) % 16 == 0) && (reinterpret_cast<uintptr_t>(im) % 16 == 0);
         const AfxChromaLists L = *lists;
-        const size_t lds2 = sizeof(float) * ((size_t)CH_FRAMES * (num | 1) + (size_t)CH_FRAMES * chromaNum) +
-                            ((sizeof(AfxChromaLists) + 15) & ~(size_t)15);
-        if (lds2 > 48 * 1024)
-            AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma_v2),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(k_cqt_chroma_v2, dim3((unsigned)((rows + CH_FRAMES - 1) / CH_FRAMES)), dim3(256), lds2,
-                           (hipStream_t)stream, re, im, rows, num, L, chromaNum, isMag, normType, out, vec4);
-        AFX_LAUNCH_CHECK("k_cqt_chroma_v2");
+        const size_t lds = sizeof(float) * ((size_t)CH_FRAMES * (num | 1) + (size_t)CH_FRAMES * chromaNum) +
+                           ((sizeof(AfxChromaLists) + 15) & ~(size_t)15);
+        if (lds > 48 * 1024)
+            AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_cqt_chroma, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, re, im, rows, num,
+                           L, chromaNum, isMag, normType, out, vec4);
+        AFX_LAUNCH_CHECK("k_cqt_chroma");
         return AFX_OK;
     }
-    hipLaunchKernelGGL(k_cqt_chroma, dim3((unsigned)((rows + CH_FRAMES - 1) / CH_FRAMES)), dim3(256),
-                       lds, (hipStream_t)stream, re, im, rows, num, fold, chromaNum, isMag, normType, out, vec4);
-    AFX_LAUNCH_CHECK("k_cqt_chroma");
+    // byte-sized bin lists do not cover this plan (e.g. 36 bins / octave x 8 octaves = 288 bins): flag scan
+    const size_t lds = sizeof(float) * (size_t)CH_FRAMES * chromaNum;
+    if (!fold || lds > 150 * 1024) {
+        afxdev_set_error("cqt chroma: %d classes of %d bins are outside the kernels' range", chromaNum, num);
+        return AFX_ERR_UNSUPPORTED;
+    }
+    if (lds > 48 * 1024)
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_chroma_scan),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cqt_chroma_scan, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, re, im, rows, num,
+                       fold, chromaNum, isMag, normType, out);
+    AFX_LAUNCH_CHECK("k_cqt_chroma_scan");
     return AFX_OK;
 }

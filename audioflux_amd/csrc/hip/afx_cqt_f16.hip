@@ -373,10 +373,8 @@ int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
 
 template <int H>
 int dispatch_f16(const AfxCqtOctaveArgs *a, void *stream) {
-    const char *ex = getenv("AFX_CQT_EXP");
-    const bool r12 = a->rows == 12 && !getenv("AFX_CQT_STORE32");
-    if (ex && atoi(ex) == 3) return r12 ? launch_f16<H, true, true>(a, stream) : launch_f16<H, false, true>(a, stream);
-    return r12 ? launch_f16<H, true, false>(a, stream) : launch_f16<H, false, false>(a, stream);
+    // 12 bins per octave: the tile is transposed through LDS and leaves as 12-byte-per-lane stores
+    return a->rows == 12 ? launch_f16<H, true, false>(a, stream) : launch_f16<H, false, false>(a, stream);
 }
 
 }  // namespace

@@ -586,7 +586,7 @@ extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const 
     CwtGeom g = make_geom(d, tw);
     g.num = num;
     const int L1 = 1 << d->r1, L2 = 1 << d->r2;
-    if (d->fastTw && d->r1 == 8 && d->r2 == 9 && !getenv("AFX_NO_FUSED")) {
+    if (d->fastTw && d->r1 == 8 && d->r2 == 9 && !afxdev_no_fused()) {
         const float2 *Xt2 = reinterpret_cast<const float2 *>(Xt);
         float2 *B2 = reinterpret_cast<float2 *>(scratchB);
         hipStream_t s = (hipStream_t)stream;

@@ -35,6 +35,13 @@ int afxdev_current_device(void);      /* this thread's HIP device, -1 if none */
 int afxdev_bind_stream(void *stream); /* thread's device := the stream's device */
 #define AFX_MAX_DEVICES 16           /* power of two; per-device one-time flags */
 int afxdev_error_count(void);         /* failures reported on this thread so far */
+/* a void entry point ends in failure `st`: one stderr line (who, status, last message) and the thread's
+ * failure count advances even when no message was recorded on the way (the wrappers raise on it) */
+void afxdev_report_failure(const char *who, int st);
+/* process-wide switches, read from the environment once: AFX_NO_FUSED (size-generic kernels only: no wave-level /
+ * register-resident / matrix-core specialisation), AFX_CQT_F32 (CQT octave products on the float32 matrix cores) */
+int afxdev_no_fused(void);
+int afxdev_cqt_f32(void);
 /* first statement of every compute entry point: the object's device becomes current */
 #define AFX_ENTER(o) do { if ((o) != NULL) (void)afxdev_bind_stream((o)->stream); } while (0)
 
@@ -280,25 +287,6 @@ typedef struct {
 int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
 /* f16 matrix-core variant; AFX_ERR_UNSUPPORTED when the plan / alignment is outside its scope */
 int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream);
-/* all seven octaves of the default plan (+ chroma) in one launch (afx_cqt_all.hip; AFX_CQT_FUSED=1, off by
- * default): level l = the signal decimated l times, hop 128 >> l, octave 6 - l */
-typedef struct {
-    const float *x[7];        /* device: signal of level l                                   */
-    long long xStride[7];     /* samples between consecutive clips of level l                */
-    int validLength[7];       /* samples framed at level l                                   */
-    float octScale[7];        /* sqrt(2^l)                                                   */
-    const unsigned short *imageH; /* the shared f16 (hi, lo) image, fragment order           */
-    const float *colMul;      /* [32] 2^-s_j of its columns                                  */
-    const float *scale;       /* [num] sqrt(len_j) or ones                                   */
-    int num, timeLength, batch;
-    long long outStride;
-    float *outRe, *outIm;     /* [batch][T, num]                                             */
-    float *chroma;            /* [batch][T, 12] or NULL                                      */
-    long long chromaStride;
-    int isMag, normType;
-    unsigned char cls[84];    /* chroma class of every bin (with chroma != NULL)             */
-} AfxCqtAllArgs;
-int afxk_cqt_all_f16(const AfxCqtAllArgs *a, void *stream);
 /* batch clips: x + b*xStride -> y + b*yStride */
 int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, int dstLen,
                       long long yStride, int batch, const float *taps32, float sqrtRatio,
@@ -315,8 +303,8 @@ typedef struct AfxChromaLists_ {
     unsigned short start[65];
     unsigned char bins[256];
 } AfxChromaLists;
-/* fold: device 0/1 matrix [chromaNum][num]; lists: the same as bin lists (host struct, may be NULL; used by the
- * AFX_CQT_CHROMA_V2 kernel, which takes it as a kernel argument) */
+/* fold: device 0/1 matrix [chromaNum][num]; lists: the same as bin lists (host struct, a kernel argument of
+ * k_cqt_chroma); NULL or a plan beyond the list form (num > 255, chromaNum > 64): the size-generic flag scan */
 int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num,
                     const unsigned char *fold, const AfxChromaLists *lists, int chromaNum, int isMag,
                     int normType, float *out, void *stream);

@@ -1,9 +1,10 @@
 // afx_gemm_bf16.hip -- C[M,N] = A[M,K] B[N,K]^T on the bf16 matrix cores with float32-equivalent operands.
 //
-// STATUS: written at the end of round 2 without hardware access.  Compiled, never run: switched OFF by default
-// (AFX_GEMM_BF16=1 routes afxk_gemm_nt's large shapes here).
+// The 128 x 128 tile kernel of afxk_gemm_nt (wide, 16-byte aligned shapes: the dense filter-bank products).  Written
+// at the end of round 2, first run on the device in round 3: parity tests unchanged, the dense gammatone-128 route
+// 5.40 -> 5.04 ms per 934 000 frames against the float32 matrix-core kernel it replaces (profiles/r03_round_start.txt).
 //
-// k_gemm_nt128 (afx_gemm.hip) runs the dense filter-bank products (gammatone / chroma banks x spectra) at
+// Round 2's k_gemm_nt128 ran the dense filter-bank products (gammatone / chroma banks x spectra) at
 // 110 TFLOP/s on v_mfma_f32_32x32x2_f32 -- 70 % of a pipe that runs at the vector rate (64 cycles per 32x32x2).
 // v_mfma_f32_32x32x16_bf16 does 8x the products in half the time.  Power spectra span ten decades inside one frame
 // and feed a logarithm, so (unlike the CQT's f16 words, afx_cqt_f16.hip) no per-tile exponent will do: every float32
@@ -14,7 +15,7 @@
 // accumulated in float32 by the matrix core: six MFMAs of 32 cycles per 16 k-steps = 192 cycles against 512 on the
 // f32 pipe.  numpy model: elementwise relative error 8.5e-7, the f32 GEMM's 9.4e-7.
 //
-// Tiling as k_gemm_nt128: 128 x 128 outputs per workgroup, four waves own 64 x 64 quadrants (2 x 2 MFMA tiles each),
+// Tiling: 128 x 128 outputs per workgroup, four waves own 64 x 64 quadrants (2 x 2 MFMA tiles each),
 // K in steps of 16 (one MFMA k-step), double-buffered LDS.  The loader converts while it stages: a thread takes four
 // consecutive k of two A rows and two B rows (16-byte loads), forms the three words (v_cvt_pk_bf16_f32, round to
 // nearest even; the remainders are exact float32 subtractions) and stores 8 bytes per word plane.  A plane row is
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt128_bf16x3(const float *__res
 
 }  // namespace
 
-// same contract as the k_gemm_nt128 branch of afxk_gemm_nt (pre == AFX_MAP_NONE, 16-byte aligned operands with row
-// pitches that are multiples of 4 floats); AFX_ERR_UNSUPPORTED otherwise
+// contract (the wide branch of afxk_gemm_nt, pre == AFX_MAP_NONE): 16-byte aligned operands with row
+// pitches that are multiples of 4 floats; AFX_ERR_UNSUPPORTED otherwise
 extern "C" int afxk_gemm_nt128_bf16(const float *A, long long lda, const float *B, int ldb, float *C, long long ldc,
                                     long long M, int N, int K, int post, float postArg, void *stream) {
     if (M <= 0 || N <= 0 || K <= 0) return AFX_OK;

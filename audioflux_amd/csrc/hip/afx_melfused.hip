@@ -451,7 +451,7 @@ extern "C" void afxk_mel4k_destroy(void *plan);
 extern "C" int afxk_mel4k_kind(const void *plan);
 
 extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
-    if (getenv("AFX_NO_FUSED")) return -1;
+    if (afxdev_no_fused()) return -1;
     if (radix2Exp == 10) return afxk_mel1k_variant(tapsA, tapsB);
     if (radix2Exp == 12) return afxk_mel4k_variant(tapsA, tapsB);
     if (radix2Exp != 11) return -1;

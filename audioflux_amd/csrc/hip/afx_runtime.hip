@@ -33,13 +33,33 @@ bool device_is_gfx950(int dev, char *why, size_t n) {
 }
 }  // namespace
 
+// AFX_QUIET: read once per process
+static bool quiet() {
+    static const bool q = getenv("AFX_QUIET") != nullptr;
+    return q;
+}
+
 extern "C" void afxdev_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     ++t_err_count;
-    if (getenv("AFX_QUIET") == nullptr) fprintf(stderr, "[audioflux_mi355x] %s\n", g_err);
+    if (!quiet()) fprintf(stderr, "[audioflux_mi355x] %s\n", g_err);
+}
+
+extern "C" void afxdev_report_failure(const char *who, int st) {
+    ++t_err_count;
+    if (!quiet()) fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, g_err);
+}
+
+extern "C" int afxdev_no_fused(void) {
+    static const int v = getenv("AFX_NO_FUSED") != nullptr;
+    return v;
+}
+extern "C" int afxdev_cqt_f32(void) {
+    static const int v = getenv("AFX_CQT_F32") != nullptr;
+    return v;
 }
 
 extern "C" const char *afxdev_last_error(void) { return g_err; }

@@ -375,8 +375,7 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     // 252 VGPRs + 620 B/lane of scratch and measured SLOWER than this kernel (38 vs 57 M frames/s):
     // not dispatched.
     const bool cplx = a->mode == AFX_SPEC_COMPLEX;
-    if (a->radix2Exp == 11 && !a->bandStart && !a->energy && a->binLo >= 0 && !getenv("AFX_NO_FUSED") &&
-        !getenv("AFX_NO_STFT_WAVE")) {
+    if (a->radix2Exp == 11 && !a->bandStart && !a->energy && a->binLo >= 0 && !afxdev_no_fused()) {
         if (const float2 *tab = wave_tables())
             return cplx ? launch_stft_wave<11, true>(a, tab, frames, stream)
                         : launch_stft_wave<11, false>(a, tab, frames, stream);

@@ -463,7 +463,7 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
     }
 
     /* banded bank: STFT and filter bank in one launch of the size-generic kernel */
-    if (o->dBandMeta && !getenv("AFX_NO_BAND")) {
+    if (o->dBandMeta) {
         a.x = dData;
         a.batch = batch;
         a.binLo = 0;
@@ -591,7 +591,7 @@ void bftObj_bft(BFTObj o, float *dataArr, int dataLength, float *mRealArr3, floa
     int st = bftObj_bftBatch(o, dataArr, 1, dataLength, mRealArr3, mImageArr3);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] bftObj_bft failed (%d): %s\n", st, afxdev_last_error());
+        afxdev_report_failure("bftObj_bft", st);
     }
 }
 

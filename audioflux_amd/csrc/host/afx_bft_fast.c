@@ -23,7 +23,7 @@ int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hB
     if (afx_bandplan_build(hBank, o->num, o->F, &band) != 0) return AFX_OK;
     int st = AFX_OK;
     int fits = afxk_melfused_variant(o->radix2Exp, band.tapsA, band.tapsB) >= 0;
-    if (!fits && (o->radix2Exp == 11 || o->radix2Exp == 12) && !getenv("AFX_NO_SPLIT")) {
+    if (!fits && (o->radix2Exp == 11 || o->radix2Exp == 12)) {
         /* rows longer than the compiled tap variants (mel-40 / -64 / -80, bark, erb, higher sample
          * rates): cut them into segments, smallest variant first (afx_bandplan.c); the last number
          * is the length of the kernel's zero-padded power row (PROW_F of afx_melfused{,4k}.hip) */
@@ -102,7 +102,7 @@ int afx_bft_try_fast_cc(struct OpaqueBFT *o, struct OpaqueXXCC *x, const float *
                         CepstralRectifyType *rectifyType, float *dMel, float *dCc, void *stream,
                         int *used) {
     *used = 0;
-    if (!o->fast || !o->resultType || o->isTemporal || getenv("AFX_NO_FUSED_CC")) return AFX_OK;
+    if (!o->fast || !o->resultType || o->isTemporal) return AFX_OK;
     if (rectifyType && *rectifyType != CepstralRectify_Log) return AFX_OK;
     if (x->num != o->num || ccNum < 1 || ccNum > 16) return AFX_OK;
     AfxMelFusedArgs a;

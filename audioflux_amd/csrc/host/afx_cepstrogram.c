@@ -129,7 +129,7 @@ static void run(CepstrogramObj o, int cepNum, const float *hData, int dataLength
     if (st == AFX_OK && hData) o->cachedTime = T;
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+        afxdev_report_failure(who, st);
     }
 }
 
@@ -168,8 +168,7 @@ int cepstrogramObj_cepstrogramBatchDevice(CepstrogramObj o, int cepNum, const fl
     int st = afxk_cepstrogram(&a, hipStream);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] cepstrogramObj_cepstrogramBatchDevice failed (%d): %s\n", st,
-                afxdev_last_error());
+        afxdev_report_failure("cepstrogramObj_cepstrogramBatchDevice", st);
     }
     return st;
 }

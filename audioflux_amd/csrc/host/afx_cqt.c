@@ -41,7 +41,7 @@ struct OpaqueCQT {
                               * its power-of-two scaled columns, in MFMA fragment order (afx_cqt_f16.hip) */
     float *dColMul;          /* [groups][32]: 2^-s_j undoing the column scaling */
     unsigned char *dFold;
-    AfxChromaLists foldLists; /* the folding matrix as per-class bin lists (AFX_CQT_CHROMA_V2 kernel) */
+    AfxChromaLists foldLists; /* the folding matrix as per-class bin lists (k_cqt_chroma) */
     int haveLists;
     int foldChromaNum;
     float *dX;               /* staged input of the host-pointer calls */
@@ -62,7 +62,7 @@ struct OpaqueCQT {
 
 static void fail(CQTObj o, int st, const char *who) {
     o->status = st;
-    fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+    afxdev_report_failure(who, st);
 }
 
 /* float32 -> IEEE binary16, round to nearest even (gcc 11 on x86-64 has no _Float16) */
@@ -316,7 +316,7 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     float *timeKernel = NULL;
     size_t timeKernelBytes = 0;
     o->colTiles = 0;
-    if (N >= 256 && N <= 2048 && 2 * bpo <= 96 && !getenv("AFX_NO_FUSED")) {
+    if (N >= 256 && N <= 2048 && 2 * bpo <= 96 && !afxdev_no_fused()) {
         const int ct = (2 * bpo + 31) / 32, cols = ct * 32;
         const int groups = rowsTotal / bpo;
         timeKernelBytes = sizeof(float) * (size_t)groups * N * cols;
@@ -384,7 +384,7 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     if (o->colTiles) {
         UP(o->dTimeKernel, timeKernel, timeKernelBytes);
     }
-    if (o->colTiles == 1 && N == 512 && !getenv("AFX_CQT_F32")) {
+    if (o->colTiles == 1 && N == 512 && !afxdev_cqt_f32()) {
         /* f16 (hi, lo) words of the image for the f16 matrix-core kernel (afx_cqt_f16.hip) */
         const int groups = rowsTotal / bpo;
         const size_t perGroup = (size_t)2 * (N / 16) * 64 * 8;
@@ -436,164 +436,16 @@ void cqtObj_setScale(CQTObj o, int flag) {
 /* The octave recursion on HBM-resident clips: dX + b*xStride (b < batch, dataLength
  * samples each) -> dRe/dIm [batch][T, num].  dSig[0/1] hold the decimated signals of all
  * clips (pitch = dataLength/2 samples).  Asynchronous on `stream`. */
-/* ---- AFX_CQT_FUSED (off by default; written without hardware access at the end of round 2):
- * the six decimations of a pass, then ONE launch for its seven octave products (+ the chroma when dChroma != NULL
- * and the folding matrix is a partition of the bins into 12 classes).
- *   AFX_CQT_FUSED=1: decimations and the launch in order on the caller's stream, pass by pass;
- *   AFX_CQT_FUSED=2: the decimations of pass p + 1 on a side stream under the launch of pass p (two level buffers).
- * AFX_ERR_UNSUPPORTED: the caller takes the per-octave path. */
-static int cqt_fused_mode(CQTObj o) {
-    const char *e = getenv("AFX_CQT_FUSED");
-    if (!e || atoi(e) < 1) return 0;
-    if (o->octaveNum != 7 || o->binPerOctave != 12 || o->num != 84 || o->vFlag || o->fftLength != 512 ||
-        o->slideLength != 128 || !o->dTimeKernelH || !o->dColMul)
-        return 0;
-    return atoi(e) >= 2 ? 2 : 1;
-}
-
-/* chroma class of every bin from the bin lists; AFX_ERR_UNSUPPORTED unless they partition the 84 bins into 12 */
-static int cqt_fused_classes(CQTObj o, int cn, unsigned char *cls) {
-    if (cn != 12 || !o->haveLists) return AFX_ERR_UNSUPPORTED;
-    memset(cls, 255, 84);
-    for (int c = 0; c < 12; c++)
-        for (int q = o->foldLists.start[c]; q < o->foldLists.start[c + 1]; q++) {
-            const int j = o->foldLists.bins[q];
-            if (j >= 84 || cls[j] != 255) return AFX_ERR_UNSUPPORTED; /* a bin in two classes */
-            cls[j] = (unsigned char)c;
-        }
-    for (int j = 0; j < 84; j++)
-        if (cls[j] == 255) return AFX_ERR_UNSUPPORTED; /* a bin in no class */
-    return AFX_OK;
-}
-
-static size_t cqt_level_floats(int dataLength, int batch) {
-    size_t total = 0;
-    long long p = ((long long)dataLength / 2 + 3) & ~3LL;
-    for (int k = 1; k < 7; k++) {
-        total += (size_t)p * batch;
-        p = ((p / 2) + 3) & ~3LL;
-    }
-    return total;
-}
-
-/* the six decimations of `batch` clips into level buffer dSig[which] (already reserved), on `stream`;
- * fills the level table of a */
-static int cqt_fused_levels(CQTObj o, const float *dX, int batch, int dataLength, long long xStride, int which,
-                            AfxCqtAllArgs *a, void *stream) {
-    const float *cur = dX;
-    long long curStride = xStride, levelPitch = ((long long)dataLength / 2 + 3) & ~3LL;
-    size_t levelOff = 0;
-    int len = dataLength, hop = o->slideLength, st = AFX_OK;
-    for (int l = 0; l < 7 && st == AFX_OK; l++) {
-        const int frames = len / hop + 1;
-        a->x[l] = cur;
-        a->xStride[l] = curStride;
-        a->validLength[l] = len - (frames > 1 ? len % hop : 0); /* stft_algorithm.c:838-843 */
-        a->octScale[l] = l == 0 ? 1.f : sqrtf((float)(1 << l));
-        if (l == 6) break;
-        const int next = (int)floorf(len * 0.5f);
-        float *dNext = o->dSig[which] + levelOff;
-        st = afxk_cqt_decimate(cur, len, curStride, dNext, next, levelPitch, batch, o->taps, sqrtf(0.5f), stream);
-        cur = dNext;
-        curStride = levelPitch;
-        levelOff += (size_t)levelPitch * batch;
-        levelPitch = ((levelPitch / 2) + 3) & ~3LL;
-        len = next;
-        hop /= 2;
-    }
-    return st;
-}
-
-static int cqt_fused_launch(CQTObj o, AfxCqtAllArgs *a, int batch, int T, float *dRe, float *dIm, float *dChroma,
-                            int isMag, int nrm, void *stream) {
-    a->imageH = o->dTimeKernelH;
-    a->colMul = o->dColMul;
-    a->scale = o->isScale ? o->dScaleOn : o->dScaleOff;
-    a->num = o->num;
-    a->timeLength = T;
-    a->batch = batch;
-    a->outStride = (long long)T * o->num;
-    a->outRe = dRe;
-    a->outIm = dIm;
-    a->chroma = dChroma;
-    a->chromaStride = (long long)T * 12;
-    a->isMag = isMag;
-    a->normType = nrm;
-    return afxk_cqt_all_f16(a, stream);
-}
-
-/* one pass, everything on the caller's stream (AFX_CQT_FUSED=1, and the one-clip entry points in either mode) */
-static int cqt_run_device_fused(CQTObj o, const float *dX, int batch, int dataLength, long long xStride,
-                                float *dRe, float *dIm, float *dChroma, int cn, int isMag, int nrm, void *stream) {
-    if (!cqt_fused_mode(o)) return AFX_ERR_UNSUPPORTED;
-    AfxCqtAllArgs a;
-    memset(&a, 0, sizeof(a));
-    if (dChroma && cqt_fused_classes(o, cn, a.cls) != AFX_OK) return AFX_ERR_UNSUPPORTED;
-    int st = afxdev_reserve((void **)&o->dSig[0], &o->capSig[0], sizeof(float) * cqt_level_floats(dataLength, batch));
-    if (st == AFX_OK) st = cqt_fused_levels(o, dX, batch, dataLength, xStride, 0, &a, stream);
-    if (st == AFX_OK)
-        st = cqt_fused_launch(o, &a, batch, dataLength / o->slideLength + 1, dRe, dIm, dChroma, isMag, nrm, stream);
-    return st;
-}
-
-/* all passes of a batched call with the decimations one pass ahead on a side stream (AFX_CQT_FUSED=2) */
-static int cqt_fused_passes(CQTObj o, const float *dData, int batch, int dataLength, long long clipStride,
-                            float *dReal, float *dImag, float *dChroma, int cn, int isMag, int nrm, int chunk,
-                            void *stream) {
-    if (cqt_fused_mode(o) != 2) return AFX_ERR_UNSUPPORTED;
-    AfxCqtAllArgs a[2];
-    memset(a, 0, sizeof(a));
-    if (dChroma) {
-        if (cqt_fused_classes(o, cn, a[0].cls) != AFX_OK) return AFX_ERR_UNSUPPORTED;
-        memcpy(a[1].cls, a[0].cls, sizeof(a[0].cls));
-    }
-    const int T = dataLength / o->slideLength + 1;
-    const int passes = (batch + chunk - 1) / chunk;
-    int st = AFX_OK;
-    void *side = o->stream != stream ? o->stream : o->stream2;
-    if (!side) {
-        st = afxdev_stream_create(&o->stream2);
-        side = o->stream2;
-    }
-    const size_t lf = sizeof(float) * cqt_level_floats(dataLength, batch < chunk ? batch : chunk);
-    if (st == AFX_OK) st = afxdev_reserve((void **)&o->dSig[0], &o->capSig[0], lf);
-    if (st == AFX_OK && passes > 1) st = afxdev_reserve((void **)&o->dSig[1], &o->capSig[1], lf);
-    /* the side stream starts behind everything the caller's stream has enqueued (inputs ready, level buffers free) */
-    if (st == AFX_OK) st = afxdev_stream_wait_stream(side, stream);
-    if (st == AFX_OK)
-        st = cqt_fused_levels(o, dData, batch < chunk ? batch : chunk, dataLength, clipStride, 0, &a[0], side);
-    for (int p = 0; p < passes && st == AFX_OK; p++) {
-        const int b0 = p * chunk, nb = batch - b0 < chunk ? batch - b0 : chunk;
-        st = afxdev_stream_wait_stream(stream, side); /* the levels of pass p are complete */
-        if (st == AFX_OK && p + 1 < passes) {
-            /* buffer (p + 1) & 1 was read by the launch of pass p - 1, which the caller's stream has already
-             * enqueued: the side stream waits for it, then decimates pass p + 1 under the launch of pass p */
-            const int b1 = b0 + chunk, nb1 = batch - b1 < chunk ? batch - b1 : chunk;
-            st = afxdev_stream_wait_stream(side, stream);
-            if (st == AFX_OK)
-                st = cqt_fused_levels(o, dData + (long long)b1 * clipStride, nb1, dataLength, clipStride, (p + 1) & 1,
-                                      &a[(p + 1) & 1], side);
-        }
-        if (st == AFX_OK)
-            st = cqt_fused_launch(o, &a[p & 1], nb, T, dReal + (long long)b0 * T * o->num,
-                                  dImag + (long long)b0 * T * o->num,
-                                  dChroma ? dChroma + (long long)b0 * T * 12 : NULL, isMag, nrm, stream);
-    }
-    return st;
-}
-
 static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, long long xStride,
                           float *dRe, float *dIm, void *stream) {
     const int T = dataLength / o->slideLength + 1;
     const long long pitch = ((long long)dataLength / 2 + 3) & ~3LL;
-    int st = cqt_run_device_fused(o, dX, batch, dataLength, xStride, dRe, dIm, NULL, 0, 0, 0, stream);
-    if (st != AFX_ERR_UNSUPPORTED) return st;
-    st = AFX_OK;
+    int st = AFX_OK;
     /* The decimation chain (signal of octave k from octave k+1: memory / latency bound) does not depend on
      * the octave products (matrix-core bound): it runs ahead on a side stream, every level in its own
      * slice of dSig[0] (pitch, pitch/2, ... samples per clip: < 2 pitch in all), and the octave kernel of a
-     * level waits only for the decimation that produced its input.  AFX_CQT_OVERLAP=0: one stream, in order. */
-    const int overlap = o->octaveNum > 1 && !(getenv("AFX_CQT_OVERLAP") && atoi(getenv("AFX_CQT_OVERLAP")) == 0);
+     * level waits only for the decimation that produced its input (round 2: -0.25 ms per cfg-5 step). */
+    const int overlap = o->octaveNum > 1;
     void *side = NULL;
     if (overlap) {
         side = o->stream != stream ? o->stream : o->stream2;
@@ -738,11 +590,7 @@ int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLengt
     /* scratch is shared between calls: order this call after the previous one's stream */
     if (o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
     const int chunk = cqt_chunk_clips(o, T, batch);
-    int fused = st == AFX_OK ? cqt_fused_passes(o, dData, batch, dataLength, clipStride, dReal, dImag, NULL, 0, 0, 0,
-                                                chunk, hipStream)
-                             : AFX_ERR_UNSUPPORTED;
-    if (fused != AFX_ERR_UNSUPPORTED) st = fused;
-    for (int b0 = 0; fused == AFX_ERR_UNSUPPORTED && b0 < batch && st == AFX_OK; b0 += chunk) {
+    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride,
                             dReal + (long long)b0 * T * o->num, dImag + (long long)b0 * T * o->num,
@@ -937,16 +785,9 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
     const int T = dataLength / o->slideLength + 1;
     if (st == AFX_OK && o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
     const int chunk = cqt_chunk_clips(o, T, batch);
-    int fused = st == AFX_OK ? cqt_fused_passes(o, dData, batch, dataLength, clipStride, dReal, dImag, dChroma, cn,
-                                                isMag, nrm, chunk, hipStream)
-                             : AFX_ERR_UNSUPPORTED;
-    if (fused != AFX_ERR_UNSUPPORTED) st = fused;
-    for (int b0 = 0; fused == AFX_ERR_UNSUPPORTED && b0 < batch && st == AFX_OK; b0 += chunk) {
+    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;
-        st = cqt_run_device_fused(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im,
-                                  dChroma + (long long)b0 * T * cn, cn, isMag, nrm, hipStream);
-        if (st != AFX_ERR_UNSUPPORTED) continue; /* one launch did both (or failed) */
         st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im, hipStream);
         if (st == AFX_OK)
             st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag, nrm,

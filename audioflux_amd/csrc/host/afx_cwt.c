@@ -556,12 +556,11 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
                 o->dims.support = o->dSupport;
                 /* narrow-band scales (<= maxR rows of the transposed spectrum hold every
                  * non-zero) skip the row pass: list the wide scales first, then the classes
-                 * R = 2, 4, 8, 16 (afx_device.h).  AFX_CWT_NARROW=0 sends every scale through
-                 * both passes; AFX_CWT_NARROW_MAX bounds the widest class used. */
+                 * R = 2, 4, 8, 16 (afx_device.h).  AFX_CWT_NARROW_MAX bounds the widest class used
+                 * (0: every scale takes both passes). */
                 int *order = (int *)malloc(sizeof(int) * (size_t)num);
-                const char *en = getenv("AFX_CWT_NARROW"), *em = getenv("AFX_CWT_NARROW_MAX");
-                int maxR = em ? atoi(em) : AFX_CWT_NARROW_MAX_DEFAULT;
-                if (en && atoi(en) == 0) maxR = 0;
+                const char *em = getenv("AFX_CWT_NARROW_MAX");
+                const int maxR = em ? atoi(em) : AFX_CWT_NARROW_MAX_DEFAULT;
                 if (order && st == AFX_OK && maxR >= 2) {
                     afx_cwt_classify_host(sup, num, maxR, order, &o->dims.nWide, o->dims.nNarrow);
                     /* device image: order[num] followed by the (scale, first support row) pairs */
@@ -597,7 +596,7 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
     }
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dBankT, sizeof(float) * num * L);
     if (st == AFX_OK) st = afxdev_h2d(o->dBankT, bankT, sizeof(float) * num * L, o->stream);
-    if (st == AFX_OK && fftLength <= 16384 && !getenv("AFX_NO_FUSED")) {
+    if (st == AFX_OK && fftLength <= 16384 && !afxdev_no_fused()) {
         st = afxdev_malloc((void **)&o->dBankN, sizeof(float) * num * L);
         if (st == AFX_OK) st = afxdev_h2d(o->dBankN, o->hBank, sizeof(float) * num * L, o->stream);
     }
@@ -686,7 +685,7 @@ static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+        afxdev_report_failure(who, st);
     }
 }
 
@@ -732,7 +731,7 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
         o->lastUsed = 1;
         if (st != AFX_OK) {
             o->status = st;
-            fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+            afxdev_report_failure(who, st);
         }
         return st;
     }
@@ -747,7 +746,7 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * the wrapper's default L = 2^13 (otherwise launch-bound). */
     const int nTwoPass = o->dims.order ? o->dims.nWide : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
-    const int overlap = !(getenv("AFX_CWT_OVERLAP") && atoi(getenv("AFX_CWT_OVERLAP")) == 0);
+    const int overlap = 1; /* (round 2: the three-chain schedule below is +10 % over one stream) */
     int group = nTwoPass > 0 ? (int)((overlap ? 48.0e6 : 96.0e6) / ((double)nTwoPass * L * 8.0)) : 32;
     if (group < 1) group = 1;
     {
@@ -764,15 +763,13 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
     /* independent two-pass chains in flight (each with its own intermediate): 2 measured best on cfg 4
      * with one chunk per launch pair (26.8 k vs 25.5 k chunks/s on one chain of two chunks) */
     int chains = (overlap && nTwoPass > 0) ? 2 : 1;
-    if (getenv("AFX_CWT_CHAINS") && atoi(getenv("AFX_CWT_CHAINS")) >= 1) chains = atoi(getenv("AFX_CWT_CHAINS"));
-    if (chains > 4) chains = 4;
     if (nTwoPass == 0) chains = 1;
     if (st == AFX_OK && nTwoPass > 0)
         st = afxdev_reserve((void **)&o->dGB, &o->capGB, sizeof(float) * gbFloats * chains);
     /* The narrow-band scales (no intermediate; bound by their instruction stream) run on a side stream
      * beside the two-pass launches of the wide scales (bound by the intermediate's round trip, and
      * short launches with < 2 waves per SIMD): both depend only on the forward transform of the
-     * batch.  Joined before the next forward batch overwrites the spectra.  AFX_CWT_OVERLAP=0: one stream. */
+     * batch.  Joined before the next forward batch overwrites the spectra. */
     void *side = NULL, *pipe = NULL; /* narrow-band side stream */
     if (nTwoPass > 0 && nTwoPass < o->num && overlap) {
         side = o->stream != hipStream ? o->stream : o->stream2;
@@ -821,7 +818,7 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
 
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+        afxdev_report_failure(who, st);
     }
     return st;
 }

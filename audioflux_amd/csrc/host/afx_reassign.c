@@ -212,7 +212,7 @@ void reassignObj_reassign(ReassignObj o, float *dataArr, int dataLength, float *
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] reassignObj_reassign failed (%d): %s\n", st, afxdev_last_error());
+        afxdev_report_failure("reassignObj_reassign", st);
     }
 }
 

@@ -433,7 +433,7 @@ int spectrogramObj_getBinBandLength(SpectrogramObj o) { return o ? o->num : 0; }
 
 static void fail(SpectrogramObj o, int st, const char *who) {
     o->status = st;
-    fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+    afxdev_report_failure(who, st);
 }
 
 /* the norm exponent the core applies: for a magnitude chroma the reference raises the FOLDED

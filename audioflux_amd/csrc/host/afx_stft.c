@@ -260,7 +260,7 @@ void afx_stft_keep_tail(STFTObj o, const float *dataArr, int dataLength, int tot
 
 static void fail(STFTObj o, int st, const char *who) {
     o->status = st;
-    fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, afxdev_last_error());
+    afxdev_report_failure(who, st);
 }
 
 void stftObj_stft(STFTObj o, float *dataArr, int dataLength, float *mRealArr, float *mImageArr) {

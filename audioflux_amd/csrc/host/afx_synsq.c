@@ -98,7 +98,7 @@ void synsqObj_synsq(SynsqObj o, float *freArr, SpectralFilterBankScaleType scale
     free(fn);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] synsqObj_synsq failed (%d): %s\n", st, afxdev_last_error());
+        afxdev_report_failure("synsqObj_synsq", st);
     }
 }
 

@@ -152,7 +152,7 @@ void wsstObj_wsst(WSSTObj o, float *dataArr, float *mRealArr1, float *mImageArr1
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] wsstObj_wsst failed (%d): %s\n", st, afxdev_last_error());
+        afxdev_report_failure("wsstObj_wsst", st);
     }
 }
 

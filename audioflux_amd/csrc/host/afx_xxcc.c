@@ -63,7 +63,7 @@ int xxccObj_xxccDevice(XXCCObj o, const float *dIn, long long rows, int ccNum,
     AFX_ENTER(o);
     if (!o || !dIn || !dOut) return AFX_ERR_ARG;
     if (ccNum > o->num || ccNum < 1) return AFX_ERR_ARG;
-    if (afxk_cepstrum_supported(dIn, o->num, ccNum) && !getenv("AFX_NO_FUSED"))
+    if (afxk_cepstrum_supported(dIn, o->num, ccNum) && !afxdev_no_fused())
         return afxk_cepstrum(dIn, rows, o->num, o->dDct, ccNum, rectify_to_map(rectifyType), dOut,
                              hipStream);
     return afxk_gemm_nt(dIn, o->num, o->dDct, o->num, dOut, ccNum, rows, ccNum, o->num,
@@ -96,7 +96,7 @@ void xxccObj_xxcc(XXCCObj o, float *mDataArr1, int ccNum, CepstralRectifyType *r
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] xxccObj_xxcc failed (%d): %s\n", st, afxdev_last_error());
+        afxdev_report_failure("xxccObj_xxcc", st);
     }
 }
 
@@ -118,7 +118,7 @@ int xxccObj_xxccBatch(XXCCObj o, const float *mDataArr1, long long rows, int ccN
     o->timeLength = keep;
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] xxccObj_xxccBatch failed (%d): %s\n", st, afxdev_last_error());
+        afxdev_report_failure("xxccObj_xxccBatch", st);
     }
     return st;
 }
@@ -161,8 +161,7 @@ void xxccObj_xxccStandard(XXCCObj o, float *mDataArr1, int ccNum, float *energyA
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     if (st != AFX_OK) {
         o->status = st;
-        fprintf(stderr, "[audioflux_mi355x] xxccObj_xxccStandard failed (%d): %s\n", st,
-                afxdev_last_error());
+        afxdev_report_failure("xxccObj_xxccStandard", st);
     }
 }
 

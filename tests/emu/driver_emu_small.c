@@ -1,7 +1,7 @@
 /* One short clip through the CQT + chroma call on the fully emulated library (tests/emu), for ThreadSanitizer: the lanes of
  * the emulated kernels are host threads that meet only at the kernels' own cross-lane operations and LDS-ordering points,
  * so an LDS word written by one lane and read by another without such a point in between is a reported data race --
- * i.e. a missing wave_lds_order() / __syncthreads() in the kernel.  AFX_CQT_FUSED / AFX_CQT_CHROMA_V2 / AFX_CQT_F32 select
+ * i.e. a missing wave_lds_order() / __syncthreads() in the kernel.  AFX_CQT_F32 selects
  * the kernels.  Exit status 0 and no ThreadSanitizer report = pass. */
 #include <stdio.h>
 #include <stdlib.h>

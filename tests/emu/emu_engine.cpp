@@ -20,7 +20,7 @@ struct Block {
     std::vector<Wave> waves;
 };
 std::mutex g_mu;
-std::map<std::string, int> g_counts;  // launches by kernel expression, e.g. "(k_cqt_all_f16<CHROMA>)"
+std::map<std::string, int> g_counts;  // launches by kernel expression, e.g. "(k_cqt_octave_f16<H, R12, TIMING>)"
 thread_local Wave *t_wave;
 thread_local Block *t_block;
 thread_local int t_lane;

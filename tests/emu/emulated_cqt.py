@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The DEVICE code of the f16 CQT kernels on the CPU (tests/emu): golden CQT / chroma vectors through the C host code,
-the real launchers and k_cqt_octave_f16 / k_cqt_all_f16 compiled for the host and run one thread per lane.
-AFX_LIB = the library tests/test_emulated_kernels.py builds; AFX_CQT_FUSED selects the all-octave kernel.
+the real launchers and the CQT kernels compiled for the host and run one thread per lane.
+AFX_LIB = the library tests/test_emulated_kernels.py builds; AFX_CQT_F32=1 selects the float32 matrix-core octave kernels.
 Prints one line per comparison, the launches seen, and OK."""
 import ctypes as C
 import os
@@ -77,11 +77,11 @@ def main():
         fn = list((C.c_int * 4).in_dll(lib, "afx_functional_launches"))
     except ValueError:
         fn = [0, 0, 0, 0]
-    print("launches: emulated octave_f16 %d, emulated all_f16 %d; contract-level octave_f32 %d, chroma %d" % (
-        lib.afx_emulated_launches(b"k_cqt_octave_f16"), lib.afx_emulated_launches(b"k_cqt_all_f16"), fn[1], fn[3]))
-    print("          emulated decimate %d, chroma %d, chroma_v2 %d, octave_mfma (f32) %d" % (
-        lib.afx_emulated_launches(b"k_cqt_decimate"), lib.afx_emulated_launches(b"k_cqt_chroma") - lib.afx_emulated_launches(b"k_cqt_chroma_v2"),
-        lib.afx_emulated_launches(b"k_cqt_chroma_v2"), lib.afx_emulated_launches(b"k_cqt_octave_mfma")))
+    print("launches: emulated octave_f16 %d; contract-level octave_f32 %d, chroma %d" % (
+        lib.afx_emulated_launches(b"k_cqt_octave_f16"), fn[1], fn[3]))
+    print("          emulated decimate %d, chroma %d, chroma_scan %d, octave_mfma (f32) %d" % (
+        lib.afx_emulated_launches(b"k_cqt_decimate"), lib.afx_emulated_launches(b"k_cqt_chroma") - lib.afx_emulated_launches(b"k_cqt_chroma_scan"),
+        lib.afx_emulated_launches(b"k_cqt_chroma_scan"), lib.afx_emulated_launches(b"k_cqt_octave_mfma")))
     print("OK")
 
 

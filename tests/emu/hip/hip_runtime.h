@@ -1,5 +1,5 @@
 // tests/emu/hip/hip_runtime.h -- a HOST EMULATION of the slice of HIP / gfx950 that the CQT wave kernels use, so that
-// their DEVICE code (audioflux_amd/csrc/hip/afx_cqt_f16.hip, afx_cqt_all.hip, included unchanged) can be compiled for
+// their DEVICE code (audioflux_amd/csrc/hip/afx_cqt_f16.hip, afx_gemm_bf16.hip, ..., included unchanged) can be compiled for
 // x86 and run on the CPU: tests/emu/cqt_emulated_*.cpp + tests/test_emulated_kernels.py.
 //
 // One host thread per lane.  Per-lane code runs as written; every cross-lane operation (MFMA, DPP, readlane,

@@ -192,19 +192,3 @@ int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num, c
     return AFX_OK;
 }
 
-/* level l = signal decimated l times, hop 128 >> l, octave 6 - l, one shared image */
-int afxk_cqt_all_f16(const AfxCqtAllArgs *a, void *stream) {
-    (void)stream;
-    if (!a->imageH || !a->colMul || a->num != 84 || a->batch <= 0 || a->timeLength <= 0) return AFX_ERR_UNSUPPORTED;
-    afx_functional_launches[2]++;
-    double *G = image_from_words(a->imageH, a->colMul, 512, 12);
-    for (int l = 0; l < 7; l++)
-        octave_product(a->x[l], a->xStride[l], a->validLength[l], 128 >> l, 512, G, 12, a->scale, a->octScale[l], a->num,
-                       12 * (6 - l), a->outRe, a->outIm, a->outStride, a->batch, a->timeLength);
-    free(G);
-    if (a->chroma)
-        for (int b = 0; b < a->batch; b++)
-            chroma_rows(a->outRe + b * a->outStride, a->outIm + b * a->outStride, a->timeLength, 84, a->cls, 12, a->isMag,
-                        a->normType, a->chroma + b * a->chromaStride);
-    return AFX_OK;
-}

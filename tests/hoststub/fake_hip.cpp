@@ -12,13 +12,11 @@
 // hipStreamWaitEvent edges, host synchronisation) and, for the CQT kernels -- whose argument lists it decodes -- the
 // address ranges every launch reads and writes: two launches that touch overlapping ranges, at least one writing,
 // without an ordering between them are reported as "FAKEHIP RACE".  That checks the multi-stream schedules of
-// afx_cqt.c (decimations on a side stream, the double-buffered level signals of AFX_CQT_FUSED=2) on the CPU;
+// afx_cqt.c (decimations on a side stream under the octave products) and afx_cwt.c (three chains) on the CPU;
 // A decoded range that starts inside one of the library's own allocations and ends past it is a "FAKEHIP OVERRUN".
 // FAKEHIP_ORDER=1 switches this on; FAKEHIP_DROP_WAIT=<k> ignores the k-th hipStreamWaitEvent (the detector's own
 // test).
-// With it the launch arithmetic of every kernel -- including the ones that have not been on hardware yet
-// (AFX_CQT_FUSED, AFX_CQT_CHROMA_V2, AFX_GEMM_BF16) -- runs at the BASELINE sizes and far beyond them without a
-// GPU.  It says nothing about what the kernels compute.  Test infrastructure, never linked into the product.
+// With it the launch arithmetic of every kernel runs at the BASELINE sizes and far beyond them without a GPU.  It says nothing about what the kernels compute.  Test infrastructure, never linked into the product.
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
@@ -156,13 +154,13 @@ struct CwtGeomView {
 const char *short_name(const std::string &mangled) {
     static const char *known[] = {"k_cwt_fwd_cols", "k_cwt_fwd_rows", "k_cwt_inv_rows512", "k_cwt_inv_cols256_nb", "k_cwt_inv_cols256",
                                   "k_cqt_decimate", "k_cqt_octave_f16", "k_cqt_octave_mfma_w", "k_cqt_octave_mfma", "k_cqt_octave",
-                                  "k_cqt_all_f16", "k_cqt_chroma_v2", "k_cqt_chroma"};
+                                  "k_cqt_chroma"};
     for (const char *k : known)
         if (mangled.find(k) != std::string::npos) return k;
     return nullptr;
 }
 
-// the CQT kernels' argument lists (afx_cqt.hip, afx_cqt_f16.hip, afx_cqt_all.hip) -> the ranges a launch reads / writes
+// the CQT kernels' argument lists (afx_cqt.hip, afx_cqt_f16.hip) -> the ranges a launch reads / writes
 void record_accesses(const std::string &mangled, dim3 g, void **args, const void *stream) {
     const char *k = order_on() ? short_name(mangled) : nullptr;
     if (!k) return;
@@ -238,15 +236,7 @@ void record_accesses(const std::string &mangled, dim3 g, void **args, const void
             touch(vc, stream, stamp, name, a.outRe + b * a.outStride, (long long)a.timeLength * a.num, true);
             touch(vc, stream, stamp, name, a.outIm + b * a.outStride, (long long)a.timeLength * a.num, true);
         }
-    } else if (name == "k_cqt_all_f16") {
-        const AfxCqtAllArgs &a = *static_cast<const AfxCqtAllArgs *>(args[0]);
-        for (int b = 0; b < a.batch; ++b) {
-            for (int l = 0; l < 7; ++l) touch(vc, stream, stamp, name, a.x[l] + b * a.xStride[l], a.validLength[l], false);
-            touch(vc, stream, stamp, name, a.outRe + b * a.outStride, (long long)a.timeLength * a.num, true);
-            touch(vc, stream, stamp, name, a.outIm + b * a.outStride, (long long)a.timeLength * a.num, true);
-            if (a.chroma) touch(vc, stream, stamp, name, a.chroma + b * a.chromaStride, (long long)a.timeLength * 12, true);
-        }
-    } else {  // k_cqt_chroma, k_cqt_chroma_v2: (re, im, rows, num, fold | lists, chromaNum, isMag, normType, out, vec4)
+    } else {  // k_cqt_chroma, k_cqt_chroma_scan: (re, im, rows, num, lists | fold, chromaNum, isMag, normType, out[, vec4])
         const float *re = *static_cast<const float **>(args[0]), *im = *static_cast<const float **>(args[1]);
         const long long rows = *static_cast<long long *>(args[2]);
         const int num = *static_cast<int *>(args[3]), cn = *static_cast<int *>(args[5]);

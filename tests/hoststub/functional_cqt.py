@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The CQT host code against the reference's golden vectors, with tests/hoststub/cqt_functional.c standing in for the
 kernels (double-precision loops that do what afx_device.h says each launcher does).  Environment switches select the
-launch path whose glue is exercised (default per-octave f16 arguments, AFX_CQT_F32, AFX_CQT_FUSED=1|2, AFX_CQT_CHUNK,
+launch path whose glue is exercised (default per-octave f16 arguments, AFX_CQT_F32, AFX_CQT_CHUNK,
 AFX_NO_FUSED for the spectral-kernel arguments).  Raw ctypes, no torch; AFX_LIB = the library built by
 tests/test_hoststub.py.  Prints one line per comparison and OK at the end."""
 import ctypes as C
@@ -82,7 +82,7 @@ def run(name, gold):
             check(f"{name} cqt beside chroma {cname}", reb[2] + 1j * imb[2], -want, 1e-5)
     lib.cqtObj_free(h)
     n = (C.c_int * 4).in_dll(lib, "afx_functional_launches")
-    print(f"{name} launches: octave_f16 {n[0]} octave_f32 {n[1]} all {n[2]} chroma {n[3]}")
+    print(f"{name} launches: octave_f16 {n[0]} octave_f32 {n[1]} chroma {n[3]}")
     for i in range(4):
         n[i] = 0
 

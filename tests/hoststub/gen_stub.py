@@ -39,6 +39,9 @@ int afxdev_ensure(void) { return AFX_OK; }
 const char *afxdev_last_error(void) { return g_err; }
 void afxdev_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); g_errs++; }
 int afxdev_error_count(void) { return g_errs; }
+void afxdev_report_failure(const char *who, int st) { (void)who; (void)st; g_errs++; }
+int afxdev_no_fused(void) { return getenv("AFX_NO_FUSED") != NULL; }
+int afxdev_cqt_f32(void) { return getenv("AFX_CQT_F32") != NULL; }
 /* (a request beyond 16 GiB fails like hipMalloc would on a full device: the constructor must hand the status on) */
 int afxdev_malloc(void **dptr, size_t bytes) {
     if (DRY) { *dptr = bytes > ((size_t)288 << 30) ? NULL : dry_alloc(bytes); return *dptr ? AFX_OK : AFX_ERR_NOMEM; }
@@ -87,21 +90,6 @@ int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
     touch_read(a->colMul, 32);
     touch_read((const float *)a->timeKernelH, 2 * 32 * 64 * 8 / 2);
     cqt_octave_touch(a);
-    return AFX_OK;
-}
-int afxk_cqt_all_f16(const AfxCqtAllArgs *a, void *stream) {
-    (void)stream;
-    if (!a->imageH || !a->colMul || a->num != 84) return AFX_ERR_UNSUPPORTED;
-    touch_read(a->colMul, 32);
-    touch_read((const float *)a->imageH, 2 * 32 * 64 * 8 / 2);
-    touch_read(a->scale, a->num);
-    for (int b = 0; b < a->batch; b++) {
-        for (int l = 0; l < 7; l++) touch_read(a->x[l] + b * a->xStride[l], a->validLength[l]);
-        touch_write(a->outRe + b * a->outStride, (long long)a->timeLength * a->num, 1.f);
-        touch_write(a->outIm + b * a->outStride, (long long)a->timeLength * a->num, 2.f);
-        if (a->chroma) touch_write(a->chroma + b * a->chromaStride, (long long)a->timeLength * 12, 3.f);
-    }
-    if (a->chroma) for (int j = 0; j < 84; j++) if (a->cls[j] >= 12) return AFX_ERR_ARG;
     return AFX_OK;
 }
 int afxk_cqt_chroma(const float *re, const float *im, long long rows, int num, const unsigned char *fold,
@@ -327,9 +315,9 @@ void afxk_melfused_destroy(void *plan) { free(plan); }
 int afxk_melfused_kind(const void *plan) { return plan ? 1 : 0; }
 '''
 
-DONE = {"afxdev_ensure", "afxdev_last_error", "afxdev_set_error", "afxdev_error_count", "afxdev_malloc", "afxdev_free",
+DONE = {"afxdev_ensure", "afxdev_last_error", "afxdev_set_error", "afxdev_error_count", "afxdev_report_failure", "afxdev_no_fused", "afxdev_cqt_f32", "afxdev_malloc", "afxdev_free",
         "afxdev_memset", "afxdev_h2d", "afxdev_d2h", "afxdev_d2d", "afxdev_stream_create", "afxdev_stream_destroy",
-        "afxdev_reserve", "afxk_cqt_decimate", "afxk_cqt_octave", "afxk_cqt_octave_f16", "afxk_cqt_all_f16",
+        "afxdev_reserve", "afxk_cqt_decimate", "afxk_cqt_octave", "afxk_cqt_octave_f16",
         "afxk_cqt_chroma", "afxk_stft", "afxk_istft", "afxk_spec_map", "afxk_row_post", "afxk_gemm_nt",
         "afxk_xxcc_standard", "afxk_cwt_forward", "afxk_cwt_inverse", "afxk_cwt_small", "afxk_wsst_squeeze",
         "afxk_synsq_phase", "afxk_reassign", "afxk_cqt_deconv", "afxk_cepstrogram", "afxk_cepstrum_supported",

@@ -9,9 +9,8 @@ the C host code + the real launchers of those files + their kernels, emulated: e
   * the shipped kernels -- the headline k_stft_mel_v2 (BASELINE cfg 1: mel 1.8e-7, MFCC 2.0e-7 of the golden vectors, the
     device's own figures), k_cqt_decimate, k_cqt_octave_f16, k_cqt_chroma and the f32 matrix-core octave kernels, all
     measured and parity-tested on the MI355X -- reproduce the golden vectors here too: that calibrates the emulation;
-  * k_cqt_all_f16 (AFX_CQT_FUSED, seven octaves + chroma in one launch), k_cqt_chroma_v2 (AFX_CQT_CHROMA_V2) and
-    k_gemm_nt128_bf16x3 (AFX_GEMM_BF16) were written without hardware access and have never run on a device: their
-    device code meets the golden vectors / a float64 product here, tails and all;
+  * k_cqt_chroma (host-built bin lists) and k_gemm_nt128_bf16x3 were written against this emulation at the end of round 2
+    and passed their first device run in round 3 unchanged (profiles/r03_round_start.txt); they stay covered here;
   * the rest of the fused STFT family (n_fft 1024, 4096, 2048 complex) runs its golden cases the same way.
 
 What this cannot show: timing, register pressure, the hardware's own accumulation order inside an MFMA.
@@ -31,7 +30,7 @@ INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audio
 STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
                                                      "afxk_melfused_destroy", "afxk_melfused_kind")]
 
-EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "cqt_emulated_all", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
+EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
              "mel_emulated_melfused1k", "mel_emulated_melfused4k")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
@@ -39,7 +38,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (
 
 @pytest.fixture(scope="module")
 def emulated(tmp_path_factory):
-    """C host objects + the launchers AND kernels of afx_cqt.hip, afx_cqt_f16.hip, afx_cqt_all.hip, afx_gemm_bf16.hip compiled
+    """C host objects + the launchers AND kernels of afx_cqt.hip, afx_cqt_f16.hip, afx_gemm_bf16.hip compiled
     for the host (every CQT launch is emulated device code) + the stand-in for the rest of the device layer"""
     import re
     from concurrent.futures import ThreadPoolExecutor
@@ -78,8 +77,7 @@ def emulated(tmp_path_factory):
 
 def _run(lib, script, args, env=""):
     e = dict(os.environ)
-    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED", "AFX_CQT_CHROMA_V2", "AFX_CQT_EXP", "AFX_CQT_STORE32",
-              "AFX_CQT_OVERLAP"):
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_NO_FUSED"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
@@ -92,17 +90,18 @@ def _run(lib, script, args, env=""):
 
 def _launches(out):
     import re
-    m = re.search(r"emulated octave_f16 (\d+), emulated all_f16 (\d+);.*\n\s+emulated decimate (\d+), chroma (\d+), chroma_v2 (\d+), "
+    m = re.search(r"emulated octave_f16 (\d+);.*\n\s+emulated decimate (\d+), chroma (\d+), chroma_scan (\d+), "
                   r"octave_mfma \(f32\) (\d+)", out)
     assert m, out[-2000:]
-    return dict(zip(("octave_f16", "all_f16", "decimate", "chroma", "chroma_v2", "octave_f32"), map(int, m.groups())))
+    return dict(zip(("octave_f16", "decimate", "chroma", "chroma_scan", "octave_f32"), map(int, m.groups())))
 
 
 def test_shipped_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
     """calibration: the kernels the device runs by default -- k_cqt_decimate, k_cqt_octave_f16 (all seven hop
-    instantiations, the 12-byte transposed stores), k_cqt_chroma -- through the emulation"""
+    instantiations, the 12-byte transposed stores), k_cqt_chroma (12 and 6 classes, max and min normalisation) --
+    through the emulation"""
     n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min"]))
-    assert n["octave_f16"] == 21 and n["decimate"] == 18 and n["chroma"] == 2 and n["all_f16"] + n["chroma_v2"] + n["octave_f32"] == 0, n
+    assert n["octave_f16"] == 21 and n["decimate"] == 18 and n["chroma"] == 2 and n["chroma_scan"] + n["octave_f32"] == 0, n
 
 
 def test_headline_kernel_emulated_meets_the_golden_vectors(emulated):
@@ -130,26 +129,8 @@ def test_f32_matrix_core_octave_kernels_emulated(emulated):
     assert n["octave_f32"] == 14 and n["octave_f16"] == 0, n
 
 
-@pytest.mark.parametrize("env,case,chromas", [("AFX_CQT_FUSED=1", "c84_32k_area", ["power_max", "mag_p2"]),
-                                              ("AFX_CQT_FUSED=2 AFX_CQT_CHUNK=1", "c84_32k_area", ["p1"]),
-                                              ("AFX_CQT_FUSED=1", "c84_44k_none_noscale", ["none"])])
-def test_all_octave_kernel_emulated_meets_the_golden_vectors(emulated, env, case, chromas):
-    """k_cqt_all_f16 (never on hardware): CQT and chroma of the golden cases from ONE emulated launch per pass -- level
-    walk, next-level prefetch, per-level multipliers, chroma accumulation and normalisation, tail tiles (235 frames),
-    an odd row stride; no octave or chroma launch besides it"""
-    n = _launches(_run(emulated, "emulated_cqt.py", [case, *chromas], env))
-    assert n["all_f16"] > 0 and n["decimate"] > 0 and n["octave_f16"] + n["octave_f32"] + n["chroma"] + n["chroma_v2"] == 0, n
-
-
-def test_chroma_v2_emulated_meets_the_golden_vectors(emulated):
-    """k_cqt_chroma_v2 (AFX_CQT_CHROMA_V2; never on hardware -- an earlier version of it hung the device): 12 and 6
-    classes, max and min normalisation, on the emulated CQT rows"""
-    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min"], "AFX_CQT_CHROMA_V2=1"))
-    assert n["chroma_v2"] == 2 and n["chroma"] == 0, n
-
-
 def test_bf16x3_gemm_emulated_matches_float64(emulated):
-    """k_gemm_nt128_bf16x3 (never on hardware): loader / three-word split / 24 MFMAs per k-step / epilogue with every
+    """k_gemm_nt128_bf16x3: loader / three-word split / 24 MFMAs per k-step / epilogue with every
     tail, elementwise against float64 on operands spanning ten decades"""
     out = _run(emulated, "emulated_gemm.py", [])
     assert out.count("elementwise relative error") == 3
@@ -198,17 +179,16 @@ def emulated_tsan(tmp_path_factory):
     return exes
 
 
-@pytest.mark.parametrize("exe,env", [("small", ""), ("small", "AFX_CQT_FUSED=1"), ("small", "AFX_CQT_CHROMA_V2=1"), ("small", "AFX_CQT_F32=1"),
-                                     ("small", "AFX_CQT_STORE32=1"), ("gemm", ""), ("bft", "")])
+@pytest.mark.parametrize("exe,env", [("small", ""), ("small", "AFX_CQT_F32=1"), ("gemm", ""), ("bft", "")])
 def test_emulated_kernels_have_no_lds_races(emulated_tsan, exe, env):
     """the lanes of an emulated kernel are host threads that meet only at the kernel's own cross-lane operations and
     LDS-ordering points (wave_lds_order, __syncthreads): under ThreadSanitizer an LDS word written by one lane and read
     by another without such a point in between is a data race -- a missing ordering point in the kernel, which on the
-    device shows up only when the compiler or the hardware reorders the two accesses.  None in the shipped kernels, none
-    in k_cqt_all_f16 / k_cqt_chroma_v2 / k_gemm_nt128_bf16x3; "bft": the fused STFT -> filter-bank kernels of n_fft 1024 /
+    device shows up only when the compiler or the hardware reorders the two accesses.  None in the CQT kernels or the
+    three-word GEMM; "bft": the fused STFT -> filter-bank kernels of n_fft 1024 /
     4096 / 2048-complex (tests/emu/driver_emu_bft.c)."""
     e = dict(os.environ)
-    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED", "AFX_CQT_CHROMA_V2", "AFX_CQT_EXP", "AFX_CQT_STORE32"):
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_NO_FUSED"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())

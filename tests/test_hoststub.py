@@ -2,8 +2,8 @@
 device layer (tests/hoststub/gen_stub.py: "device" memory is host memory, kernels do no arithmetic, the CQT launchers
 touch every range they are handed).
 
-  * tests/hoststub/driver_cqt.c drives every CQT entry point -- passes (AFX_CQT_CHUNK), the f32 / f16 / fused-launch
-    glue (AFX_CQT_F32, AFX_CQT_FUSED=1|2), chroma with a changing class count, free -- with leak detection on;
+  * tests/hoststub/driver_cqt.c drives every CQT entry point -- passes (AFX_CQT_CHUNK), the f32 / f16 glue
+    (AFX_CQT_F32), chroma with a changing class count, free -- with leak detection on;
   * the whole `-m gpu` suite then runs against the sanitized library (AFX_HOSTSTUB=1: parity assertions are skipped,
     tests that need torch end with ImportError): every constructor and every first compute call of every test case
     goes through the host code under the sanitizers.  Results are meaningless there; a sanitizer report is a failure.
@@ -65,24 +65,21 @@ def _run_driver(exe, env, knobs):
     assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-3000:]
 
 
-@pytest.mark.parametrize("env", ["", "AFX_CQT_CHUNK=2", "AFX_CQT_OVERLAP=0 AFX_CQT_CHUNK=3", "AFX_CQT_F32=1",
-                                 "AFX_CQT_FUSED=1", "AFX_CQT_FUSED=1 AFX_CQT_CHUNK=2", "AFX_CQT_FUSED=2",
-                                 "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2", "AFX_CQT_CHROMA_V2=1"])
+@pytest.mark.parametrize("env", ["", "AFX_CQT_CHUNK=2", "AFX_CQT_CHUNK=3", "AFX_CQT_F32=1", "AFX_NO_FUSED=1"])
 def test_cqt_host_logic_is_clean_under_sanitizers(built, env):
     _run_driver(built[2]["driver_cqt"], env,
-                ("AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2"))
+                ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_NO_FUSED"))
 
 
-@pytest.mark.parametrize("env", ["", "AFX_SCRATCH_MB=1", "AFX_NO_FUSED_CC=1", "AFX_NO_FUSED=1", "AFX_CWT_GROUP=2",
-                                 "AFX_CWT_OVERLAP=0", "AFX_CWT_CHAINS=3 AFX_CWT_GROUP=1", "AFX_CWT_NARROW_MAX=0"])
+@pytest.mark.parametrize("env", ["", "AFX_SCRATCH_MB=1", "AFX_NO_FUSED=1", "AFX_CWT_GROUP=2", "AFX_CWT_GROUP=1",
+                                 "AFX_CWT_NARROW_MAX=0"])
 def test_device_pointer_entry_points_are_clean_under_sanitizers(built, env):
     """tests/hoststub/driver_batch.c: the ...BatchDevice calls of include/afx_batch.h (which the Python GPU tests reach
     through torch tensors) with exactly-sized buffers: mel + MFCC in one call, dense-bank route in several chunks,
     temporal features, complex results, STFT / inverse STFT, spectrogram object, cepstrogram, reassignment, CWT at
     2^12 and 2^16 (chunk groups, chains, narrow-band plan on / off, padded), PWT, WSST"""
     _run_driver(built[2]["driver_batch"], env,
-                ("AFX_SCRATCH_MB", "AFX_NO_FUSED_CC", "AFX_NO_FUSED", "AFX_CWT_GROUP", "AFX_CWT_OVERLAP", "AFX_CWT_CHAINS",
-                 "AFX_CWT_NARROW_MAX"))
+                ("AFX_SCRATCH_MB", "AFX_NO_FUSED", "AFX_CWT_GROUP", "AFX_CWT_NARROW_MAX"))
 
 
 def test_every_gpu_test_case_drives_clean_host_code(built):
@@ -166,17 +163,14 @@ def functional(tmp_path_factory):
 
 
 @pytest.mark.parametrize("env,path", [("", "octave_f16"), ("AFX_CQT_CHUNK=2", "octave_f16"), ("AFX_CQT_F32=1", "octave_f32"),
-                                      ("AFX_NO_FUSED=1", "octave_f32"), ("AFX_CQT_FUSED=1", "all"),
-                                      ("AFX_CQT_FUSED=1 AFX_CQT_CHUNK=1", "all"), ("AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2", "all"),
-                                      ("AFX_CQT_FUSED=2", "all")])
+                                      ("AFX_NO_FUSED=1", "octave_f32")])
 def test_cqt_host_glue_meets_the_golden_vectors_with_functional_launchers(functional, env, path):
     """tests/hoststub/functional_cqt.py: the reference's golden CQT / chroma vectors through the C host code with the
     kernels replaced by their contracts.  Every launch path's arguments (f16 image words and column multipliers,
-    float32 image, spectral kernels, the level table / class table of the all-octave launch, passes with a row stride
-    that is not a multiple of four) must reproduce the reference to 1e-5 -- including AFX_CQT_FUSED, whose kernel has not
-    been on hardware yet: its host half is pinned here.  `path` = the launcher the default 84-bin plan must have used."""
+    float32 image, spectral kernels, passes with a row stride that is not a multiple of four) must reproduce the
+    reference to 1e-5.  `path` = the launcher the default 84-bin plan must have used."""
     e = dict(os.environ)
-    for k in ("AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_NO_FUSED"):
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_NO_FUSED"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
@@ -187,13 +181,13 @@ def test_cqt_host_glue_meets_the_golden_vectors_with_functional_launchers(functi
     assert r.returncode == 0 and "\nOK" in out, out[-3000:]
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
     import re
-    m = re.search(r"c84_32k_area launches: octave_f16 (\d+) octave_f32 (\d+) all (\d+) chroma (\d+)", out)
+    m = re.search(r"c84_32k_area launches: octave_f16 (\d+) octave_f32 (\d+) chroma (\d+)", out)
     assert m, out[-2000:]
-    n = dict(zip(("octave_f16", "octave_f32", "all", "chroma"), map(int, m.groups())))
-    assert n[path] > 0 and all(n[k] == 0 for k in ("octave_f16", "octave_f32", "all") if k != path), n
+    n = dict(zip(("octave_f16", "octave_f32", "chroma"), map(int, m.groups())))
+    assert n[path] > 0 and all(n[k] == 0 for k in ("octave_f16", "octave_f32") if k != path), n
 
 
-@pytest.mark.parametrize("env", ["", "AFX_CQT_FUSED=1"])
+@pytest.mark.parametrize("env", ["", "AFX_CQT_F32=1"])
 def test_reference_wrapper_drives_the_cqt_host_code_on_the_cpu(functional, tmp_path, env):
     """tests/dropin/flows.py cqt_functional: the reference's own unmodified Python wrapper (set_fft_lib) on the host
     objects + functional CQT launchers, against the stock library through the same wrapper: CQT, chroma, frequency
@@ -205,7 +199,7 @@ def test_reference_wrapper_drives_the_cqt_host_code_on_the_cpu(functional, tmp_p
     if not (os.path.exists(flows.STOCK) and (os.path.exists(flows.WRAPPER_ZIP) or os.path.isdir("/root/reference/python/audioflux"))):
         pytest.skip("needs oracle/_ref (make -C oracle)")
     e = dict(os.environ)
-    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_NO_FUSED"):
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_NO_FUSED"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
@@ -274,22 +268,19 @@ def launch_audit(tmp_path_factory):
 
 
 @pytest.mark.parametrize("env,expect", [("", "k_stft_mel_v2"), ("AFX_NO_FUSED=1", "k_stft_generic"),
-                                        ("AFX_CQT_F32=1", "k_cqt_octave_mfma"), ("AFX_CQT_FUSED=1", "k_cqt_all_f16"),
-                                        ("AFX_CQT_FUSED=2", "k_cqt_all_f16"), ("AFX_CQT_CHROMA_V2=1", "k_cqt_chroma_v2"),
-                                        ("AFX_GEMM_BF16=1", "bf16x3"), ("AFX_CWT_NARROW_MAX=0", "k_cwt_inv_rows512"),
-                                        ("AFX_NO_FUSED_CC=1", "k_cepstrum_mfma"), ("AFX_SCRATCH_MB=64", "k_gemm_nt128")])
+                                        ("AFX_CQT_F32=1", "k_cqt_octave_mfma"), ("AFX_CQT_CHUNK=7", "k_cqt_chroma"),
+                                        ("AFX_CWT_NARROW_MAX=0", "k_cwt_inv_rows512"), ("AFX_SCRATCH_MB=64", "bf16x3")])
 def test_launch_audit(launch_audit, env, expect):
     """every device-pointer entry point at the BASELINE sizes (must succeed), 20x, and far beyond the device's memory,
     through the real launchers: no launch configuration outside the HIP limits (block size, grid dimensions, dynamic
     LDS vs the raised attribute and the 160 KB of a CU), no UBSan / integer-check report in the launch arithmetic, and
-    the kernel the switch is about was reached -- including the kernels that have not been on hardware yet.  Launches
+    the kernel the switch is about was reached.  Launches
     with 2^32 or more threads in one dimension are rejected by the stand-in runtime as HIP rejects them; they may only
     come from batches whose buffers exceed the device (the size-generic STFT / cepstrogram / inverse-STFT launchers
     split such batches into launches of whole clips -- found here: 4 477 clips of 30 s at n_fft 512 / hop 128 used to
     fail)."""
     e = dict(os.environ)
-    for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_GEMM_BF16", "AFX_CWT_NARROW_MAX",
-              "AFX_NO_FUSED_CC", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK"):
+    for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CWT_NARROW_MAX", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
@@ -305,13 +296,9 @@ def test_launch_audit(launch_audit, env, expect):
 
 
 @pytest.mark.parametrize("driver,env", [("driver_batch", ""), ("driver_batch", "AFX_SCRATCH_MB=1"), ("driver_batch", "AFX_NO_FUSED=1"),
-                                        ("driver_batch", "AFX_NO_FUSED_CC=1"), ("driver_batch", "AFX_CWT_CHAINS=3 AFX_CWT_GROUP=1"),
-                                        ("driver_batch", "AFX_GEMM_BF16=1"), ("driver_batch", "AFX_CWT_GROUP=2"),
-                                        ("driver_batch", "AFX_CWT_NARROW_MAX=0"), ("driver_batch", "AFX_CWT_OVERLAP=0"), ("driver_cqt", ""), ("driver_cqt", "AFX_CQT_F32=1"),
-                                        ("driver_cqt", "AFX_NO_FUSED=1"), ("driver_cqt", "AFX_CQT_FUSED=1"),
-                                        ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_FUSED=2 AFX_CQT_CHUNK=1"),
-                                        ("driver_cqt", "AFX_CQT_CHUNK=2"), ("driver_cqt", "AFX_CQT_OVERLAP=0"),
-                                        ("driver_cqt", "AFX_CQT_CHROMA_V2=1")])
+                                        ("driver_batch", "AFX_CWT_GROUP=1"), ("driver_batch", "AFX_CWT_GROUP=2"),
+                                        ("driver_batch", "AFX_CWT_NARROW_MAX=0"), ("driver_cqt", ""), ("driver_cqt", "AFX_CQT_F32=1"),
+                                        ("driver_cqt", "AFX_NO_FUSED=1"), ("driver_cqt", "AFX_CQT_CHUNK=2")])
 def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
     """the configurations of tests/hoststub/driver_batch.c / driver_cqt.c (mel / gammatone / 40-band / temporal banks,
     STFT and inverse, spectrogram, cepstrogram at two sizes, reassignment, CWT at 2^12 and 2^16 padded and not, PWT,
@@ -319,12 +306,11 @@ def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
     and the checking HIP stand-in.  For the CQT kernels the stand-in also decodes the argument lists and keeps the
     happens-before relation of the streams: a launch that reads or writes a range another stream's launch writes,
     without an event or synchronisation between them, is a "FAKEHIP RACE" (the side-stream decimations of the default
-    path, the double-buffered level signals of AFX_CQT_FUSED=2); the same for the four-step CWT kernels, whose scale
+    path); the same for the four-step CWT kernels, whose scale
     lists it reads from the retained uploads (forward batch -> narrow-band scales on a side stream + two-pass chunk
     groups alternating over the chain streams, each with its own intermediate)."""
     e = dict(os.environ)
-    for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHROMA_V2", "AFX_GEMM_BF16", "AFX_CWT_CHAINS", "AFX_CWT_GROUP",
-              "AFX_NO_FUSED_CC", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "FAKEHIP_DROP_WAIT"):
+    for k in ("AFX_NO_FUSED", "AFX_CQT_F32", "AFX_CWT_GROUP", "AFX_SCRATCH_MB", "AFX_CQT_CHUNK", "FAKEHIP_DROP_WAIT"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
@@ -336,13 +322,12 @@ def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
     assert not any(b in out for b in bad), "\n".join(ln for ln in out.splitlines() if any(b in ln for b in bad))[:3000]
 
 
-@pytest.mark.parametrize("env,pair", [("", "k_cqt_decimate (write)  <->  k_cqt_octave_f16 (read)"),
-                                      ("AFX_CQT_FUSED=2 AFX_CQT_CHUNK=2", "k_cqt_decimate (write)  <->  k_cqt_all_f16 (read)")])
+@pytest.mark.parametrize("env,pair", [("", "k_cqt_decimate (write)  <->  k_cqt_octave_f16 (read)")])
 def test_the_stream_order_check_sees_a_lost_wait(launch_audit, env, pair):
     """the detector's own test: with the second hipStreamWaitEvent of the run ignored (FAKEHIP_DROP_WAIT=2: "the octave
     product waits for the decimation that produced its input") the same driver must end in a race report"""
     e = dict(os.environ)
-    for k in ("AFX_CQT_F32", "AFX_CQT_FUSED", "AFX_CQT_CHUNK", "AFX_CQT_OVERLAP", "AFX_NO_FUSED"):
+    for k in ("AFX_CQT_F32", "AFX_CQT_CHUNK", "AFX_NO_FUSED"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())

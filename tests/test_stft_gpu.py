@@ -175,11 +175,10 @@ def test_degenerate_inputs():
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("r,hop", [(11, 512), (11, 301), (12, 1024), (12, 700)])
-def test_wave_kernel_every_padding_mode_and_the_generic_kernel(r, hop, monkeypatch):
+def test_wave_kernel_every_padding_mode_and_the_generic_kernel(r, hop):
     """n_fft 2048 runs one wave per frame (k_stft_wave): interior frames by vector loads, frames touching
     the clip's ends sample by sample through the padding index map -- every position x mode, against
-    the compiled reference (n_fft 4096: the size-generic kernel, same checks); and the size-generic
-    kernel (AFX_NO_STFT_WAVE=1) agrees"""
+    the compiled reference (n_fft 4096: the size-generic kernel, same checks)"""
     n = 1 << r
     x = cases.noise(300 + r + hop, 5 * n + 123)
     for pos in (0, 1, 2):
@@ -193,16 +192,8 @@ def test_wave_kernel_every_padding_mode_and_the_generic_kernel(r, hop, monkeypat
             re, im = rr.stft(x)
             gre, gim = o.stft_full(x)
             assert_parity(gre + 1j * gim, re + 1j * im, TOL, f"r{r} hop{hop} pos{pos} mode{mode}")
-    o = af.STFT(radix2_exp=r, window_type=af.WindowType.HANN, slide_length=hop)
-    wre, wim = o.stft_full(x)
-    monkeypatch.setenv("AFX_NO_STFT_WAVE", "1")
-    gre, gim = o.stft_full(x)
-    assert_parity(wre + 1j * wim, gre + 1j * gim, TOL, "wave vs size-generic kernel")
 
 
-@pytest.mark.skipif(not os.environ.get("AFX_TEST_UNVERIFIED"),
-                    reason="written without hardware access at the end of round 2: enabled by tools/gpu_round_start.sh, "
-                           "made unconditional once it has passed on the device")
 def test_batches_beyond_2_32_threads_per_launch_are_split():
     """the size-generic kernels run one workgroup per frame and HIP rejects a launch with 2^32 or more threads in one
     dimension: afxk_stft / afxk_istft split such a batch into launches of whole clips (found by the CPU launch audit,
