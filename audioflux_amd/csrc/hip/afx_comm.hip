@@ -91,12 +91,19 @@ extern "C" int afx_comm_get_unique_id(void *id) {
     return AFX_OK;
 }
 
+// The communicator is bound to the CALLING THREAD'S CURRENT HIP device -- what hipSetDevice / torch.cuda.set_device /
+// afx_set_device last selected on this thread -- not to the library's default: with one process per GPU every rank
+// must initialise RCCL on its own device (all on the default device = duplicate-GPU error or a hang).  The thread's
+// current device is left as it was.
 extern "C" int afx_comm_create(AfxCommObj *comm, int worldSize, int rank, const void *id) {
     if (!comm) return AFX_ERR_ARG;
     *comm = nullptr;
     if (!id || worldSize < 1 || rank < 0 || rank >= worldSize) return AFX_ERR_ARG;
-    int st = afxdev_ensure();  // the communicator lives on the library's device of this process
-    if (st != AFX_OK) return st;
+    int dev = -1;
+    if (afxdev_device_count() <= 0 || hipGetDevice(&dev) != hipSuccess || dev < 0) {
+        afxdev_set_error("afx_comm_create: no current HIP device");
+        return AFX_ERR_NODEVICE;
+    }
     const Rccl *r = rccl();
     if (!r) return AFX_ERR_UNSUPPORTED;
     AfxComm *c = static_cast<AfxComm *>(calloc(1, sizeof(AfxComm)));
@@ -105,13 +112,13 @@ extern "C" int afx_comm_create(AfxCommObj *comm, int worldSize, int rank, const 
     memcpy(&u, id, sizeof(u));
     ncclResult_t e = r->commInitRank(&c->comm, worldSize, u, rank);
     if (e != ncclSuccess) {
-        afxdev_set_error("ncclCommInitRank(world %d, rank %d) failed: %s", worldSize, rank, r->errorString(e));
+        afxdev_set_error("ncclCommInitRank(world %d, rank %d, device %d) failed: %s", worldSize, rank, dev, r->errorString(e));
         free(c);
         return AFX_ERR_HIP;
     }
     c->world = worldSize;
     c->rank = rank;
-    c->device = afxdev_current_device();
+    c->device = dev;
     *comm = c;
     return AFX_OK;
 }
@@ -124,9 +131,23 @@ extern "C" int afx_gather(AfxCommObj c, const float *dSend, long long count, flo
     if (c->rank == root && !dRecv) return AFX_ERR_ARG;
     const Rccl *r = rccl();
     if (!r) return AFX_ERR_UNSUPPORTED;
-    if (afxdev_current_device() != c->device) AFX_HIP(hipSetDevice(c->device));
+    // the stream (and with it the slabs) must live on the communicator's device
+    if (hipStream) {
+        hipDevice_t sd = 0;
+        if (hipStreamGetDevice((hipStream_t)hipStream, &sd) == hipSuccess && (int)sd != c->device) {
+            afxdev_set_error("afx_gather: stream on device %d, communicator on device %d", (int)sd, c->device);
+            return AFX_ERR_ARG;
+        }
+    }
     if (count == 0) return AFX_OK;
-    AFX_NCCL(r, r->gather(dSend, dRecv, (size_t)count, ncclFloat32, root, c->comm, (hipStream_t)hipStream));
+    const int prev = afxdev_current_device();
+    if (prev != c->device) AFX_HIP(hipSetDevice(c->device));
+    const ncclResult_t e = r->gather(dSend, dRecv, (size_t)count, ncclFloat32, root, c->comm, (hipStream_t)hipStream);
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);  // the caller's device stays current
+    if (e != ncclSuccess) {
+        afxdev_set_error("ncclGather failed: %s", r->errorString(e));
+        return AFX_ERR_HIP;
+    }
     return AFX_OK;
 }
 

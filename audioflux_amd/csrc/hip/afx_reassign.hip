@@ -173,11 +173,17 @@ extern "C" int afxk_reassign(const AfxReassignArgs *a, int order, int *idxScratc
     unsigned endBit = 1;
     while (endBit < 64 && (1ull << endBit) < (unsigned long long)nMax) ++endBit;
     AFX_HIP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keysIn, keysOut, srcIn, srcOut, (size_t)nMax, 0u, 64u, hs));
-    AFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&keysIn), sizeof(unsigned long long) * nMax, hs));
-    AFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&keysOut), sizeof(unsigned long long) * nMax, hs));
-    AFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&srcOut), sizeof(unsigned) * nMax, hs));
-    AFX_HIP(hipMallocAsync(&tmp, tmpBytes ? tmpBytes : 4, hs));
     int st = AFX_OK;
+    {   // stream-ordered scratch; any failure frees what was obtained (the frees below take nullptr)
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&keysIn), sizeof(unsigned long long) * nMax, hs);
+        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void **>(&keysOut), sizeof(unsigned long long) * nMax, hs);
+        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void **>(&srcOut), sizeof(unsigned) * nMax, hs);
+        if (e == hipSuccess) e = hipMallocAsync(&tmp, tmpBytes ? tmpBytes : 4, hs);
+        if (e != hipSuccess) {
+            afxdev_set_error("reassign: %lld coefficients of sort scratch: %s", nMax, hipGetErrorString(e));
+            st = AFX_ERR_NOMEM;
+        }
+    }
     for (int c0 = 0; c0 < a->batch && st == AFX_OK; c0 += per) {
         const int nc = (a->batch - c0 < per) ? a->batch - c0 : per;
         const long long n = (long long)nc * cells;
@@ -192,10 +198,10 @@ extern "C" int afxk_reassign(const AfxReassignArgs *a, int order, int *idxScratc
         hipLaunchKernelGGL(k_reassign_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, b, c0, n, keysOut, srcOut);
     }
     (void)endBit;
-    (void)hipFreeAsync(keysIn, hs);
-    (void)hipFreeAsync(keysOut, hs);
-    (void)hipFreeAsync(srcOut, hs);
-    (void)hipFreeAsync(tmp, hs);
+    if (keysIn) (void)hipFreeAsync(keysIn, hs);
+    if (keysOut) (void)hipFreeAsync(keysOut, hs);
+    if (srcOut) (void)hipFreeAsync(srcOut, hs);
+    if (tmp) (void)hipFreeAsync(tmp, hs);
     if (st != AFX_OK) return st;
     AFX_LAUNCH_CHECK("k_reassign_sum");
     return AFX_OK;

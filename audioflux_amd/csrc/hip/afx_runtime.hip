@@ -221,13 +221,40 @@ extern "C" int afxdev_stream_create(void **stream) {
     return AFX_OK;
 }
 
-// `waiter` waits (on the device) for everything enqueued on `signaler` so far
+// `waiter` waits (on the device) for everything enqueued on `signaler` so far.  The multi-stream schedules (CQT
+// decimations under the octave products, the CWT chains) call this two or three times per launch group: the
+// events come from a small per-thread, per-device ring instead of a create / destroy pair per call (a wait
+// captures the record that precedes it, so an event may be recorded again while an earlier wait is pending).
+namespace {
+struct EventRing {
+    hipEvent_t ev[8];
+    int dev = -1, next = 0;  // (no destructor: a thread may end after the HIP runtime has shut down)
+};
+thread_local EventRing t_events;
+}  // namespace
+
 extern "C" int afxdev_stream_wait_stream(void *waiter, void *signaler) {
-    hipEvent_t ev;
-    AFX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int dev = -1;
+    AFX_HIP(hipGetDevice(&dev));
+    EventRing &r = t_events;
+    if (r.dev != dev) {
+        if (r.dev >= 0)
+            for (hipEvent_t e : r.ev) (void)hipEventDestroy(e);
+        r.dev = -1;
+        for (int i = 0; i < 8; ++i) {
+            if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) {
+                for (int j = 0; j < i; ++j) (void)hipEventDestroy(r.ev[j]);
+                afxdev_set_error("stream wait: hipEventCreate failed");
+                return AFX_ERR_HIP;
+            }
+        }
+        r.dev = dev;
+        r.next = 0;
+    }
+    hipEvent_t ev = r.ev[r.next];
+    r.next = (r.next + 1) & 7;
     hipError_t e = hipEventRecord(ev, (hipStream_t)signaler);
     if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
-    (void)hipEventDestroy(ev);  // released by the runtime once the recorded work has completed
     if (e != hipSuccess) {
         afxdev_set_error("stream wait: %s", hipGetErrorString(e));
         return AFX_ERR_HIP;

@@ -24,6 +24,12 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    if "LOCAL_RANK" in os.environ and torch.cuda.is_available():
+        # one process per GPU: torch's current device AND the library's default device (new objects, their
+        # streams and scratch; the device afx_comm_create binds a communicator to) are this rank's GPU
+        from . import _lib
+        torch.cuda.set_device(local)
+        _lib.check(_lib.get_lib().afx_set_device(local), "afx_set_device")
     return rank, local, world
 
 

@@ -21,9 +21,13 @@ DCT-II); it is timed live with HIP events on the stream it is launched on (torch
 handed to the library).  `achieved` = SURVEY 8d's algorithmic bytes per unit x units per launch /
 that duration; `sustained_ms` repeats the step back to back for >= 1 s (sustained clocks, where the
 K-step region of a short run sees boost clocks); `traffic` = HBM bytes per launch from the round's
-own rocprofv3 --pmc passes of this command (profiles/r02_bench_cfg<N>_pmc.json, written by
+own rocprofv3 --pmc passes of this command (profiles/r03_bench_cfg<N>_pmc.json, written by
 tools/prof_traffic.py), null when that file is absent.  After the timed region clip 0 of the
 benchmarked outputs is checked against the oracle (1e-5 peak / L2).
+`secondary` (--config 2 at one GPU, the driver's line): cfg 4 and cfg 5 measured in the same process after the
+headline -- value, ms_per_step, frac, PMC traffic, oracle check each.  With N > 1 `gather` says whether the
+exchange hides behind the compute: gather_ms (device time of the collective on rank 0's side stream),
+exposed_ms (step time beyond the step's own compute) and overlap_hidden_ms.
 `cpu_baseline` times the reference's own C path (oracle/_ref, built-in FFT + naive
 double-accumulating matmul: no FFTW/MKL in this image) on the host cores for a bounded sample.
 """
@@ -326,28 +330,32 @@ class DryRun:
     """AFX_BENCH_DRYRUN=1: a CPU stand-in for the kernels (tests/test_dist_cpu.py runs this file under
     torch.distributed.run with the gloo backend): the distributed control flow of a bench run -- clip
     ownership, double-buffered slabs, the side-stream gather, fences, the max-over-ranks clock, the
-    JSON line -- executes unchanged; every clip's "features" carry its global index."""
-    config = 2
+    JSON line -- executes unchanged; every clip's "features" carry its global index.  `config` picks
+    the slab names and widths of the real workload (cfg 2: mfcc[.,13] + mel[.,128]; cfg 5: chroma[.,12]
+    + cqt[.,84]); `first_clip` is the rank's offset in the job's clip order (shard_range)."""
     metric, unit = "dry run (no device)", "frames/s"
     default_clips = 4
     bytes_per_unit = 2612
     kernel = "none (CPU stand-in)"
-    gather_choices = ("mfcc", "mel")
+    SLABS = {2: (("mfcc", 13), ("mel", 128)), 5: (("chroma", 12), ("cqt", 84))}
 
-    def __init__(self, torch, af, dev, rank, clips):
+    def __init__(self, torch, af, dev, rank, clips, config=2, first_clip=None):
         self.torch, self.clips, self.rank = torch, clips, rank
+        self.first = rank * clips if first_clip is None else first_clip
         self.T, self.units = 7, clips * 7
-        self.mel = torch.zeros((clips, self.T, 128))
-        self.cc = [torch.zeros((clips, self.T, 13)) for _ in range(2)]
-        self.workload, self.outputs = f"dry run, {clips} clips per rank", "CPU tensors"
+        (self.small, ws), (self.big, wb) = self.SLABS[config]
+        self.gather_choices = (self.small, self.big)
+        self.wide = torch.zeros((clips, self.T, wb))
+        self.cc = [torch.zeros((clips, self.T, ws)) for _ in range(2)]
+        self.workload, self.outputs = f"dry run of cfg {config}, {clips} clips on this rank", "CPU tensors"
 
     def step(self, i):
-        ids = self.torch.arange(self.rank * self.clips, (self.rank + 1) * self.clips, dtype=self.torch.float32)
+        ids = self.torch.arange(self.first, self.first + self.clips, dtype=self.torch.float32)
         self.cc[i & 1][:] = (ids * 1000 + i)[:, None, None]   # clip id and step, checkable after the gather
-        self.mel[:] = ids[:, None, None]
+        self.wide[:] = ids[:, None, None]
 
     def slab(self, i, which):
-        return self.cc[i & 1] if which == "mfcc" else self.mel
+        return self.cc[i & 1] if which == self.small else self.wide
 
     def check(self, i):
         return None
@@ -363,13 +371,129 @@ def pmc_traffic(config, clips):
     """HBM bytes per step from the round's rocprofv3 --pmc passes of this command
     (tools/prof_traffic.py): 2 x FETCH_SIZE (gfx950 tallies wide coalesced reads at half,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB, scaled to this run's clip count"""
-    path = os.path.join(ROOT, "profiles", f"r02_bench_cfg{config}_pmc.json")
-    try:
-        rec = json.load(open(path))
-        per_step = (2.0 * rec["fetch_kib_per_step"] + rec["write_kib_per_step"]) * 1024.0
-        return per_step * clips / rec["clips"], os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
-        return None, None
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_bench_cfg{config}_pmc.json")
+        try:
+            rec = json.load(open(path))
+            per_step = (2.0 * rec["fetch_kib_per_step"] + rec["write_kib_per_step"]) * 1024.0
+            return per_step * clips / rec["clips"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+class CpuEvent:
+    """stand-in for torch.cuda.Event in the dry run"""
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s, gathers=(), which=(), dry=False):
+    """W untimed steps, then exactly `steps` steps between barrier + synchronize fences; per-step device time from
+    events on the launch stream; optionally a back-to-back loop of >= sustained_s seconds.  With `gathers` the slabs
+    of step i travel to rank 0 on a side stream while step i + 1 computes (double-buffered sources)."""
+    Event = CpuEvent if dry else torch.cuda.Event
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    comm = torch.cuda.Stream(device=dev) if (gathers and not dry) else None
+    ev, gev = [], []
+
+    def step(i, timed):
+        e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
+        e0.record()
+        w.step(i)
+        e1.record()
+        if timed:
+            ev.append((e0, e1))
+        if gathers:
+            # the slabs of this step go to rank 0 while the next step computes (double-buffered
+            # sources; the previous gather has had a whole step to finish)
+            for g in gathers:
+                g.wait()
+            if comm is not None:
+                comm.wait_stream(torch.cuda.current_stream())
+            with (torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()):
+                g0, g1 = Event(enable_timing=True), Event(enable_timing=True)
+                g0.record()
+                for g, name in zip(gathers, which):
+                    g.start(w.slab(i, name))
+                g1.record()
+                if timed:
+                    gev.append((g0, g1))
+
+    def fence():
+        for g in gathers:
+            g.wait()
+        if comm is not None:
+            torch.cuda.current_stream().wait_stream(comm)
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    if clock_warmup > 0 and not dry:
+        # untimed, like the W steps below: brings the clocks to their loaded state.  Compute only --
+        # the ranks run different numbers of steps in a fixed wall time, and every collective must be
+        # entered the same number of times by all of them
+        tw, i = time.perf_counter(), 0
+        while time.perf_counter() - tw < clock_warmup:
+            w.step(i)
+            i += 1
+            if i % 8 == 0:
+                sync()
+        sync()
+    for i in range(warmup):
+        step(i, False)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    res = {"elapsed": elapsed, "last": max(steps - 1, 0),
+           "kern_ms": float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if ev else None,
+           "gather_ms": float(np.mean([g0.elapsed_time(g1) for g0, g1 in gev])) if gev else None,
+           "sustained_ms": None}
+    if sustained_s > 0 and world == 1 and not dry:  # outside the timed region
+        n, s0, s1 = 0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        s0.record()
+        while True:
+            w.step(n)
+            n += 1
+            if n % 8 == 0 or sustained_s < 1.0:
+                torch.cuda.synchronize()
+                if time.perf_counter() - t1 >= sustained_s:
+                    break
+        s1.record()
+        torch.cuda.synchronize()
+        res["sustained_ms"] = s0.elapsed_time(s1) / n
+        res["last"] = n - 1
+    return res
+
+
+def roofline(W, w, clips, m):
+    kern_ms, sus = m["kern_ms"], m["sustained_ms"]
+    achieved = w.units * W.bytes_per_unit / (kern_ms * 1e-3) / 1e9 if kern_ms else None
+    traffic, traffic_src = pmc_traffic(W.config, clips) if hasattr(W, "config") else (None, None)
+    alg = w.units * W.bytes_per_unit
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+            "kernel": W.kernel, "kernel_ms": kern_ms,
+            "algorithmic_bytes_per_unit": W.bytes_per_unit, "units_per_launch": w.units,
+            "sustained_ms": sus, "sustained_value": (w.units / (sus * 1e-3)) if sus else None,
+            "sustained_frac": (alg / (sus * 1e-3) / 1e9 / HBM_PEAK_GBS) if sus else None}
 
 
 def main():
@@ -379,12 +503,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (0: the configuration's own)")
+    ap.add_argument("--total-clips", type=int, default=0, help="clips of the whole job, sharded over the ranks in "
+                    "contiguous ceil-sized blocks (dist.shard_range; the last ranks may get fewer) instead of --clips each")
     ap.add_argument("--gather", default="", help="comma list of feature slabs gathered to rank 0 when N > 1 "
                     "(cfg 2: mfcc[,mel]; cfg 5: chroma[,cqt]); default: the first one")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="--config 2 at one GPU also measures cfg 4 and cfg 5 "
+                    "after the headline (outside its timed region) and reports them under `secondary`")
     ap.add_argument("--clock-warmup", type=float, default=0.5, help="seconds of untimed steps before the W warm-up "
                     "steps: the device ramps its clocks over tens of ms after idling, and W steps of ~1.5 ms end "
                     "long before that (0 disables; reported as config.clock_warmup_s)")
@@ -401,123 +529,54 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if dry:
         dev = torch.device("cpu")
-
-        class Event:  # stand-in for torch.cuda.Event
-            def __init__(self, enable_timing=True):
-                self.t = 0.0
-
-            def record(self):
-                self.t = time.perf_counter()
-
-            def elapsed_time(self, other):
-                return (other.t - self.t) * 1e3
-
-        def sync():
-            pass
     else:
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
         af._lib.check(af.get_lib().afx_set_device(local), "afx_set_device")
-        Event, sync = torch.cuda.Event, torch.cuda.synchronize
 
     W = DryRun if dry else WORKLOADS[a.config]
-    clips = a.clips or W.default_clips
-    w = W(torch, af, dev, rank, clips)
-    which = [g for g in (a.gather.split(",") if a.gather else list(W.gather_choices[:1])) if g]
+    if a.total_clips > 0:
+        spans = [afd.shard_range(a.total_clips, r, world) for r in range(world)]
+        counts = [hi - lo for lo, hi in spans]
+        clips, first = counts[rank], spans[rank][0]
+        assert min(counts) > 0, f"--total-clips {a.total_clips} leaves a rank of {world} without clips"
+    else:
+        clips = a.clips or W.default_clips
+        counts, first = [clips] * world, rank * clips
+    w = W(torch, af, dev, rank, clips, a.config, first) if dry else W(torch, af, dev, rank, clips)
+    choices = w.gather_choices if dry else W.gather_choices
+    which = [g for g in (a.gather.split(",") if a.gather else list(choices[:1])) if g]
     for g in which:
-        assert g in W.gather_choices, f"--gather {g}: config {a.config} offers {W.gather_choices}"
-    gathers = ([afd.FeatureGather(dst=0, counts=[clips] * world) for _ in which]
-               if (world > 1 and not a.no_gather) else [])
-    comm = torch.cuda.Stream(device=dev) if (gathers and not dry) else None
+        assert g in choices, f"--gather {g}: config {a.config} offers {choices}"
+    gathers = ([afd.FeatureGather(dst=0, counts=counts) for _ in which] if (world > 1 and not a.no_gather) else [])
 
-    ev = []
-
-    def step(i, timed):
-        e0 = Event(enable_timing=True)
-        e1 = Event(enable_timing=True)
-        e0.record()
-        w.step(i)
-        e1.record()
-        if timed:
-            ev.append((e0, e1))
-        if gathers:
-            # the slabs of this step go to rank 0 while the next step computes (double-buffered
-            # sources; the previous gather has had a whole step to finish)
-            for g in gathers:
-                g.wait()
-            if comm is not None:
-                comm.wait_stream(torch.cuda.current_stream())
-            with (torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()):
-                for g, name in zip(gathers, which):
-                    g.start(w.slab(i, name))
-
-    def fence():
-        for g in gathers:
-            g.wait()
-        if comm is not None:
-            torch.cuda.current_stream().wait_stream(comm)
-        sync()
-        if world > 1:
-            dist.barrier()
-        sync()
-
-    if a.clock_warmup > 0 and not dry:
-        # untimed, like the W steps below: brings the clocks to their loaded state.  Compute only --
-        # the ranks run different numbers of steps in a fixed wall time, and every collective must be
-        # entered the same number of times by all of them
-        tw, i = time.perf_counter(), 0
-        while time.perf_counter() - tw < a.clock_warmup:
-            w.step(i)
-            i += 1
-            if i % 8 == 0:
-                sync()
-        sync()
-    for i in range(a.warmup):
-        step(i, False)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i, True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if ev else None
+    m = measure(w, torch, dist, dev, world, a.steps, a.warmup, a.clock_warmup,
+                0.0 if a.no_sustained else 1.0, gathers, which, dry)
+    elapsed = m["elapsed"]
 
     # ---- outside the timed region ----------------------------------------------------------------
-    sustained_ms = None
-    if world == 1 and not a.no_sustained and not dry:
-        n, s0, s1 = 0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t1 = time.perf_counter()
-        s0.record()
-        while True:
-            w.step(n)
-            n += 1
-            if n % 8 == 0:
-                torch.cuda.synchronize()
-                if time.perf_counter() - t1 >= 1.0:
-                    break
-        s1.record()
-        torch.cuda.synchronize()
-        sustained_ms = s0.elapsed_time(s1) / n
     if dry and gathers and rank == 0:
         # the gathered slab of the last step: rank r's clips follow rank r-1's, every clip carries its id
         got = gathers[0].wait()
-        last = a.steps - 1
-        want = torch.arange(world * clips, dtype=torch.float32) * 1000 + last
-        assert got.shape == (world * clips, w.T, 13) and bool((got[:, 0, 0] == want).all()), "gathered slab order"
+        total = sum(counts)
+        want = torch.arange(total, dtype=torch.float32) * 1000 + (a.steps - 1)
+        assert got.shape[0] == total and got.shape[1] == w.T and bool((got[:, 0, 0] == want).all()), "gathered slab order"
     err = None
     if rank == 0 and not a.no_check:
-        err = w.check(max(a.steps - 1, 0) if sustained_ms is None else n - 1)
+        err = w.check(m["last"])
         assert err is None or err <= 1e-5, f"benchmarked output differs from the oracle: {err:.3e}"
 
+    units_all = w.units
+    if world > 1:  # shards may differ (--total-clips): the job's units are the sum over ranks
+        tu = torch.tensor([w.units], device=dev, dtype=torch.float64)
+        dist.all_reduce(tu, op=dist.ReduceOp.SUM)
+        units_all = float(tu.item())
+    else:
+        units_all = float(w.units)
+
     if rank == 0:
-        value = w.units * world * a.steps / elapsed
-        achieved = w.units * W.bytes_per_unit / (kern_ms * 1e-3) / 1e9 if kern_ms else None
-        traffic, traffic_src = pmc_traffic(a.config, clips)
+        value = units_all * a.steps / elapsed
         par = f"clips sharded x{world}"
         if gathers:
             par += f", RCCL gather of {'+'.join(which)} to rank 0 (side stream, overlapped)"
@@ -526,25 +585,54 @@ def main():
         out = {
             "metric": W.metric, "value": value, "unit": W.unit, "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": getattr(w, "dtype", "f32"), "data": "synthetic",
+            "scaling": "strong" if a.total_clips > 0 else "weak", "vs_baseline": None,
+            "dtype": getattr(w, "dtype", "f32"), "data": "synthetic",
             "config": {"workload": w.workload, "clips_per_gpu": clips, "units_per_step_per_gpu": w.units,
                        "outputs": w.outputs, "parallelism": par, "clock_warmup_s": a.clock_warmup},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": W.kernel, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_unit": W.bytes_per_unit, "units_per_launch": w.units,
-                         "sustained_ms": sustained_ms,
-                         "sustained_value": (w.units / (sustained_ms * 1e-3)) if sustained_ms else None,
-                         "sustained_frac": (w.units * W.bytes_per_unit / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                         if sustained_ms else None},
+            "roofline": roofline(W, w, clips, m),
             "oracle_check": {"clip0_max_rel_err": err, "bar": 1e-5},
         }
+        if a.total_clips > 0:
+            out["config"]["total_clips"], out["config"]["clips_per_rank"] = a.total_clips, counts
+        if world > 1:
+            # does the gather hide behind the next step?  gather_ms: device time of the collective(s) on the side
+            # stream of rank 0; exposed_ms: what a step costs beyond its own compute; hidden = the rest
+            ms_step = 1e3 * elapsed / a.steps
+            exposed = max(0.0, ms_step - (m["kern_ms"] or 0.0))
+            gm = m["gather_ms"]
+            out["gather"] = {"slabs": which if gathers else [], "gather_ms": gm, "compute_ms": m["kern_ms"],
+                             "exposed_ms": exposed if gathers else 0.0,
+                             "overlap_hidden_ms": max(0.0, gm - exposed) if (gathers and gm is not None) else None}
+            assert not gathers or out["gather"]["gather_ms"] is not None, "N > 1 with a gather must report gather_ms"
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = w.cpu()
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and a.config == 2 and not dry and not a.no_secondary:
+            # BASELINE configs[3] / [4] on the same line: measured in this process after the headline, each with
+            # its own fences, device-event step time, sustained loop and oracle check (a few seconds in all)
+            del w
+            torch.cuda.empty_cache()
+            out["secondary"] = {}
+            for cfg, (k, wu) in ((4, (2, 1)), (5, (10, 2))):
+                try:
+                    W2 = WORKLOADS[cfg]
+                    w2 = W2(torch, af, dev, rank, W2.default_clips)
+                    m2 = measure(w2, torch, dist, dev, 1, k, wu, 0.3, 0.0 if a.no_sustained else 0.7)
+                    e2 = None if a.no_check else w2.check(m2["last"])
+                    assert e2 is None or e2 <= 1e-5, f"cfg {cfg}: benchmarked output differs from the oracle: {e2:.3e}"
+                    r2 = roofline(W2, w2, W2.default_clips, m2)
+                    out["secondary"][f"cfg{cfg}"] = {
+                        "metric": W2.metric, "value": w2.units * k / m2["elapsed"], "unit": W2.unit, "steps": k,
+                        "warmup": wu, "ms_per_step": 1e3 * m2["elapsed"] / k, "workload": w2.workload,
+                        "dtype": getattr(w2, "dtype", "f32"), "frac": r2["frac"], "sustained_frac": r2["sustained_frac"],
+                        "traffic": r2["traffic"], "traffic_over_algorithmic": r2["traffic_over_algorithmic"],
+                        "roofline": r2, "oracle_check": {"clip0_max_rel_err": e2, "bar": 1e-5}}
+                    del w2
+                    torch.cuda.empty_cache()
+                except Exception as e:  # never lose the headline line to a secondary configuration
+                    out["secondary"][f"cfg{cfg}"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -174,7 +174,10 @@ int afx_write_npy_f32(const char *path, const float *data, int ndim, const long 
  * bound at run time (dlopen of librccl.so.1; a copy already mapped by the process is shared), so
  * single-GPU deployments never load it.  Bootstrap: rank 0 calls afx_comm_get_unique_id and
  * hands the 128 bytes to the other ranks by whatever the launcher offers (MPI, a file, the
- * torch.distributed store: audioflux_amd/dist.py), then every rank calls afx_comm_create.
+ * torch.distributed store: audioflux_amd/dist.py), then every rank calls afx_comm_create -- the
+ * communicator is bound to the calling thread's CURRENT HIP device (one process per GPU: select the
+ * rank's GPU with afx_set_device / hipSetDevice first); afx_gather returns -6 when `hipStream` lives
+ * on another device, and leaves the caller's current device as it found it.
  * afx_gather is asynchronous on `hipStream` like ncclGather (rccl.h:745): `count` floats from
  * dSend on every rank, worldSize*count floats into dRecv on `root` (dRecv is ignored elsewhere).
  * All return 0 or a negative status (-4: RCCL not installed). */

@@ -50,6 +50,9 @@ def test_shard_range_partitions_everything():
             spans = [shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # BASELINE cfg 5 plus one clip over the eight GPUs of a node: ceil-sized blocks, the last rank gets the remainder
+    spans = [shard_range(1001, r, 8) for r in range(8)]
+    assert [hi - lo for lo, hi in spans] == [126] * 7 + [119] and spans[-1][1] == 1001
 
 
 @pytest.mark.timeout(120)
@@ -69,8 +72,9 @@ def test_gather_world2_gloo(n_clips):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("gather", ["mfcc", "mfcc,mel"])
-def test_bench_control_flow_world2_gloo(gather):
+@pytest.mark.parametrize("gather,extra", [("mfcc", []), ("mfcc,mel", []), ("chroma", ["--config", "5", "--total-clips", "7"]),
+                                          ("chroma,cqt", ["--config", "5"])])
+def test_bench_control_flow_world2_gloo(gather, extra):
     """bench.py itself under `torch.distributed.run --nproc-per-node 2` with the kernels replaced by a CPU
     stand-in (AFX_BENCH_DRYRUN=1, gloo): the launch line the driver uses, clip ownership, the
     double-buffered side-stream gather(s), fences, the max-over-ranks clock and the JSON contract; rank 0
@@ -80,14 +84,22 @@ def test_bench_control_flow_world2_gloo(gather):
     env = dict(os.environ, AFX_BENCH_DRYRUN="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--gather", gather]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--gather", gather, *extra]
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]  # ONE JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    sharded = "--total-clips" in extra  # 7 clips over 2 ranks: 4 + 3 through dist.shard_range, the short slab padded
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == ("strong" if sharded else "weak")
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
-    assert d["config"]["units_per_step_per_gpu"] * 2 * 3 / (d["ms_per_step"] * 3e-3) == pytest.approx(d["value"], rel=1e-6)
+    units = 7 * 7 if sharded else d["config"]["units_per_step_per_gpu"] * 2
+    assert units * 3 / (d["ms_per_step"] * 3e-3) == pytest.approx(d["value"], rel=1e-6)
+    if sharded:
+        assert d["config"]["clips_per_rank"] == [4, 3]
+    # N > 1 says whether the exchange hides behind the compute
+    g = d["gather"]
+    assert g["slabs"] == gather.split(",") and g["gather_ms"] is not None and g["gather_ms"] >= 0
+    assert g["overlap_hidden_ms"] is not None and g["exposed_ms"] >= 0
     assert "RCCL gather of " + "+".join(gather.split(",")) in d["config"]["parallelism"]
     assert "cpu_baseline" not in d  # N > 1: no CPU baseline leg

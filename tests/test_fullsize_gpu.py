@@ -50,6 +50,91 @@ def test_cfg2_full_corpus_shift_property_and_sampled_reference():
             assert_parity(cc[i].cpu().numpy(), rcc[0], what=f"cfg2 mfcc clip {i}")
 
 
+def test_cfg2_second_distribution_three_sines_plus_noise():
+    """SURVEY 8d's second corpus for cfg 2: 1000 x 30 s of 0.3 sin 220 Hz + 0.2 sin 880 Hz + 0.1 sin 3520 Hz + 1e-3
+    noise (seed 2).  Mel at the plain bar; the MFCC takes log10 of bands that hold only the 1e-3 noise floor next to
+    tones 50-110 dB above it, where every float32 FFT (the reference's radix-2 one included) carries ~1e-7 of the
+    frame's PEAK: bar = max(1e-5, 3 x the reference's own distance from a float64 evaluation), logged."""
+    import numpy as np
+    import torch
+    from oracle import restate
+    from tests.conftest import l2_rel, parity_log, peak_rel
+    clips, n, hop, t = 1000, 480000, 512, 934
+    g = torch.Generator(device="cuda").manual_seed(2)
+    tt = torch.arange(n, device="cuda", dtype=torch.float64) / 16000.0
+    tones = (0.3 * torch.sin(2 * np.pi * 220 * tt) + 0.2 * torch.sin(2 * np.pi * 880 * tt)
+             + 0.1 * torch.sin(2 * np.pi * 3520 * tt)).to(torch.float32)
+    x = tones[None, :] + 1e-3 * torch.randn((clips, n), device="cuda", generator=g)
+    x[1::2] = x[0::2]                         # every clip twice: position independence over the whole corpus
+    bft = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+                 scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+    bft.set_result_type(1)
+    xx = af.XXCC(128)
+    mel, cc = af.mel_mfcc_device(bft, xx, x, 13)
+    torch.cuda.synchronize()
+    assert mel.shape == (clips, t, 128) and bool(torch.isfinite(mel).all()) and bool(torch.isfinite(cc).all())
+    assert torch.equal(mel[1::2], mel[0::2]) and torch.equal(cc[1::2], cc[0::2])
+    if ref.available():
+        bank, _, _ = restate.mel_bank(128, 2048, 16000, 0.0, 8000.0)
+        for i in (0, 998, 501):
+            xi = x[i].cpu().numpy()
+            rmel, rcc = ref.mel_mfcc(xi[None])
+            fmel = restate.bft(xi.astype(np.float64), bank, 2048, 512)
+            fcc = restate.xxcc(fmel)
+            assert_parity(mel[i].cpu().numpy(), rmel[0], what=f"cfg2 tones mel clip {i}")
+            got = cc[i].cpu().numpy()
+            ref_d = max(peak_rel(rcc[0], fcc), l2_rel(rcc[0], fcc))
+            for tag, other in (("reference", rcc[0]), ("float64", fcc)):
+                d = max(peak_rel(got, other), l2_rel(got, other))
+                bar = max(1e-5, 3.0 * ref_d)
+                parity_log(f"cfg2 tones mfcc clip {i} vs {tag}", d, bar, "max(1e-5, 3 x reference-vs-float64)",
+                           {"reference_vs_float64": ref_d})
+                assert d <= bar, f"cfg2 tones mfcc clip {i} vs {tag}: {d:.3e} > {bar:.3e}"
+
+
+def test_cfg4_whole_corpus_through_the_output_ring():
+    """cfg 4 as bench.py runs it: 1000 clips x 7 chunks = 7000 chunks of 2^16 samples (the 7th zero padded from sample
+    47 784 on), 32 chunks per device call into a two-slot output ring.  The second half of the corpus repeats the first
+    3488 chunks (109 calls later: same ring slot, same position in its call): per-chunk checksums formed before the
+    slot is overwritten must agree bit for bit, and chunks sampled at the corpus's ends, a ragged one and a repeated one
+    meet the compiled reference."""
+    import torch
+    chunks, r, num, grp, rep = 7000, 16, 84, 32, 3488
+    o = af.CWT(num=num, radix2_exp=r, samplate=44100, low_fre=32.703, bin_per_octave=12,
+               wavelet_type=af.WaveletContinueType.MORLET,
+               scale_type=af.SpectralFilterBankScaleType.OCTAVE, is_padding=True)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.zeros((1000, 7 * 65536), device="cuda")
+    x[:, :441000] = 0.1 * torch.randn((1000, 441000), device="cuda", generator=g)
+    x = x.view(chunks, 65536)
+    x[rep:2 * rep] = x[:rep].clone()
+    ring = [(torch.empty((grp, num, 65536), device="cuda"), torch.empty((grp, num, 65536), device="cuda")) for _ in range(2)]
+    sums = torch.empty((chunks, 2), device="cuda", dtype=torch.float64)
+    picks = {0: None, 6: None, rep + 6: None, 3499: None, chunks - 1: None}   # 6, 6999: ragged (zero-padded) chunks
+    k = 0
+    for c0 in range(0, chunks, grp):
+        n = min(grp, chunks - c0)
+        re, im = ring[k & 1]
+        o.cwt_device(x[c0:c0 + n], re[:n], im[:n])
+        sums[c0:c0 + n, 0] = re[:n].double().sum(dim=(1, 2))
+        sums[c0:c0 + n, 1] = (re[:n].double() ** 2 + im[:n].double() ** 2).sum(dim=(1, 2))
+        for i in picks:
+            if c0 <= i < c0 + n:
+                picks[i] = (re[i - c0].cpu().numpy(), im[i - c0].cpu().numpy())
+        k += 1
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(sums).all())
+    assert torch.equal(sums[rep:2 * rep], sums[:rep])
+    assert (picks[6][0] == picks[rep + 6][0]).all() and (picks[6][1] == picks[rep + 6][1]).all()
+    if ref.available():
+        rr = ref.RefCWT(num=num, radix2_exp=r, samplate=44100, low_fre=32.703, bin_per_octave=12,
+                        wavelet_type=int(af.WaveletContinueType.MORLET),
+                        scale_type=int(af.SpectralFilterBankScaleType.OCTAVE), is_padding=1)
+        for i in (0, 6, 3499, chunks - 1):
+            rre, rim = rr.cwt(x[i].cpu().numpy())
+            assert_parity(picks[i][0] + 1j * picks[i][1], rre + 1j * rim, what=f"cfg4 ring chunk {i}")
+
+
 def test_cfg4_cwt_chunks_linearity_and_sampled_reference():
     import torch
     chunks, r, num = 48, 16, 84

@@ -155,3 +155,22 @@ def test_split_f16_octave_product_model_matches_golden_cqt(name, golden_dir):
     want = gold[f"{name}/re"] + 1j * gold[f"{name}/im"]
     assert_parity(q, want, 1e-5, name + " (f16 model)")
     assert_parity(q, restate.cqt(*args), 2e-6, name + " (f16 model vs float64 restatement)")
+
+
+@pytest.mark.parametrize("name", cases.REAL_AUDIO)
+def test_restatement_on_real_audio(name, golden_dir):
+    """round 3: the float64 restatement against the compiled reference's outputs on excerpts of the reference's own
+    sample clips (tests/golden/real_audio.npz, made by tests/golden/make_real_audio.py) -- speech, a decaying chord,
+    chord + clicks; the GPU tests use both as checkers (tests/test_realaudio_gpu.py)"""
+    g = np.load(os.path.join(golden_dir, "real_audio.npz"))
+    x = cases.real_audio(name, golden_dir)
+    assert x.shape == (cases.REAL_AUDIO_LEN,) and np.abs(x).max() > 0.05
+    sr = cases.REAL_AUDIO_SR
+    bank, _, _ = restate.mel_bank(128, 2048, sr, 0.0, sr / 2.0)
+    mel = restate.bft(x.astype(np.float64), bank, 2048, 512)
+    assert_parity(mel, g[f"{name}/mel"], 1e-5, f"{name} mel")
+    assert_parity(restate.xxcc(mel), g[f"{name}/mfcc"], 1e-5, f"{name} mfcc")
+    Q = restate.cqt(x.astype(np.float64), 84, sr, 32.703, 12, 1, "area")
+    assert_parity(Q[::4], g[f"{name}/cqt"], 1e-5, f"{name} cqt")
+    # MAX-normalised chroma of speech pauses: the reference's float32 chain is 2.5e-5 from float64 there
+    assert_parity(restate.cqt_chroma(Q, 12, 12, "power", "max", 32.703), g[f"{name}/chroma"], 5e-5, f"{name} chroma")

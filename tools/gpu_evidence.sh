@@ -24,9 +24,9 @@ if has prof; then
   timeout 300 bash tools/prof.sh ev_$TAG > /dev/null 2>&1
   cp gpurun_out/prof_ev_$TAG/summary.txt $OUT/rocprofv3_bench_cfg2_summary.txt 2>/dev/null
   timeout 200 python tools/prof_traffic.py 2 > $OUT/traffic_cfg2.log 2>&1
-  timeout 200 python tools/prof_traffic.py 5 --clips 16 > $OUT/traffic_cfg5.log 2>&1
+  timeout 200 python tools/prof_traffic.py 5 --clips 125 > $OUT/traffic_cfg5.log 2>&1
   timeout 200 python tools/prof_traffic.py 4 --clips 20 --steps 1 > $OUT/traffic_cfg4.log 2>&1
-  cp gpurun_out/r02_bench_cfg*_pmc.json $OUT/ 2>/dev/null
+  cp gpurun_out/r03_bench_cfg*_pmc.json $OUT/ 2>/dev/null
   for c in 5 4; do
     timeout 200 bash tools/prof_cmd.sh ev_${TAG}_cfg$c "" python bench.py --config $c --clips $([ $c = 4 ] && echo 40 || echo 125) --steps 3 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
     cp gpurun_out/prof_ev_${TAG}_cfg$c/summary.txt $OUT/rocprofv3_bench_cfg${c}_trace.txt 2>/dev/null
@@ -43,6 +43,6 @@ if has rates; then
     echo "== tools/$t" >> $OUT/rates.txt
     timeout 120 python tools/$t 2>&1 | grep -vE "^\s*$|Warning|warn|amdgpu.ids" | tail -n 14 >> $OUT/rates.txt
   done
-  timeout 200 python tools/ab2.py "" "AFX_NO_FUSED_CC=1" > $OUT/ab2.txt 2>&1
+  
 fi
 ls $OUT; cat $OUT/status.txt 2>/dev/null
