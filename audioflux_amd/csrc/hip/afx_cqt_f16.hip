@@ -36,6 +36,7 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_pkmath.h"
+#include "afx_f16split.h"
 
 namespace {
 
@@ -65,37 +66,6 @@ struct CqF16 {
     // fragment offset of step ks relative to the lane's base (compile-time immediates)
     __host__ __device__ static constexpr int step(int ks) { return 32 * ks + (PAD ? 16 * ((16 * ks) / H) : 0); }
 };
-
-__device__ __forceinline__ float dpp_f(float v, int ctrl) {
-    // all lanes read a lane of their own row: row_mask / bank_mask 0xf, bound_ctrl on
-    switch (ctrl) {
-        case 0xB1: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
-        case 0x4E: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
-        case 0x141: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));
-        default: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));
-    }
-}
-
-// (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
-// fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).
-// One asm statement: VALU->VALU dependences are interlocked, and hipcc's own form of this costs 7 instructions.
-__device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigned &hi, unsigned &lo) {
-#ifndef AFX_HOST_EMULATION
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(x0), "v"(x1), "s"(up));
-#else  // tests/emu (the kernel compiled for the host): the same four roundings in C
-    const _Float16 h0 = (_Float16)(x0 * up), h1 = (_Float16)(x1 * up);
-    const _Float16 l0 = (_Float16)(x0 * up - (float)h0), l1 = (_Float16)(x1 * up - (float)h1);
-    unsigned short b[4];
-    __builtin_memcpy(&b[0], &h0, 2), __builtin_memcpy(&b[1], &h1, 2), __builtin_memcpy(&b[2], &l0, 2), __builtin_memcpy(&b[3], &l1, 2);
-    hi = (unsigned)b[0] | ((unsigned)b[1] << 16);
-    lo = (unsigned)b[2] | ((unsigned)b[3] << 16);
-#endif
-}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));

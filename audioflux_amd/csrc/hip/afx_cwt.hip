@@ -590,19 +590,25 @@ extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const 
         const float2 *Xt2 = reinterpret_cast<const float2 *>(Xt);
         float2 *B2 = reinterpret_cast<float2 *>(scratchB);
         hipStream_t s = (hipStream_t)stream;
-        // wide scales: row pass -> intermediate -> column pass
-        const int nWide = d->order ? d->nWide : num;
+        // wide scales: row pass -> intermediate -> column pass.  The first nTd entries of the order list are the
+        // short-kernel scales the host runs through afxk_cwt_td (afx_cwt_td.hip) -- for the plain transform only: the
+        // derivative bank (isDet) has no time-domain image, its nTd scales take both passes here.
+        const int nTd = d->order ? d->nTd : 0;
+        const int skip = (!isDet && d->td) ? nTd : 0;
+        const int nWide = d->order ? (nTd - skip) + d->nWide : num;
         if (nWide > 0 && (parts & AFX_CWT_WIDE)) {
+            CwtGeom gw = g;
+            if (gw.order) gw.order += skip;
             hipLaunchKernelGGL(k_cwt_inv_rows512, dim3(L1 / (4 * ROWS_PER_WAVE), nWide, chunks), dim3(256), 0, s,
-                               g, Xt2, bankT, isDet, B2);
+                               gw, Xt2, bankT, isDet, B2);
             AFX_LAUNCH_CHECK("k_cwt_inv_rows512");
-            hipLaunchKernelGGL(k_cwt_inv_cols256, dim3(L2 / 16, nWide, chunks), dim3(256), 0, s, g, B2, outRe,
+            hipLaunchKernelGGL(k_cwt_inv_cols256, dim3(L2 / 16, nWide, chunks), dim3(256), 0, s, gw, B2, outRe,
                                outIm);
             AFX_LAUNCH_CHECK("k_cwt_inv_cols256");
         }
         // narrow-band scales: column pass only, straight from the spectrum
         if (d->order && (parts & AFX_CWT_NARROW)) {
-            int base = nWide;
+            int base = nTd + d->nWide;
             if (d->nNarrow[0] > 0) {
                 hipLaunchKernelGGL(k_cwt_inv_cols256_nb<2>, dim3(L2 / 16, d->nNarrow[0], chunks), dim3(256), 0, s,
                                    g, Xt2, bankT, isDet, base, outRe, outIm);

@@ -207,7 +207,31 @@ typedef struct {
     const int *orderLo;  /* device [num][2]: (order[i], support[2 order[i]]) -- one read per workgroup */
     int nWide;
     int nNarrow[4];
+    int nTd;                 /* > 0: the FIRST nTd entries of `order` run the time-domain kernel (afx_cwt_td.hip),
+                              * the nWide two-pass scales and the narrow-band classes follow */
+    const struct AfxCwtTdPlan_ *td;
 } AfxCwtPlanDims;
+/* ---- short-kernel ("wide") scales in the time domain on the f16 matrix cores (afx_cwt_td.hip) ----
+ * pair: two scales share one MFMA column tile -- 32 columns = 2 scales x (re, im) x 8 output phases */
+#define AFX_CWT_TD_MAXK 1024   /* taps (incl. the 8 phase shifts) of the longest kernel the LDS-resident image takes */
+typedef struct {
+    int scale[2];            /* result rows (C order: row 0 = highest frequency); scale[1] < 0: a single scale */
+    int kh;                  /* the window of output n0 starts at position n0 - kh (multiple of 8)           */
+    int ks;                  /* K steps of 16 taps (multiple of 4)                                            */
+    long long img;           /* byte offset of the pair's image in the blob: [word 2][ks][64 lanes][8] f16,
+                              * the B-fragment order of v_mfma_f32_32x32x16_f16 (afx_cqt_time_kernel_f16)     */
+    int wgBase, wgCount;     /* persistent workgroups serving this pair (in proportion to ks)                 */
+    float colMul[32];        /* 2^-s_c of the image columns                                                   */
+} AfxCwtTdPair;
+typedef struct AfxCwtTdPlan_ {
+    const AfxCwtTdPair *pairs;   /* device [nPairs], longest kernels first */
+    const unsigned char *image;  /* device blob */
+    int nPairs, maxKs, wgTotal;
+    int wrap;                    /* 0: reflect padding (isPadding, cwt_algorithm.c:404-414), 1: circular */
+} AfxCwtTdPlan;
+/* chunk c at x + c xStride (dataLength = 2^r samples) -> outRe/outIm [chunks][num][dataLength], rows p->pairs[].scale */
+int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStride, int chunks, int dataLength, int num,
+                float *outRe, float *outIm, void *stream);
 #define AFX_CWT_FASTTW_FLOATS (2 * (8 * 64 + 8 * 8 + 16 * 16))
 /* `chunks` signals, chunk c at x + c*xStride -> Xt[c][L] complex (transposed layout:
  * frequency k1 + 2^r1 k2 at [k1][k2]); scratchA: chunks*L complex */
@@ -219,6 +243,7 @@ int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const float *x, l
  * AFX_CWT_NARROW = the narrow-band scales (no scratch, any number of chunks per launch) */
 #define AFX_CWT_WIDE 1
 #define AFX_CWT_NARROW 2
+/* (the time-domain scales of the plan, d->nTd, are not part of either: afxk_cwt_td runs them from the signal itself) */
 int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, const float *bankT,
                      int num, int isDet, int chunks, float *scratchB, float *outRe, float *outIm,
                      int parts, void *stream);

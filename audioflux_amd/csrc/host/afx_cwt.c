@@ -40,6 +40,10 @@ struct OpaqueCWT {
     float *dBankN, *dBankDetN; /* natural-layout banks of the in-LDS path (L <= 16384), else NULL */
     int *dSupport;           /* [num][2]: k2 range holding every non-zero of the scale's wavelet */
     int *dOrder;             /* [num]: wide scales first, then the narrow-band classes (afx_device.h) */
+    AfxCwtTdPlan td;         /* time-domain plan of the short-kernel scales (afx_cwt_td.hip); nPairs 0: none */
+    AfxCwtTdPair *dTdPairs;
+    unsigned char *dTdImage;
+    void *tdStream;          /* side stream of the time-domain launches */
     float *dGA, *dGXt, *dGB; /* scratch of the batched calls: `group` chunks at a time */
     size_t capGA, capGXt, capGB;
     int haveSpectrum;
@@ -481,6 +485,171 @@ long long afx_cwt_fft_length(int radix2Exp, int isPadding) {
     return pad_rule(radix2Exp, isPadding, "transform length", &fftLength, &rL) < 0 ? -1 : fftLength;
 }
 
+/* ---- time-domain plan (afx_cwt_td.hip) -------------------------------------------------------------------
+ * A wavelet that is wide in frequency is short in time: g_j = IFFT(psi_j), evaluated here in double from the bank's
+ * own float32 row.  Scale j qualifies when the taps beyond |t| = Kh_j (rule below) hold less than 5e-7 of its L2 norm and the kernel (2 Kh_j + 1 taps + the 8 phase shifts) fits the
+ * LDS-resident image (AFX_CWT_TD_MAXK).  Qualifying scales are paired longest first; `order` is rewritten to
+ * [time-domain scales | remaining two-pass scales | narrow-band classes].  Nothing qualifies -> nPairs = 0 and the
+ * plan is the round-2 one.  (morlet at BASELINE cfg 4: 36 of the 40 two-pass scales, 121 .. 1009 taps.) */
+typedef struct {
+    int scale, kh;
+    double *re, *im; /* taps t = -kh .. kh at [t + kh] */
+} TdCand;
+
+static int td_cand_cmp(const void *a, const void *b) {
+    const TdCand *x = (const TdCand *)a, *y = (const TdCand *)b;
+    if (x->kh != y->kh) return y->kh - x->kh; /* longest first */
+    return x->scale - y->scale;
+}
+
+static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
+    const long long L = o->fftLength;
+    const int D = o->dataLength, pad = o->padLength;
+    if (D < 8192 || *nWide < 1) return AFX_OK;
+    double *re = (double *)malloc(sizeof(double) * (size_t)L), *im = (double *)malloc(sizeof(double) * (size_t)L);
+    TdCand *cand = (TdCand *)calloc((size_t)*nWide, sizeof(TdCand));
+    int st = (re && im && cand) ? AFX_OK : AFX_ERR_NOMEM, nc = 0;
+    for (int w = 0; w < *nWide && st == AFX_OK; w++) {
+        const int j = order[w];
+        const float *row = o->hBank + (size_t)j * L;
+        for (long long k = 0; k < L; k++) re[k] = row[k], im[k] = 0.0;
+        st = afx_fft_f64(rL, re, im, 1); /* g = IFFT(psi): the 1 / L goes into the taps below */
+        if (st != AFX_OK) break;
+        /* Kh: the last |t| above 1e-6 of the peak, stretched by 8 % (a Gaussian envelope falls from 1e-6 to 1e-7
+         * over that much; the float32 arithmetic of the bank leaves a floor of isolated values up to 5e-8 of the
+         * peak all over the period -- a threshold at 1e-7 or below would chase it).  Accepted when the dropped
+         * taps hold less than 5e-7 of the kernel's L2 norm = the relative error against the reference for a white
+         * input (morlet, cfg 4: 1.5e-7, all of it the floor). */
+        double peak = 0.0, energy = 0.0;
+        for (long long k = 0; k < L; k++) {
+            const double a2 = re[k] * re[k] + im[k] * im[k];
+            if (a2 > peak) peak = a2;
+            energy += a2;
+        }
+        if (!(peak > 0.0)) continue;
+        long long k6 = 0;
+        for (long long k = 0; k < L; k++)
+            if (re[k] * re[k] + im[k] * im[k] > 1e-12 * peak) {
+                const long long t = k <= L / 2 ? k : L - k;
+                if (t > k6) k6 = t;
+            }
+        const long long kh = (long long)ceil(1.08 * (double)k6) + 2;
+        if (2 * kh + 8 > AFX_CWT_TD_MAXK - 56 || (pad > 0 && kh > pad) || kh >= D) continue;
+        double tail = 0.0;
+        for (long long k = kh + 1; k < L - kh; k++) tail += re[k] * re[k] + im[k] * im[k];
+        if (tail > 2.5e-13 * energy) continue; /* (5e-7)^2 */
+        TdCand *c = &cand[nc];
+        c->scale = j;
+        c->kh = (int)kh;
+        c->re = (double *)malloc(sizeof(double) * (size_t)(2 * kh + 1));
+        c->im = (double *)malloc(sizeof(double) * (size_t)(2 * kh + 1));
+        if (!c->re || !c->im) {
+            free(c->re);
+            free(c->im);
+            st = AFX_ERR_NOMEM;
+            break;
+        }
+        for (long long t = -kh; t <= kh; t++) {
+            const long long k = t < 0 ? L + t : t;
+            c->re[t + kh] = re[k] / (double)L;
+            c->im[t + kh] = im[k] / (double)L;
+        }
+        nc++;
+    }
+    free(re);
+    free(im);
+    const int nPairs = (nc + 1) / 2;
+    AfxCwtTdPair *pairs = NULL;
+    unsigned char *blob = NULL;
+    float *G = NULL;
+    if (st == AFX_OK && nc > 0) {
+        qsort(cand, (size_t)nc, sizeof(TdCand), td_cand_cmp);
+        pairs = (AfxCwtTdPair *)calloc((size_t)nPairs, sizeof(AfxCwtTdPair));
+        if (!pairs) st = AFX_ERR_NOMEM;
+        size_t blobBytes = 0;
+        int ksSum = 0, maxKs = 0;
+        for (int p = 0; p < nPairs && st == AFX_OK; p++) {
+            const TdCand *a = &cand[2 * p], *b = 2 * p + 1 < nc ? &cand[2 * p + 1] : NULL;
+            const int kh = (a->kh + 7) & ~7; /* a is the longer one */
+            const int kt = (2 * kh + 8 + 63) & ~63;
+            pairs[p].scale[0] = a->scale;
+            pairs[p].scale[1] = b ? b->scale : -1;
+            pairs[p].kh = kh;
+            pairs[p].ks = kt / 16;
+            pairs[p].img = (long long)blobBytes;
+            blobBytes += (size_t)2 * pairs[p].ks * 1024;
+            ksSum += pairs[p].ks;
+            if (pairs[p].ks > maxKs) maxKs = pairs[p].ks;
+        }
+        if (st == AFX_OK) {
+            blob = (unsigned char *)malloc(blobBytes);
+            G = (float *)malloc(sizeof(float) * 32 * (size_t)(16 * maxKs));
+            if (!blob || !G) st = AFX_ERR_NOMEM;
+        }
+        /* persistent workgroups in proportion to the K steps of a pair (every workgroup then does about the same
+         * number of matrix instructions): ~1024 in all = four rounds of the 256 CUs */
+        int base = 0;
+        for (int p = 0; p < nPairs && st == AFX_OK; p++) {
+            const int kt = 16 * pairs[p].ks, kh = pairs[p].kh;
+            memset(G, 0, sizeof(float) * 32 * (size_t)kt);
+            for (int c = 0; c < 32; c++) {
+                const TdCand *sc = (c >> 4) == 0 ? &cand[2 * p] : (2 * p + 1 < nc ? &cand[2 * p + 1] : NULL);
+                if (!sc) continue;
+                const int part = (c >> 3) & 1, ph = c & 7;
+                for (int m = 0; m < kt; m++) {
+                    const int t = ph + kh - m; /* y[n0 + 8 i + ph] = sum_m win[8 i + m] g[ph + kh - m] */
+                    if (t < -sc->kh || t > sc->kh) continue;
+                    G[(size_t)m * 32 + c] = (float)(part ? sc->im[t + sc->kh] : sc->re[t + sc->kh]);
+                }
+            }
+            afx_cqt_time_kernel_f16(G, kt, (unsigned short *)(blob + pairs[p].img), pairs[p].colMul);
+            int wg = (int)(1024.0 * pairs[p].ks / ksSum + 0.5);
+            if (wg < 1) wg = 1;
+            pairs[p].wgBase = base;
+            pairs[p].wgCount = wg;
+            base += wg;
+        }
+        if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTdPairs, sizeof(AfxCwtTdPair) * (size_t)nPairs);
+        if (st == AFX_OK) st = afxdev_h2d(o->dTdPairs, pairs, sizeof(AfxCwtTdPair) * (size_t)nPairs, o->stream);
+        if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTdImage, blobBytes);
+        if (st == AFX_OK) st = afxdev_h2d(o->dTdImage, blob, blobBytes, o->stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+        if (st == AFX_OK) {
+            o->td.pairs = o->dTdPairs;
+            o->td.image = o->dTdImage;
+            o->td.nPairs = nPairs;
+            o->td.maxKs = maxKs;
+            o->td.wgTotal = base;
+            o->td.wrap = pad > 0 ? 0 : 1;
+            /* order := [time-domain scales, pair by pair | the other two-pass scales | narrow-band classes] */
+            int *rest = (int *)malloc(sizeof(int) * (size_t)*nWide);
+            if (!rest) st = AFX_ERR_NOMEM;
+            int nr = 0;
+            for (int w = 0; w < *nWide && rest; w++) {
+                int taken = 0;
+                for (int c = 0; c < nc; c++) taken |= cand[c].scale == order[w];
+                if (!taken) rest[nr++] = order[w];
+            }
+            if (rest) {
+                for (int c = 0; c < nc; c++) order[c] = cand[c].scale;
+                memcpy(order + nc, rest, sizeof(int) * (size_t)nr);
+                o->dims.nTd = nc;
+                *nWide = nr;
+            }
+            free(rest);
+        }
+    }
+    for (int c = 0; c < nc; c++) {
+        free(cand[c].re);
+        free(cand[c].im);
+    }
+    free(cand);
+    free(pairs);
+    free(blob);
+    free(G);
+    return st;
+}
+
 static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, const float *customBank,
                       const float *customFre, const int *customBin) {
     const int num = proto->num, D = proto->dataLength, pad = proto->padLength;
@@ -563,6 +732,8 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
                 const int maxR = em ? atoi(em) : AFX_CWT_NARROW_MAX_DEFAULT;
                 if (order && st == AFX_OK && maxR >= 2) {
                     afx_cwt_classify_host(sup, num, maxR, order, &o->dims.nWide, o->dims.nNarrow);
+                    if (st == AFX_OK && !getenv("AFX_CWT_NO_TD")) st = cwt_td_plan(o, rL, order, &o->dims.nWide);
+                    if (o->dims.nTd > 0) o->dims.td = &o->td;
                     /* device image: order[num] followed by the (scale, first support row) pairs */
                     int *img = (int *)malloc(sizeof(int) * 3 * (size_t)num);
                     if (!img) st = AFX_ERR_NOMEM;
@@ -677,9 +848,13 @@ static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *
     if (st == AFX_OK && small)
         st = afxk_cwt_small(&o->dims, o->dTw, dataArr ? o->dX : NULL, 0, 1, isDet ? o->dBankDetN : o->dBankN,
                             o->num, isDet, o->dXt, dRe, dIm, o->stream);
-    else if (st == AFX_OK)
+    else if (st == AFX_OK) {
         st = afxk_cwt_inverse(&o->dims, o->dTw, o->dXt, dBank, o->num, isDet, 1, o->dB, dRe, dIm,
                               AFX_CWT_WIDE | AFX_CWT_NARROW, o->stream);
+        /* the short-kernel scales straight from the signal (dX keeps the last uploaded chunk) */
+        if (st == AFX_OK && !isDet && o->dims.nTd > 0)
+            st = afxk_cwt_td(&o->td, o->dX, 0, 1, o->dataLength, o->num, dRe, dIm, o->stream);
+    }
     if (st == AFX_OK && re) st = afxdev_d2h(re, dRe, outB, o->stream);
     if (st == AFX_OK && im) st = afxdev_d2h(im, dIm, outB, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
@@ -744,7 +919,16 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * pass 22.6 us per chunk at group 1, 32 us at group 4); with the 40 wide scales the
      * narrow-band plan leaves: 2 chunks (+9 %, profiles/r01_cwt_narrowband.txt); 16 chunks at
      * the wrapper's default L = 2^13 (otherwise launch-bound). */
-    const int nTwoPass = o->dims.order ? o->dims.nWide : o->num; /* scales that write the intermediate */
+    /* the short-kernel scales of the plain transform run in the time domain (afx_cwt_td.hip) -- from the signal, not
+     * from the spectrum: all chunks of the call at once on a side stream of their own, joined at the end */
+    const int useTd = !isDet && o->dims.nTd > 0;
+    if (st == AFX_OK && useTd) {
+        if (!o->tdStream) st = afxdev_stream_create(&o->tdStream);
+        if (st == AFX_OK) st = afxdev_stream_wait_stream(o->tdStream, hipStream);
+        if (st == AFX_OK)
+            st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, o->tdStream);
+    }
+    const int nTwoPass = o->dims.order ? o->dims.nWide + (useTd ? 0 : o->dims.nTd) : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
     const int overlap = 1; /* (round 2: the three-chain schedule below is +10 % over one stream) */
     int group = nTwoPass > 0 ? (int)((overlap ? 48.0e6 : 96.0e6) / ((double)nTwoPass * L * 8.0)) : 32;
@@ -813,6 +997,7 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
                                   hipStream);
         if (st == AFX_OK && side) st = afxdev_stream_wait_stream(hipStream, side);
     }
+    if (st == AFX_OK && useTd) st = afxdev_stream_wait_stream(hipStream, o->tdStream);
     o->lastStream = hipStream;
     o->lastUsed = 1;
 
@@ -904,6 +1089,7 @@ void cwtObj_free(CWTObj o) {
     if (!o) return;
     if (o->stream) afxdev_stream_sync(o->stream);
     if (o->stream2) afxdev_stream_sync(o->stream2);
+    if (o->tdStream) afxdev_stream_sync(o->tdStream);
     for (int i = 0; i < 3; i++)
         if (o->chain[i]) afxdev_stream_sync(o->chain[i]);
     if (o->lastUsed && o->lastStream) afxdev_stream_sync(o->lastStream); /* the caller's stream may still run our kernels */
@@ -919,11 +1105,14 @@ void cwtObj_free(CWTObj o) {
     afxdev_free(o->dBankDetN);
     afxdev_free(o->dSupport);
     afxdev_free(o->dOrder);
+    afxdev_free(o->dTdPairs);
+    afxdev_free(o->dTdImage);
     afxdev_free(o->dGA);
     afxdev_free(o->dGXt);
     afxdev_free(o->dGB);
     afxdev_free(o->dOut);
     afxdev_stream_destroy(o->stream2);
+    afxdev_stream_destroy(o->tdStream);
     for (int i = 0; i < 3; i++) afxdev_stream_destroy(o->chain[i]);
     afxdev_stream_destroy(o->stream);
     free(o->freBandArr);

@@ -52,6 +52,8 @@ int afx_log2_exact(int v);
 /* the reference's float32 radix-2 DIT FFT, operation for operation (kernel banks are
  * thresholded on its output, so the host copy must round identically) */
 void afx_fft_ref32(int radix2Exp, const float *re1, const float *im1, float *re2, float *im2);
+/* in-place radix-2 complex FFT in double (inverse != 0: e^{+...}, unnormalised); 0 or AFX_ERR_NOMEM */
+int afx_fft_f64(int log2n, double *re, double *im, int inverse);
 
 /* ---- chroma banks ------------------------------------------------------ */
 /* afx_cqt.c: 0/1 folding matrix [chromaNum, num] of log-spaced bins onto chroma classes

@@ -118,6 +118,52 @@ void afx_fft_ref32(int r, const float *re1, const float *im1, float *re2, float 
     free(ws);
 }
 
+/* in-place radix-2 complex FFT in double: X[k] = sum_n x[n] e^{-+ 2 pi i k n / N} (inverse != 0: the + sign, no 1/N).
+ * Plan-time helper (time-domain images of the wide CWT scales, afx_cwt.c); 0 or AFX_ERR_NOMEM */
+int afx_fft_f64(int log2n, double *re, double *im, int inverse) {
+    const size_t n = (size_t)1 << log2n, half = n / 2;
+    if (log2n < 1) return 0;
+    double *wc = (double *)malloc(sizeof(double) * half), *ws = (double *)malloc(sizeof(double) * half);
+    if (!wc || !ws) {
+        free(wc);
+        free(ws);
+        return -5;
+    }
+    for (size_t i = 0; i < half; i++) {
+        const double ang = 2.0 * M_PI * (double)i / (double)n;
+        wc[i] = cos(ang);
+        ws[i] = inverse ? sin(ang) : -sin(ang);
+    }
+    for (size_t i = 0, j = 0; i < n; i++) { /* bit reversal */
+        if (i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+        size_t m = half;
+        while (m >= 1 && (j & m)) {
+            j ^= m;
+            m >>= 1;
+        }
+        j |= m;
+    }
+    for (size_t len = 2, step = half; len <= n; len <<= 1, step >>= 1) {
+        const size_t h = len / 2;
+        for (size_t b = 0; b < n; b += len)
+            for (size_t k = 0; k < h; k++) {
+                const double c = wc[k * step], sn = ws[k * step];
+                const double ur = re[b + k], ui = im[b + k];
+                const double vr = re[b + k + h] * c - im[b + k + h] * sn, vi = re[b + k + h] * sn + im[b + k + h] * c;
+                re[b + k] = ur + vr;
+                im[b + k] = ui + vi;
+                re[b + k + h] = ur - vr;
+                im[b + k + h] = ui - vi;
+            }
+    }
+    free(wc);
+    free(ws);
+    return 0;
+}
+
 /* ---- on-wire format of gathered features ------------------------------------
  * NumPy .npy, format version 1.0: magic, header dict {'descr': '<f4', 'fortran_order': False,
  * 'shape': (...)}, padded with spaces to a multiple of 64 bytes, then the C-ordered float32 data.
