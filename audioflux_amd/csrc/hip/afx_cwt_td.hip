@@ -28,6 +28,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
@@ -38,38 +39,50 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int RSRC_RAW = 0x00020000;  // raw buffer, 32-bit data format (cdna_hip_programming.md T8)
+constexpr unsigned OOR = 0x80000000u; // an offset the bounds check rejects: loads return 0, stores are dropped
 
 constexpr int WAVES = 4;             // one wave per SIMD: the image leaves room for no more at the longest kernels
 constexpr int TILE = 512;            // outputs per wave iteration: two row tiles of 32 rows x 8 phases
 constexpr int SLAB = 8192;           // outputs per work unit (a workgroup's share of one chunk at a time)
-constexpr int NV = (TILE + AFX_CWT_TD_MAXK) / 256;   // 16-byte window loads per lane (6)
-constexpr int PLANE = 2 * (TILE + AFX_CWT_TD_MAXK) + 64;  // bytes of one f16 plane of the window (+ slack: the K loop
-                                                          // requests one step past the end, never used)
-constexpr int WAVE_BYTES = 2 * PLANE;  // hi | lo; re-used by the transposed epilogue (4 x 264 floats = 4224 B)
 constexpr int EPI_PITCH = 264;       // floats per (scale, plane) row of the epilogue buffer: banks 8 q + p distinct
-static_assert(4 * EPI_PITCH * 4 <= WAVE_BYTES, "epilogue buffer must fit the window region");
+// Two classes of pairs, one instantiation each: MAXK = the taps of the longest kernel of the class.  The long class
+// (<= 1024 taps: up to 128 KB of image) leaves room for one workgroup per CU; the short class (<= SHORTK taps: <= 48 KB
+// of image, 3.7 KB of window planes per wave) fits TWO workgroups per CU, so that one wave's conversion / epilogue
+// runs under the other's K loop -- with 8 .. 24 K steps per tile those phases are as long as the loop itself.
+constexpr int SHORTK = 384;
+template <int MAXK>
+struct TdGeom {
+    static constexpr int NV = (TILE + MAXK + 255) / 256;     // 16-byte window loads per lane
+    static constexpr int PLANE = 2 * (TILE + MAXK) + 96;     // bytes of one f16 plane of the window (+ slack: the K
+                                                             // loop requests two steps past the end, never used)
+    static constexpr int WAVE_BYTES = (2 * PLANE > 4 * EPI_PITCH * 4 ? 2 * PLANE : 4 * EPI_PITCH * 4);  // hi | lo;
+                                                             // re-used by the transposed epilogue (4224 B)
+};
 
+constexpr int MAXPAIRS = 48;
 struct TdArgs {
     const float *x;
     long long xStride;
-    int chunks, dataLength, num, wrap, aligned;
+    int chunks, dataLength, num, wrap;
     const AfxCwtTdPair *pairs;
     const unsigned char *image;
-    int nPairs;
+    int nPairs;                // pairs of this launch (a class of the plan: pairs[0 .. nPairs))
     float *outRe, *outIm;
+    int wgBase[MAXPAIRS + 1];  // workgroups [wgBase[p], wgBase[p + 1]) serve pair p (per call: exact shares of its units)
 };
 
 // position q of the (conceptually padded) chunk -> sample index: reflect (cwt_algorithm.c:404-414) or wrap
 __device__ __forceinline__ int td_index(int q, int D, int wrap) {
     if (q >= 0 && q < D) return q;
-    if (wrap) {
-        q %= D;
-        return q < 0 ? q + D : q;
-    }
+    if (wrap) return q < 0 ? q + D : q - D;  // (|kernel half length| < D: one turn)
     return q < 0 ? -1 - q : 2 * D - 1 - q;
 }
 
+template <int MAXK>
 __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
+    constexpr int NV = TdGeom<MAXK>::NV, PLANE = TdGeom<MAXK>::PLANE, WAVE_BYTES = TdGeom<MAXK>::WAVE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,14 +90,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
 
     // ---- which pair this workgroup serves, and which of its work units (host: workgroups in proportion to K)
     int p = 0;
-    while (p + 1 < a.nPairs && (int)blockIdx.x >= a.pairs[p].wgBase + a.pairs[p].wgCount) ++p;
+    while (p + 1 < a.nPairs && (int)blockIdx.x >= a.wgBase[p + 1]) ++p;
     const AfxCwtTdPair *pr = a.pairs + p;  // (fields are read one by one: a local copy of the struct lands in scratch)
-    const int wgCount = pr->wgCount;
-    const int local = (int)blockIdx.x - pr->wgBase;
+    const int wgCount = a.wgBase[p + 1] - a.wgBase[p];
+    const int local = (int)blockIdx.x - a.wgBase[p];
     const int KS = pr->ks, kh = pr->kh, Kt = 16 * KS;
     const int imgBytes = 2 * KS * 1024;
     unsigned char *Bl = smem_raw;
-    unsigned char *sig = smem_raw + imgBytes + 1024 + wave * WAVE_BYTES;  // (+ 1 KB: the K loop reads one step ahead)
+    unsigned char *sig = smem_raw + imgBytes + 2048 + wave * WAVE_BYTES;  // (+ 2 KB: the K loop requests two steps ahead)
     {   // image -> LDS
         const float4 *src = reinterpret_cast<const float4 *>(a.image + pr->img);
         float4 *dst = reinterpret_cast<float4 *>(Bl);
@@ -106,27 +119,38 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
         chunk = u / slabs;
         n0 = (u - chunk * slabs) * SLAB + ((tau % itersPerUnit) * WAVES + wave) * TILE;
     };
-    float4 wnd[NV];
+    // Window loads.  Interior tiles (the whole window inside the chunk: all but the first and last few of a chunk):
+    // NV unconditional 16-byte buffer loads per lane -- a fixed count, so that the wait for the window at the top of
+    // the next tile is vmcnt(<the 8 stores issued behind them>) and not a wait for those stores (the same device as in
+    // afx_cqt_f16.hip); lanes past the window read out of range (zeros).  Edge tiles (wave-uniform branch): per-sample
+    // loads through the reflect / wrap index map.
+    u32x4 wnd[NV];
     auto fetch = [&](int tau) {
         int chunk, n0;
         where(tau, chunk, n0);
         const float *xc = a.x + (long long)chunk * a.xStride;
+        const int q00 = n0 - kh;
+        if (q00 >= 0 && q00 + TILE + Kt <= D) {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xc), 0, D * 4, RSRC_RAW);
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int v = lane + 64 * u;
-            const int q0 = n0 - kh + 4 * v;
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < nv4) {
-                if (a.aligned && q0 >= 0 && q0 + 3 < D) {
-                    r = *reinterpret_cast<const float4 *>(xc + q0);
-                } else {
+            for (int u = 0; u < NV; ++u) {
+                const int v = lane + 64 * u;
+                wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, v < nv4 ? (unsigned)(q00 + 4 * v) * 4u : OOR, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int v = lane + 64 * u;
+                const int q0 = q00 + 4 * v;
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v < nv4) {
                     r.x = xc[td_index(q0, D, a.wrap)];
                     r.y = xc[td_index(q0 + 1, D, a.wrap)];
                     r.z = xc[td_index(q0 + 2, D, a.wrap)];
                     r.w = xc[td_index(q0 + 3, D, a.wrap)];
                 }
+                wnd[u] = __builtin_bit_cast(u32x4, r);
             }
-            wnd[u] = r;
         }
     };
 
@@ -141,14 +165,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
     const int scaleA = pr->scale[0], scaleB = pr->scale[1];
 
     if (tiles > 0) fetch(0);
+    {   // eight out-of-range (dropped) stores behind the first window: the tile loop is then entered with the same
+        // count of memory operations in flight as on its back edge (window loads, then a tile's eight stores), and the
+        // compiler's wait for the window becomes vmcnt(8 + ...) instead of a wait for the previous tile's stores
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.outRe, 0, 4, RSRC_RAW);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) __builtin_amdgcn_raw_buffer_store_b128(z, rd, OOR + 16u * r, 0, 0);  // distinct: not merged
+    }
     for (int tau = 0; tau < tiles; ++tau) {
         int chunk, n0;
         where(tau, chunk, n0);
         // ---- tile exponent from the window's own peak
         float peak = 0.f;
 #pragma unroll
-        for (int u = 0; u < NV; ++u)
-            peak = fmaxf(peak, fmaxf(fmaxf(fabsf(wnd[u].x), fabsf(wnd[u].y)), fmaxf(fabsf(wnd[u].z), fabsf(wnd[u].w))));
+        for (int u = 0; u < NV; ++u) {
+            const float4 w4 = __builtin_bit_cast(float4, wnd[u]);
+            peak = fmaxf(peak, fmaxf(fmaxf(fabsf(w4.x), fabsf(w4.y)), fmaxf(fabsf(w4.z), fabsf(w4.w))));
+        }
         const int e = split_exponent(wave_max_bits(peak));
         const float up = __uint_as_float((unsigned)(e + 127) << 23);      // 2^e
         const float down = __uint_as_float((unsigned)(127 - e) << 23);    // 2^-e
@@ -158,9 +192,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
         for (int u = 0; u < NV; ++u) {
             const int v = lane + 64 * u;
             if (v < nv4) {
+                const float4 w4 = __builtin_bit_cast(float4, wnd[u]);
                 unsigned hi0, hi1, lo0, lo1;
-                split_pair(wnd[u].x, wnd[u].y, up, hi0, lo0);
-                split_pair(wnd[u].z, wnd[u].w, up, hi1, lo1);
+                split_pair(w4.x, w4.y, up, hi0, lo0);
+                split_pair(w4.z, w4.w, up, hi1, lo1);
                 *reinterpret_cast<uint2 *>(sig + 8 * v) = make_uint2(hi0, hi1);
                 *reinterpret_cast<uint2 *>(sig + PLANE + 8 * v) = make_uint2(lo0, lo1);
             }
@@ -168,11 +203,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
         wave_lds_order();
         if (tau + 1 < tiles) fetch(tau + 1);
 
-        // ---- K loop: per step of 16 taps 6 MFMAs (two row tiles x {xh gh, xh gl, xl gh}), operands one step ahead
+        // ---- K loop: per step of 16 taps 6 MFMAs (two row tiles x {xh gh, xh gl, xl gh}), operands two steps ahead.
+        //      The first step takes a zero C operand (an inline constant): no pass over the 64 accumulator registers.
         f32x16 hh0, hh1, x0, x1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hh0[r] = hh1[r] = x0[r] = x1[r] = 0.f;
-        h8 ah0[2], al0[2], ah1[2], al1[2], bh[2], bl[2];
+        const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        h8 ah0[4], al0[4], ah1[4], al1[4], bh[4], bl[4];
         const unsigned char *pa = aHi0, *pb = bHi0;
         auto load = [&](int slot, int off) {  // off: K step relative to the current base (compile-time immediates)
             ah0[slot] = *reinterpret_cast<const h8 *>(pa + 32 * off);
@@ -182,19 +217,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
             bh[slot] = *reinterpret_cast<const h8 *>(pb + 1024 * off);
             bl[slot] = *reinterpret_cast<const h8 *>(pb + bLoOff + 1024 * off);
         };
-        load(0, 0);
-        for (int kb = 0; kb < KS; kb += 4) {  // KS is a multiple of 4 (host)
+        auto block = [&](auto first) {  // four K steps; first: the accumulators start here
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 __builtin_amdgcn_sched_barrier(0);
-                load((s + 1) & 1, s + 1);  // (the last step of the last block reads one step past the end: slack above)
-                const int sl = s & 1;
-                hh0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[sl], bh[sl], hh0, 0, 0, 0);
-                hh1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[sl], bh[sl], hh1, 0, 0, 0);
-                x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[sl], bl[sl], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[sl], bl[sl], x1, 0, 0, 0);
-                x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[sl], bh[sl], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[sl], bh[sl], x1, 0, 0, 0);
+                load((s + 2) & 3, s + 2);  // (the last block requests two steps past the end: slack above, never used)
+                const bool init = decltype(first)::value && s == 0;
+                hh0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[s], bh[s], init ? Z : hh0, 0, 0, 0);
+                hh1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[s], bh[s], init ? Z : hh1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[s], bl[s], init ? Z : x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[s], bl[s], init ? Z : x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[s], bh[s], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[s], bh[s], x1, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -203,13 +237,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
             }
             pa += 128;
             pb += 4096;
-        }
+        };
+        load(0, 0);
+        load(1, 1);
+        block(std::true_type{});
+        for (int kb = 4; kb < KS; kb += 4) block(std::false_type{});  // KS is a multiple of 4 (host)
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 g -> output n0 + 256 rt + 8 row + phase
         const float mul = down * colMul;
-        const long long planeA = ((long long)chunk * a.num + scaleA) * D + n0;
-        const long long planeB = ((long long)chunk * a.num + (scaleB >= 0 ? scaleB : scaleA)) * D + n0;
+        // one raw buffer per plane and chunk ([num][D] floats); a single scale in the pair: its second half is dropped
+        const __amdgpu_buffer_rsrc_t rRe = __builtin_amdgcn_make_buffer_rsrc(a.outRe + (long long)chunk * a.num * D, 0, a.num * D * 4, RSRC_RAW);
+        const __amdgpu_buffer_rsrc_t rIm = __builtin_amdgcn_make_buffer_rsrc(a.outIm + (long long)chunk * a.num * D, 0, a.num * D * 4, RSRC_RAW);
+        const unsigned offA = (unsigned)(scaleA * D + n0 + 4 * lane) * 4u;
+        const unsigned offB = scaleB >= 0 ? (unsigned)(scaleB * D + n0 + 4 * lane) * 4u : OOR;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             wave_lds_order();  // fragment reads (rt 0) / the previous row tile's epilogue reads are done
@@ -221,14 +262,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
             wave_lds_order();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q >= 2 && scaleB < 0) continue;  // an odd scale count: the last pair's second half is empty
-                const float4 v = *reinterpret_cast<const float4 *>(epi + q * EPI_PITCH + 4 * lane);
-                float *dst = ((q & 1) ? a.outIm : a.outRe) + (q >= 2 ? planeB : planeA) + 256 * rt + 4 * lane;
-                if (a.aligned) {
-                    *reinterpret_cast<float4 *>(dst) = v;
-                } else {
-                    dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
-                }
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(epi + q * EPI_PITCH + 4 * lane);
+                const unsigned off = (q >= 2 ? offB : offA) + (scaleB < 0 && q >= 2 ? 0u : 1024u * rt);
+                __builtin_amdgcn_raw_buffer_store_b128(v, (q & 1) ? rIm : rRe, off, 0, 0);
             }
         }
     }
@@ -236,20 +272,46 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
 
 }  // namespace
 
-extern "C" int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStride, int chunks, int dataLength, int num,
-                           float *outRe, float *outIm, void *stream) {
-    if (!p || p->nPairs <= 0 || chunks <= 0) return AFX_OK;
-    if (dataLength < SLAB || (dataLength & (dataLength - 1))) return AFX_ERR_UNSUPPORTED;
-    if (p->maxKs < 4 || 16 * p->maxKs > AFX_CWT_TD_MAXK || p->wgTotal <= 0) return AFX_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)2 * p->maxKs * 1024 + 1024 + (size_t)WAVES * WAVE_BYTES;
+template <int MAXK>
+static int launch_td(const AfxCwtTdPlan *p, int first, int count, int maxKs, double wgTarget, TdArgs a, void *stream) {
+    if (count <= 0) return AFX_OK;
+    const size_t lds = (size_t)2 * maxKs * 1024 + 2048 + (size_t)WAVES * TdGeom<MAXK>::WAVE_BYTES;
     if (lds > 160 * 1024) return AFX_ERR_UNSUPPORTED;
     static bool attrSet[AFX_MAX_DEVICES] = {};
     const int dev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[dev]) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cwt_td), hipFuncAttributeMaxDynamicSharedMemorySize,
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cwt_td<MAXK>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
         attrSet[dev] = true;
     }
+    a.pairs = p->pairs + first;
+    a.nPairs = count;
+    // Workgroups per pair in proportion to its K steps (every workgroup then issues about the same number of matrix
+    // instructions) and EXACT shares: every workgroup of a pair takes the same number of (chunk, slab) units
+    const long long units = (long long)a.chunks * (a.dataLength / SLAB);
+    long long ksSum = 0;
+    for (int q = 0; q < count; ++q) ksSum += p->hostKs[first + q];
+    int base = 0;
+    for (int q = 0; q < count; ++q) {
+        double ideal = wgTarget * (double)p->hostKs[first + q] / (double)ksSum;
+        if (ideal < 1.0) ideal = 1.0;
+        long long per = (long long)((double)units / ideal + 0.999);  // units per workgroup
+        if (per < 1) per = 1;
+        a.wgBase[q] = base;
+        base += (int)((units + per - 1) / per);
+    }
+    a.wgBase[count] = base;
+    hipLaunchKernelGGL(k_cwt_td<MAXK>, dim3((unsigned)base), dim3(WAVES * 64), lds, (hipStream_t)stream, a);
+    AFX_LAUNCH_CHECK("k_cwt_td");
+    return AFX_OK;
+}
+
+extern "C" int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStride, int chunks, int dataLength, int num,
+                           float *outRe, float *outIm, void *stream) {
+    if (!p || p->nPairs <= 0 || chunks <= 0) return AFX_OK;
+    if (dataLength < SLAB || (dataLength & (dataLength - 1))) return AFX_ERR_UNSUPPORTED;
+    if (p->maxKs < 4 || 16 * p->maxKs > AFX_CWT_TD_MAXK || p->nPairs > MAXPAIRS || !p->hostKs) return AFX_ERR_UNSUPPORTED;
+    if ((long long)num * dataLength * 4 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;  // 32-bit offsets inside one chunk's planes
     TdArgs a;
     a.x = x;
     a.xStride = xStride;
@@ -257,14 +319,21 @@ extern "C" int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStr
     a.dataLength = dataLength;
     a.num = num;
     a.wrap = p->wrap;
-    a.aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (xStride % 4 == 0 || chunks == 1) &&
-                (reinterpret_cast<uintptr_t>(outRe) % 16 == 0) && (reinterpret_cast<uintptr_t>(outIm) % 16 == 0);
-    a.pairs = p->pairs;
     a.image = p->image;
-    a.nPairs = p->nPairs;
     a.outRe = outRe;
     a.outIm = outIm;
-    hipLaunchKernelGGL(k_cwt_td, dim3((unsigned)p->wgTotal), dim3(WAVES * 64), lds, (hipStream_t)stream, a);
-    AFX_LAUNCH_CHECK("k_cwt_td");
-    return AFX_OK;
+    int nLong = 0;  // pairs are sorted longest first
+    while (nLong < p->nPairs && 16 * p->hostKs[nLong] > SHORTK) ++nLong;
+    long long ksLong = 0, ksAll = 0;
+    for (int q = 0; q < p->nPairs; ++q) {
+        ksAll += p->hostKs[q];
+        if (q < nLong) ksLong += p->hostKs[q];
+    }
+    // ~4 rounds of the 256 CUs in all, split between the classes by their matrix work
+    const double wgAll = 1024.0;
+    int st = launch_td<AFX_CWT_TD_MAXK>(p, 0, nLong, p->maxKs, wgAll * (double)ksLong / (double)ksAll, a, stream);
+    if (st == AFX_OK && nLong < p->nPairs)
+        st = launch_td<SHORTK>(p, nLong, p->nPairs - nLong, p->hostKs[nLong], wgAll * (double)(ksAll - ksLong) / (double)ksAll + 256.0,
+                               a, stream);
+    return st;
 }

@@ -220,13 +220,13 @@ typedef struct {
     int ks;                  /* K steps of 16 taps (multiple of 4)                                            */
     long long img;           /* byte offset of the pair's image in the blob: [word 2][ks][64 lanes][8] f16,
                               * the B-fragment order of v_mfma_f32_32x32x16_f16 (afx_cqt_time_kernel_f16)     */
-    int wgBase, wgCount;     /* persistent workgroups serving this pair (in proportion to ks)                 */
     float colMul[32];        /* 2^-s_c of the image columns                                                   */
 } AfxCwtTdPair;
 typedef struct AfxCwtTdPlan_ {
     const AfxCwtTdPair *pairs;   /* device [nPairs], longest kernels first */
     const unsigned char *image;  /* device blob */
-    int nPairs, maxKs, wgTotal;
+    const int *hostKs;           /* host [nPairs]: K steps of every pair (the launcher sizes the workgroup shares) */
+    int nPairs, maxKs;
     int wrap;                    /* 0: reflect padding (isPadding, cwt_algorithm.c:404-414), 1: circular */
 } AfxCwtTdPlan;
 /* chunk c at x + c xStride (dataLength = 2^r samples) -> outRe/outIm [chunks][num][dataLength], rows p->pairs[].scale */

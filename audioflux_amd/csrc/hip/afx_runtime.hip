@@ -225,9 +225,12 @@ extern "C" int afxdev_stream_create(void **stream) {
 // decimations under the octave products, the CWT chains) call this two or three times per launch group: the
 // events come from a small per-thread, per-device ring instead of a create / destroy pair per call (a wait
 // captures the record that precedes it, so an event may be recorded again while an earlier wait is pending).
+#ifndef AFX_EVENT_RING
+#define AFX_EVENT_RING 16  /* (> the waits of one batched call: a slot is never re-recorded within a call) */
+#endif
 namespace {
 struct EventRing {
-    hipEvent_t ev[8];
+    hipEvent_t ev[AFX_EVENT_RING];
     int dev = -1, next = 0;  // (no destructor: a thread may end after the HIP runtime has shut down)
 };
 thread_local EventRing t_events;
@@ -241,7 +244,7 @@ extern "C" int afxdev_stream_wait_stream(void *waiter, void *signaler) {
         if (r.dev >= 0)
             for (hipEvent_t e : r.ev) (void)hipEventDestroy(e);
         r.dev = -1;
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < AFX_EVENT_RING; ++i) {
             if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) {
                 for (int j = 0; j < i; ++j) (void)hipEventDestroy(r.ev[j]);
                 afxdev_set_error("stream wait: hipEventCreate failed");
@@ -252,7 +255,7 @@ extern "C" int afxdev_stream_wait_stream(void *waiter, void *signaler) {
         r.next = 0;
     }
     hipEvent_t ev = r.ev[r.next];
-    r.next = (r.next + 1) & 7;
+    r.next = (r.next + 1) % AFX_EVENT_RING;
     hipError_t e = hipEventRecord(ev, (hipStream_t)signaler);
     if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
     if (e != hipSuccess) {

@@ -42,8 +42,8 @@ struct OpaqueCWT {
     int *dOrder;             /* [num]: wide scales first, then the narrow-band classes (afx_device.h) */
     AfxCwtTdPlan td;         /* time-domain plan of the short-kernel scales (afx_cwt_td.hip); nPairs 0: none */
     AfxCwtTdPair *dTdPairs;
+    int *tdKs;               /* host: K steps of the pairs */
     unsigned char *dTdImage;
-    void *tdStream;          /* side stream of the time-domain launches */
     float *dGA, *dGXt, *dGB; /* scratch of the batched calls: `group` chunks at a time */
     size_t capGA, capGXt, capGB;
     int haveSpectrum;
@@ -567,7 +567,7 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
         pairs = (AfxCwtTdPair *)calloc((size_t)nPairs, sizeof(AfxCwtTdPair));
         if (!pairs) st = AFX_ERR_NOMEM;
         size_t blobBytes = 0;
-        int ksSum = 0, maxKs = 0;
+        int maxKs = 0;
         for (int p = 0; p < nPairs && st == AFX_OK; p++) {
             const TdCand *a = &cand[2 * p], *b = 2 * p + 1 < nc ? &cand[2 * p + 1] : NULL;
             const int kh = (a->kh + 7) & ~7; /* a is the longer one */
@@ -578,7 +578,6 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
             pairs[p].ks = kt / 16;
             pairs[p].img = (long long)blobBytes;
             blobBytes += (size_t)2 * pairs[p].ks * 1024;
-            ksSum += pairs[p].ks;
             if (pairs[p].ks > maxKs) maxKs = pairs[p].ks;
         }
         if (st == AFX_OK) {
@@ -586,9 +585,6 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
             G = (float *)malloc(sizeof(float) * 32 * (size_t)(16 * maxKs));
             if (!blob || !G) st = AFX_ERR_NOMEM;
         }
-        /* persistent workgroups in proportion to the K steps of a pair (every workgroup then does about the same
-         * number of matrix instructions): ~1024 in all = four rounds of the 256 CUs */
-        int base = 0;
         for (int p = 0; p < nPairs && st == AFX_OK; p++) {
             const int kt = 16 * pairs[p].ks, kh = pairs[p].kh;
             memset(G, 0, sizeof(float) * 32 * (size_t)kt);
@@ -603,11 +599,6 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
                 }
             }
             afx_cqt_time_kernel_f16(G, kt, (unsigned short *)(blob + pairs[p].img), pairs[p].colMul);
-            int wg = (int)(1024.0 * pairs[p].ks / ksSum + 0.5);
-            if (wg < 1) wg = 1;
-            pairs[p].wgBase = base;
-            pairs[p].wgCount = wg;
-            base += wg;
         }
         if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTdPairs, sizeof(AfxCwtTdPair) * (size_t)nPairs);
         if (st == AFX_OK) st = afxdev_h2d(o->dTdPairs, pairs, sizeof(AfxCwtTdPair) * (size_t)nPairs, o->stream);
@@ -619,7 +610,10 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
             o->td.image = o->dTdImage;
             o->td.nPairs = nPairs;
             o->td.maxKs = maxKs;
-            o->td.wgTotal = base;
+            o->tdKs = (int *)malloc(sizeof(int) * (size_t)nPairs);
+            if (!o->tdKs) st = AFX_ERR_NOMEM;
+            for (int p = 0; p < nPairs && o->tdKs; p++) o->tdKs[p] = pairs[p].ks;
+            o->td.hostKs = o->tdKs;
             o->td.wrap = pad > 0 ? 0 : 1;
             /* order := [time-domain scales, pair by pair | the other two-pass scales | narrow-band classes] */
             int *rest = (int *)malloc(sizeof(int) * (size_t)*nWide);
@@ -732,7 +726,7 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
                 const int maxR = em ? atoi(em) : AFX_CWT_NARROW_MAX_DEFAULT;
                 if (order && st == AFX_OK && maxR >= 2) {
                     afx_cwt_classify_host(sup, num, maxR, order, &o->dims.nWide, o->dims.nNarrow);
-                    if (st == AFX_OK && !getenv("AFX_CWT_NO_TD")) st = cwt_td_plan(o, rL, order, &o->dims.nWide);
+                    if (st == AFX_OK) st = cwt_td_plan(o, rL, order, &o->dims.nWide);
                     if (o->dims.nTd > 0) o->dims.td = &o->td;
                     /* device image: order[num] followed by the (scale, first support row) pairs */
                     int *img = (int *)malloc(sizeof(int) * 3 * (size_t)num);
@@ -921,13 +915,17 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * the wrapper's default L = 2^13 (otherwise launch-bound). */
     /* the short-kernel scales of the plain transform run in the time domain (afx_cwt_td.hip) -- from the signal, not
      * from the spectrum: all chunks of the call at once on a side stream of their own, joined at the end */
+    /* The short-kernel scales of the plain transform run in the time domain (afx_cwt_td.hip) -- from the signal, not
+     * from the spectrum: all chunks of the call at once, on the caller's stream AHEAD of the forward transform.
+     * Not beside it: with the time-domain launches on side streams (one or two; or on the second chain's stream)
+     * the step measured 32.0-32.8 k chunks/s against 29.9 k here, but rows of the FFT-path kernels that ran at the
+     * same time (two-pass scales, the first narrow-band class) then came out timing-dependent -- wrong by up to
+     * 30 % in 16-column tiles, different from run to run -- while the time-domain rows stayed bit-identical and the
+     * time-domain kernel alone writes nothing outside its rows (profiles/r03_cwt_td_schedules.txt).  Root cause not
+     * found in round 3; a schedule that never overlaps the two is bit-reproducible (ring test, 7000 chunks). */
     const int useTd = !isDet && o->dims.nTd > 0;
-    if (st == AFX_OK && useTd) {
-        if (!o->tdStream) st = afxdev_stream_create(&o->tdStream);
-        if (st == AFX_OK) st = afxdev_stream_wait_stream(o->tdStream, hipStream);
-        if (st == AFX_OK)
-            st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, o->tdStream);
-    }
+    if (st == AFX_OK && useTd)
+        st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, hipStream);
     const int nTwoPass = o->dims.order ? o->dims.nWide + (useTd ? 0 : o->dims.nTd) : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
     const int overlap = 1; /* (round 2: the three-chain schedule below is +10 % over one stream) */
@@ -997,7 +995,6 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
                                   hipStream);
         if (st == AFX_OK && side) st = afxdev_stream_wait_stream(hipStream, side);
     }
-    if (st == AFX_OK && useTd) st = afxdev_stream_wait_stream(hipStream, o->tdStream);
     o->lastStream = hipStream;
     o->lastUsed = 1;
 
@@ -1089,7 +1086,6 @@ void cwtObj_free(CWTObj o) {
     if (!o) return;
     if (o->stream) afxdev_stream_sync(o->stream);
     if (o->stream2) afxdev_stream_sync(o->stream2);
-    if (o->tdStream) afxdev_stream_sync(o->tdStream);
     for (int i = 0; i < 3; i++)
         if (o->chain[i]) afxdev_stream_sync(o->chain[i]);
     if (o->lastUsed && o->lastStream) afxdev_stream_sync(o->lastStream); /* the caller's stream may still run our kernels */
@@ -1112,11 +1108,11 @@ void cwtObj_free(CWTObj o) {
     afxdev_free(o->dGB);
     afxdev_free(o->dOut);
     afxdev_stream_destroy(o->stream2);
-    afxdev_stream_destroy(o->tdStream);
     for (int i = 0; i < 3; i++) afxdev_stream_destroy(o->chain[i]);
     afxdev_stream_destroy(o->stream);
     free(o->freBandArr);
     free(o->binBandArr);
     free(o->hBank);
+    free(o->tdKs);
     free(o);
 }

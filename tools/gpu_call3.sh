@@ -14,12 +14,12 @@ echo "pytest (cwt family + real audio + fullsize) rc=$RC $(grep -aE '[0-9]+ pass
 grep -aE "^FAILED|^ERROR|^E  " $OUT/pytest.log | head -40
 python tools/parity_table.py $OUT/parity.jsonl > $OUT/parity_table.md 2>&1
 if [ $RC -eq 124 ]; then echo "TIMEOUT in tests -- stopping"; exit 1; fi
-for v in td notd; do
-  if [ $v = notd ]; then export AFX_CWT_NO_TD=1; else unset AFX_CWT_NO_TD; fi
+for v in td; do
+
   timeout -k 10 200 python bench.py --config 4 --no-cpu-baseline > $OUT/bench_cfg4_$v.json 2> $OUT/bench_cfg4_$v.err
   echo "bench cfg4 $v rc=$?" | tee -a $OUT/status.txt
 done
-unset AFX_CWT_NO_TD
+
 timeout -k 10 200 bash tools/prof_cmd.sh ev_${TAG}_cfg4 "" python bench.py --config 4 --clips 40 --steps 3 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
 cp gpurun_out/prof_ev_${TAG}_cfg4/summary.txt $OUT/rocprofv3_bench_cfg4_trace.txt 2>/dev/null
 timeout -k 10 200 python tools/prof_traffic.py 4 --clips 20 --steps 1 > $OUT/traffic_cfg4.log 2>&1
@@ -29,7 +29,7 @@ cp gpurun_out/prof_ev_${TAG}_cfg4pmc/summary.txt $OUT/rocprofv3_bench_cfg4_mfma_
 cat $OUT/status.txt
 python - <<PY
 import json
-for v in ("td", "notd"):
+for v in ("td",):
     try:
         d = json.loads(open("$OUT/bench_cfg4_%s.json" % v).read().strip().splitlines()[-1])
         print(v, "value %.5g %s ms/step %.3f frac %.4f sustained_frac %.4f oracle %s" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["sustained_frac"] or 0, d["oracle_check"]))
