@@ -306,8 +306,10 @@ static int launch_td(const AfxCwtTdPlan *p, int first, int count, int maxKs, dou
     return AFX_OK;
 }
 
+// streamShort (NULL: `stream`): where the short-kernel class is launched -- beside the long class when it is another
+// stream (two workgroups of it fit a CU, so it fills the long class's tail); the caller joins the two
 extern "C" int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStride, int chunks, int dataLength, int num,
-                           float *outRe, float *outIm, void *stream) {
+                           float *outRe, float *outIm, void *stream, void *streamShort) {
     if (!p || p->nPairs <= 0 || chunks <= 0) return AFX_OK;
     if (dataLength < SLAB || (dataLength & (dataLength - 1))) return AFX_ERR_UNSUPPORTED;
     if (p->maxKs < 4 || 16 * p->maxKs > AFX_CWT_TD_MAXK || p->nPairs > MAXPAIRS || !p->hostKs) return AFX_ERR_UNSUPPORTED;
@@ -334,6 +336,6 @@ extern "C" int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStr
     int st = launch_td<AFX_CWT_TD_MAXK>(p, 0, nLong, p->maxKs, wgAll * (double)ksLong / (double)ksAll, a, stream);
     if (st == AFX_OK && nLong < p->nPairs)
         st = launch_td<SHORTK>(p, nLong, p->nPairs - nLong, p->hostKs[nLong], wgAll * (double)(ksAll - ksLong) / (double)ksAll + 256.0,
-                               a, stream);
+                               a, streamShort ? streamShort : stream);
     return st;
 }

@@ -231,7 +231,7 @@ typedef struct AfxCwtTdPlan_ {
 } AfxCwtTdPlan;
 /* chunk c at x + c xStride (dataLength = 2^r samples) -> outRe/outIm [chunks][num][dataLength], rows p->pairs[].scale */
 int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStride, int chunks, int dataLength, int num,
-                float *outRe, float *outIm, void *stream);
+                float *outRe, float *outIm, void *stream, void *streamShort /* short-kernel class; NULL: `stream` */);
 #define AFX_CWT_FASTTW_FLOATS (2 * (8 * 64 + 8 * 8 + 16 * 16))
 /* `chunks` signals, chunk c at x + c*xStride -> Xt[c][L] complex (transposed layout:
  * frequency k1 + 2^r1 k2 at [k1][k2]); scratchA: chunks*L complex */

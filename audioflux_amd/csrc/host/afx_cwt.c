@@ -847,7 +847,7 @@ static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *
                               AFX_CWT_WIDE | AFX_CWT_NARROW, o->stream);
         /* the short-kernel scales straight from the signal (dX keeps the last uploaded chunk) */
         if (st == AFX_OK && !isDet && o->dims.nTd > 0)
-            st = afxk_cwt_td(&o->td, o->dX, 0, 1, o->dataLength, o->num, dRe, dIm, o->stream);
+            st = afxk_cwt_td(&o->td, o->dX, 0, 1, o->dataLength, o->num, dRe, dIm, o->stream, NULL);
     }
     if (st == AFX_OK && re) st = afxdev_d2h(re, dRe, outB, o->stream);
     if (st == AFX_OK && im) st = afxdev_d2h(im, dIm, outB, o->stream);
@@ -924,8 +924,8 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * time-domain kernel alone writes nothing outside its rows (profiles/r03_cwt_td_schedules.txt).  Root cause not
      * found in round 3; a schedule that never overlaps the two is bit-reproducible (ring test, 7000 chunks). */
     const int useTd = !isDet && o->dims.nTd > 0;
-    if (st == AFX_OK && useTd)
-        st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, hipStream);
+    if (st == AFX_OK && useTd) /* (its two kernel classes side by side on two streams: no gain, 31.5 vs 31.5 k chunks/s) */
+        st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, hipStream, NULL);
     const int nTwoPass = o->dims.order ? o->dims.nWide + (useTd ? 0 : o->dims.nTd) : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
     const int overlap = 1; /* (round 2: the three-chain schedule below is +10 % over one stream) */
