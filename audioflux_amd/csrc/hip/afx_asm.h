@@ -1,0 +1,111 @@
+// afx_asm.h -- every hand-issued gfx950 instruction sequence of the kernels, in one place: packed-f32 complex
+// primitives with VOP3P operand modifiers, the mixed-precision f16 split, DS reads / writes with immediate offsets and
+// explicit s_waitcnt, L1-bypassing loads.  Kernels include it as <afx_asm.h>: the product build finds this file; the
+// CPU lane emulator of the test suite (tests/emu) puts its own afx_asm.h -- the same operations in C -- ahead of it
+// on the include path, so no kernel source carries a second implementation of these helpers.
+#ifndef AFX_ASM_H
+#define AFX_ASM_H
+
+#include <hip/hip_runtime.h>
+
+typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
+
+// ---- packed-f32 complex primitives -------------------------------------------------------
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2 pk_add_mi(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2 pk_add_pi(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y)
+__device__ __forceinline__ v2 pk_add_conj(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - conj(b) = (a.x - b.x, a.y + b.y)
+__device__ __forceinline__ v2 pk_sub_conj(v2 a, v2 b) {
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// complex product a * b
+// (both instructions in ONE asm statement: the compiler pads every inline-asm VALU result with an
+// s_nop before its first use -- it cannot see that the hardware interlocks the dependence)
+__device__ __forceinline__ v2 cmul(v2 a, v2 b) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                  // (ax bx, ax by)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"              // (-ay by + ., ay bx + .)
+        : "=&v"(t), "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// complex multiply-accumulate c + a * b: two packed fmas
+__device__ __forceinline__ v2 cfma(v2 a, v2 b, v2 c) {
+    v2 t, r;
+    asm("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                          // (ax bx + cx, ax by + cy)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"              // (-ay by + ., ay bx + .)
+        : "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// w * (-i d):  real = w.x d.y + w.y d.x,  imag = w.y d.y - w.x d.x
+__device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                  // (dy wx, dy wy)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"              // (dx wy + ., -dx wx + .)
+        : "=&v"(t), "=v"(r) : "v"(d), "v"(w));
+    return r;
+}
+// (-i) a = (a.y, -a.x) as one multiply by the constant pair (1, -1)
+__device__ __forceinline__ v2 mul_mi(v2 a) {
+    v2 r;
+    const v2 c = {1.f, -1.f};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+}
+
+
+// ---- float32 -> (hi, lo) binary16 words --------------------------------------------------
+// (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
+// fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).
+// One asm statement: VALU->VALU dependences are interlocked, and hipcc's own form of this costs 7 instructions.
+__device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigned &hi, unsigned &lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(x0), "v"(x1), "s"(up));
+}
+
+
+
+// ---- LDS traffic issued by hand (hipcc fuses two float2 reads from one base into ds_read2_b64, which the LDS serves
+// at half rate, and sinks plain loads next to their first use).  addr: a byte address in LDS (lds_addr); off: immediate.
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
+#define RD64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+// (the same read through a pointer into a static __shared__ array)
+#define RD128_P(dst, ptr, off) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((unsigned)(size_t)(ptr)), "n"(off) : "memory")
+// two rows with one instruction; offsets in units of 8 bytes (<= 255)
+#define WR2_64(addr, d0, d1, o0, o1) \
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
+// two dwords 64-dword units apart; offsets in units of 256 bytes (<= 255)
+#define WR2ST_32(addr, d0, d1, o0, o1) \
+    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
+// the value of an asm result is only defined behind the wait that follows it: pin its first use there
+#define PIN(x) asm volatile("" : "+v"(x))
+#define LDS_WAIT_N(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+// ---- global memory
+#define VM_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")             // own stores -> L2 (vmcnt counts stores on gfx9)
+#define VM_LGKM_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+// 16-byte load served by the L2, never by this CU's L1 (rows another lane of the wave stored a moment ago)
+#define LOAD_SC1_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+
+#endif /* AFX_ASM_H */

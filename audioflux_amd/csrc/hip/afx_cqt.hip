@@ -500,30 +500,20 @@ __global__ __launch_bounds__(256) void k_cqt_decimate(const float *__restrict__ 
     // and 2-way bank conflicts, SQ_LDS_BANK_CONFLICT was 65 % of the kernel's LDS cycles)
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 ev[9], ov[9];
-    const unsigned ae = (unsigned)(size_t)XE + 16u * tid, ao = (unsigned)(size_t)XO + 16u * tid;
-#ifndef AFX_HOST_EMULATION
-#define DEC_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-    DEC_RD(ev[0], ae, 0);   DEC_RD(ov[0], ao, 0);   DEC_RD(ev[1], ae, 16);  DEC_RD(ov[1], ao, 16);
-    DEC_RD(ev[2], ae, 32);  DEC_RD(ov[2], ao, 32);  DEC_RD(ev[3], ae, 48);  DEC_RD(ov[3], ao, 48);
-    DEC_RD(ev[4], ae, 64);  DEC_RD(ov[4], ao, 64);  DEC_RD(ev[5], ae, 80);  DEC_RD(ov[5], ao, 80);
-    DEC_RD(ev[6], ae, 96);  DEC_RD(ov[6], ao, 96);  DEC_RD(ev[7], ae, 112); DEC_RD(ov[7], ao, 112);
-    DEC_RD(ev[8], ae, 128); DEC_RD(ov[8], ao, 128);
-#undef DEC_RD
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else  // tests/emu (the kernel compiled for the host): the same 9 + 9 sixteen-byte reads
-    (void)ae, (void)ao;
-    for (int b = 0; b < 9; ++b) {
-        ev[b] = *reinterpret_cast<const f4 *>(XE + 4 * tid + 4 * b);
-        ov[b] = *reinterpret_cast<const f4 *>(XO + 4 * tid + 4 * b);
-    }
-#endif
+    const float *pe = XE + 4 * tid, *po = XO + 4 * tid;
+    // hand-issued aligned ds_read_b128 (hipcc narrows these reads to unaligned ds_read2 pieces: 65 % of the LDS
+    // cycles were bank conflicts)
+    RD128_P(ev[0], pe, 0);   RD128_P(ov[0], po, 0);   RD128_P(ev[1], pe, 16);  RD128_P(ov[1], po, 16);
+    RD128_P(ev[2], pe, 32);  RD128_P(ov[2], po, 32);  RD128_P(ev[3], pe, 48);  RD128_P(ov[3], po, 48);
+    RD128_P(ev[4], pe, 64);  RD128_P(ov[4], po, 64);  RD128_P(ev[5], pe, 80);  RD128_P(ov[5], po, 80);
+    RD128_P(ev[6], pe, 96);  RD128_P(ov[6], po, 96);  RD128_P(ev[7], pe, 112); RD128_P(ov[7], po, 112);
+    RD128_P(ev[8], pe, 128); RD128_P(ov[8], po, 128);
+    LDS_WAIT_N(0);
     float E[36], O[36];
 #pragma unroll
     for (int b = 0; b < 9; ++b) {
-#ifndef AFX_HOST_EMULATION
-        // the asm results are only defined after the wait above: pin the uses behind it
-        asm volatile("" : "+v"(ev[b]), "+v"(ov[b]));
-#endif
+        PIN(ev[b]);  // the asm results are only defined after the wait above: pin the uses behind it
+        PIN(ov[b]);
         E[4 * b] = ev[b].x; E[4 * b + 1] = ev[b].y; E[4 * b + 2] = ev[b].z; E[4 * b + 3] = ev[b].w;
         O[4 * b] = ov[b].x; O[4 * b + 1] = ov[b].y; O[4 * b + 2] = ov[b].z; O[4 * b + 3] = ov[b].w;
     }

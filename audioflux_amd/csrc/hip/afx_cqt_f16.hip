@@ -73,10 +73,9 @@ constexpr int RSRC_RAW = 0x00020000;  // raw buffer, 32-bit data format (cdna_hi
 
 // R12: 12 bins per octave (the default ladder) -> the tile's results are transposed through LDS and leave as four
 // 12-byte-per-lane stores (one lane = 3 consecutive bins of one frame and plane); otherwise 32 dword stores.
-// TIMING: per-phase s_memtime sums to dbg (AFX_CQT_EXP=3; tools only).
-template <int H, bool R12, bool TIMING>
+template <int H, bool R12>
 // hop 128: 19 KB of window planes per wave leave room for four waves (one per SIMD, up to 512 VGPRs)
-__global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtOctaveArgs a, int tilesPerClip, unsigned long long *dbg) {
+__global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtOctaveArgs a, int tilesPerClip) {
     using C = CqF16<H>;
     constexpr int NSTORE = R12 ? 4 : 32;  // memory stores per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -151,23 +150,8 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
 #pragma unroll
         for (int r = 0; r < NSTORE; ++r) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, OOR + 4u * r, 0, 0);  // distinct: not merged
     }
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = TIMING ? __builtin_readcyclecounter() : 0, ntile = 0;
-    const unsigned long long c0 = tprev, r0 = TIMING ? __builtin_amdgcn_s_memrealtime() : 0;
-    auto stamp = [&](int k) {
-        if (TIMING) {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long now = __builtin_readcyclecounter();
-            ph[k] += now - tprev;
-            tprev = now;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
     for (; t < totalTiles; t += stride) {
         const int clip = t / tilesPerClip, t0 = (t - clip * tilesPerClip) * 32;
-        stamp(0);  // loop overhead
-#ifndef AFX_HOST_EMULATION
-        if (TIMING) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory"); stamp(1); }  // window arrival
-#endif
         // ---- tile exponent: peak of the window -> [2^13, 2^14)
         float peak = 0.f;
 #pragma unroll
@@ -217,9 +201,7 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
             }
         }
         wave_lds_order();
-        stamp(2);  // peak + conversion + LDS writes
         if (t + stride < totalTiles) fetch(t + stride);
-        stamp(3);  // prefetch issue
 
         // ---- K loop: 32 steps x (xh gh, xh gl, xl gh), operands two steps ahead
         f32x16 hh, hl, lh;
@@ -252,9 +234,6 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifndef AFX_HOST_EMULATION
-        if (TIMING) { asm volatile("s_nop 0" ::: "memory"); stamp(4); ++ntile; }  // K loop
-#endif
         // ---- D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
         {
             const long long po = (long long)clip * a.outStride;
@@ -284,19 +263,10 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
                 }
             }
         }
-        stamp(5);  // epilogue
-    }
-    if (TIMING && dbg && lane == 0) {
-        unsigned long long *d = dbg + (size_t)(blockIdx.x * waves + wave) * 8;
-        for (int k = 0; k < 6; ++k) d[k] = ph[k];
-        d[6] = ntile;
-        // shader cycles per 100 MHz tick over the tile loop, x 1000
-        const unsigned long long dc = __builtin_readcyclecounter() - c0, dr = __builtin_amdgcn_s_memrealtime() - r0;
-        d[7] = dr ? dc * 1000ull / dr : 0;
     }
 }
 
-template <int H, bool R12, bool TIMING>
+template <int H, bool R12>
 int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
     using C = CqF16<H>;
     int waves = (160 * 1024 - C::B_BYTES) / C::WAVE_BYTES;
@@ -304,7 +274,7 @@ int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
     if (waves >= 4) waves &= ~3;  // the same number of waves on every SIMD
     if (waves < 1) return AFX_ERR_UNSUPPORTED;
     const size_t lds = (size_t)C::B_BYTES + (size_t)waves * C::WAVE_BYTES;
-    const void *fn = reinterpret_cast<const void *>(k_cqt_octave_f16<H, R12, TIMING>);
+    const void *fn = reinterpret_cast<const void *>(k_cqt_octave_f16<H, R12>);
     AFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tilesPerClip = (a->timeLength + 31) / 32;
     const long long total = (long long)tilesPerClip * (a->batch > 0 ? a->batch : 1);
@@ -313,38 +283,16 @@ int launch_f16(const AfxCqtOctaveArgs *a, void *stream) {
     if (wgs > 256) wgs = 256;  // one persistent workgroup per CU
     AfxCqtOctaveArgs b = *a;
     if (b.batch <= 0) b.batch = 1;
-    unsigned long long *dbg = nullptr;
-    if (TIMING) {
-        AFX_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * 8 * wgs * waves));
-        AFX_HIP(hipMemset(dbg, 0, sizeof(unsigned long long) * 8 * wgs * waves));
-    }
-    hipLaunchKernelGGL((k_cqt_octave_f16<H, R12, TIMING>), dim3((unsigned)wgs), dim3(64 * waves), lds, (hipStream_t)stream, b,
-                       tilesPerClip, dbg);
+    hipLaunchKernelGGL((k_cqt_octave_f16<H, R12>), dim3((unsigned)wgs), dim3(64 * waves), lds, (hipStream_t)stream, b,
+                       tilesPerClip);
     AFX_LAUNCH_CHECK("k_cqt_octave_f16");
-    if (TIMING) {
-        AFX_HIP(hipStreamSynchronize((hipStream_t)stream));
-        const size_t n = (size_t)8 * wgs * waves;
-        unsigned long long *h = (unsigned long long *)malloc(sizeof(unsigned long long) * n);
-        AFX_HIP(hipMemcpy(h, dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
-        double ph[6] = {0, 0, 0, 0, 0, 0}, nt = 0, mhz = 0;
-        for (size_t w = 0; w < (size_t)wgs * waves; ++w) {
-            for (int k = 0; k < 6; ++k) ph[k] += (double)h[w * 8 + k];
-            nt += (double)h[w * 8 + 6];
-            mhz += (double)h[w * 8 + 7] / 10.0;
-        }
-        fprintf(stderr, "cqt_f16<%d> %d waves/CU, %.0f MHz; shader cycles per tile: loop %.0f window-wait %.0f convert %.0f "
-                "prefetch %.0f kloop %.0f epilogue %.0f\n", H, waves, mhz / ((double)wgs * waves), ph[0] / nt, ph[1] / nt,
-                ph[2] / nt, ph[3] / nt, ph[4] / nt, ph[5] / nt);
-        free(h);
-        AFX_HIP(hipFree(dbg));
-    }
     return AFX_OK;
 }
 
 template <int H>
 int dispatch_f16(const AfxCqtOctaveArgs *a, void *stream) {
     // 12 bins per octave: the tile is transposed through LDS and leaves as 12-byte-per-lane stores
-    return a->rows == 12 ? launch_f16<H, true, false>(a, stream) : launch_f16<H, false, false>(a, stream);
+    return a->rows == 12 ? launch_f16<H, true>(a, stream) : launch_f16<H, false>(a, stream);
 }
 
 }  // namespace

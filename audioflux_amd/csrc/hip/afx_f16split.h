@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <afx_asm.h>
+
 namespace {
 
 __device__ __forceinline__ float dpp_f(float v, int ctrl) {
@@ -20,27 +22,7 @@ __device__ __forceinline__ float dpp_f(float v, int ctrl) {
     }
 }
 
-// (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
-// fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).
-// One asm statement: VALU->VALU dependences are interlocked, and hipcc's own form of this costs 7 instructions.
-__device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigned &hi, unsigned &lo) {
-#ifndef AFX_HOST_EMULATION
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(x0), "v"(x1), "s"(up));
-#else  // tests/emu (the kernel compiled for the host): the same four roundings in C
-    const _Float16 h0 = (_Float16)(x0 * up), h1 = (_Float16)(x1 * up);
-    const _Float16 l0 = (_Float16)(x0 * up - (float)h0), l1 = (_Float16)(x1 * up - (float)h1);
-    unsigned short b[4];
-    __builtin_memcpy(&b[0], &h0, 2), __builtin_memcpy(&b[1], &h1, 2), __builtin_memcpy(&b[2], &l0, 2), __builtin_memcpy(&b[3], &l1, 2);
-    hi = (unsigned)b[0] | ((unsigned)b[1] << 16);
-    lo = (unsigned)b[2] | ((unsigned)b[3] << 16);
-#endif
-}
-
+// (split_pair -- four v_fma_mix in one asm statement -- lives in afx_asm.h)
 
 // wave maximum of a non-negative float without LDS traffic: four DPP steps give every row of 16 lanes its maximum,
 // the four rows meet on the scalar unit (non-negative floats order like their bit patterns).  Returns the bits.

@@ -85,30 +85,7 @@ struct KArgs2 {
     float *energy, *rms, *zcr;  // [totalFrames]
 };
 
-#ifndef AFX_HOST_EMULATION
-__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
-#define RD64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#define RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-// two rows with one instruction; offsets in units of 8 bytes (<= 255)
-#define WR2_64(addr, d0, d1, o0, o1) \
-    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
-// two dwords 64-dword units apart; offsets in units of 256 bytes (<= 255)
-#define WR2ST_32(addr, d0, d1, o0, o1) \
-    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
-#define PIN(x) asm volatile("" : "+v"(x))
-#define LDS_WAIT_N(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
-#else  // tests/emu (the kernel compiled for the host): LDS addresses are offsets into the emulation's LDS array
-__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(static_cast<const unsigned char *>(p) - afx_emu_lds); }
-// (every DS instruction is a rendezvous of the wave, as on the device where a wave's DS operations execute in issue order)
-#define RD64(dst, addr, off) (afx_emu_ds(), __builtin_memcpy(&(dst), afx_emu_lds + (addr) + (off), 8), afx_emu_ds())
-#define RD128(dst, addr, off) (afx_emu_ds(), __builtin_memcpy(&(dst), afx_emu_lds + (addr) + (off), 16), afx_emu_ds())
-#define WR2_64(addr, d0, d1, o0, o1) \
-    (__builtin_memcpy(afx_emu_lds + (addr) + 8 * (o0), &(d0), 8), __builtin_memcpy(afx_emu_lds + (addr) + 8 * (o1), &(d1), 8))
-#define WR2ST_32(addr, d0, d1, o0, o1) \
-    (__builtin_memcpy(afx_emu_lds + (addr) + 256 * (o0), &(d0), 4), __builtin_memcpy(afx_emu_lds + (addr) + 256 * (o1), &(d1), 4))
-#define PIN(x) ((void)0)
-#define LDS_WAIT_N(n) ((void)0)
-#endif
+// (lds_addr, RD64 / RD128, WR2_64, WR2ST_32, PIN, LDS_WAIT_N and the L1-bypassing load: afx_asm.h)
 
 // Orders this wave's LDS stores before its later LDS loads of other lanes' data: DS operations of
 // one wave execute in issue order, lgkmcnt(0) drains them, the wave barrier pins the compiler.
@@ -234,15 +211,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
     //      the matching DCT elements come from the LDS table.  Called one frame AFTER the 16th row was
     //      stored, so the s_waitcnt finds those stores long complete; reads bypass the CU's L1.
     auto cc_block = [&](long long fb, int cnt) {
-#ifndef AFX_HOST_EMULATION
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores -> L2 (vmcnt counts stores on gfx9)
-#else
-        afx_emu_ds();  // tests/emu: the rows were stored by the other lanes' threads
-#endif
+        VM_WAIT_ALL();  // own stores -> L2 (vmcnt counts stores on gfx9)
         int ln = lane;
-#ifndef AFX_HOST_EMULATION
-        asm volatile("" : "+v"(ln));  // keep this block's per-lane values out of the frame loop's registers
-#endif
+        PIN(ln);  // keep this block's per-lane values out of the frame loop's registers
         const int fi = ln & 15, g = ln >> 4;
         const long long r = fb + (fi < cnt ? fi : cnt - 1);  // tail: duplicate the last row, not stored
         const v4f *src = reinterpret_cast<const v4f *>(a.out + r * 128) + g;
@@ -255,17 +226,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         for (int h = 0; h < 2; ++h) {
             v4f av[4], dv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)  // sc1: served by the L2, never by this CU's L1
-#ifndef AFX_HOST_EMULATION
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(av[u]) : "v"(src + 4 * (4 * h + u)) : "memory");
-#else
-                av[u] = src[4 * (4 * h + u)];
-#endif
+            for (int u = 0; u < 4; ++u) LOAD_SC1_B128(av[u], src + 4 * (4 * h + u));  // served by the L2, never by this CU's L1
 #pragma unroll
             for (int u = 0; u < 4; ++u) RD128(dv[u], ad, 16 * (4 * h + u));
-#ifndef AFX_HOST_EMULATION
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
+            VM_LGKM_WAIT_ALL();
 #pragma unroll
             for (int u = 0; u < 4; ++u) PIN(av[u]);
 #pragma unroll

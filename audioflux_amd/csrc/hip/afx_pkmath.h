@@ -5,7 +5,6 @@
 
 #include <hip/hip_runtime.h>
 
-typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
 
 // ---- packed-f32 complex primitives -------------------------------------------------------
 // VOP3P operand modifiers: op_sel[i] / op_sel_hi[i] pick the half of source i that feeds the
@@ -13,98 +12,8 @@ typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned
 // these modifiers (it emits v_xor + v_mov per complex multiply), so the three patterns that
 // need them are spelled out.  Plain VALU->VALU dependences are hardware-interlocked on gfx9.
 
-// a + (-i) b = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ v2 pk_add_mi(v2 a, v2 b) {
-    v2 r;
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-#else  // tests/emu: the same arithmetic in C
-    r = v2{a.x + b.y, a.y - b.x};
-#endif
-    return r;
-}
-// a + i b = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ v2 pk_add_pi(v2 a, v2 b) {
-    v2 r;
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-#else  // tests/emu: the same arithmetic in C
-    r = v2{a.x - b.y, a.y + b.x};
-#endif
-    return r;
-}
-// a + conj(b) = (a.x + b.x, a.y - b.y)
-__device__ __forceinline__ v2 pk_add_conj(v2 a, v2 b) {
-    v2 r;
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-#else  // tests/emu: the same arithmetic in C
-    r = v2{a.x + b.x, a.y - b.y};
-#endif
-    return r;
-}
-// a - conj(b) = (a.x - b.x, a.y + b.y)
-__device__ __forceinline__ v2 pk_sub_conj(v2 a, v2 b) {
-    v2 r;
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-#else  // tests/emu: the same arithmetic in C
-    r = v2{a.x - b.x, a.y + b.y};
-#endif
-    return r;
-}
-// complex product a * b
-// (both instructions in ONE asm statement: the compiler pads every inline-asm VALU result with an
-// s_nop before its first use -- it cannot see that the hardware interlocks the dependence)
-__device__ __forceinline__ v2 cmul(v2 a, v2 b) {
-    v2 t, r;
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                  // (ax bx, ax by)
-        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"              // (-ay by + ., ay bx + .)
-        : "=&v"(t), "=v"(r) : "v"(a), "v"(b));
-#else  // tests/emu: the same arithmetic in C
-    t = v2{a.x * b.x, a.x * b.y};
-    r = v2{__builtin_fmaf(-a.y, b.y, t.x), __builtin_fmaf(a.y, b.x, t.y)};
-#endif
-    return r;
-}
-// complex multiply-accumulate c + a * b: two packed fmas
-__device__ __forceinline__ v2 cfma(v2 a, v2 b, v2 c) {
-    v2 t, r;
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                          // (ax bx + cx, ax by + cy)
-        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"              // (-ay by + ., ay bx + .)
-        : "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(c));
-#else  // tests/emu: the same arithmetic in C
-    t = v2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.x, b.y, c.y)};
-    r = v2{__builtin_fmaf(-a.y, b.y, t.x), __builtin_fmaf(a.y, b.x, t.y)};
-#endif
-    return r;
-}
-// w * (-i d):  real = w.x d.y + w.y d.x,  imag = w.y d.y - w.x d.x
-__device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
-    v2 t, r;
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                  // (dy wx, dy wy)
-        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"              // (dx wy + ., -dx wx + .)
-        : "=&v"(t), "=v"(r) : "v"(d), "v"(w));
-#else  // tests/emu: the same arithmetic in C
-    t = v2{d.y * w.x, d.y * w.y};
-    r = v2{__builtin_fmaf(d.x, w.y, t.x), __builtin_fmaf(-d.x, w.x, t.y)};
-#endif
-    return r;
-}
-// (-i) a = (a.y, -a.x) as one multiply by the constant pair (1, -1)
-__device__ __forceinline__ v2 mul_mi(v2 a) {
-    v2 r;
-    const v2 c = {1.f, -1.f};
-#ifndef AFX_HOST_EMULATION
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(c));
-#else  // tests/emu: the same arithmetic in C
-    r = v2{a.y * c.x, a.x * c.y};
-#endif
-    return r;
-}
+// (the eight primitives themselves -- inline assembly -- live in afx_asm.h)
+#include <afx_asm.h>
 
 // forward 4-point DFT in place: (p0,p1,p2,p3) -> (X0,X1,X2,X3); 8 v_pk_add_f32
 __device__ __forceinline__ void dft4(v2 &p0, v2 &p1, v2 &p2, v2 &p3) {

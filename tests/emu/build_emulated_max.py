@@ -32,8 +32,8 @@ for u in UNITS:
         f.write('#include "hip/hip_runtime.h"\nnamespace {\nalignas(16) unsigned char smem[160 * 1024];\nalignas(16) unsigned char smem_raw[160 * 1024];\nalignas(16) float s[40 * 1024];\n}\n'
                 'static unsigned char *const afx_emu_lds = smem;\nstatic inline void afx_emu_ds() { emu::wave_barrier(); }\n'
                 f'#include "{E}/{u}_host.hip"\n')
-    jobs.append([CL + "++", "-std=c++17", "-O2", "-g", "-fPIC", "-Wno-unused", f"-I{ROOT}/tests/emu", *INC, "-c", f"{E}/emu_{u}.cpp", "-o", f"{E}/emu_{u}.o"])
-jobs.append([CL + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{ROOT}/tests/emu", *INC, "-c", f"{ROOT}/tests/emu/emu_engine.cpp", "-o", f"{E}/emu_engine.o"])
+    jobs.append([CL + "++", "-std=c++17", "-O2", "-g", "-fPIC", "-Wno-unused", f"-I{ROOT}/tests/emu", f"-I{ROOT}/tests/emu/hip", *INC, "-c", f"{E}/emu_{u}.cpp", "-o", f"{E}/emu_{u}.o"])
+jobs.append([CL + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{ROOT}/tests/emu", f"-I{ROOT}/tests/emu/hip", *INC, "-c", f"{ROOT}/tests/emu/emu_engine.cpp", "-o", f"{E}/emu_engine.o"])
 subprocess.run([sys.executable, f"{ROOT}/tests/hoststub/gen_stub.py", f"{hipdir}/afx_device.h", f"{E}/stub.c", "--functional-cqt"], check=True)
 stubsrc = open(f"{E}/stub.c").read()
 present = [n for n in sorted(renames) if re.search(r"\b" + n + r"\s*\(", stubsrc)]

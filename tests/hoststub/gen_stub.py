@@ -191,9 +191,31 @@ int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, 
     touch_read(Xt, 2 * L * chunks);
     touch_read(bankT, (long long)num * L);
     if (parts & AFX_CWT_WIDE) touch_write(scratchB, 2 * L * chunks * (d->order ? d->nWide : num), 0.f);
-    touch_write(outRe, (long long)chunks * num * d->dataLength, 1.f);
-    touch_write(outIm, (long long)chunks * num * d->dataLength, 2.f);
+    if (!d->order) { /* no execution order: every scale is in the wide part */
+        if (parts & AFX_CWT_WIDE) {
+            touch_write(outRe, (long long)chunks * num * d->dataLength, 1.f);
+            touch_write(outIm, (long long)chunks * num * d->dataLength, 2.f);
+        }
+        return AFX_OK;
+    }
+#ifdef AFX_STUB_DRY
+    (void)outRe; (void)outIm; /* dry mode: device addresses have no memory behind them (the order list included) */
     return AFX_OK;
+#else
+    /* the rows of the requested parts only (afx_device.h: [time-domain | two-pass | narrow-band classes]); the
+     * time-domain rows of the plain transform belong to afxk_cwt_td */
+    const int skip = (!isDet && d->td) ? d->nTd : 0;
+    int lo = num, hi = 0;
+    if (parts & AFX_CWT_WIDE) lo = skip, hi = d->nTd + d->nWide;
+    if (parts & AFX_CWT_NARROW) { if (lo > d->nTd + d->nWide) lo = d->nTd + d->nWide; hi = num; }
+    for (int c = 0; c < chunks; c++)
+        for (int i = lo; i < hi; i++) {
+            const long long at = ((long long)c * num + d->order[i]) * d->dataLength;
+            touch_write(outRe + at, d->dataLength, 1.f);
+            touch_write(outIm + at, d->dataLength, 2.f);
+        }
+    return AFX_OK;
+#endif
 }
 int afxk_cwt_small(const AfxCwtPlanDims *d, const float *tw, const float *x, long long xStride, int chunks,
                    const float *bankNatural, int num, int isDet, float *X, float *outRe, float *outIm, void *stream) {

@@ -2,8 +2,9 @@
 
 tests/emu/hip/hip_runtime.h emulates the slice of HIP / gfx950 the f16 CQT kernels and the bf16 GEMM use -- the MFMA
 operand / result layouts, DPP, readlane, raw buffer loads and stores with their bounds behaviour, LDS with the wave /
-workgroup rendezvous -- and the kernels' .hip files are included unchanged (their two inline-assembly helpers have a C
-twin under AFX_HOST_EMULATION; afx_cqt.hip's two static LDS arrays become host statics).  The library under test is
+workgroup rendezvous -- and the kernels' .hip files are included unchanged: their hand-issued instruction sequences all
+live in <afx_asm.h>, which resolves to tests/emu/hip/afx_asm.h (the same operations in C) in these builds and to
+audioflux_amd/csrc/hip/afx_asm.h (inline assembly) in the product; afx_cqt.hip's two static LDS arrays become host statics.  The library under test is
 the C host code + the real launchers of those files + their kernels, emulated: every launch of the CQT path.
 
   * the shipped kernels -- the headline k_stft_mel_v2 (BASELINE cfg 1: mel 1.8e-7, MFCC 2.0e-7 of the golden vectors, the
@@ -27,10 +28,10 @@ STUB = os.path.join(ROOT, "tests", "hoststub")
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
 INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
 
-STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
+STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cwt_td", "afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
                                                      "afxk_melfused_destroy", "afxk_melfused_kind")]
 
-EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
+EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "cwt_emulated_td", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
              "mel_emulated_melfused1k", "mel_emulated_melfused4k")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
@@ -61,9 +62,9 @@ def emulated(tmp_path_factory):
     # (the stand-in's own versions of the launchers that the emulated translation units bring step aside)
     jobs.append(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", *STANDIN_RENAMES, *INC, "-c", stub, "-o", os.path.join(tmp, "stub.o")])
     for f in EMU_UNITS:
-        jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o",
+        jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", f"-I{EMU}/hip", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o",
                      os.path.join(tmp, f + ".o")])
-    jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
+    jobs.append([CLANG + "++", "-std=c++17", "-O2", "-g", "-fPIC", f"-I{EMU}", f"-I{EMU}/hip", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
                  os.path.join(tmp, "cqt_emulated_main.o")])
     with ThreadPoolExecutor(8) as ex:
         for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
@@ -129,6 +130,16 @@ def test_f32_matrix_core_octave_kernels_emulated(emulated):
     assert n["octave_f32"] == 14 and n["octave_f16"] == 0, n
 
 
+def test_time_domain_cwt_kernel_emulated(emulated):
+    """k_cwt_td (round 3, afx_cwt_td.hip): the host plan (double IFFT of the bank rows, truncation, pairing, f16 images),
+    the launcher (two kernel classes, exact workgroup shares) and the device code -- window fetch with the reflect / wrap
+    index map at the chunk edges, the (hi, lo) split, the K loop, the transposed epilogue -- on BASELINE cfg 4's plan,
+    padded and circular, a speech clip and a -80 dB level step: every row the plan owns within 5e-6 of the reference
+    (on the MI355X: 4e-7 on the bench clip)"""
+    out = _run(emulated, "emulated_cwt_td.py", [])
+    assert out.count("time-domain rows") == 2, out[-800:]
+
+
 def test_bf16x3_gemm_emulated_matches_float64(emulated):
     """k_gemm_nt128_bf16x3: loader / three-word split / 24 MFMAs per k-step / epilogue with every
     tail, elementwise against float64 on operands spanning ten decades"""
@@ -160,10 +171,10 @@ def emulated_tsan(tmp_path_factory):
     for d in ("driver_emu_small", "driver_emu_gemm", "driver_emu_bft"):
         jobs.append([CLANG, "-std=gnu11", *san, *INC, "-c", os.path.join(EMU, d + ".c"), "-o", os.path.join(tmp, d + ".drv")])
     for f in EMU_UNITS:
-        jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o", os.path.join(tmp, f + ".o")])
-    jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
+        jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", f"-I{EMU}/hip", *INC, "-c", os.path.join(EMU, f + ".cpp"), "-o", os.path.join(tmp, f + ".o")])
+    jobs.append([CLANG + "++", "-std=c++17", *san, f"-I{EMU}", f"-I{EMU}/hip", *INC, "-c", os.path.join(tmp, "cqt_emulated_main.cpp"), "-o",
                  os.path.join(tmp, "cqt_emulated_main.o")])
-    jobs.append([CLANG + "++", "-std=c++17", *san, "-DAFX_EMU_NO_LDS_ORDER", f"-I{EMU}", *INC, "-c", os.path.join(EMU, "cqt_emulated_f16.cpp"),
+    jobs.append([CLANG + "++", "-std=c++17", *san, "-DAFX_EMU_NO_LDS_ORDER", f"-I{EMU}", f"-I{EMU}/hip", *INC, "-c", os.path.join(EMU, "cqt_emulated_f16.cpp"),
                  "-o", os.path.join(tmp, "cqt_emulated_f16.neg")])
     with ThreadPoolExecutor(8) as ex:
         for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
