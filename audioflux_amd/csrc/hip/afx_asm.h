@@ -11,16 +11,22 @@
 typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
 
 // ---- packed-f32 complex primitives -------------------------------------------------------
+// The two quarter-turn adds are written as v_pk_fma_f32 with the constant 1.0 -- NOT as v_pk_add_f32 with an op_sel
+// half swap (the form they had until round 3): on gfx950 that form returns wrong sums in lanes 48-63 of a wave
+// while another wave of the CU streams v_mfma + ds_read_b128 back to back (measured: tools/micro/mfma_corun.hip,
+// profiles/r03_pk_add_opsel.txt; alone, or beside VALU-only / LDS-only kernels, it is exact).  v_pk_fma_f32 and
+// v_pk_mul_f32 with the same swap are not affected, the compiler never emits the swap on v_pk_add_f32, and the
+// product with 1.0 is exact: same bits, same issue cost.
 // a + (-i) b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ v2 pk_add_mi(v2 a, v2 b) {
     v2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 // a + i b = (a.x - b.y, a.y + b.x)
 __device__ __forceinline__ v2 pk_add_pi(v2 a, v2 b) {
     v2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 // a + conj(b) = (a.x + b.x, a.y - b.y)

@@ -226,7 +226,7 @@ extern "C" int afxdev_stream_create(void **stream) {
 // events come from a small per-thread, per-device ring instead of a create / destroy pair per call (a wait
 // captures the record that precedes it, so an event may be recorded again while an earlier wait is pending).
 #ifndef AFX_EVENT_RING
-#define AFX_EVENT_RING 16  /* (> the waits of one batched call: a slot is never re-recorded within a call) */
+#define AFX_EVENT_RING 16  /* (a wait is bound to the record that precedes it at enqueue time: re-recording a slot later is harmless) */
 #endif
 namespace {
 struct EventRing {

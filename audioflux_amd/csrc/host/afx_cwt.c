@@ -33,7 +33,7 @@ struct OpaqueCWT {
     AfxCwtPlanDims dims;
     void *stream;
     void *stream2;           /* side stream of the batched device call: narrow-band scales */
-    void *chain[3];          /* side streams of the extra two-pass chains */
+    void *chain[3];          /* side streams: [0], [1] extra two-pass chains, [2] the time-domain scales */
     float *dTw, *dBankT, *dBankDetT;
     float *dX, *dA, *dXt, *dB, *dOut; /* scratch of the one-chunk calls */
     float *dFastTw;          /* twiddle tables of the register-FFT kernels (L = 2^17) */
@@ -913,19 +913,21 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * pass 22.6 us per chunk at group 1, 32 us at group 4); with the 40 wide scales the
      * narrow-band plan leaves: 2 chunks (+9 %, profiles/r01_cwt_narrowband.txt); 16 chunks at
      * the wrapper's default L = 2^13 (otherwise launch-bound). */
-    /* the short-kernel scales of the plain transform run in the time domain (afx_cwt_td.hip) -- from the signal, not
-     * from the spectrum: all chunks of the call at once on a side stream of their own, joined at the end */
     /* The short-kernel scales of the plain transform run in the time domain (afx_cwt_td.hip) -- from the signal, not
-     * from the spectrum: all chunks of the call at once, on the caller's stream AHEAD of the forward transform.
-     * Not beside it: with the time-domain launches on side streams (one or two; or on the second chain's stream)
-     * the step measured 32.0-32.8 k chunks/s against 29.9 k here, but rows of the FFT-path kernels that ran at the
-     * same time (two-pass scales, the first narrow-band class) then came out timing-dependent -- wrong by up to
-     * 30 % in 16-column tiles, different from run to run -- while the time-domain rows stayed bit-identical and the
-     * time-domain kernel alone writes nothing outside its rows (profiles/r03_cwt_td_schedules.txt).  Root cause not
-     * found in round 3; a schedule that never overlaps the two is bit-reproducible (ring test, 7000 chunks). */
+     * from the spectrum: all chunks of the call at once on a side stream of their own, beside the forward transforms
+     * and the FFT-path scales (they write disjoint rows), joined before the call returns.  (Until the packed adds of
+     * afx_asm.h were rewritten this overlap left wrong 16-sample pieces in the FFT-path rows: v_pk_add_f32 with an
+     * op_sel half swap misbehaves beside a wave that streams v_mfma + ds_read_b128 -- DESIGN.md section 4.3,
+     * profiles/r03_pk_add_opsel.txt; with v_pk_fma_f32 in its place every schedule is bit-reproducible.) */
     const int useTd = !isDet && o->dims.nTd > 0;
-    if (st == AFX_OK && useTd) /* (its two kernel classes side by side on two streams: no gain, 31.5 vs 31.5 k chunks/s) */
-        st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, hipStream, NULL);
+    void *tds = NULL;
+    if (st == AFX_OK && useTd) {
+        if (!o->chain[2]) st = afxdev_stream_create(&o->chain[2]);
+        tds = o->chain[2];
+        if (st == AFX_OK) st = afxdev_stream_wait_stream(tds, hipStream);
+        if (st == AFX_OK)
+            st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, tds, NULL);
+    }
     const int nTwoPass = o->dims.order ? o->dims.nWide + (useTd ? 0 : o->dims.nTd) : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
     const int overlap = 1; /* (round 2: the three-chain schedule below is +10 % over one stream) */
@@ -995,6 +997,7 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
                                   hipStream);
         if (st == AFX_OK && side) st = afxdev_stream_wait_stream(hipStream, side);
     }
+    if (st == AFX_OK && tds) st = afxdev_stream_wait_stream(hipStream, tds);
     o->lastStream = hipStream;
     o->lastUsed = 1;
 

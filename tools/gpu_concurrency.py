@@ -167,6 +167,9 @@ def main():
 
     Job.others = [fft, fft2, td, td2, full, full2]
     res = {}
+    if len(sys.argv) > 2 and sys.argv[2] == "co":
+        Job.explain = 0
+    res["fft|td"] = pair(fft, td)
     res["full|full"] = pair(full, full2, reps=2)
     res["full|fft"] = pair(full, fft, reps=2)
     res["full|td"] = pair(full, td, reps=2)
