@@ -1,0 +1,51 @@
+"""Objects on different streams must not change each other's results.
+
+Round 3: the packed-f32 butterflies (afx_asm.h pk_add_mi / pk_add_pi, then v_pk_add_f32 with an op_sel half swap)
+returned wrong sums in lanes 48-63 whenever a kernel that streams v_mfma + ds_read_b128 (the time-domain CWT kernel,
+the CQT f16 octave kernels) really ran beside them -- between two objects on two streams, or inside one batched CWT
+call with its time-domain scales on a side stream (profiles/r03_pk_add_opsel.txt).  The probes run in a child
+process with 8 HIP hardware queues, so that the streams do not share (and serialise on) one queue."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _child(args, timeout=300):
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    res = subprocess.run(args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    return res.returncode, res.stdout.decode(errors="replace")
+
+
+@pytest.mark.parametrize("partner", ["full", "seq", "cqt", "mel"])
+def test_fft_path_cwt_is_bitwise_stable_beside_other_kernels(partner):
+    """an FFT-path-only CWT object (48 low scales) on one stream, `partner` on another: every output bit equals the
+    solo run's (partner full: an 84-scale CWT object incl. its time-domain kernel; seq: time-domain-only object then
+    FFT-only object on one stream; cqt: the CQT + chroma call; mel: the fused mel + MFCC call)"""
+    rc, out = _child([sys.executable, os.path.join("tools", "gpu_concurrency2.py"), partner, "48"])
+    assert rc == 0, out[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("RESULT")]
+    assert lines and lines[-1].rstrip().endswith("wrong elements 0"), out[-2000:]
+
+
+def test_packed_adds_of_afx_asm_are_exact_beside_mfma_and_lds_traffic(tmp_path):
+    """tools/micro/mfma_corun.hip: dft16 / cmul / the quarter-turn adds as shipped, beside back-to-back
+    v_mfma + ds_read_b128 partners, compared bitwise with their solo runs (needs hipcc on the box)"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    exe = str(tmp_path / "mfma_corun")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "audioflux_amd", "csrc", "hip"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "micro", "mfma_corun.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    rc, out = _child([exe])
+    assert rc == 0, out[-2000:]
+    shipped = [ln for ln in out.splitlines() if ln.startswith("victim [shipped:")]
+    assert len(shipped) >= 40
+    bad = [ln for ln in shipped if "]: 0 wrong words" not in ln]
+    assert not bad, "\n".join(bad)

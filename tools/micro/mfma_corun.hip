@@ -323,29 +323,29 @@ int main() {
 #define PAIRV(M, NAME) {NAME, 2, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_pairs<M>, dim3(vb), dim3(256), 0, s, (float2 *)o, 4000); }}
 #define FORMV(M, NAME) {NAME, 2, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_forms<M>, dim3(vb), dim3(256), 0, s, (float2 *)o, 4000); }}
     const Victim victims[] = {
-        FORMV(1, "form: pk_add_mi / pk_add_pi of afx_asm.h as shipped (v_pk_fma_f32 with 1.0, swapped src0, neg)"),
-        FORMV(11, "form: v_pk_add_f32 swap + neg (afx_asm.h until round 3)"),
+        FORMV(1, "shipped: pk_add_mi / pk_add_pi of afx_asm.h (v_pk_fma_f32 with 1.0, swapped src0, neg)"),
+        FORMV(11, "form: v_pk_add_f32 swap + neg (pk_add_mi / pk_add_pi until round 3)"),
         FORMV(2, "form: v_pk_add_f32 swap only"),
         FORMV(3, "form: v_pk_add_f32 neg only"),
         FORMV(4, "form: v_pk_add_f32 no modifier"),
         FORMV(5, "form: v_pk_add_f32 swap + neg, early-clobber destination"),
         FORMV(6, "form: v_pk_fma_f32 with (1,-1) constant pair, swapped src0"),
-        FORMV(8, "form: v_pk_mul_f32 swap (mul_mi)"),
+        FORMV(8, "shipped: mul_mi of afx_asm.h (v_pk_mul_f32 with the swap)"),
         FORMV(9, "form: v_add_f32 + v_sub_f32"),
         FORMV(10, "form: compiler-generated (a.x + b.y, a.y - b.x)"),
         PAIRV(0, "asm: v_mul_f32 -> v_fma_f32 adjacent (scalar f32)"),
         PAIRV(1, "asm: v_pk_mul_f32 -> v_pk_fma_f32 adjacent, straight selects"),
-        PAIRV(2, "asm: cmul of afx_asm.h (adjacent, cross-half op_sel)"),
+        PAIRV(2, "shipped: cmul of afx_asm.h (adjacent, cross-half op_sel)"),
         PAIRV(3, "asm: cmul with s_nop 0 between"),
         PAIRV(4, "asm: cmul with s_nop 1 between"),
-        PAIRV(5, "asm: single-instruction statements (pk_add_mi / pk_add_pi), compiler-padded"),
+        PAIRV(5, "shipped: pk_add_mi / pk_add_pi chains, one statement each (compiler-padded)"),
         PAIRV(6, "compiler: serial v_fma_f32 chain"),
         PAIRV(7, "compiler: serial float2 fma chain"),
         PAIRV(8, "asm: two cmuls interleaved (dependent instructions two apart)"),
         {"scalar f32 fma chains (compiler)", 1, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_plain, dim3(vb), dim3(256), 0, s, (float *)o, 3000); }},
         {"float2 arithmetic (compiler-chosen v_pk_*)", 2, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_float2, dim3(vb), dim3(256), 0, s, (float2 *)o, 1500); }},
-        {"dft16 + cmul (afx_asm.h packed-f32 helpers), registers only", 2, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_dft16<false>, dim3(vb), dim3(256), 0, s, (float2 *)o, 400); }},
-        {"dft16 + cmul + LDS exchange", 2, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_dft16<true>, dim3(vb), dim3(256), 0, s, (float2 *)o, 300); }},
+        {"shipped: dft16 + cmul (afx_pkmath.h), registers only", 2, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_dft16<false>, dim3(vb), dim3(256), 0, s, (float2 *)o, 400); }},
+        {"shipped: dft16 + cmul + LDS exchange", 2, [](hipStream_t s, void *o, int vb) { hipLaunchKernelGGL(v_dft16<true>, dim3(vb), dim3(256), 0, s, (float2 *)o, 300); }},
     };
     struct Partner {
         const char *name;
