@@ -456,6 +456,94 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
                    outIm + ((long long)blockIdx.z * g.num + j) * D);
 }
 
+// Scales whose support spans 17 ... 32 rows: the same kernel with the R-term sum taken in two blocks of rows
+// (16, then R2 = 4 / 8 / 16) through the one staging buffer -- such a scale has neither a short time kernel (it is
+// not a candidate of afx_cwt_td.hip) nor a band narrow enough for the single-block kernel, and its row pass +
+// 1 MB intermediate + column pass cost 2.7 x what the R-term sums cost here (profiles/r03_cwt_nb2.txt).
+template <int R2>
+__global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const float2 *__restrict__ Xt,
+                                                             const float *__restrict__ bankT, int isDet,
+                                                             int listBase, float *__restrict__ outRe,
+                                                             float *__restrict__ outIm) {
+    constexpr int R = 16;
+    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]; before that the staged products of one block of rows
+    v2 *zs = ex;
+    __shared__ v2 tlo[256], thi[512];  // W_L^m (m < 256), W_L^(256 q) (q < 512)
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
+    const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
+    const int c0 = blockIdx.x * 16, m1 = c0 + c;
+    const int2 jl = reinterpret_cast<const int2 *>(g.orderLo)[listBase + blockIdx.y];
+    const int j = jl.x;
+    int lo = jl.y;
+    if (lo + R + R2 > L2) lo = L2 - R - R2;
+    const float2 *xc = Xt + (long long)blockIdx.z * L + lo;
+    const float *bankj = bankT + (long long)j * L + lo;
+    float2 xv[R], t3[16];
+    float bw[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int idx = tid + 256 * i, k2 = idx & (R - 1), k1 = idx / R;
+        xv[i] = xc[k1 * L2 + k2];
+        bw[i] = bankj[k1 * L2 + k2];
+    }
+    const float2 ta = g.tw[256 * tid], tb = g.tw[tid];
+    cols256_twiddles(g, gq, t3);
+    __builtin_amdgcn_sched_barrier(0);
+    thi[tid] = v2{ta.x, ta.y};
+    thi[tid + 256] = v2{-ta.x, -ta.y};
+    tlo[tid] = v2{tb.x, tb.y};
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        zs[tid + 256 * i] = isDet ? v2{-bw[i] * xv[i].y, -(bw[i] * xv[i].x)} : v2{bw[i] * xv[i].x, -(bw[i] * xv[i].y)};
+    // second block of rows: requested now, staged once the first block's sums are taken
+    float2 xw[R2];
+    float bv[R2];
+#pragma unroll
+    for (int i = 0; i < R2; ++i) {
+        const int idx = tid + 256 * i, k2 = idx & (R2 - 1), k1 = idx / R2;
+        xw[i] = xc[k1 * L2 + R + k2];
+        bv[i] = bankj[k1 * L2 + R + k2];
+    }
+    __syncthreads();
+    v2 acc[16];
+    {
+        v2 w5[R];
+#pragma unroll
+        for (int k2 = 0; k2 < R; ++k2) w5[k2] = thi[((lo + k2) * m1) & (L2 - 1)];  // W_512^((lo + k2) m1)
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const v2 *z = zs + (16 * a + gq) * R;
+            acc[a] = cmul(z[0], w5[0]);
+#pragma unroll
+            for (int k2 = 1; k2 < R; ++k2) acc[a] = cfma(z[k2], w5[k2], acc[a]);
+        }
+    }
+    __syncthreads();  // every thread is done with the first block
+#pragma unroll
+    for (int i = 0; i < R2; ++i)
+        zs[tid + 256 * i] = isDet ? v2{-bv[i] * xw[i].y, -(bv[i] * xw[i].x)} : v2{bv[i] * xw[i].x, -(bv[i] * xw[i].y)};
+    __syncthreads();
+    v2 r[16];
+    {
+        v2 w5[R2];
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) w5[k2] = thi[((lo + R + k2) * m1) & (L2 - 1)];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const v2 *z = zs + (16 * a + gq) * R2;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) acc[a] = cfma(z[k2], w5[k2], acc[a]);
+            const int m = m1 * (16 * a + gq);  // four-step twiddle W_L^(m1 k1), m1 k1 < L
+            r[a] = cmul(acc[a], cmul(tlo[m & 255], thi[m >> 8]));
+        }
+    }
+    __syncthreads();  // every thread is done with zs before the exchange buffer is written
+    const long long D = g.dataLength;
+    cols256_finish(g, r, t3, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
+                   outIm + ((long long)blockIdx.z * g.num + j) * D);
+}
+
 // ---- transforms that fit one CU's LDS (L <= 16384: the reference wrapper's default sizes) ----
 // No four-step split, no HBM intermediate: the forward kernel transforms one reflect-padded chunk
 // per workgroup into the natural-order spectrum X[chunk][k]; the inverse kernel takes one
@@ -631,6 +719,24 @@ extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const 
                 hipLaunchKernelGGL(k_cwt_inv_cols256_nb<16>, dim3(L2 / 16, d->nNarrow[3], chunks), dim3(256), 0, s,
                                    g, Xt2, bankT, isDet, base, outRe, outIm);
                 AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb<16>");
+            }
+            base += d->nNarrow[3];
+            if (d->nNarrow[4] > 0) {
+                hipLaunchKernelGGL(k_cwt_inv_cols256_nb2<4>, dim3(L2 / 16, d->nNarrow[4], chunks), dim3(256), 0, s,
+                                   g, Xt2, bankT, isDet, base, outRe, outIm);
+                AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb2<4>");
+            }
+            base += d->nNarrow[4];
+            if (d->nNarrow[5] > 0) {
+                hipLaunchKernelGGL(k_cwt_inv_cols256_nb2<8>, dim3(L2 / 16, d->nNarrow[5], chunks), dim3(256), 0, s,
+                                   g, Xt2, bankT, isDet, base, outRe, outIm);
+                AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb2<8>");
+            }
+            base += d->nNarrow[5];
+            if (d->nNarrow[6] > 0) {
+                hipLaunchKernelGGL(k_cwt_inv_cols256_nb2<16>, dim3(L2 / 16, d->nNarrow[6], chunks), dim3(256), 0, s,
+                                   g, Xt2, bankT, isDet, base, outRe, outIm);
+                AFX_LAUNCH_CHECK("k_cwt_inv_cols256_nb2<16>");
             }
         }
         return AFX_OK;

@@ -202,11 +202,12 @@ typedef struct {
      * k2 of the transposed spectrum needs no row pass and no intermediate -- the column kernel
      * forms its operands from the spectrum directly (k_cwt_inv_cols256_nb).
      * order: device [num] scale indices, the nWide wide scales first, then the scales of the
-     * classes R = 2, 4, 8, 16 (nNarrow[0..3] of them); NULL: every scale takes both passes */
+     * classes R = 2, 4, 8, 16 (nNarrow[0..3] of them) and the two-block classes R = 20, 24, 32 (nNarrow[4..6]);
+     * NULL: every scale takes both passes */
     const int *order;
     const int *orderLo;  /* device [num][2]: (order[i], support[2 order[i]]) -- one read per workgroup */
     int nWide;
-    int nNarrow[4];
+    int nNarrow[7];
     int nTd;                 /* > 0: the FIRST nTd entries of `order` run the time-domain kernel (afx_cwt_td.hip),
                               * the nWide two-pass scales and the narrow-band classes follow */
     const struct AfxCwtTdPlan_ *td;

@@ -719,7 +719,7 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
                 o->dims.support = o->dSupport;
                 /* narrow-band scales (<= maxR rows of the transposed spectrum hold every
                  * non-zero) skip the row pass: list the wide scales first, then the classes
-                 * R = 2, 4, 8, 16 (afx_device.h).  AFX_CWT_NARROW_MAX bounds the widest class used
+                 * R = 2, 4, 8, 16, 20, 24, 32 (afx_device.h).  AFX_CWT_NARROW_MAX bounds the widest class used
                  * (0: every scale takes both passes). */
                 int *order = (int *)malloc(sizeof(int) * (size_t)num);
                 const char *em = getenv("AFX_CWT_NARROW_MAX");
@@ -799,18 +799,18 @@ void afx_cwt_support_host(const float *bank, int num, long long fftLength, int r
 }
 
 /* Execution order of the scales in the register-FFT inverse (afx_device.h): scales whose support
- * spans more than maxR rows ("wide": row pass + column pass) first, then the narrow-band classes
- * R = 2, 4, 8, 16 (support width <= R, > R/2), each in ascending scale order.  maxR is clamped
- * to 16; maxR < 2 makes every scale wide. */
-void afx_cwt_classify_host(const int *sup, int num, int maxR, int *order, int *nWide, int nNarrow[4]) {
-    if (maxR > 16) maxR = 16;
+ * spans more than maxR rows ("wide": row pass + column pass, or the time-domain kernel) first, then the
+ * narrow-band classes R = 2, 4, 8, 16 (support width <= R, > R/2) and the two-block classes R = 20, 24, 32, each
+ * in ascending scale order.  maxR is clamped to 32; maxR < 2 makes every scale wide. */
+void afx_cwt_classify_host(const int *sup, int num, int maxR, int *order, int *nWide, int nNarrow[7]) {
+    if (maxR > 32) maxR = 32;
     int q = 0;
-    for (int cls = -1; cls < 4; cls++) {
+    for (int cls = -1; cls < 7; cls++) {
         int n = 0;
         for (int i = 0; i < num; i++) {
             const int w = sup[2 * i + 1] - sup[2 * i];
             int c = -1;
-            if (w <= maxR && maxR >= 2) c = w <= 2 ? 0 : w <= 4 ? 1 : w <= 8 ? 2 : 3;
+            if (w <= maxR && maxR >= 2) c = w <= 2 ? 0 : w <= 4 ? 1 : w <= 8 ? 2 : w <= 16 ? 3 : w <= 20 ? 4 : w <= 24 ? 5 : 6;
             if (c == cls) order[q++] = i, n++;
         }
         if (cls < 0) *nWide = n;

@@ -83,12 +83,14 @@ int afx_cwt_create_custom(struct OpaqueCWT **cwtObj, int num, int radix2Exp, int
 long long afx_cwt_fft_length(int radix2Exp, int isPadding);
 /* narrow-band scale planning of the register-FFT inverse (host-only, exported for tests):
  * rows k2 of the transposed spectrum (k = k1 + 2^r1 k2) that hold each wavelet's non-zeros, and
- * the execution order wide scales | classes R = 2, 4, 8, 16 (see afx_device.h) */
+ * the execution order wide scales | classes R = 2, 4, 8, 16 | two-block classes R = 20, 24, 32 (see afx_device.h) */
 void afx_cwt_support_host(const float *bank, int num, long long fftLength, int r1, int *sup);
-void afx_cwt_classify_host(const int *sup, int num, int maxR, int *order, int *nWide, int nNarrow[4]);
+void afx_cwt_classify_host(const int *sup, int num, int maxR, int *order, int *nWide, int nNarrow[7]);
 /* widest narrow-band class used unless AFX_CWT_NARROW_MAX says otherwise (0: every scale takes
- * both passes); 16 measured best on BASELINE cfg 4 (profiles/r01_cwt_narrowband.txt) */
-#define AFX_CWT_NARROW_MAX_DEFAULT 16
+ * both passes).  BASELINE cfg 4, round 3 (profiles/r03_cwt_nb2.txt): 20 -- the four scales of 17 ... 20 rows that
+ * are too long for the time-domain kernel -- 34.5 k chunks/s; 16: 33.2 k; 24 / 32 take scales away from the
+ * time-domain kernel, which is the cheaper one for them: 32.9 k / 30.2 k */
+#define AFX_CWT_NARROW_MAX_DEFAULT 20
 
 /* ---- afx_bandplan.c ----------------------------------------------------- */
 struct AfxBandPlanTag; /* AfxBandPlan is declared in afx_device.h */

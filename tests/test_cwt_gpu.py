@@ -48,7 +48,7 @@ def test_cwt_linearity_and_reuse():
     assert o.cwt(a[:1000]).shape == (30, 2048) and o.cwt(np.concatenate([a, b])).shape == (30, 2048)
 
 
-@pytest.mark.parametrize("max_r", [2, 4, 8, 16])
+@pytest.mark.parametrize("max_r", [2, 4, 8, 16, 20, 24, 32])
 def test_cwt_narrow_band_scales_equal_two_pass(max_r, monkeypatch):
     """L = 2^17 (BASELINE cfg 4): scales whose wavelet occupies <= max_r rows of the transposed
     spectrum skip the row pass (k_cwt_inv_cols256_nb); every scale must agree with the two-pass

@@ -55,14 +55,17 @@ def _bank(num, r, sr, wavelet, lo, pad=True):
     return m
 
 
+CLASS_ROWS = (2, 4, 8, 16, 20, 24, 32)
+
+
 def _classify(sup, max_r):
     N = af.get_lib()
     num = len(sup) // 2
     order = np.full(num, -1, np.int32)
     n_wide = C.c_int(-1)
-    n_narrow = (C.c_int * 4)(-1, -1, -1, -1)
+    n_narrow = (C.c_int * 7)(*([-1] * 7))
     N.afx_cwt_classify_host.restype = None
-    N.afx_cwt_classify_host.argtypes = [ip, C.c_int, C.c_int, ip, ip, C.c_int * 4]
+    N.afx_cwt_classify_host.argtypes = [ip, C.c_int, C.c_int, ip, ip, C.c_int * 7]
     N.afx_cwt_classify_host(sup.ctypes.data_as(ip), num, max_r, order.ctypes.data_as(ip), C.byref(n_wide), n_narrow)
     return order, n_wide.value, list(n_narrow)
 
@@ -84,20 +87,21 @@ def test_narrow_band_scale_plan_cfg4():
     width = sup[1::2] - sup[0::2]
     # rows run from the highest centre frequency down: supports shrink monotonically
     assert np.all(np.diff(width) <= 0) and width[-1] <= 2 < width[0]
-    for max_r in (0, 1, 2, 4, 8, 16, 64):
+    for max_r in (0, 1, 2, 4, 8, 16, 20, 24, 32, 64):
         order, n_wide, n_narrow = _classify(sup, max_r)
         assert sorted(order.tolist()) == list(range(num))
         assert n_wide + sum(n_narrow) == num
-        eff = min(max_r, 16) if max_r >= 2 else 0
+        eff = min(max_r, 32) if max_r >= 2 else 0
         assert np.all(width[order[:n_wide]] > eff)
         base = n_wide
-        for cls, n in enumerate(n_narrow):
+        for cls, n in enumerate(n_narrow):  # classes R = 2, 4, 8, 16 and the two-block classes 20, 24, 32
             w = width[order[base:base + n]]
-            assert np.all(w <= (2 << cls)) and np.all(w <= eff)
+            assert np.all(w <= CLASS_ROWS[cls]) and np.all(w <= eff)
             if cls:
-                assert np.all(w > (1 << cls))
+                assert np.all(w > CLASS_ROWS[cls - 1])
             assert np.all(np.diff(order[base:base + n]) > 0)
             base += n
+    assert _classify(sup, 32)[2][4:] == [4, 3, 5]  # widths 17-20 (scales 36-39), 21-24, 25-32
     assert _classify(sup, 0)[1] == num and _classify(sup, 8)[1] < num
 
 
@@ -123,6 +127,6 @@ def test_narrow_band_plan_every_family(wavelet):
         if pos < n_wide:
             continue
         cls = int(np.searchsorted(np.cumsum(n_narrow), pos - n_wide, side="right"))
-        lo = min(int(sup[2 * i]), 512 - (2 << cls))
-        inside = ((k >> 8) >= lo) & ((k >> 8) < lo + (2 << cls))
+        lo = min(int(sup[2 * i]), 512 - CLASS_ROWS[cls])
+        inside = ((k >> 8) >= lo) & ((k >> 8) < lo + CLASS_ROWS[cls])
         assert not bank[i][~inside].any()
