@@ -11,12 +11,18 @@
 typedef float v2 __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
 
 // ---- packed-f32 complex primitives -------------------------------------------------------
-// The two quarter-turn adds are written as v_pk_fma_f32 with the constant 1.0 -- NOT as v_pk_add_f32 with an op_sel
-// half swap (the form they had until round 3): on gfx950 that form returns wrong sums in lanes 48-63 of a wave
-// while another wave of the CU streams v_mfma + ds_read_b128 back to back (measured: tools/micro/mfma_corun.hip,
-// profiles/r03_pk_add_opsel.txt; alone, or beside VALU-only / LDS-only kernels, it is exact).  v_pk_fma_f32 and
-// v_pk_mul_f32 with the same swap are not affected, the compiler never emits the swap on v_pk_add_f32, and the
-// product with 1.0 is exact: same bits, same issue cost.
+// RULE for every packed-f32 instruction in this library (hand-written here or compiler-generated):
+//     never op_sel[0] = 0 together with op_sel[1] = 1
+// i.e. the LOW result lane must not take src0's low half and src1's HIGH half.  On gfx950 such an instruction
+// (v_pk_add_f32, v_pk_mul_f32 and v_pk_fma_f32 alike; whatever op_sel_hi and neg say) returns wrong values in lanes
+// 48-63 of a wave while another wave of the CU streams v_mfma + ds_read_b128 back to back; alone, or beside VALU-only
+// or LDS-only kernels, it is exact -- which is why no single-stream test ever saw it.  Every other select pattern
+// (src0 swapped or broadcast, src1 low broadcast, both swapped) is exact under the same co-runner.  Measured:
+// tools/micro/pk_forms_corun.hip, tools/micro/mfma_corun.hip, profiles/r03_pk_add_opsel.txt.  Commutative operands are
+// therefore ordered so that the half-swapped one is src0 (the quarter-turn adds below became v_pk_fma_f32 with the
+// constant 1.0 for that: the product is exact, same bits, same issue cost), the library is built with
+// -fno-slp-vectorize (the SLP vectoriser forms such instructions from scalar code), and tests/test_isa_forms.py
+// disassembles the shipped code objects and fails on any instruction that breaks the rule.
 // a + (-i) b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ v2 pk_add_mi(v2 a, v2 b) {
     v2 r;
@@ -63,8 +69,14 @@ __device__ __forceinline__ v2 cfma(v2 a, v2 b, v2 c) {
 __device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
     v2 t, r;
     asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                  // (dy wx, dy wy)
-        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"              // (dx wy + ., -dx wx + .)
-        : "=&v"(t), "=v"(r) : "v"(d), "v"(w));
+        "v_pk_fma_f32 %1, %3, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]"              // (wy dx + ., -wx dx + .)
+        : "=&v"(t), "=v"(r) : "v"(d), "v"(w));  // (the swapped factor is src0: see the rule above)
+    return r;
+}
+// a.x + a.y as ONE scalar add (the compiler's own form is v_pk_add_f32 a, a with a half swap: see the rule above)
+__device__ __forceinline__ float hsum(v2 a) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a.x), "v"(a.y));
     return r;
 }
 // (-i) a = (a.y, -a.x) as one multiply by the constant pair (1, -1)

@@ -336,8 +336,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k(KArgs a) {
                     }
                 }
             }
-            accA = sA.x + sA.y;
-            accB = sB.x + sB.y;
+            accA = hsum(sA);
+            accB = hsum(sB);
         }
         if (!CPLX && !SPLIT && a.postPow) {
             accA = powf(accA, a.normValue);

@@ -55,6 +55,8 @@ __device__ __forceinline__ v2 cmul_mi(v2 d, v2 w) {
     r = v2{__builtin_fmaf(d.x, w.y, t.x), __builtin_fmaf(-d.x, w.x, t.y)};
     return r;
 }
+// a.x + a.y
+__device__ __forceinline__ float hsum(v2 a) { return a.x + a.y; }
 // (-i) a = (a.y, -a.x) as one multiply by the constant pair (1, -1)
 __device__ __forceinline__ v2 mul_mi(v2 a) {
     v2 r;

@@ -49,3 +49,35 @@ def test_packed_adds_of_afx_asm_are_exact_beside_mfma_and_lds_traffic(tmp_path):
     assert len(shipped) >= 40
     bad = [ln for ln in shipped if "]: 0 wrong words" not in ln]
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("victim", ["mel", "stft", "ceps", "cqt", "cwt", "spec"])
+def test_every_family_is_bitwise_stable_beside_matrix_core_kernels(victim):
+    """tools/gpu_concurrency3.py: the family's batched device call on one stream, a full CWT object / the CQT + chroma
+    call on another; every output bit equals the solo run's (before the operand-select rule of afx_asm.h was enforced
+    on compiler-generated code too, the STFT and cepstrogram wave kernels failed this beside the CWT)"""
+    rc, out = _child([sys.executable, os.path.join("tools", "gpu_concurrency3.py"), victim])
+    assert rc == 0, out[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("RESULT")]
+    assert len(lines) == 2 and all(ln.split("wrong elements ")[1].startswith("0 ") for ln in lines), out[-2000:]
+
+
+def test_operand_select_rule_on_the_device(tmp_path):
+    """tools/micro/pk_forms_corun.hip: every packed-f32 form that keeps the rule of afx_asm.h (not op_sel[0] = 0 with
+    op_sel[1] = 1) is exact beside the v_mfma + ds_read_b128 partner -- what tests/test_isa_forms.py relies on"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    exe = str(tmp_path / "pk_forms_corun")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", os.path.join(ROOT, "tools", "micro", "pk_forms_corun.hip"),
+                           "-o", exe], stderr=subprocess.DEVNULL)
+    rc, out = _child([exe])
+    assert rc == 0, out[-2000:]
+    import re
+    rows = [ln for ln in out.splitlines() if ln.startswith("v_pk_")]
+    assert len(rows) >= 26
+    for ln in rows:
+        m = re.search(r"op_sel:\[([01]),([01])", ln)
+        keeps_rule = not (m and m.group(1) == "0" and m.group(2) == "1")
+        if keeps_rule:
+            assert re.search(r"\)\s+0 wrong words", ln), ln

@@ -1,0 +1,60 @@
+"""The shipped device code must not contain a packed-f32 instruction with op_sel[0] = 0 and op_sel[1] = 1.
+
+Round 3 (csrc/hip/afx_asm.h, profiles/r03_pk_add_opsel.txt): on gfx950 a v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 whose
+low result lane takes src0's low half and src1's HIGH half returns wrong values in lanes 48-63 while another wave of the
+CU streams v_mfma + ds_read_b128 -- exact alone, wrong beside the time-domain CWT kernel or the CQT f16 kernels.  The
+hand-written helpers order their operands accordingly and the library is built without the SLP vectoriser; this test
+disassembles every code object of the built library and fails on any instruction that breaks the rule, wherever it
+came from."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+import audioflux_amd._lib as _lib
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+PK = re.compile(r"\b(v_pk_(?:add|mul|fma)_f32)\b([^\n;]*)")
+SEL = re.compile(r"\bop_sel:\[([01]),([01])")
+
+
+def vulnerable(line):
+    m = PK.search(line)
+    if not m:
+        return False
+    s = SEL.search(m.group(2))
+    return bool(s) and s.group(1) == "0" and s.group(2) == "1"
+
+
+def test_the_rule_matcher():
+    assert vulnerable("v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
+    assert vulnerable("v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]")
+    assert vulnerable("v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]")
+    assert not vulnerable("v_pk_fma_f32 v[0:1], v[2:3], 1.0, v[6:7] op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]")
+    assert not vulnerable("v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]")
+    assert not vulnerable("v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+    assert not vulnerable("v_pk_add_f32 v[0:1], v[2:3], v[4:5]")
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="no llvm-objdump in this image")
+def test_no_packed_f32_instruction_breaks_the_operand_select_rule(tmp_path):
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([OBJDUMP, "--offloading", lib], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = sorted(f for f in os.listdir(tmp_path) if "amdgcn" in f and "gfx950" in f)
+    assert len(objs) >= 15, objs  # one code object per .hip file
+    packed, bad = 0, []
+    for f in objs:
+        dis = subprocess.run([OBJDUMP, "-d", str(tmp_path / f)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        sym = "?"
+        for line in dis.splitlines():
+            if line.endswith(">:"):
+                sym = line.split("<")[-1][:-2]
+            if "v_pk_" in line:
+                packed += 1
+                if vulnerable(line):
+                    bad.append((f, sym[:80], line.strip()[:120]))
+    assert packed > 20000, packed  # the FFT kernels are made of these
+    assert not bad, f"{len(bad)} instructions break the rule, e.g. {bad[:5]}"
