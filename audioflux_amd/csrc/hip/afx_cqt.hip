@@ -623,9 +623,11 @@ __global__ __launch_bounds__(256) void k_cqt_chroma(const float *__restrict__ re
             float4 a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + 256 * u, n4 - 1);
-                a[u] = pr4[e];
-                b[u] = pi4[e];
+                const int e = e0 + 256 * u;  // (in the last trip whole waves fall past the end: no load is issued for them)
+                if (e < n4) {
+                    a[u] = pr4[e];
+                    b[u] = pi4[e];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

@@ -2,7 +2,6 @@
 // One victim kernel per (instruction, op_sel / neg form) -- the forms found in the shipped kernels' ISA, hand-written and
 // compiler-generated -- each compared bitwise with its solo run (see tools/micro/mfma_corun.hip, profiles/r03_pk_add_opsel.txt).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/pk_forms_corun.hip -o tools/micro/pk_forms_corun
-// GENERATED by tools/micro/gen_pk_forms.py
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -43,6 +42,8 @@ __device__ __forceinline__ v2 step(v2 z, v2 w, v2 c) {
     if (F == 23) { asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(z), "v"(w), "v"(c)); }
     if (F == 24) { asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(z), "v"(w), "v"(c)); }
     if (F == 25) { asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(z), "v"(w), "v"(c)); }
+    if (F == 26) { asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(z), "v"(w)); r = r * 0.75f + c; }  // (z.hi, w.lo): the compiler's pair shuffle
+    if (F == 27) { asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(z), "v"(w)); r = r * 0.75f + c; }  // (z.lo, w.hi)
     return r;
 }
 
@@ -136,6 +137,8 @@ int main() {
         V(23, "v_pk_fma_f32 op_sel:[0,0,1] op_sel_hi:[1,1,0] (src2 swap)"),
         V(24, "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (src1 swap)"),
         V(25, "v_pk_fma_f32 op_sel:[1,0,0] op_sel_hi:[0,1,1] (src0 swap)"),
+        V(26, "v_pk_mov_b32 op_sel:[1,0] (src0 hi, src1 lo: the form the compiler emits)"),
+        V(27, "v_pk_mov_b32 op_sel:[0,1] (src0 lo, src1 hi)"),
     };
     int bad = 0;
     for (const Victim &v : victims) {
