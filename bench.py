@@ -226,8 +226,8 @@ class Cfg4:
     unit = "chunks/s"
     default_clips = 1000
     bytes_per_unit = 65536 * (4 + 8 * 84)  # 676 B per input sample
-    kernel = ("all launches of one step: k_cwt_td (36 short-kernel scales in the time domain, f16 matrix cores), "
-              "k_cwt_fwd_* + k_cwt_inv_rows512 + k_cwt_inv_cols256 (4 two-pass scales), k_cwt_inv_cols256_nb<R> (44 narrow-band scales)")
+    kernel = ("all launches of one step: k_cwt_td (36 short-kernel scales in the time domain, f16 matrix cores, own stream), "
+              "k_cwt_fwd_*, k_cwt_inv_cols256_nb<R> (44 narrow-band scales) + k_cwt_inv_cols256_nb2<4> (4 scales of 17-20 rows)")
     dtype = "f32 (36 of 84 scales: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ()
     GROUP = 32  # chunks per device call: the [84, 2^16] complex outputs (44 MB per chunk) are ring-buffered

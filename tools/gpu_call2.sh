@@ -13,14 +13,15 @@ rm -f $OUT/parity.jsonl
 echo "pytest -m gpu rc=$? $(grep -aE '[0-9]+ passed|failed' $OUT/pytest.log | tail -n 1)" | tee $OUT/status.txt
 grep -aE "^FAILED|^ERROR" $OUT/pytest.log | head -40
 python tools/parity_table.py $OUT/parity.jsonl > $OUT/parity_table.md 2>&1
-timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
-echo "bench default rc=$?" | tee -a $OUT/status.txt
 timeout -k 10 300 bash tools/prof.sh ev_$TAG > /dev/null 2>&1
 cp gpurun_out/prof_ev_$TAG/summary.txt $OUT/rocprofv3_bench_cfg2_summary.txt 2>/dev/null
 timeout -k 10 200 python tools/prof_traffic.py 2 > $OUT/traffic_cfg2.log 2>&1
 timeout -k 10 200 python tools/prof_traffic.py 5 --clips 125 > $OUT/traffic_cfg5.log 2>&1
 timeout -k 10 200 python tools/prof_traffic.py 4 --clips 20 --steps 1 > $OUT/traffic_cfg4.log 2>&1
 cp gpurun_out/r03_bench_cfg*_pmc.json $OUT/ 2>/dev/null
+cp gpurun_out/r03_bench_cfg*_pmc.json profiles/ 2>/dev/null   # the bench line below quotes THIS build's traffic
+timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "bench default rc=$?" | tee -a $OUT/status.txt
 for c in 5 4; do
   timeout -k 10 200 bash tools/prof_cmd.sh ev_${TAG}_cfg$c "" python bench.py --config $c --clips $([ $c = 4 ] && echo 40 || echo 125) --steps 3 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
   cp gpurun_out/prof_ev_${TAG}_cfg$c/summary.txt $OUT/rocprofv3_bench_cfg${c}_trace.txt 2>/dev/null
