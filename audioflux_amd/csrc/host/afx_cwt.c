@@ -915,10 +915,10 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * the wrapper's default L = 2^13 (otherwise launch-bound). */
     /* The short-kernel scales of the plain transform run in the time domain (afx_cwt_td.hip) -- from the signal, not
      * from the spectrum: all chunks of the call at once on a side stream of their own, beside the forward transforms
-     * and the FFT-path scales (they write disjoint rows), joined before the call returns.  (Until the packed adds of
-     * afx_asm.h were rewritten this overlap left wrong 16-sample pieces in the FFT-path rows: v_pk_add_f32 with an
-     * op_sel half swap misbehaves beside a wave that streams v_mfma + ds_read_b128 -- DESIGN.md section 4.3,
-     * profiles/r03_pk_add_opsel.txt; with v_pk_fma_f32 in its place every schedule is bit-reproducible.) */
+     * and the FFT-path scales (they write disjoint rows), joined before the call returns.  (This overlap is what exposed
+     * the operand-select rule of afx_asm.h: packed-f32 instructions with op_sel[0] = 0 and op_sel[1] = 1 are not exact
+     * beside a wave that streams v_mfma + ds_read_b128 -- DESIGN.md section 4.3, profiles/r03_pk_add_opsel.txt; with
+     * the rule kept every schedule is bit-reproducible.) */
     const int useTd = !isDet && o->dims.nTd > 0;
     void *tds = NULL;
     if (st == AFX_OK && useTd) {
@@ -930,8 +930,8 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
     }
     const int nTwoPass = o->dims.order ? o->dims.nWide + (useTd ? 0 : o->dims.nTd) : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
-    const int overlap = 1; /* (round 2: the three-chain schedule below is +10 % over one stream) */
-    int group = nTwoPass > 0 ? (int)((overlap ? 48.0e6 : 96.0e6) / ((double)nTwoPass * L * 8.0)) : 32;
+    /* (two chains of 48 MB each: round 2's three-stream schedule, +10 % over one stream) */
+    int group = nTwoPass > 0 ? (int)(48.0e6 / ((double)nTwoPass * L * 8.0)) : 32;
     if (group < 1) group = 1;
     {
         const char *e = getenv("AFX_CWT_GROUP");
@@ -946,8 +946,7 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
     const size_t gbFloats = (size_t)2 * L * group * o->num;
     /* independent two-pass chains in flight (each with its own intermediate): 2 measured best on cfg 4
      * with one chunk per launch pair (26.8 k vs 25.5 k chunks/s on one chain of two chunks) */
-    int chains = (overlap && nTwoPass > 0) ? 2 : 1;
-    if (nTwoPass == 0) chains = 1;
+    const int chains = nTwoPass > 0 ? 2 : 1;
     if (st == AFX_OK && nTwoPass > 0)
         st = afxdev_reserve((void **)&o->dGB, &o->capGB, sizeof(float) * gbFloats * chains);
     /* The narrow-band scales (no intermediate; bound by their instruction stream) run on a side stream
@@ -955,7 +954,7 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * short launches with < 2 waves per SIMD): both depend only on the forward transform of the
      * batch.  Joined before the next forward batch overwrites the spectra. */
     void *side = NULL, *pipe = NULL; /* narrow-band side stream */
-    if (nTwoPass > 0 && nTwoPass < o->num && overlap) {
+    if (nTwoPass > 0 && nTwoPass < o->num) {
         side = o->stream != hipStream ? o->stream : o->stream2;
         if (!side) {
             st = afxdev_stream_create(&o->stream2);
