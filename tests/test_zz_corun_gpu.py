@@ -1,4 +1,5 @@
-"""Objects on different streams must not change each other's results.
+"""Objects on different streams must not change each other's results.  (Named to run last: these tests probe a
+hardware behaviour with child processes and micro kernels; the parity suite proper is recorded before them.)
 
 Round 3: the packed-f32 butterflies (afx_asm.h pk_add_mi / pk_add_pi, then v_pk_add_f32 with an op_sel half swap)
 returned wrong sums in lanes 48-63 whenever a kernel that streams v_mfma + ds_read_b128 (the time-domain CWT kernel,
