@@ -34,7 +34,7 @@ __global__ void k_cqt_octave(AfxCqtOctaveArgs a) {
     const float2 *tw = reinterpret_cast<const float2 *>(a.twiddle);
     const int tid = threadIdx.x, nth = blockDim.x;
     const long long frame = blockIdx.x;
-    const long long start = frame * (long long)a.hop - (N >> 1);
+    const long long start = frame * (long long)a.hop - (a.rightPad ? 0 : (N >> 1));
     const float *x = a.x + (long long)blockIdx.y * a.xStride;
     float *outRe = a.outRe + (long long)blockIdx.y * a.outStride;
     float *outIm = a.outIm + (long long)blockIdx.y * a.outStride;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_cqt_octave_mfma(AfxCqtOctaveArgs
     auto fetch = [&](int g) {
         const int clip = g / tilesPerClip, t0 = (g - clip * tilesPerClip) * 32;
         const float *x = a.x + (long long)clip * a.xStride;
-        const long long p0 = (long long)t0 * a.hop - (N >> 1);
+        const long long p0 = (long long)t0 * a.hop - (a.rightPad ? 0 : (N >> 1));
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int s = 4 * (tid + u * nth);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_cqt_octave_mfma(AfxCqtOctaveArgs
             __syncthreads();
             if (g + (int)gridDim.x < totalTiles) fetch(g + gridDim.x);
         } else {
-            const long long p0 = (long long)t0 * a.hop - (N >> 1);
+            const long long p0 = (long long)t0 * a.hop - (a.rightPad ? 0 : (N >> 1));
             // (eight independent loads in flight per thread: one load per trip would serialise
             // the whole window on memory latency)
             for (int sb = tid; sb < S; sb += 8 * nth) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(NV > 10 ? 256 : 512) void k_cqt_octave_mfma_w(AfxCq
     auto fetch = [&](int g) {
         const int clip = g / tilesPerClip, t0 = (g - clip * tilesPerClip) * 32;
         const float *x = a.x + (long long)clip * a.xStride;
-        const long long p0 = (long long)t0 * a.hop - (N >> 1);
+        const long long p0 = (long long)t0 * a.hop - (a.rightPad ? 0 : (N >> 1));
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int s = 4 * (lane + 64 * u);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
         const int clip = t / tilesPerClip, t0 = (t - clip * tilesPerClip) * 32;
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.x + (long long)clip * a.xStride), 0, a.validLength * 4, RSRC_RAW);
-        const int p0 = t0 * H - (C::N >> 1);
+        const int p0 = t0 * H - (a.rightPad ? 0 : (C::N >> 1));
 #pragma unroll
         for (int u = 0; u < C::NV; ++u)
             wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (p0 + 4 * (lane + 64 * u)) * 4, 0, 0);

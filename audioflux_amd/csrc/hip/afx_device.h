@@ -309,6 +309,8 @@ typedef struct {
     const unsigned short *timeKernelH; /* device [2][N/16][64][8] f16 (hi, lo) words of the scaled image in
                               * MFMA fragment order (afx_cqt_f16.hip); NULL: float32 kernels     */
     const float *colMul;     /* device [32]: 2^-s_j of the image columns                          */
+    int rightPad;            /* 0: frame t covers samples [t hop - N/2, t hop + N/2) (centre padding, the default);
+                              * 1: [t hop, t hop + N) (cqt_algorithm.c:1303-1318: the streaming object pads on the right) */
 } AfxCqtOctaveArgs;
 int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
 /* f16 matrix-core variant; AFX_ERR_UNSUPPORTED when the plan / alignment is outside its scope */

@@ -30,6 +30,13 @@ struct OpaqueCQT {
     float *sLenArr;          /* host, num: sqrt(len) */
     float taps[32];          /* resampler FIR h_j = table[256 j] */
     int timeLength;          /* frames of the last cqt call */
+    /* streaming (isContinue, cqt_algorithm.c:345-456): samples kept from the previous calls, and the assembled
+     * tail + new data of a call; tailLength < 0: that many samples of the next call are skipped (hop > fftLength) */
+    int isContinue;
+    float *tailData;         /* host, fftLength + slideLength floats */
+    int tailLength;
+    float *validData;        /* host */
+    size_t capValid;
     /* device */
     void *stream;
     void *stream2;           /* side stream of the device call when the caller's stream IS `stream` */
@@ -209,10 +216,6 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     if (isContinue) cont = *isContinue;
     if (normalType) norm = *normalType;
     if (isScale) scaleFlag = *isScale;
-    if (cont) {
-        afxdev_set_error("cqtObj_newWith: isContinue=1 (streaming) is not implemented by the MI355X backend");
-        return AFX_ERR_UNSUPPORTED;
-    }
     const int octaveNum = num / bpo;
     if (norm == SpectralFilterBankNormal_BandWidth && (octaveNum < 2 || vFlag)) {
         afxdev_set_error("cqtObj_newWith: BandWidth normalisation of a single octave reads before the "
@@ -233,6 +236,7 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     o->minFre = fmin;
     o->windowType = win;
     o->normType = norm;
+    o->isContinue = cont ? 1 : 0;
 
     /* ---- frequencies, lengths (cqt_filterBank.c:159-246) */
     o->freBandArr = (float *)calloc((size_t)num + 2, sizeof(float));
@@ -259,6 +263,14 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     for (int i = 0; i < num; i++) o->sLenArr[i] = sqrtf(q * sr / (o->freBandArr[i] + bet / value));
     if (slide <= 0) slide = o->fftLength / 4;
     o->slideLength = slide;
+    if (o->isContinue) {
+        o->tailData = (float *)calloc((size_t)o->fftLength, sizeof(float));
+        if (!o->tailData) {
+            cqtObj_free(o);
+            free(lenTop);
+            return AFX_ERR_NOMEM;
+        }
+    }
     if (o->radix2Exp < 1 || o->radix2Exp > 14 || (slide >> (octaveNum - 1)) < 1) {
         afxdev_set_error("cqtObj_newWith: fftLength %d / slideLength %d unsupported for %d octaves",
                          o->fftLength, slide, octaveNum);
@@ -422,8 +434,55 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
 }
 
 int cqtObj_calTimeLength(CQTObj o, int dataLength) {
-    if (!o || dataLength <= 0) return 0;
+    if (!o) return 0;
+    if (o->isContinue) { /* cqt_algorithm.c:281-288: whole frames of tail + new samples */
+        const long long total = (long long)dataLength + o->tailLength;
+        return total < o->fftLength ? 0 : (int)((total - o->fftLength) / o->slideLength + 1);
+    }
+    if (dataLength <= 0) return 0;
     return dataLength / o->slideLength + 1; /* padded framing, cqt_algorithm.c:289-297 */
+}
+
+/* Streaming object: the samples left over by the previous calls followed by the new ones, the frames they hold, and
+ * the new tail (_cqtObj_dealData, cqt_algorithm.c:345-456; __calTimeAndTailLen :309-327).  Returns the number of
+ * frames (0: not a whole frame yet -- everything went to the tail), < 0 on allocation failure; *valid / *validLength
+ * = the assembled signal.  (A negative tail -- hop > fftLength -- is that many samples of the next call to skip.) */
+static int cqt_stream_take(CQTObj o, const float *data, int dataLength, const float **valid, int *validLength) {
+    const int N = o->fftLength, hop = o->slideLength;
+    const long long total = (long long)o->tailLength + dataLength;
+    *valid = NULL;
+    *validLength = 0;
+    if (total < N) {
+        if (total > 0) {
+            if (o->tailLength >= 0) memcpy(o->tailData + o->tailLength, data, sizeof(float) * (size_t)dataLength);
+            else memcpy(o->tailData, data - o->tailLength, sizeof(float) * (size_t)total);
+        }
+        o->tailLength = (int)total;
+        return 0;
+    }
+    const int frames = (int)((total - N) / hop + 1);
+    const int tailLen = (int)((total - N) % hop) + (N - hop);
+    if ((size_t)total + (size_t)N > o->capValid) {
+        float *p = (float *)realloc(o->validData, sizeof(float) * ((size_t)total + (size_t)N));
+        if (!p) return -1;
+        o->validData = p;
+        o->capValid = (size_t)total + (size_t)N;
+    }
+    int vl = 0;
+    if (o->tailLength < 0) {
+        vl = dataLength + o->tailLength;
+        memcpy(o->validData, data - o->tailLength, sizeof(float) * (size_t)vl);
+    } else {
+        if (o->tailLength > 0) memcpy(o->validData, o->tailData, sizeof(float) * (size_t)o->tailLength);
+        vl = o->tailLength;
+        memcpy(o->validData + vl, data, sizeof(float) * (size_t)dataLength);
+        vl += dataLength;
+    }
+    if (tailLen > 0) memcpy(o->tailData, o->validData + (vl - tailLen), sizeof(float) * (size_t)tailLen);
+    o->tailLength = tailLen;
+    *valid = o->validData;
+    *validLength = vl;
+    return frames;
 }
 
 int cqtObj_getFFTLength(CQTObj o) { return o ? o->fftLength : 0; }
@@ -438,7 +497,8 @@ void cqtObj_setScale(CQTObj o, int flag) {
  * clips (pitch = dataLength/2 samples).  Asynchronous on `stream`. */
 static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, long long xStride,
                           float *dRe, float *dIm, void *stream) {
-    const int T = dataLength / o->slideLength + 1;
+    /* streaming objects frame from sample 0 (right padding) and keep whole frames only (cqt_algorithm.c:923-928) */
+    const int T = o->isContinue ? (dataLength - o->fftLength) / o->slideLength + 1 : dataLength / o->slideLength + 1;
     const long long pitch = ((long long)dataLength / 2 + 3) & ~3LL;
     int st = AFX_OK;
     /* The decimation chain (signal of octave k from octave k+1: memory / latency bound) does not depend on
@@ -483,6 +543,7 @@ static int cqt_run_device(CQTObj o, const float *dX, int batch, int dataLength, 
     a.outIm = dIm;
     a.batch = batch;
     a.outStride = (long long)T * o->num;
+    a.rightPad = o->isContinue;
 
     const float *cur = dX;
     long long curStride = xStride;
@@ -536,15 +597,31 @@ void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float
         afxdev_set_error("cqtObj_cqt: NULL object");
         return;
     }
-    if (!dataArr || dataLength <= 0 || !mRealArr || !mImageArr) return;
-    const int T = dataLength / o->slideLength + 1;
+    if (!dataArr || dataLength <= 0) return;
+    if (!o->isContinue && (!mRealArr || !mImageArr)) return;
+    const float *src = dataArr;
+    int T = dataLength / o->slideLength + 1;
+    if (o->isContinue) { /* tail of the previous calls + these samples; the rest waits for the next call */
+        T = cqt_stream_take(o, dataArr, dataLength, &src, &dataLength);
+        if (T < 0) {
+            fail(o, AFX_ERR_NOMEM, "cqtObj_cqt");
+            return;
+        }
+        o->timeLength = T;
+        if (T == 0) return; /* (the samples are kept; nothing is written) */
+        if (!mRealArr || !mImageArr) {
+            afxdev_set_error("cqtObj_cqt: %d frames are due but an output pointer is NULL", T);
+            fail(o, AFX_ERR_ARG, "cqtObj_cqt");
+            return;
+        }
+    }
     const size_t outB = sizeof(float) * (size_t)T * o->num;
     int st = AFX_OK;
     if (o->lastUsed && o->lastStream != o->stream) st = afxdev_stream_sync(o->lastStream);
     o->lastUsed = 0;
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dOut, &o->capOut, 2 * outB);
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dX, &o->capX, sizeof(float) * (size_t)dataLength);
-    if (st == AFX_OK) st = afxdev_h2d(o->dX, dataArr, sizeof(float) * (size_t)dataLength, o->stream);
+    if (st == AFX_OK) st = afxdev_h2d(o->dX, src, sizeof(float) * (size_t)dataLength, o->stream);
     float *dRe = o->dOut, *dIm = o->dOut + (size_t)T * o->num;
     if (st == AFX_OK) st = cqt_run_device(o, o->dX, 1, dataLength, dataLength, dRe, dIm, o->stream);
     if (st == AFX_OK) st = afxdev_d2h(mRealArr, dRe, outB, o->stream);
@@ -581,6 +658,10 @@ static int cqt_chunk_clips(CQTObj o, int T, int batch) { return afx_cqt_pass_cli
 int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLength,
                           long long clipStride, float *dReal, float *dImag, void *hipStream) {
     AFX_ENTER(o);
+    if (o && o->isContinue) { /* a streaming object carries one signal's tail from call to call */
+        afxdev_set_error("cqtObj_cqtBatchDevice: the object was created with isContinue = 1; streaming objects take cqtObj_cqt");
+        return AFX_ERR_UNSUPPORTED;
+    }
     if (!o || !dData || !dReal || !dImag || batch <= 0 || dataLength <= 0 || clipStride < dataLength) {
         afxdev_set_error("cqtObj_cqtBatchDevice: bad argument");
         return AFX_ERR_ARG;
@@ -606,6 +687,10 @@ int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLengt
 int cqtObj_cqtBatch(CQTObj o, const float *dataArr, int batch, int dataLength, float *mRealArr,
                     float *mImageArr) {
     AFX_ENTER(o);
+    if (o && o->isContinue) { /* a streaming object carries one signal's tail from call to call */
+        afxdev_set_error("cqtObj_cqtBatch: the object was created with isContinue = 1; streaming objects take cqtObj_cqt");
+        return AFX_ERR_UNSUPPORTED;
+    }
     if (!o || !dataArr || !mRealArr || !mImageArr || batch <= 0 || dataLength <= 0) {
         afxdev_set_error("cqtObj_cqtBatch: bad argument");
         return AFX_ERR_ARG;
@@ -775,6 +860,10 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
                                 float *dReal, float *dImag, int *chromaNum, SpectralDataType *dataType,
                                 ChromaDataNormalType *normType, float *dChroma, void *hipStream) {
     AFX_ENTER(o);
+    if (o && o->isContinue) { /* a streaming object carries one signal's tail from call to call */
+        afxdev_set_error("cqtObj_cqtChromaBatchDevice: the object was created with isContinue = 1; streaming objects take cqtObj_cqt");
+        return AFX_ERR_UNSUPPORTED;
+    }
     if (!o || !dData || !dReal || !dImag || !dChroma || batch <= 0 || dataLength <= 0 || clipStride < dataLength) {
         afxdev_set_error("cqtObj_cqtChromaBatchDevice: bad argument");
         return AFX_ERR_ARG;
@@ -928,5 +1017,7 @@ void cqtObj_free(CQTObj o) {
     afxdev_stream_destroy(o->stream);
     free(o->freBandArr);
     free(o->sLenArr);
+    free(o->tailData);
+    free(o->validData);
     free(o);
 }

@@ -177,7 +177,7 @@ class RefCepstrogram:
 
 class RefCQT:
     def __init__(self, num=84, samplate=None, min_fre=None, bin_per_octave=None, factor=None, beta=None,
-                 thresh=None, window_type=None, slide_length=None, normal_type=None, is_scale=None):
+                 thresh=None, window_type=None, slide_length=None, normal_type=None, is_scale=None, is_continue=None):
         L = lib()
         self.L = L
         self.num = num
@@ -185,7 +185,7 @@ class RefCQT:
         L.cqtObj_newWith.argtypes = [C.POINTER(C.c_void_p), C.c_int, ip, fp, ip, fp, fp, fp, ip, ip, ip, ip, ip]
         self.status = L.cqtObj_newWith(C.byref(self.obj), num, _pi(samplate), _pf(min_fre),
                                        _pi(bin_per_octave), _pf(factor), _pf(beta), _pf(thresh),
-                                       _pi(window_type), _pi(slide_length), None, _pi(normal_type),
+                                       _pi(window_type), _pi(slide_length), _pi(is_continue), _pi(normal_type),
                                        _pi(is_scale))
         L.cqtObj_calTimeLength.argtypes = [C.c_void_p, C.c_int]
         L.cqtObj_getFFTLength.argtypes = [C.c_void_p]

@@ -438,19 +438,21 @@ def decimate2(x):
 
 
 def cqt(x, num=84, samplate=32000, min_fre=32.703196, bpo=12, window_type=1, normal="none",
-        hop=None, is_scale=True):
-    """[T, num] complex: the octave recursion of _cqtObj_cqt"""
+        hop=None, is_scale=True, right_pad=False):
+    """[T, num] complex: the octave recursion of _cqtObj_cqt.  right_pad: the streaming object's framing
+    (cqt_algorithm.c:1303-1318, :923-928): frames start at sample 0, whole frames of the top octave only"""
     fre, n, lens, K = cqt_plan(num, samplate, min_fre, bpo, window_type, normal)
     octaves = num // bpo
     hop = hop or n // 4
     x = np.asarray(x, np.float64)
-    T = len(x) // hop + 1
+    T = (len(x) - n) // hop + 1 if right_pad else len(x) // hop + 1
     out = np.zeros((T, num), complex)
     h = hop
     for k, o in enumerate(range(octaves - 1, -1, -1)):
         frames = len(x) // h + 1
         valid = len(x) - (len(x) % h if frames > 1 else 0)  # stft_algorithm.c:838-843
-        xp = np.concatenate([np.zeros(n // 2), x[:valid], np.zeros(n // 2 + n)])
+        lead = 0 if right_pad else n // 2
+        xp = np.concatenate([np.zeros(lead), x[:valid], np.zeros(2 * n + h * T)])
         idx = np.arange(n)[None, :] + h * np.arange(T)[:, None]
         S = np.fft.rfft(xp[idx], axis=1)
         Q = S @ K.T  # plain complex product, no conjugate (flux_complex.c:53-87)
@@ -462,6 +464,29 @@ def cqt(x, num=84, samplate=32000, min_fre=32.703196, bpo=12, window_type=1, nor
             x = decimate2(x)
             h //= 2
     return out
+
+
+class CqtStream:
+    """cqtObj_cqt of an isContinue = 1 object (_cqtObj_dealData, cqt_algorithm.c:345-456): the samples left over by
+    the previous calls are put in front of the new ones; whole frames are transformed, the rest is kept"""
+
+    def __init__(self, **plan):
+        self.plan = plan
+        n = cqt_plan(plan.get("num", 84), plan.get("samplate", 32000), plan.get("min_fre", 32.703196),
+                     plan.get("bpo", 12), plan.get("window_type", 1), plan.get("normal", "none"))[1]
+        self.n, self.hop = n, plan.get("hop") or n // 4
+        self.tail = np.zeros(0)
+
+    def cqt(self, x):
+        x = np.asarray(x, np.float64)
+        total = len(self.tail) + len(x)
+        valid = np.concatenate([self.tail, x])
+        if total < self.n:
+            self.tail = valid
+            return np.zeros((0, self.plan.get("num", 84)), complex)
+        tail_len = (total - self.n) % self.hop + (self.n - self.hop)
+        self.tail = valid[len(valid) - tail_len:] if tail_len > 0 else np.zeros(0)
+        return cqt(valid, right_pad=True, **self.plan)
 
 
 def cqt_deconv(mag):

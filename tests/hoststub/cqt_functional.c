@@ -52,7 +52,7 @@ int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, i
 
 /* out[b][t][colBase + j] = octScale / scale[colBase + j] * sum_n x_b[t hop - N/2 + n] G[n][j] (Re), G[n][rows + j] (Im);
  * samples outside [0, validLength) are zero */
-static void octave_product(const float *x, long long xStride, int validLength, int hop, int N, const double *G, int rows,
+static void octave_product(const float *x, long long xStride, int validLength, int hop, int rightPad, int N, const double *G, int rows,
                            const float *scale, float octScale, int num, int colBase, float *outRe, float *outIm,
                            long long outStride, int batch, int timeLength) {
     double *acc = (double *)malloc(sizeof(double) * 2 * (size_t)rows);
@@ -61,7 +61,7 @@ static void octave_product(const float *x, long long xStride, int validLength, i
         for (int t = 0; t < timeLength; t++) {
             memset(acc, 0, sizeof(double) * 2 * (size_t)rows);
             for (int n = 0; n < N; n++) {
-                const long long s = (long long)t * hop - N / 2 + n;
+                const long long s = (long long)t * hop - (rightPad ? 0 : N / 2) + n;
                 if (s < 0 || s >= validLength) continue;
                 const double v = x[b * xStride + s];
                 const double *g = G + (size_t)n * 2 * rows;
@@ -101,7 +101,7 @@ int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
     if (2 * a->rows > 32) return AFX_ERR_UNSUPPORTED;
     afx_functional_launches[0]++;
     double *G = image_from_words(a->timeKernelH, a->colMul, 512, a->rows);
-    octave_product(a->x, a->xStride, a->validLength, a->hop, 512, G, a->rows, a->scale, a->octScale, a->num, a->colBase,
+    octave_product(a->x, a->xStride, a->validLength, a->hop, a->rightPad, 512, G, a->rows, a->scale, a->octScale, a->num, a->colBase,
                    a->outRe, a->outIm, a->outStride, a->batch > 0 ? a->batch : 1, a->timeLength);
     free(G);
     return AFX_OK;
@@ -134,7 +134,7 @@ int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream) {
             }
         }
     }
-    octave_product(a->x, a->xStride, a->validLength, a->hop, N, G, rows, a->scale, a->octScale, a->num, a->colBase,
+    octave_product(a->x, a->xStride, a->validLength, a->hop, a->rightPad, N, G, rows, a->scale, a->octScale, a->num, a->colBase,
                    a->outRe, a->outIm, a->outStride, a->batch > 0 ? a->batch : 1, a->timeLength);
     free(G);
     return AFX_OK;

@@ -87,10 +87,56 @@ def run(name, gold):
         n[i] = 0
 
 
+def run_stream(name):
+    """isContinue = 1 (cqt_algorithm.c:345-456): a signal fed in pieces -- shorter than a frame, shorter than a hop,
+    long, a few samples -- against the float64 restatement of the reference's tail handling (oracle/restate.py:
+    CqtStream, pinned against the compiled reference in tests/test_oracle.py); the batch entry points refuse."""
+    from oracle import restate
+    name, _, hop = name.partition("@")  # "<case>@<hop>": the case's plan with another hop
+    c = cases.CQT_CASES[name]
+    sr, num = c["samplate"], c["num"]
+    x = (0.1 * np.random.default_rng(41).standard_normal(60000)).astype(np.float32)
+    h = vp()
+    hop = int(hop) if hop else c.get("slide_length")
+    st = lib.cqtObj_newWith(C.byref(h), num, C.byref(C.c_int(sr)), C.byref(C.c_float(c["min_fre"])),
+                            C.byref(C.c_int(c["bin_per_octave"])), None, None, None, C.byref(C.c_int(c["window_type"])),
+                            C.byref(C.c_int(hop)) if hop else None, C.byref(C.c_int(1)),
+                            C.byref(C.c_int(c["normal_type"])), C.byref(C.c_int(c["is_scale"])))
+    assert st == 0, st
+    normal = {0: "none", 1: "area", 2: "bandwidth"}[c["normal_type"]]
+    want = restate.CqtStream(num=num, samplate=sr, min_fre=float(np.float32(c["min_fre"])), bpo=c["bin_per_octave"], window_type=c["window_type"],
+                             normal=normal, hop=hop, is_scale=bool(c["is_scale"]))
+    pos, frames = 0, 0
+    for n in (300, 4000, 100, 130, 9000, 511, 12000, 7, 1, 2000, 20000):
+        seg = np.ascontiguousarray(x[pos:pos + n])
+        pos += n
+        T = lib.cqtObj_calTimeLength(h, n)
+        w = want.cqt(seg)
+        assert T == w.shape[0], (n, T, w.shape)
+        re, im = np.full((max(T, 1), num), 7.0, np.float32), np.full((max(T, 1), num), 7.0, np.float32)
+        lib.cqtObj_cqt(h, p(seg), n, p(re), p(im))
+        if T:
+            check(f"{name} stream +{n} samples -> {T} frames", re[:T] + 1j * im[:T], w, 1e-5)
+        else:
+            assert (re == 7.0).all() and (im == 7.0).all(), "no frame: the outputs must stay untouched"
+        frames += T
+    assert frames == (pos - want.n) // want.hop + 1, (frames, pos)  # the pieces add up to the one-shot framing
+    stream = (C.c_char * 8)()
+    out = np.zeros((1, 4, num), np.float32)
+    assert lib.cqtObj_cqtBatchDevice(h, p(x), 1, 4000, C.c_longlong(4000), p(out), p(out), C.cast(stream, vp)) != 0
+    lib.cqtObj_free(h)
+    n4 = (C.c_int * 4).in_dll(lib, "afx_functional_launches")
+    for i in range(4):
+        n4[i] = 0
+
+
 def main():
     gold = np.load(os.path.join(ROOT, "tests", "golden", "cqt.npz"))
     for name in sys.argv[1:]:
-        run(name, gold)
+        if name.startswith("stream:"):
+            run_stream(name[7:])
+        else:
+            run(name, gold)
     print("OK")
 
 

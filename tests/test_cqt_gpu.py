@@ -67,3 +67,60 @@ def test_cqt_linearity():
     a, b = cases.noise(90, 6000), cases.noise(91, 6000)
     qa, qb, qs = o.cqt(a), o.cqt(b), o.cqt((a + 2 * b).astype(np.float32))
     assert_parity(qs, qa + 2 * qb, 2e-6, "linearity")
+
+
+@pytest.mark.parametrize("sr,hop,pieces", [
+    (32000, None, (4000, 4000, 511, 12000)),           # the default hop: every octave on the f16 kernels
+    (32000, None, (300, 300, 300, 300, 4000, 200, 9000)),
+    (44100, 96, (700, 100, 9000, 8000)),               # hop 96 -> 48 ... 1.5: float32 kernels from the second octave on
+])
+def test_streaming_cqt_matches_compiled_reference(sr, hop, pieces):
+    """isContinue = 1 (cqt_algorithm.c:345-456): a signal fed piece by piece -- the tail of the previous calls is put
+    in front of the new samples, frames start at sample 0 (right padding), whole frames only -- against the compiled
+    reference's streaming object fed the same pieces, call by call, and the frame counts the wrapper reports."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    x = (0.1 * np.random.default_rng(9).standard_normal(sum(pieces))).astype(np.float32)
+    x += 0.2 * np.sin(2 * np.pi * 440.0 / sr * np.arange(len(x))).astype(np.float32)
+    o = af.CQT(num=84, samplate=sr, slide_length=hop, is_continue=True)
+    r = ref.RefCQT(84, samplate=sr, slide_length=hop, is_continue=1, normal_type=1)
+    pos = 0
+    for n in pieces:
+        seg = x[pos:pos + n]
+        pos += n
+        want_t = r.L.cqtObj_calTimeLength(r.obj, n)
+        assert o.cal_time_length(n) == want_t
+        re, im = r.cqt(seg)
+        got = o.cqt(seg)  # (num, time)
+        assert got.shape == (84, want_t)
+        if want_t:
+            assert_parity(got.T, re + 1j * im, 1e-5, f"+{n} samples -> {want_t} frames")
+            ch = o.chroma(got)
+            assert ch.shape == (12, want_t) and np.isfinite(ch).all()
+
+
+def test_streaming_cqt_pieces_equal_the_restatement_where_the_reference_is_not_stable():
+    """piece sequences the reference's own buffer handling does not survive (a short piece right after a long one:
+    'double free or corruption', tests/test_oracle.py) against the float64 restatement of its tail rule; the pieces'
+    frame counts add up to the whole signal's (the values do not: every call zero-pads its lower octaves, whose
+    frames span fftLength 2^k samples, on the right -- the reference's behaviour); batch calls refuse a streaming object"""
+    import torch
+    from oracle import restate
+    pieces = (300, 4000, 100, 130, 9000, 511, 12000, 7, 1, 2000)
+    x = (0.1 * np.random.default_rng(10).standard_normal(sum(pieces))).astype(np.float32)
+    o = af.CQT(num=84, samplate=32000, is_continue=True)
+    s = restate.CqtStream(num=84, samplate=32000, normal="area")
+    pos, frames = 0, 0
+    for n in pieces:
+        seg = x[pos:pos + n]
+        pos += n
+        w = s.cqt(seg)
+        got = o.cqt(seg)
+        assert got.shape == (84, w.shape[0])
+        if w.shape[0]:
+            assert_parity(got.T, w, 1e-5, f"+{n} samples")
+            frames += w.shape[0]
+    assert frames == (len(x) - 512) // 128 + 1
+    with pytest.raises(RuntimeError):
+        o.cqt_device(torch.zeros((1, 4000), device="cuda"))

@@ -176,7 +176,8 @@ def test_cqt_host_glue_meets_the_golden_vectors_with_functional_launchers(functi
         e.update(kv.split("=") for kv in env.split())
     e.update(LD_PRELOAD=_asan_runtime(), ASAN_OPTIONS="detect_leaks=0", AFX_LIB=functional, UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([sys.executable, os.path.join(HERE, "functional_cqt.py"), "c84_32k_area", "c84_44k_none_noscale",
-                        "c48_16k_area", "c72_24bpo_hop200"], capture_output=True, text=True, env=e, timeout=900)
+                        "c48_16k_area", "c72_24bpo_hop200", "stream:c84_32k_area", "stream:c48_16k_area@192"],
+                       capture_output=True, text=True, env=e, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "\nOK" in out, out[-3000:]
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]

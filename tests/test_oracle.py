@@ -174,3 +174,25 @@ def test_restatement_on_real_audio(name, golden_dir):
     assert_parity(Q[::4], g[f"{name}/cqt"], 1e-5, f"{name} cqt")
     # MAX-normalised chroma of speech pauses: the reference's float32 chain is 2.5e-5 from float64 there
     assert_parity(restate.cqt_chroma(Q, 12, 12, "power", "max", 32.703), g[f"{name}/chroma"], 5e-5, f"{name} chroma")
+
+
+@pytest.mark.parametrize("pieces", [(4000, 4000, 511, 12000), (300, 300, 300, 300, 4000), (700, 100, 9000), (4000, 200, 300, 4000)])
+def test_streaming_cqt_restatement_matches_compiled_reference(pieces):
+    """cqtObj_cqt of an isContinue = 1 object (cqt_algorithm.c:345-456): restate.CqtStream against the compiled
+    reference, call by call.  (Piece sequences on which the reference itself is stable: a short piece right after a
+    long one can end it with 'double free or corruption' -- e.g. 4000 then 130 samples -- in its buffer resizing.)"""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    x = (0.1 * np.random.default_rng(5).standard_normal(sum(pieces))).astype(np.float32)
+    r = ref.RefCQT(84, samplate=32000, is_continue=1)
+    s = restate.CqtStream(num=84, samplate=32000)
+    pos = 0
+    for n in pieces:
+        seg = x[pos:pos + n]
+        pos += n
+        re, im = r.cqt(seg)
+        w = s.cqt(seg)
+        assert re.shape == w.shape
+        if w.size:
+            assert_parity(re + 1j * im, w, 1e-5, f"+{n} samples")
