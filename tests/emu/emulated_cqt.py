@@ -37,7 +37,37 @@ def p(a):
     return a.ctypes.data_as(fp)
 
 
+def stream_pieces():
+    """isContinue = 1: pieces of a signal through the emulated kernels against the float64 restatement of the
+    reference's tail rule (oracle/restate.py: CqtStream) -- the rightPad framing of every octave kernel"""
+    from oracle import restate
+    hop = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    x = (0.1 * np.random.default_rng(9).standard_normal(9000)).astype(np.float32)
+    h = vp()
+    st = lib.cqtObj_newWith(C.byref(h), 84, C.byref(C.c_int(32000)), None, None, None, None, None, None,
+                            C.byref(C.c_int(hop)) if hop else None, C.byref(C.c_int(1)), None, None)
+    assert st == 0, st
+    want = restate.CqtStream(num=84, samplate=32000, normal="none", hop=hop or None)
+    pos = 0
+    for n in (4000, 300, 3000):
+        seg = np.ascontiguousarray(x[pos:pos + n])
+        pos += n
+        T = lib.cqtObj_calTimeLength(h, n)
+        w = want.cqt(seg)
+        assert T == w.shape[0], (T, w.shape)
+        re, im = np.zeros((T, 84), np.float32), np.zeros((T, 84), np.float32)
+        lib.cqtObj_cqt(h, p(seg), n, p(re), p(im))
+        if T:
+            err = np.abs((re + 1j * im) - w).max(axis=0) / np.abs(w).max()
+            print("   per-octave worst error:", [f"{err[12 * o:12 * o + 12].max():.1e}" for o in range(7)], flush=True)
+            check(f"stream +{n} samples -> {T} frames", re + 1j * im, w, 1e-5)
+    lib.cqtObj_free(h)
+    print("OK")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "stream":
+        return stream_pieces()
     name = sys.argv[1] if len(sys.argv) > 1 else "c84_32k_area"
     gold = np.load(os.path.join(ROOT, "tests", "golden", "cqt.npz"))
     c = cases.CQT_CASES[name]

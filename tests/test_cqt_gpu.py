@@ -72,32 +72,31 @@ def test_cqt_linearity():
 @pytest.mark.parametrize("sr,hop,pieces", [
     (32000, None, (4000, 4000, 511, 12000)),           # the default hop: every octave on the f16 kernels
     (32000, None, (300, 300, 300, 300, 4000, 200, 9000)),
-    (44100, 96, (700, 100, 9000, 8000)),               # hop 96 -> 48 ... 1.5: float32 kernels from the second octave on
+    (44100, 96, (700, 100, 9000, 8000)),               # hop 96 -> 48 ... 1: float32 kernels
 ])
-def test_streaming_cqt_matches_compiled_reference(sr, hop, pieces):
+def test_streaming_cqt_matches_the_reference_call_by_call(sr, hop, pieces):
     """isContinue = 1 (cqt_algorithm.c:345-456): a signal fed piece by piece -- the tail of the previous calls is put
-    in front of the new samples, frames start at sample 0 (right padding), whole frames only -- against the compiled
-    reference's streaming object fed the same pieces, call by call, and the frame counts the wrapper reports."""
-    from oracle import ref
-    if not ref.available():
-        pytest.skip("oracle/_ref not built")
+    in front of the new samples, frames start at sample 0 (right padding), whole frames only.  Checked against the
+    float64 restatement of that rule (oracle/restate.py: CqtStream), which tests/test_oracle.py pins against the
+    compiled reference in a child process: the reference's own streaming object corrupts its heap on some piece
+    sequences, so it is kept out of this process."""
+    from oracle import restate
     x = (0.1 * np.random.default_rng(9).standard_normal(sum(pieces))).astype(np.float32)
     x += 0.2 * np.sin(2 * np.pi * 440.0 / sr * np.arange(len(x))).astype(np.float32)
     o = af.CQT(num=84, samplate=sr, slide_length=hop, is_continue=True)
-    r = ref.RefCQT(84, samplate=sr, slide_length=hop, is_continue=1, normal_type=1)
+    s = restate.CqtStream(num=84, samplate=sr, min_fre=float(np.float32(32.703)), normal="area", hop=hop)
     pos = 0
     for n in pieces:
         seg = x[pos:pos + n]
         pos += n
-        want_t = r.L.cqtObj_calTimeLength(r.obj, n)
-        assert o.cal_time_length(n) == want_t
-        re, im = r.cqt(seg)
+        w = s.cqt(seg)
+        assert o.cal_time_length(n) == w.shape[0]
         got = o.cqt(seg)  # (num, time)
-        assert got.shape == (84, want_t)
-        if want_t:
-            assert_parity(got.T, re + 1j * im, 1e-5, f"+{n} samples -> {want_t} frames")
+        assert got.shape == (84, w.shape[0])
+        if w.shape[0]:
+            assert_parity(got.T, w, 1e-5, f"+{n} samples -> {w.shape[0]} frames")
             ch = o.chroma(got)
-            assert ch.shape == (12, want_t) and np.isfinite(ch).all()
+            assert ch.shape == (12, w.shape[0]) and np.isfinite(ch).all()
 
 
 def test_streaming_cqt_pieces_equal_the_restatement_where_the_reference_is_not_stable():
@@ -110,7 +109,7 @@ def test_streaming_cqt_pieces_equal_the_restatement_where_the_reference_is_not_s
     pieces = (300, 4000, 100, 130, 9000, 511, 12000, 7, 1, 2000)
     x = (0.1 * np.random.default_rng(10).standard_normal(sum(pieces))).astype(np.float32)
     o = af.CQT(num=84, samplate=32000, is_continue=True)
-    s = restate.CqtStream(num=84, samplate=32000, normal="area")
+    s = restate.CqtStream(num=84, samplate=32000, min_fre=float(np.float32(32.703)), normal="area")
     pos, frames = 0, 0
     for n in pieces:
         seg = x[pos:pos + n]

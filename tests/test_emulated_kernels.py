@@ -105,6 +105,12 @@ def test_shipped_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
     assert n["octave_f16"] == 21 and n["decimate"] == 18 and n["chroma"] == 2 and n["chroma_scan"] + n["octave_f32"] == 0, n
 
 
+def test_streaming_cqt_through_the_emulated_octave_kernels(emulated):
+    """isContinue = 1 objects frame from sample 0 (rightPad of AfxCqtOctaveArgs): pieces of a signal through
+    k_cqt_octave_f16 / k_cqt_decimate on the CPU against the float64 restatement of the reference's tail rule"""
+    _run(emulated, "emulated_cqt.py", ["stream"])
+
+
 def test_headline_kernel_emulated_meets_the_golden_vectors(emulated):
     """k_stft_mel_v2 (afx_melfused2.hip; 624-654 M frames/s on the device): BASELINE cfg 1 -- golden mel spectrogram and
     MFCC-13 of the reference -- from ONE emulated launch (wave FFT, band plan, log10 + DCT-II on the f32 matrix cores),
