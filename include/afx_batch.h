@@ -99,7 +99,8 @@ int cwtObj_cwtDetBatchDevice(CWTObj cwtObj, const float *dData, int chunks, long
 /* ---- CQT + chroma (BASELINE config 5) -----------------------------------------------
  * batch clips of dataLength samples -> real/imag [batch][T, num], T = cqtObj_calTimeLength.
  * Same as calling cqtObj_cqt (cqt_algorithm.h) per clip; all clips of the batch go through
- * each octave of the recursion in one launch. */
+ * each octave of the recursion in one launch.  Objects created with isContinue = 1 carry one signal's
+ * tail from call to call: the batch calls return AFX_ERR_UNSUPPORTED (-4) for them. */
 int cqtObj_cqtBatch(CQTObj cqtObj, const float *dataArr, int batch, int dataLength,
                     float *mRealArr, float *mImageArr);
 int cqtObj_cqtBatchDevice(CQTObj cqtObj, const float *dData, int batch, int dataLength,

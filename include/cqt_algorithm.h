@@ -22,8 +22,10 @@ int cqtObj_new(CQTObj *cqtObj, int num, int samplate, float minFre, int *isConti
 
 /* num must be a multiple of binPerOctave.  defaults: samplate 32000,
  * minFre 32.703 (C1), binPerOctave 12, factor 1, beta 0, thresh 0.01,
- * window Hann, slideLength fftLength/4, isContinue 0 (1 is rejected: -2),
- * normal None, isScale 1.  returns 0 ok, -1 bad arguments, <= -2 backend.
+ * window Hann, slideLength fftLength/4, isContinue 0, normal None, isScale 1.
+ * isContinue 1: cqtObj_cqt keeps the samples that do not fill a frame for the next call and frames from
+ * sample 0 (cqt_algorithm.c:345-456, :923-928); cqtObj_calTimeLength then counts the kept samples in.
+ * returns 0 ok, -1 bad arguments, <= -2 backend.
  * replaces cqtObj_newWith, cqt_algorithm.c:123-247 */
 int cqtObj_newWith(CQTObj *cqtObj, int num,
                    int *samplate, float *minFre, int *binPerOctave,
