@@ -114,21 +114,11 @@ __global__ void k_cepstrogram(AfxCepstrogramArgs a) {
 // N = 4096 splits every transform into the 2048-point real transforms E, O of the even / odd
 // samples: X[k] = E[k] + W_4096^k O[k], X[2048 - k] = conj(E[k] - W_4096^k O[k]); it has the
 // closed-form lifters only (larger cepNum takes the size-generic kernel).
-#ifndef AFX_CEPS_CW   // compile-time experiment switches (tools/variants.sh, tools/gpu_ceps_ab.sh)
-#define AFX_CEPS_CW 8
-#endif
-#ifndef AFX_CEPS_CW4
-#define AFX_CEPS_CW4 8
-#endif
-#ifndef AFX_CEPS_NB
-#define AFX_CEPS_NB 20
-#endif
-#ifndef AFX_CEPS_FASTLOG
-#define AFX_CEPS_FASTLOG 0
-#endif
-constexpr int CW = AFX_CEPS_CW;    // waves per workgroup, N = 2048 (the tables are shared)
-constexpr int CW4 = AFX_CEPS_CW4;  // N = 4096
-constexpr int LNB = AFX_CEPS_NB;   // bins per batch of the closed-form lifters (divides 20)
+// (waves per workgroup 4 / 8 / 12, lifter batches of 10 / 20 bins and the fast logarithm were measured as
+// compile-time variants in round 1: profiles/r01_cepstrogram_wave.txt)
+constexpr int CW = 8;     // waves per workgroup, N = 2048 (the tables are shared)
+constexpr int CW4 = 8;    // N = 4096
+constexpr int LNB = 20;   // bins per batch of the closed-form lifters (divides 20)
 constexpr int DIRECT_Q = 16;       // largest cepNum of the closed-form lifters
 
 struct CepWArgs {
@@ -143,11 +133,7 @@ struct CepWArgs {
 __device__ __forceinline__ float log_power(v2 z) {
     float p = z.x * z.x + z.y * z.y;
     if (p < 1e-16f) p = 1e-16f;  // cepstrogram_algorithm.c:219-229
-#if AFX_CEPS_FASTLOG
-    return __logf(p);
-#else
     return logf(p);
-#endif
 }
 
 // closed-form lifter outputs of NB bins: w[i] = W_N^k of the bin, Lk[i] its log power;

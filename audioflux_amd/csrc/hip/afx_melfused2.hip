@@ -42,10 +42,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int NFFT = 2048;
 constexpr int MC = 1024;
-#ifndef AFX_WAVES
-#define AFX_WAVES 12
-#endif
-constexpr int WAVES = AFX_WAVES;             // one workgroup per CU, 3 waves per SIMD
+constexpr int WAVES = 12;                    // one workgroup per CU, 3 waves per SIMD (8: - 5 %, profiles/r02_ab_headline.txt)
 constexpr int P1 = 72;                       // float2 per row of the exchange-1 image
 constexpr int PROW_OFF = 5120;               // byte offset of the power row in a wave's region
 constexpr int PROW_F = 1104;                 // 1025 bins + zero pad for the fixed-length band loops

@@ -1,5 +1,5 @@
-"""n_fft 2048 / hop 512 and n_fft 4096 / hop 1024 with banks whose rows exceed the fused kernel's tap variants: split plan
-(default) vs the size-generic kernel (AFX_NO_SPLIT=1), 500 clips x 30 s @ 16 kHz, real power results"""
+"""n_fft 2048 / hop 512 and n_fft 4096 / hop 1024 with banks whose rows exceed the fused kernel's tap variants (split band
+plans; AFX_NO_FUSED=1 gives the size-generic kernels for comparison), 500 clips x 30 s @ 16 kHz, real power results"""
 import os
 import sys
 
