@@ -225,9 +225,7 @@ extern "C" int afxdev_stream_create(void **stream) {
 // decimations under the octave products, the CWT chains) call this two or three times per launch group: the
 // events come from a small per-thread, per-device ring instead of a create / destroy pair per call (a wait
 // captures the record that precedes it, so an event may be recorded again while an earlier wait is pending).
-#ifndef AFX_EVENT_RING
 #define AFX_EVENT_RING 16  /* (a wait is bound to the record that precedes it at enqueue time: re-recording a slot later is harmless) */
-#endif
 namespace {
 struct EventRing {
     hipEvent_t ev[AFX_EVENT_RING];
