@@ -62,6 +62,43 @@ int afx_pwt_bank_host(int num, long long L, int samplate, SpectralFilterBankScal
         free(b);
         return AFX_OK;
     }
+    if (style == SpectralFilterBankStyle_Gammatone) {
+        /* auditory_filterBank.c:509-582 in its pseudo layout: the magnitude responses are written back to back at
+         * the HALF pitch F = N/2 + 1 (:545-551, `i*len`), the normalisation and the interior doubling then walk the
+         * same memory at the FULL pitch N (:554-581, `i*mLength`).  Row i of the bank the transform applies is
+         * therefore floats [i N, (i + 1) N) of the concatenated half rows -- the tail of response 2i - 1, response 2i,
+         * most of response 2i + 1 (its upper part lands on the negative-frequency bins) -- and rows from about num / 2 on
+         * are zero (0 / 0 = NaN under Area normalisation, as in the reference).  Reproduced as it is. */
+        float *resp = (float *)calloc((size_t)num * F, sizeof(float));
+        if (!resp) return AFX_ERR_NOMEM;
+        int st = afx_auditory_bank(num, N, samplate, scale, style, SpectralFilterBankNormal_None, low, high, bpo, resp, fre, bin);
+        if (st == AFX_OK) {
+            /* (the half-layout builder has doubled the interior bins: exact to undo) */
+            for (int i = 0; i < num; i++)
+                for (int j = 1; j < F - 1; j++) resp[(size_t)i * F + j] *= 0.5f;
+            memcpy(bank, resp, sizeof(float) * (size_t)num * F);
+            if (normal == SpectralFilterBankNormal_Area || normal == SpectralFilterBankNormal_BandWidth) {
+                for (int i = 0; i < num; i++) {
+                    float *row = bank + (size_t)i * N;
+                    float w;
+                    if (normal == SpectralFilterBankNormal_Area) {
+                        double sum = 0.0; /* __vsum accumulates in double (flux_vector.c:1493-1501) */
+                        for (int j = 1; j < N - 1; j++) sum += row[j];
+                        w = row[0] + row[N - 1];
+                        w += (float)sum * 2;
+                    } else {
+                        w = (float)(1.019 * 24.7 * (0.00437 * fre[i] + 1));
+                        w /= 2;
+                    }
+                    for (int j = 0; j < N; j++) row[j] = row[j] / w;
+                }
+            }
+            for (int i = 0; i < num; i++)
+                for (int j = 1; j < N - 1; j++) bank[(size_t)i * N + j] *= 2;
+        }
+        free(resp);
+        return st;
+    }
     float *half = (float *)calloc((size_t)num * F, sizeof(float));
     if (!half) return AFX_ERR_NOMEM;
     const int st = afx_auditory_bank(num, N, samplate, scale, style, normal, low, high, bpo, half, fre, bin);
@@ -134,11 +171,6 @@ int pwtObj_new(PWTObj *pwtObj, int num, int radix2Exp, int *samplate, float *low
     if (num < 2 || num > D / 2 + 1) {
         printf("num is error!\n");
         return -1;
-    }
-    if (style == SpectralFilterBankStyle_Gammatone) {
-        afxdev_set_error("pwtObj_new: the gammatone style is not supported (the reference lays this bank out "
-                         "with two different row pitches in the pseudo layout)");
-        return AFX_ERR_UNSUPPORTED;
     }
     const long long L = afx_cwt_fft_length(radix2Exp, isPad);
     if (L < 0) return AFX_ERR_UNSUPPORTED;

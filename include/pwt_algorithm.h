@@ -22,9 +22,9 @@ typedef struct OpaquePWT *PWTObj;
  * samplate 32000, lowFre 0 (octave / log: C1), highFre samplate/2, binPerOctave 12 (4..48),
  * scale Octave, style Slaney, normal None, isPadding 0 (1: reflect-pad by half a block).
  * returns 0, -100 bad radix2Exp, 1 bad scale type, -1 bad num / range, -4 for what this
- * backend does not run: the gammatone style (the reference builds that bank with an
- * inconsistent row pitch in this mode, auditory_filterBank.c:509-591) and padding beyond
- * 2^16 samples (non-power-of-two transform); <= -2 backend failure.
+ * backend does not run: padding beyond 2^16 samples (non-power-of-two transform); <= -2 backend failure.
+ * (The gammatone style is built as the reference builds it in this mode -- responses written at the half-spectrum
+ * pitch, normalised and doubled at the full pitch, auditory_filterBank.c:509-591: the upper half of the rows is zero.)
  * replaces pwt_algorithm.c:65-293 */
 int pwtObj_new(PWTObj *pwtObj, int num, int radix2Exp, int *samplate, float *lowFre, float *highFre,
                int *binPerOctave, SpectralFilterBankScaleType *scaleType,

@@ -112,10 +112,13 @@ def test_status_codes_without_device():
     args = [None] * 8
     args[4] = C.cast(C.pointer(scale), C.c_void_p)
     assert f(C.byref(obj), 84, 12, *args) == 1 and not obj
-    style = C.c_int(2)  # gammatone: refused, see pwt_algorithm.h
+    style = C.c_int(2)  # gammatone: a valid plan since round 3 -- the constructor gets as far as the device
     mel = C.c_int(2)
     args = [None] * 8
     args[4], args[5] = C.cast(C.pointer(mel), C.c_void_p), C.cast(C.pointer(style), C.c_void_p)
-    assert f(C.byref(obj), 40, 12, *args) == -4 and not obj
     lib.pwtObj_free.argtypes = [C.c_void_p]
+    st = f(C.byref(obj), 40, 12, *args)
+    assert st in (0, -2), st  # -2: no gfx950 device on this machine
+    if st == 0:
+        lib.pwtObj_free(obj)
     lib.pwtObj_free(None)
