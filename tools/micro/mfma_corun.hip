@@ -367,6 +367,7 @@ int main() {
     for (const Victim &v : victims) {
         const size_t bytes = vn * v.words * sizeof(float);
         CK(hipMemset(dOut, 0xff, vn * sizeof(float2)));
+        CK(hipDeviceSynchronize());  // (the victim's stream is non-blocking: it does not wait for the null stream's memset)
         v.launch(sv, dOut, VB);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(ref.data(), dOut, bytes, hipMemcpyDeviceToHost));
