@@ -71,6 +71,178 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 constexpr int RSRC_RAW = 0x00020000;  // raw buffer, 32-bit data format (cdna_hip_programming.md T8)
 
+// ---- the pieces of one 32-frame tile, shared by the per-octave kernel and the pyramid kernel ----
+
+// exponent e of a tile: its window's peak -> [2^13, 2^14)
+template <int H>
+__device__ __forceinline__ int cq_window_exponent(const u32x4 (&wnd)[CqF16<H>::NV], int lane) {
+    using C = CqF16<H>;
+    float peak = 0.f;
+#pragma unroll
+    for (int u = 0; u < C::NV; ++u) {
+        float4 v = __builtin_bit_cast(float4, wnd[u]);
+        if (256 * (u + 1) > C::S) {  // the last register reaches past the window: those samples are not the tile's
+            const int s = 4 * (lane + 64 * u);
+            if (s >= C::S) v.x = 0.f;
+            if (s + 1 >= C::S) v.y = 0.f;
+            if (s + 2 >= C::S) v.z = 0.f;
+            if (s + 3 >= C::S) v.w = 0.f;
+        }
+        peak = fmaxf(peak, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    // wave maximum without LDS traffic: four DPP steps give every row of 16 lanes its maximum, the four rows meet
+    // on the scalar unit (non-negative floats order like their bit patterns)
+    return split_exponent(wave_max_bits(peak));
+}
+
+// window registers (lane l, register u: samples 4 (l + 64 u) .. + 3) -> (xh, xl) planes, every copy
+template <int H>
+__device__ __forceinline__ void cq_convert_window(const u32x4 (&wnd)[CqF16<H>::NV], float up, unsigned char *sig, int lane) {
+    using C = CqF16<H>;
+#pragma unroll
+    for (int u = 0; u < C::NV; ++u) {
+        const int s = 4 * (lane + 64 * u);
+        if (s < C::S) {
+            const float4 v = __builtin_bit_cast(float4, wnd[u]);
+            unsigned hi0, hi1, lo0, lo1;
+            split_pair(v.x, v.y, up, hi0, lo0);
+            split_pair(v.z, v.w, up, hi1, lo1);
+            const int base = C::MARGIN + 2 * s + (C::PAD ? 16 * (s / H) : 0);
+#pragma unroll
+            for (int c = 0; c < C::COPIES; ++c) {
+                unsigned char *d = sig + c * C::CS + base - 2 * c * H;
+                if ((2 * c * H) % 8 == 0) {
+                    *reinterpret_cast<uint2 *>(d) = make_uint2(hi0, hi1);
+                    *reinterpret_cast<uint2 *>(d + C::PART) = make_uint2(lo0, lo1);
+                } else {
+                    reinterpret_cast<unsigned *>(d)[0] = hi0;
+                    reinterpret_cast<unsigned *>(d)[1] = hi1;
+                    reinterpret_cast<unsigned *>(d + C::PART)[0] = lo0;
+                    reinterpret_cast<unsigned *>(d + C::PART)[1] = lo1;
+                }
+            }
+        }
+    }
+}
+
+// K loop: 32 steps x (xh gh, xh gl, xl gh), operands two steps ahead; nothing but MFMAs and DS reads at
+// immediate offsets between the two scheduling barriers
+template <int H>
+__device__ __forceinline__ void cq_kloop(const unsigned char *aHi, const unsigned char *aLo, const unsigned char *bHi,
+                                         const unsigned char *bLo, f32x16 &hh, f32x16 &hl, f32x16 &lh) {
+    using C = CqF16<H>;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hh[r] = hl[r] = lh[r] = 0.f;
+    h8 ah[3], al[3], bh[3], bl[3];
+    auto load = [&](int ks, int slot) {
+        ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
+        al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
+        bh[slot] = *reinterpret_cast<const h8 *>(bHi + 1024 * ks);
+        bl[slot] = *reinterpret_cast<const h8 *>(bLo + 1024 * ks);
+    };
+    load(0, 0);
+    load(1, 1);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < C::KS) load(ks + 2, (ks + 2) % 3);
+        const int sl = ks % 3;
+        hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bh[sl], hh, 0, 0, 0);
+        hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bl[sl], hl, 0, 0, 0);
+        lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl], bh[sl], lh, 0, 0, 0);
+        if (ks + 2 < C::KS) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// What a lane needs of an octave to scale and place its results (12 bins per octave or the generic column form)
+struct CqLane {
+    float colMul;                   // 2^-s_j sqrt(2^k) / sqrt(len_j) of the lane's image column
+    unsigned voffRe, voffIm;        // generic epilogue: lane = column, 16 rows
+    unsigned char *epiW;            // transposed epilogue (12 bins per octave): where the lane's 16 values go ...
+    const unsigned char *epiR;      // ... and where its four 12-byte pieces come from
+    unsigned voff12;
+    unsigned rowBytes, planeBytes;
+};
+
+__device__ __forceinline__ CqLane cq_lane_setup(int lane, unsigned char *sig, int rows, int colBase, int num, int timeLength,
+                                                const float *colMul, const float *scale, float octScale) {
+    const int i = lane & 31, g = lane >> 5;
+    CqLane L;
+    const bool colOk = i < 2 * rows, colIm = i >= rows;
+    const int colOff = colBase + (colOk ? (colIm ? i - rows : i) : 0);
+    L.colMul = colMul[i] * (octScale / scale[colOff]);
+    const unsigned OOR = 0x80000000u;
+    L.planeBytes = (unsigned)timeLength * (unsigned)num * 4u;
+    L.rowBytes = (unsigned)num * 4u;
+    const unsigned laneOff = (unsigned)(4 * g * num + colOff) * 4u;
+    L.voffRe = (colOk && !colIm) ? laneOff : OOR;
+    L.voffIm = (colOk && colIm) ? laneOff : OOR;
+    // the lane's 16 values go to epi[frame][plane][piece][word] ...
+    const int jj = i < 12 ? i : i - 12;
+    L.epiW = sig + (i < 24 ? (i >= 12 ? 64 : 0) + (jj / 3) * 16 + (jj % 3) * 4 : (i - 24) * 16 + 12) + 4 * g * 128;
+    // ... and leave as: store q, lane L -> frame 16 (q >> 1) + (L >> 2), plane q & 1, bins 3 (L & 3) .. + 2
+    L.epiR = sig + (lane >> 2) * 128 + (lane & 3) * 16;
+    L.voff12 = (unsigned)(lane >> 2) * L.rowBytes + (unsigned)(colBase + 3 * (lane & 3)) * 4u;
+    return L;
+}
+
+// results of one tile -> memory.  D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5).  Output: per clip one
+// raw buffer per plane, T x num floats; rows past timeLength and the padding columns fall out of range and are dropped
+// by the bounds check, so every tile issues the same number of stores.
+template <bool R12>
+__device__ __forceinline__ void cq_store_tile(const f32x16 &hh, const f32x16 &hl, const f32x16 &lh, float down, const CqLane &L,
+                                              float *outRe, float *outIm, int t0) {
+    const __amdgpu_buffer_rsrc_t rRe = __builtin_amdgcn_make_buffer_rsrc(outRe, 0, (int)L.planeBytes, RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t rIm = __builtin_amdgcn_make_buffer_rsrc(outIm, 0, (int)L.planeBytes, RSRC_RAW);
+    const float mul = down * L.colMul;
+    const unsigned tileOff = (unsigned)t0 * L.rowBytes;
+    if (R12) {
+        wave_lds_order();  // the last fragment reads are done: the window region is free
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            *reinterpret_cast<float *>(L.epiW + ((r & 3) + 8 * (r >> 2)) * 128) = (hh[r] + (hl[r] + lh[r])) * mul;
+        wave_lds_order();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(L.epiR + (q >> 1) * 2048 + (q & 1) * 64);
+            const u32x3 v3 = {v.x, v.y, v.z};
+            __builtin_amdgcn_raw_buffer_store_b96(v3, (q & 1) ? rIm : rRe, L.voff12 + tileOff + (unsigned)(q >> 1) * 16u * L.rowBytes, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ro = tileOff + (unsigned)((r & 3) + 8 * (r >> 2)) * L.rowBytes;  // scalar
+            const unsigned v = __float_as_uint((hh[r] + (hl[r] + lh[r])) * mul);
+            __builtin_amdgcn_raw_buffer_store_b32(v, rRe, L.voffRe + ro, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(v, rIm, L.voffIm + ro, 0, 0);
+        }
+    }
+}
+
+// image -> LDS: all of a thread's 16-byte loads in flight, then the stores
+__device__ __forceinline__ void cq_image_to_lds(const unsigned short *timeKernelH, unsigned char *Bl, int tid, int nth) {
+    const float4 *src = reinterpret_cast<const float4 *>(timeKernelH);
+    float4 *dstl = reinterpret_cast<float4 *>(Bl);
+    constexpr int Q = CqF16<128>::B_BYTES / 16;  // 4096
+    for (int e0 = tid; e0 < Q; e0 += 8 * nth) {
+        float4 tq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * nth < Q) tq[u] = src[e0 + u * nth];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * nth < Q) dstl[e0 + u * nth] = tq[u];
+    }
+}
+
 // R12: 12 bins per octave (the default ladder) -> the tile's results are transposed through LDS and leave as four
 // 12-byte-per-lane stores (one lane = 3 consecutive bins of one frame and plane); otherwise 32 dword stores.
 template <int H, bool R12>
@@ -84,39 +256,11 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
     unsigned char *Bl = smem_raw;                                  // [2][KS][64] x 16 bytes
     unsigned char *sig = smem_raw + C::B_BYTES + wave * C::WAVE_BYTES;
     const int i = lane & 31, g = lane >> 5;
-    {   // image -> LDS: all of a thread's 16-byte loads in flight, then the stores
-        const float4 *src = reinterpret_cast<const float4 *>(a.timeKernelH);
-        float4 *dstl = reinterpret_cast<float4 *>(Bl);
-        constexpr int Q = C::B_BYTES / 16;  // 4096
-        for (int e0 = tid; e0 < Q; e0 += 8 * nth) {
-            float4 tq[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) tq[u] = src[(e0 + u * nth) & (Q - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dstl[(e0 + u * nth) & (Q - 1)] = tq[u];  // Q is a multiple of 8 nth
-        }
-    }
+    cq_image_to_lds(a.timeKernelH, Bl, tid, nth);
     __syncthreads();
 
-    // Output: per clip one raw buffer per plane, T x num floats; rows past timeLength and the padding columns
-    // fall out of range and are dropped by the bounds check, so every tile issues the same NSTORE stores
-    // (the compiler can then count them: waiting for the prefetched window does not wait for stores).
-    const bool colOk = i < 2 * a.rows, colIm = i >= a.rows;
-    const int colOff = a.colBase + (colOk ? (colIm ? i - a.rows : i) : 0);
-    const float colMul = a.colMul[i] * (a.octScale / a.scale[colOff]);  // 2^-s_j sqrt(2^k) / sqrt(len_j)
+    const CqLane L = cq_lane_setup(lane, sig, a.rows, a.colBase, a.num, a.timeLength, a.colMul, a.scale, a.octScale);
     const unsigned OOR = 0x80000000u;
-    const unsigned planeBytes = (unsigned)a.timeLength * (unsigned)a.num * 4u;
-    const unsigned rowBytes = (unsigned)a.num * 4u;
-    // generic epilogue: lane = column, 16 rows
-    const unsigned laneOff = (unsigned)(4 * g * a.num + colOff) * 4u;
-    const unsigned voffRe = (colOk && !colIm) ? laneOff : OOR;
-    const unsigned voffIm = (colOk && colIm) ? laneOff : OOR;
-    // transposed epilogue (R12): the lane's 16 values go to epi[frame][plane][piece][word] ...
-    const int jj = i < 12 ? i : i - 12;
-    unsigned char *epiW = sig + (i < 24 ? (i >= 12 ? 64 : 0) + (jj / 3) * 16 + (jj % 3) * 4 : (i - 24) * 16 + 12) + 4 * g * 128;
-    // ... and leave as: store q, lane L -> frame 16 (q >> 1) + (L >> 2), plane q & 1, bins 3 (L & 3) .. + 2
-    const unsigned char *epiR = sig + (lane >> 2) * 128 + (lane & 3) * 16;
-    const unsigned voff12 = (unsigned)(lane >> 2) * rowBytes + (unsigned)(a.colBase + 3 * (lane & 3)) * 4u;
     // A fragment base of this lane: row i of copy i mod COPIES, first step
     const int cpy = i % C::COPIES;
     const unsigned char *aHi = sig + cpy * C::CS + C::at(i * H + 8 * g, cpy);
@@ -153,116 +297,309 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
     for (; t < totalTiles; t += stride) {
         const int clip = t / tilesPerClip, t0 = (t - clip * tilesPerClip) * 32;
         // ---- tile exponent: peak of the window -> [2^13, 2^14)
-        float peak = 0.f;
-#pragma unroll
-        for (int u = 0; u < C::NV; ++u) {
-            const float4 v = __builtin_bit_cast(float4, wnd[u]);
-            peak = fmaxf(peak, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        }
-        // wave maximum without LDS traffic: four DPP steps give every row of 16 lanes its maximum, the four
-        // rows meet on the scalar unit (non-negative floats order like their bit patterns)
-        peak = fmaxf(peak, dpp_f(peak, 0xB1));   // quad_perm [1,0,3,2]
-        peak = fmaxf(peak, dpp_f(peak, 0x4E));   // quad_perm [2,3,0,1]
-        peak = fmaxf(peak, dpp_f(peak, 0x141));  // row_half_mirror
-        peak = fmaxf(peak, dpp_f(peak, 0x140));  // row_mirror
-        const unsigned pk = __float_as_uint(peak);
-        const unsigned p01 = max((unsigned)__builtin_amdgcn_readlane((int)pk, 0), (unsigned)__builtin_amdgcn_readlane((int)pk, 16));
-        const unsigned p23 = max((unsigned)__builtin_amdgcn_readlane((int)pk, 32), (unsigned)__builtin_amdgcn_readlane((int)pk, 48));
-        const int pe = (int)((max(p01, p23) >> 23) & 0xff) - 127;  // floor(log2 peak) of a normal
-        int e = 13 - pe;
-        if (pe == -127) e = 0;  // zero / subnormal window
-        e = e > 126 ? 126 : e;
+        const int e = cq_window_exponent<H>(wnd, lane);
         const float up = __uint_as_float((unsigned)(e + 127) << 23);      // 2^e
         const float down = __uint_as_float((unsigned)(127 - e) << 23);    // 2^-e
         // ---- window -> (xh, xl) planes (every copy)
         wave_lds_order();  // the fragment / epilogue reads of the previous tile are done
+        cq_convert_window<H>(wnd, up, sig, lane);
+        wave_lds_order();
+        if (t + stride < totalTiles) fetch(t + stride);
+        f32x16 hh, hl, lh;
+        cq_kloop<H>(aHi, aLo, bHi, bLo, hh, hl, lh);
+        const long long po = (long long)clip * a.outStride;
+        cq_store_tile<R12>(hh, hl, lh, down, L, a.outRe + po, a.outIm + po, t0);
+    }
+}
+
+// ================================================================================================================
+// k_cqt_pyramid: the default ladder (N = 512, 12 bins per octave, seven octaves, hop 128 ... 2) in ONE persistent
+// launch.  Reference: the octave recursion of _cqtObj_cqt (src/cqt_algorithm.c:951-1048) -- per octave frame + FFT +
+// sparse kernel product, then the 2:1 "Fast" resampler (src/dsp/resample_algorithm.c:430-521) makes the next level.
+//
+// A workgroup of eleven waves walks a run of 32-frame tiles of one clip, one STEP per tile:
+//   * waves 0-6, CONSUMERS: wave k owns octave level k (hop 128 >> k).  Per step: the level's window -> (xh, xl) planes
+//     in the wave's own LDS region -> 96 MFMAs -> the tile's 12 bins of 32 rows to memory; the next window is already
+//     on its way into registers while the matrix cores work.  Exactly the tile of k_cqt_octave_f16 above.
+//   * waves 7-10, PRODUCERS: the decimation chain, level k -> k+1 in BLOCKS of 32 hop_(k+1) samples (what a tile of
+//     level k+1 advances by): the 63-tap FIR of k_cqt_decimate (afx_cqt.hip), same taps in the same order, 256 outputs
+//     per round from even/odd copies of the input in the wave's LDS region.  Stage 0 (clip -> level 1) takes two
+//     waves, stage 1 one, stages 2-5 share the last.
+// The level signals live in per-workgroup RINGS in global memory (8192 ... 1024 samples per level, 68 KB per
+// workgroup): written once, read a step or two later by the same CU, overwritten four blocks on -- they stay in the
+// L2 and never reach HBM, a clip is read from HBM once.  Ring loads bypass the CU's L1 (sc0 sc1), ring stores are
+// drained (vmcnt(0)) before the step's s_barrier: ONE barrier per step is the only synchronisation.
+//
+// Schedule (step s; "block b of level k" = samples [32 b hop_k, 32 (b+1) hop_k)):
+//   stage k writes block s - 2k of level k+1; it reads blocks b-1 .. b+1 of level k (the clip for k = 0), whose last
+//   one was written in step s - 1;
+//   consumer k >= 1 computes tile s - 2k - e_k (e = 1,1,1,1,2,4: the blocks a window reaches past its tile), whose
+//   window it fetched during step s - 1 from blocks written up to step s - 2; consumer 0 reads the clip and follows
+//   consumer 1.  A ring of 4 blocks (8 / 16 for the two smallest levels) holds everything alive at a step.
+// A run [t0, t1) therefore takes steps t0 - 9 ... t1 + 15: nine blocks of lead-in for the dependency cone of the
+// lowest octave, fifteen steps for the pipeline to drain (tools/proto_cqt_pyramid.py checks every read of the
+// schedule against the writes).  Positions outside a level's signal are written as zeros, so no load needs a mask
+// except the consumer's validLength rule.
+// Arithmetic is the per-octave path's, operation for operation: results are bit-identical to it.
+
+namespace pyr {
+constexpr int CONSUMERS = 7, PRODUCERS = 4, WAVES = CONSUMERS + PRODUCERS;
+constexpr int LEAD = 9, DRAIN = 15;
+__host__ __device__ constexpr int ring_size(int k) { return k == 1 ? 8192 : k == 2 ? 4096 : k == 3 ? 2048 : 1024; }
+__host__ __device__ constexpr int ring_off(int k) {
+    return k <= 1 ? 0 : k == 2 ? 8192 : k == 3 ? 12288 : k == 4 ? 14336 : k == 5 ? 15360 : 16384;
+}
+static_assert(ring_off(6) + ring_size(6) == AFX_CQT_PYR_RING_FLOATS, "ring layout");
+__host__ __device__ constexpr int win_ahead(int k) { return k == 5 ? 2 : k == 6 ? 4 : 1; }
+__host__ __device__ constexpr int lag(int k) { return k == 0 ? 3 : 2 * k + win_ahead(k); }
+__host__ __device__ constexpr int plane_bytes(int k) {
+    return k == 0 ? CqF16<128>::WAVE_BYTES : k == 1 ? CqF16<64>::WAVE_BYTES : k == 2 ? CqF16<32>::WAVE_BYTES
+         : k == 3 ? CqF16<16>::WAVE_BYTES : k == 4 ? CqF16<8>::WAVE_BYTES : k == 5 ? CqF16<4>::WAVE_BYTES : CqF16<2>::WAVE_BYTES;
+}
+__host__ __device__ constexpr int plane_off(int k) { return k == 0 ? 0 : plane_off(k - 1) + plane_bytes(k - 1); }
+constexpr int FIR_WORDS = 296;                       // even / odd input copies of one round, floats each
+constexpr int FIR_BYTES = 2 * FIR_WORDS * 4;
+constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + PRODUCERS * FIR_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+constexpr int AUX_L2 = 17;                           // sc0 sc1: served by the L2, never by this CU's L1
+// blocks of level k (1..6) a run [t0, t1) needs: [t0 - need_back(k), t1 + need_ahead(k)]
+__host__ __device__ constexpr int need_back(int k) { return 10 - k; }
+__host__ __device__ constexpr int need_ahead(int k) { return 9 - k; }
+}  // namespace pyr
+
+__device__ __forceinline__ void pyr_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ---- consumer: octave level K of the run [t0c, t1c) of `clip`
+template <int K>
+__device__ __forceinline__ void pyr_consumer(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int clip,
+                                             int t0c, int t1c) {  // one run
+    constexpr int H = 128 >> K;
+    using C = CqF16<H>;
+    constexpr int NVA = K == 0 ? C::NV / 2 : C::NV;  // level 0: half of the next window before the K loop, half behind it
+    constexpr unsigned RMASK = (unsigned)pyr::ring_size(K) - 1u;
+    unsigned char *Bl = smem;
+    unsigned char *sig = smem + C::B_BYTES + pyr::plane_off(K);
+    const int i = lane & 31, g = lane >> 5;
+    const CqLane L = cq_lane_setup(lane, sig, 12, (6 - K) * 12, a.num, a.timeLength, a.colMul, a.scale, a.octScale[K]);
+    const int cpy = i % C::COPIES;
+    const unsigned char *aHi = sig + cpy * C::CS + C::at(i * H + 8 * g, cpy);
+    const unsigned char *aLo = aHi + C::PART;
+    const unsigned char *bHi = Bl + lane * 16;
+    const unsigned char *bLo = bHi + C::KS * 64 * 16;
+    const int valid = a.valid[K];
+    // level 0: the clip, framed samples only (the bounds check supplies the zero padding on both sides); other
+    // levels: the ring (zeros outside the signal are IN the ring; samples in [valid, len) are masked below)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        K == 0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long long)clip * a.xStride), 0, valid * 4, RSRC_RAW)
+               : __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(K), 0, pyr::ring_size(K) * 4, RSRC_RAW);
+    float *outRe = a.outRe + (long long)clip * a.outStride, *outIm = a.outIm + (long long)clip * a.outStride;
+    u32x4 wnd[C::NV];
+    auto fetch = [&](int t, int u0, int u1) {
+        const int p0 = t * 32 * H - (C::N >> 1);
 #pragma unroll
         for (int u = 0; u < C::NV; ++u) {
-            const int s = 4 * (lane + 64 * u);
-            if (s < C::S) {
-                const float4 v = __builtin_bit_cast(float4, wnd[u]);
-                unsigned hi0, hi1, lo0, lo1;
-                split_pair(v.x, v.y, up, hi0, lo0);
-                split_pair(v.z, v.w, up, hi1, lo1);
-                const int base = C::MARGIN + 2 * s + (C::PAD ? 16 * (s / H) : 0);
+            if (u < u0 || u >= u1) continue;
+            const int pos = p0 + 4 * (lane + 64 * u);
+            if (K == 0) wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pos * 4, 0, 0);
+            else wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)pos & RMASK) * 4u), 0, pyr::AUX_L2);
+        }
+    };
+    const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
+    for (int s = s0; s <= s1; ++s) {
+        const int t = s - pyr::lag(K);
+        const bool act = t >= t0c && t < t1c, actNext = t + 1 >= t0c && t + 1 < t1c;  // wave-uniform
+        float down = 0.f;
+        if (act) {
+            const int p0 = t * 32 * H - (C::N >> 1);
+            if (K != 0 && p0 + C::S > valid) {  // stft_algorithm.c:838-843: samples past validLength are not framed
 #pragma unroll
-                for (int c = 0; c < C::COPIES; ++c) {
-                    unsigned char *d = sig + c * C::CS + base - 2 * c * H;
-                    if ((2 * c * H) % 8 == 0) {
-                        *reinterpret_cast<uint2 *>(d) = make_uint2(hi0, hi1);
-                        *reinterpret_cast<uint2 *>(d + C::PART) = make_uint2(lo0, lo1);
-                    } else {
-                        reinterpret_cast<unsigned *>(d)[0] = hi0;
-                        reinterpret_cast<unsigned *>(d)[1] = hi1;
-                        reinterpret_cast<unsigned *>(d + C::PART)[0] = lo0;
-                        reinterpret_cast<unsigned *>(d + C::PART)[1] = lo1;
-                    }
+                for (int u = 0; u < C::NV; ++u) {
+                    const int pos = p0 + 4 * (lane + 64 * u);
+                    if (pos >= valid) wnd[u].x = 0u;
+                    if (pos + 1 >= valid) wnd[u].y = 0u;
+                    if (pos + 2 >= valid) wnd[u].z = 0u;
+                    if (pos + 3 >= valid) wnd[u].w = 0u;
                 }
+            }
+            const int e = cq_window_exponent<H>(wnd, lane);
+            const float up = __uint_as_float((unsigned)(e + 127) << 23);
+            down = __uint_as_float((unsigned)(127 - e) << 23);
+            wave_lds_order();
+            cq_convert_window<H>(wnd, up, sig, lane);
+            wave_lds_order();
+        }
+        if (actNext) fetch(t + 1, 0, NVA);
+        f32x16 hh, hl, lh;
+        if (act) cq_kloop<H>(aHi, aLo, bHi, bLo, hh, hl, lh);
+        // the prefetched window is in its registers BEFORE the step's barrier (its ring blocks are overwritten three
+        // steps on; nothing younger is in flight here, so this wait costs nothing) ...
+#pragma unroll
+        for (int u = 0; u < NVA; ++u) PIN(wnd[u]);
+        if (act) cq_store_tile<true>(hh, hl, lh, down, L, outRe, outIm, t * 32);
+        // ... level 0 reads the clip, nothing overwrites it: the second half follows the tile's stores
+        if (K == 0 && actNext) fetch(t + 1, NVA, C::NV);
+        pyr_barrier();
+    }
+}
+
+// ---- producer: one round of the 2:1 resampler, 256 outputs i0 ... i0 + 255 of level k+1 (the first nOut stored), four per
+// lane.  k_cqt_decimate's arithmetic: even / odd copies of the input window in LDS, XE[m] = x[2 (i0 - 15 + m)],
+// XO[m] = x[2 (i0 - 16 + m) + 1]; left taps j = 0..31 at x[2i - j], then right taps j = 1..31 at x[2i + j], one fma chain.
+template <bool CLIP>
+__device__ __forceinline__ void pyr_fir_round(const __amdgpu_buffer_rsrc_t &src, unsigned srcMask, int i0, int nOut,
+                                              const AfxCqtPyramidArgs &a, const __amdgpu_buffer_rsrc_t &dst, unsigned dstMask,
+                                              int dstLen, float *XE, float *XO, int lane) {
+    const int i = i0 + 4 * lane;
+    const bool mine = 4 * lane < nOut;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i0 < dstLen && i0 + 256 > 0) {  // (a block outside the signal is zeros)
+        // 16 bytes at s_q = 2 i0 - 32 + 4 q hold XE[2q-1], XO[2q], XE[2q], XO[2q+1]; q = 0 ... 146
+        u32x4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = lane + 64 * u;
+            if (q < 147) {
+                const int sq = 2 * i0 - 32 + 4 * q;
+                v[u] = CLIP ? __builtin_amdgcn_raw_buffer_load_b128(src, sq * 4, 0, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(src, (int)(((unsigned)sq & srcMask) * 4u), 0, pyr::AUX_L2);
+            }
+        }
+        wave_lds_order();  // the previous round's reads are done
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = lane + 64 * u;
+            if (q < 147) {
+                const float4 f = __builtin_bit_cast(float4, v[u]);
+                const int m = 2 * q - 1;
+                if (m >= 0) XE[m] = f.x;
+                XO[m + 1] = f.y;
+                XE[m + 1] = f.z;
+                XO[m + 2] = f.w;
             }
         }
         wave_lds_order();
-        if (t + stride < totalTiles) fetch(t + stride);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 ev[9], ov[9];
+        const float *pe = XE + 4 * lane, *po = XO + 4 * lane;
+        RD128_P(ev[0], pe, 0);   RD128_P(ov[0], po, 0);   RD128_P(ev[1], pe, 16);  RD128_P(ov[1], po, 16);
+        RD128_P(ev[2], pe, 32);  RD128_P(ov[2], po, 32);  RD128_P(ev[3], pe, 48);  RD128_P(ov[3], po, 48);
+        RD128_P(ev[4], pe, 64);  RD128_P(ov[4], po, 64);  RD128_P(ev[5], pe, 80);  RD128_P(ov[5], po, 80);
+        RD128_P(ev[6], pe, 96);  RD128_P(ov[6], po, 96);  RD128_P(ev[7], pe, 112); RD128_P(ov[7], po, 112);
+        RD128_P(ev[8], pe, 128); RD128_P(ov[8], po, 128);
+        LDS_WAIT_N(0);
+        float E[36], O[36];
+#pragma unroll
+        for (int b = 0; b < 9; ++b) {
+            PIN(ev[b]);
+            PIN(ov[b]);
+            E[4 * b] = ev[b].x; E[4 * b + 1] = ev[b].y; E[4 * b + 2] = ev[b].z; E[4 * b + 3] = ev[b].w;
+            O[4 * b] = ov[b].x; O[4 * b + 1] = ov[b].y; O[4 * b + 2] = ov[b].z; O[4 * b + 3] = ov[b].w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {  // x[2i - j]: even j -> x[2 (i - j/2)], odd j -> x[2 (i - (j+1)/2) + 1]
+                const float x = (j & 1) ? O[q + 16 - (j + 1) / 2] : E[q + 15 - j / 2];
+                acc = __fmaf_rn(a.taps[j], x, acc);
+            }
+#pragma unroll
+            for (int j = 1; j < 32; ++j) {  // x[2i + j]: even j -> x[2 (i + j/2)], odd j -> x[2 (i + (j-1)/2) + 1]
+                const float x = (j & 1) ? O[q + 16 + (j - 1) / 2] : E[q + 15 + j / 2];
+                acc = __fmaf_rn(a.taps[j], x, acc);
+            }
+            r[q] = (i + q >= 0 && i + q < dstLen) ? acc / a.sqrtRatio : 0.f;
+        }
+    }
+    if (mine) {
+        const u32x4 o = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, dst, (int)(((unsigned)i & dstMask) * 4u), 0, 0);
+    }
+}
 
-        // ---- K loop: 32 steps x (xh gh, xh gl, xl gh), operands two steps ahead
-        f32x16 hh, hl, lh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hh[r] = hl[r] = lh[r] = 0.f;
-        h8 ah[3], al[3], bh[3], bl[3];
-        auto load = [&](int ks, int slot) {
-            ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
-            al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
-            bh[slot] = *reinterpret_cast<const h8 *>(bHi + 1024 * ks);
-            bl[slot] = *reinterpret_cast<const h8 *>(bLo + 1024 * ks);
-        };
-        load(0, 0);
-        load(1, 1);
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 < C::KS) load(ks + 2, (ks + 2) % 3);
-            const int sl = ks % 3;
-            hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bh[sl], hh, 0, 0, 0);
-            hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bl[sl], hl, 0, 0, 0);
-            lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl], bh[sl], lh, 0, 0, 0);
-            if (ks + 2 < C::KS) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
+// stage k (level k -> k+1), block b, rounds [r0, r1) of the block's 32 hop_(k+1) outputs
+__device__ __forceinline__ void pyr_stage(int k, int b, int r0, int r1, const AfxCqtPyramidArgs &a, float *wgRing, int clip,
+                                          float *XE, float *XO, int lane) {
+    const int blockOut = 32 * (64 >> k);  // 2048, 1024, ..., 64
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(k + 1), 0, pyr::ring_size(k + 1) * 4, RSRC_RAW);
+    const unsigned dstMask = (unsigned)pyr::ring_size(k + 1) - 1u;
+    if (k == 0) {
+        const __amdgpu_buffer_rsrc_t src =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long long)clip * a.xStride), 0, a.len[0] * 4, RSRC_RAW);
+        for (int r = r0; r < r1; ++r)
+            pyr_fir_round<true>(src, 0u, b * blockOut + 256 * r, 256, a, dst, dstMask, a.len[1], XE, XO, lane);
+    } else {
+        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(k), 0, pyr::ring_size(k) * 4, RSRC_RAW);
+        const unsigned srcMask = (unsigned)pyr::ring_size(k) - 1u;
+        for (int r = r0; r < r1; ++r)
+            pyr_fir_round<false>(src, srcMask, b * blockOut + 256 * r, blockOut < 256 ? blockOut : 256, a, dst, dstMask, a.len[k + 1], XE, XO,
+                                 lane);
+    }
+}
+
+__device__ __forceinline__ void pyr_producer(int pw, const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing,
+                                             int clip, int t0c, int t1c) {
+    float *XE = reinterpret_cast<float *>(smem + CqF16<128>::B_BYTES + pyr::plane_off(7) + pw * pyr::FIR_BYTES);
+    float *XO = XE + pyr::FIR_WORDS;
+    const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
+    // stage k writes block s - 2k of level k+1 when the run needs that block
+    auto due = [&](int k, int s) {
+        const int b = s - 2 * k;
+        return b >= t0c - pyr::need_back(k + 1) && b <= t1c + pyr::need_ahead(k + 1);
+    };
+    for (int s = s0; s <= s1; ++s) {
+        if (pw < 2) {
+            if (due(0, s)) pyr_stage(0, s, 4 * pw, 4 * pw + 4, a, wgRing, clip, XE, XO, lane);
+        } else if (pw == 2) {
+            if (due(1, s)) pyr_stage(1, s - 2, 0, 4, a, wgRing, clip, XE, XO, lane);
+        } else {
+            if (due(2, s)) pyr_stage(2, s - 4, 0, 2, a, wgRing, clip, XE, XO, lane);
+            if (due(3, s)) pyr_stage(3, s - 6, 0, 1, a, wgRing, clip, XE, XO, lane);
+            if (due(4, s)) pyr_stage(4, s - 8, 0, 1, a, wgRing, clip, XE, XO, lane);
+            if (due(5, s)) pyr_stage(5, s - 10, 0, 1, a, wgRing, clip, XE, XO, lane);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
-        {
-            const long long po = (long long)clip * a.outStride;
-            const __amdgpu_buffer_rsrc_t rRe = __builtin_amdgcn_make_buffer_rsrc(a.outRe + po, 0, (int)planeBytes, RSRC_RAW);
-            const __amdgpu_buffer_rsrc_t rIm = __builtin_amdgcn_make_buffer_rsrc(a.outIm + po, 0, (int)planeBytes, RSRC_RAW);
-            const float mul = down * colMul;
-            const unsigned tileOff = (unsigned)t0 * rowBytes;
-            if (R12) {
-                wave_lds_order();  // the last fragment reads are done: the window region is free
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    *reinterpret_cast<float *>(epiW + ((r & 3) + 8 * (r >> 2)) * 128) = (hh[r] + (hl[r] + lh[r])) * mul;
-                wave_lds_order();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(epiR + (q >> 1) * 2048 + (q & 1) * 64);
-                    const u32x3 v3 = {v.x, v.y, v.z};
-                    __builtin_amdgcn_raw_buffer_store_b96(v3, (q & 1) ? rIm : rRe, voff12 + tileOff + (unsigned)(q >> 1) * 16u * rowBytes, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned ro = tileOff + (unsigned)((r & 3) + 8 * (r >> 2)) * rowBytes;  // scalar
-                    const unsigned v = __float_as_uint((hh[r] + (hl[r] + lh[r])) * mul);
-                    __builtin_amdgcn_raw_buffer_store_b32(v, rRe, voffRe + ro, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(v, rIm, voffIm + ro, 0, 0);
-                }
-            }
-        }
+        VM_WAIT_ALL();  // the blocks are in the L2 before the other waves pass the barrier
+        pyr_barrier();
+    }
+}
+
+// the runs of this workgroup, one after the other; ROLE 0-6: consumer of that level, 7: producer (wave - 7)
+template <int ROLE>
+__device__ __forceinline__ void pyr_role(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int items) {
+    const int nT = (a.timeLength + 31) / 32;
+    const int pw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - pyr::CONSUMERS;
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+        const int clip = it / a.chunksPerClip, chunk = it - clip * a.chunksPerClip;
+        const int t0c = chunk * a.tilesPerChunk;
+        const int t1c = t0c + a.tilesPerChunk < nT ? t0c + a.tilesPerChunk : nT;
+        if (t0c >= t1c) continue;  // (uniform over the workgroup)
+        if (ROLE < pyr::CONSUMERS) pyr_consumer<(ROLE < pyr::CONSUMERS ? ROLE : 0)>(a, smem, lane, wgRing, clip, t0c, t1c);
+        else pyr_producer(pw, a, smem, lane, wgRing, clip, t0c, t1c);
+    }
+}
+
+__global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidArgs a, int items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cq_image_to_lds(a.timeKernelH, smem_raw, tid, 64 * pyr::WAVES);
+    __syncthreads();
+    float *wgRing = a.ring + (size_t)blockIdx.x * AFX_CQT_PYR_RING_FLOATS;
+    // (the loop over the workgroup's runs sits INSIDE every role: around the switch, the compiler hoists the per-lane
+    // constants of all eight roles in front of it and spills them)
+    switch (wave) {
+        case 0: pyr_role<0>(a, smem_raw, lane, wgRing, items); break;
+        case 1: pyr_role<1>(a, smem_raw, lane, wgRing, items); break;
+        case 2: pyr_role<2>(a, smem_raw, lane, wgRing, items); break;
+        case 3: pyr_role<3>(a, smem_raw, lane, wgRing, items); break;
+        case 4: pyr_role<4>(a, smem_raw, lane, wgRing, items); break;
+        case 5: pyr_role<5>(a, smem_raw, lane, wgRing, items); break;
+        case 6: pyr_role<6>(a, smem_raw, lane, wgRing, items); break;
+        default: pyr_role<7>(a, smem_raw, lane, wgRing, items); break;
     }
 }
 
@@ -314,4 +651,36 @@ extern "C" int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
         case 2: return dispatch_f16<2>(a, stream);
         default: return AFX_ERR_UNSUPPORTED;
     }
+}
+
+// ---- the pyramid launch ----
+extern "C" int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerClip, int *tilesPerChunk) {
+    if (batch <= 0 || timeLength <= 0) return 0;
+    const int nT = (timeLength + 31) / 32;
+    // runs of one clip: as many as fill the CUs, but long enough that the 24 steps of lead-in and drain stay small
+    int cpc = AFX_CQT_PYR_MAX_WGS / batch;
+    if (cpc > nT / 48) cpc = nT / 48;
+    if (cpc < 1) cpc = 1;
+    int tpc = (nT + cpc - 1) / cpc;
+    if (const char *e = getenv("AFX_CQT_PYR_TILES"))  // tests: short runs, so that small inputs cross run boundaries
+        if (atoi(e) > 0 && atoi(e) < tpc) tpc = atoi(e);
+    cpc = (nT + tpc - 1) / tpc;  // no empty runs
+    if (chunksPerClip) *chunksPerClip = cpc;
+    if (tilesPerChunk) *tilesPerChunk = tpc;
+    const long long items = (long long)batch * cpc;
+    return (int)(items < AFX_CQT_PYR_MAX_WGS ? items : AFX_CQT_PYR_MAX_WGS);
+}
+
+extern "C" int afxk_cqt_pyramid(const AfxCqtPyramidArgs *a, void *stream) {
+    if (!a->x || !a->timeKernelH || !a->colMul || !a->scale || !a->outRe || !a->outIm || !a->ring) return AFX_ERR_ARG;
+    if (a->batch <= 0 || a->timeLength <= 0 || a->chunksPerClip <= 0 || a->tilesPerChunk <= 0) return AFX_ERR_ARG;
+    // 32-bit byte offsets inside one clip's signal and one clip's output plane
+    if (a->len[0] > (1 << 28) || (long long)a->timeLength * a->num > (1LL << 28)) return AFX_ERR_UNSUPPORTED;
+    const long long items = (long long)a->batch * a->chunksPerClip;
+    if (items > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)(items < AFX_CQT_PYR_MAX_WGS ? items : AFX_CQT_PYR_MAX_WGS);
+    AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, pyr::LDS_BYTES));
+    hipLaunchKernelGGL(k_cqt_pyramid, dim3(grid), dim3(64 * pyr::WAVES), pyr::LDS_BYTES, (hipStream_t)stream, *a, (int)items);
+    AFX_LAUNCH_CHECK("k_cqt_pyramid");
+    return AFX_OK;
 }

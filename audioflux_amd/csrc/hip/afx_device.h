@@ -315,6 +315,38 @@ typedef struct {
 int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
 /* f16 matrix-core variant; AFX_ERR_UNSUPPORTED when the plan / alignment is outside its scope */
 int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream);
+/* The whole default ladder in ONE persistent launch (afx_cqt_f16.hip: k_cqt_pyramid): N = 512, 12 bins per octave,
+ * seven octaves, hop 128 halving to 2.  Every workgroup walks a run of 32-frame tiles of one clip; seven of its
+ * waves own one octave each (window -> f16 (hi, lo) planes -> matrix-core product -> rows), four run the 63-tap 2:1
+ * decimation chain one block per level and step ahead of them; the level signals live in per-workgroup rings of
+ * `ring` that stay in the L2, so a clip is read from HBM once and no level signal goes back to it.
+ * cqt_algorithm.c:951-1048 (octave recursion), dsp/resample_algorithm.c:430-521 (the resampler). */
+#define AFX_CQT_PYR_LEVELS 7
+#define AFX_CQT_PYR_RING_FLOATS 17408 /* per workgroup: rings of 8192, 4096, 2048, 1024, 1024, 1024 samples */
+#define AFX_CQT_PYR_MAX_WGS 256
+typedef struct {
+    const float *x;          /* device clips (level 0)                                  */
+    long long xStride;       /* samples between clips                                   */
+    int batch, timeLength, num; /* clips, frames per clip, output row pitch (84)       */
+    int len[AFX_CQT_PYR_LEVELS];   /* samples of every level (floorf(len/2) ladder)    */
+    int valid[AFX_CQT_PYR_LEVELS]; /* framed samples of every level (stft_algorithm.c:838-843) */
+    const unsigned short *timeKernelH; /* as AfxCqtOctaveArgs                           */
+    const float *colMul, *scale;
+    float octScale[AFX_CQT_PYR_LEVELS]; /* sqrt(2^k) of level k (cqt_algorithm.c:1218-1221)   */
+    float *outRe, *outIm;    /* device [batch][T, num]                                  */
+    long long outStride;
+    float *ring;             /* device scratch, AFX_CQT_PYR_RING_FLOATS floats per workgroup */
+    float taps[32];          /* resampler FIR                                           */
+    float sqrtRatio;
+    int chunksPerClip, tilesPerChunk; /* work items: clip-major runs of tiles            */
+    /* chroma in the same launch (chromaNum == 12 == bins per octave): NULL = off         */
+    float *chroma;           /* device [batch][T, 12]                                   */
+    int chromaClass[12];     /* class of bin j of an octave (the 0/1 folding matrix)    */
+    int chromaMag, chromaNorm; /* |Q| instead of |Q|^2; 0 none 1 max 2 min 3 P2 4 P1     */
+} AfxCqtPyramidArgs;
+/* workgroups the launch will use (the caller sizes `ring` with it) */
+int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerClip, int *tilesPerChunk);
+int afxk_cqt_pyramid(const AfxCqtPyramidArgs *a, void *stream);
 /* batch clips: x + b*xStride -> y + b*yStride */
 int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, int dstLen,
                       long long yStride, int batch, const float *taps32, float sqrtRatio,

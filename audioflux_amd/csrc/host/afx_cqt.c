@@ -55,6 +55,8 @@ struct OpaqueCQT {
     size_t capX;
     float *dSig[2];          /* ping-pong decimated signals, all clips of a batch */
     size_t capSig[2];
+    float *dRing;            /* level rings of the one-launch ladder (k_cqt_pyramid), per workgroup */
+    size_t capRing;
     void *lastStream;        /* stream of the previous device call (scratch ordering) */
     int lastUsed;
     float *dOut;             /* re | im [T,num] */
@@ -492,6 +494,68 @@ void cqtObj_setScale(CQTObj o, int flag) {
     if (o) o->isScale = flag;
 }
 
+/* ---- the default ladder in one launch (afx_cqt_f16.hip: k_cqt_pyramid) ----
+ * N = 512, 12 bins per octave, seven octaves, hop 128, one image for all octaves, f16 matrix-core plan, centre
+ * padding.  AFX_CQT_PYRAMID=0 (read at the first call of the process) keeps the per-octave launches. */
+static int cqt_pyramid_ok(CQTObj o, int dataLength) {
+    static int env = -1;
+    if (env < 0) {
+        const char *e = getenv("AFX_CQT_PYRAMID");
+        env = !(e && e[0] == '0');
+    }
+    return env && !afxdev_no_fused() && o->dTimeKernelH && o->dColMul && o->colTiles == 1 && o->radix2Exp == 9 &&
+           o->binPerOctave == 12 && o->octaveNum == AFX_CQT_PYR_LEVELS && o->slideLength == 128 && !o->isContinue &&
+           !o->vFlag && dataLength > 0 && dataLength <= (1 << 28) &&
+           afxk_cqt_pyramid_plan(1, dataLength / 128 + 1, NULL, NULL) > 0; /* (0: a device layer without the kernel) */
+}
+
+/* dX + b*xStride (b < batch) -> dRe/dIm [batch][T, num] (+ dChroma [batch][T, 12] when cn == 12); asynchronous on `stream` */
+static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength, long long xStride, float *dRe,
+                           float *dIm, float *dChroma, int isMag, int nrm, void *stream) {
+    AfxCqtPyramidArgs a;
+    memset(&a, 0, sizeof(a));
+    const int T = dataLength / o->slideLength + 1;
+    const int wgs = afxk_cqt_pyramid_plan(batch, T, &a.chunksPerClip, &a.tilesPerChunk);
+    int st = afxdev_reserve((void **)&o->dRing, &o->capRing, sizeof(float) * (size_t)wgs * AFX_CQT_PYR_RING_FLOATS);
+    if (st != AFX_OK) return st;
+    a.x = dX;
+    a.xStride = xStride;
+    a.batch = batch;
+    a.timeLength = T;
+    a.num = o->num;
+    int len = dataLength, hop = o->slideLength;
+    for (int k = 0; k < AFX_CQT_PYR_LEVELS; k++) {
+        const int frames = len / hop + 1;
+        a.len[k] = len;
+        a.valid[k] = len - (frames > 1 ? len % hop : 0);          /* stft_algorithm.c:838-843 */
+        a.octScale[k] = k == 0 ? 1.f : sqrtf((float)(1 << k));    /* dLenArr, cqt_algorithm.c:1218-1221 */
+        len = (int)floorf(len * 0.5f);                            /* resampleObj_calDataLength */
+        hop /= 2;
+    }
+    a.timeKernelH = o->dTimeKernelH;
+    a.colMul = o->dColMul;
+    a.scale = o->isScale ? o->dScaleOn : o->dScaleOff;
+    a.outRe = dRe;
+    a.outIm = dIm;
+    a.outStride = (long long)T * o->num;
+    a.ring = o->dRing;
+    memcpy(a.taps, o->taps, sizeof(a.taps));
+    a.sqrtRatio = sqrtf(0.5f);
+    a.chroma = dChroma;
+    a.chromaMag = isMag;
+    a.chromaNorm = nrm;
+    if (dChroma) { /* class of bin j of an octave: the row of the folding matrix that holds it */
+        for (int j = 0; j < 12; j++) {
+            a.chromaClass[j] = -1;
+            for (int c = 0; c < 12; c++)
+                for (int q = o->foldLists.start[c]; q < o->foldLists.start[c + 1]; q++)
+                    if (o->foldLists.bins[q] == j) a.chromaClass[j] = c;
+            if (a.chromaClass[j] < 0) return AFX_ERR_UNSUPPORTED;
+        }
+    }
+    return afxk_cqt_pyramid(&a, stream);
+}
+
 /* The octave recursion on HBM-resident clips: dX + b*xStride (b < batch, dataLength
  * samples each) -> dRe/dIm [batch][T, num].  dSig[0/1] hold the decimated signals of all
  * clips (pitch = dataLength/2 samples).  Asynchronous on `stream`. */
@@ -623,7 +687,9 @@ void cqtObj_cqt(CQTObj o, float *dataArr, int dataLength, float *mRealArr, float
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dX, &o->capX, sizeof(float) * (size_t)dataLength);
     if (st == AFX_OK) st = afxdev_h2d(o->dX, src, sizeof(float) * (size_t)dataLength, o->stream);
     float *dRe = o->dOut, *dIm = o->dOut + (size_t)T * o->num;
-    if (st == AFX_OK) st = cqt_run_device(o, o->dX, 1, dataLength, dataLength, dRe, dIm, o->stream);
+    if (st == AFX_OK)
+        st = cqt_pyramid_ok(o, dataLength) ? cqt_run_pyramid(o, o->dX, 1, dataLength, dataLength, dRe, dIm, NULL, 0, 0, o->stream)
+                                           : cqt_run_device(o, o->dX, 1, dataLength, dataLength, dRe, dIm, o->stream);
     if (st == AFX_OK) st = afxdev_d2h(mRealArr, dRe, outB, o->stream);
     if (st == AFX_OK) st = afxdev_d2h(mImageArr, dIm, outB, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
@@ -670,12 +736,16 @@ int cqtObj_cqtBatchDevice(CQTObj o, const float *dData, int batch, int dataLengt
     const int T = dataLength / o->slideLength + 1;
     /* scratch is shared between calls: order this call after the previous one's stream */
     if (o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
-    const int chunk = cqt_chunk_clips(o, T, batch);
-    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
-        const int nb = batch - b0 < chunk ? batch - b0 : chunk;
-        st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride,
-                            dReal + (long long)b0 * T * o->num, dImag + (long long)b0 * T * o->num,
-                            hipStream);
+    if (st == AFX_OK && cqt_pyramid_ok(o, dataLength)) { /* one launch for all clips: nothing to merge between passes */
+        st = cqt_run_pyramid(o, dData, batch, dataLength, clipStride, dReal, dImag, NULL, 0, 0, hipStream);
+    } else {
+        const int chunk = cqt_chunk_clips(o, T, batch);
+        for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
+            const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+            st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride,
+                                dReal + (long long)b0 * T * o->num, dImag + (long long)b0 * T * o->num,
+                                hipStream);
+        }
     }
     o->lastStream = hipStream;
     o->lastUsed = 1;
@@ -873,14 +943,21 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
     if (st == AFX_ERR_ARG) return st;
     const int T = dataLength / o->slideLength + 1;
     if (st == AFX_OK && o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
-    const int chunk = cqt_chunk_clips(o, T, batch);
-    for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
-        const int nb = batch - b0 < chunk ? batch - b0 : chunk;
-        float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;
-        st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im, hipStream);
+    if (st == AFX_OK && cqt_pyramid_ok(o, dataLength)) {
+        st = cqt_run_pyramid(o, dData, batch, dataLength, clipStride, dReal, dImag, NULL, 0, 0, hipStream);
         if (st == AFX_OK)
-            st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag, nrm,
-                                 dChroma + (long long)b0 * T * cn, hipStream);
+            st = afxk_cqt_chroma(dReal, dImag, (long long)batch * T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag,
+                                 nrm, dChroma, hipStream);
+    } else {
+        const int chunk = cqt_chunk_clips(o, T, batch);
+        for (int b0 = 0; b0 < batch && st == AFX_OK; b0 += chunk) {
+            const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+            float *re = dReal + (long long)b0 * T * o->num, *im = dImag + (long long)b0 * T * o->num;
+            st = cqt_run_device(o, dData + (long long)b0 * clipStride, nb, dataLength, clipStride, re, im, hipStream);
+            if (st == AFX_OK)
+                st = afxk_cqt_chroma(re, im, (long long)nb * T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag, nrm,
+                                     dChroma + (long long)b0 * T * cn, hipStream);
+        }
     }
     o->lastStream = hipStream;
     o->lastUsed = 1;
@@ -1009,6 +1086,7 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dX);
     afxdev_free(o->dSig[0]);
     afxdev_free(o->dSig[1]);
+    afxdev_free(o->dRing);
     afxdev_free(o->dOut);
     afxdev_free(o->dIn);
     afxdev_free(o->dDct);

@@ -92,6 +92,7 @@ int lane();
 }  // namespace emu
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu::launch(#kernel, (grid), (block), [&] { kernel(__VA_ARGS__); })
 static inline void __syncthreads() { emu::block_barrier(); }
+#define __builtin_amdgcn_s_barrier() emu::block_barrier()  // (k_cqt_pyramid: one per step, every wave of the workgroup)
 
 // ---- cross-lane operations
 static inline int emu_readlane(int v, int src) {

@@ -46,7 +46,7 @@ def emulated(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp("emu"))
     stub = os.path.join(tmp, "stub.c")
     subprocess.run([sys.executable, os.path.join(STUB, "gen_stub.py"), os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"),
-                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16"], check=True)
+                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16", "--omit=afxk_cqt_pyramid", "--omit=afxk_cqt_pyramid_plan"], check=True)
     # afx_cqt.hip keeps two arrays in static LDS: on the host, storage shared by the lanes' threads
     src = open(os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_cqt.hip")).read()
     patched, n = re.subn(r"(?m)^(\s*)__shared__ ", r"\1static ", src)
@@ -163,7 +163,7 @@ def emulated_tsan(tmp_path_factory):
     san = ["-O1", "-gline-tables-only", "-fsanitize=thread", "-fno-omit-frame-pointer"]
     stub = os.path.join(tmp, "stub.c")
     subprocess.run([sys.executable, os.path.join(STUB, "gen_stub.py"), os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"),
-                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16"], check=True)
+                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16", "--omit=afxk_cqt_pyramid", "--omit=afxk_cqt_pyramid_plan"], check=True)
     src = open(os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_cqt.hip")).read()
     with open(os.path.join(tmp, "afx_cqt_host.hip"), "w") as f:
         f.write(re.sub(r"(?m)^(\s*)__shared__ ", r"\1static ", src))
