@@ -95,10 +95,15 @@ __device__ __forceinline__ int cq_window_exponent(const u32x4 (&wnd)[CqF16<H>::N
     return split_exponent(wave_max_bits(peak));
 }
 
-// window registers (lane l, register u: samples 4 (l + 64 u) .. + 3) -> (xh, xl) planes, every copy
+// window registers (lane l, register u: samples 4 (l + 64 u) .. + 3) -> (xh, xl) planes, every copy.  One address
+// register: sample s = 4 l + 256 u sits at at(4 l, 0) + u (512 + 16 * 256 / H) (the pad count of 256 u samples is a
+// constant), so every store has an immediate offset -- as per-u addresses the compiler keeps 18 registers alive across
+// the tile and spills them.
 template <int H>
 __device__ __forceinline__ void cq_convert_window(const u32x4 (&wnd)[CqF16<H>::NV], float up, unsigned char *sig, int lane) {
     using C = CqF16<H>;
+    constexpr int USTEP = 512 + (C::PAD ? 16 * (256 / H) : 0);
+    unsigned char *d0 = sig + C::MARGIN + 8 * lane + (C::PAD ? 16 * ((4 * lane) / H) : 0);
 #pragma unroll
     for (int u = 0; u < C::NV; ++u) {
         const int s = 4 * (lane + 64 * u);
@@ -107,10 +112,9 @@ __device__ __forceinline__ void cq_convert_window(const u32x4 (&wnd)[CqF16<H>::N
             unsigned hi0, hi1, lo0, lo1;
             split_pair(v.x, v.y, up, hi0, lo0);
             split_pair(v.z, v.w, up, hi1, lo1);
-            const int base = C::MARGIN + 2 * s + (C::PAD ? 16 * (s / H) : 0);
 #pragma unroll
             for (int c = 0; c < C::COPIES; ++c) {
-                unsigned char *d = sig + c * C::CS + base - 2 * c * H;
+                unsigned char *d = d0 + (u * USTEP + c * C::CS - 2 * c * H);
                 if ((2 * c * H) % 8 == 0) {
                     *reinterpret_cast<uint2 *>(d) = make_uint2(hi0, hi1);
                     *reinterpret_cast<uint2 *>(d + C::PART) = make_uint2(lo0, lo1);
@@ -345,10 +349,9 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
 namespace pyr {
 constexpr int CONSUMERS = 7, PRODUCERS = 4, WAVES = CONSUMERS + PRODUCERS;
 constexpr int LEAD = 9, DRAIN = 15;
-__host__ __device__ constexpr int ring_size(int k) { return k == 1 ? 8192 : k == 2 ? 4096 : k == 3 ? 2048 : 1024; }
-__host__ __device__ constexpr int ring_off(int k) {
-    return k <= 1 ? 0 : k == 2 ? 8192 : k == 3 ? 12288 : k == 4 ? 14336 : k == 5 ? 15360 : 16384;
-}
+__host__ __device__ constexpr int ring_size(int k) { return k >= 4 ? 1024 : 16384 >> k; }  // 8192, 4096, 2048, 1024 x 3
+__host__ __device__ constexpr int ring_off(int k) { return k <= 4 ? 16384 - (32768 >> k) : 14336 + (k - 4) * 1024; }
+static_assert(ring_off(1) == 0 && ring_off(2) == 8192 && ring_off(3) == 12288 && ring_off(4) == 14336 && ring_off(5) == 15360, "ring layout");
 static_assert(ring_off(6) + ring_size(6) == AFX_CQT_PYR_RING_FLOATS, "ring layout");
 __host__ __device__ constexpr int win_ahead(int k) { return k == 5 ? 2 : k == 6 ? 4 : 1; }
 __host__ __device__ constexpr int lag(int k) { return k == 0 ? 3 : 2 * k + win_ahead(k); }
@@ -357,8 +360,8 @@ __host__ __device__ constexpr int plane_bytes(int k) {
          : k == 3 ? CqF16<16>::WAVE_BYTES : k == 4 ? CqF16<8>::WAVE_BYTES : k == 5 ? CqF16<4>::WAVE_BYTES : CqF16<2>::WAVE_BYTES;
 }
 __host__ __device__ constexpr int plane_off(int k) { return k == 0 ? 0 : plane_off(k - 1) + plane_bytes(k - 1); }
-constexpr int FIR_WORDS = 296;                       // even / odd input copies of one round, floats each
-constexpr int FIR_BYTES = 2 * FIR_WORDS * 4;
+constexpr int FIR_WORDS = 296;                       // even / odd input copies of a PAIR of rounds, float2 each
+constexpr int FIR_BYTES = 2 * FIR_WORDS * 8;
 constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + PRODUCERS * FIR_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr int AUX_L2 = 17;                           // sc0 sc1: served by the L2, never by this CU's L1
@@ -367,6 +370,30 @@ __host__ __device__ constexpr int need_back(int k) { return 10 - k; }
 __host__ __device__ constexpr int need_ahead(int k) { return 9 - k; }
 }  // namespace pyr
 
+// phase stamps of the TIMING instantiation (tools/pyr_phases.py): shader cycles per role and phase, summed over the steps
+template <bool TIMING>
+struct PyrClock {
+    unsigned long long t, acc[8];
+    __device__ __forceinline__ PyrClock() {
+        if (TIMING) {
+            for (int i = 0; i < 8; ++i) acc[i] = 0;
+            t = __builtin_amdgcn_s_memtime();
+        }
+    }
+    __device__ __forceinline__ void lap(int slot) {
+        if (TIMING) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // the stamp is an SMEM result
+            const unsigned long long n = __builtin_amdgcn_s_memtime();
+            acc[slot] += n - t;
+            t = n;
+        }
+    }
+    __device__ __forceinline__ void flush(unsigned long long *dst, int lane) {
+        if (TIMING && dst && lane == 0)
+            for (int i = 0; i < 8; ++i) dst[i] += acc[i];
+    }
+};
+
 __device__ __forceinline__ void pyr_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -374,9 +401,9 @@ __device__ __forceinline__ void pyr_barrier() {
 }
 
 // ---- consumer: octave level K of the run [t0c, t1c) of `clip`
-template <int K>
+template <int K, bool TIMING>
 __device__ __forceinline__ void pyr_consumer(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int clip,
-                                             int t0c, int t1c) {  // one run
+                                             int t0c, int t1c, unsigned long long *tim) {  // one run
     constexpr int H = 128 >> K;
     using C = CqF16<H>;
     constexpr int NVA = K == 0 ? C::NV / 2 : C::NV;  // level 0: half of the next window before the K loop, half behind it
@@ -409,6 +436,7 @@ __device__ __forceinline__ void pyr_consumer(const AfxCqtPyramidArgs &a, unsigne
         }
     };
     const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
+    PyrClock<TIMING> clk;
     for (int s = s0; s <= s1; ++s) {
         const int t = s - pyr::lag(K);
         const bool act = t >= t0c && t < t1c, actNext = t + 1 >= t0c && t + 1 < t1c;  // wave-uniform
@@ -428,160 +456,290 @@ __device__ __forceinline__ void pyr_consumer(const AfxCqtPyramidArgs &a, unsigne
             const int e = cq_window_exponent<H>(wnd, lane);
             const float up = __uint_as_float((unsigned)(e + 127) << 23);
             down = __uint_as_float((unsigned)(127 - e) << 23);
+            if (TIMING) {  // time the wait for the window apart from the conversion
+#pragma unroll
+                for (int u = 0; u < C::NV; ++u) PIN(wnd[u]);
+                clk.lap(0);
+            }
             wave_lds_order();
             cq_convert_window<H>(wnd, up, sig, lane);
             wave_lds_order();
+            clk.lap(1);
         }
         if (actNext) fetch(t + 1, 0, NVA);
+        clk.lap(2);
         f32x16 hh, hl, lh;
         if (act) cq_kloop<H>(aHi, aLo, bHi, bLo, hh, hl, lh);
+        clk.lap(3);
         // the prefetched window is in its registers BEFORE the step's barrier (its ring blocks are overwritten three
         // steps on; nothing younger is in flight here, so this wait costs nothing) ...
 #pragma unroll
         for (int u = 0; u < NVA; ++u) PIN(wnd[u]);
+        clk.lap(4);
         if (act) cq_store_tile<true>(hh, hl, lh, down, L, outRe, outIm, t * 32);
         // ... level 0 reads the clip, nothing overwrites it: the second half follows the tile's stores
         if (K == 0 && actNext) fetch(t + 1, NVA, C::NV);
+        clk.lap(5);
         pyr_barrier();
+        clk.lap(6);
+    }
+    clk.flush(tim, lane);
+}
+
+// ---- producers: the 2:1 resampler in rounds of 256 outputs i0 ... i0 + 255 of level k+1 (the first nOut stored), four per
+// lane, TWO ROUNDS AT A TIME (A, B: any two rounds, also of different stages -- the taps are the same): their inputs are
+// staged in LDS interleaved, E2[m] = (XE_A[m], XE_B[m]) with XE[m] = x[2 (i0 - 15 + m)], O2 likewise with
+// XO[m] = x[2 (i0 - 16 + m) + 1], so that a 16-byte read returns aligned register pairs and one v_pk_fma_f32 applies a tap
+// to both rounds.  k_cqt_decimate's arithmetic per output: left taps j = 0..31 at x[2i - j], then right taps j = 1..31 at
+// x[2i + j], one fma chain, divided by sqrt(ratio) -- the same bits.
+//
+// Producer PW, pair p of a step (stage, round of the block): 0: (0,0|0,1) (0,2|0,3); 1: (0,4|0,5) (0,6|0,7); 2: (1,0|1,1) (1,2|1,3);
+// 3: (2,0|2,1) (3,0|4,0) (5,0|-).  Stage k writes block s - 2k of level k+1.
+namespace pyr {
+__host__ __device__ constexpr int pair_stage(int pw, int p, int half) {  // -1: no round in this half
+    return pw < 2 ? 0 : pw == 2 ? 1 : p == 0 ? 2 : p == 1 ? 3 + half : half ? -1 : 5;
+}
+__host__ __device__ constexpr int pair_round(int pw, int p, int half) {
+    return pw < 2 ? 4 * pw + 2 * p + half : pw == 2 ? 2 * p + half : p == 0 ? half : 0;
+}
+}  // namespace pyr
+
+struct PyrRound {
+    int i0;         // first output
+    bool on, zero;  // due in this step; the block lies outside the signal (zeros, no input needed)
+};
+
+template <int K>
+__device__ __forceinline__ PyrRound pyr_round_of(int s, int r, int t0c, int t1c, const AfxCqtPyramidArgs &a) {
+    PyrRound R;
+    if (K < 0) {
+        R.i0 = 0;
+        R.on = false;
+        R.zero = true;
+        return R;
+    }
+    constexpr int KK = K < 0 ? 0 : K, blockOut = 2048 >> KK;
+    const int b = s - 2 * KK;
+    R.i0 = b * blockOut + 256 * r;
+    R.on = b >= t0c - pyr::need_back(KK + 1) && b <= t1c + pyr::need_ahead(KK + 1);  // the run needs that block
+    R.zero = R.i0 >= a.len[KK + 1] || R.i0 + 256 <= 0;
+    return R;
+}
+
+// the round's input on its way: 16 bytes at s_q = 2 i0 - 32 + 4 q hold XE[2q-1], XO[2q], XE[2q], XO[2q+1]; q = 0 ... 146.
+// No control flow around the loads (a load in a branch ends in a copy of its result, i.e. a wait right behind it): a
+// lane or a round with nothing to fetch loads from an out-of-range offset (zeros, no memory access).  Level 0 is the
+// clip -- its bounds check supplies the zeros on both sides --, the others a ring with the zeros inside.
+template <int K>
+__device__ __forceinline__ void pyr_fir_issue(const PyrRound &R, const AfxCqtPyramidArgs &a, float *wgRing, int clip, int lane,
+                                              u32x4 (&v)[3]) {
+    constexpr int KK = K < 0 ? 0 : K;
+    const bool live = K >= 0 && R.on && !R.zero;
+    const __amdgpu_buffer_rsrc_t src =
+        KK == 0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long long)clip * a.xStride), 0, a.len[0] * 4, RSRC_RAW)
+                : __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(KK), 0, pyr::ring_size(KK) * 4, RSRC_RAW);
+    constexpr unsigned mask = KK == 0 ? 0xffffffffu : (unsigned)pyr::ring_size(KK) - 1u;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int q = lane + 64 * u;
+        unsigned off = ((unsigned)(2 * R.i0 - 32 + 4 * q) & mask) * 4u;
+        if (!live || q >= 147) off = 0x80000000u;
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(src, (int)off, 0, pyr::AUX_L2);
     }
 }
 
-// ---- producer: one round of the 2:1 resampler, 256 outputs i0 ... i0 + 255 of level k+1 (the first nOut stored), four per
-// lane.  k_cqt_decimate's arithmetic: even / odd copies of the input window in LDS, XE[m] = x[2 (i0 - 15 + m)],
-// XO[m] = x[2 (i0 - 16 + m) + 1]; left taps j = 0..31 at x[2i - j], then right taps j = 1..31 at x[2i + j], one fma chain.
-template <bool CLIP>
-__device__ __forceinline__ void pyr_fir_round(const __amdgpu_buffer_rsrc_t &src, unsigned srcMask, int i0, int nOut,
-                                              const AfxCqtPyramidArgs &a, const __amdgpu_buffer_rsrc_t &dst, unsigned dstMask,
-                                              int dstLen, float *XE, float *XO, int lane) {
-    const int i = i0 + 4 * lane;
-    const bool mine = 4 * lane < nOut;
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
-    if (i0 < dstLen && i0 + 256 > 0) {  // (a block outside the signal is zeros)
-        // 16 bytes at s_q = 2 i0 - 32 + 4 q hold XE[2q-1], XO[2q], XE[2q], XO[2q+1]; q = 0 ... 146
-        u32x4 v[3];
+// the four outputs of a lane -> its ring, zeros outside the signal
+template <int K>
+__device__ __forceinline__ void pyr_fir_store(const PyrRound &R, const float (&r)[4], const AfxCqtPyramidArgs &a, float *wgRing, int lane) {
+    if (K < 0) return;
+    constexpr int KK = K < 0 ? 0 : K, blockOut = 2048 >> KK, nOut = blockOut < 256 ? blockOut : 256;
+    if (!R.on || 4 * lane >= nOut) return;
+    const int i = R.i0 + 4 * lane, dstLen = a.len[KK + 1];
+    u32x4 o;
+    o.x = (i >= 0 && i < dstLen) ? __float_as_uint(r[0]) : 0u;
+    o.y = (i + 1 >= 0 && i + 1 < dstLen) ? __float_as_uint(r[1]) : 0u;
+    o.z = (i + 2 >= 0 && i + 2 < dstLen) ? __float_as_uint(r[2]) : 0u;
+    o.w = (i + 3 >= 0 && i + 3 < dstLen) ? __float_as_uint(r[3]) : 0u;
+    const __amdgpu_buffer_rsrc_t dst =
+        __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(KK + 1), 0, pyr::ring_size(KK + 1) * 4, RSRC_RAW);
+    constexpr unsigned dstMask = (unsigned)pyr::ring_size(KK + 1) - 1u;
+    __builtin_amdgcn_raw_buffer_store_b128(o, dst, (int)(((unsigned)i & dstMask) * 4u), 0, 0);
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int KA, int KB, bool TIMING>
+__device__ __forceinline__ void pyr_fir_pair(const PyrRound &RA, const PyrRound &RB, u32x4 (&va)[3], u32x4 (&vb)[3], const v2 (&hp)[16],
+                                             float sqrtRatio, const AfxCqtPyramidArgs &a, float *wgRing, v2 *E2, v2 *O2, int lane,
+                                             PyrClock<TIMING> &clk) {
+    const bool liveA = KA >= 0 && RA.on && !RA.zero, liveB = KB >= 0 && RB.on && !RB.zero;
+    float rA[4] = {0.f, 0.f, 0.f, 0.f}, rB[4] = {0.f, 0.f, 0.f, 0.f};
+    if (liveA || liveB) {
+        if (TIMING) {
+            clk.lap(0);
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int q = lane + 64 * u;
-            if (q < 147) {
-                const int sq = 2 * i0 - 32 + 4 * q;
-                v[u] = CLIP ? __builtin_amdgcn_raw_buffer_load_b128(src, sq * 4, 0, 0)
-                            : __builtin_amdgcn_raw_buffer_load_b128(src, (int)(((unsigned)sq & srcMask) * 4u), 0, pyr::AUX_L2);
+            for (int u = 0; u < 3; ++u) {
+                PIN(va[u]);
+                PIN(vb[u]);
             }
+            clk.lap(2);  // waiting for the rounds' input
         }
-        wave_lds_order();  // the previous round's reads are done
+        __builtin_amdgcn_wave_barrier();  // (the previous pair's reads were waited for before its taps)
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int q = lane + 64 * u;
             if (q < 147) {
-                const float4 f = __builtin_bit_cast(float4, v[u]);
+                const float4 fa = __builtin_bit_cast(float4, va[u]), fb = __builtin_bit_cast(float4, vb[u]);
                 const int m = 2 * q - 1;
-                if (m >= 0) XE[m] = f.x;
-                XO[m + 1] = f.y;
-                XE[m + 1] = f.z;
-                XO[m + 2] = f.w;
+                if (m >= 0) E2[m] = v2{fa.x, fb.x};
+                O2[m + 1] = v2{fa.y, fb.y};
+                E2[m + 1] = v2{fa.z, fb.z};
+                O2[m + 2] = v2{fa.w, fb.w};
             }
         }
         wave_lds_order();
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        f4 ev[9], ov[9];
-        const float *pe = XE + 4 * lane, *po = XO + 4 * lane;
-        RD128_P(ev[0], pe, 0);   RD128_P(ov[0], po, 0);   RD128_P(ev[1], pe, 16);  RD128_P(ov[1], po, 16);
-        RD128_P(ev[2], pe, 32);  RD128_P(ov[2], po, 32);  RD128_P(ev[3], pe, 48);  RD128_P(ov[3], po, 48);
-        RD128_P(ev[4], pe, 64);  RD128_P(ov[4], po, 64);  RD128_P(ev[5], pe, 80);  RD128_P(ov[5], po, 80);
-        RD128_P(ev[6], pe, 96);  RD128_P(ov[6], po, 96);  RD128_P(ev[7], pe, 112); RD128_P(ov[7], po, 112);
-        RD128_P(ev[8], pe, 128); RD128_P(ov[8], po, 128);
-        LDS_WAIT_N(0);
-        float E[36], O[36];
+        // entries e (two per 16-byte read) of the lane's window: E2[4 lane + e], O2[4 lane + e]; the left taps need
+        // entries 0 ... 18 of both, the right taps 16 ... 34: two register sets of 20, one after the other
+        const v2 *pe = E2 + 4 * lane, *po = O2 + 4 * lane;
+        v2 acc[4] = {v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}};
+        {
+            f4 ev[10], ov[10];
+            RD128_P(ev[0], pe, 0);    RD128_P(ov[0], po, 0);    RD128_P(ev[1], pe, 16);   RD128_P(ov[1], po, 16);
+            RD128_P(ev[2], pe, 32);   RD128_P(ov[2], po, 32);   RD128_P(ev[3], pe, 48);   RD128_P(ov[3], po, 48);
+            RD128_P(ev[4], pe, 64);   RD128_P(ov[4], po, 64);   RD128_P(ev[5], pe, 80);   RD128_P(ov[5], po, 80);
+            RD128_P(ev[6], pe, 96);   RD128_P(ov[6], po, 96);   RD128_P(ev[7], pe, 112);  RD128_P(ov[7], po, 112);
+            RD128_P(ev[8], pe, 128);  RD128_P(ov[8], po, 128);  RD128_P(ev[9], pe, 144);  RD128_P(ov[9], po, 144);
+            LDS_WAIT_N(0);
+            clk.lap(3);  // staging through LDS
 #pragma unroll
-        for (int b = 0; b < 9; ++b) {
-            PIN(ev[b]);
-            PIN(ov[b]);
-            E[4 * b] = ev[b].x; E[4 * b + 1] = ev[b].y; E[4 * b + 2] = ev[b].z; E[4 * b + 3] = ev[b].w;
-            O[4 * b] = ov[b].x; O[4 * b + 1] = ov[b].y; O[4 * b + 2] = ov[b].z; O[4 * b + 3] = ov[b].w;
+            for (int b = 0; b < 10; ++b) {
+                PIN(ev[b]);
+                PIN(ov[b]);
+            }
+            auto E = [&](int e) { return (e & 1) ? v2{ev[e >> 1].z, ev[e >> 1].w} : v2{ev[e >> 1].x, ev[e >> 1].y}; };
+            auto O = [&](int e) { return (e & 1) ? v2{ov[e >> 1].z, ov[e >> 1].w} : v2{ov[e >> 1].x, ov[e >> 1].y}; };
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {  // x[2i - j]: even j -> x[2 (i - j/2)], odd j -> x[2 (i - (j+1)/2) + 1]
+                if (j & 1) {
+                    const int e = 16 - (j + 1) / 2;
+                    pk_tap4_hi(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], O(e), O(e + 1), O(e + 2), O(e + 3));
+                } else {
+                    const int e = 15 - j / 2;
+                    pk_tap4_lo(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], E(e), E(e + 1), E(e + 2), E(e + 3));
+                }
+            }
+        }
+        {
+            f4 ev[10], ov[10];  // entries 16 ... 35
+            RD128_P(ev[0], pe, 128);  RD128_P(ov[0], po, 128);  RD128_P(ev[1], pe, 144);  RD128_P(ov[1], po, 144);
+            RD128_P(ev[2], pe, 160);  RD128_P(ov[2], po, 160);  RD128_P(ev[3], pe, 176);  RD128_P(ov[3], po, 176);
+            RD128_P(ev[4], pe, 192);  RD128_P(ov[4], po, 192);  RD128_P(ev[5], pe, 208);  RD128_P(ov[5], po, 208);
+            RD128_P(ev[6], pe, 224);  RD128_P(ov[6], po, 224);  RD128_P(ev[7], pe, 240);  RD128_P(ov[7], po, 240);
+            RD128_P(ev[8], pe, 256);  RD128_P(ov[8], po, 256);  RD128_P(ev[9], pe, 272);  RD128_P(ov[9], po, 272);
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int b = 0; b < 10; ++b) {
+                PIN(ev[b]);
+                PIN(ov[b]);
+            }
+            auto E = [&](int e) { return ((e - 16) & 1) ? v2{ev[(e - 16) >> 1].z, ev[(e - 16) >> 1].w} : v2{ev[(e - 16) >> 1].x, ev[(e - 16) >> 1].y}; };
+            auto O = [&](int e) { return ((e - 16) & 1) ? v2{ov[(e - 16) >> 1].z, ov[(e - 16) >> 1].w} : v2{ov[(e - 16) >> 1].x, ov[(e - 16) >> 1].y}; };
+#pragma unroll
+            for (int j = 1; j < 32; ++j) {  // x[2i + j]: even j -> x[2 (i + j/2)], odd j -> x[2 (i + (j-1)/2) + 1]
+                if (j & 1) {
+                    const int e = 16 + (j - 1) / 2;
+                    pk_tap4_hi(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], O(e), O(e + 1), O(e + 2), O(e + 3));
+                } else {
+                    const int e = 15 + j / 2;
+                    pk_tap4_lo(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], E(e), E(e + 1), E(e + 2), E(e + 3));
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {  // x[2i - j]: even j -> x[2 (i - j/2)], odd j -> x[2 (i - (j+1)/2) + 1]
-                const float x = (j & 1) ? O[q + 16 - (j + 1) / 2] : E[q + 15 - j / 2];
-                acc = __fmaf_rn(a.taps[j], x, acc);
-            }
-#pragma unroll
-            for (int j = 1; j < 32; ++j) {  // x[2i + j]: even j -> x[2 (i + j/2)], odd j -> x[2 (i + (j-1)/2) + 1]
-                const float x = (j & 1) ? O[q + 16 + (j - 1) / 2] : E[q + 15 + j / 2];
-                acc = __fmaf_rn(a.taps[j], x, acc);
-            }
-            r[q] = (i + q >= 0 && i + q < dstLen) ? acc / a.sqrtRatio : 0.f;
+            rA[q] = acc[q].x / sqrtRatio;
+            rB[q] = acc[q].y / sqrtRatio;
+        }
+        if (TIMING) {
+            PIN(rA[0]); PIN(rA[3]); PIN(rB[0]); PIN(rB[3]);
+            clk.lap(4);  // the taps
         }
     }
-    if (mine) {
-        const u32x4 o = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, dst, (int)(((unsigned)i & dstMask) * 4u), 0, 0);
-    }
+    pyr_fir_store<KA>(RA, rA, a, wgRing, lane);
+    pyr_fir_store<KB>(RB, rB, a, wgRing, lane);
 }
 
-// stage k (level k -> k+1), block b, rounds [r0, r1) of the block's 32 hop_(k+1) outputs
-__device__ __forceinline__ void pyr_stage(int k, int b, int r0, int r1, const AfxCqtPyramidArgs &a, float *wgRing, int clip,
-                                          float *XE, float *XO, int lane) {
-    const int blockOut = 32 * (64 >> k);  // 2048, 1024, ..., 64
-    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(k + 1), 0, pyr::ring_size(k + 1) * 4, RSRC_RAW);
-    const unsigned dstMask = (unsigned)pyr::ring_size(k + 1) - 1u;
-    if (k == 0) {
-        const __amdgpu_buffer_rsrc_t src =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long long)clip * a.xStride), 0, a.len[0] * 4, RSRC_RAW);
-        for (int r = r0; r < r1; ++r)
-            pyr_fir_round<true>(src, 0u, b * blockOut + 256 * r, 256, a, dst, dstMask, a.len[1], XE, XO, lane);
-    } else {
-        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(k), 0, pyr::ring_size(k) * 4, RSRC_RAW);
-        const unsigned srcMask = (unsigned)pyr::ring_size(k) - 1u;
-        for (int r = r0; r < r1; ++r)
-            pyr_fir_round<false>(src, srcMask, b * blockOut + 256 * r, blockOut < 256 ? blockOut : 256, a, dst, dstMask, a.len[k + 1], XE, XO,
-                                 lane);
-    }
-}
-
-__device__ __forceinline__ void pyr_producer(int pw, const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing,
-                                             int clip, int t0c, int t1c) {
-    float *XE = reinterpret_cast<float *>(smem + CqF16<128>::B_BYTES + pyr::plane_off(7) + pw * pyr::FIR_BYTES);
-    float *XO = XE + pyr::FIR_WORDS;
+template <int PW, bool TIMING>
+__device__ __forceinline__ void pyr_producer(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int clip,
+                                             int t0c, int t1c, unsigned long long *tim) {
+    v2 *E2 = reinterpret_cast<v2 *>(smem + CqF16<128>::B_BYTES + pyr::plane_off(7) + PW * pyr::FIR_BYTES);
+    v2 *O2 = E2 + pyr::FIR_WORDS;
     const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
-    // stage k writes block s - 2k of level k+1 when the run needs that block
-    auto due = [&](int k, int s) {
-        const int b = s - 2 * k;
-        return b >= t0c - pyr::need_back(k + 1) && b <= t1c + pyr::need_ahead(k + 1);
-    };
-    for (int s = s0; s <= s1; ++s) {
-        if (pw < 2) {
-            if (due(0, s)) pyr_stage(0, s, 4 * pw, 4 * pw + 4, a, wgRing, clip, XE, XO, lane);
-        } else if (pw == 2) {
-            if (due(1, s)) pyr_stage(1, s - 2, 0, 4, a, wgRing, clip, XE, XO, lane);
-        } else {
-            if (due(2, s)) pyr_stage(2, s - 4, 0, 2, a, wgRing, clip, XE, XO, lane);
-            if (due(3, s)) pyr_stage(3, s - 6, 0, 1, a, wgRing, clip, XE, XO, lane);
-            if (due(4, s)) pyr_stage(4, s - 8, 0, 1, a, wgRing, clip, XE, XO, lane);
-            if (due(5, s)) pyr_stage(5, s - 10, 0, 1, a, wgRing, clip, XE, XO, lane);
-        }
-        VM_WAIT_ALL();  // the blocks are in the L2 before the other waves pass the barrier
-        pyr_barrier();
+    v2 hp[16];  // the taps in VECTOR registers, pairs (h[2n], h[2n+1]): as scalars next to the descriptors they spill
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        hp[n] = v2{a.taps[2 * n], a.taps[2 * n + 1]};
+        PIN(hp[n]);
     }
+    const float sqrtRatio = a.sqrtRatio;
+    PyrClock<TIMING> clk;
+    constexpr int K0A = pyr::pair_stage(PW, 0, 0), K0B = pyr::pair_stage(PW, 0, 1), K1A = pyr::pair_stage(PW, 1, 0), K1B = pyr::pair_stage(PW, 1, 1);
+    constexpr int K2A = PW == 3 ? pyr::pair_stage(PW, 2, 0) : -1, K2B = -1;
+    constexpr int R0A = pyr::pair_round(PW, 0, 0), R0B = pyr::pair_round(PW, 0, 1), R1A = pyr::pair_round(PW, 1, 0), R1B = pyr::pair_round(PW, 1, 1);
+    // the input of a pair is requested one pair ahead, and across the step's barrier when it comes from the clip
+    // (producers 0 and 1; a ring block is only complete behind the barrier): two register sets, used in turn
+    constexpr bool AHEAD = PW < 2;
+    u32x4 a0[3], b0[3], a1[3], b1[3];
+    if (AHEAD) {
+        pyr_fir_issue<K0A>(pyr_round_of<K0A>(s0, R0A, t0c, t1c, a), a, wgRing, clip, lane, a0);
+        pyr_fir_issue<K0B>(pyr_round_of<K0B>(s0, R0B, t0c, t1c, a), a, wgRing, clip, lane, b0);
+    }
+    for (int s = s0; s <= s1; ++s) {
+        const PyrRound P0A = pyr_round_of<K0A>(s, R0A, t0c, t1c, a), P0B = pyr_round_of<K0B>(s, R0B, t0c, t1c, a);
+        const PyrRound P1A = pyr_round_of<K1A>(s, R1A, t0c, t1c, a), P1B = pyr_round_of<K1B>(s, R1B, t0c, t1c, a);
+        if (!AHEAD) {
+            pyr_fir_issue<K0A>(P0A, a, wgRing, clip, lane, a0);
+            pyr_fir_issue<K0B>(P0B, a, wgRing, clip, lane, b0);
+        }
+        pyr_fir_issue<K1A>(P1A, a, wgRing, clip, lane, a1);
+        pyr_fir_issue<K1B>(P1B, a, wgRing, clip, lane, b1);
+        pyr_fir_pair<K0A, K0B, TIMING>(P0A, P0B, a0, b0, hp, sqrtRatio, a, wgRing, E2, O2, lane, clk);
+        if (AHEAD) {  // (harmless behind the run's last step)
+            pyr_fir_issue<K0A>(pyr_round_of<K0A>(s + 1, R0A, t0c, t1c, a), a, wgRing, clip, lane, a0);
+            pyr_fir_issue<K0B>(pyr_round_of<K0B>(s + 1, R0B, t0c, t1c, a), a, wgRing, clip, lane, b0);
+        }
+        const PyrRound P2A = pyr_round_of<K2A>(s, 0, t0c, t1c, a), P2B = pyr_round_of<K2B>(s, 0, t0c, t1c, a);
+        if (PW == 3) {
+            pyr_fir_issue<K2A>(P2A, a, wgRing, clip, lane, a0);
+            pyr_fir_issue<K2B>(P2B, a, wgRing, clip, lane, b0);
+        }
+        pyr_fir_pair<K1A, K1B, TIMING>(P1A, P1B, a1, b1, hp, sqrtRatio, a, wgRing, E2, O2, lane, clk);
+        if (PW == 3) pyr_fir_pair<K2A, K2B, TIMING>(P2A, P2B, a0, b0, hp, sqrtRatio, a, wgRing, E2, O2, lane, clk);
+        clk.lap(5);
+        VM_WAIT_ALL();  // the blocks are in the L2 before the other waves pass the barrier
+        clk.lap(1);
+        pyr_barrier();
+        clk.lap(6);
+    }
+    clk.flush(tim, lane);
 }
 
-// the runs of this workgroup, one after the other; ROLE 0-6: consumer of that level, 7: producer (wave - 7)
-template <int ROLE>
+// the runs of this workgroup, one after the other; ROLE 0-6: consumer of that level, 7-10: producer ROLE - 7
+template <int ROLE, bool TIMING>
 __device__ __forceinline__ void pyr_role(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int items) {
+    unsigned long long *tim = TIMING && a.timing ? a.timing + ((size_t)blockIdx.x * pyr::WAVES + (threadIdx.x >> 6)) * 8 : nullptr;
     const int nT = (a.timeLength + 31) / 32;
-    const int pw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - pyr::CONSUMERS;
     for (int it = blockIdx.x; it < items; it += gridDim.x) {
         const int clip = it / a.chunksPerClip, chunk = it - clip * a.chunksPerClip;
         const int t0c = chunk * a.tilesPerChunk;
         const int t1c = t0c + a.tilesPerChunk < nT ? t0c + a.tilesPerChunk : nT;
         if (t0c >= t1c) continue;  // (uniform over the workgroup)
-        if (ROLE < pyr::CONSUMERS) pyr_consumer<(ROLE < pyr::CONSUMERS ? ROLE : 0)>(a, smem, lane, wgRing, clip, t0c, t1c);
-        else pyr_producer(pw, a, smem, lane, wgRing, clip, t0c, t1c);
+        if (ROLE < pyr::CONSUMERS) pyr_consumer<(ROLE < pyr::CONSUMERS ? ROLE : 0), TIMING>(a, smem, lane, wgRing, clip, t0c, t1c, tim);
+        else pyr_producer<(ROLE >= pyr::CONSUMERS ? ROLE - pyr::CONSUMERS : 0), TIMING>(a, smem, lane, wgRing, clip, t0c, t1c, tim);
     }
 }
 
+template <bool TIMING>
 __global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidArgs a, int items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -592,14 +750,17 @@ __global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidAr
     // (the loop over the workgroup's runs sits INSIDE every role: around the switch, the compiler hoists the per-lane
     // constants of all eight roles in front of it and spills them)
     switch (wave) {
-        case 0: pyr_role<0>(a, smem_raw, lane, wgRing, items); break;
-        case 1: pyr_role<1>(a, smem_raw, lane, wgRing, items); break;
-        case 2: pyr_role<2>(a, smem_raw, lane, wgRing, items); break;
-        case 3: pyr_role<3>(a, smem_raw, lane, wgRing, items); break;
-        case 4: pyr_role<4>(a, smem_raw, lane, wgRing, items); break;
-        case 5: pyr_role<5>(a, smem_raw, lane, wgRing, items); break;
-        case 6: pyr_role<6>(a, smem_raw, lane, wgRing, items); break;
-        default: pyr_role<7>(a, smem_raw, lane, wgRing, items); break;
+        case 0: pyr_role<0, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 1: pyr_role<1, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 2: pyr_role<2, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 3: pyr_role<3, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 4: pyr_role<4, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 5: pyr_role<5, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 6: pyr_role<6, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 7: pyr_role<7, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 8: pyr_role<8, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 9: pyr_role<9, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        default: pyr_role<10, TIMING>(a, smem_raw, lane, wgRing, items); break;
     }
 }
 
@@ -679,8 +840,14 @@ extern "C" int afxk_cqt_pyramid(const AfxCqtPyramidArgs *a, void *stream) {
     const long long items = (long long)a->batch * a->chunksPerClip;
     if (items > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)(items < AFX_CQT_PYR_MAX_WGS ? items : AFX_CQT_PYR_MAX_WGS);
-    AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, pyr::LDS_BYTES));
-    hipLaunchKernelGGL(k_cqt_pyramid, dim3(grid), dim3(64 * pyr::WAVES), pyr::LDS_BYTES, (hipStream_t)stream, *a, (int)items);
+    if (a->timing) {  // the instrumented instantiation (tools/pyr_phases.py)
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_pyramid<true>), hipFuncAttributeMaxDynamicSharedMemorySize, pyr::LDS_BYTES));
+        hipLaunchKernelGGL(k_cqt_pyramid<true>, dim3(grid), dim3(64 * pyr::WAVES), pyr::LDS_BYTES, (hipStream_t)stream, *a, (int)items);
+        AFX_LAUNCH_CHECK("k_cqt_pyramid<timing>");
+        return AFX_OK;
+    }
+    AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_pyramid<false>), hipFuncAttributeMaxDynamicSharedMemorySize, pyr::LDS_BYTES));
+    hipLaunchKernelGGL(k_cqt_pyramid<false>, dim3(grid), dim3(64 * pyr::WAVES), pyr::LDS_BYTES, (hipStream_t)stream, *a, (int)items);
     AFX_LAUNCH_CHECK("k_cqt_pyramid");
     return AFX_OK;
 }

@@ -343,6 +343,8 @@ typedef struct {
     float *chroma;           /* device [batch][T, 12]                                   */
     int chromaClass[12];     /* class of bin j of an octave (the 0/1 folding matrix)    */
     int chromaMag, chromaNorm; /* |Q| instead of |Q|^2; 0 none 1 max 2 min 3 P2 4 P1     */
+    unsigned long long *timing; /* NULL, or device [workgroups][11 waves][8]: shader cycles per phase, summed
+                              * (the instrumented instantiation; tools/pyr_phases.py)      */
 } AfxCqtPyramidArgs;
 /* workgroups the launch will use (the caller sizes `ring` with it) */
 int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerClip, int *tilesPerChunk);

@@ -57,6 +57,7 @@ struct OpaqueCQT {
     size_t capSig[2];
     float *dRing;            /* level rings of the one-launch ladder (k_cqt_pyramid), per workgroup */
     size_t capRing;
+    unsigned long long *dTiming; /* AFX_CQT_PYR_TIMING=1: phase cycles of the instrumented kernel (afx_cqt_pyramid_timing) */
     void *lastStream;        /* stream of the previous device call (scratch ordering) */
     int lastUsed;
     float *dOut;             /* re | im [T,num] */
@@ -541,6 +542,15 @@ static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength,
     a.ring = o->dRing;
     memcpy(a.taps, o->taps, sizeof(a.taps));
     a.sqrtRatio = sqrtf(0.5f);
+    if (getenv("AFX_CQT_PYR_TIMING")) { /* measurement builds only: the instrumented instantiation */
+        const size_t bytes = sizeof(unsigned long long) * AFX_CQT_PYR_MAX_WGS * 11 * 8;
+        if (!o->dTiming) {
+            st = afxdev_malloc((void **)&o->dTiming, bytes);
+            if (st == AFX_OK) st = afxdev_memset(o->dTiming, 0, bytes, stream);
+            if (st != AFX_OK) return st;
+        }
+        a.timing = o->dTiming;
+    }
     a.chroma = dChroma;
     a.chromaMag = isMag;
     a.chromaNorm = nrm;
@@ -554,6 +564,18 @@ static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength,
         }
     }
     return afxk_cqt_pyramid(&a, stream);
+}
+
+/* AFX_CQT_PYR_TIMING=1: copies out (and clears) the phase cycles the instrumented k_cqt_pyramid accumulated:
+ * [256 workgroups][11 waves][8 phases]; returns the words copied, 0 when nothing was recorded (tools/pyr_phases.py) */
+int afx_cqt_pyramid_timing(CQTObj o, unsigned long long *host) {
+    if (!o || !o->dTiming || !host) return 0;
+    const size_t bytes = sizeof(unsigned long long) * AFX_CQT_PYR_MAX_WGS * 11 * 8;
+    if (o->lastUsed) afxdev_stream_sync(o->lastStream);
+    if (afxdev_d2h(host, o->dTiming, bytes, o->stream) != AFX_OK || afxdev_stream_sync(o->stream) != AFX_OK) return 0;
+    afxdev_memset(o->dTiming, 0, bytes, o->stream);
+    afxdev_stream_sync(o->stream);
+    return AFX_CQT_PYR_MAX_WGS * 11 * 8;
 }
 
 /* The octave recursion on HBM-resident clips: dX + b*xStride (b < batch, dataLength
@@ -1087,6 +1109,7 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dSig[0]);
     afxdev_free(o->dSig[1]);
     afxdev_free(o->dRing);
+    afxdev_free(o->dTiming);
     afxdev_free(o->dOut);
     afxdev_free(o->dIn);
     afxdev_free(o->dDct);

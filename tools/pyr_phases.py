@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""GPU: where the steps of k_cqt_pyramid go -- AFX_CQT_PYR_TIMING=1 runs the instrumented instantiation; shader cycles
+per wave role and phase, averaged over the workgroups and divided by the steps of a run.
+usage: tools/pyr_phases.py [clips] [steps]"""
+import ctypes as C, os, sys, time
+os.environ["AFX_CQT_PYR_TIMING"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import audioflux_amd as af
+clips = int(sys.argv[1]) if len(sys.argv) > 1 else 125
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+n = 1323000
+o = af.CQT(num=84, samplate=44100, low_fre=32.703, bin_per_octave=12, normal_type=af.SpectralFilterBankNormalType.AREA)
+x = 0.1 * torch.randn((clips, n), device="cuda")
+T = o.cal_time_length(n)
+re = torch.empty((clips, T, 84), device="cuda"); im = torch.empty_like(re)
+lib = af.get_lib()
+lib.afx_cqt_pyramid_timing.restype = C.c_int
+buf = np.zeros((256, 11, 8), np.uint64)
+for _ in range(3):
+    o.cqt_device(x, re, im)
+torch.cuda.synchronize()
+lib.afx_cqt_pyramid_timing(C.c_void_p(o._obj.value if hasattr(o._obj, "value") else o._obj), buf.ctypes.data_as(C.c_void_p))
+t0 = time.perf_counter()
+for _ in range(reps):
+    o.cqt_device(x, re, im)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) * 1e3 / reps
+got = lib.afx_cqt_pyramid_timing(C.c_void_p(o._obj.value if hasattr(o._obj, "value") else o._obj), buf.ctypes.data_as(C.c_void_p))
+assert got, "no timing recorded (AFX_CQT_PYR_TIMING)"
+nT = (T + 31) // 32
+wgs = min(256, clips * max(1, min(256 // clips, nT // 48)))
+used = buf[:wgs].astype(np.float64)
+print(f"{clips} clips, {ms:.3f} ms per call (instrumented), {wgs} workgroups; cycles per step and wave (mean over workgroups)")
+cpc = max(1, min(256 // clips, nT // 48)); tpc = -(-nT // cpc); steps = (tpc + 25) * reps * max(1, -(-clips * cpc // 256))
+names_c = ["wait-window", "convert", "fetch-issue", "k-loop", "wait-prefetch", "store(+fetchB)", "barrier", "-"]
+names_p = ["issue-loads", "vm-wait", "wait-input", "lds-stage", "taps", "stores/other", "barrier", "-"]
+for w in range(11):
+    m = used[:, w, :].mean(axis=0) / steps
+    nm = names_c if w < 7 else names_p
+    print(f"wave {w:2d} ({'octave level %d' % w if w < 7 else 'producer %d' % (w - 7)}): total {m.sum():8.0f} | " +
+          "  ".join(f"{nm[i]} {m[i]:.0f}" for i in range(8) if nm[i] != "-"))
+tot = used.sum(axis=2).mean() / steps
+print(f"cycles per step ~{tot:.0f}; at {ms*1e-3/ (steps/reps) * 1e9:.0f} ns per step -> clock ~{tot / (ms*1e-3/(steps/reps)) / 1e6:.0f} MHz")
