@@ -321,56 +321,69 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
 // launch.  Reference: the octave recursion of _cqtObj_cqt (src/cqt_algorithm.c:951-1048) -- per octave frame + FFT +
 // sparse kernel product, then the 2:1 "Fast" resampler (src/dsp/resample_algorithm.c:430-521) makes the next level.
 //
-// A workgroup of eleven waves walks a run of 32-frame tiles of one clip, one STEP per tile:
-//   * waves 0-6, CONSUMERS: wave k owns octave level k (hop 128 >> k).  Per step: the level's window -> (xh, xl) planes
-//     in the wave's own LDS region -> 96 MFMAs -> the tile's 12 bins of 32 rows to memory; the next window is already
-//     on its way into registers while the matrix cores work.  Exactly the tile of k_cqt_octave_f16 above.
-//   * waves 7-10, PRODUCERS: the decimation chain, level k -> k+1 in BLOCKS of 32 hop_(k+1) samples (what a tile of
-//     level k+1 advances by): the 63-tap FIR of k_cqt_decimate (afx_cqt.hip), same taps in the same order, 256 outputs
-//     per round from even/odd copies of the input in the wave's LDS region.  Stage 0 (clip -> level 1) takes two
-//     waves, stage 1 one, stages 2-5 share the last.
+// A workgroup of seven waves walks a run of 32-frame tiles of one clip, one STEP per tile; wave k owns octave level k
+// (hop H = 128 >> k).  Per step: the level's window -> (xh, xl) planes in the wave's own LDS region -> 96 MFMAs ->
+// the tile's 12 bins of 32 rows to memory (the tile of k_cqt_octave_f16 above) -- and then, FROM THE SAME PLANES, the
+// next level's samples: row t' of the tile holds the 63 inputs of the H/2 resampler outputs (32 t + t') H/2 + c',
+// y = sum_m h[|m|] x[2i + m], at window positions n = 2c' + 256 + m, so the 2:1 resampler is one more product of the
+// Toeplitz operand with a banded matrix W[n][c'] = h[|n - 256 - 2c'|]: 5-8 K steps of three MFMAs per 32 columns
+// (+ 15 ... 48 MFMAs on the tile's 96), no second pass over the signal, no vector-unit filter.  W is never stored: a
+// lane's eight taps of a K step are eight consecutive entries of the tap table T[d] = h[|d|] 2^15 (f16 (hi, lo) words,
+// zeros outside |d| <= 31) at d = 16 ks + 8 g - 256 - 2c'; four copies of the table shifted by 2 (c' mod 4) make that
+// a 16-byte aligned read at an immediate offset, the copies 704 bytes apart put the 16 lanes of a read group on 16
+// distinct bank quads.  [A vector-unit resampler in four more waves was measured first: 13-17 k cycles per step
+// against 5-6 k for the octave waves -- one wave issues a vector instruction every ~5.5 cycles, and packed f32
+// arithmetic beside MFMA waves is slower than scalar (profiles/r04_cqt_pyramid.txt).]
+// The arithmetic of the resampler is therefore the octave product's: operands as (hi, lo) binary16 words of the
+// tile-scaled samples (>= 22 bits of every sample) and of the taps, three products, float32 accumulation -- as close
+// to the exact filter as the reference's float32 chain, not the same bits (tests: both against the reference).
+//
 // The level signals live in per-workgroup RINGS in global memory (8192 ... 1024 samples per level, 68 KB per
-// workgroup): written once, read a step or two later by the same CU, overwritten four blocks on -- they stay in the
+// workgroup): written once, read a few steps later by the same CU, overwritten four blocks on -- they stay in the
 // L2 and never reach HBM, a clip is read from HBM once.  Ring loads bypass the CU's L1 (sc0 sc1), ring stores are
 // drained (vmcnt(0)) before the step's s_barrier: ONE barrier per step is the only synchronisation.
 //
-// Schedule (step s; "block b of level k" = samples [32 b hop_k, 32 (b+1) hop_k)):
-//   stage k writes block s - 2k of level k+1; it reads blocks b-1 .. b+1 of level k (the clip for k = 0), whose last
-//   one was written in step s - 1;
-//   consumer k >= 1 computes tile s - 2k - e_k (e = 1,1,1,1,2,4: the blocks a window reaches past its tile), whose
-//   window it fetched during step s - 1 from blocks written up to step s - 2; consumer 0 reads the clip and follows
-//   consumer 1.  A ring of 4 blocks (8 / 16 for the two smallest levels) holds everything alive at a step.
-// A run [t0, t1) therefore takes steps t0 - 9 ... t1 + 15: nine blocks of lead-in for the dependency cone of the
-// lowest octave, fifteen steps for the pipeline to drain (tools/proto_cqt_pyramid.py checks every read of the
-// schedule against the writes).  Positions outside a level's signal are written as zeros, so no load needs a mask
-// except the consumer's validLength rule.
-// Arithmetic is the per-octave path's, operation for operation: results are bit-identical to it.
+// Schedule (step s; "block b of level k" = samples [32 b hop_k, 32 (b+1) hop_k) = what tile b of level k-1 produces):
+// wave k works on tile s - lag_k, lag = 0, 3, 6, 9, 12, 16, 22: its window reaches e_k = 1,1,1,1,2,4 blocks past its
+// tile, those were written by wave k-1 in step (t + e_k) + lag_(k-1), are visible one step later, when the window is
+// requested, and used one step after that.  A ring of 4 blocks (8 / 16 for the two smallest levels) holds what is
+// alive at a step.  A run [t0, t1) of tiles takes steps t0 - 9 ... t1 + 21: wave k also runs the resampler alone on
+// the tiles [t0 - (9 - k), t0) and [t1, t1 + (8 - k)] whose blocks the lower octaves of the run reach into
+// (tools/proto_cqt_pyramid.py checks every read of the schedule against the writes).  Positions outside a level's
+// signal are written as zeros; the framing rule (samples in [validLength, length) are not framed but ARE resampled,
+// stft_algorithm.c:838-843) costs the few tiles at a clip's end a second conversion.
 
 namespace pyr {
-constexpr int CONSUMERS = 7, PRODUCERS = 4, WAVES = CONSUMERS + PRODUCERS;
-constexpr int LEAD = 9, DRAIN = 15;
+constexpr int WAVES = 7;
+constexpr int LEAD = 9, DRAIN = 21;
 __host__ __device__ constexpr int ring_size(int k) { return k >= 4 ? 1024 : 16384 >> k; }  // 8192, 4096, 2048, 1024 x 3
 __host__ __device__ constexpr int ring_off(int k) { return k <= 4 ? 16384 - (32768 >> k) : 14336 + (k - 4) * 1024; }
 static_assert(ring_off(1) == 0 && ring_off(2) == 8192 && ring_off(3) == 12288 && ring_off(4) == 14336 && ring_off(5) == 15360, "ring layout");
 static_assert(ring_off(6) + ring_size(6) == AFX_CQT_PYR_RING_FLOATS, "ring layout");
-__host__ __device__ constexpr int win_ahead(int k) { return k == 5 ? 2 : k == 6 ? 4 : 1; }
-__host__ __device__ constexpr int lag(int k) { return k == 0 ? 3 : 2 * k + win_ahead(k); }
+__host__ __device__ constexpr int lag(int k) { return k == 0 ? 0 : k <= 4 ? 3 * k : k == 5 ? 16 : 22; }
 __host__ __device__ constexpr int plane_bytes(int k) {
     return k == 0 ? CqF16<128>::WAVE_BYTES : k == 1 ? CqF16<64>::WAVE_BYTES : k == 2 ? CqF16<32>::WAVE_BYTES
          : k == 3 ? CqF16<16>::WAVE_BYTES : k == 4 ? CqF16<8>::WAVE_BYTES : k == 5 ? CqF16<4>::WAVE_BYTES : CqF16<2>::WAVE_BYTES;
 }
 __host__ __device__ constexpr int plane_off(int k) { return k == 0 ? 0 : plane_off(k - 1) + plane_bytes(k - 1); }
-constexpr int FIR_WORDS = 296;                       // even / odd input copies of a PAIR of rounds, float2 each
-constexpr int FIR_BYTES = 2 * FIR_WORDS * 8;
-constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + PRODUCERS * FIR_BYTES;
+// the tap table: 2 word planes x 4 shifted copies
+constexpr int TAB_COPY = AFX_CQT_PYR_TAB_COPY, TAB_PLANE = 4 * TAB_COPY, TAB_BYTES = 2 * TAB_PLANE;
+static_assert(TAB_BYTES == AFX_CQT_PYR_TAB_HALFS * 2, "tap table");
+// level 0's next window on its way (LDS-DMA, float32 in sample order): 18 x 1 KB
+constexpr int STAGE_BYTES = CqF16<128>::NV * 1024;
+constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + TAB_BYTES + STAGE_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr int AUX_L2 = 17;                           // sc0 sc1: served by the L2, never by this CU's L1
-// blocks of level k (1..6) a run [t0, t1) needs: [t0 - need_back(k), t1 + need_ahead(k)]
-__host__ __device__ constexpr int need_back(int k) { return 10 - k; }
-__host__ __device__ constexpr int need_ahead(int k) { return 9 - k; }
+// tiles of level k whose resampler output (block of level k+1) a run [t0, t1) needs: [t0 - need_back(k), t1 + need_ahead(k)]
+__host__ __device__ constexpr int need_back(int k) { return 9 - k; }
+__host__ __device__ constexpr int need_ahead(int k) { return 8 - k; }
+// K steps of the resampler product for column tile CT of hop H: positions 2c' + 225 ... 2c' + 287 of the valid columns
+__host__ __device__ constexpr int dec_cols(int H) { return H / 2 < 32 ? H / 2 : 32; }
+__host__ __device__ constexpr int dec_ks0(int ct) { return (225 + 64 * ct) / 16; }
+__host__ __device__ constexpr int dec_ks1(int H, int ct) { return (2 * (dec_cols(H) - 1 + 32 * ct) + 287) / 16; }
 }  // namespace pyr
 
-// phase stamps of the TIMING instantiation (tools/pyr_phases.py): shader cycles per role and phase, summed over the steps
+// phase stamps of the TIMING instantiation (tools/pyr_phases.py): shader cycles per wave and phase, summed over the steps
 template <bool TIMING>
 struct PyrClock {
     unsigned long long t, acc[8];
@@ -400,16 +413,82 @@ __device__ __forceinline__ void pyr_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// ---- consumer: octave level K of the run [t0c, t1c) of `clip`
+// the resampler product of the tile in the planes: columns c' = 32 CT + (lane & 31) of every frame row
+template <int H, int CT>
+__device__ __forceinline__ void pyr_dec_loop(const unsigned char *aHi, const unsigned char *aLo, const unsigned char *tHi, const unsigned char *tLo,
+                                             f32x16 &hh, f32x16 &hl, f32x16 &lh) {
+    using C = CqF16<H>;
+    constexpr int KS0 = pyr::dec_ks0(CT), KS1 = pyr::dec_ks1(H, CT);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hh[r] = hl[r] = lh[r] = 0.f;
+    h8 ah[2], al[2], th[2], tl[2];
+    auto load = [&](int ks, int slot) {
+        ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
+        al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
+        th[slot] = *reinterpret_cast<const h8 *>(tHi + 32 * ks);
+        tl[slot] = *reinterpret_cast<const h8 *>(tLo + 32 * ks);
+    };
+    load(KS0, 0);
+#pragma unroll
+    for (int ks = KS0; ks <= KS1; ++ks) {
+        const int sl = (ks - KS0) & 1;
+        if (ks < KS1) load(ks + 1, sl ^ 1);
+        // the taps as the A operand: result ROW = output c', COLUMN = frame -- a lane then holds runs of four consecutive
+        // outputs of its frame (16-byte stores)
+        hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[sl], ah[sl], hh, 0, 0, 0);
+        hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[sl], ah[sl], hl, 0, 0, 0);
+        lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[sl], al[sl], lh, 0, 0, 0);
+    }
+}
+
+// ... and its results -> the ring of the next level.  Lane (frame t' = lane & 31, g = lane >> 5) holds outputs
+// c' = 32 CT + 8 q + 4 g + j (register 4 q + j) of sample row (32 t + t') H/2: four 16-byte stores.  A block is a
+// ring slot (ring sizes are multiples of the block), so the address is a lane constant + immediates; zeros outside the
+// signal (only the first and the last blocks of a clip take the masked path).
+template <int H, int CT>
+__device__ __forceinline__ void pyr_dec_store(const f32x16 &hh, const f32x16 &hl, const f32x16 &lh, float mul, int t, int lane,
+                                              const __amdgpu_buffer_rsrc_t &ring, unsigned ringMask, int dstLen) {
+    constexpr int W = H / 2;                      // outputs per frame
+    constexpr int NQ = W - 32 * CT >= 32 ? 4 : W >= 8 ? W / 8 : 1;  // 16-byte pieces per lane that hold valid outputs
+    const int tf = lane & 31, g = lane >> 5;
+    const int i0 = (32 * t + tf) * W + 32 * CT + 4 * g;
+    const bool laneOk = W >= 8 || g == 0;         // W = 4, 2: outputs 0 ... W-1 sit in the g = 0 half only
+    const unsigned base = laneOk ? ((unsigned)i0 & ringMask) * 4u : 0x80000000u;
+    const int blockLo = 32 * t * W, blockHi = blockLo + 32 * W;
+    const bool inside = blockLo >= 0 && blockHi <= dstLen;  // wave-uniform
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = (hh[4 * q + j] + (hl[4 * q + j] + lh[4 * q + j])) * mul;
+            if (!inside) {
+                const int i = i0 + 8 * q + j;
+                if (i < 0 || i >= dstLen) v[j] = 0.f;
+            }
+        }
+        if (W >= 4) {
+            const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(o, ring, (int)(base + 32u * q), 0, 0);
+        } else {  // hop 4: two outputs per frame
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), ring, (int)base, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), ring, (int)(base + 4u), 0, 0);
+        }
+    }
+}
+
+// ---- wave K: octave level K of the run [t0c, t1c) of `clip`
 template <int K, bool TIMING>
-__device__ __forceinline__ void pyr_consumer(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int clip,
-                                             int t0c, int t1c, unsigned long long *tim) {  // one run
+__device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int clip,
+                                         int t0c, int t1c, unsigned long long *tim) {
     constexpr int H = 128 >> K;
     using C = CqF16<H>;
-    constexpr int NVA = K == 0 ? C::NV / 2 : C::NV;  // level 0: half of the next window before the K loop, half behind it
-    constexpr unsigned RMASK = (unsigned)pyr::ring_size(K) - 1u;
+    constexpr unsigned RMASK = K == 0 ? 0xffffffffu : (unsigned)pyr::ring_size(K) - 1u;
+    constexpr bool DEC = K < AFX_CQT_PYR_LEVELS - 1;  // the last level feeds nobody
+    constexpr int KN = K + 1 < AFX_CQT_PYR_LEVELS ? K + 1 : K;
     unsigned char *Bl = smem;
     unsigned char *sig = smem + C::B_BYTES + pyr::plane_off(K);
+    const unsigned char *tab = smem + C::B_BYTES + pyr::plane_off(7);
     const int i = lane & 31, g = lane >> 5;
     const CqLane L = cq_lane_setup(lane, sig, 12, (6 - K) * 12, a.num, a.timeLength, a.colMul, a.scale, a.octScale[K]);
     const int cpy = i % C::COPIES;
@@ -417,325 +496,177 @@ __device__ __forceinline__ void pyr_consumer(const AfxCqtPyramidArgs &a, unsigne
     const unsigned char *aLo = aHi + C::PART;
     const unsigned char *bHi = Bl + lane * 16;
     const unsigned char *bLo = bHi + C::KS * 64 * 16;
-    const int valid = a.valid[K];
-    // level 0: the clip, framed samples only (the bounds check supplies the zero padding on both sides); other
-    // levels: the ring (zeros outside the signal are IN the ring; samples in [valid, len) are masked below)
+    // tap-table fragment of column c' = i (+ 32 per column tile: 64 bytes down): copy c' mod 4, entry 8 g - 8 (c' >> 2) - 96 (+ 16 ks)
+    const unsigned char *tHi = tab + (i & 3) * pyr::TAB_COPY + 2 * (8 * g - 8 * (i >> 2) - 96);
+    const unsigned char *tLo = tHi + pyr::TAB_PLANE;
+    const int valid = a.valid[K], len = a.len[K];
+    // level 0: the clip (the bounds check supplies the zeros on both sides); other levels: the ring, zeros inside
     const __amdgpu_buffer_rsrc_t rsrc =
-        K == 0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long long)clip * a.xStride), 0, valid * 4, RSRC_RAW)
+        K == 0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long long)clip * a.xStride), 0, len * 4, RSRC_RAW)
                : __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(K), 0, pyr::ring_size(K) * 4, RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t ringNext =
+        __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(KN), 0, pyr::ring_size(KN) * 4, RSRC_RAW);
+    constexpr unsigned NMASK = (unsigned)pyr::ring_size(KN) - 1u;
     float *outRe = a.outRe + (long long)clip * a.outStride, *outIm = a.outIm + (long long)clip * a.outStride;
-    u32x4 wnd[C::NV];
-    auto fetch = [&](int t, int u0, int u1) {
+    // the window of a tile is requested one step ahead: levels 1-6 into registers (<= 10 x 16 bytes per lane); level 0's
+    // eighteen would crowd the K loop out of the register file -- they go straight to LDS (LDS-DMA, float32 in sample
+    // order: the lane / register pattern of `wnd`) and are read behind the wave's own vmcnt wait
+    unsigned char *stage = smem + C::B_BYTES + pyr::plane_off(7) + pyr::TAB_BYTES;
+    u32x4 wnd[C::NV], keep[K == 0 ? 1 : C::NV];
+    auto fetch = [&](int t) {
         const int p0 = t * 32 * H - (C::N >> 1);
 #pragma unroll
         for (int u = 0; u < C::NV; ++u) {
-            if (u < u0 || u >= u1) continue;
             const int pos = p0 + 4 * (lane + 64 * u);
-            if (K == 0) wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pos * 4, 0, 0);
+            if (K == 0) LDS_DMA_B128(rsrc, stage + 1024 * u, (int)((unsigned)pos * 4u));
             else wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)pos & RMASK) * 4u), 0, pyr::AUX_L2);
         }
     };
+    auto arrived = [&]() {  // level 0: LDS -> registers
+        if (K == 0) {
+            VM_WAIT_ALL();
+#pragma unroll
+            for (int u = 0; u < C::NV; ++u) wnd[u] = *reinterpret_cast<const u32x4 *>(stage + 1024 * u + 16 * lane);
+        }
+    };
+    auto clear_from = [&](int t, int first) {  // samples at positions >= first are not part of this use of the window
+        const int p0 = t * 32 * H - (C::N >> 1);
+#pragma unroll
+        for (int u = 0; u < C::NV; ++u) {
+            const int pos = p0 + 4 * (lane + 64 * u);
+            if (pos >= first) wnd[u].x = 0u;
+            if (pos + 1 >= first) wnd[u].y = 0u;
+            if (pos + 2 >= first) wnd[u].z = 0u;
+            if (pos + 3 >= first) wnd[u].w = 0u;
+        }
+    };
+    auto clear_outside = [&](int t, int lo, int hi) {
+        const int p0 = t * 32 * H - (C::N >> 1);
+#pragma unroll
+        for (int u = 0; u < C::NV; ++u) {
+            const int pos = p0 + 4 * (lane + 64 * u);
+            if (pos < lo || pos >= hi) wnd[u].x = 0u;
+            if (pos + 1 < lo || pos + 1 >= hi) wnd[u].y = 0u;
+            if (pos + 2 < lo || pos + 2 >= hi) wnd[u].z = 0u;
+            if (pos + 3 < lo || pos + 3 >= hi) wnd[u].w = 0u;
+        }
+    };
+    auto to_planes = [&]() {  // wnd -> planes; returns 2^-e
+        const int e = cq_window_exponent<H>(wnd, lane);
+        const float up = __uint_as_float((unsigned)(e + 127) << 23);
+        wave_lds_order();
+        cq_convert_window<H>(wnd, up, sig, lane);
+        wave_lds_order();
+        return __uint_as_float((unsigned)(127 - e) << 23);
+    };
+    auto resample = [&](int t, float down) {  // planes -> block t of the next level
+        f32x16 hh, hl, lh;
+        pyr_dec_loop<H, 0>(aHi, aLo, tHi, tLo, hh, hl, lh);
+        pyr_dec_store<H, 0>(hh, hl, lh, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
+        if (H / 2 > 32) {
+            pyr_dec_loop<H, 1>(aHi, aLo, tHi - 128, tLo - 128, hh, hl, lh);  // columns 32 ... 63: 64 table entries down
+            pyr_dec_store<H, 1>(hh, hl, lh, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
+        }
+    };
+    // wave K works on tile s - lag: the octave's rows for tiles of the run, the resampler for the tiles whose block a
+    // lower octave of the run reaches into
+    auto has_oct = [&](int t) { return t >= t0c && t < t1c; };
+    auto has_dec = [&](int t) { return DEC && t >= t0c - pyr::need_back(K) && t <= t1c + pyr::need_ahead(K); };
     const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
     PyrClock<TIMING> clk;
     for (int s = s0; s <= s1; ++s) {
         const int t = s - pyr::lag(K);
-        const bool act = t >= t0c && t < t1c, actNext = t + 1 >= t0c && t + 1 < t1c;  // wave-uniform
+        const bool oct = has_oct(t), dec = has_dec(t), next = has_oct(t + 1) || has_dec(t + 1);  // wave-uniform
+        const int p0 = t * 32 * H - (C::N >> 1);
+        const bool framed = p0 + C::S > valid;  // the framing rule bites: the octave sees fewer samples than the resampler
+        const bool empty = p0 + C::S <= 0 || p0 >= len;  // nothing of the signal in the window: zeros out
+        bool redo = false;
         float down = 0.f;
-        if (act) {
-            const int p0 = t * 32 * H - (C::N >> 1);
-            if (K != 0 && p0 + C::S > valid) {  // stft_algorithm.c:838-843: samples past validLength are not framed
-#pragma unroll
-                for (int u = 0; u < C::NV; ++u) {
-                    const int pos = p0 + 4 * (lane + 64 * u);
-                    if (pos >= valid) wnd[u].x = 0u;
-                    if (pos + 1 >= valid) wnd[u].y = 0u;
-                    if (pos + 2 >= valid) wnd[u].z = 0u;
-                    if (pos + 3 >= valid) wnd[u].w = 0u;
-                }
-            }
-            const int e = cq_window_exponent<H>(wnd, lane);
-            const float up = __uint_as_float((unsigned)(e + 127) << 23);
-            down = __uint_as_float((unsigned)(127 - e) << 23);
+        if (oct || (dec && !empty)) {
+            arrived();
             if (TIMING) {  // time the wait for the window apart from the conversion
 #pragma unroll
                 for (int u = 0; u < C::NV; ++u) PIN(wnd[u]);
                 clk.lap(0);
             }
-            wave_lds_order();
-            cq_convert_window<H>(wnd, up, sig, lane);
-            wave_lds_order();
+            if (oct && framed) {
+                redo = dec;
+                if (K != 0 && redo) {  // (the ring block behind the window is being overwritten by now: keep the samples)
+#pragma unroll
+                    for (int u = 0; u < C::NV; ++u) keep[u] = wnd[u];
+                }
+                clear_from(t, valid);
+            }
+            // a tile resampled but not transformed: row t' reads window positions t' H + 225 ... t' H + H + 285, i.e. the
+            // level's samples 32 t H - 31 ... 32 (t+1) H + 29, and only their blocks are sure to be written (what else
+            // the window covers is not this run's: out of the tile exponent with it)
+            if (!oct) clear_outside(t, p0 + 224, p0 + 32 * H + 288);
+            down = to_planes();
             clk.lap(1);
         }
-        if (actNext) fetch(t + 1, 0, NVA);
+        if (next && !redo) fetch(t + 1);  // (a tile done twice asks for its successor when it is through)
         clk.lap(2);
+        // the resampler first: its stores have the whole K loop to reach the L2 (the wait for the prefetched window
+        // behind the loop covers them: no wait at the barrier), and the octave's epilogue transposes through the planes
+        if (DEC && dec) {
+            if (empty) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                pyr_dec_store<H, 0>(z, z, z, 0.f, t, lane, ringNext, NMASK, a.len[KN]);
+                if (H / 2 > 32) pyr_dec_store<H, 1>(z, z, z, 0.f, t, lane, ringNext, NMASK, a.len[KN]);
+            } else if (!redo) {
+                resample(t, down);
+            }
+        }
+        clk.lap(5);
         f32x16 hh, hl, lh;
-        if (act) cq_kloop<H>(aHi, aLo, bHi, bLo, hh, hl, lh);
+        if (oct) cq_kloop<H>(aHi, aLo, bHi, bLo, hh, hl, lh);
         clk.lap(3);
-        // the prefetched window is in its registers BEFORE the step's barrier (its ring blocks are overwritten three
-        // steps on; nothing younger is in flight here, so this wait costs nothing) ...
+        // the prefetched window is in its registers, the block in the L2, BEFORE the step's barrier (the window's ring
+        // blocks are overwritten three steps on)
+        if (K != 0) {
 #pragma unroll
-        for (int u = 0; u < NVA; ++u) PIN(wnd[u]);
+            for (int u = 0; u < C::NV; ++u) PIN(wnd[u]);
+        }
+        VM_WAIT_ALL();
         clk.lap(4);
-        if (act) cq_store_tile<true>(hh, hl, lh, down, L, outRe, outIm, t * 32);
-        // ... level 0 reads the clip, nothing overwrites it: the second half follows the tile's stores
-        if (K == 0 && actNext) fetch(t + 1, NVA, C::NV);
-        clk.lap(5);
+        if (oct) cq_store_tile<true>(hh, hl, lh, down, L, outRe, outIm, t * 32);
+        if (DEC && redo) {  // a clip's last tiles: the resampler wants the samples the framing rule dropped
+            if (K == 0) {
+                wave_lds_order();
+                fetch(t);  // (the clip: still there)
+                arrived();
+            } else {
+#pragma unroll
+                for (int u = 0; u < C::NV; ++u) wnd[u] = keep[u];
+            }
+            down = to_planes();
+            resample(t, down);
+            if (next) {
+                wave_lds_order();
+                fetch(t + 1);
+            }
+        }
+        if (DEC && redo) VM_WAIT_ALL();
+        clk.lap(7);
         pyr_barrier();
         clk.lap(6);
     }
     clk.flush(tim, lane);
 }
 
-// ---- producers: the 2:1 resampler in rounds of 256 outputs i0 ... i0 + 255 of level k+1 (the first nOut stored), four per
-// lane, TWO ROUNDS AT A TIME (A, B: any two rounds, also of different stages -- the taps are the same): their inputs are
-// staged in LDS interleaved, E2[m] = (XE_A[m], XE_B[m]) with XE[m] = x[2 (i0 - 15 + m)], O2 likewise with
-// XO[m] = x[2 (i0 - 16 + m) + 1], so that a 16-byte read returns aligned register pairs and one v_pk_fma_f32 applies a tap
-// to both rounds.  k_cqt_decimate's arithmetic per output: left taps j = 0..31 at x[2i - j], then right taps j = 1..31 at
-// x[2i + j], one fma chain, divided by sqrt(ratio) -- the same bits.
-//
-// Producer PW, pair p of a step (stage, round of the block): 0: (0,0|0,1) (0,2|0,3); 1: (0,4|0,5) (0,6|0,7); 2: (1,0|1,1) (1,2|1,3);
-// 3: (2,0|2,1) (3,0|4,0) (5,0|-).  Stage k writes block s - 2k of level k+1.
-namespace pyr {
-__host__ __device__ constexpr int pair_stage(int pw, int p, int half) {  // -1: no round in this half
-    return pw < 2 ? 0 : pw == 2 ? 1 : p == 0 ? 2 : p == 1 ? 3 + half : half ? -1 : 5;
-}
-__host__ __device__ constexpr int pair_round(int pw, int p, int half) {
-    return pw < 2 ? 4 * pw + 2 * p + half : pw == 2 ? 2 * p + half : p == 0 ? half : 0;
-}
-}  // namespace pyr
-
-struct PyrRound {
-    int i0;         // first output
-    bool on, zero;  // due in this step; the block lies outside the signal (zeros, no input needed)
-};
-
-template <int K>
-__device__ __forceinline__ PyrRound pyr_round_of(int s, int r, int t0c, int t1c, const AfxCqtPyramidArgs &a) {
-    PyrRound R;
-    if (K < 0) {
-        R.i0 = 0;
-        R.on = false;
-        R.zero = true;
-        return R;
-    }
-    constexpr int KK = K < 0 ? 0 : K, blockOut = 2048 >> KK;
-    const int b = s - 2 * KK;
-    R.i0 = b * blockOut + 256 * r;
-    R.on = b >= t0c - pyr::need_back(KK + 1) && b <= t1c + pyr::need_ahead(KK + 1);  // the run needs that block
-    R.zero = R.i0 >= a.len[KK + 1] || R.i0 + 256 <= 0;
-    return R;
-}
-
-// the round's input on its way: 16 bytes at s_q = 2 i0 - 32 + 4 q hold XE[2q-1], XO[2q], XE[2q], XO[2q+1]; q = 0 ... 146.
-// No control flow around the loads (a load in a branch ends in a copy of its result, i.e. a wait right behind it): a
-// lane or a round with nothing to fetch loads from an out-of-range offset (zeros, no memory access).  Level 0 is the
-// clip -- its bounds check supplies the zeros on both sides --, the others a ring with the zeros inside.
-template <int K>
-__device__ __forceinline__ void pyr_fir_issue(const PyrRound &R, const AfxCqtPyramidArgs &a, float *wgRing, int clip, int lane,
-                                              u32x4 (&v)[3]) {
-    constexpr int KK = K < 0 ? 0 : K;
-    const bool live = K >= 0 && R.on && !R.zero;
-    const __amdgpu_buffer_rsrc_t src =
-        KK == 0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long long)clip * a.xStride), 0, a.len[0] * 4, RSRC_RAW)
-                : __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(KK), 0, pyr::ring_size(KK) * 4, RSRC_RAW);
-    constexpr unsigned mask = KK == 0 ? 0xffffffffu : (unsigned)pyr::ring_size(KK) - 1u;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int q = lane + 64 * u;
-        unsigned off = ((unsigned)(2 * R.i0 - 32 + 4 * q) & mask) * 4u;
-        if (!live || q >= 147) off = 0x80000000u;
-        v[u] = __builtin_amdgcn_raw_buffer_load_b128(src, (int)off, 0, pyr::AUX_L2);
-    }
-}
-
-// the four outputs of a lane -> its ring, zeros outside the signal
-template <int K>
-__device__ __forceinline__ void pyr_fir_store(const PyrRound &R, const float (&r)[4], const AfxCqtPyramidArgs &a, float *wgRing, int lane) {
-    if (K < 0) return;
-    constexpr int KK = K < 0 ? 0 : K, blockOut = 2048 >> KK, nOut = blockOut < 256 ? blockOut : 256;
-    if (!R.on || 4 * lane >= nOut) return;
-    const int i = R.i0 + 4 * lane, dstLen = a.len[KK + 1];
-    u32x4 o;
-    o.x = (i >= 0 && i < dstLen) ? __float_as_uint(r[0]) : 0u;
-    o.y = (i + 1 >= 0 && i + 1 < dstLen) ? __float_as_uint(r[1]) : 0u;
-    o.z = (i + 2 >= 0 && i + 2 < dstLen) ? __float_as_uint(r[2]) : 0u;
-    o.w = (i + 3 >= 0 && i + 3 < dstLen) ? __float_as_uint(r[3]) : 0u;
-    const __amdgpu_buffer_rsrc_t dst =
-        __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(KK + 1), 0, pyr::ring_size(KK + 1) * 4, RSRC_RAW);
-    constexpr unsigned dstMask = (unsigned)pyr::ring_size(KK + 1) - 1u;
-    __builtin_amdgcn_raw_buffer_store_b128(o, dst, (int)(((unsigned)i & dstMask) * 4u), 0, 0);
-}
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-template <int KA, int KB, bool TIMING>
-__device__ __forceinline__ void pyr_fir_pair(const PyrRound &RA, const PyrRound &RB, u32x4 (&va)[3], u32x4 (&vb)[3], const v2 (&hp)[16],
-                                             float sqrtRatio, const AfxCqtPyramidArgs &a, float *wgRing, v2 *E2, v2 *O2, int lane,
-                                             PyrClock<TIMING> &clk) {
-    const bool liveA = KA >= 0 && RA.on && !RA.zero, liveB = KB >= 0 && RB.on && !RB.zero;
-    float rA[4] = {0.f, 0.f, 0.f, 0.f}, rB[4] = {0.f, 0.f, 0.f, 0.f};
-    if (liveA || liveB) {
-        if (TIMING) {
-            clk.lap(0);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                PIN(va[u]);
-                PIN(vb[u]);
-            }
-            clk.lap(2);  // waiting for the rounds' input
-        }
-        __builtin_amdgcn_wave_barrier();  // (the previous pair's reads were waited for before its taps)
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int q = lane + 64 * u;
-            if (q < 147) {
-                const float4 fa = __builtin_bit_cast(float4, va[u]), fb = __builtin_bit_cast(float4, vb[u]);
-                const int m = 2 * q - 1;
-                if (m >= 0) E2[m] = v2{fa.x, fb.x};
-                O2[m + 1] = v2{fa.y, fb.y};
-                E2[m + 1] = v2{fa.z, fb.z};
-                O2[m + 2] = v2{fa.w, fb.w};
-            }
-        }
-        wave_lds_order();
-        // entries e (two per 16-byte read) of the lane's window: E2[4 lane + e], O2[4 lane + e]; the left taps need
-        // entries 0 ... 18 of both, the right taps 16 ... 34: two register sets of 20, one after the other
-        const v2 *pe = E2 + 4 * lane, *po = O2 + 4 * lane;
-        v2 acc[4] = {v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}};
-        {
-            f4 ev[10], ov[10];
-            RD128_P(ev[0], pe, 0);    RD128_P(ov[0], po, 0);    RD128_P(ev[1], pe, 16);   RD128_P(ov[1], po, 16);
-            RD128_P(ev[2], pe, 32);   RD128_P(ov[2], po, 32);   RD128_P(ev[3], pe, 48);   RD128_P(ov[3], po, 48);
-            RD128_P(ev[4], pe, 64);   RD128_P(ov[4], po, 64);   RD128_P(ev[5], pe, 80);   RD128_P(ov[5], po, 80);
-            RD128_P(ev[6], pe, 96);   RD128_P(ov[6], po, 96);   RD128_P(ev[7], pe, 112);  RD128_P(ov[7], po, 112);
-            RD128_P(ev[8], pe, 128);  RD128_P(ov[8], po, 128);  RD128_P(ev[9], pe, 144);  RD128_P(ov[9], po, 144);
-            LDS_WAIT_N(0);
-            clk.lap(3);  // staging through LDS
-#pragma unroll
-            for (int b = 0; b < 10; ++b) {
-                PIN(ev[b]);
-                PIN(ov[b]);
-            }
-            auto E = [&](int e) { return (e & 1) ? v2{ev[e >> 1].z, ev[e >> 1].w} : v2{ev[e >> 1].x, ev[e >> 1].y}; };
-            auto O = [&](int e) { return (e & 1) ? v2{ov[e >> 1].z, ov[e >> 1].w} : v2{ov[e >> 1].x, ov[e >> 1].y}; };
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {  // x[2i - j]: even j -> x[2 (i - j/2)], odd j -> x[2 (i - (j+1)/2) + 1]
-                if (j & 1) {
-                    const int e = 16 - (j + 1) / 2;
-                    pk_tap4_hi(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], O(e), O(e + 1), O(e + 2), O(e + 3));
-                } else {
-                    const int e = 15 - j / 2;
-                    pk_tap4_lo(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], E(e), E(e + 1), E(e + 2), E(e + 3));
-                }
-            }
-        }
-        {
-            f4 ev[10], ov[10];  // entries 16 ... 35
-            RD128_P(ev[0], pe, 128);  RD128_P(ov[0], po, 128);  RD128_P(ev[1], pe, 144);  RD128_P(ov[1], po, 144);
-            RD128_P(ev[2], pe, 160);  RD128_P(ov[2], po, 160);  RD128_P(ev[3], pe, 176);  RD128_P(ov[3], po, 176);
-            RD128_P(ev[4], pe, 192);  RD128_P(ov[4], po, 192);  RD128_P(ev[5], pe, 208);  RD128_P(ov[5], po, 208);
-            RD128_P(ev[6], pe, 224);  RD128_P(ov[6], po, 224);  RD128_P(ev[7], pe, 240);  RD128_P(ov[7], po, 240);
-            RD128_P(ev[8], pe, 256);  RD128_P(ov[8], po, 256);  RD128_P(ev[9], pe, 272);  RD128_P(ov[9], po, 272);
-            LDS_WAIT_N(0);
-#pragma unroll
-            for (int b = 0; b < 10; ++b) {
-                PIN(ev[b]);
-                PIN(ov[b]);
-            }
-            auto E = [&](int e) { return ((e - 16) & 1) ? v2{ev[(e - 16) >> 1].z, ev[(e - 16) >> 1].w} : v2{ev[(e - 16) >> 1].x, ev[(e - 16) >> 1].y}; };
-            auto O = [&](int e) { return ((e - 16) & 1) ? v2{ov[(e - 16) >> 1].z, ov[(e - 16) >> 1].w} : v2{ov[(e - 16) >> 1].x, ov[(e - 16) >> 1].y}; };
-#pragma unroll
-            for (int j = 1; j < 32; ++j) {  // x[2i + j]: even j -> x[2 (i + j/2)], odd j -> x[2 (i + (j-1)/2) + 1]
-                if (j & 1) {
-                    const int e = 16 + (j - 1) / 2;
-                    pk_tap4_hi(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], O(e), O(e + 1), O(e + 2), O(e + 3));
-                } else {
-                    const int e = 15 + j / 2;
-                    pk_tap4_lo(acc[0], acc[1], acc[2], acc[3], hp[j >> 1], E(e), E(e + 1), E(e + 2), E(e + 3));
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            rA[q] = acc[q].x / sqrtRatio;
-            rB[q] = acc[q].y / sqrtRatio;
-        }
-        if (TIMING) {
-            PIN(rA[0]); PIN(rA[3]); PIN(rB[0]); PIN(rB[3]);
-            clk.lap(4);  // the taps
-        }
-    }
-    pyr_fir_store<KA>(RA, rA, a, wgRing, lane);
-    pyr_fir_store<KB>(RB, rB, a, wgRing, lane);
-}
-
-template <int PW, bool TIMING>
-__device__ __forceinline__ void pyr_producer(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int clip,
-                                             int t0c, int t1c, unsigned long long *tim) {
-    v2 *E2 = reinterpret_cast<v2 *>(smem + CqF16<128>::B_BYTES + pyr::plane_off(7) + PW * pyr::FIR_BYTES);
-    v2 *O2 = E2 + pyr::FIR_WORDS;
-    const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
-    v2 hp[16];  // the taps in VECTOR registers, pairs (h[2n], h[2n+1]): as scalars next to the descriptors they spill
-#pragma unroll
-    for (int n = 0; n < 16; ++n) {
-        hp[n] = v2{a.taps[2 * n], a.taps[2 * n + 1]};
-        PIN(hp[n]);
-    }
-    const float sqrtRatio = a.sqrtRatio;
-    PyrClock<TIMING> clk;
-    constexpr int K0A = pyr::pair_stage(PW, 0, 0), K0B = pyr::pair_stage(PW, 0, 1), K1A = pyr::pair_stage(PW, 1, 0), K1B = pyr::pair_stage(PW, 1, 1);
-    constexpr int K2A = PW == 3 ? pyr::pair_stage(PW, 2, 0) : -1, K2B = -1;
-    constexpr int R0A = pyr::pair_round(PW, 0, 0), R0B = pyr::pair_round(PW, 0, 1), R1A = pyr::pair_round(PW, 1, 0), R1B = pyr::pair_round(PW, 1, 1);
-    // the input of a pair is requested one pair ahead, and across the step's barrier when it comes from the clip
-    // (producers 0 and 1; a ring block is only complete behind the barrier): two register sets, used in turn
-    constexpr bool AHEAD = PW < 2;
-    u32x4 a0[3], b0[3], a1[3], b1[3];
-    if (AHEAD) {
-        pyr_fir_issue<K0A>(pyr_round_of<K0A>(s0, R0A, t0c, t1c, a), a, wgRing, clip, lane, a0);
-        pyr_fir_issue<K0B>(pyr_round_of<K0B>(s0, R0B, t0c, t1c, a), a, wgRing, clip, lane, b0);
-    }
-    for (int s = s0; s <= s1; ++s) {
-        const PyrRound P0A = pyr_round_of<K0A>(s, R0A, t0c, t1c, a), P0B = pyr_round_of<K0B>(s, R0B, t0c, t1c, a);
-        const PyrRound P1A = pyr_round_of<K1A>(s, R1A, t0c, t1c, a), P1B = pyr_round_of<K1B>(s, R1B, t0c, t1c, a);
-        if (!AHEAD) {
-            pyr_fir_issue<K0A>(P0A, a, wgRing, clip, lane, a0);
-            pyr_fir_issue<K0B>(P0B, a, wgRing, clip, lane, b0);
-        }
-        pyr_fir_issue<K1A>(P1A, a, wgRing, clip, lane, a1);
-        pyr_fir_issue<K1B>(P1B, a, wgRing, clip, lane, b1);
-        pyr_fir_pair<K0A, K0B, TIMING>(P0A, P0B, a0, b0, hp, sqrtRatio, a, wgRing, E2, O2, lane, clk);
-        if (AHEAD) {  // (harmless behind the run's last step)
-            pyr_fir_issue<K0A>(pyr_round_of<K0A>(s + 1, R0A, t0c, t1c, a), a, wgRing, clip, lane, a0);
-            pyr_fir_issue<K0B>(pyr_round_of<K0B>(s + 1, R0B, t0c, t1c, a), a, wgRing, clip, lane, b0);
-        }
-        const PyrRound P2A = pyr_round_of<K2A>(s, 0, t0c, t1c, a), P2B = pyr_round_of<K2B>(s, 0, t0c, t1c, a);
-        if (PW == 3) {
-            pyr_fir_issue<K2A>(P2A, a, wgRing, clip, lane, a0);
-            pyr_fir_issue<K2B>(P2B, a, wgRing, clip, lane, b0);
-        }
-        pyr_fir_pair<K1A, K1B, TIMING>(P1A, P1B, a1, b1, hp, sqrtRatio, a, wgRing, E2, O2, lane, clk);
-        if (PW == 3) pyr_fir_pair<K2A, K2B, TIMING>(P2A, P2B, a0, b0, hp, sqrtRatio, a, wgRing, E2, O2, lane, clk);
-        clk.lap(5);
-        VM_WAIT_ALL();  // the blocks are in the L2 before the other waves pass the barrier
-        clk.lap(1);
-        pyr_barrier();
-        clk.lap(6);
-    }
-    clk.flush(tim, lane);
-}
-
-// the runs of this workgroup, one after the other; ROLE 0-6: consumer of that level, 7-10: producer ROLE - 7
-template <int ROLE, bool TIMING>
+// the runs of this workgroup, one after the other
+template <int K, bool TIMING>
 __device__ __forceinline__ void pyr_role(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int items) {
-    unsigned long long *tim = TIMING && a.timing ? a.timing + ((size_t)blockIdx.x * pyr::WAVES + (threadIdx.x >> 6)) * 8 : nullptr;
+    unsigned long long *tim = TIMING && a.timing ? a.timing + ((size_t)blockIdx.x * 11 + (threadIdx.x >> 6)) * 8 : nullptr;
     const int nT = (a.timeLength + 31) / 32;
     for (int it = blockIdx.x; it < items; it += gridDim.x) {
         const int clip = it / a.chunksPerClip, chunk = it - clip * a.chunksPerClip;
         const int t0c = chunk * a.tilesPerChunk;
         const int t1c = t0c + a.tilesPerChunk < nT ? t0c + a.tilesPerChunk : nT;
         if (t0c >= t1c) continue;  // (uniform over the workgroup)
-        if (ROLE < pyr::CONSUMERS) pyr_consumer<(ROLE < pyr::CONSUMERS ? ROLE : 0), TIMING>(a, smem, lane, wgRing, clip, t0c, t1c, tim);
-        else pyr_producer<(ROLE >= pyr::CONSUMERS ? ROLE - pyr::CONSUMERS : 0), TIMING>(a, smem, lane, wgRing, clip, t0c, t1c, tim);
+        pyr_wave<K, TIMING>(a, smem, lane, wgRing, clip, t0c, t1c, tim);
     }
 }
 
@@ -745,10 +676,15 @@ __global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidAr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cq_image_to_lds(a.timeKernelH, smem_raw, tid, 64 * pyr::WAVES);
+    {
+        const unsigned *src = reinterpret_cast<const unsigned *>(a.decTab);
+        unsigned *dst = reinterpret_cast<unsigned *>(smem_raw + CqF16<128>::B_BYTES + pyr::plane_off(7));
+        for (int e = tid; e < pyr::TAB_BYTES / 4; e += 64 * pyr::WAVES) dst[e] = src[e];
+    }
     __syncthreads();
     float *wgRing = a.ring + (size_t)blockIdx.x * AFX_CQT_PYR_RING_FLOATS;
     // (the loop over the workgroup's runs sits INSIDE every role: around the switch, the compiler hoists the per-lane
-    // constants of all eight roles in front of it and spills them)
+    // constants of all seven roles in front of it and spills them)
     switch (wave) {
         case 0: pyr_role<0, TIMING>(a, smem_raw, lane, wgRing, items); break;
         case 1: pyr_role<1, TIMING>(a, smem_raw, lane, wgRing, items); break;
@@ -756,11 +692,7 @@ __global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidAr
         case 3: pyr_role<3, TIMING>(a, smem_raw, lane, wgRing, items); break;
         case 4: pyr_role<4, TIMING>(a, smem_raw, lane, wgRing, items); break;
         case 5: pyr_role<5, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 6: pyr_role<6, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 7: pyr_role<7, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 8: pyr_role<8, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 9: pyr_role<9, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        default: pyr_role<10, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        default: pyr_role<6, TIMING>(a, smem_raw, lane, wgRing, items); break;
     }
 }
 
@@ -818,7 +750,7 @@ extern "C" int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
 extern "C" int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerClip, int *tilesPerChunk) {
     if (batch <= 0 || timeLength <= 0) return 0;
     const int nT = (timeLength + 31) / 32;
-    // runs of one clip: as many as fill the CUs, but long enough that the 24 steps of lead-in and drain stay small
+    // runs of one clip: as many as fill the CUs, but long enough that the 30 steps of lead-in and drain stay small
     int cpc = AFX_CQT_PYR_MAX_WGS / batch;
     if (cpc > nT / 48) cpc = nT / 48;
     if (cpc < 1) cpc = 1;
@@ -833,7 +765,7 @@ extern "C" int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerCl
 }
 
 extern "C" int afxk_cqt_pyramid(const AfxCqtPyramidArgs *a, void *stream) {
-    if (!a->x || !a->timeKernelH || !a->colMul || !a->scale || !a->outRe || !a->outIm || !a->ring) return AFX_ERR_ARG;
+    if (!a->x || !a->timeKernelH || !a->colMul || !a->scale || !a->outRe || !a->outIm || !a->ring || !a->decTab) return AFX_ERR_ARG;
     if (a->batch <= 0 || a->timeLength <= 0 || a->chunksPerClip <= 0 || a->tilesPerChunk <= 0) return AFX_ERR_ARG;
     // 32-bit byte offsets inside one clip's signal and one clip's output plane
     if (a->len[0] > (1 << 28) || (long long)a->timeLength * a->num > (1LL << 28)) return AFX_ERR_UNSUPPORTED;

@@ -316,14 +316,16 @@ int afxk_cqt_octave(const AfxCqtOctaveArgs *a, void *stream);
 /* f16 matrix-core variant; AFX_ERR_UNSUPPORTED when the plan / alignment is outside its scope */
 int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream);
 /* The whole default ladder in ONE persistent launch (afx_cqt_f16.hip: k_cqt_pyramid): N = 512, 12 bins per octave,
- * seven octaves, hop 128 halving to 2.  Every workgroup walks a run of 32-frame tiles of one clip; seven of its
- * waves own one octave each (window -> f16 (hi, lo) planes -> matrix-core product -> rows), four run the 63-tap 2:1
- * decimation chain one block per level and step ahead of them; the level signals live in per-workgroup rings of
- * `ring` that stay in the L2, so a clip is read from HBM once and no level signal goes back to it.
+ * seven octaves, hop 128 halving to 2.  Every workgroup walks a run of 32-frame tiles of one clip; its seven waves own
+ * one octave each (window -> f16 (hi, lo) planes -> matrix-core product -> rows) and make the next level's samples
+ * from the same planes (the 63-tap 2:1 resampler as one more matrix-core product); the level signals live in
+ * per-workgroup rings of `ring` that stay in the L2, so a clip is read from HBM once and no level signal goes back to it.
  * cqt_algorithm.c:951-1048 (octave recursion), dsp/resample_algorithm.c:430-521 (the resampler). */
 #define AFX_CQT_PYR_LEVELS 7
 #define AFX_CQT_PYR_RING_FLOATS 17408 /* per workgroup: rings of 8192, 4096, 2048, 1024, 1024, 1024 samples */
 #define AFX_CQT_PYR_MAX_WGS 256
+#define AFX_CQT_PYR_TAB_COPY 704       /* bytes of one shifted copy of the tap table (328 f16 entries, padded) */
+#define AFX_CQT_PYR_TAB_HALFS (2 * 4 * AFX_CQT_PYR_TAB_COPY / 2) /* [2 words][4 copies]                */
 typedef struct {
     const float *x;          /* device clips (level 0)                                  */
     long long xStride;       /* samples between clips                                   */
@@ -336,8 +338,9 @@ typedef struct {
     float *outRe, *outIm;    /* device [batch][T, num]                                  */
     long long outStride;
     float *ring;             /* device scratch, AFX_CQT_PYR_RING_FLOATS floats per workgroup */
-    float taps[32];          /* resampler FIR                                           */
-    float sqrtRatio;
+    const unsigned short *decTab; /* device [AFX_CQT_PYR_TAB_HALFS]: the resampler taps h[|d|] 2^15 as f16 (hi, lo)
+                              * words, d = -160 ... 167, four copies shifted by 0, 2, 4, 6 entries (afx_cqt_dec_table) */
+    float decMul;            /* 2^-15 / sqrt(ratio): undoes the table scaling, applies the resampler's isScale   */
     int chunksPerClip, tilesPerChunk; /* work items: clip-major runs of tiles            */
     /* chroma in the same launch (chromaNum == 12 == bins per octave): NULL = off         */
     float *chroma;           /* device [batch][T, 12]                                   */

@@ -57,6 +57,7 @@ struct OpaqueCQT {
     size_t capSig[2];
     float *dRing;            /* level rings of the one-launch ladder (k_cqt_pyramid), per workgroup */
     size_t capRing;
+    unsigned short *dDecTab; /* the resampler taps as the f16 table of k_cqt_pyramid (afx_cqt_dec_table) */
     unsigned long long *dTiming; /* AFX_CQT_PYR_TIMING=1: phase cycles of the instrumented kernel (afx_cqt_pyramid_timing) */
     void *lastStream;        /* stream of the previous device call (scratch ordering) */
     int lastUsed;
@@ -127,6 +128,25 @@ void afx_cqt_time_kernel_f16(const float *G, int N, unsigned short *out, float *
             out[(((size_t)1 * KS + ks) * 64 + l) * 8 + e] = lo;
         }
     }
+}
+
+/* The 2:1 resampler's taps as k_cqt_pyramid reads them (afx_device.h: AfxCqtPyramidArgs.decTab): T[d] = h[|d|] 2^15 for
+ * |d| <= 31, zero elsewhere, as binary16 (hi, lo) words, out[word][copy a][x] = T[x - 160 - 2a], x < 352: the copy
+ * shifted by 2a entries makes the eight taps of column c' = 4m + a of a K step a 16-byte aligned fragment. */
+void afx_cqt_dec_table(const float *taps32, unsigned short *out) {
+    const int per = AFX_CQT_PYR_TAB_COPY / 2;
+    memset(out, 0, sizeof(unsigned short) * AFX_CQT_PYR_TAB_HALFS);
+    for (int a = 0; a < 4; a++)
+        for (int x = 0; x < per; x++) {
+            int d = x - 160 - 2 * a;
+            if (d < 0) d = -d;
+            if (d > 31) continue;
+            const float v = ldexpf(taps32[d], 15); /* exact */
+            const unsigned short hi = cqt_f32_to_f16(v);
+            const unsigned short lo = cqt_f32_to_f16(v - cqt_f16_to_f32(hi));
+            out[(0 * 4 + a) * per + x] = hi;
+            out[(1 * 4 + a) * per + x] = lo;
+        }
 }
 
 int cqtObj_new(CQTObj *cqtObj, int num, int samplate, float minFre, int *isContinue) {
@@ -410,6 +430,12 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
                 afx_cqt_time_kernel_f16(timeKernel + (size_t)g * N * 32, N, kh + (size_t)g * perGroup, cm + (size_t)g * 32);
             UP(o->dTimeKernelH, kh, sizeof(unsigned short) * (size_t)groups * perGroup);
             UP(o->dColMul, cm, sizeof(float) * (size_t)groups * 32);
+            {   /* the resampler's tap table of the one-launch ladder (k_cqt_pyramid) */
+                unsigned short dt[AFX_CQT_PYR_TAB_HALFS];
+                afx_cqt_dec_table(o->taps, dt);
+                UP(o->dDecTab, dt, sizeof(dt));
+                if (st == AFX_OK) st = afxdev_stream_sync(o->stream); /* dt leaves scope */
+            }
             /* the uploads above are asynchronous on o->stream: synced below before the host copies are freed */
             if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
         }
@@ -504,7 +530,7 @@ static int cqt_pyramid_ok(CQTObj o, int dataLength) {
         const char *e = getenv("AFX_CQT_PYRAMID");
         env = !(e && e[0] == '0');
     }
-    return env && !afxdev_no_fused() && o->dTimeKernelH && o->dColMul && o->colTiles == 1 && o->radix2Exp == 9 &&
+    return env && !afxdev_no_fused() && o->dTimeKernelH && o->dColMul && o->dDecTab && o->colTiles == 1 && o->radix2Exp == 9 &&
            o->binPerOctave == 12 && o->octaveNum == AFX_CQT_PYR_LEVELS && o->slideLength == 128 && !o->isContinue &&
            !o->vFlag && dataLength > 0 && dataLength <= (1 << 28) &&
            afxk_cqt_pyramid_plan(1, dataLength / 128 + 1, NULL, NULL) > 0; /* (0: a device layer without the kernel) */
@@ -540,8 +566,8 @@ static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength,
     a.outIm = dIm;
     a.outStride = (long long)T * o->num;
     a.ring = o->dRing;
-    memcpy(a.taps, o->taps, sizeof(a.taps));
-    a.sqrtRatio = sqrtf(0.5f);
+    a.decTab = o->dDecTab;
+    a.decMul = (float)(ldexp(1.0, -15) / (double)sqrtf(0.5f));
     if (getenv("AFX_CQT_PYR_TIMING")) { /* measurement builds only: the instrumented instantiation */
         const size_t bytes = sizeof(unsigned long long) * AFX_CQT_PYR_MAX_WGS * 11 * 8;
         if (!o->dTiming) {
@@ -564,6 +590,18 @@ static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength,
         }
     }
     return afxk_cqt_pyramid(&a, stream);
+}
+
+/* test hook: the level rings of the first `wgs` workgroups as the last k_cqt_pyramid launch left them
+ * (AFX_CQT_PYR_RING_FLOATS floats each: levels 1 ... 6 at offsets 0, 8192, 12288, 14336, 15360, 16384; sample p of a
+ * level at p mod the ring's size) -- tests/test_cqt_pyramid.py checks the resampler against the filter in float64 */
+int afx_cqt_pyramid_rings(CQTObj o, float *host, int wgs) {
+    if (!o || !o->dRing || !host || wgs <= 0) return 0;
+    const size_t bytes = sizeof(float) * (size_t)wgs * AFX_CQT_PYR_RING_FLOATS;
+    if (bytes > o->capRing) return 0;
+    if (o->lastUsed) afxdev_stream_sync(o->lastStream);
+    if (afxdev_d2h(host, o->dRing, bytes, o->stream) != AFX_OK || afxdev_stream_sync(o->stream) != AFX_OK) return 0;
+    return wgs;
 }
 
 /* AFX_CQT_PYR_TIMING=1: copies out (and clears) the phase cycles the instrumented k_cqt_pyramid accumulated:
@@ -1110,6 +1148,7 @@ void cqtObj_free(CQTObj o) {
     afxdev_free(o->dSig[1]);
     afxdev_free(o->dRing);
     afxdev_free(o->dTiming);
+    afxdev_free(o->dDecTab);
     afxdev_free(o->dOut);
     afxdev_free(o->dIn);
     afxdev_free(o->dDct);

@@ -64,6 +64,9 @@ unsigned char *afx_chroma_fold(int chromaNum, int num, int bpo, float minFre);
  * of v_mfma_f32_32x32x16_f16: out[word][N/16 steps][64 lanes][8], lane l = 32 g + j holds rows
  * 16 ks + 8 g + e of column j; colMul[32] = 2^-s_j (afx_cqt_f16.hip) */
 void afx_cqt_time_kernel_f16(const float *G, int N, unsigned short *out, float *colMul);
+/* afx_cqt.c: the 2:1 resampler's 32 taps -> out[AFX_CQT_PYR_TAB_HALFS] (afx_device.h): T[d] = h[|d|] 2^15 as binary16
+ * (hi, lo) words, [word][copy a][x] = T[x - 160 - 2a] -- the operand table of k_cqt_pyramid's resampler product */
+void afx_cqt_dec_table(const float *taps32, unsigned short *out);
 /* afx_cqt.c: 0/1 folding matrix -> per-class bin lists (afx_device.h: AfxChromaLists); 0 on success */
 struct AfxChromaLists_;
 int afx_chroma_lists(const unsigned char *fold, int chromaNum, int num, struct AfxChromaLists_ *out);

@@ -32,10 +32,10 @@ nT = (T + 31) // 32
 wgs = min(256, clips * max(1, min(256 // clips, nT // 48)))
 used = buf[:wgs].astype(np.float64)
 print(f"{clips} clips, {ms:.3f} ms per call (instrumented), {wgs} workgroups; cycles per step and wave (mean over workgroups)")
-cpc = max(1, min(256 // clips, nT // 48)); tpc = -(-nT // cpc); steps = (tpc + 25) * reps * max(1, -(-clips * cpc // 256))
-names_c = ["wait-window", "convert", "fetch-issue", "k-loop", "wait-prefetch", "store(+fetchB)", "barrier", "-"]
+cpc = max(1, min(256 // clips, nT // 48)); tpc = -(-nT // cpc); steps = (tpc + 31) * reps * max(1, -(-clips * cpc // 256))
+names_c = ["wait-window", "convert", "fetch-issue", "k-loop", "wait-prefetch", "resample", "barrier", "store+vm-wait"]
 names_p = ["issue-loads", "vm-wait", "wait-input", "lds-stage", "taps", "stores/other", "barrier", "-"]
-for w in range(11):
+for w in range(7):
     m = used[:, w, :].mean(axis=0) / steps
     nm = names_c if w < 7 else names_p
     print(f"wave {w:2d} ({'octave level %d' % w if w < 7 else 'producer %d' % (w - 7)}): total {m.sum():8.0f} | " +
