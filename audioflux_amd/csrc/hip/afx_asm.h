@@ -140,10 +140,6 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 #define PIN(x) asm volatile("" : "+v"(x))
 #define LDS_WAIT_N(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
 // ---- global memory
-// 16 bytes per lane from a raw buffer straight into LDS (no VGPR): lane l's dwords land at lds + 16 l; out-of-range dwords
-// arrive as zeros; counted by vmcnt -- the issuing wave reads the bytes behind its own s_waitcnt vmcnt
-#define LDS_DMA_B128(rsrc, lds, voff) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void *)(lds), 16, (voff), 0, 0, 0)
 #define VM_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")             // own stores -> L2 (vmcnt counts stores on gfx9)
 #define VM_LGKM_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 // 16-byte load served by the L2, never by this CU's L1 (rows another lane of the wave stored a moment ago)

@@ -354,13 +354,13 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_cqt_octave_f16(AfxCqtO
 // stft_algorithm.c:838-843) costs the few tiles at a clip's end a second conversion.
 
 namespace pyr {
-constexpr int WAVES = 7;
-constexpr int LEAD = 9, DRAIN = 21;
+constexpr int WAVES = 8;
+constexpr int LEAD = 9, DRAIN = 22;
 __host__ __device__ constexpr int ring_size(int k) { return k >= 4 ? 1024 : 16384 >> k; }  // 8192, 4096, 2048, 1024 x 3
 __host__ __device__ constexpr int ring_off(int k) { return k <= 4 ? 16384 - (32768 >> k) : 14336 + (k - 4) * 1024; }
 static_assert(ring_off(1) == 0 && ring_off(2) == 8192 && ring_off(3) == 12288 && ring_off(4) == 14336 && ring_off(5) == 15360, "ring layout");
 static_assert(ring_off(6) + ring_size(6) == AFX_CQT_PYR_RING_FLOATS, "ring layout");
-__host__ __device__ constexpr int lag(int k) { return k == 0 ? 0 : k <= 4 ? 3 * k : k == 5 ? 16 : 22; }
+__host__ __device__ constexpr int lag(int k) { return k <= 4 ? 3 * k + 1 : k == 5 ? 17 : 23; }  // (level 0 is PREPARED a step before)
 __host__ __device__ constexpr int plane_bytes(int k) {
     return k == 0 ? CqF16<128>::WAVE_BYTES : k == 1 ? CqF16<64>::WAVE_BYTES : k == 2 ? CqF16<32>::WAVE_BYTES
          : k == 3 ? CqF16<16>::WAVE_BYTES : k == 4 ? CqF16<8>::WAVE_BYTES : k == 5 ? CqF16<4>::WAVE_BYTES : CqF16<2>::WAVE_BYTES;
@@ -369,9 +369,9 @@ __host__ __device__ constexpr int plane_off(int k) { return k == 0 ? 0 : plane_o
 // the tap table: 2 word planes x 4 shifted copies
 constexpr int TAB_COPY = AFX_CQT_PYR_TAB_COPY, TAB_PLANE = 4 * TAB_COPY, TAB_BYTES = 2 * TAB_PLANE;
 static_assert(TAB_BYTES == AFX_CQT_PYR_TAB_HALFS * 2, "tap table");
-// level 0's next window on its way (LDS-DMA, float32 in sample order): 18 x 1 KB
-constexpr int STAGE_BYTES = CqF16<128>::NV * 1024;
-constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + TAB_BYTES + STAGE_BYTES;
+// level 0's second plane buffer (tiles alternate), and the 2^-e of the two
+constexpr int ALT_BYTES = CqF16<128>::WAVE_BYTES;
+constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + TAB_BYTES + ALT_BYTES + 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr int AUX_L2 = 17;                           // sc0 sc1: served by the L2, never by this CU's L1
 // tiles of level k whose resampler output (block of level k+1) a run [t0, t1) needs: [t0 - need_back(k), t1 + need_ahead(k)]
@@ -413,7 +413,7 @@ __device__ __forceinline__ void pyr_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// the resampler product of the tile in the planes: columns c' = 32 CT + (lane & 31) of every frame row
+// the resampler product of the tile in the planes: outputs c' = 32 CT + (row) of every frame (column); operands two steps ahead
 template <int H, int CT>
 __device__ __forceinline__ void pyr_dec_loop(const unsigned char *aHi, const unsigned char *aLo, const unsigned char *tHi, const unsigned char *tLo,
                                              f32x16 &hh, f32x16 &hl, f32x16 &lh) {
@@ -421,7 +421,7 @@ __device__ __forceinline__ void pyr_dec_loop(const unsigned char *aHi, const uns
     constexpr int KS0 = pyr::dec_ks0(CT), KS1 = pyr::dec_ks1(H, CT);
 #pragma unroll
     for (int r = 0; r < 16; ++r) hh[r] = hl[r] = lh[r] = 0.f;
-    h8 ah[2], al[2], th[2], tl[2];
+    h8 ah[3], al[3], th[3], tl[3];
     auto load = [&](int ks, int slot) {
         ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
         al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
@@ -429,15 +429,42 @@ __device__ __forceinline__ void pyr_dec_loop(const unsigned char *aHi, const uns
         tl[slot] = *reinterpret_cast<const h8 *>(tLo + 32 * ks);
     };
     load(KS0, 0);
+    load(KS0 + 1, 1);
 #pragma unroll
     for (int ks = KS0; ks <= KS1; ++ks) {
-        const int sl = (ks - KS0) & 1;
-        if (ks < KS1) load(ks + 1, sl ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 <= KS1) load(ks + 2, (ks + 2 - KS0) % 3);
+        const int sl = (ks - KS0) % 3;
         // the taps as the A operand: result ROW = output c', COLUMN = frame -- a lane then holds runs of four consecutive
         // outputs of its frame (16-byte stores)
         hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[sl], ah[sl], hh, 0, 0, 0);
         hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[sl], ah[sl], hl, 0, 0, 0);
         lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[sl], al[sl], lh, 0, 0, 0);
+        if (ks + 2 <= KS1) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The framing rule (stft_algorithm.c:838-843: samples in [validLength, length) are not framed) on planes that hold the
+// whole signal -- the resampler reads those samples --: window samples first ... last - 1 become zeros in both word planes
+// and every copy, two bytes per lane and trip (a clip's last tiles only; at most hop - 1 samples)
+template <int H>
+__device__ __forceinline__ void cq_zero_samples(unsigned char *sig, int first, int last, int lane) {
+    using C = CqF16<H>;
+    for (int s = first + lane; s < last; s += 64) {
+#pragma unroll
+        for (int c = 0; c < C::COPIES; ++c) {
+            unsigned char *d = sig + c * C::CS + C::at(s, c);
+            *reinterpret_cast<unsigned short *>(d) = 0;
+            *reinterpret_cast<unsigned short *>(d + C::PART) = 0;
+        }
     }
 }
 
@@ -477,26 +504,35 @@ __device__ __forceinline__ void pyr_dec_store(const f32x16 &hh, const f32x16 &hl
     }
 }
 
-// ---- wave K: octave level K of the run [t0c, t1c) of `clip`
-template <int K, bool TIMING>
+// ---- one wave's part of the run [t0c, t1c) of `clip`.  PART 0: level K whole (levels 1-6).  Level 0 is shared by two
+// waves -- its window is 18 x 16 bytes per lane, too much beside a K loop --: PART 2 (wave 7) PREPARES tile s: window
+// -> planes (two buffers, by the tile's parity) and 2^-e in LDS; PART 1 (wave 0) works on tile s - 1 from the planes
+// of the step before: resampler, K loop, rows.
+template <int K, int PART, bool TIMING>
 __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int clip,
                                          int t0c, int t1c, unsigned long long *tim) {
     constexpr int H = 128 >> K;
     using C = CqF16<H>;
+    constexpr bool PREP = PART != 1, WORK = PART != 2;
+    // The two waves of a SIMD share its matrix pipe: one of them converts first and multiplies behind it, the other (EARLY:
+    // levels 4-6) multiplies first -- on planes it prepared at the end of the step before -- and converts behind that.
+    constexpr bool EARLY = PART == 0 && K >= 4;
     constexpr unsigned RMASK = K == 0 ? 0xffffffffu : (unsigned)pyr::ring_size(K) - 1u;
     constexpr bool DEC = K < AFX_CQT_PYR_LEVELS - 1;  // the last level feeds nobody
     constexpr int KN = K + 1 < AFX_CQT_PYR_LEVELS ? K + 1 : K;
+    constexpr int LAG = PART == 2 ? 0 : pyr::lag(K);
+    constexpr int ALT = K == 0 ? pyr::plane_off(7) + pyr::TAB_BYTES - pyr::plane_off(0) : 0;  // level 0's second plane buffer
     unsigned char *Bl = smem;
-    unsigned char *sig = smem + C::B_BYTES + pyr::plane_off(K);
+    unsigned char *sig0 = smem + C::B_BYTES + pyr::plane_off(K);
+    float *downSlot = reinterpret_cast<float *>(smem + C::B_BYTES + pyr::plane_off(7) + pyr::TAB_BYTES + pyr::ALT_BYTES);
     const unsigned char *tab = smem + C::B_BYTES + pyr::plane_off(7);
     const int i = lane & 31, g = lane >> 5;
-    const CqLane L = cq_lane_setup(lane, sig, 12, (6 - K) * 12, a.num, a.timeLength, a.colMul, a.scale, a.octScale[K]);
+    const CqLane L0 = cq_lane_setup(lane, sig0, 12, (6 - K) * 12, a.num, a.timeLength, a.colMul, a.scale, a.octScale[K]);
     const int cpy = i % C::COPIES;
-    const unsigned char *aHi = sig + cpy * C::CS + C::at(i * H + 8 * g, cpy);
-    const unsigned char *aLo = aHi + C::PART;
+    const unsigned char *aHi0 = sig0 + cpy * C::CS + C::at(i * H + 8 * g, cpy);
     const unsigned char *bHi = Bl + lane * 16;
     const unsigned char *bLo = bHi + C::KS * 64 * 16;
-    // tap-table fragment of column c' = i (+ 32 per column tile: 64 bytes down): copy c' mod 4, entry 8 g - 8 (c' >> 2) - 96 (+ 16 ks)
+    // tap-table fragment of column c' = i (+ 32 per column tile: 128 bytes down): copy c' mod 4, entry 8 g - 8 (c' >> 2) - 96 (+ 16 ks)
     const unsigned char *tHi = tab + (i & 3) * pyr::TAB_COPY + 2 * (8 * g - 8 * (i >> 2) - 96);
     const unsigned char *tLo = tHi + pyr::TAB_PLANE;
     const int valid = a.valid[K], len = a.len[K];
@@ -508,148 +544,117 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(KN), 0, pyr::ring_size(KN) * 4, RSRC_RAW);
     constexpr unsigned NMASK = (unsigned)pyr::ring_size(KN) - 1u;
     float *outRe = a.outRe + (long long)clip * a.outStride, *outIm = a.outIm + (long long)clip * a.outStride;
-    // the window of a tile is requested one step ahead: levels 1-6 into registers (<= 10 x 16 bytes per lane); level 0's
-    // eighteen would crowd the K loop out of the register file -- they go straight to LDS (LDS-DMA, float32 in sample
-    // order: the lane / register pattern of `wnd`) and are read behind the wave's own vmcnt wait
-    unsigned char *stage = smem + C::B_BYTES + pyr::plane_off(7) + pyr::TAB_BYTES;
-    u32x4 wnd[C::NV], keep[K == 0 ? 1 : C::NV];
-    auto fetch = [&](int t) {
+    constexpr int NW = PREP ? C::NV : 1;
+    u32x4 wnd[NW];
+    auto fetch = [&](int t) {  // the window of a tile, requested one step ahead
         const int p0 = t * 32 * H - (C::N >> 1);
 #pragma unroll
-        for (int u = 0; u < C::NV; ++u) {
+        for (int u = 0; u < (PREP ? C::NV : 0); ++u) {
             const int pos = p0 + 4 * (lane + 64 * u);
-            if (K == 0) LDS_DMA_B128(rsrc, stage + 1024 * u, (int)((unsigned)pos * 4u));
-            else wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)pos & RMASK) * 4u), 0, pyr::AUX_L2);
+            wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)pos & RMASK) * 4u), 0, K == 0 ? 0 : pyr::AUX_L2);
         }
     };
-    auto arrived = [&]() {  // level 0: LDS -> registers
-        if (K == 0) {
-            VM_WAIT_ALL();
-#pragma unroll
-            for (int u = 0; u < C::NV; ++u) wnd[u] = *reinterpret_cast<const u32x4 *>(stage + 1024 * u + 16 * lane);
-        }
-    };
-    auto clear_from = [&](int t, int first) {  // samples at positions >= first are not part of this use of the window
+    // the wave works on tile s - LAG: the octave's rows for the tiles of the run, the resampler also for the tiles
+    // whose block a lower octave of the run reaches into
+    auto has_oct = [&](int t) { return t >= t0c && t < t1c; };
+    auto has_dec = [&](int t) { return DEC && t >= t0c - pyr::need_back(K) && t <= t1c + pyr::need_ahead(K); };
+    auto is_empty = [&](int t) {  // nothing of the signal in the tile's window: zeros out
         const int p0 = t * 32 * H - (C::N >> 1);
-#pragma unroll
-        for (int u = 0; u < C::NV; ++u) {
-            const int pos = p0 + 4 * (lane + 64 * u);
-            if (pos >= first) wnd[u].x = 0u;
-            if (pos + 1 >= first) wnd[u].y = 0u;
-            if (pos + 2 >= first) wnd[u].z = 0u;
-            if (pos + 3 >= first) wnd[u].w = 0u;
-        }
+        return p0 + C::S <= 0 || p0 >= len;
     };
-    auto clear_outside = [&](int t, int lo, int hi) {
+    auto is_live = [&](int t) { return has_oct(t) || (has_dec(t) && !is_empty(t)); };
+    // window registers -> planes, the WHOLE signal (the resampler reads what the framing rule drops); returns 2^-e
+    auto prepare = [&](int t, unsigned char *sig) {
         const int p0 = t * 32 * H - (C::N >> 1);
+        if (!has_oct(t)) {
+            // a tile resampled but not transformed: row t' reads window positions t' H + 225 ... t' H + H + 285, i.e.
+            // the level's samples 32 t H - 31 ... 32 (t+1) H + 29, and only their blocks are sure to be written (what
+            // else the window covers is not this run's: out of the tile exponent with it)
+            const int lo = p0 + 224, hi = p0 + 32 * H + 288;
 #pragma unroll
-        for (int u = 0; u < C::NV; ++u) {
-            const int pos = p0 + 4 * (lane + 64 * u);
-            if (pos < lo || pos >= hi) wnd[u].x = 0u;
-            if (pos + 1 < lo || pos + 1 >= hi) wnd[u].y = 0u;
-            if (pos + 2 < lo || pos + 2 >= hi) wnd[u].z = 0u;
-            if (pos + 3 < lo || pos + 3 >= hi) wnd[u].w = 0u;
+            for (int u = 0; u < NW; ++u) {
+                const int pos = p0 + 4 * (lane + 64 * u);
+                if (pos < lo || pos >= hi) wnd[u].x = 0u;
+                if (pos + 1 < lo || pos + 1 >= hi) wnd[u].y = 0u;
+                if (pos + 2 < lo || pos + 2 >= hi) wnd[u].z = 0u;
+                if (pos + 3 < lo || pos + 3 >= hi) wnd[u].w = 0u;
+            }
         }
-    };
-    auto to_planes = [&]() {  // wnd -> planes; returns 2^-e
-        const int e = cq_window_exponent<H>(wnd, lane);
+        const int e = cq_window_exponent<H>(reinterpret_cast<const u32x4(&)[C::NV]>(wnd), lane);
         const float up = __uint_as_float((unsigned)(e + 127) << 23);
         wave_lds_order();
-        cq_convert_window<H>(wnd, up, sig, lane);
+        cq_convert_window<H>(reinterpret_cast<const u32x4(&)[C::NV]>(wnd), up, sig, lane);
         wave_lds_order();
         return __uint_as_float((unsigned)(127 - e) << 23);
     };
-    auto resample = [&](int t, float down) {  // planes -> block t of the next level
-        f32x16 hh, hl, lh;
-        pyr_dec_loop<H, 0>(aHi, aLo, tHi, tLo, hh, hl, lh);
-        pyr_dec_store<H, 0>(hh, hl, lh, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
-        if (H / 2 > 32) {
-            pyr_dec_loop<H, 1>(aHi, aLo, tHi - 128, tLo - 128, hh, hl, lh);  // columns 32 ... 63: 64 table entries down
-            pyr_dec_store<H, 1>(hh, hl, lh, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
-        }
-    };
-    // wave K works on tile s - lag: the octave's rows for tiles of the run, the resampler for the tiles whose block a
-    // lower octave of the run reaches into
-    auto has_oct = [&](int t) { return t >= t0c && t < t1c; };
-    auto has_dec = [&](int t) { return DEC && t >= t0c - pyr::need_back(K) && t <= t1c + pyr::need_ahead(K); };
     const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
     PyrClock<TIMING> clk;
+    float downNext = 0.f;  // (EARLY waves: 2^-e of the planes prepared at the end of the step before)
     for (int s = s0; s <= s1; ++s) {
-        const int t = s - pyr::lag(K);
-        const bool oct = has_oct(t), dec = has_dec(t), next = has_oct(t + 1) || has_dec(t + 1);  // wave-uniform
+        const int t = s - LAG;
+        const bool oct = has_oct(t), dec = has_dec(t), empty = is_empty(t), live = is_live(t), next = is_live(t + 1);  // wave-uniform
+        const int buf = K == 0 ? (t & 1) : 0;
+        unsigned char *sig = sig0 + buf * ALT;
+        const unsigned char *aHi = aHi0 + buf * ALT;
         const int p0 = t * 32 * H - (C::N >> 1);
-        const bool framed = p0 + C::S > valid;  // the framing rule bites: the octave sees fewer samples than the resampler
-        const bool empty = p0 + C::S <= 0 || p0 >= len;  // nothing of the signal in the window: zeros out
-        bool redo = false;
-        float down = 0.f;
-        if (oct || (dec && !empty)) {
-            arrived();
+        float down = downNext;
+        if (EARLY && next) fetch(t + 1);  // (the same blocks a convert-first wave asks for in this step: all written by step s - 1)
+        if (PREP && !EARLY && live) {
             if (TIMING) {  // time the wait for the window apart from the conversion
 #pragma unroll
-                for (int u = 0; u < C::NV; ++u) PIN(wnd[u]);
+                for (int u = 0; u < NW; ++u) PIN(wnd[u]);
                 clk.lap(0);
             }
-            if (oct && framed) {
-                redo = dec;
-                if (K != 0 && redo) {  // (the ring block behind the window is being overwritten by now: keep the samples)
-#pragma unroll
-                    for (int u = 0; u < C::NV; ++u) keep[u] = wnd[u];
-                }
-                clear_from(t, valid);
-            }
-            // a tile resampled but not transformed: row t' reads window positions t' H + 225 ... t' H + H + 285, i.e. the
-            // level's samples 32 t H - 31 ... 32 (t+1) H + 29, and only their blocks are sure to be written (what else
-            // the window covers is not this run's: out of the tile exponent with it)
-            if (!oct) clear_outside(t, p0 + 224, p0 + 32 * H + 288);
-            down = to_planes();
+            down = prepare(t, sig);
+            if (PART == 2 && lane == 0) downSlot[buf] = down;
             clk.lap(1);
         }
-        if (next && !redo) fetch(t + 1);  // (a tile done twice asks for its successor when it is through)
+        if (PART == 1 && live) down = downSlot[buf];
+        if (PREP && !EARLY && next) fetch(t + 1);
         clk.lap(2);
-        // the resampler first: its stores have the whole K loop to reach the L2 (the wait for the prefetched window
-        // behind the loop covers them: no wait at the barrier), and the octave's epilogue transposes through the planes
-        if (DEC && dec) {
+        // the resampler first: its stores have the whole K loop to reach the L2 (the wait behind the loop covers them: no
+        // wait at the barrier), and the octave's epilogue transposes through the planes
+        if (WORK && DEC && dec) {
+            f32x16 dh, dl, dm;
             if (empty) {
-                f32x16 z;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                pyr_dec_store<H, 0>(z, z, z, 0.f, t, lane, ringNext, NMASK, a.len[KN]);
-                if (H / 2 > 32) pyr_dec_store<H, 1>(z, z, z, 0.f, t, lane, ringNext, NMASK, a.len[KN]);
-            } else if (!redo) {
-                resample(t, down);
+                for (int r = 0; r < 16; ++r) dh[r] = dl[r] = dm[r] = 0.f;
+            } else {
+                pyr_dec_loop<H, 0>(aHi, aHi + C::PART, tHi, tLo, dh, dl, dm);
+            }
+            pyr_dec_store<H, 0>(dh, dl, dm, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
+            if (H / 2 > 32) {
+                if (!empty) pyr_dec_loop<H, 1>(aHi, aHi + C::PART, tHi - 128, tLo - 128, dh, dl, dm);  // outputs 32 ... 63: 64 table entries down
+                pyr_dec_store<H, 1>(dh, dl, dm, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
             }
         }
         clk.lap(5);
         f32x16 hh, hl, lh;
-        if (oct) cq_kloop<H>(aHi, aLo, bHi, bLo, hh, hl, lh);
+        if (WORK && oct) {
+            if (p0 + C::S > valid) cq_zero_samples<H>(sig, valid - p0 > 0 ? valid - p0 : 0, (len < p0 + C::S ? len : p0 + C::S) - p0, lane);
+            wave_lds_order();
+            cq_kloop<H>(aHi, aHi + C::PART, bHi, bLo, hh, hl, lh);
+        }
         clk.lap(3);
         // the prefetched window is in its registers, the block in the L2, BEFORE the step's barrier (the window's ring
         // blocks are overwritten three steps on)
-        if (K != 0) {
+        if (PREP && K != 0) {
 #pragma unroll
-            for (int u = 0; u < C::NV; ++u) PIN(wnd[u]);
+            for (int u = 0; u < NW; ++u) PIN(wnd[u]);
         }
-        VM_WAIT_ALL();
+        if (WORK && DEC) VM_WAIT_ALL();
         clk.lap(4);
-        if (oct) cq_store_tile<true>(hh, hl, lh, down, L, outRe, outIm, t * 32);
-        if (DEC && redo) {  // a clip's last tiles: the resampler wants the samples the framing rule dropped
-            if (K == 0) {
-                wave_lds_order();
-                fetch(t);  // (the clip: still there)
-                arrived();
-            } else {
-#pragma unroll
-                for (int u = 0; u < C::NV; ++u) wnd[u] = keep[u];
-            }
-            down = to_planes();
-            resample(t, down);
-            if (next) {
-                wave_lds_order();
-                fetch(t + 1);
-            }
+        if (WORK && oct) {
+            CqLane L = L0;
+            L.epiW += buf * ALT;
+            L.epiR += buf * ALT;
+            cq_store_tile<true>(hh, hl, lh, down, L, outRe, outIm, t * 32);
         }
-        if (DEC && redo) VM_WAIT_ALL();
         clk.lap(7);
+        if (EARLY && next) {  // the next tile's planes now: the matrix-core work of the next step starts at its barrier
+            downNext = prepare(t + 1, sig);
+            clk.lap(1);
+        }
         pyr_barrier();
         clk.lap(6);
     }
@@ -657,7 +662,7 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
 }
 
 // the runs of this workgroup, one after the other
-template <int K, bool TIMING>
+template <int K, int PART, bool TIMING>
 __device__ __forceinline__ void pyr_role(const AfxCqtPyramidArgs &a, unsigned char *smem, int lane, float *wgRing, int items) {
     unsigned long long *tim = TIMING && a.timing ? a.timing + ((size_t)blockIdx.x * 11 + (threadIdx.x >> 6)) * 8 : nullptr;
     const int nT = (a.timeLength + 31) / 32;
@@ -666,7 +671,7 @@ __device__ __forceinline__ void pyr_role(const AfxCqtPyramidArgs &a, unsigned ch
         const int t0c = chunk * a.tilesPerChunk;
         const int t1c = t0c + a.tilesPerChunk < nT ? t0c + a.tilesPerChunk : nT;
         if (t0c >= t1c) continue;  // (uniform over the workgroup)
-        pyr_wave<K, TIMING>(a, smem, lane, wgRing, clip, t0c, t1c, tim);
+        pyr_wave<K, PART, TIMING>(a, smem, lane, wgRing, clip, t0c, t1c, tim);
     }
 }
 
@@ -684,15 +689,18 @@ __global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidAr
     __syncthreads();
     float *wgRing = a.ring + (size_t)blockIdx.x * AFX_CQT_PYR_RING_FLOATS;
     // (the loop over the workgroup's runs sits INSIDE every role: around the switch, the compiler hoists the per-lane
-    // constants of all seven roles in front of it and spills them)
+    // constants of all eight roles in front of it and spills them)
+    // wave ids w and w + 4 share a SIMD: (level 0's multiplier, its preparer), (1, 6), (2, 5), (3, 4) -- 144 + 0, 120 + 96,
+    // 114 + 111, 111 + 111 MFMAs per step, one convert-first and one multiply-first wave each
     switch (wave) {
-        case 0: pyr_role<0, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 1: pyr_role<1, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 2: pyr_role<2, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 3: pyr_role<3, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 4: pyr_role<4, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        case 5: pyr_role<5, TIMING>(a, smem_raw, lane, wgRing, items); break;
-        default: pyr_role<6, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 0: pyr_role<0, 1, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 4: pyr_role<0, 2, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 1: pyr_role<1, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 5: pyr_role<6, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 2: pyr_role<2, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 6: pyr_role<5, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        case 3: pyr_role<3, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
+        default: pyr_role<4, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
     }
 }
 

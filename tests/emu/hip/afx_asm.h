@@ -106,12 +106,6 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigne
     (__builtin_memcpy(afx_emu_lds + (addr) + 256 * (o0), &(d0), 4), __builtin_memcpy(afx_emu_lds + (addr) + 256 * (o1), &(d1), 4))
 #define PIN(x) ((void)0)
 #define LDS_WAIT_N(n) ((void)0)
-// LDS-DMA: lane l's 16 bytes (bounds-checked per dword) at lds + 16 l
-#define LDS_DMA_B128(rsrc, lds, voff)                                                                       \
-    do {                                                                                                    \
-        const emu_u32x4 _d = emu_load_b128((rsrc), (voff), 0);                                              \
-        __builtin_memcpy(reinterpret_cast<unsigned char *>(lds) + 16 * emu::lane(), &_d, 16);               \
-    } while (0)
 #define VM_WAIT_ALL() afx_emu_ds()  // rows stored by the other lanes' threads
 #define VM_LGKM_WAIT_ALL() ((void)0)
 #define LOAD_SC1_B128(dst, ptr) ((dst) = *(ptr))

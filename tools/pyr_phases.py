@@ -35,10 +35,11 @@ print(f"{clips} clips, {ms:.3f} ms per call (instrumented), {wgs} workgroups; cy
 cpc = max(1, min(256 // clips, nT // 48)); tpc = -(-nT // cpc); steps = (tpc + 31) * reps * max(1, -(-clips * cpc // 256))
 names_c = ["wait-window", "convert", "fetch-issue", "k-loop", "wait-prefetch", "resample", "barrier", "store+vm-wait"]
 names_p = ["issue-loads", "vm-wait", "wait-input", "lds-stage", "taps", "stores/other", "barrier", "-"]
-for w in range(7):
+for w in range(8):
     m = used[:, w, :].mean(axis=0) / steps
     nm = names_c if w < 7 else names_p
-    print(f"wave {w:2d} ({'octave level %d' % w if w < 7 else 'producer %d' % (w - 7)}): total {m.sum():8.0f} | " +
-          "  ".join(f"{nm[i]} {m[i]:.0f}" for i in range(8) if nm[i] != "-"))
+    role = ["level 0 (multiply)", "level 1", "level 2", "level 3", "level 0 (prepare)", "level 6 (early)", "level 5 (early)", "level 4 (early)"][w]
+    print(f"wave {w} ({role}): total {m.sum():8.0f} | " +
+          "  ".join(f"{names_c[i]} {m[i]:.0f}" for i in range(8)))
 tot = used.sum(axis=2).mean() / steps
 print(f"cycles per step ~{tot:.0f}; at {ms*1e-3/ (steps/reps) * 1e9:.0f} ns per step -> clock ~{tot / (ms*1e-3/(steps/reps)) / 1e6:.0f} MHz")
