@@ -201,9 +201,9 @@ __device__ __forceinline__ CqLane cq_lane_setup(int lane, unsigned char *sig, in
 // results of one tile -> memory.  D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5).  Output: per clip one
 // raw buffer per plane, T x num floats; rows past timeLength and the padding columns fall out of range and are dropped
 // by the bounds check, so every tile issues the same number of stores.
-template <bool R12>
+template <bool R12, int AUX = 0>
 __device__ __forceinline__ void cq_store_tile(const f32x16 &hh, const f32x16 &hl, const f32x16 &lh, float down, const CqLane &L,
-                                              float *outRe, float *outIm, int t0) {
+                                              float *outRe, float *outIm, int t0, u32x3 *pieces = nullptr) {
     const __amdgpu_buffer_rsrc_t rRe = __builtin_amdgcn_make_buffer_rsrc(outRe, 0, (int)L.planeBytes, RSRC_RAW);
     const __amdgpu_buffer_rsrc_t rIm = __builtin_amdgcn_make_buffer_rsrc(outIm, 0, (int)L.planeBytes, RSRC_RAW);
     const float mul = down * L.colMul;
@@ -218,7 +218,8 @@ __device__ __forceinline__ void cq_store_tile(const f32x16 &hh, const f32x16 &hl
         for (int q = 0; q < 4; ++q) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(L.epiR + (q >> 1) * 2048 + (q & 1) * 64);
             const u32x3 v3 = {v.x, v.y, v.z};
-            __builtin_amdgcn_raw_buffer_store_b96(v3, (q & 1) ? rIm : rRe, L.voff12 + tileOff + (unsigned)(q >> 1) * 16u * L.rowBytes, 0, 0);
+            if (pieces) pieces[q] = v3;  // (the pyramid's chroma: bins 3 (lane & 3) .. + 2 of frame 16 (q >> 1) + (lane >> 2), plane q & 1)
+            __builtin_amdgcn_raw_buffer_store_b96(v3, (q & 1) ? rIm : rRe, L.voff12 + tileOff + (unsigned)(q >> 1) * 16u * L.rowBytes, 0, AUX);
         }
     } else {
 #pragma unroll
@@ -374,6 +375,7 @@ constexpr int ALT_BYTES = CqF16<128>::WAVE_BYTES;
 constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + TAB_BYTES + ALT_BYTES + 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr int AUX_L2 = 17;                           // sc0 sc1: served by the L2, never by this CU's L1
+constexpr int AUX_STREAM = 2;                        // nt: the clip and the rows pass through once -- they must not push the rings out of the L2
 // tiles of level k whose resampler output (block of level k+1) a run [t0, t1) needs: [t0 - need_back(k), t1 + need_ahead(k)]
 __host__ __device__ constexpr int need_back(int k) { return 9 - k; }
 __host__ __device__ constexpr int need_ahead(int k) { return 8 - k; }
@@ -504,6 +506,70 @@ __device__ __forceinline__ void pyr_dec_store(const f32x16 &hh, const f32x16 &hl
     }
 }
 
+// ---- chroma in the same launch (cqt_algorithm.c:484-597 for chromaNum = 12 = bins per octave: class c sums one bin of
+// every octave, then the frame's 12 values are normalised).  The octaves of a frame are finished 1 ... 23 steps apart, so
+// the sums travel through memory: the output rows themselves hold the partial sums -- level 0 writes its 12 powers, every
+// further level adds its own (the partials of the ~23 tiles in flight stay in the L2), level 6 adds, normalises and
+// writes the result.  Summation order is therefore highest octave first (the reference and k_cqt_chroma: lowest
+// first): the same terms, last-bit differences.  A lane holds bins 3 (lane & 3) .. + 2 of frame 16 h + (lane >> 2) after the
+// rows' transposition: the partials are requested before the K loop and arrive during it.
+struct PyrChroma {
+    __amdgpu_buffer_rsrc_t rows;  // the clip's [T][12] output
+    unsigned off[3];              // byte offsets of the lane's three classes inside a row
+    float part[2][3];             // partial sums of the two half tiles
+};
+
+template <int K>
+__device__ __forceinline__ void pyr_chroma_request(PyrChroma &ch, int t, int lane) {
+    if (K == 0) return;  // (the first level stores)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            ch.part[h][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                ch.rows, (int)((unsigned)(32 * t + 16 * h + (lane >> 2)) * 48u + ch.off[j]), 0, pyr::AUX_L2));
+}
+
+template <int K>
+__device__ __forceinline__ void pyr_chroma_add(PyrChroma &ch, const u32x3 (&pieces)[4], int t, int lane, int isMag, int normType) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const u32x3 re = pieces[2 * h], im = pieces[2 * h + 1];
+        float v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float x = __uint_as_float(re[j]), y = __uint_as_float(im[j]);
+            float p = __fmaf_rn(x, x, y * y);
+            if (isMag) p = sqrtf(p);
+            v[j] = K == 0 ? p : ch.part[h][j] + p;
+        }
+        if (K == AFX_CQT_PYR_LEVELS - 1 && normType != 0) {  // the frame's 12 values sit in the four lanes of a quad
+            float red = normType == 2 ? 3.4e38f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float av = fabsf(v[j]);
+                if (normType == 1) red = fmaxf(red, av);
+                else if (normType == 2) red = fminf(red, av);
+                else if (normType == 3) red += av * av;
+                else red += av;
+            }
+            const float r1 = dpp_f(red, 0xB1);  // quad_perm [1,0,3,2]
+            red = normType == 1 ? fmaxf(red, r1) : normType == 2 ? fminf(red, r1) : red + r1;
+            const float r2 = dpp_f(red, 0x4E);  // quad_perm [2,3,0,1]
+            red = normType == 1 ? fmaxf(red, r2) : normType == 2 ? fminf(red, r2) : red + r2;
+            if (normType == 3) red = sqrtf(red);
+            if (red != 0.f) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v[j] = v[j] / red;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), ch.rows,
+                                                  (int)((unsigned)(32 * t + 16 * h + (lane >> 2)) * 48u + ch.off[j]), 0, 0);
+    }
+}
+
 // ---- one wave's part of the run [t0c, t1c) of `clip`.  PART 0: level K whole (levels 1-6).  Level 0 is shared by two
 // waves -- its window is 18 x 16 bytes per lane, too much beside a K loop --: PART 2 (wave 7) PREPARES tile s: window
 // -> planes (two buffers, by the tile's parity) and 2^-e in LDS; PART 1 (wave 0) works on tile s - 1 from the planes
@@ -546,12 +612,18 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
     float *outRe = a.outRe + (long long)clip * a.outStride, *outIm = a.outIm + (long long)clip * a.outStride;
     constexpr int NW = PREP ? C::NV : 1;
     u32x4 wnd[NW];
+    const bool chromaOn = WORK && a.chroma != nullptr;
+    PyrChroma ch;
+    ch.rows = __builtin_amdgcn_make_buffer_rsrc(a.chroma ? a.chroma + (long long)clip * a.timeLength * 12 : a.outRe, 0,
+                                                a.chroma ? a.timeLength * 48 : 0, RSRC_RAW);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ch.off[j] = 4u * (unsigned)a.chromaClass[3 * (lane & 3) + j];
     auto fetch = [&](int t) {  // the window of a tile, requested one step ahead
         const int p0 = t * 32 * H - (C::N >> 1);
 #pragma unroll
         for (int u = 0; u < (PREP ? C::NV : 0); ++u) {
             const int pos = p0 + 4 * (lane + 64 * u);
-            wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)pos & RMASK) * 4u), 0, K == 0 ? 0 : pyr::AUX_L2);
+            wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)pos & RMASK) * 4u), 0, K == 0 ? pyr::AUX_STREAM : pyr::AUX_L2);
         }
     };
     // the wave works on tile s - LAG: the octave's rows for the tiles of the run, the resampler also for the tiles
@@ -630,6 +702,7 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         }
         clk.lap(5);
         f32x16 hh, hl, lh;
+        if (chromaOn && oct) pyr_chroma_request<K>(ch, t, lane);
         if (WORK && oct) {
             if (p0 + C::S > valid) cq_zero_samples<H>(sig, valid - p0 > 0 ? valid - p0 : 0, (len < p0 + C::S ? len : p0 + C::S) - p0, lane);
             wave_lds_order();
@@ -648,7 +721,9 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
             CqLane L = L0;
             L.epiW += buf * ALT;
             L.epiR += buf * ALT;
-            cq_store_tile<true>(hh, hl, lh, down, L, outRe, outIm, t * 32);
+            u32x3 pieces[4];
+            cq_store_tile<true, pyr::AUX_STREAM>(hh, hl, lh, down, L, outRe, outIm, t * 32, pieces);
+            if (chromaOn) pyr_chroma_add<K>(ch, pieces, t, lane, a.chromaMag, a.chromaNorm);
         }
         clk.lap(7);
         if (EARLY && next) {  // the next tile's planes now: the matrix-core work of the next step starts at its barrier

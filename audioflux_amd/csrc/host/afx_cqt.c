@@ -1004,8 +1004,10 @@ int cqtObj_cqtChromaBatchDevice(CQTObj o, const float *dData, int batch, int dat
     const int T = dataLength / o->slideLength + 1;
     if (st == AFX_OK && o->lastStream != hipStream && o->lastUsed) st = afxdev_stream_sync(o->lastStream);
     if (st == AFX_OK && cqt_pyramid_ok(o, dataLength)) {
-        st = cqt_run_pyramid(o, dData, batch, dataLength, clipStride, dReal, dImag, NULL, 0, 0, hipStream);
-        if (st == AFX_OK)
+        /* 12 classes of 12 bins per octave: the sums travel with the rows through the one launch */
+        const int fused = cn == 12 && o->haveLists;
+        st = cqt_run_pyramid(o, dData, batch, dataLength, clipStride, dReal, dImag, fused ? dChroma : NULL, isMag, nrm, hipStream);
+        if (st == AFX_OK && !fused)
             st = afxk_cqt_chroma(dReal, dImag, (long long)batch * T, o->num, o->dFold, o->haveLists ? &o->foldLists : NULL, cn, isMag,
                                  nrm, dChroma, hipStream);
     } else {

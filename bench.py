@@ -21,7 +21,7 @@ DCT-II); it is timed live with HIP events on the stream it is launched on (torch
 handed to the library).  `achieved` = SURVEY 8d's algorithmic bytes per unit x units per launch /
 that duration; `sustained_ms` repeats the step back to back for >= 1 s (sustained clocks, where the
 K-step region of a short run sees boost clocks); `traffic` = HBM bytes per launch from the round's
-own rocprofv3 --pmc passes of this command (profiles/r03_bench_cfg<N>_pmc.json, written by
+own rocprofv3 --pmc passes of this command (profiles/r04_bench_cfg<N>_pmc.json, written by
 tools/prof_traffic.py), null when that file is absent.  After the timed region clip 0 of the
 benchmarked outputs is checked against the oracle (1e-5 peak / L2).
 `secondary` (--config 2 at one GPU, the driver's line): cfg 4 and cfg 5 measured in the same process after the
@@ -282,8 +282,9 @@ class Cfg5:
     unit = "frames/s"
     default_clips = 125
     bytes_per_unit = 4 * 128 + 8 * 84 + 4 * 12  # hop 128 samples in, 84 complex + 12 chroma out
-    kernel = ("all launches of one step, per pass of the clips: 7 x k_cqt_octave_f16 (one per octave), "
-              "6 x k_cqt_decimate, k_cqt_chroma")
+    kernel = ("k_cqt_pyramid: ONE persistent launch per step -- eight role-specialised waves per workgroup walk runs of 32-frame "
+              "tiles (octave products and the 2:1 resampler on the f16 matrix cores, level signals in L2-resident rings, chroma-12 as "
+              "partial sums through the output rows)")
     dtype = "f32 (octave products: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ("chroma", "cqt")
 
@@ -372,7 +373,7 @@ def pmc_traffic(config, clips):
     """HBM bytes per step from the round's rocprofv3 --pmc passes of this command
     (tools/prof_traffic.py): 2 x FETCH_SIZE (gfx950 tallies wide coalesced reads at half,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB, scaled to this run's clip count"""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_bench_cfg{config}_pmc.json")
         try:
             rec = json.load(open(path))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The DEVICE code of the f16 CQT kernels on the CPU (tests/emu): golden CQT / chroma vectors through the C host code,
 the real launchers and the CQT kernels compiled for the host and run one thread per lane.
-AFX_LIB = the library tests/test_emulated_kernels.py builds; AFX_CQT_F32=1 selects the float32 matrix-core octave kernels.
+AFX_LIB = the library tests/test_emulated_kernels.py builds; AFX_CQT_F32=1 selects the float32 matrix-core octave kernels,
+AFX_CQT_PYRAMID=0 the per-octave launches instead of the one-launch ladder (k_cqt_pyramid).
 Prints one line per comparison, the launches seen, and OK."""
 import ctypes as C
 import os
@@ -109,6 +110,7 @@ def main():
         fn = [0, 0, 0, 0]
     print("launches: emulated octave_f16 %d; contract-level octave_f32 %d, chroma %d" % (
         lib.afx_emulated_launches(b"k_cqt_octave_f16"), fn[1], fn[3]))
+    print("          emulated pyramid %d" % lib.afx_emulated_launches(b"k_cqt_pyramid"))
     print("          emulated decimate %d, chroma %d, chroma_scan %d, octave_mfma (f32) %d" % (
         lib.afx_emulated_launches(b"k_cqt_decimate"), lib.afx_emulated_launches(b"k_cqt_chroma") - lib.afx_emulated_launches(b"k_cqt_chroma_scan"),
         lib.afx_emulated_launches(b"k_cqt_chroma_scan"), lib.afx_emulated_launches(b"k_cqt_octave_mfma")))

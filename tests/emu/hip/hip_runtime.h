@@ -228,6 +228,7 @@ static inline emu_u32x4 emu_load_b128(const __amdgpu_buffer_rsrc_t &r, int voff,
 }
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) emu_make_rsrc((p), (stride), (num), (flags))
 #define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) emu_load_b128((r), (voff), (soff))
+#define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) emu_buf_load((r), (unsigned)(voff) + (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, aux) emu_buf_store((r), (unsigned)(voff) + (unsigned)(soff), (v))
 #define __builtin_amdgcn_raw_buffer_store_b96(v, r, voff, soff, aux)                      \
     do {                                                                                   \

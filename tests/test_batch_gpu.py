@@ -88,7 +88,9 @@ def test_cqt_batch_device_equals_loop_and_reference():
         rre, rim = r.cqt(x[2])
         assert_parity(got[2].T, rre + 1j * rim, what="cqt batch vs reference")
         assert_parity(gch[2].T, r.chroma(rre, rim), what="chroma batch vs reference")
-    # the fused call, in one pass and in passes of 3 clips: same bits as the two calls
+    # the fused call, in one pass and in passes of 3 clips: the transform's bits are those of the two calls; its chroma
+    # travels through the one-launch ladder as partial sums, highest octave first (the chroma kernel of the separate
+    # call sums lowest first): the same terms, last-bit differences of the normalised values
     for chunk in (None, "3"):
         if chunk:
             os.environ["AFX_CQT_CHUNK"] = chunk
@@ -98,7 +100,8 @@ def test_cqt_batch_device_equals_loop_and_reference():
             torch.cuda.synchronize()
         finally:
             os.environ.pop("AFX_CQT_CHUNK", None)
-        assert torch.equal(re3, re) and torch.equal(im3, im) and torch.equal(ch3, ch), f"fused call, chunk {chunk}"
+        assert torch.equal(re3, re) and torch.equal(im3, im), f"fused call, chunk {chunk}"
+        assert float((ch3 - ch).abs().max()) <= 2e-6, f"fused call's chroma, chunk {chunk}: {float((ch3 - ch).abs().max()):.2e}"
         assert torch.equal(re4, re) and torch.equal(im4, im), f"cqt_device in passes, chunk {chunk}"
     # ragged tail + padded row stride
     wide = torch.zeros((3, n + 77), dtype=torch.float32, device="cuda")

@@ -123,3 +123,58 @@ def test_streaming_cqt_pieces_equal_the_restatement_where_the_reference_is_not_s
     assert frames == (len(x) - 512) // 128 + 1
     with pytest.raises(RuntimeError):
         o.cqt_device(torch.zeros((1, 4000), device="cuda"))
+
+
+_LADDER_SHAPES = [(3, 61000, 61005), (40, 200000, 200000), (7, 1323000, 1323000), (1, 500000, 500000), (300, 33000, 33000),
+                  (2, 128 * 32 * 5 - 1, 128 * 32 * 5 + 3), (2, 700, 700)]
+
+
+def _ladder_child(out):
+    import hashlib
+
+    import torch
+    o = af.CQT(num=84, samplate=44100, low_fre=32.703, bin_per_octave=12, normal_type=af.SpectralFilterBankNormalType.AREA)
+    res = {}
+    for si, (batch, n, stride) in enumerate(_LADDER_SHAPES):
+        g = torch.Generator(device="cuda").manual_seed(batch + n)
+        x = 0.1 * torch.randn((batch, stride), generator=g, device="cuda")
+        x[:, n // 2:] *= 1e-3  # a -60 dB level step: the tile exponents change along the clip
+        T = o.cal_time_length(n)
+        re = torch.zeros((batch, T, 84), device="cuda")
+        im = torch.zeros_like(re)
+        ch = torch.zeros((batch, T, 12), device="cuda")
+        hs = []
+        for _ in range(2):
+            o.cqt_chroma_device(x[:, :n], out_real=re, out_imag=im, out=ch)  # (a view: the clip stride stays `stride`)
+            torch.cuda.synchronize()
+            hs.append(hashlib.sha256(re.cpu().numpy().tobytes() + im.cpu().numpy().tobytes() + ch.cpu().numpy().tobytes()).hexdigest())
+        assert hs[0] == hs[1], f"shape {si}: two runs differ"
+        assert bool(torch.isfinite(re).all() and torch.isfinite(im).all() and torch.isfinite(ch).all()), si
+        keep = slice(0, min(batch, 3))
+        res[f"re{si}"], res[f"im{si}"], res[f"ch{si}"] = re[keep].cpu().numpy(), im[keep].cpu().numpy(), ch[keep].cpu().numpy()
+    np.savez(out, **res)
+
+
+def test_one_launch_ladder_against_the_per_octave_launches(tmp_path):
+    """k_cqt_pyramid (the default for 84 bins, hop 128: one persistent launch, eight role-specialised waves per workgroup,
+    the 2:1 resampler as a matrix-core product, level rings that stay in the L2, chroma-12 as partial sums through the
+    output rows) against AFX_CQT_PYRAMID=0 (seven octave launches, six float32 filter launches, the chroma kernel): the
+    octave products are the same arithmetic, the level signals agree to rounding -- bars 2e-6 of the tensor peak, 1e-5 of
+    ANY frame's own peak across a -60 dB level step, 1e-5 on the normalised chroma --, and the ladder repeats bit for
+    bit.  Shapes: many short clips (one run each), few long ones (runs of ~160 tiles that start and end mid-clip), an odd
+    clip stride, a clip that ends mid-tile, a clip shorter than one window.  Two child processes: the switch is read
+    once per process."""
+    import subprocess
+    import sys
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {os.getcwd()!r}); from tests import test_cqt_gpu as t; "
+                            f"t._ladder_child({str(tmp_path / ('p' + v + '.npz'))!r})"],
+                           capture_output=True, text=True, env=dict(os.environ, AFX_CQT_PYRAMID=v), timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    a, b = np.load(tmp_path / "p1.npz"), np.load(tmp_path / "p0.npz")
+    for si, shape in enumerate(_LADDER_SHAPES):
+        qa, qb = a[f"re{si}"] + 1j * a[f"im{si}"], b[f"re{si}"] + 1j * b[f"im{si}"]
+        peak = np.abs(qa - qb).max() / np.abs(qb).max()
+        frame = (np.abs(qa - qb).max(axis=2) / np.maximum(np.abs(qb).max(axis=2), 1e-30)).max()
+        chd = np.abs(a[f"ch{si}"] - b[f"ch{si}"]).max()
+        assert peak <= 2e-6 and frame <= 1e-5 and chd <= 1e-5, (shape, peak, frame, chd)

@@ -78,7 +78,7 @@ def emulated(tmp_path_factory):
 
 def _run(lib, script, args, env=""):
     e = dict(os.environ)
-    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_NO_FUSED"):
+    for k in ("AFX_CQT_CHUNK", "AFX_CQT_F32", "AFX_NO_FUSED", "AFX_CQT_PYRAMID", "AFX_CQT_PYR_TILES"):
         e.pop(k, None)
     if env:
         e.update(kv.split("=") for kv in env.split())
@@ -91,18 +91,29 @@ def _run(lib, script, args, env=""):
 
 def _launches(out):
     import re
-    m = re.search(r"emulated octave_f16 (\d+);.*\n\s+emulated decimate (\d+), chroma (\d+), chroma_scan (\d+), "
+    m = re.search(r"emulated octave_f16 (\d+);.*\n\s+emulated pyramid (\d+)\n\s+emulated decimate (\d+), chroma (\d+), chroma_scan (\d+), "
                   r"octave_mfma \(f32\) (\d+)", out)
     assert m, out[-2000:]
-    return dict(zip(("octave_f16", "decimate", "chroma", "chroma_scan", "octave_f32"), map(int, m.groups())))
+    return dict(zip(("octave_f16", "pyramid", "decimate", "chroma", "chroma_scan", "octave_f32"), map(int, m.groups())))
 
 
 def test_shipped_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
-    """calibration: the kernels the device runs by default -- k_cqt_decimate, k_cqt_octave_f16 (all seven hop
-    instantiations, the 12-byte transposed stores), k_cqt_chroma (12 and 6 classes, max and min normalisation) --
-    through the emulation"""
-    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min"]))
-    assert n["octave_f16"] == 21 and n["decimate"] == 18 and n["chroma"] == 2 and n["chroma_scan"] + n["octave_f32"] == 0, n
+    """calibration: the kernels the device runs by default through the emulation.  The default ladder (84 bins) is ONE
+    launch, k_cqt_pyramid: eight role-specialised waves per workgroup, the 2:1 resampler as a matrix-core product from
+    the octave waves' own planes, level rings in memory behind one barrier per step, chroma-12 as partial sums through
+    the output rows; 6 classes (six_min) go through k_cqt_chroma.  Runs of 3 tiles (AFX_CQT_PYR_TILES) make the 157
+    frames of the golden clip cross run boundaries: same numbers."""
+    for env in ("", "AFX_CQT_PYR_TILES=3"):
+        n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "mag_p2", "six_min"], env))
+        assert n["pyramid"] == 4 and n["chroma"] == 1 and n["octave_f16"] + n["decimate"] + n["chroma_scan"] + n["octave_f32"] == 0, n
+
+
+def test_per_octave_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
+    """AFX_CQT_PYRAMID=0: the per-octave launches -- k_cqt_decimate, k_cqt_octave_f16 (all seven hop instantiations, the
+    12-byte transposed stores), k_cqt_chroma (12 and 6 classes, max and min normalisation); what every plan outside the
+    default ladder still runs"""
+    n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max", "six_min"], "AFX_CQT_PYRAMID=0"))
+    assert n["octave_f16"] == 21 and n["decimate"] == 18 and n["chroma"] == 2 and n["pyramid"] + n["chroma_scan"] + n["octave_f32"] == 0, n
 
 
 def test_streaming_cqt_through_the_emulated_octave_kernels(emulated):
@@ -217,6 +228,8 @@ def test_emulated_kernels_have_no_lds_races(emulated_tsan, exe, env):
 
 
 def test_the_lds_race_check_sees_missing_ordering_points(emulated_tsan):
-    """with k_cqt_octave_f16's wave_lds_order() calls compiled out the same run is full of reports"""
+    """with the wave_lds_order() calls of afx_cqt_f16.hip (k_cqt_pyramid, k_cqt_octave_f16) compiled out the same run is
+    full of reports"""
     r = subprocess.run([emulated_tsan["negative"]], capture_output=True, text=True, env=dict(os.environ, AFX_QUIET="1"), timeout=1500)
-    assert "WARNING: ThreadSanitizer: data race" in r.stderr and "k_cqt_octave_f16" in r.stderr, (r.stdout + r.stderr)[-2000:]
+    assert "WARNING: ThreadSanitizer: data race" in r.stderr and ("k_cqt_pyramid" in r.stderr or "k_cqt_octave_f16" in r.stderr), \
+        (r.stdout + r.stderr)[-2000:]

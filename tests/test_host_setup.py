@@ -195,3 +195,31 @@ def test_chroma_lists_equal_the_folding_matrix():
         for j in range(12):
             acc[cls[12 * octave + j]] = np.float32(acc[cls[12 * octave + j]] + pw[12 * octave + j])
     assert np.array_equal(acc, per_class)
+
+
+def test_cqt_resampler_tap_table_matches_numpy():
+    """afx_cqt_dec_table (host side of k_cqt_pyramid's resampler product): T[d] = h[|d|] 2^15 as binary16 (hi, lo) words,
+    [word][copy a][x] = T[x - 160 - 2a]; bit for bit against numpy.float16, hi + lo = the tap to 2^-21 of itself, zeros
+    outside |d| <= 31, and the taps are the reference resampler's (oracle/restate.py: halfband_taps)"""
+    import ctypes
+
+    from audioflux_amd import _lib
+    from oracle import restate
+    lib = _lib.get_lib()
+    fn = lib.afx_cqt_dec_table
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    taps = np.asarray(restate.halfband_taps(), np.float64)[:32].astype(np.float32)
+    out = np.zeros((2, 4, 352), np.uint16)
+    fn(taps.ctypes.data, out.ctypes.data)
+    for a in range(4):
+        d = np.abs(np.arange(352) - 160 - 2 * a)
+        v = np.where(d <= 31, np.ldexp(taps[np.minimum(d, 31)], 15), np.float32(0)).astype(np.float32)
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float32)).astype(np.float16)
+        assert np.array_equal(out[0, a].view(np.float16), hi) and np.array_equal(out[1, a].view(np.float16), lo), a
+        nz = v != 0
+        assert nz.sum() == 63 and np.array_equal(out[0, a][nz], hi.view(np.uint16)[nz])
+        err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - v)
+        assert np.all(err <= np.abs(v) * 2.0 ** -21)
+    assert 8192 <= np.ldexp(taps[0], 15) < 16384  # the centre tap puts the table's peak into [2^13, 2^14)

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT"; T=${1:-p}; D=gpurun_out/pyr_$T; mkdir -p $D
 export TMPDIR=/tmp
 (timeout -k 10 400 python -m pytest tests/test_cqt_gpu.py -q -m gpu -x 2>&1 | tail -n 15) > $D/pytest_cqt.txt; cat $D/pytest_cqt.txt
-timeout -k 10 300 python tools/pyr_compare.py > $D/compare.txt 2>&1; tail -n 12 $D/compare.txt
+(timeout -k 10 400 python -m pytest tests/test_cqt_gpu.py -q -m gpu -k ladder 2>&1 | tail -n 5) > $D/compare.txt; cat $D/compare.txt
 for v in 1 0; do
   AFX_CQT_PYRAMID=$v timeout -k 10 300 python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline > $D/bench5_pyr$v.json 2> $D/bench5_pyr$v.err
   python - <<P
