@@ -61,7 +61,7 @@ struct TdGeom {
                                                              // re-used by the transposed epilogue (4224 B)
 };
 
-constexpr int MAXPAIRS = 48;
+constexpr int MAXPAIRS = AFX_CWT_TD_MAXPAIRS;
 struct TdArgs {
     const float *x;
     long long xStride;
@@ -306,14 +306,27 @@ static int launch_td(const AfxCwtTdPlan *p, int first, int count, int maxKs, dou
     return AFX_OK;
 }
 
+// every precondition of the two launches below (the host plans with it: afx_cwt.c: cwt_td_plan)
+extern "C" int afxk_cwt_td_fits(const AfxCwtTdPlan *p, int dataLength, int num) {
+    if (!p || p->nPairs <= 0 || !p->hostKs) return AFX_ERR_UNSUPPORTED;
+    if (dataLength < SLAB || (dataLength & (dataLength - 1))) return AFX_ERR_UNSUPPORTED;
+    if (p->maxKs < 4 || 16 * p->maxKs > AFX_CWT_TD_MAXK) return AFX_ERR_UNSUPPORTED;
+    if ((long long)num * dataLength * 4 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;  // 32-bit offsets inside one chunk's planes
+    int nLong = 0;  // pairs are sorted longest first; each class is one launch of <= MAXPAIRS pairs
+    while (nLong < p->nPairs && 16 * p->hostKs[nLong] > SHORTK) ++nLong;
+    if (nLong > MAXPAIRS || p->nPairs - nLong > MAXPAIRS) return AFX_ERR_UNSUPPORTED;
+    if (nLong > 0 && (size_t)2 * p->maxKs * 1024 + 2048 + (size_t)WAVES * TdGeom<AFX_CWT_TD_MAXK>::WAVE_BYTES > 160 * 1024) return AFX_ERR_UNSUPPORTED;
+    if (nLong < p->nPairs && (size_t)2 * p->hostKs[nLong] * 1024 + 2048 + (size_t)WAVES * TdGeom<SHORTK>::WAVE_BYTES > 160 * 1024)
+        return AFX_ERR_UNSUPPORTED;
+    return AFX_OK;
+}
+
 // streamShort (NULL: `stream`): where the short-kernel class is launched -- beside the long class when it is another
 // stream (two workgroups of it fit a CU, so it fills the long class's tail); the caller joins the two
 extern "C" int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStride, int chunks, int dataLength, int num,
                            float *outRe, float *outIm, void *stream, void *streamShort) {
     if (!p || p->nPairs <= 0 || chunks <= 0) return AFX_OK;
-    if (dataLength < SLAB || (dataLength & (dataLength - 1))) return AFX_ERR_UNSUPPORTED;
-    if (p->maxKs < 4 || 16 * p->maxKs > AFX_CWT_TD_MAXK || p->nPairs > MAXPAIRS || !p->hostKs) return AFX_ERR_UNSUPPORTED;
-    if ((long long)num * dataLength * 4 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;  // 32-bit offsets inside one chunk's planes
+    if (afxk_cwt_td_fits(p, dataLength, num) != AFX_OK) return AFX_ERR_UNSUPPORTED;
     TdArgs a;
     a.x = x;
     a.xStride = xStride;

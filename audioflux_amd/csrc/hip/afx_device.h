@@ -214,6 +214,7 @@ typedef struct {
 } AfxCwtPlanDims;
 /* ---- short-kernel ("wide") scales in the time domain on the f16 matrix cores (afx_cwt_td.hip) ----
  * pair: two scales share one MFMA column tile -- 32 columns = 2 scales x (re, im) x 8 output phases */
+#define AFX_CWT_TD_MAXPAIRS 48 /* pairs of scales one time-domain launch takes (two launches: long and short kernels) */
 #define AFX_CWT_TD_MAXK 1024   /* taps (incl. the 8 phase shifts) of the longest kernel the LDS-resident image takes */
 typedef struct {
     int scale[2];            /* result rows (C order: row 0 = highest frequency); scale[1] < 0: a single scale */
@@ -231,6 +232,9 @@ typedef struct AfxCwtTdPlan_ {
     int wrap;                    /* 0: reflect padding (isPadding, cwt_algorithm.c:404-414), 1: circular */
 } AfxCwtTdPlan;
 /* chunk c at x + c xStride (dataLength = 2^r samples) -> outRe/outIm [chunks][num][dataLength], rows p->pairs[].scale */
+/* AFX_OK when afxk_cwt_td takes this plan for chunks of dataLength samples and `num` output scales (every precondition
+ * of the launch: checked once, when the object is planned -- a plan that fails goes back to the FFT path) */
+int afxk_cwt_td_fits(const AfxCwtTdPlan *p, int dataLength, int num);
 int afxk_cwt_td(const AfxCwtTdPlan *p, const float *x, long long xStride, int chunks, int dataLength, int num,
                 float *outRe, float *outIm, void *stream, void *streamShort /* short-kernel class; NULL: `stream` */);
 #define AFX_CWT_FASTTW_FLOATS (2 * (8 * 64 + 8 * 8 + 16 * 16))

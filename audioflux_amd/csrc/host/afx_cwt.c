@@ -505,7 +505,8 @@ static int td_cand_cmp(const void *a, const void *b) {
 static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
     const long long L = o->fftLength;
     const int D = o->dataLength, pad = o->padLength;
-    if (D < 8192 || *nWide < 1) return AFX_OK;
+    /* (AFX_NO_FUSED: the size-generic inverse computes EVERY scale -- no second writer of those rows) */
+    if (D < 8192 || *nWide < 1 || afxdev_no_fused()) return AFX_OK;
     double *re = (double *)malloc(sizeof(double) * (size_t)L), *im = (double *)malloc(sizeof(double) * (size_t)L);
     TdCand *cand = (TdCand *)calloc((size_t)*nWide, sizeof(TdCand));
     int st = (re && im && cand) ? AFX_OK : AFX_ERR_NOMEM, nc = 0;
@@ -558,12 +559,25 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
     }
     free(re);
     free(im);
-    const int nPairs = (nc + 1) / 2;
+    int nPairs = (nc + 1) / 2;
     AfxCwtTdPair *pairs = NULL;
     unsigned char *blob = NULL;
     float *G = NULL;
     if (st == AFX_OK && nc > 0) {
         qsort(cand, (size_t)nc, sizeof(TdCand), td_cand_cmp);
+        /* a launch takes AFX_CWT_TD_MAXPAIRS pairs: the candidates beyond that -- the LONGEST kernels, the dearest ones in
+         * the time domain -- stay on the FFT path (a bank of 36 bins per octave, or a linear one of 256 scales, has more
+         * than 96 short-kernel scales) */
+        const int cap = 2 * AFX_CWT_TD_MAXPAIRS;
+        if (nc > cap) {
+            for (int c = 0; c < nc - cap; c++) {
+                free(cand[c].re);
+                free(cand[c].im);
+            }
+            memmove(cand, cand + (nc - cap), sizeof(TdCand) * (size_t)cap);
+            nc = cap;
+        }
+        nPairs = (nc + 1) / 2;
         pairs = (AfxCwtTdPair *)calloc((size_t)nPairs, sizeof(AfxCwtTdPair));
         if (!pairs) st = AFX_ERR_NOMEM;
         size_t blobBytes = 0;
@@ -615,9 +629,20 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
             for (int p = 0; p < nPairs && o->tdKs; p++) o->tdKs[p] = pairs[p].ks;
             o->td.hostKs = o->tdKs;
             o->td.wrap = pad > 0 ? 0 : 1;
+            if (st == AFX_OK && afxk_cwt_td_fits(&o->td, D, o->num) != AFX_OK) {
+                /* the launch would refuse this plan: every scale stays on the FFT path (nothing is re-ordered) */
+                afxdev_free(o->dTdPairs);
+                afxdev_free(o->dTdImage);
+                o->dTdPairs = NULL;
+                o->dTdImage = NULL;
+                free(o->tdKs);
+                o->tdKs = NULL;
+                memset(&o->td, 0, sizeof(o->td));
+                nc = -nc; /* (skip the re-ordering below; the candidates are still freed) */
+            }
             /* order := [time-domain scales, pair by pair | the other two-pass scales | narrow-band classes] */
-            int *rest = (int *)malloc(sizeof(int) * (size_t)*nWide);
-            if (!rest) st = AFX_ERR_NOMEM;
+            int *rest = nc > 0 ? (int *)malloc(sizeof(int) * (size_t)*nWide) : NULL;
+            if (!rest && nc > 0) st = AFX_ERR_NOMEM;
             int nr = 0;
             for (int w = 0; w < *nWide && rest; w++) {
                 int taken = 0;
@@ -633,7 +658,7 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
             free(rest);
         }
     }
-    for (int c = 0; c < nc; c++) {
+    for (int c = 0; c < (nc < 0 ? -nc : nc); c++) {
         free(cand[c].re);
         free(cand[c].im);
     }
@@ -996,7 +1021,10 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
                                   hipStream);
         if (st == AFX_OK && side) st = afxdev_stream_wait_stream(hipStream, side);
     }
-    if (st == AFX_OK && tds) st = afxdev_stream_wait_stream(hipStream, tds);
+    if (tds) { /* also on the way out of a failed call: the time-domain kernel may still be writing dReal / dImag */
+        const int js = st == AFX_OK ? afxdev_stream_wait_stream(hipStream, tds) : afxdev_stream_sync(tds);
+        if (st == AFX_OK) st = js;
+    }
     o->lastStream = hipStream;
     o->lastUsed = 1;
 

@@ -271,8 +271,8 @@ class Cfg4:
         re, im = self.ring[slot]
         return _parity(re[0].cpu().numpy() + 1j * im[0].cpu().numpy(), rre + 1j * rim)
 
-    def cpu(self):
-        return cpu_baseline(cpu_worker_cfg4, "chunks/s", (2, 1, 2), "2^16-sample chunks (84 morlet scales, padded)")
+    def cpu(self, budget_s=25.0):
+        return cpu_baseline(cpu_worker_cfg4, "chunks/s", (2, 1, 2), "2^16-sample chunks (84 morlet scales, padded)", budget_s)
 
 
 class Cfg5:
@@ -324,8 +324,8 @@ class Cfg5:
         return max(_parity(self.re[0].cpu().numpy() + 1j * self.im[0].cpu().numpy(), rre + 1j * rim),
                    _parity(self.ch[i & 1][0].cpu().numpy(), rch))
 
-    def cpu(self):
-        return cpu_baseline(cpu_worker_cfg5, "frames/s", (1, 1, 1), "30 s @44.1 kHz clips (CQT-84 + chroma-12)")
+    def cpu(self, budget_s=25.0):
+        return cpu_baseline(cpu_worker_cfg5, "frames/s", (1, 1, 1), "30 s @44.1 kHz clips (CQT-84 + chroma-12)", budget_s)
 
 
 class DryRun:
@@ -515,6 +515,8 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="--config 2 at one GPU also measures cfg 4 and cfg 5 "
                     "after the headline (outside its timed region) and reports them under `secondary`")
+    ap.add_argument("--no-legacy", action="store_true", help="skip the reference's published benchmark through its own wrapper "
+                    "(tools/legacy_bench.py; --config 2 at one GPU)")
     ap.add_argument("--clock-warmup", type=float, default=0.5, help="seconds of untimed steps before the W warm-up "
                     "steps: the device ramps its clocks over tens of ms after idling, and W steps of ~1.5 ms end "
                     "long before that (0 disables; reported as config.clock_warmup_s)")
@@ -631,10 +633,25 @@ def main():
                         "dtype": getattr(w2, "dtype", "f32"), "frac": r2["frac"], "sustained_frac": r2["sustained_frac"],
                         "traffic": r2["traffic"], "traffic_over_algorithmic": r2["traffic_over_algorithmic"],
                         "roofline": r2, "oracle_check": {"clip0_max_rel_err": e2, "bar": 1e-5}}
+                    if not a.no_cpu_baseline:  # the reference on the host cores, a few seconds per configuration
+                        try:
+                            out["secondary"][f"cfg{cfg}"]["cpu_baseline"] = w2.cpu(budget_s=6.0)
+                        except Exception as e:
+                            out["secondary"][f"cfg{cfg}"]["cpu_baseline"] = {"error": repr(e)}
                     del w2
                     torch.cuda.empty_cache()
                 except Exception as e:  # never lose the headline line to a secondary configuration
                     out["secondary"][f"cfg{cfg}"] = {"error": repr(e)}
+        if world == 1 and a.config == 2 and not dry and not a.no_legacy:
+            # the reference's own published benchmark through its unmodified wrapper + this library (host pointers, one
+            # clip per call, PCIe inside the clock) -- a fresh interpreter, after everything else
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "legacy_bench.py")], capture_output=True, text=True,
+                                   timeout=240, env=dict(os.environ, AFX_HIP_RUNTIME="system"))
+                out["legacy"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                out["legacy"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

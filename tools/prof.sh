@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-legacy $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py $ARGS > $OUT/trace_bench.log 2>&1
 i=0
 for CTRS in \

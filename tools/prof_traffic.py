@@ -51,7 +51,7 @@ def main():
     a = ap.parse_args()
     warm = 1
     args = ["--config", str(a.config), "--steps", str(a.steps), "--warmup", str(warm), "--no-cpu-baseline",
-            "--no-sustained", "--no-check", "--no-secondary", "--clock-warmup", "0"]
+            "--no-sustained", "--no-check", "--no-secondary", "--no-legacy", "--clock-warmup", "0"]
     if a.clips:
         args += ["--clips", str(a.clips)]
     tmp = os.path.join(ROOT, "gpurun_out", f"prof_traffic_cfg{a.config}")
