@@ -87,6 +87,7 @@ def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_n
     rr = ref.RefCepstrogram(r, wt, hop)
     from oracle import restate
     want0, bar0 = None, {}
+    K = {"cep": 2.0, "env": 4.0, "det": 5.0}
     for i in range(clips):
         want = rr.cepstrogram(x[i, :length], cep_num)
         want0 = want if i == 0 else want0
@@ -95,8 +96,12 @@ def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_n
         # bins: the reference itself is up to 5e-5 of the output's peak away from a float64
         # evaluation there, and every float32 evaluation scatters around the exact value by that
         # order, with a factor that depends on how deep the frame's deepest spectral null is.
-        # The bar is therefore the larger of TOL and 6x the reference's own distance from float64
-        # (peak- and L2-relative separately), for the comparison with the reference AND with float64.
+        # The bar is therefore the larger of TOL and K x the reference's own distance from float64
+        # (peak- and L2-relative separately), for the comparison with the reference AND with float64:
+        # K = 2 for the cepstrum, 4 for the envelope, 5 for the details (round 3: 6 for all; measured
+        # at worst 1.5 / 3.9 (below TOL) / 4.3 over these 33 shapes -- the maximum of a heavy-tailed
+        # error, one bin decides it; tests/test_realaudio_gpu.py pins the well-conditioned part of
+        # real clips at plain 1e-5).
         f64 = restate.cepstrogram(x[i, :length].astype(np.float64), 1 << r, hop, cep_num, window_type=wt)
         for k, name in enumerate(("cep", "env", "det")):
             got = outs[k][i].cpu().numpy().astype(np.float64)
@@ -105,14 +110,14 @@ def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_n
             ref_p = np.abs(want[k] - f64[k]).max() / peak
             ref_l = np.linalg.norm(want[k] - f64[k]) / l2
             if i == 0:
-                bar0[name] = max(TOL[name], 6.0 * max(ref_p, ref_l))
+                bar0[name] = max(TOL[name], K[name] * max(ref_p, ref_l))
             for tag, other in (("reference", want[k]), ("float64", f64[k])):
                 p_err = np.abs(got - other).max() / peak
                 l_err = np.linalg.norm(got - other) / l2
                 parity_log(f"cepstrogram wave {name} r{r} hop{hop} q{cep_num} clip{i} vs {tag}", max(p_err, l_err),
-                           max(TOL[name], 6.0 * max(ref_p, ref_l)), "max(TOL, 6 x reference-vs-float64)",
+                           max(TOL[name], K[name] * max(ref_p, ref_l)), f"max(TOL, {K[name]:g} x reference-vs-float64)",
                            {"reference_vs_float64": float(max(ref_p, ref_l))})
-                assert p_err <= max(TOL[name], 6.0 * ref_p) and l_err <= max(TOL[name], 6.0 * ref_l), (
+                assert p_err <= max(TOL[name], K[name] * ref_p) and l_err <= max(TOL[name], K[name] * ref_l), (
                     f"clip {i} {name} hop {hop} q {cep_num} vs {tag}: peak-rel {p_err:.2e} (reference vs float64 "
                     f"{ref_p:.2e}), l2-rel {l_err:.2e} ({ref_l:.2e})")
     # and against the size-generic kernel behind the one-clip entry point (clip 0: plain noise);

@@ -35,25 +35,26 @@ def clip(name):
     return cases.real_audio(name) if name in cases.REAL_AUDIO else cases.hard_clip(name)
 
 
-def check(what, got, want, f64, per_frame=True, tol=TOL):
-    """tensor bars vs reference and vs float64 (uncertainty-aware, see the module docstring) + per-frame bars"""
+def check(what, got, want, f64, per_frame=True, tol=TOL, k=2.0):
+    """tensor bars vs reference and vs float64 (uncertainty-aware, see the module docstring) + per-frame bars: nothing
+    may sit further than k = 2 x the reference's own distance from float64 (round 3: 3 x) wherever that exceeds 1e-5"""
     got = np.asarray(got)
     assert got.shape == np.shape(want) == np.shape(f64) and np.all(np.isfinite(got)), what
     ref_d = max(peak_rel(want, f64), l2_rel(want, f64))
     for tag, other in (("reference", want), ("float64", f64)):
         d = max(peak_rel(got, other), l2_rel(got, other))
-        bar = max(tol, 3.0 * ref_d)
-        parity_log(f"{what} vs {tag}", d, bar, "max(1e-5, 3 x reference-vs-float64)", {"reference_vs_float64": ref_d})
+        bar = max(tol, k * ref_d)
+        parity_log(f"{what} vs {tag}", d, bar, f"max(1e-5, {k:g} x reference-vs-float64)", {"reference_vs_float64": ref_d})
         assert d <= bar, f"{what} vs {tag}: {d:.3e} > {bar:.3e} (reference vs float64 {ref_d:.3e})"
     if per_frame:
         pf_ref = cases.per_frame_rel(want, f64)
         pf64 = cases.per_frame_rel(got, f64)
         pfr = cases.per_frame_rel(got, want)
-        parity_log(f"{what} per-frame vs float64", pf64, max(tol, 3.0 * pf_ref) if pf_ref > tol else tol, "per-frame",
+        parity_log(f"{what} per-frame vs float64", pf64, max(tol, k * pf_ref) if pf_ref > tol else tol, "per-frame",
                    {"reference_vs_float64": pf_ref})
-        parity_log(f"{what} per-frame vs reference", pfr, max(tol, 3.0 * pf_ref), "per-frame",
+        parity_log(f"{what} per-frame vs reference", pfr, max(tol, k * pf_ref), "per-frame",
                    {"reference_vs_float64": pf_ref})
-        assert pfr <= max(tol, 3.0 * pf_ref), f"{what} per-frame vs reference {pfr:.3e} (reference vs float64 {pf_ref:.3e})"
+        assert pfr <= max(tol, k * pf_ref), f"{what} per-frame vs reference {pfr:.3e} (reference vs float64 {pf_ref:.3e})"
         return pf64, pf_ref
     return None
 
@@ -149,7 +150,9 @@ def test_cwt_four_step_kernels(name, golden_dir):
     fre = np.asarray(o.get_fre_band_arr(), np.float64)[::-1]
     F = restate.cwt(x.astype(np.float64), fre, SR, "morlet", 6.0, 2.0, True)
     got = o.cwt(x)[::-1]          # the wrapper returns ascending frequency, the C layout (and F, R) is descending
-    check(f"{name} cwt (rows = scales)", got, R, F)
+    # (dc_offset: every scale's row is the remainder of a kernel that sums to ~0 times a constant -- measured 2.8 x the
+    # reference's own distance per row; the one clip that keeps the 3 x bar)
+    check(f"{name} cwt (rows = scales)", got, R, F, k=3.0 if name == "dc_offset" else 2.0)
     # time blocks of 512 samples as rows: the whole chunk goes through ONE float32 transform of 2^17 points in the
     # reference and here, so a quiet stretch carries the rounding of the loud one in both -- uncertainty-aware bar
     blk = lambda a: np.asarray(a).reshape(84, 128, 512).transpose(1, 0, 2).reshape(128, -1)
@@ -161,8 +164,16 @@ def test_cwt_four_step_kernels(name, golden_dir):
 
 @pytest.mark.parametrize("name", CLIPS)
 def test_cepstrogram_wave_kernel(name):
-    """k_cepstrogram_w2048 on real audio: ln|S|^2 amplifies the float32 error of the spectrum at near-empty bins, the
-    bar is the conditioning-aware one of tests/test_cepstrogram_gpu.py (6 x the reference's own distance from float64)"""
+    """k_cepstrogram_w2048 on real audio.  ln|S|^2 amplifies the float32 error of the spectrum at near-empty bins by
+    peak / |S|^2 -- in the reference as much as here, with another realisation of the rounding -- so two float32
+    implementations cannot agree there, and the liftering spreads one such bin over its whole frame.  Two statements:
+      * the WELL-CONDITIONED part is the reference's to 1e-5: frames whose weakest bin holds more than 1e-10 of the frame's
+        peak power -- all of `cepstrum`, and `envelope`'s and `details`' bins above 1e-5 of the peak there (a float32
+        transform leaves ~1e-7 of the peak AMPLITUDE on every bin, i.e. 2e-7 sqrt(peak / |S|^2) on ln|S|^2: 1e-4 = 1e-5 of the
+        outputs' peak of ~10 where |S|^2 > 4e-6 of the peak) -- against the COMPILED REFERENCE, plain bar;
+      * on the whole tensor the kernel is no further from the float64 evaluation than k x the reference is: k = 2 for the
+        cepstrum, 4 for envelope / details (round 3: 6; measured 2.6 / 3.3 at worst -- the maximum of a heavy-tailed error
+        over 10^6 elements), both logged."""
     import torch
     x = clip(name)
     want = ref.RefCepstrogram(11, 1, 512).cepstrogram(x, 4)
@@ -170,14 +181,28 @@ def test_cepstrogram_wave_kernel(name):
     o = af.Cepstrogram(radix2_exp=11, window_type=af.WindowType.HANN, slide_length=512)
     outs = o.cepstrogram_device(torch.from_numpy(x[None]).cuda(), cep_num=4)
     torch.cuda.synchronize()
+    fr = restate.frames_of(x.astype(np.float64), 2048, 512) * restate.fft_window(1, 2048)[None, :]
+    rel = np.abs(np.fft.fft(fr, axis=1)) ** 2
+    rel /= np.maximum(rel.max(axis=1, keepdims=True), 1e-300)
+    good_frames = rel.min(axis=1) > 1e-10
+    good = (rel[:, :1025] > 1e-5) & good_frames[:, None]
     for k, nm in enumerate(("cep", "env", "det")):
         got = outs[k][0].cpu().numpy().astype(np.float64)
         assert got.shape == f64[k].shape and np.isfinite(got).all()
         peak, l2 = np.abs(f64[k]).max(), np.linalg.norm(f64[k])
+        # -- the well-conditioned part against the compiled reference, plain 1e-5
+        m = np.broadcast_to(good_frames[:, None], got.shape) if nm == "cep" else good
+        if m.any():
+            d = np.abs(got - want[k])[m].max() / peak
+            parity_log(f"{name} cepstrogram {nm} vs reference, well-conditioned part ({100.0 * m.mean():.0f} % of the elements)", d, TOL,
+                       "peak over frames with min |S|^2 > 1e-10 peak" + ("" if nm == "cep" else ", bins > 1e-5 peak"))
+            assert d <= TOL, f"{name} {nm} well-conditioned part vs reference: {d:.3e}"
+        # -- the whole tensor, conditioning-aware
         ref_d = max(np.abs(want[k] - f64[k]).max() / peak, np.linalg.norm(want[k] - f64[k]) / l2)
+        kk = 2.0 if nm == "cep" else 4.0
         for tag, other in (("reference", want[k]), ("float64", f64[k])):
             d = max(np.abs(got - other).max() / peak, np.linalg.norm(got - other) / l2)
-            bar = max(2e-5 if nm == "det" else TOL, 6.0 * ref_d)
-            parity_log(f"{name} cepstrogram {nm} vs {tag}", d, bar, "max(TOL, 6 x reference-vs-float64)",
+            bar = max(2e-5 if nm == "det" else TOL, kk * ref_d)
+            parity_log(f"{name} cepstrogram {nm} vs {tag}", d, bar, f"max(TOL, {kk:g} x reference-vs-float64)",
                        {"reference_vs_float64": float(ref_d)})
             assert d <= bar, f"{name} {nm} vs {tag}: {d:.3e} > {bar:.3e}"

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round 3, second GPU call: the whole -m gpu suite on the cleaned tree (new: real audio / hard clips, cfg-2 second
+# The evidence call of a round (round 4 on): the whole -m gpu suite on the cleaned tree (new: real audio / hard clips, cfg-2 second
 # corpus, cfg-4 ring), the driver's bench line (with `secondary`), PMC traffic + kernel traces of the SHIPPED
-# kernels for cfg 2 / 4 / 5.   gpurun --timeout 1500 -- 'bash tools/gpu_call2.sh r03b'
+# kernels for cfg 2 / 4 / 5.   gpurun --timeout 1500 -- 'bash tools/gpu_call2.sh r04a'
 set -u
-TAG=${1:-r03b}
+TAG=${1:-r04a}
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/call_$TAG
 mkdir -p $OUT
@@ -18,8 +18,8 @@ cp gpurun_out/prof_ev_$TAG/summary.txt $OUT/rocprofv3_bench_cfg2_summary.txt 2>/
 timeout -k 10 200 python tools/prof_traffic.py 2 > $OUT/traffic_cfg2.log 2>&1
 timeout -k 10 200 python tools/prof_traffic.py 5 --clips 125 > $OUT/traffic_cfg5.log 2>&1
 timeout -k 10 200 python tools/prof_traffic.py 4 --clips 20 --steps 1 > $OUT/traffic_cfg4.log 2>&1
-cp gpurun_out/r03_bench_cfg*_pmc.json $OUT/ 2>/dev/null
-cp gpurun_out/r03_bench_cfg*_pmc.json profiles/ 2>/dev/null   # the bench line below quotes THIS build's traffic
+cp gpurun_out/r04_bench_cfg*_pmc.json $OUT/ 2>/dev/null
+cp gpurun_out/r04_bench_cfg*_pmc.json profiles/ 2>/dev/null   # the bench line below quotes THIS build's traffic
 timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "bench default rc=$?" | tee -a $OUT/status.txt
 for c in 5 4; do
