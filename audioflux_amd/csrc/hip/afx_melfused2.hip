@@ -92,6 +92,23 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Wave priority by phase of the frame (s_setprio): phases 0 window, 1 first radix-16 + twiddles + exchange writes, 2 exchange
+// reads, 3 second radix-16, 4 last radix-4 + split, 5 band, 6 store / cepstra; bit p of AFX_PRIO_MASK raises phase p to
+// AFX_PRIO_LEVEL.  The three waves of a SIMD are in different phases of their frames; with the transform's phases (1-4,
+// dense packed arithmetic between short LDS exchanges) above the window / band / store phases (LDS- and memory-latency
+// bound) a wave that can keep the vector unit busy wins the issue port: 1.53-1.56 -> 1.47-1.48 ms per step, measured
+// interleaved against masks 0x0A, 0x1F, 0x3E, 0x20, 0x61 and levels 1 / 2 / 3 (profiles/r04_ab_headline.txt).
+#ifndef AFX_PRIO_MASK
+#define AFX_PRIO_MASK 0x1E
+#endif
+#ifndef AFX_PRIO_LEVEL
+#define AFX_PRIO_LEVEL 1
+#endif
+#define MEL_PHASE(p)                                                                                       \
+    do {                                                                                                   \
+        if (AFX_PRIO_MASK != 0) __builtin_amdgcn_s_setprio(((AFX_PRIO_MASK >> (p)) & 1) ? AFX_PRIO_LEVEL : 0); \
+    } while (0)
+
 __device__ __forceinline__ v2 lo2(v4f q) { return v2{q.x, q.y}; }
 __device__ __forceinline__ v2 hi2(v4f q) { return v2{q.z, q.w}; }
 
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
 
     for (; f < fEnd; ++f) {
         v2 v[16];
+        MEL_PHASE(0);
         // ---- 1. window: 8 x 16 bytes per lane, the first half is used while the second lands ----
         {
             v4f wv[8];
@@ -319,6 +337,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         }
 
         // ---- 2a. radix-16 over n1, twiddle W_1024^(lane k1), transpose through LDS -----------
+        MEL_PHASE(1);
         dft16(v);
         {
             v4f tq[8];  // requested after the butterflies: held across them they would spill
@@ -339,6 +358,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
             }
         }
         wave_lds_sync();
+        MEL_PHASE(2);
         {
             v4f rq[8];
 #pragma unroll
@@ -353,6 +373,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         }
 
         // ---- 2b. radix-16 over m1, twiddle W_64^(m2 j1) -> image V[q = k1 + 16 j1][m2] --------
+        MEL_PHASE(3);
         dft16(v);
         {
             v4f tq[8];
@@ -375,6 +396,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         wave_lds_sync();
 
         // ---- 3. last radix-4 + real-input split -> spectrum values in registers --------------
+        MEL_PHASE(4);
         float pk[2][4], pq[2][4], p512;
         {
             v4f zalo[2], zahi[2], zblo[2], zbhi[2], wlo[2], whi[2];
@@ -445,6 +467,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         if (lane0) prow[512] = p512;
         wave_lds_sync();
 
+        MEL_PHASE(5);
         // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset
         //         ds_read_b64 (conflict-free by the plan's bank-aware lane assignment); the NEXT
         //         block of four quads is requested before this block's values are waited for --------
@@ -503,6 +526,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
         }
+        MEL_PHASE(6);
         // ---- 5. store (first the cepstra of the 16 rows stored before this one, if that many wait) ----
         if constexpr (CC) {
             if (ccN == 16) cc_block(f - 16, 16);
@@ -606,6 +630,10 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
 template <int TA, int TB, bool SPLIT, bool CC, bool TEMPORAL>
 int launch_hop(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     // register re-use of the overlapping frames for hop = 128 * SHIFT: N/8, N/4, N/2
+#ifdef AFX_EXPERIMENTS  // measurement builds only (make EXTRA=-DAFX_EXPERIMENTS): AFX_EXP_MEL=noshift fetches every frame whole
+    if (const char *e = getenv("AFX_EXP_MEL"))
+        if (strstr(e, "noshift")) return launch_variant<TA, TB, 0, SPLIT, CC, TEMPORAL>(p, a, stream);
+#endif
     switch (a->hop) {
         case 256: return launch_variant<TA, TB, 2, SPLIT, CC, TEMPORAL>(p, a, stream);
         case 512: return launch_variant<TA, TB, 4, SPLIT, CC, TEMPORAL>(p, a, stream);

@@ -483,6 +483,26 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
     return res
 
 
+def pmc_compute(config):
+    """the compute side of the roofline from the round's PMC passes (tools/prof.sh + tools/prof_compute.py): how busy the
+    vector unit, the LDS, the SIMDs' issue ports and the matrix pipe were under the dominant kernel -- what bounds a
+    kernel that is nowhere near the HBM roofline; replayed from profiles/, like `traffic`"""
+    for rnd in ("r04",):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_bench_cfg{config}_compute.json")
+        try:
+            rec = json.load(open(path))
+            out = {k: rec.get(k) for k in ("valu_busy", "lds_busy", "issue_busy", "mfma_busy", "lds_bank_conflict_share",
+                                           "shader_clock_mhz", "valu_insts_per_unit_and_wave", "lds_insts_per_unit_and_wave")}
+            busiest = max((v, k) for k, v in out.items() if k.endswith("_busy") and v is not None)
+            out["bound"] = {"issue_busy": "instruction issue (SIMD issue ports)", "valu_busy": "vector unit", "lds_busy": "LDS",
+                            "mfma_busy": "matrix pipe"}[busiest[1]]
+            out["source"] = os.path.relpath(path, ROOT)
+            return out
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def roofline(W, w, clips, m):
     kern_ms, sus = m["kern_ms"], m["sustained_ms"]
     achieved = w.units * W.bytes_per_unit / (kern_ms * 1e-3) / 1e9 if kern_ms else None
@@ -495,7 +515,8 @@ def roofline(W, w, clips, m):
             "kernel": W.kernel, "kernel_ms": kern_ms,
             "algorithmic_bytes_per_unit": W.bytes_per_unit, "units_per_launch": w.units,
             "sustained_ms": sus, "sustained_value": (w.units / (sus * 1e-3)) if sus else None,
-            "sustained_frac": (alg / (sus * 1e-3) / 1e9 / HBM_PEAK_GBS) if sus else None}
+            "sustained_frac": (alg / (sus * 1e-3) / 1e9 / HBM_PEAK_GBS) if sus else None,
+            "compute": pmc_compute(W.config) if hasattr(W, "config") else None}
 
 
 def main():
