@@ -24,6 +24,12 @@
 #include "afx_pkmath.h"
 
 
+#ifdef AFX_NO_PRIO  // measurement builds only
+#define AFX_TRANSFORM_PRIO(p) ((void)0)
+#else
+#define AFX_TRANSFORM_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
 namespace {
 
 constexpr int NFFT = 2048;
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_cplx(KArgs a) {
             }
         }
 
+        AFX_TRANSFORM_PRIO(1);  // (afx_melfused2.hip: the transform's phases above the window / band / store phases of the SIMD's other waves)
         // ---- 2a. radix-16 over n1, twiddle, transpose through LDS ---------------
         v2 t1[16];
 #pragma unroll
@@ -275,6 +282,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_cplx(KArgs a) {
             if (lane < PROW_F - 1025 - 64) prow[1025 + 64 + lane] = 0.f;
             wave_lds_sync();
 
+            AFX_TRANSFORM_PRIO(0);
             // ---- 4. banded filter bank: weights by ds_read_b128, the row by ds_read_b64 (starts are
             //         even; conflict-free by the plan's bank-aware lane assignment), operands in
             //         blocks of 4 quads so that one LDS round trip is paid per block -------------
