@@ -152,6 +152,33 @@ static inline emu_f32x16 emu_mfma_32x32x16_f16(emu_h8 a, emu_h8 b, emu_f32x16 c)
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16_f16((a), (b), (c))
 
+// v_mfma_f32_16x16x32_f16: A operand lane l = row l & 15, k = 8 (l >> 4) + e; B operand lane l = column l & 15, same k;
+// D register r of lane l = row 4 (l >> 4) + r, column l & 15
+typedef float emu_f32x4h __attribute__((ext_vector_type(4)));
+static inline emu_f32x4h emu_mfma_16x16x32_f16(emu_h8 a, emu_h8 b, emu_f32x4h c) {
+    unsigned *x = emu::exchange();
+    const int l = emu::lane();
+    memcpy(x + l * 32, &a, 16);
+    memcpy(x + l * 32 + 4, &b, 16);
+    emu::wave_barrier();
+    const int col = l & 15;
+    emu_f32x4h d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            _Float16 av, bv;
+            memcpy(&av, reinterpret_cast<const char *>(x + (row + 16 * (k >> 3)) * 32) + 2 * (k & 7), 2);
+            memcpy(&bv, reinterpret_cast<const char *>(x + (col + 16 * (k >> 3)) * 32 + 4) + 2 * (k & 7), 2);
+            acc += (float)av * (float)bv;
+        }
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32_f16((a), (b), (c))
+
 // v_mfma_f32_32x32x2_f32: A operand lane l = row l & 31, k = l >> 5; B operand lane l = column l & 31, k = l >> 5
 static inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c) {
     unsigned *x = emu::exchange();
