@@ -334,19 +334,20 @@ class DryRun:
     ownership, double-buffered slabs, the side-stream gather, fences, the max-over-ranks clock, the
     JSON line -- executes unchanged; every clip's "features" carry its global index.  `config` picks
     the slab names and widths of the real workload (cfg 2: mfcc[.,13] + mel[.,128]; cfg 5: chroma[.,12]
-    + cqt[.,84]); `first_clip` is the rank's offset in the job's clip order (shard_range)."""
+    + cqt[.,84]; cfg 4: none -- replicas only, nothing is gathered); `first_clip` is the rank's offset
+    in the job's clip order (shard_range)."""
     metric, unit = "dry run (no device)", "frames/s"
     default_clips = 4
     bytes_per_unit = 2612
     kernel = "none (CPU stand-in)"
-    SLABS = {2: (("mfcc", 13), ("mel", 128)), 5: (("chroma", 12), ("cqt", 84))}
+    SLABS = {2: (("mfcc", 13), ("mel", 128)), 4: (("", 1), ("", 1)), 5: (("chroma", 12), ("cqt", 84))}
 
     def __init__(self, torch, af, dev, rank, clips, config=2, first_clip=None):
         self.torch, self.clips, self.rank = torch, clips, rank
         self.first = rank * clips if first_clip is None else first_clip
         self.T, self.units = 7, clips * 7
         (self.small, ws), (self.big, wb) = self.SLABS[config]
-        self.gather_choices = (self.small, self.big)
+        self.gather_choices = tuple(n for n in (self.small, self.big) if n)
         self.wide = torch.zeros((clips, self.T, wb))
         self.cc = [torch.zeros((clips, self.T, ws)) for _ in range(2)]
         self.workload, self.outputs = f"dry run of cfg {config}, {clips} clips on this rank", "CPU tensors"

@@ -103,3 +103,27 @@ def test_bench_control_flow_world2_gloo(gather, extra):
     assert g["overlap_hidden_ms"] is not None and g["exposed_ms"] >= 0
     assert "RCCL gather of " + "+".join(gather.split(",")) in d["config"]["parallelism"]
     assert "cpu_baseline" not in d  # N > 1: no CPU baseline leg
+
+
+@pytest.mark.timeout(300)
+def test_bench_replicas_only_world2_gloo():
+    """`bench.py --config 4 --gpus 2` dry: the CWT configuration has no exchange step (replicas
+    only), so N > 1 is the launch line, the barriers, the max-over-ranks clock and the summed units --
+    no gather object, no `gather` block on the line."""
+    import json
+    import subprocess
+    env = dict(os.environ, AFX_BENCH_DRYRUN="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--config", "4", "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    units = d["config"]["units_per_step_per_gpu"] * 2
+    assert units * 3 / (d["ms_per_step"] * 3e-3) == pytest.approx(d["value"], rel=1e-6)
+    assert "gather" not in d or d["gather"] is None or not d["gather"].get("slabs")
+    assert "RCCL gather" not in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d
