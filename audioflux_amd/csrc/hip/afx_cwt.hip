@@ -679,10 +679,10 @@ extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const 
         float2 *B2 = reinterpret_cast<float2 *>(scratchB);
         hipStream_t s = (hipStream_t)stream;
         // wide scales: row pass -> intermediate -> column pass.  The first nTd entries of the order list are the
-        // short-kernel scales the host runs through afxk_cwt_td (afx_cwt_td.hip) -- for the plain transform only: the
-        // derivative bank (isDet) has no time-domain image, its nTd scales take both passes here.
+        // short-kernel scales the host runs through afxk_cwt_td (afx_cwt_td.hip); a derivative bank (isDet) without
+        // time-domain images of its own (d->tdDet) takes both passes here for them.
         const int nTd = d->order ? d->nTd : 0;
-        const int skip = (!isDet && d->td) ? nTd : 0;
+        const int skip = (isDet ? d->tdDet : d->td) ? nTd : 0;
         const int nWide = d->order ? (nTd - skip) + d->nWide : num;
         if (nWide > 0 && (parts & AFX_CWT_WIDE)) {
             CwtGeom gw = g;

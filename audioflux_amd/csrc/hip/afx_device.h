@@ -211,6 +211,7 @@ typedef struct {
     int nTd;                 /* > 0: the FIRST nTd entries of `order` run the time-domain kernel (afx_cwt_td.hip),
                               * the nWide two-pass scales and the narrow-band classes follow */
     const struct AfxCwtTdPlan_ *td;
+    const struct AfxCwtTdPlan_ *tdDet; /* the derivative bank's kernels for the same nTd scales; NULL: its scales take both passes */
 } AfxCwtPlanDims;
 /* ---- short-kernel ("wide") scales in the time domain on the f16 matrix cores (afx_cwt_td.hip) ----
  * pair: two scales share one MFMA column tile -- 32 columns = 2 scales x (re, im) x 8 output phases */

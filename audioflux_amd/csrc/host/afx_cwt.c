@@ -44,6 +44,11 @@ struct OpaqueCWT {
     AfxCwtTdPair *dTdPairs;
     int *tdKs;               /* host: K steps of the pairs */
     unsigned char *dTdImage;
+    AfxCwtTdPlan tdDet;      /* the same scales with the derivative bank (cwtObj_enableDet); nPairs 0: two-pass */
+    AfxCwtTdPair *dTdPairsDet;
+    int *tdKsDet;
+    unsigned char *dTdImageDet;
+    int *hOrder;             /* host copy of the first nTd entries of the order list */
     float *dGA, *dGXt, *dGB; /* scratch of the batched calls: `group` chunks at a time */
     size_t capGA, capGXt, capGB;
     int haveSpectrum;
@@ -502,18 +507,29 @@ static int td_cand_cmp(const void *a, const void *b) {
     return x->scale - y->scale;
 }
 
-static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
+static void td_cand_free(TdCand *cand, int nc) {
+    for (int c = 0; c < nc && cand; c++) {
+        free(cand[c].re);
+        free(cand[c].im);
+    }
+    free(cand);
+}
+
+/* the scales of `list` whose kernel is short: g = IFFT(psi) for the plain bank, IFFT(j w psi) for the derivative bank
+ * (weights = the angular frequencies of cwtObj_enableDet; the float32 product the two-pass path multiplies with) */
+static int td_candidates(CWTObj o, int rL, const int *list, int n, const float *weights, TdCand **out, int *nOut) {
     const long long L = o->fftLength;
     const int D = o->dataLength, pad = o->padLength;
-    /* (AFX_NO_FUSED: the size-generic inverse computes EVERY scale -- no second writer of those rows) */
-    if (D < 8192 || *nWide < 1 || afxdev_no_fused()) return AFX_OK;
     double *re = (double *)malloc(sizeof(double) * (size_t)L), *im = (double *)malloc(sizeof(double) * (size_t)L);
-    TdCand *cand = (TdCand *)calloc((size_t)*nWide, sizeof(TdCand));
+    TdCand *cand = (TdCand *)calloc((size_t)n, sizeof(TdCand));
     int st = (re && im && cand) ? AFX_OK : AFX_ERR_NOMEM, nc = 0;
-    for (int w = 0; w < *nWide && st == AFX_OK; w++) {
-        const int j = order[w];
+    for (int w = 0; w < n && st == AFX_OK; w++) {
+        const int j = list[w];
         const float *row = o->hBank + (size_t)j * L;
-        for (long long k = 0; k < L; k++) re[k] = row[k], im[k] = 0.0;
+        if (weights)
+            for (long long k = 0; k < L; k++) re[k] = 0.0, im[k] = (float)(row[k] * weights[k]);
+        else
+            for (long long k = 0; k < L; k++) re[k] = row[k], im[k] = 0.0;
         st = afx_fft_f64(rL, re, im, 1); /* g = IFFT(psi): the 1 / L goes into the taps below */
         if (st != AFX_OK) break;
         /* Kh: the last |t| above 1e-6 of the peak, stretched by 8 % (a Gaussian envelope falls from 1e-6 to 1e-7
@@ -544,9 +560,8 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
         c->kh = (int)kh;
         c->re = (double *)malloc(sizeof(double) * (size_t)(2 * kh + 1));
         c->im = (double *)malloc(sizeof(double) * (size_t)(2 * kh + 1));
+        nc++; /* (counted before the check: td_cand_free releases a half-allocated entry too) */
         if (!c->re || !c->im) {
-            free(c->re);
-            free(c->im);
             st = AFX_ERR_NOMEM;
             break;
         }
@@ -555,14 +570,111 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
             c->re[t + kh] = re[k] / (double)L;
             c->im[t + kh] = im[k] / (double)L;
         }
-        nc++;
     }
     free(re);
     free(im);
-    int nPairs = (nc + 1) / 2;
-    AfxCwtTdPair *pairs = NULL;
+    if (st != AFX_OK) {
+        td_cand_free(cand, nc);
+        cand = NULL;
+        nc = 0;
+    }
+    *out = cand;
+    *nOut = nc;
+    return st;
+}
+
+typedef struct {
+    AfxCwtTdPlan *plan;
+    AfxCwtTdPair **dPairs;
+    unsigned char **dImage;
+    int **hostKs;
+} TdSlot;
+
+static void td_slot_clear(TdSlot t) {
+    afxdev_free(*t.dPairs);
+    afxdev_free(*t.dImage);
+    *t.dPairs = NULL;
+    *t.dImage = NULL;
+    free(*t.hostKs);
+    *t.hostKs = NULL;
+    memset(t.plan, 0, sizeof(*t.plan));
+}
+
+/* pairs (longest first), matrix-core images and the device copies of `nc` sorted candidates; the slot stays empty
+ * (AFX_OK, plan->nPairs 0) when the launch would refuse the plan */
+static int td_upload(CWTObj o, const TdCand *cand, int nc, TdSlot t) {
+    const int nPairs = (nc + 1) / 2;
+    AfxCwtTdPair *pairs = (AfxCwtTdPair *)calloc((size_t)nPairs, sizeof(AfxCwtTdPair));
     unsigned char *blob = NULL;
     float *G = NULL;
+    int st = pairs ? AFX_OK : AFX_ERR_NOMEM;
+    size_t blobBytes = 0;
+    int maxKs = 0;
+    for (int p = 0; p < nPairs && st == AFX_OK; p++) {
+        const TdCand *a = &cand[2 * p], *b = 2 * p + 1 < nc ? &cand[2 * p + 1] : NULL;
+        const int kh = (a->kh + 7) & ~7; /* a is the longer one */
+        const int kt = (2 * kh + 8 + 63) & ~63;
+        pairs[p].scale[0] = a->scale;
+        pairs[p].scale[1] = b ? b->scale : -1;
+        pairs[p].kh = kh;
+        pairs[p].ks = kt / 16;
+        pairs[p].img = (long long)blobBytes;
+        blobBytes += (size_t)2 * pairs[p].ks * 1024;
+        if (pairs[p].ks > maxKs) maxKs = pairs[p].ks;
+    }
+    if (st == AFX_OK) {
+        blob = (unsigned char *)malloc(blobBytes);
+        G = (float *)malloc(sizeof(float) * 32 * (size_t)(16 * maxKs));
+        if (!blob || !G) st = AFX_ERR_NOMEM;
+    }
+    for (int p = 0; p < nPairs && st == AFX_OK; p++) {
+        const int kt = 16 * pairs[p].ks, kh = pairs[p].kh;
+        memset(G, 0, sizeof(float) * 32 * (size_t)kt);
+        for (int c = 0; c < 32; c++) {
+            const TdCand *sc = (c >> 4) == 0 ? &cand[2 * p] : (2 * p + 1 < nc ? &cand[2 * p + 1] : NULL);
+            if (!sc) continue;
+            const int part = (c >> 3) & 1, ph = c & 7;
+            for (int m = 0; m < kt; m++) {
+                const int tt = ph + kh - m; /* y[n0 + 8 i + ph] = sum_m win[8 i + m] g[ph + kh - m] */
+                if (tt < -sc->kh || tt > sc->kh) continue;
+                G[(size_t)m * 32 + c] = (float)(part ? sc->im[tt + sc->kh] : sc->re[tt + sc->kh]);
+            }
+        }
+        afx_cqt_time_kernel_f16(G, kt, (unsigned short *)(blob + pairs[p].img), pairs[p].colMul);
+    }
+    if (st == AFX_OK) st = afxdev_malloc((void **)t.dPairs, sizeof(AfxCwtTdPair) * (size_t)nPairs);
+    if (st == AFX_OK) st = afxdev_h2d(*t.dPairs, pairs, sizeof(AfxCwtTdPair) * (size_t)nPairs, o->stream);
+    if (st == AFX_OK) st = afxdev_malloc((void **)t.dImage, blobBytes);
+    if (st == AFX_OK) st = afxdev_h2d(*t.dImage, blob, blobBytes, o->stream);
+    if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
+    if (st == AFX_OK) {
+        *t.hostKs = (int *)malloc(sizeof(int) * (size_t)nPairs);
+        if (!*t.hostKs) st = AFX_ERR_NOMEM;
+    }
+    if (st == AFX_OK) {
+        for (int p = 0; p < nPairs; p++) (*t.hostKs)[p] = pairs[p].ks;
+        t.plan->pairs = *t.dPairs;
+        t.plan->image = *t.dImage;
+        t.plan->nPairs = nPairs;
+        t.plan->maxKs = maxKs;
+        t.plan->hostKs = *t.hostKs;
+        t.plan->wrap = o->padLength > 0 ? 0 : 1;
+        if (afxk_cwt_td_fits(t.plan, o->dataLength, o->num) != AFX_OK) td_slot_clear(t);
+    } else {
+        td_slot_clear(t);
+    }
+    free(pairs);
+    free(blob);
+    free(G);
+    return st;
+}
+
+static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
+    /* (AFX_NO_FUSED: the size-generic inverse computes EVERY scale -- no second writer of those rows) */
+    if (o->dataLength < 8192 || *nWide < 1 || afxdev_no_fused()) return AFX_OK;
+    TdCand *cand = NULL;
+    int nc = 0;
+    int st = td_candidates(o, rL, order, *nWide, NULL, &cand, &nc);
     if (st == AFX_OK && nc > 0) {
         qsort(cand, (size_t)nc, sizeof(TdCand), td_cand_cmp);
         /* a launch takes AFX_CWT_TD_MAXPAIRS pairs: the candidates beyond that -- the LONGEST kernels, the dearest ones in
@@ -575,74 +687,15 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
                 free(cand[c].im);
             }
             memmove(cand, cand + (nc - cap), sizeof(TdCand) * (size_t)cap);
+            memset(cand + cap, 0, sizeof(TdCand) * (size_t)(nc - cap));
             nc = cap;
         }
-        nPairs = (nc + 1) / 2;
-        pairs = (AfxCwtTdPair *)calloc((size_t)nPairs, sizeof(AfxCwtTdPair));
-        if (!pairs) st = AFX_ERR_NOMEM;
-        size_t blobBytes = 0;
-        int maxKs = 0;
-        for (int p = 0; p < nPairs && st == AFX_OK; p++) {
-            const TdCand *a = &cand[2 * p], *b = 2 * p + 1 < nc ? &cand[2 * p + 1] : NULL;
-            const int kh = (a->kh + 7) & ~7; /* a is the longer one */
-            const int kt = (2 * kh + 8 + 63) & ~63;
-            pairs[p].scale[0] = a->scale;
-            pairs[p].scale[1] = b ? b->scale : -1;
-            pairs[p].kh = kh;
-            pairs[p].ks = kt / 16;
-            pairs[p].img = (long long)blobBytes;
-            blobBytes += (size_t)2 * pairs[p].ks * 1024;
-            if (pairs[p].ks > maxKs) maxKs = pairs[p].ks;
-        }
-        if (st == AFX_OK) {
-            blob = (unsigned char *)malloc(blobBytes);
-            G = (float *)malloc(sizeof(float) * 32 * (size_t)(16 * maxKs));
-            if (!blob || !G) st = AFX_ERR_NOMEM;
-        }
-        for (int p = 0; p < nPairs && st == AFX_OK; p++) {
-            const int kt = 16 * pairs[p].ks, kh = pairs[p].kh;
-            memset(G, 0, sizeof(float) * 32 * (size_t)kt);
-            for (int c = 0; c < 32; c++) {
-                const TdCand *sc = (c >> 4) == 0 ? &cand[2 * p] : (2 * p + 1 < nc ? &cand[2 * p + 1] : NULL);
-                if (!sc) continue;
-                const int part = (c >> 3) & 1, ph = c & 7;
-                for (int m = 0; m < kt; m++) {
-                    const int t = ph + kh - m; /* y[n0 + 8 i + ph] = sum_m win[8 i + m] g[ph + kh - m] */
-                    if (t < -sc->kh || t > sc->kh) continue;
-                    G[(size_t)m * 32 + c] = (float)(part ? sc->im[t + sc->kh] : sc->re[t + sc->kh]);
-                }
-            }
-            afx_cqt_time_kernel_f16(G, kt, (unsigned short *)(blob + pairs[p].img), pairs[p].colMul);
-        }
-        if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTdPairs, sizeof(AfxCwtTdPair) * (size_t)nPairs);
-        if (st == AFX_OK) st = afxdev_h2d(o->dTdPairs, pairs, sizeof(AfxCwtTdPair) * (size_t)nPairs, o->stream);
-        if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTdImage, blobBytes);
-        if (st == AFX_OK) st = afxdev_h2d(o->dTdImage, blob, blobBytes, o->stream);
-        if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
-        if (st == AFX_OK) {
-            o->td.pairs = o->dTdPairs;
-            o->td.image = o->dTdImage;
-            o->td.nPairs = nPairs;
-            o->td.maxKs = maxKs;
-            o->tdKs = (int *)malloc(sizeof(int) * (size_t)nPairs);
-            if (!o->tdKs) st = AFX_ERR_NOMEM;
-            for (int p = 0; p < nPairs && o->tdKs; p++) o->tdKs[p] = pairs[p].ks;
-            o->td.hostKs = o->tdKs;
-            o->td.wrap = pad > 0 ? 0 : 1;
-            if (st == AFX_OK && afxk_cwt_td_fits(&o->td, D, o->num) != AFX_OK) {
-                /* the launch would refuse this plan: every scale stays on the FFT path (nothing is re-ordered) */
-                afxdev_free(o->dTdPairs);
-                afxdev_free(o->dTdImage);
-                o->dTdPairs = NULL;
-                o->dTdImage = NULL;
-                free(o->tdKs);
-                o->tdKs = NULL;
-                memset(&o->td, 0, sizeof(o->td));
-                nc = -nc; /* (skip the re-ordering below; the candidates are still freed) */
-            }
+        const TdSlot slot = {&o->td, &o->dTdPairs, &o->dTdImage, &o->tdKs};
+        st = td_upload(o, cand, nc, slot);
+        if (st == AFX_OK && o->td.nPairs > 0) {
             /* order := [time-domain scales, pair by pair | the other two-pass scales | narrow-band classes] */
-            int *rest = nc > 0 ? (int *)malloc(sizeof(int) * (size_t)*nWide) : NULL;
-            if (!rest && nc > 0) st = AFX_ERR_NOMEM;
+            int *rest = (int *)malloc(sizeof(int) * (size_t)*nWide);
+            if (!rest) st = AFX_ERR_NOMEM;
             int nr = 0;
             for (int w = 0; w < *nWide && rest; w++) {
                 int taken = 0;
@@ -658,14 +711,31 @@ static int cwt_td_plan(CWTObj o, int rL, int *order, int *nWide) {
             free(rest);
         }
     }
-    for (int c = 0; c < (nc < 0 ? -nc : nc); c++) {
-        free(cand[c].re);
-        free(cand[c].im);
+    td_cand_free(cand, nc);
+    return st;
+}
+
+/* cwtObj_enableDet: the same nTd scales with the derivative bank's kernels -- all of them or none (the order list is
+ * shared with the plain transform; a scale whose weighted kernel no longer qualifies keeps every derivative scale on
+ * the two-pass path) */
+static int cwt_td_plan_det(CWTObj o, const float *weights) {
+    if (o->dims.nTd < 1 || !o->dims.td || !o->hOrder) return AFX_OK;
+    {
+        const char *e = getenv("AFX_CWT_TD_DET"); /* "0": the derivative scales keep round 3's two-pass path (A/B, tools/wsst_traffic.py) */
+        if (e && e[0] == '0') return AFX_OK;
     }
-    free(cand);
-    free(pairs);
-    free(blob);
-    free(G);
+    int rL = 0;
+    while ((1LL << rL) < o->fftLength) rL++;
+    TdCand *cand = NULL;
+    int nc = 0;
+    int st = td_candidates(o, rL, o->hOrder, o->dims.nTd, weights, &cand, &nc);
+    if (st == AFX_OK && nc == o->dims.nTd) {
+        qsort(cand, (size_t)nc, sizeof(TdCand), td_cand_cmp);
+        const TdSlot slot = {&o->tdDet, &o->dTdPairsDet, &o->dTdImageDet, &o->tdKsDet};
+        st = td_upload(o, cand, nc, slot);
+        if (st == AFX_OK && o->tdDet.nPairs > 0) o->dims.tdDet = &o->tdDet;
+    }
+    td_cand_free(cand, nc);
     return st;
 }
 
@@ -752,7 +822,12 @@ static int cwt_create(CWTObj *cwtObj, const struct OpaqueCWT *proto, int rL, con
                 if (order && st == AFX_OK && maxR >= 2) {
                     afx_cwt_classify_host(sup, num, maxR, order, &o->dims.nWide, o->dims.nNarrow);
                     if (st == AFX_OK) st = cwt_td_plan(o, rL, order, &o->dims.nWide);
-                    if (o->dims.nTd > 0) o->dims.td = &o->td;
+                    if (o->dims.nTd > 0) {
+                        o->dims.td = &o->td;
+                        o->hOrder = (int *)malloc(sizeof(int) * (size_t)o->dims.nTd);
+                        if (!o->hOrder) st = AFX_ERR_NOMEM;
+                        else memcpy(o->hOrder, order, sizeof(int) * (size_t)o->dims.nTd);
+                    }
                     /* device image: order[num] followed by the (scale, first support row) pairs */
                     int *img = (int *)malloc(sizeof(int) * 3 * (size_t)num);
                     if (!img) st = AFX_ERR_NOMEM;
@@ -871,8 +946,9 @@ static void run(CWTObj o, float *dataArr, const float *dBank, int isDet, float *
         st = afxk_cwt_inverse(&o->dims, o->dTw, o->dXt, dBank, o->num, isDet, 1, o->dB, dRe, dIm,
                               AFX_CWT_WIDE | AFX_CWT_NARROW, o->stream);
         /* the short-kernel scales straight from the signal (dX keeps the last uploaded chunk) */
-        if (st == AFX_OK && !isDet && o->dims.nTd > 0)
-            st = afxk_cwt_td(&o->td, o->dX, 0, 1, o->dataLength, o->num, dRe, dIm, o->stream, NULL);
+        const AfxCwtTdPlan *td = isDet ? o->dims.tdDet : o->dims.td;
+        if (st == AFX_OK && td && o->dims.nTd > 0)
+            st = afxk_cwt_td(td, o->dX, 0, 1, o->dataLength, o->num, dRe, dIm, o->stream, NULL);
     }
     if (st == AFX_OK && re) st = afxdev_d2h(re, dRe, outB, o->stream);
     if (st == AFX_OK && im) st = afxdev_d2h(im, dIm, outB, o->stream);
@@ -944,14 +1020,15 @@ static int cwt_batch_device(CWTObj o, const float *dData, int chunks, long long 
      * the operand-select rule of afx_asm.h: packed-f32 instructions with op_sel[0] = 0 and op_sel[1] = 1 are not exact
      * beside a wave that streams v_mfma + ds_read_b128 -- DESIGN.md section 4.3, profiles/r03_pk_add_opsel.txt; with
      * the rule kept every schedule is bit-reproducible.) */
-    const int useTd = !isDet && o->dims.nTd > 0;
+    const AfxCwtTdPlan *tdPlan = isDet ? o->dims.tdDet : o->dims.td; /* (derivative bank: cwt_td_plan_det) */
+    const int useTd = tdPlan && o->dims.nTd > 0;
     void *tds = NULL;
     if (st == AFX_OK && useTd) {
         if (!o->chain[2]) st = afxdev_stream_create(&o->chain[2]);
         tds = o->chain[2];
         if (st == AFX_OK) st = afxdev_stream_wait_stream(tds, hipStream);
         if (st == AFX_OK)
-            st = afxk_cwt_td(&o->td, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, tds, NULL);
+            st = afxk_cwt_td(tdPlan, dData, chunkStride, chunks, o->dataLength, o->num, dReal, dImag, tds, NULL);
     }
     const int nTwoPass = o->dims.order ? o->dims.nWide + (useTd ? 0 : o->dims.nTd) : o->num; /* scales that write the intermediate */
     /* (no two-pass scale at all: the group only paces the loop below -- one forward batch) */
@@ -1094,6 +1171,7 @@ void cwtObj_enableDet(CWTObj o, int flag) {
     if (st == AFX_OK) st = afxdev_h2d(o->dBankDetT, t, sizeof(float) * (size_t)o->num * L, o->stream);
     if (st == AFX_OK) st = afxdev_stream_sync(o->stream);
     free(t);
+    if (st == AFX_OK) st = cwt_td_plan_det(o, w);
     free(w);
     if (st != AFX_OK) {
         afxdev_free(o->dBankDetT);
@@ -1144,5 +1222,9 @@ void cwtObj_free(CWTObj o) {
     free(o->binBandArr);
     free(o->hBank);
     free(o->tdKs);
+    afxdev_free(o->dTdPairsDet);
+    afxdev_free(o->dTdImageDet);
+    free(o->tdKsDet);
+    free(o->hOrder);
     free(o);
 }

@@ -24,7 +24,7 @@ lib.afx_emulated_launches.argtypes = [C.c_char_p]
 lib.cwtObj_getFreBandArr.restype = C.POINTER(C.c_float)
 
 
-def run(is_padding, r, num, low_fre, clip):
+def run(is_padding, r, num, low_fre, clip, det=False):
     sr = 32000
     D = 1 << r
     h = vp()
@@ -39,8 +39,10 @@ def run(is_padding, r, num, low_fre, clip):
     re = np.zeros((1, num, D), np.float32)
     im = np.zeros_like(re)
     stream = (C.c_char * 8)()
+    if det:
+        lib.cwtObj_enableDet(h, C.c_int(1))  # the derivative bank's own time-domain plan (cwt_td_plan_det)
     before = lib.afx_emulated_launches(b"k_cwt_td")
-    st = lib.cwtObj_cwtBatchDevice(h, xs.ctypes.data_as(vp), 1, C.c_longlong(D), re.ctypes.data_as(vp), im.ctypes.data_as(vp),
+    st = (lib.cwtObj_cwtDetBatchDevice if det else lib.cwtObj_cwtBatchDevice)(h, xs.ctypes.data_as(vp), 1, C.c_longlong(D), re.ctypes.data_as(vp), im.ctypes.data_as(vp),
                                    C.cast(stream, vp))
     assert st == 0, st
     launches = lib.afx_emulated_launches(b"k_cwt_td") - before
@@ -50,8 +52,11 @@ def run(is_padding, r, num, low_fre, clip):
     if ref.available():
         rr = ref.RefCWT(num=num, radix2_exp=r, samplate=sr, low_fre=low_fre, bin_per_octave=12, wavelet_type=1, scale_type=5,
                         is_padding=is_padding)
-        wre, wim = rr.cwt(x)
+        wre, wim = rr.cwt(x, det=det)
         want, who = wre + 1j * wim, "compiled reference"
+    elif det:
+        print("derivative transform: no compiled reference here, skipped", flush=True)
+        return
     else:
         want, who = restate.cwt(x.astype(np.float64), fre, sr, "morlet", 6.0, 2.0, bool(is_padding)), "float64 restatement"
     got = re[0] + 1j * im[0]
@@ -60,13 +65,14 @@ def run(is_padding, r, num, low_fre, clip):
     own = [j for j in range(num) if not np.all(re[0, j] == re[0, j, 0])]
     assert own == list(range(num)), own
     err = max(np.abs(got[j] - want[j]).max() / np.abs(want[j]).max() for j in own)
-    print(f"pad {is_padding} 2^{r} clip {clip}: {len(own)} time-domain rows in {launches} launch(es), worst row {err:.2e} vs {who}", flush=True)
+    print(f"pad {is_padding} 2^{r} clip {clip}{' derivative' if det else ''}: {len(own)} time-domain rows in {launches} launch(es), worst row {err:.2e} vs {who}", flush=True)
     assert err <= 5e-6, err
 
 
 def main():
     run(1, 16, 16, 1661.22, "voice")       # BASELINE cfg 4's chunk geometry (reflect padded, L = 2^17), its 16 highest scales
     run(0, 17, 6, 2793.83, "level_step")   # no padding: circular, L = 2^17 = the chunk itself
+    run(1, 16, 16, 1661.22, "voice", det=True)  # cwtObj_cwtDet's scales on kernels IFFT(j w psi)
     print("OK")
 
 

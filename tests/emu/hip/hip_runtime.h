@@ -125,6 +125,7 @@ static inline int emu_mov_dpp(int v, int ctrl) {
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_memrealtime() 0ull
 #define __builtin_amdgcn_s_memtime() 0ull
+#define __builtin_amdgcn_s_setprio(p) ((void)0)  // wave priorities order the issue port, not the results
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 emu_h8 __attribute__((ext_vector_type(8)));

@@ -204,7 +204,7 @@ int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const float *Xt, 
 #else
     /* the rows of the requested parts only (afx_device.h: [time-domain | two-pass | narrow-band classes]); the
      * time-domain rows of the plain transform belong to afxk_cwt_td */
-    const int skip = (!isDet && d->td) ? d->nTd : 0;
+    const int skip = (isDet ? d->tdDet : d->td) ? d->nTd : 0;
     int lo = num, hi = 0;
     if (parts & AFX_CWT_WIDE) lo = skip, hi = d->nTd + d->nWide;
     if (parts & AFX_CWT_NARROW) { if (lo > d->nTd + d->nWide) lo = d->nTd + d->nWide; hi = num; }

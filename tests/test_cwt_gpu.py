@@ -98,3 +98,35 @@ def test_more_short_kernel_scales_than_the_time_domain_launch_takes():
     assert_parity(got, rre + 1j * rim, TOL, "150 short-kernel scales")
     got2 = o.cwt(x)[::-1]  # (the object stays usable)
     assert np.array_equal(got, got2)
+
+
+def test_derivative_transform_time_domain_scales_against_reference():
+    """BASELINE cfg 4's object with cwtObj_enableDet: the 36 short-kernel scales of the DERIVATIVE transform run in
+    the time domain too (kernels IFFT(j w psi), cwt_algorithm.c:485-528) -- every scale against the compiled reference
+    at 1e-5 of the scale's own peak, from the batched device entry and from the one-chunk host entry."""
+    import torch
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("compiled reference not built")
+    kw = dict(num=84, radix2_exp=16, samplate=44100, low_fre=32.703, bin_per_octave=12)
+    o = af.CWT(wavelet_type=af.WaveletContinueType.MORLET, scale_type=af.SpectralFilterBankScaleType.OCTAVE, is_padding=True, **kw)
+    o.enable_det(True)
+    rng = np.random.default_rng(4242)
+    n = 1 << 16
+    x = (0.1 * rng.standard_normal((2, n))).astype(np.float32)
+    x[1] += np.sin(np.arange(n) * (2 * np.pi * 3520.0 / 44100)).astype(np.float32)  # energy in a short-kernel scale
+    r = ref.RefCWT(wavelet_type=1, scale_type=5, is_padding=1, **kw)
+    re, im = o.cwt_device(torch.from_numpy(x).cuda(), det=True)
+    torch.cuda.synchronize()
+    got = (re.cpu().numpy() + 1j * im.cpu().numpy())
+    worst = 0.0
+    for c in range(2):
+        rre, rim = r.cwt(x[c], det=True)
+        want = rre + 1j * rim  # (the device entry and the reference: C order, row 0 = highest frequency)
+        peak = np.abs(want).max(axis=1, keepdims=True)
+        err = (np.abs(got[c] - want) / peak).max(axis=1)
+        worst = max(worst, float(err.max()))
+        assert err.max() <= 1e-5, (c, np.argmax(err), err.max())
+    from tests.conftest import parity_log
+    parity_log("cwt/derivative transform, per scale (36 time-domain scales)", worst, 1e-5, kind="per-scale peak")
+    assert_parity(o.cwt_det(x[1])[::-1], (lambda a, b: a + 1j * b)(*r.cwt(x[1], det=True)), TOL, "host entry, derivative")

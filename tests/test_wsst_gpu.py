@@ -68,6 +68,21 @@ def test_wsst_full_resolution_against_compiled_reference():
     assert abs(s.sum() - W[ok].sum()) <= 1e-3 * np.abs(W[ok]).sum()
 
 
+def test_wsst_at_the_cwt_headline_geometry_against_compiled_reference():
+    """84 morlet scales, 2^16-sample chunk, reflect padded (L = 2^17, BASELINE cfg 4's CWT object): the plain and the
+    derivative transform both run their 36 short-kernel scales in the time domain (afx_cwt_td.hip); the squeezed
+    tensor against the compiled reference under the index-flip accounting of the smaller cases."""
+    c = dict(num=84, radix2_exp=16, samplate=44100, low_fre=32.703, wavelet_type=1, scale_type=5, is_padding=1)
+    x = cases.mix(411, 1 << 16, 44100)
+    r = ref.RefWSST(84, 16, samplate=44100, low_fre=32.703, wavelet_type=1, scale_type=5, is_padding=1)
+    want, _ = r.wsst(x)
+    o = make(c)
+    s, _ = o.wsst_raw(x)
+    W, v = coordinates(c, x, r.fre_band())
+    n_diff = explained(s, want, W, v, 0.001, "cfg 4 geometry")
+    assert n_diff < 0.002 * want.size
+
+
 def test_accumulate_semantics_and_device_batch():
     import torch
     c = cases.WSST_CASES["morlet_octave48"]

@@ -19,11 +19,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_pass(counter, out_dir, bench_args):
+def run_pass(counter, out_dir, bench_args, script="bench.py", extra_env=None):
     os.makedirs(out_dir, exist_ok=True)
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", **(extra_env or {}))
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", "pmc", "--",
-           sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
+           sys.executable, os.path.join(ROOT, script)] + bench_args
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
     assert dbs, res.stdout[-2000:]
