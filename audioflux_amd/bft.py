@@ -144,8 +144,9 @@ class BFT:
             raise ValueError("call bft first")
         return self._temporal
 
-    def bft_batch(self, data_arr, result_type=1):
-        """Additive: (clips, n) host array -> (clips, time, num) in ONE library call."""
+    def bft_batch(self, data_arr, result_type=1, out=None):
+        """Additive: (clips, n) host array -> (clips, time, num) in ONE library call.  `out` (real results only): a
+        float32 C-contiguous array of that shape to write into -- a caller that loops keeps its pages mapped."""
         x = _util.as_f32(data_arr)
         if x.ndim != 2:
             raise ValueError("bft_batch expects (clips, n)")
@@ -153,7 +154,12 @@ class BFT:
             self.set_result_type(result_type)
         b, n = x.shape
         t = self.cal_time_length(n)
-        re = np.zeros((b, t, self.num), np.float32)
+        if out is not None and result_type == 1:
+            if out.dtype != np.float32 or out.shape != (b, t, self.num) or not out.flags.c_contiguous:
+                raise ValueError(f"out must be a C-contiguous float32 array of shape {(b, t, self.num)}")
+            re = out
+        else:
+            re = np.zeros((b, t, self.num), np.float32)
         im = np.zeros((b, t, self.num), np.float32) if result_type == 0 else None
         fn = self._lib.bftObj_bftBatch
         fn.restype = c_int
