@@ -28,7 +28,7 @@ STUB = os.path.join(ROOT, "tests", "hoststub")
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
 INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
 
-STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cwt_td", "afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
+STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cwt_td_fits", "afxk_cwt_td", "afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
                                                      "afxk_melfused_destroy", "afxk_melfused_kind")]
 
 EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "cwt_emulated_td", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
