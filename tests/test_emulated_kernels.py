@@ -151,10 +151,10 @@ def test_time_domain_cwt_kernel_emulated(emulated):
     """k_cwt_td (round 3, afx_cwt_td.hip): the host plan (double IFFT of the bank rows, truncation, pairing, f16 images),
     the launcher (two kernel classes, exact workgroup shares) and the device code -- window fetch with the reflect / wrap
     index map at the chunk edges, the (hi, lo) split, the K loop, the transposed epilogue -- on BASELINE cfg 4's plan,
-    padded and circular, a speech clip and a -80 dB level step: every row the plan owns within 5e-6 of the reference
-    (on the MI355X: 4e-7 on the bench clip)"""
+    padded and circular, a speech clip and a -80 dB level step, and the derivative transform's plan (cwtObj_enableDet,
+    round 4): every row the plan owns within 5e-6 of the reference (on the MI355X: 4e-7 on the bench clip)"""
     out = _run(emulated, "emulated_cwt_td.py", [])
-    assert out.count("time-domain rows") == 2, out[-800:]
+    assert out.count("time-domain rows") == 3 and "derivative: 16 time-domain rows" in out, out[-800:]
 
 
 def test_bf16x3_gemm_emulated_matches_float64(emulated):
