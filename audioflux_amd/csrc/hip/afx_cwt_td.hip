@@ -241,7 +241,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
         load(0, 0);
         load(1, 1);
         block(std::true_type{});
-        for (int kb = 4; kb < KS; kb += 4) block(std::false_type{});  // KS is a multiple of 4 (host)
+        for (int kb = 4; kb + 4 <= KS; kb += 4) block(std::false_type{});  // KS is even and >= 4 (host)
+        if (KS & 2) {  // taps are rounded to 32: a last half block, its operands were requested by the block before
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                hh0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[s], bh[s], hh0, 0, 0, 0);
+                hh1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[s], bh[s], hh1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[s], bl[s], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[s], bl[s], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[s], bh[s], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[s], bh[s], x1, 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 g -> output n0 + 256 rt + 8 row + phase
@@ -311,6 +323,8 @@ extern "C" int afxk_cwt_td_fits(const AfxCwtTdPlan *p, int dataLength, int num) 
     if (!p || p->nPairs <= 0 || !p->hostKs) return AFX_ERR_UNSUPPORTED;
     if (dataLength < SLAB || (dataLength & (dataLength - 1))) return AFX_ERR_UNSUPPORTED;
     if (p->maxKs < 4 || 16 * p->maxKs > AFX_CWT_TD_MAXK) return AFX_ERR_UNSUPPORTED;
+    for (int q = 0; q < p->nPairs; ++q)
+        if (p->hostKs[q] < 4 || (p->hostKs[q] & 1)) return AFX_ERR_UNSUPPORTED;  // whole blocks of four K steps + at most one half block
     if ((long long)num * dataLength * 4 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;  // 32-bit offsets inside one chunk's planes
     int nLong = 0;  // pairs are sorted longest first; each class is one launch of <= MAXPAIRS pairs
     while (nLong < p->nPairs && 16 * p->hostKs[nLong] > SHORTK) ++nLong;

@@ -220,7 +220,7 @@ typedef struct {
 typedef struct {
     int scale[2];            /* result rows (C order: row 0 = highest frequency); scale[1] < 0: a single scale */
     int kh;                  /* the window of output n0 starts at position n0 - kh (multiple of 8)           */
-    int ks;                  /* K steps of 16 taps (multiple of 4)                                            */
+    int ks;                  /* K steps of 16 taps (even, >= 4)                                               */
     long long img;           /* byte offset of the pair's image in the blob: [word 2][ks][64 lanes][8] f16,
                               * the B-fragment order of v_mfma_f32_32x32x16_f16 (afx_cqt_time_kernel_f16)     */
     float colMul[32];        /* 2^-s_c of the image columns                                                   */

@@ -57,6 +57,7 @@ struct OpaqueCQT {
     size_t capSig[2];
     float *dRing;            /* level rings of the one-launch ladder (k_cqt_pyramid), per workgroup */
     size_t capRing;
+    int noPyramid;           /* AFX_CQT_PYRAMID=0 when the object was created: per-octave launches */
     unsigned short *dDecTab; /* the resampler taps as the f16 table of k_cqt_pyramid (afx_cqt_dec_table) */
     unsigned long long *dTiming; /* AFX_CQT_PYR_TIMING=1: phase cycles of the instrumented kernel (afx_cqt_pyramid_timing) */
     void *lastStream;        /* stream of the previous device call (scratch ordering) */
@@ -260,6 +261,10 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     o->windowType = win;
     o->normType = norm;
     o->isContinue = cont ? 1 : 0;
+    {
+        const char *e = getenv("AFX_CQT_PYRAMID"); /* read per object, at creation (no process-wide latch) */
+        o->noPyramid = e && e[0] == '0';
+    }
 
     /* ---- frequencies, lengths (cqt_filterBank.c:159-246) */
     o->freBandArr = (float *)calloc((size_t)num + 2, sizeof(float));
@@ -523,14 +528,9 @@ void cqtObj_setScale(CQTObj o, int flag) {
 
 /* ---- the default ladder in one launch (afx_cqt_f16.hip: k_cqt_pyramid) ----
  * N = 512, 12 bins per octave, seven octaves, hop 128, one image for all octaves, f16 matrix-core plan, centre
- * padding.  AFX_CQT_PYRAMID=0 (read at the first call of the process) keeps the per-octave launches. */
+ * padding.  AFX_CQT_PYRAMID=0 (read when the object is created) keeps the per-octave launches. */
 static int cqt_pyramid_ok(CQTObj o, int dataLength) {
-    static int env = -1;
-    if (env < 0) {
-        const char *e = getenv("AFX_CQT_PYRAMID");
-        env = !(e && e[0] == '0');
-    }
-    return env && !afxdev_no_fused() && o->dTimeKernelH && o->dColMul && o->dDecTab && o->colTiles == 1 && o->radix2Exp == 9 &&
+    return !o->noPyramid && !afxdev_no_fused() && o->dTimeKernelH && o->dColMul && o->dDecTab && o->colTiles == 1 && o->radix2Exp == 9 &&
            o->binPerOctave == 12 && o->octaveNum == AFX_CQT_PYR_LEVELS && o->slideLength == 128 && !o->isContinue &&
            !o->vFlag && dataLength > 0 && dataLength <= (1 << 28) &&
            afxk_cqt_pyramid_plan(1, dataLength / 128 + 1, NULL, NULL) > 0; /* (0: a device layer without the kernel) */

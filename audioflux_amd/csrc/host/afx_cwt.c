@@ -613,7 +613,8 @@ static int td_upload(CWTObj o, const TdCand *cand, int nc, TdSlot t) {
     for (int p = 0; p < nPairs && st == AFX_OK; p++) {
         const TdCand *a = &cand[2 * p], *b = 2 * p + 1 < nc ? &cand[2 * p + 1] : NULL;
         const int kh = (a->kh + 7) & ~7; /* a is the longer one */
-        const int kt = (2 * kh + 8 + 63) & ~63;
+        int kt = (2 * kh + 8 + 31) & ~31; /* K steps come in pairs, at least four (afx_cwt_td.hip) */
+        if (kt < 64) kt = 64;
         pairs[p].scale[0] = a->scale;
         pairs[p].scale[1] = b ? b->scale : -1;
         pairs[p].kh = kh;
