@@ -84,6 +84,13 @@ def test_batch_equals_per_clip_loop():
     loop = np.stack([o.bft(x, result_type=1).T for x in xs])
     batch = o.bft_batch(xs, result_type=1)
     assert np.array_equal(loop, batch)  # same kernels, same order of operations
+    # a caller that loops keeps its result array (out=): written in place, shape and layout checked
+    keep = np.full_like(batch, np.nan)
+    assert o.bft_batch(xs, result_type=1, out=keep) is keep and np.array_equal(keep, batch)
+    with pytest.raises(ValueError):
+        o.bft_batch(xs, result_type=1, out=np.zeros(batch.shape[::-1], np.float32))
+    with pytest.raises(ValueError):
+        o.bft_batch(xs, result_type=1, out=np.zeros(batch.shape, np.float64))
 
 
 def test_device_resident_api_matches_host_api():
