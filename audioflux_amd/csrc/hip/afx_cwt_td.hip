@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
         }
     };
 
-    const float colMul = pr->colMul[i];
+    const float colMul = pr->colMul[i], colSum = pr->colSum[i];
     // A fragments: row i of row tile rt, half g, K step ks = the 16 bytes at 16 (32 rt + i + g + 2 ks)
     const unsigned char *aHi0 = sig + 16 * (i + g);
     const unsigned char *bHi0 = Bl + 16 * lane;
@@ -176,14 +176,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
     for (int tau = 0; tau < tiles; ++tau) {
         int chunk, n0;
         where(tau, chunk, n0);
-        // ---- tile exponent from the window's own peak
-        float peak = 0.f;
+        // ---- tile exponent from the window's own peak.  A window that sits on a constant (all samples within a quarter
+        //      of the extreme one, m) is split as x - m: the (hi, lo) words carry 22 bits of every SAMPLE, so under an
+        //      offset they would round the offset, not the signal, and a kernel that sums to ~0 cancels the offset but
+        //      not its rounding (measured: rows 2.8e-5 of their peak from float64 on a clip at 0.5 +- 0.05, the reference
+        //      4e-6).  x - m is exact (x / m in [3/4, 5/4]); the constant's own response m sum_k g[k] comes back in the
+        //      epilogue from the kernel's bin 0 (AfxCwtTdPair.colSum).  m is then moved to the middle of
+        //      the samples, which halves what is left to split.
+        float ppos = 0.f, pneg = 0.f;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const float4 w4 = __builtin_bit_cast(float4, wnd[u]);
-            peak = fmaxf(peak, fmaxf(fmaxf(fabsf(w4.x), fabsf(w4.y)), fmaxf(fabsf(w4.z), fabsf(w4.w))));
+            ppos = fmaxf(ppos, fmaxf(fmaxf(w4.x, w4.y), fmaxf(w4.z, w4.w)));
+            pneg = fmaxf(pneg, fmaxf(fmaxf(-w4.x, -w4.y), fmaxf(-w4.z, -w4.w)));
         }
-        const int e = split_exponent(wave_max_bits(peak));
+        const unsigned bpos = wave_max_bits(ppos), bneg = wave_max_bits(pneg);
+        unsigned peakBits = bpos > bneg ? bpos : bneg;
+        float base = 0.f;
+        if ((bpos == 0u || bneg == 0u) && peakBits != 0u && peakBits < 0x7f800000u) {  // one sign throughout (wave-uniform)
+            const float m = bneg == 0u ? __uint_as_float(bpos) : -__uint_as_float(bneg);
+            float dev = 0.f;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const float4 w4 = __builtin_bit_cast(float4, wnd[u]);
+                if (lane + 64 * u < nv4)  // (registers beyond the window hold zeros)
+                    dev = fmaxf(dev, fmaxf(fmaxf(fabsf(w4.x - m), fabsf(w4.y - m)), fmaxf(fabsf(w4.z - m), fabsf(w4.w - m))));
+            }
+            const float range = __uint_as_float(wave_max_bits(dev));  // extreme sample to the opposite extreme
+            if (range <= 0.25f * fabsf(m)) {
+                base = m - copysignf(0.5f * range, m);  // the middle of the samples: every x / base in [3/4, 8/7], x - base exact
+                peakBits = __float_as_uint(0.5f * range + fabsf(m) * 0x1p-22f);  // >= max |x - base| (the middle is rounded)
+            }
+        }
+        const int e = split_exponent(peakBits);
         const float up = __uint_as_float((unsigned)(e + 127) << 23);      // 2^e
         const float down = __uint_as_float((unsigned)(127 - e) << 23);    // 2^-e
         // ---- window -> (xh, xl) planes
@@ -194,8 +219,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
             if (v < nv4) {
                 const float4 w4 = __builtin_bit_cast(float4, wnd[u]);
                 unsigned hi0, hi1, lo0, lo1;
-                split_pair(w4.x, w4.y, up, hi0, lo0);
-                split_pair(w4.z, w4.w, up, hi1, lo1);
+                split_pair(w4.x - base, w4.y - base, up, hi0, lo0);
+                split_pair(w4.z - base, w4.w - base, up, hi1, lo1);
                 *reinterpret_cast<uint2 *>(sig + 8 * v) = make_uint2(hi0, hi1);
                 *reinterpret_cast<uint2 *>(sig + PLANE + 8 * v) = make_uint2(lo0, lo1);
             }
@@ -258,6 +283,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
 
         // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 g -> output n0 + 256 rt + 8 row + phase
         const float mul = down * colMul;
+        const float back = base * colSum;  // the response to the constant that was taken out of the window
         // one raw buffer per plane and chunk ([num][D] floats); a single scale in the pair: its second half is dropped
         const __amdgpu_buffer_rsrc_t rRe = __builtin_amdgcn_make_buffer_rsrc(a.outRe + (long long)chunk * a.num * D, 0, a.num * D * 4, RSRC_RAW);
         const __amdgpu_buffer_rsrc_t rIm = __builtin_amdgcn_make_buffer_rsrc(a.outIm + (long long)chunk * a.num * D, 0, a.num * D * 4, RSRC_RAW);
@@ -269,7 +295,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = rt == 0 ? (hh0[r] + x0[r]) : (hh1[r] + x1[r]);
-                epiW[8 * ((r & 3) + 8 * (r >> 2))] = v * mul;
+                epiW[8 * ((r & 3) + 8 * (r >> 2))] = fmaf(v, mul, back);
             }
             wave_lds_order();
 #pragma unroll

@@ -224,6 +224,7 @@ typedef struct {
     long long img;           /* byte offset of the pair's image in the blob: [word 2][ks][64 lanes][8] f16,
                               * the B-fragment order of v_mfma_f32_32x32x16_f16 (afx_cqt_time_kernel_f16)     */
     float colMul[32];        /* 2^-s_c of the image columns                                                   */
+    float colSum[32];        /* the WHOLE kernel's response to a constant 1 (its spectrum's bin 0), per image column      */
 } AfxCwtTdPair;
 typedef struct AfxCwtTdPlan_ {
     const AfxCwtTdPair *pairs;   /* device [nPairs], longest kernels first */

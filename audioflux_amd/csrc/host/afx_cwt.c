@@ -499,6 +499,7 @@ long long afx_cwt_fft_length(int radix2Exp, int isPadding) {
 typedef struct {
     int scale, kh;
     double *re, *im; /* taps t = -kh .. kh at [t + kh] */
+    double dcRe, dcIm; /* sum of ALL L taps = the spectrum's bin 0: the whole kernel's response to a constant */
 } TdCand;
 
 static int td_cand_cmp(const void *a, const void *b) {
@@ -530,6 +531,7 @@ static int td_candidates(CWTObj o, int rL, const int *list, int n, const float *
             for (long long k = 0; k < L; k++) re[k] = 0.0, im[k] = (float)(row[k] * weights[k]);
         else
             for (long long k = 0; k < L; k++) re[k] = row[k], im[k] = 0.0;
+        const double dcRe = re[0], dcIm = im[0];
         st = afx_fft_f64(rL, re, im, 1); /* g = IFFT(psi): the 1 / L goes into the taps below */
         if (st != AFX_OK) break;
         /* Kh: the last |t| above 1e-6 of the peak, stretched by 8 % (a Gaussian envelope falls from 1e-6 to 1e-7
@@ -558,6 +560,8 @@ static int td_candidates(CWTObj o, int rL, const int *list, int n, const float *
         TdCand *c = &cand[nc];
         c->scale = j;
         c->kh = (int)kh;
+        c->dcRe = dcRe;
+        c->dcIm = dcIm;
         c->re = (double *)malloc(sizeof(double) * (size_t)(2 * kh + 1));
         c->im = (double *)malloc(sizeof(double) * (size_t)(2 * kh + 1));
         nc++; /* (counted before the check: td_cand_free releases a half-allocated entry too) */
@@ -640,6 +644,10 @@ static int td_upload(CWTObj o, const TdCand *cand, int nc, TdSlot t) {
                 if (tt < -sc->kh || tt > sc->kh) continue;
                 G[(size_t)m * 32 + c] = (float)(part ? sc->im[tt + sc->kh] : sc->re[tt + sc->kh]);
             }
+            /* the response to a constant (afx_cwt_td.hip takes one out of a window that sits on an offset): that of the
+             * WHOLE kernel, the spectrum's bin 0 -- the dropped tails add up coherently on a constant (4e-8 of it, 7e-6 of
+             * a quiet row's peak under an offset of 50 x the signal) */
+            pairs[p].colSum[c] = (float)(part ? sc->dcIm : sc->dcRe);
         }
         afx_cqt_time_kernel_f16(G, kt, (unsigned short *)(blob + pairs[p].img), pairs[p].colMul);
     }

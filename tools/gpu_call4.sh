@@ -1,7 +1,7 @@
 #!/bin/bash
 # The evidence call of a round (round 4 on): the whole -m gpu suite on the cleaned tree (new: real audio / hard clips, cfg-2 second
 # corpus, cfg-4 ring), the driver's bench line (with `secondary`), PMC traffic + kernel traces of the SHIPPED
-# kernels for cfg 2 / 4 / 5.   gpurun --timeout 1500 -- 'bash tools/gpu_call2.sh r04a'
+# kernels for cfg 2 / 4 / 5.   gpurun --timeout 1800 -- 'bash tools/gpu_call4.sh r04a'
 set -u
 TAG=${1:-r04a}
 cd "$GRAFT_REPO_ROOT"
@@ -26,6 +26,7 @@ for c in 5 4; do
   timeout -k 10 200 bash tools/prof_cmd.sh ev_${TAG}_cfg$c "" python bench.py --config $c --clips $([ $c = 4 ] && echo 40 || echo 125) --steps 3 --warmup 1 --no-cpu-baseline --no-sustained --no-check --clock-warmup 0 > /dev/null 2>&1
   cp gpurun_out/prof_ev_${TAG}_cfg$c/summary.txt $OUT/rocprofv3_bench_cfg${c}_trace.txt 2>/dev/null
 done
+timeout -k 10 120 python tools/bench_hostabi.py > $OUT/hostabi.txt 2>&1
 cat $OUT/status.txt
 python - <<PY
 import json
