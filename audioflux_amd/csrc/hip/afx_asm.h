@@ -88,25 +88,6 @@ __device__ __forceinline__ v2 mul_mi(v2 a) {
 }
 
 
-// ---- one filter tap on two signals at once: a_q += (t, t) * d_q for four accumulator pairs, t = the LOW (pk_tap4_lo) or
-// HIGH (pk_tap4_hi) half of the tap pair `hp` (src0 broadcast by op_sel / op_sel_hi; src1 plain: within the RULE above).
-// One volatile statement per tap: four independent v_pk_fma_f32 back to back, the statements in program order -- the
-// compiler's scheduler would otherwise re-serialise the chains, and a dependent fma waits for its predecessor.
-__device__ __forceinline__ void pk_tap4_lo(v2 &a0, v2 &a1, v2 &a2, v2 &a3, v2 hp, v2 d0, v2 d1, v2 d2, v2 d3) {
-    asm volatile("v_pk_fma_f32 %0, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-                 "v_pk_fma_f32 %1, %4, %6, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-                 "v_pk_fma_f32 %2, %4, %7, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-                 "v_pk_fma_f32 %3, %4, %8, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(hp), "v"(d0), "v"(d1), "v"(d2), "v"(d3));
-}
-__device__ __forceinline__ void pk_tap4_hi(v2 &a0, v2 &a1, v2 &a2, v2 &a3, v2 hp, v2 d0, v2 d1, v2 d2, v2 d3) {
-    asm volatile("v_pk_fma_f32 %0, %4, %5, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 %1, %4, %6, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 %2, %4, %7, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 %3, %4, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(hp), "v"(d0), "v"(d1), "v"(d2), "v"(d3));
-}
-
 // ---- float32 -> (hi, lo) binary16 words --------------------------------------------------
 // (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
 // fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).

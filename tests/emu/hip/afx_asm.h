@@ -66,20 +66,6 @@ __device__ __forceinline__ v2 mul_mi(v2 a) {
 }
 
 
-// one filter tap on two signals at once: a_q += (t, t) * d_q, t = the low / high half of the tap pair
-__device__ __forceinline__ void pk_tap4_lo(v2 &a0, v2 &a1, v2 &a2, v2 &a3, v2 hp, v2 d0, v2 d1, v2 d2, v2 d3) {
-    a0 = v2{__builtin_fmaf(hp.x, d0.x, a0.x), __builtin_fmaf(hp.x, d0.y, a0.y)};
-    a1 = v2{__builtin_fmaf(hp.x, d1.x, a1.x), __builtin_fmaf(hp.x, d1.y, a1.y)};
-    a2 = v2{__builtin_fmaf(hp.x, d2.x, a2.x), __builtin_fmaf(hp.x, d2.y, a2.y)};
-    a3 = v2{__builtin_fmaf(hp.x, d3.x, a3.x), __builtin_fmaf(hp.x, d3.y, a3.y)};
-}
-__device__ __forceinline__ void pk_tap4_hi(v2 &a0, v2 &a1, v2 &a2, v2 &a3, v2 hp, v2 d0, v2 d1, v2 d2, v2 d3) {
-    a0 = v2{__builtin_fmaf(hp.y, d0.x, a0.x), __builtin_fmaf(hp.y, d0.y, a0.y)};
-    a1 = v2{__builtin_fmaf(hp.y, d1.x, a1.x), __builtin_fmaf(hp.y, d1.y, a1.y)};
-    a2 = v2{__builtin_fmaf(hp.y, d2.x, a2.x), __builtin_fmaf(hp.y, d2.y, a2.y)};
-    a3 = v2{__builtin_fmaf(hp.y, d3.x, a3.x), __builtin_fmaf(hp.y, d3.y, a3.y)};
-}
-
 // (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
 // fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).
 // One asm statement: VALU->VALU dependences are interlocked, and hipcc's own form of this costs 7 instructions.
