@@ -583,6 +583,10 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
     // The two waves of a SIMD share its matrix pipe: one of them converts first and multiplies behind it, the other (EARLY:
     // levels 4-6) multiplies first -- on planes it prepared at the end of the step before -- and converts behind that.
     constexpr bool EARLY = PART == 0 && K >= 4;
+    // ... and a convert-first level wave (levels 1-3) keeps a tile's accumulators over the barrier and stores its rows at the
+    // START of the next step, while its partner is already multiplying: at the end of a step both waves of a SIMD used to sit
+    // in their epilogues with the matrix pipe idle (phase clocks: 72 % busy on the busiest SIMD).  Same values, one step later.
+    constexpr bool LATE = PART == 0 && K >= 1 && K < 4;
     constexpr unsigned RMASK = K == 0 ? 0xffffffffu : (unsigned)pyr::ring_size(K) - 1u;
     constexpr bool DEC = K < AFX_CQT_PYR_LEVELS - 1;  // the last level feeds nobody
     constexpr int KN = K + 1 < AFX_CQT_PYR_LEVELS ? K + 1 : K;
@@ -661,7 +665,23 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
     };
     const int s0 = t0c - pyr::LEAD, s1 = t1c + pyr::DRAIN;
     PyrClock<TIMING> clk;
+    // the two waves of a SIMD want its matrix pipe at the same time for most of a step, and the arbiter serves the OLDER wave
+    // first: the multiply-first wave -- the one with the longer chain behind its products (rows, then the next tile's planes)
+    // -- got what the other left (phase clocks: 65 cycles per MFMA against 35).  It goes first instead.
+    __builtin_amdgcn_s_setprio(EARLY ? 2 : 0);
     float downNext = 0.f;  // (EARLY waves: 2^-e of the planes prepared at the end of the step before)
+    f32x16 hh, hl, lh;
+    bool pend = false;     // (LATE waves: the tile of the step before still has to leave)
+    float pendDown = 0.f;
+    int pendT = 0;
+    auto rows_out = [&](float dn, int tt, int bf) {
+        CqLane L = L0;
+        L.epiW += bf * ALT;
+        L.epiR += bf * ALT;
+        u32x3 pieces[4];
+        cq_store_tile<true, pyr::AUX_STREAM>(hh, hl, lh, dn, L, outRe, outIm, tt * 32, pieces);
+        if (chromaOn) pyr_chroma_add<K>(ch, pieces, tt, lane, a.chromaMag, a.chromaNorm);
+    };
     for (int s = s0; s <= s1; ++s) {
         const int t = s - LAG;
         const bool oct = has_oct(t), dec = has_dec(t), empty = is_empty(t), live = is_live(t), next = is_live(t + 1);  // wave-uniform
@@ -670,6 +690,11 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         const unsigned char *aHi = aHi0 + buf * ALT;
         const int p0 = t * 32 * H - (C::N >> 1);
         float down = downNext;
+        if (LATE && pend) {  // the rows of the tile before: through the planes (still that tile's), before they are converted anew
+            rows_out(pendDown, pendT, 0);
+            pend = false;
+            clk.lap(7);
+        }
         if (EARLY && next) fetch(t + 1);  // (the same blocks a convert-first wave asks for in this step: all written by step s - 1)
         if (PREP && !EARLY && live) {
             if (TIMING) {  // time the wait for the window apart from the conversion
@@ -701,7 +726,6 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
             }
         }
         clk.lap(5);
-        f32x16 hh, hl, lh;
         if (chromaOn && oct) pyr_chroma_request<K>(ch, t, lane);
         if (WORK && oct) {
             if (p0 + C::S > valid) cq_zero_samples<H>(sig, valid - p0 > 0 ? valid - p0 : 0, (len < p0 + C::S ? len : p0 + C::S) - p0, lane);
@@ -718,12 +742,13 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         if (WORK && DEC) VM_WAIT_ALL();
         clk.lap(4);
         if (WORK && oct) {
-            CqLane L = L0;
-            L.epiW += buf * ALT;
-            L.epiR += buf * ALT;
-            u32x3 pieces[4];
-            cq_store_tile<true, pyr::AUX_STREAM>(hh, hl, lh, down, L, outRe, outIm, t * 32, pieces);
-            if (chromaOn) pyr_chroma_add<K>(ch, pieces, t, lane, a.chromaMag, a.chromaNorm);
+            if (LATE) {
+                pend = true;
+                pendDown = down;
+                pendT = t;
+            } else {
+                rows_out(down, t, buf);
+            }
         }
         clk.lap(7);
         if (EARLY && next) {  // the next tile's planes now: the matrix-core work of the next step starts at its barrier
@@ -733,6 +758,7 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         pyr_barrier();
         clk.lap(6);
     }
+    if (LATE && pend) rows_out(pendDown, pendT, 0);  // (not reached: a run ends with DRAIN steps without rows)
     clk.flush(tim, lane);
 }
 
