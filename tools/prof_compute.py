@@ -40,7 +40,9 @@ def main():
            "valu_busy": 4.0 * per["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc),
            "lds_busy": per.get("SQ_LDS_IDX_ACTIVE", 0.0) / (CUS * cyc),
            "lds_bank_conflict_share": per.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(per.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0),
-           "issue_busy": 4.0 * per.get("SQ_ACTIVE_INST_ANY", 0.0) / (SIMDS * cyc),
+           # (the counter and the cycle count come from different passes, i.e. different runs of the kernel: a saturated port
+           # can read a percent over 1 -- capped)
+           "issue_busy": min(1.0, 4.0 * per.get("SQ_ACTIVE_INST_ANY", 0.0) / (SIMDS * cyc)),
            "mfma_busy": (per["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc)) if "SQ_VALU_MFMA_BUSY_CYCLES" in per else None,
            "counters_per_dispatch": per}
     if avg_us:
