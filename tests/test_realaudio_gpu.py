@@ -207,3 +207,12 @@ def test_cepstrogram_wave_kernel(name):
             parity_log(f"{name} cepstrogram {nm} vs {tag}", d, bar, f"max(TOL, {kk:g} x reference-vs-float64)",
                        {"reference_vs_float64": float(ref_d)})
             assert d <= bar, f"{name} {nm} vs {tag}: {d:.3e} > {bar:.3e}"
+        # -- ... and in statistics that one element cannot decide: the RMS distance from float64 and its 99.9th percentile
+        #    are within 2 x the reference's own (the maximum above is the extreme of a heavy-tailed error over ~10^6 elements)
+        eg, er = np.abs(got - f64[k]).ravel(), np.abs(want[k] - f64[k]).ravel()
+        for stat, fn in (("rms", lambda e: float(np.sqrt(np.mean(e * e)))), ("p99.9", lambda e: float(np.quantile(e, 0.999)))):
+            mine, theirs = fn(eg) / peak, fn(er) / peak
+            bar = max(TOL, 2.0 * theirs)
+            parity_log(f"{name} cepstrogram {nm} {stat} distance from float64", mine, bar, "max(TOL, 2 x the reference's)",
+                       {"reference": theirs})
+            assert mine <= bar, f"{name} {nm} {stat} vs float64: {mine:.3e} > {bar:.3e} (reference {theirs:.3e})"
