@@ -495,8 +495,9 @@ def pmc_compute(config):
             out = {k: rec.get(k) for k in ("valu_busy", "lds_busy", "issue_busy", "mfma_busy", "lds_bank_conflict_share",
                                            "shader_clock_mhz", "valu_insts_per_unit_and_wave", "lds_insts_per_unit_and_wave")}
             busiest = max((v, k) for k, v in out.items() if k.endswith("_busy") and v is not None)
-            out["bound"] = {"issue_busy": "instruction issue (SIMD issue ports)", "valu_busy": "vector unit", "lds_busy": "LDS",
-                            "mfma_busy": "matrix pipe"}[busiest[1]]
+            out["bound"] = rec.get("bound") or {"issue_busy": "instruction issue (SIMD issue ports)", "valu_busy": "vector unit",
+                                                "lds_busy": "LDS", "mfma_busy": "matrix pipe"}[busiest[1]]
+            out["kernel"] = rec.get("kernel")
             out["source"] = os.path.relpath(path, ROOT)
             return out
         except (OSError, KeyError, ValueError):

@@ -23,7 +23,7 @@ def main():
     for line in open(path, errors="replace"):
         if kern not in line:
             continue
-        m = re.search(r"\s(\S+)\s+dispatches=(\d+) sum=(\S+) per_dispatch=(\S+)", line)
+        m = re.search(r"\s(\S+)\s+dispatches=\s*(\d+) sum=(\S+) per_dispatch=(\S+)", line)
         if m:
             per[m.group(1)] = float(m.group(4))
             continue
@@ -36,7 +36,15 @@ def main():
                 pass
     assert "GRBM_GUI_ACTIVE" in per and "SQ_ACTIVE_INST_VALU" in per, sorted(per)
     cyc = per["GRBM_GUI_ACTIVE"] / XCDS  # shader cycles of one dispatch
-    out = {"config": config, "kernel": kern, "source": path, "shader_cycles_per_dispatch": cyc,
+    cycles_from = "GRBM_GUI_ACTIVE / 8 XCDs"
+    if "SQ_BUSY_CYCLES" in per:
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines; the two agree within a few percent for short kernels, but the
+        # GRBM_GUI_ACTIVE-only pass of a long persistent launch has read several times the launch's duration -- the SQ figure
+        # (same pass as the busy counters) is taken when they disagree
+        sq = per["SQ_BUSY_CYCLES"] / 32.0
+        if abs(cyc - sq) > 0.25 * sq:
+            cyc, cycles_from = sq, "SQ_BUSY_CYCLES / 32 shader engines (GRBM_GUI_ACTIVE / 8 read %.3g)" % (per["GRBM_GUI_ACTIVE"] / XCDS)
+    out = {"config": config, "kernel": kern, "source": path, "shader_cycles_per_dispatch": cyc, "shader_cycles_from": cycles_from,
            "valu_busy": 4.0 * per["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc),
            "lds_busy": per.get("SQ_LDS_IDX_ACTIVE", 0.0) / (CUS * cyc),
            "lds_bank_conflict_share": per.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(per.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0),
