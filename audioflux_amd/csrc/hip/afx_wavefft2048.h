@@ -51,6 +51,10 @@ __device__ __forceinline__ void split(v2 A, v2 B, v2 w /* 0.5 W_2048^k */, v2 &x
 // free on entry; on return every lane has its values in registers and `ex` is free again.
 __device__ __forceinline__ void rfft2048(v2 (&v)[16], v2 *ex, const Tables &t, int lane, Bins &o) {
     const int k1 = lane >> 2, m2 = lane & 3;
+    // the transform (dense packed arithmetic between short LDS exchanges) runs above the latency-bound phases of the
+    // SIMD's other waves -- window, logarithm / lifters, stores: cepstrogram n_fft 4096 0.497 -> 0.403 ms, n_fft 2048
+    // 0.412 -> 0.390 ms, STFT 0.313 -> 0.303 ms per call, same bits (profiles/r04_ab_headline.txt (5))
+    __builtin_amdgcn_s_setprio(1);
     dft16(v);
     ex[lane] = v[0];
 #pragma unroll
@@ -95,6 +99,7 @@ __device__ __forceinline__ void rfft2048(v2 (&v)[16], v2 *ex, const Tables &t, i
         split(zc1, zc2, t.tw3[384], o.xc[1], o.yc[1]);  // bins 384, 640
     }
     wave_lds_order();  // every lane has its bins in registers: ex may be overwritten
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- N = 4096 ---------------------------------------------------------------------------------
