@@ -12,6 +12,7 @@ import sys
 LEVELS, LEAD, DRAIN = 7, 9, 22
 LAG = [1, 4, 7, 10, 13, 17, 23]
 RING = [0, 8192, 4096, 2048, 1024, 1024, 1024]
+ROWS_LATE = [0, 1, 1, 1, 0, 0, 0]  # levels 1-3 keep a tile's accumulators over the barrier: rows (and chroma sums) one step later
 
 
 def hop(k):
@@ -71,6 +72,16 @@ def check(t0, t1, length_tiles=None):
     # every octave tile of the run was worked on inside the step range
     for k in range(LEVELS):
         assert t0 + LAG[k] >= t0 - LEAD and t1 - 1 + LAG[k] <= t1 + DRAIN
+    # chroma partial sums travel through the output rows: level k REQUESTS tile t's partials in step t + LAG[k] (before its K
+    # loop) and ADDS its own in the step its rows leave -- the same step, or one later for the convert-first waves of levels
+    # 1-3 (ROWS_LATE: they store a tile's rows at the start of the next step).  A request must find the add of the level
+    # before it drained by a vmcnt(0) + barrier: issued at least two steps earlier; a deferred add must still fall inside the run's steps.
+    for t in range(t0, t1):
+        for k in range(1, LEVELS):
+            add_before = t + LAG[k - 1] + ROWS_LATE[k - 1]
+            assert add_before <= t + LAG[k] - 2, f"tile {t}: level {k} requests the partials in step {t + LAG[k]}, level {k - 1} adds in {add_before}"
+        for k in range(LEVELS):
+            assert t + LAG[k] + ROWS_LATE[k] <= t1 + DRAIN, f"tile {t}: the rows of level {k} leave after the run's last step"
     return reads
 
 
