@@ -4,6 +4,7 @@
 // and divide the counter by 1024 SIMDs x (SQ_BUSY_CYCLES / 32).   hipcc --offload-arch=gfx950 -O3 mfma_busy_cal.hip -o mfma_busy_cal
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 template <int WAVES>
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_only(float *out, int iters)
         for (int r = 0; r < 16; ++r) s += acc[n][r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-int main() {
+int main(int argc, char **argv) {
+    const int wgs = argc > 1 ? atoi(argv[1]) : 256;  // workgroups = CUs kept busy
     float *out;
     hipMalloc(&out, 256 * 512 * 4);
     hipEvent_t e0, e1;
@@ -32,15 +34,15 @@ int main() {
     hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_mfma_only<4>, dim3(256), dim3(256), 0, 0, out, 20000);  // one wave per SIMD
+        hipLaunchKernelGGL(k_mfma_only<4>, dim3(wgs), dim3(256), 0, 0, out, 20000);  // one wave per SIMD
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        const double mf = 256.0 * 4 * 20000 * 32;
-        printf("one wave per SIMD : %.3f ms, %.1f cycles per MFMA at 2.4 GHz, %.0f TF/s\n", ms, ms * 1e-3 * 2.4e9 / (20000.0 * 32), mf * 32768 / (ms * 1e-3) / 1e12);
+        const double mf = (double)wgs * 4 * 20000 * 32;
+        printf("%d workgroups, one wave per SIMD : %.3f ms = %.2f GHz at 32 cycles per MFMA, %.0f TF/s\n", wgs, ms, 20000.0 * 32 * 32 / (ms * 1e-3) / 1e9, mf * 32768 / (ms * 1e-3) / 1e12);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_mfma_only<8>, dim3(256), dim3(512), 0, 0, out, 10000);  // two waves per SIMD
+        hipLaunchKernelGGL(k_mfma_only<8>, dim3(wgs), dim3(512), 0, 0, out, 10000);  // two waves per SIMD
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
