@@ -154,7 +154,9 @@ class BFT:
             self.set_result_type(result_type)
         b, n = x.shape
         t = self.cal_time_length(n)
-        if out is not None and result_type == 1:
+        if out is not None and result_type != 1:
+            raise ValueError("out= is for real results (result_type=1); complex results are returned as a new complex64 array")
+        if out is not None:
             if out.dtype != np.float32 or out.shape != (b, t, self.num) or not out.flags.c_contiguous:
                 raise ValueError(f"out must be a C-contiguous float32 array of shape {(b, t, self.num)}")
             re = out

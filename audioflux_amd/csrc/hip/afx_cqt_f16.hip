@@ -682,6 +682,11 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         cq_store_tile<true, pyr::AUX_STREAM>(hh, hl, lh, dn, L, outRe, outIm, tt * 32, pieces);
         if (chromaOn) pyr_chroma_add<K>(ch, pieces, tt, lane, a.chromaMag, a.chromaNorm);
     };
+    // a convert-first wave finds the window of step s in registers requested during step s - 1; the run's first step has
+    // no step before it.  Only level 0's preparer is live there (LAG 0, need_back(0) == LEAD: tile t0c - 9 of a run that
+    // starts mid-clip is resampled); its window comes from the clip itself, never from a ring not written yet.
+    static_assert(K == 0 || pyr::need_back(K) < pyr::LEAD + LAG, "a level wave must not be live at the first step of a run");
+    if (PREP && !EARLY && is_live(s0 - LAG)) fetch(s0 - LAG);
     for (int s = s0; s <= s1; ++s) {
         const int t = s - LAG;
         const bool oct = has_oct(t), dec = has_dec(t), empty = is_empty(t), live = is_live(t), next = is_live(t + 1);  // wave-uniform
@@ -856,7 +861,7 @@ extern "C" int afxk_cqt_octave_f16(const AfxCqtOctaveArgs *a, void *stream) {
 }
 
 // ---- the pyramid launch ----
-extern "C" int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerClip, int *tilesPerChunk) {
+extern "C" int afxk_cqt_pyramid_plan(int batch, int timeLength, int maxTiles, int *chunksPerClip, int *tilesPerChunk) {
     if (batch <= 0 || timeLength <= 0) return 0;
     const int nT = (timeLength + 31) / 32;
     // runs of one clip: as many as fill the CUs, but long enough that the 30 steps of lead-in and drain stay small
@@ -864,8 +869,7 @@ extern "C" int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerCl
     if (cpc > nT / 48) cpc = nT / 48;
     if (cpc < 1) cpc = 1;
     int tpc = (nT + cpc - 1) / cpc;
-    if (const char *e = getenv("AFX_CQT_PYR_TILES"))  // tests: short runs, so that small inputs cross run boundaries
-        if (atoi(e) > 0 && atoi(e) < tpc) tpc = atoi(e);
+    if (maxTiles > 0 && maxTiles < tpc) tpc = maxTiles;  // (tests: short runs, so that small inputs cross run boundaries)
     cpc = (nT + tpc - 1) / tpc;  // no empty runs
     if (chunksPerClip) *chunksPerClip = cpc;
     if (tilesPerChunk) *tilesPerChunk = tpc;
@@ -881,12 +885,16 @@ extern "C" int afxk_cqt_pyramid(const AfxCqtPyramidArgs *a, void *stream) {
     const long long items = (long long)a->batch * a->chunksPerClip;
     if (items > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)(items < AFX_CQT_PYR_MAX_WGS ? items : AFX_CQT_PYR_MAX_WGS);
-    if (a->timing) {  // the instrumented instantiation (tools/pyr_phases.py)
+#ifdef AFX_EXPERIMENTS
+    if (a->timing) {  // the instrumented instantiation (tools/pyr_phases.py; measurement builds only: make EXTRA=-DAFX_EXPERIMENTS)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_pyramid<true>), hipFuncAttributeMaxDynamicSharedMemorySize, pyr::LDS_BYTES));
         hipLaunchKernelGGL(k_cqt_pyramid<true>, dim3(grid), dim3(64 * pyr::WAVES), pyr::LDS_BYTES, (hipStream_t)stream, *a, (int)items);
         AFX_LAUNCH_CHECK("k_cqt_pyramid<timing>");
         return AFX_OK;
     }
+#else
+    if (a->timing) return AFX_ERR_UNSUPPORTED;
+#endif
     AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cqt_pyramid<false>), hipFuncAttributeMaxDynamicSharedMemorySize, pyr::LDS_BYTES));
     hipLaunchKernelGGL(k_cqt_pyramid<false>, dim3(grid), dim3(64 * pyr::WAVES), pyr::LDS_BYTES, (hipStream_t)stream, *a, (int)items);
     AFX_LAUNCH_CHECK("k_cqt_pyramid");

@@ -356,7 +356,7 @@ typedef struct {
                               * (the instrumented instantiation; tools/pyr_phases.py)      */
 } AfxCqtPyramidArgs;
 /* workgroups the launch will use (the caller sizes `ring` with it) */
-int afxk_cqt_pyramid_plan(int batch, int timeLength, int *chunksPerClip, int *tilesPerChunk);
+int afxk_cqt_pyramid_plan(int batch, int timeLength, int maxTiles, int *chunksPerClip, int *tilesPerChunk);
 int afxk_cqt_pyramid(const AfxCqtPyramidArgs *a, void *stream);
 /* batch clips: x + b*xStride -> y + b*yStride */
 int afxk_cqt_decimate(const float *x, int srcLen, long long xStride, float *y, int dstLen,

@@ -58,6 +58,8 @@ struct OpaqueCQT {
     float *dRing;            /* level rings of the one-launch ladder (k_cqt_pyramid), per workgroup */
     size_t capRing;
     int noPyramid;           /* AFX_CQT_PYRAMID=0 when the object was created: per-octave launches */
+    int pyrTiles;            /* AFX_CQT_PYR_TILES when the object was created (tests): tiles per workgroup run, 0 = planner's */
+    int pyrTiming;           /* -DAFX_EXPERIMENTS builds, AFX_CQT_PYR_TIMING set when the object was created */
     unsigned short *dDecTab; /* the resampler taps as the f16 table of k_cqt_pyramid (afx_cqt_dec_table) */
     unsigned long long *dTiming; /* AFX_CQT_PYR_TIMING=1: phase cycles of the instrumented kernel (afx_cqt_pyramid_timing) */
     void *lastStream;        /* stream of the previous device call (scratch ordering) */
@@ -264,6 +266,11 @@ int cqtObj_newWith(CQTObj *cqtObj, int num, int *samplate, float *minFre, int *b
     {
         const char *e = getenv("AFX_CQT_PYRAMID"); /* read per object, at creation (no process-wide latch) */
         o->noPyramid = e && e[0] == '0';
+        e = getenv("AFX_CQT_PYR_TILES"); /* tests: at most this many tiles per workgroup run (read here, like the switch above) */
+        o->pyrTiles = e ? atoi(e) : 0;
+#ifdef AFX_EXPERIMENTS
+        o->pyrTiming = getenv("AFX_CQT_PYR_TIMING") != NULL; /* measurement builds: the instrumented instantiation */
+#endif
     }
 
     /* ---- frequencies, lengths (cqt_filterBank.c:159-246) */
@@ -533,7 +540,7 @@ static int cqt_pyramid_ok(CQTObj o, int dataLength) {
     return !o->noPyramid && !afxdev_no_fused() && o->dTimeKernelH && o->dColMul && o->dDecTab && o->colTiles == 1 && o->radix2Exp == 9 &&
            o->binPerOctave == 12 && o->octaveNum == AFX_CQT_PYR_LEVELS && o->slideLength == 128 && !o->isContinue &&
            !o->vFlag && dataLength > 0 && dataLength <= (1 << 28) &&
-           afxk_cqt_pyramid_plan(1, dataLength / 128 + 1, NULL, NULL) > 0; /* (0: a device layer without the kernel) */
+           afxk_cqt_pyramid_plan(1, dataLength / 128 + 1, 0, NULL, NULL) > 0; /* (0: a device layer without the kernel) */
 }
 
 /* dX + b*xStride (b < batch) -> dRe/dIm [batch][T, num] (+ dChroma [batch][T, 12] when cn == 12); asynchronous on `stream` */
@@ -542,7 +549,7 @@ static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength,
     AfxCqtPyramidArgs a;
     memset(&a, 0, sizeof(a));
     const int T = dataLength / o->slideLength + 1;
-    const int wgs = afxk_cqt_pyramid_plan(batch, T, &a.chunksPerClip, &a.tilesPerChunk);
+    const int wgs = afxk_cqt_pyramid_plan(batch, T, o->pyrTiles, &a.chunksPerClip, &a.tilesPerChunk);
     int st = afxdev_reserve((void **)&o->dRing, &o->capRing, sizeof(float) * (size_t)wgs * AFX_CQT_PYR_RING_FLOATS);
     if (st != AFX_OK) return st;
     a.x = dX;
@@ -568,7 +575,7 @@ static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength,
     a.ring = o->dRing;
     a.decTab = o->dDecTab;
     a.decMul = (float)(ldexp(1.0, -15) / (double)sqrtf(0.5f));
-    if (getenv("AFX_CQT_PYR_TIMING")) { /* measurement builds only: the instrumented instantiation */
+    if (o->pyrTiming) { /* -DAFX_EXPERIMENTS builds only: the instrumented instantiation */
         const size_t bytes = sizeof(unsigned long long) * AFX_CQT_PYR_MAX_WGS * 11 * 8;
         if (!o->dTiming) {
             st = afxdev_malloc((void **)&o->dTiming, bytes);

@@ -21,7 +21,7 @@ DCT-II); it is timed live with HIP events on the stream it is launched on (torch
 handed to the library).  `achieved` = SURVEY 8d's algorithmic bytes per unit x units per launch /
 that duration; `sustained_ms` repeats the step back to back for >= 1 s (sustained clocks, where the
 K-step region of a short run sees boost clocks); `traffic` = HBM bytes per launch from the round's
-own rocprofv3 --pmc passes of this command (profiles/r04_bench_cfg<N>_pmc.json, written by
+own rocprofv3 --pmc passes of this command (profiles/r05_bench_cfg<N>_pmc.json, written by
 tools/prof_traffic.py), null when that file is absent.  After the timed region clip 0 of the
 benchmarked outputs is checked against the oracle (1e-5 peak / L2).
 `secondary` (--config 2 at one GPU, the driver's line): cfg 4 and cfg 5 measured in the same process after the
@@ -183,6 +183,9 @@ class Cfg2:
     kernel = ("k_stft_mel_v2 (framed FFT -> |S|^2 -> banded mel bank -> log10 -> DCT-II, "
               "one launch per step)")
     gather_choices = ("mfcc", "mel")
+    # what binds the kernel (roofline.compute): the vector unit + LDS of every SIMD, not the memory system
+    bound = "issue/VALU"
+    bound_note = "vector unit 68 % + LDS 62 % busy on every SIMD; frac prices the kernel against HBM, which is not what limits it"
 
     def __init__(self, torch, af, dev, rank, clips):
         self.torch, self.af, self.clips = torch, af, clips
@@ -230,6 +233,8 @@ class Cfg4:
               "k_cwt_fwd_*, k_cwt_inv_cols256_nb<R> (44 narrow-band scales) + k_cwt_inv_cols256_nb2<4> (4 scales of 17-20 rows)")
     dtype = "f32 (36 of 84 scales: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ()
+    bound = "issue/VALU+LDS capacity"
+    bound_note = "the step is the sum of its launches: the LDS-resident f16 matrix kernel and the VALU/LDS-bound inverse transforms"
     GROUP = 32  # chunks per device call: the [84, 2^16] complex outputs (44 MB per chunk) are ring-buffered
 
     def __init__(self, torch, af, dev, rank, clips):
@@ -287,6 +292,8 @@ class Cfg5:
               "partial sums through the output rows)")
     dtype = "f32 (octave products: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ("chroma", "cqt")
+    bound = "matrix+power"
+    bound_note = "f16 matrix pipe about half busy at a power-limited clock (profiles/r04_mfma_busy_calibration.txt)"
 
     def __init__(self, torch, af, dev, rank, clips):
         self.torch, self.af, self.clips = torch, af, clips
@@ -374,7 +381,7 @@ def pmc_traffic(config, clips):
     """HBM bytes per step from the round's rocprofv3 --pmc passes of this command
     (tools/prof_traffic.py): 2 x FETCH_SIZE (gfx950 tallies wide coalesced reads at half,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB, scaled to this run's clip count"""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_bench_cfg{config}_pmc.json")
         try:
             rec = json.load(open(path))
@@ -484,19 +491,33 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
     return res
 
 
-def pmc_compute(config):
-    """the compute side of the roofline from the round's PMC passes (tools/prof.sh + tools/prof_compute.py): how busy the
-    vector unit, the LDS, the SIMDs' issue ports and the matrix pipe were under the dominant kernel -- what bounds a
-    kernel that is nowhere near the HBM roofline; replayed from profiles/, like `traffic`"""
-    for rnd in ("r04",):
+PEAK_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: peak engine clock
+VALU_PEAK_WAVE_INSTS = 1024 * PEAK_CLOCK_HZ / 4.0   # 256 CUs x 4 SIMDs, one 64-lane f32 instruction per 4 cycles
+MFMA_F16_PEAK_FLOPS = 2.5e15   # dense f16 / bf16 matrix peak
+
+
+def pmc_compute(config, units=None, kern_ms=None):
+    """the compute side of the roofline from the round's PMC passes (tools/gpu_call5.sh + tools/prof_compute.py): how busy
+    the vector unit, the LDS, the SIMDs' issue ports and the matrix pipe were under the dominant kernel -- what bounds a
+    kernel that is nowhere near the HBM roofline; replayed from profiles/, like `traffic`.  `frac_of_peak` relates THIS
+    run's rate to the unit that binds: cfg 2 vector instructions per second / (1024 SIMDs x 2.4 GHz / 4); cfg 5 matrix
+    flop/s (tiles x 807 MFMAs x 32768 flop) / the 2.5 PF dense f16 peak."""
+    for rnd in ("r05", "r04"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_bench_cfg{config}_compute.json")
         try:
             rec = json.load(open(path))
             out = {k: rec.get(k) for k in ("valu_busy", "lds_busy", "issue_busy", "mfma_busy", "lds_bank_conflict_share",
                                            "shader_clock_mhz", "valu_insts_per_unit_and_wave", "lds_insts_per_unit_and_wave")}
-            busiest = max((v, k) for k, v in out.items() if k.endswith("_busy") and v is not None)
-            out["bound"] = rec.get("bound") or {"issue_busy": "instruction issue (SIMD issue ports)", "valu_busy": "vector unit",
-                                                "lds_busy": "LDS", "mfma_busy": "matrix pipe"}[busiest[1]]
+            busiest = max((v, k) for k, v in out.items() if k.endswith("_busy") and k != "issue_busy" and v is not None)
+            out["busiest_unit"] = {"valu_busy": "vector unit", "lds_busy": "LDS", "mfma_busy": "matrix pipe"}[busiest[1]]
+            if units and kern_ms:
+                if config == 5:  # 32-frame tiles x 807 v_mfma_f32_32x32x16_f16 of 32768 flop each
+                    flops = (units / 32.0) * 807 * 32768 / (kern_ms * 1e-3)
+                    out["mfma_flops"], out["frac_of_peak"], out["peak_of"] = flops, flops / MFMA_F16_PEAK_FLOPS, "2.5 PF dense f16 MFMA"
+                elif out.get("valu_insts_per_unit_and_wave"):
+                    rate = units * out["valu_insts_per_unit_and_wave"] / (kern_ms * 1e-3)
+                    out["valu_wave_insts_per_s"], out["frac_of_peak"] = rate, rate / VALU_PEAK_WAVE_INSTS
+                    out["peak_of"] = "vector issue: 1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction"
             out["kernel"] = rec.get("kernel")
             out["source"] = os.path.relpath(path, ROOT)
             return out
@@ -510,7 +531,7 @@ def roofline(W, w, clips, m):
     achieved = w.units * W.bytes_per_unit / (kern_ms * 1e-3) / 1e9 if kern_ms else None
     traffic, traffic_src = pmc_traffic(W.config, clips) if hasattr(W, "config") else (None, None)
     alg = w.units * W.bytes_per_unit
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": getattr(W, "bound", "hbm"), "bound_note": getattr(W, "bound_note", None), "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_over_algorithmic": (traffic / alg) if traffic else None,
@@ -518,7 +539,23 @@ def roofline(W, w, clips, m):
             "algorithmic_bytes_per_unit": W.bytes_per_unit, "units_per_launch": w.units,
             "sustained_ms": sus, "sustained_value": (w.units / (sus * 1e-3)) if sus else None,
             "sustained_frac": (alg / (sus * 1e-3) / 1e9 / HBM_PEAK_GBS) if sus else None,
-            "compute": pmc_compute(W.config) if hasattr(W, "config") else None}
+            "compute": pmc_compute(W.config, w.units, kern_ms) if hasattr(W, "config") else None}
+
+
+def self_launch(n):
+    """re-exec this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (one
+    process per GPU); the ranks inherit stdout / stderr, so the launcher adds nothing to the JSON line"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -544,6 +581,12 @@ def main():
                     "steps: the device ramps its clocks over tens of ms after idling, and W steps of ~1.5 ms end "
                     "long before that (0 disables; reported as config.clock_warmup_s)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher environment, so this process becomes the launcher -- the same
+        # command under torch.distributed.run, one rank per GPU on a free port of 127.0.0.1; rank 0 prints the one
+        # JSON line on the inherited stdout, the exit status is the job's
+        sys.exit(self_launch(a.gpus))
 
     import torch
     import torch.distributed as dist
@@ -610,7 +653,8 @@ def main():
         elif world > 1:
             par += ", replicas only (no gather)"
         out = {
-            "metric": W.metric, "value": value, "unit": W.unit, "n_gpus": world, "steps": a.steps,
+            "metric": W.metric, "value": value, "unit": W.unit, "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "strong" if a.total_clips > 0 else "weak", "vs_baseline": None,
             "dtype": getattr(w, "dtype", "f32"), "data": "synthetic",
@@ -671,7 +715,8 @@ def main():
             import subprocess
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "legacy_bench.py")], capture_output=True, text=True,
-                                   timeout=240, env=dict(os.environ, AFX_HIP_RUNTIME="system"))
+                                   timeout=90,  # (1000 calls of ~0.3 ms + one interpreter start; never a reason to lose the line)
+                                   env=dict(os.environ, AFX_HIP_RUNTIME="system"))
                 out["legacy"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:
                 out["legacy"] = {"error": repr(e)}

@@ -127,3 +127,37 @@ def test_bench_replicas_only_world2_gloo():
     assert "gather" not in d or d["gather"] is None or not d["gather"].get("slabs")
     assert "RCCL gather" not in d["config"]["parallelism"]
     assert "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("config", [2, 4, 5])
+def test_bench_launches_its_own_ranks(config):
+    """plain `python bench.py --gpus 2` (no launcher environment -- how a driver that runs `python bench.py --gpus 1`
+    would ask for more GPUs): the command re-executes itself under torch.distributed.run, one rank per GPU, and
+    rank 0 still prints the ONE JSON line; `rccl_ranks` is the size of the process group that ran."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["AFX_BENCH_DRYRUN"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", str(config)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    if config == 4:
+        assert not (d.get("gather") or {}).get("slabs")
+    else:
+        assert d["gather"]["slabs"] and d["gather"]["gather_ms"] is not None
+
+
+def test_bench_launcher_passes_failures_on():
+    """a rank that dies must fail the plain command too (the driver reads the exit status)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AFX_BENCH_DRYRUN"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--gather", "nonsense"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert res.returncode != 0
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]

@@ -25,6 +25,14 @@ def main():
         print(json.dumps({"error": "wrapper archive or library missing"}))
         return
     work = tempfile.mkdtemp(prefix="afx_legacy_")
+    try:
+        run(work, runtimes, time_step)
+    finally:
+        import shutil
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def run(work, runtimes, time_step):
     flows.stage(work)
     af = flows.import_wrapper(work)
     from audioflux import fftlib

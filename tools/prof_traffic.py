@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM traffic per bench.py step from rocprofv3 PMC passes (run on the GPU box):
 
-    python tools/prof_traffic.py <config> [--clips N]   -> gpurun_out/r04_bench_cfg<config>_pmc.json
+    python tools/prof_traffic.py <config> [--clips N]   -> gpurun_out/<round>_bench_cfg<config>_pmc.json (AFX_ROUND, default r05)
 
 FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (they do not fit one pass on gfx950, and
 counters are never combined with trace domains other than kernel-trace); the library's kernels
@@ -51,7 +51,7 @@ def main():
     a = ap.parse_args()
     warm = 1
     args = ["--config", str(a.config), "--steps", str(a.steps), "--warmup", str(warm), "--no-cpu-baseline",
-            "--no-sustained", "--no-check", "--no-secondary", "--no-legacy", "--clock-warmup", "0"]
+            "--no-sustained", "--no-check", "--no-secondary", "--no-legacy", "--clock-warmup", "0"]  # (traffic does not depend on the clock state)
     if a.clips:
         args += ["--clips", str(a.clips)]
     tmp = os.path.join(ROOT, "gpurun_out", f"prof_traffic_cfg{a.config}")
@@ -71,7 +71,7 @@ def main():
         "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py " + " ".join(args),
         "note": "KiB as reported by rocprofv3; FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 (x2 in bench.py)",
     }
-    out = os.path.join(ROOT, "gpurun_out", f"r04_bench_cfg{a.config}_pmc.json")
+    out = os.path.join(ROOT, "gpurun_out", f"{os.environ.get('AFX_ROUND', 'r05')}_bench_cfg{a.config}_pmc.json")
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
