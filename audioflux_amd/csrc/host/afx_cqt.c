@@ -601,7 +601,7 @@ static int cqt_run_pyramid(CQTObj o, const float *dX, int batch, int dataLength,
 
 /* test hook: the level rings of the first `wgs` workgroups as the last k_cqt_pyramid launch left them
  * (AFX_CQT_PYR_RING_FLOATS floats each: levels 1 ... 6 at offsets 0, 8192, 12288, 14336, 15360, 16384; sample p of a
- * level at p mod the ring's size) -- tests/test_cqt_pyramid.py checks the resampler against the filter in float64 */
+ * level at p mod the ring's size) -- tests/test_cqt_pyramid.py (device) and tests/emu/emulated_cqt_rings.py (emulated) check them against the resampler in float64 */
 int afx_cqt_pyramid_rings(CQTObj o, float *host, int wgs) {
     if (!o || !o->dRing || !host || wgs <= 0) return 0;
     const size_t bytes = sizeof(float) * (size_t)wgs * AFX_CQT_PYR_RING_FLOATS;

@@ -163,7 +163,7 @@ def test_one_launch_ladder_against_the_per_octave_launches(tmp_path):
     ANY frame's own peak across a -60 dB level step, 1e-5 on the normalised chroma --, and the ladder repeats bit for
     bit.  Shapes: many short clips (one run each), few long ones (runs of ~160 tiles that start and end mid-clip), an odd
     clip stride, a clip that ends mid-tile, a clip shorter than one window.  Two child processes: the switch is read
-    once per process."""
+    when an object is created, and no other test should see it."""
     import subprocess
     import sys
     for v in ("1", "0"):
@@ -178,3 +178,27 @@ def test_one_launch_ladder_against_the_per_octave_launches(tmp_path):
         frame = (np.abs(qa - qb).max(axis=2) / np.maximum(np.abs(qb).max(axis=2), 1e-30)).max()
         chd = np.abs(a[f"ch{si}"] - b[f"ch{si}"]).max()
         assert peak <= 2e-6 and frame <= 1e-5 and chd <= 1e-5, (shape, peak, frame, chd)
+
+
+@pytest.mark.parametrize("batch,n,stride", [(3, 61000, 61005), (2, 128 * 32 * 5 - 1, 128 * 32 * 5 + 3), (2, 700, 700)])
+def test_one_launch_ladder_against_the_compiled_reference(batch, n, stride, have_ref):
+    """the call the bench times -- cqt_chroma_device: k_cqt_pyramid with chroma-12 in its epilogue -- against the COMPILED
+    REFERENCE (cqtObj_cqt + cqtObj_chroma, src/cqt_algorithm.c:463-597) on three of the ladder shapes: an odd clip stride,
+    a clip that ends one sample before a tile boundary, a clip barely longer than one window (lower octaves: shorter than
+    theirs); every clip carries a -60 dB level step.  Plain 1e-5 on the CQT tensor and on the normalised chroma."""
+    import torch
+    from oracle import ref
+    if not have_ref:
+        pytest.skip("oracle/_ref not built")
+    o = af.CQT(num=84, samplate=44100, low_fre=32.703, bin_per_octave=12, normal_type=af.SpectralFilterBankNormalType.AREA)
+    g = torch.Generator(device="cuda").manual_seed(batch + n)
+    x = 0.1 * torch.randn((batch, stride), generator=g, device="cuda")
+    x[:, n // 2:] *= 1e-3
+    re, im, ch = o.cqt_chroma_device(x[:, :n])
+    torch.cuda.synchronize()
+    xh = x[:, :n].cpu().numpy()
+    for b in range(batch):
+        r = ref.RefCQT(num=84, samplate=44100, min_fre=32.703, bin_per_octave=12, normal_type=1)  # (a fresh object per clip)
+        rre, rim = r.cqt(np.ascontiguousarray(xh[b]))
+        assert_parity(re[b].cpu().numpy() + 1j * im[b].cpu().numpy(), rre + 1j * rim, TOL, f"ladder vs reference: cqt n={n} clip {b}")
+        assert_parity(ch[b].cpu().numpy(), r.chroma(rre, rim), TOL, f"ladder vs reference: fused chroma n={n} clip {b}")

@@ -108,6 +108,15 @@ def test_shipped_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
         assert n["pyramid"] == 4 and n["chroma"] == 1 and n["octave_f16"] + n["decimate"] + n["chroma_scan"] + n["octave_f32"] == 0, n
 
 
+def test_pyramid_level_rings_emulated_against_the_float64_resampler(emulated):
+    """the ladder's level signals themselves (never visible in an output): the rings of the first workgroup after a run
+    that ends mid-clip (runs of three tiles) against restate.decimate2 in float64 -- 1e-6 of the level's peak; where six stages add up to more (levels
+    3-6: 1.1e-6 ... 1.9e-6), not farther from float64 than the reference's own float32 resampler chain (1.2e-6 ... 2.2e-6).  The matrix-core resampler replaces src/dsp/resample_algorithm.c:430-521; tests/test_cqt_pyramid.py runs the
+    same check on the device."""
+    out = _run(emulated, "emulated_cqt_rings.py", [], "AFX_CQT_PYR_TILES=3")
+    assert out.count("of the level's peak") == 6, out
+
+
 def test_per_octave_cqt_kernels_emulated_meet_the_golden_vectors(emulated):
     """AFX_CQT_PYRAMID=0: the per-octave launches -- k_cqt_decimate, k_cqt_octave_f16 (all seven hop instantiations, the
     12-byte transposed stores), k_cqt_chroma (12 and 6 classes, max and min normalisation); what every plan outside the

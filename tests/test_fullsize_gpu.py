@@ -189,6 +189,27 @@ def test_cfg5_cqt_chroma_gpu_share_duplicates_and_sampled_reference():
         assert_parity(ch[i].cpu().numpy(), rr.chroma(rre, rim), what="cfg5 chroma clip 61")
 
 
+def test_cfg5_fused_call_sampled_reference():
+    """BASELINE cfg 5 through the ONE call bench.py times (cqt_chroma_device: the one-launch ladder with chroma-12 in its
+    epilogue), one GPU's share of 125 clips: clips 0, 61 and 124 -- the first, a middle one and the last run of the last
+    workgroup -- against the compiled reference, CQT and chroma, plain 1e-5."""
+    import torch
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    clips, n, num = 125, 1323000, 84
+    o = af.CQT(num=num, samplate=44100, low_fre=32.703, bin_per_octave=12,
+               normal_type=af.SpectralFilterBankNormalType.AREA)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = 0.1 * torch.randn((clips, n), device="cuda", generator=g)
+    re, im, ch = o.cqt_chroma_device(x)
+    torch.cuda.synchronize()
+    for i in (0, 61, 124):
+        rr = ref.RefCQT(num=num, samplate=44100, min_fre=32.703, bin_per_octave=12, normal_type=1)
+        rre, rim = rr.cqt(x[i].cpu().numpy())
+        assert_parity(re[i].cpu().numpy() + 1j * im[i].cpu().numpy(), rre + 1j * rim, what=f"cfg5 fused call: cqt clip {i}")
+        assert_parity(ch[i].cpu().numpy(), rr.chroma(rre, rim), what=f"cfg5 fused call: chroma clip {i}")
+
+
 def test_cfg2_spectrogram_object_equals_bft_and_stft_round_trip():
     """the sibling objects at the cfg-2 scale: (a) the mel spectrogram object runs the BFT execution
     plan, so on the full 1000-clip corpus its result equals bftObj's bit for bit; (b) STFT ->
