@@ -293,7 +293,9 @@ class Cfg5:
     dtype = "f32 (octave products: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ("chroma", "cqt")
     bound = "matrix+power"
-    bound_note = "f16 matrix pipe about half busy at a power-limited clock (profiles/r04_mfma_busy_calibration.txt)"
+    bound_note = ("f16 matrix pipe 44 % busy at 1.77 GHz -- the clock a loop of nothing but MFMAs holds on this part (1.78 GHz, "
+                  "profiles/r04_mfma_busy_calibration.txt): the power budget sets the clock, the per-wave chains (planes -> "
+                  "MFMA -> rows) the idle share (profiles/r05_bench_cfg5_compute.json, 557 warm dispatches)")
 
     def __init__(self, torch, af, dev, rank, clips):
         self.torch, self.af, self.clips = torch, af, clips

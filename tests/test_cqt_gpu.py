@@ -185,7 +185,9 @@ def test_one_launch_ladder_against_the_compiled_reference(batch, n, stride, have
     """the call the bench times -- cqt_chroma_device: k_cqt_pyramid with chroma-12 in its epilogue -- against the COMPILED
     REFERENCE (cqtObj_cqt + cqtObj_chroma, src/cqt_algorithm.c:463-597) on three of the ladder shapes: an odd clip stride,
     a clip that ends one sample before a tile boundary, a clip barely longer than one window (lower octaves: shorter than
-    theirs); every clip carries a -60 dB level step.  Plain 1e-5 on the CQT tensor and on the normalised chroma."""
+    theirs); every clip carries a -60 dB level step.  Plain 1e-5 on the CQT tensor and on the normalised chroma of the loud frames; the
+    quiet frames behind the step (each divided by its own maximum) at plain 1e-5 too, or -- where the reference's own rounding
+    exceeds that -- not farther from the float64 restatement than the reference is."""
     import torch
     from oracle import ref
     if not have_ref:
@@ -201,4 +203,21 @@ def test_one_launch_ladder_against_the_compiled_reference(batch, n, stride, have
         r = ref.RefCQT(num=84, samplate=44100, min_fre=32.703, bin_per_octave=12, normal_type=1)  # (a fresh object per clip)
         rre, rim = r.cqt(np.ascontiguousarray(xh[b]))
         assert_parity(re[b].cpu().numpy() + 1j * im[b].cpu().numpy(), rre + 1j * rim, TOL, f"ladder vs reference: cqt n={n} clip {b}")
-        assert_parity(ch[b].cpu().numpy(), r.chroma(rre, rim), TOL, f"ladder vs reference: fused chroma n={n} clip {b}")
+        got, rch = ch[b].cpu().numpy(), r.chroma(rre, rim)
+        loud = n // 2 // 128  # frames centred in the loud half: their own maximum is the tensor's scale
+        assert_parity(got[:loud], rch[:loud], TOL, f"ladder vs reference: fused chroma n={n} clip {b}, loud frames")
+        if np.abs(got - rch).max() <= TOL:
+            assert_parity(got, rch, TOL, f"ladder vs reference: fused chroma n={n} clip {b}")
+        else:
+            # every frame is divided by its own maximum: behind the level step a frame's chroma carries the float32 rounding of
+            # windows that still hold the loud half, amplified up to 1e6 -- the REFERENCE's own distance from the exact result
+            # exceeds 1e-5 there (2.6e-5 ... 3.1e-5 on such clips).  Those frames are decided against the float64 restatement of
+            # the same formulae (oracle/restate.py, pinned to the reference by tests/test_oracle.py): not farther from it than
+            # the reference is
+            from oracle import restate
+            from tests.conftest import parity_log
+            c64 = restate.cqt_chroma(restate.cqt(xh[b], num=84, samplate=44100, min_fre=float(np.float32(32.703)), normal="area"))
+            ours, theirs = float(np.abs(got - c64).max()), float(np.abs(rch - c64).max())
+            parity_log(f"ladder vs float64: fused chroma n={n} clip {b}, frames behind the -60 dB step", ours, max(TOL, theirs),
+                       "max(1e-5, the reference's own distance from float64)")
+            assert ours <= max(TOL, theirs), (ours, theirs)
