@@ -48,7 +48,9 @@ extern "C" void afxdev_set_error(const char *fmt, ...) {
     if (!quiet()) fprintf(stderr, "[audioflux_mi355x] %s\n", g_err);
 }
 
+static void stage_drop_pending(void);  // a failed call never reaches its sync: its staged downloads must not be delivered later
 extern "C" void afxdev_report_failure(const char *who, int st) {
+    stage_drop_pending();
     ++t_err_count;
     if (!quiet()) fprintf(stderr, "[audioflux_mi355x] %s failed (%d): %s\n", who, st, g_err);
 }
@@ -196,12 +198,114 @@ extern "C" int afxdev_memset(void *dptr, int value, size_t bytes, void *stream) 
     return AFX_OK;
 }
 
+// ---- small host-pointer copies through pinned staging --------------------------------------------------------
+// The legacy entry points (one clip per call: bftObj_bft, spectrogramObj_spectrogram, cqtObj_cqt, ...) hand over
+// pageable host arrays, usually ones the runtime has never seen: hipMemcpyAsync then has the operating system pin
+// the pages first (227 us per 1.9 MB against 44 us on the wire, profiles/r04_hostabi.txt).  Copies of at most
+// AFX_STAGE_MAX bytes therefore go through a pinned slab that belongs to the stream: up = host memcpy in growing
+// pieces, each piece's DMA running under the memcpy of the next; down = DMA into the slab, the memcpy to the
+// caller's array deferred to afxdev_stream_sync (the ONLY synchronisation point of the host code -- every
+// afxdev_d2h is followed by one before its function returns).  Slab space is handed out by a bump pointer that the
+// same sync resets; what does not fit takes the plain copy.  Larger transfers (the batch entry points) are
+// unchanged: for them the runtime's own pin cache measured as good as a hand-made ring.
+namespace {
+constexpr size_t AFX_STAGE_MAX = 4u << 20;  // slab bytes per direction and stream
+constexpr int AFX_STAGE_PEND = 24;
+struct Stage {
+    void *stream = nullptr;
+    int dev = -1;
+    unsigned char *up = nullptr, *down = nullptr;
+    size_t upUsed = 0, downUsed = 0;
+    struct {
+        void *dst;
+        const unsigned char *src;
+        size_t bytes;
+    } pend[AFX_STAGE_PEND];
+    int nPend = 0;
+};
+constexpr int AFX_STAGE_SLOTS = 64;
+std::mutex g_stageMu;
+Stage g_stage[AFX_STAGE_SLOTS];  // (a stream's slabs go back to this table's free entries when the stream is destroyed)
+bool stage_off() {
+    static const bool off = getenv("AFX_NO_STAGING") != nullptr;
+    return off;
+}
+// the stage of `stream` (created on first use); nullptr: table full or no pinned memory -> plain copies
+thread_local Stage *t_lastStage = nullptr;  // the stage this thread used last
+Stage *stage_of(void *stream, bool create) {
+    Stage *&last = t_lastStage;
+    if (last && last->stream == stream) return last;
+    std::lock_guard<std::mutex> g(g_stageMu);
+    Stage *freeSlot = nullptr;
+    for (Stage &s : g_stage) {
+        if (s.stream == stream && stream) return last = &s;
+        if (!s.stream && !freeSlot) freeSlot = &s;
+    }
+    if (!create || !freeSlot || !stream) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (freeSlot->up && freeSlot->dev != dev) {  // slabs of another device's context: start over
+        (void)hipHostFree(freeSlot->up);
+        (void)hipHostFree(freeSlot->down);
+        freeSlot->up = freeSlot->down = nullptr;
+    }
+    if (!freeSlot->up) {
+        void *u = nullptr, *d = nullptr;
+        if (hipHostMalloc(&u, AFX_STAGE_MAX, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&d, AFX_STAGE_MAX, hipHostMallocDefault) != hipSuccess) {
+            (void)hipHostFree(u);
+            return nullptr;
+        }
+        freeSlot->up = static_cast<unsigned char *>(u);
+        freeSlot->down = static_cast<unsigned char *>(d);
+        freeSlot->dev = dev;
+    }
+    freeSlot->stream = stream;
+    freeSlot->upUsed = freeSlot->downUsed = 0;
+    freeSlot->nPend = 0;
+    return last = freeSlot;
+}
+}  // namespace
+
+static void stage_drop_pending(void) {
+    if (t_lastStage) t_lastStage->nPend = 0;
+}
+
 extern "C" int afxdev_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return AFX_OK;
+    Stage *s = (bytes <= AFX_STAGE_MAX && !stage_off()) ? stage_of(stream, true) : nullptr;
+    if (s && s->upUsed + bytes <= AFX_STAGE_MAX) {
+        unsigned char *slab = s->up + s->upUsed;
+        s->upUsed += (bytes + 255) & ~(size_t)255;
+        // pieces of 128 K, 256 K, 512 K, then 1 M: the first DMA starts early, later ones amortise their submission
+        size_t off = 0, piece = 128u << 10;
+        while (off < bytes) {
+            const size_t n = bytes - off < piece + (piece >> 1) ? bytes - off : piece;
+            memcpy(slab + off, static_cast<const unsigned char *>(src) + off, n);
+            AFX_HIP(hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, slab + off, n, hipMemcpyHostToDevice,
+                                   (hipStream_t)stream));
+            off += n;
+            if (piece < (1u << 20)) piece <<= 1;
+        }
+        return AFX_OK;
+    }
     AFX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return AFX_OK;
 }
 
 extern "C" int afxdev_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return AFX_OK;
+    Stage *s = (bytes <= AFX_STAGE_MAX && !stage_off()) ? stage_of(stream, true) : nullptr;
+    if (s && s->nPend < AFX_STAGE_PEND && s->downUsed + bytes <= AFX_STAGE_MAX) {
+        unsigned char *slab = s->down + s->downUsed;
+        s->downUsed += (bytes + 255) & ~(size_t)255;
+        AFX_HIP(hipMemcpyAsync(slab, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        s->pend[s->nPend].dst = dst;
+        s->pend[s->nPend].src = slab;
+        s->pend[s->nPend].bytes = bytes;
+        ++s->nPend;
+        return AFX_OK;
+    }
     AFX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return AFX_OK;
 }
@@ -264,10 +368,25 @@ extern "C" int afxdev_stream_wait_stream(void *waiter, void *signaler) {
 }
 
 extern "C" void afxdev_stream_destroy(void *stream) {
-    if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+    if (!stream) return;
+    (void)hipStreamDestroy((hipStream_t)stream);
+    std::lock_guard<std::mutex> g(g_stageMu);
+    for (Stage &s : g_stage)
+        if (s.stream == stream) {  // the slabs stay with the table entry for the next stream
+            s.stream = nullptr;
+            s.nPend = 0;
+        }
 }
 
 extern "C" int afxdev_stream_sync(void *stream) {
-    AFX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (Stage *s = stage_off() ? nullptr : stage_of(stream, false)) {
+        // staged downloads reach the caller's arrays here; the slabs are free again
+        if (e == hipSuccess)
+            for (int i = 0; i < s->nPend; ++i) memcpy(s->pend[i].dst, s->pend[i].src, s->pend[i].bytes);
+        s->nPend = 0;
+        s->upUsed = s->downUsed = 0;
+    }
+    AFX_HIP(e);
     return AFX_OK;
 }

@@ -366,6 +366,9 @@ hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t attr, int) {
 hipError_t hipMalloc(void **p, size_t bytes) { *p = dry_alloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t) { return hipMalloc(p, bytes); }
 hipError_t hipFree(void *) { return hipSuccess; }
+// pinned host memory (the staging slabs of afx_runtime.hip): plain zeroed host memory, kept until process end
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = calloc(bytes ? bytes : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipFreeAsync(void *, hipStream_t) { return hipSuccess; }
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
     std::lock_guard<std::mutex> lk(g_mu);
