@@ -212,7 +212,7 @@ namespace {
 constexpr size_t AFX_STAGE_MAX = 4u << 20;  // slab bytes per direction and stream
 constexpr int AFX_STAGE_PEND = 24;
 struct Stage {
-    void *stream = nullptr;
+    std::atomic<void *> stream{nullptr};  // (read outside the table's mutex by the per-thread shortcut)
     int dev = -1;
     unsigned char *up = nullptr, *down = nullptr;
     size_t upUsed = 0, downUsed = 0;
@@ -234,12 +234,12 @@ bool stage_off() {
 thread_local Stage *t_lastStage = nullptr;  // the stage this thread used last
 Stage *stage_of(void *stream, bool create) {
     Stage *&last = t_lastStage;
-    if (last && last->stream == stream) return last;
+    if (last && last->stream.load(std::memory_order_relaxed) == stream) return last;
     std::lock_guard<std::mutex> g(g_stageMu);
     Stage *freeSlot = nullptr;
     for (Stage &s : g_stage) {
-        if (s.stream == stream && stream) return last = &s;
-        if (!s.stream && !freeSlot) freeSlot = &s;
+        if (s.stream.load(std::memory_order_relaxed) == stream && stream) return last = &s;
+        if (!s.stream.load(std::memory_order_relaxed) && !freeSlot) freeSlot = &s;
     }
     if (!create || !freeSlot || !stream) return nullptr;
     int dev = -1;
@@ -260,9 +260,9 @@ Stage *stage_of(void *stream, bool create) {
         freeSlot->down = static_cast<unsigned char *>(d);
         freeSlot->dev = dev;
     }
-    freeSlot->stream = stream;
     freeSlot->upUsed = freeSlot->downUsed = 0;
     freeSlot->nPend = 0;
+    freeSlot->stream.store(stream, std::memory_order_relaxed);
     return last = freeSlot;
 }
 }  // namespace
@@ -372,9 +372,9 @@ extern "C" void afxdev_stream_destroy(void *stream) {
     (void)hipStreamDestroy((hipStream_t)stream);
     std::lock_guard<std::mutex> g(g_stageMu);
     for (Stage &s : g_stage)
-        if (s.stream == stream) {  // the slabs stay with the table entry for the next stream
-            s.stream = nullptr;
+        if (s.stream.load(std::memory_order_relaxed) == stream) {  // the slabs stay with the table entry for the next stream
             s.nPend = 0;
+            s.stream.store(nullptr, std::memory_order_relaxed);
         }
 }
 
