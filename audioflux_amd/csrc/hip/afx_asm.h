@@ -57,6 +57,14 @@ __device__ __forceinline__ v2 cmul(v2 a, v2 b) {
         : "=&v"(t), "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// a * conj(b) = (ax bx + ay by, ay bx - ax by)
+__device__ __forceinline__ v2 cmul_conj(v2 a, v2 b) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                  // (ax bx, ax by)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]"              // (ay by + ., ay bx - .)
+        : "=&v"(t), "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // complex multiply-accumulate c + a * b: two packed fmas
 __device__ __forceinline__ v2 cfma(v2 a, v2 b, v2 c) {
     v2 t, r;

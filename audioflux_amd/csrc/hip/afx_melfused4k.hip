@@ -378,6 +378,7 @@ struct Plan {
     int variant;  // >= 200: this file
     int num;
     int split;    // slots hold row segments (AfxBandPlan.split)
+    void *v2;     // the real-result kernel's plan (afx_melfused4k2.hip)
     float4 *dWin4;
     float2 *dTw1, *dTw2, *dTw3, *dTw4;
     float *dWLane;
@@ -438,15 +439,13 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     return AFX_OK;
 }
 
+// complex results (specMap 3 / 4); real results run k_stft_band_4k2 (afx_melfused4k2.hip)
 template <int TA, int TB, bool SPLIT = false>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
-    if (a->specMap >= 3) {
-        if (!a->outIm) return AFX_ERR_ARG;
-        return a->hop == 1024 ? launch_variant<TA, TB, 4, true, SPLIT>(p, a, stream)
-                              : launch_variant<TA, TB, 0, true, SPLIT>(p, a, stream);
-    }
-    return a->hop == 1024 ? launch_variant<TA, TB, 4, false, SPLIT>(p, a, stream)
-                          : launch_variant<TA, TB, 0, false, SPLIT>(p, a, stream);
+    if (a->specMap < 3) return AFX_ERR_ARG;
+    if (!a->outIm) return AFX_ERR_ARG;
+    return a->hop == 1024 ? launch_variant<TA, TB, 4, true, SPLIT>(p, a, stream)
+                          : launch_variant<TA, TB, 0, true, SPLIT>(p, a, stream);
 }
 
 template <typename T>
@@ -457,6 +456,11 @@ int upload(T **dptr, const void *src, size_t bytes, void *stream) {
 }
 
 }  // namespace
+
+// afx_melfused4k2.hip
+extern "C" int afxk_mel4k2_create(void **plan, int variant, const float *hWindow, const AfxBandPlan *band, void *stream);
+extern "C" int afxk_mel4k2_run(void *plan, const AfxMelFusedArgs *a, void *stream);
+extern "C" void afxk_mel4k2_destroy(void *plan);
 
 extern "C" int afxk_mel4k_variant(int tapsA, int tapsB) {
     for (int i = 0; i < kNumVariants; ++i)
@@ -472,6 +476,7 @@ extern "C" int afxk_mel4k_kind(const void *plan) {
 extern "C" void afxk_mel4k_destroy(void *plan) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p) return;
+    afxk_mel4k2_destroy(p->v2);
     afxdev_free(p->dWin4);
     afxdev_free(p->dTw1);
     afxdev_free(p->dTw2);
@@ -555,6 +560,7 @@ extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBan
     if (st == AFX_OK) st = upload(&p->dWLane, wL, sizeof(float) * (size_t)64 * WP, stream);
     if (st == AFX_OK) st = upload(&p->dMeta, meta, sizeof(meta), stream);
     if (st == AFX_OK) st = afxdev_stream_sync(stream);
+    if (st == AFX_OK) st = afxk_mel4k2_create(&p->v2, variant - 200, hWindow, band, stream);
     free(tw1);
     free(tw2);
     free(tw3);
@@ -572,6 +578,7 @@ extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream
     if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;  // fusions exist at n_fft 2048 only
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return AFX_ERR_ARG;
+    if (a->specMap < 3) return afxk_mel4k2_run(p->v2, a, stream);  // real results: afx_melfused4k2.hip
     switch (p->variant) {
         case 200: return p->split ? launch<96, 32, true>(p, a, stream) : launch<96, 32>(p, a, stream);
         case 201: return p->split ? launch<128, 64, true>(p, a, stream) : launch<128, 64>(p, a, stream);

@@ -41,6 +41,13 @@ __device__ __forceinline__ v2 cmul(v2 a, v2 b) {
     r = v2{__builtin_fmaf(-a.y, b.y, t.x), __builtin_fmaf(a.y, b.x, t.y)};
     return r;
 }
+// a * conj(b) = (ax bx + ay by, ay bx - ax by)
+__device__ __forceinline__ v2 cmul_conj(v2 a, v2 b) {
+    v2 t, r;
+    t = v2{a.x * b.x, a.x * b.y};
+    r = v2{__builtin_fmaf(a.y, b.y, t.x), __builtin_fmaf(a.y, b.x, -t.y)};
+    return r;
+}
 // complex multiply-accumulate c + a * b: two packed fmas
 __device__ __forceinline__ v2 cfma(v2 a, v2 b, v2 c) {
     v2 t, r;
