@@ -586,7 +586,13 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     // wave still streams a long contiguous run of frames (and re-uses 3/4 of every frame from registers)
     long long waves = (long long)cus * WAVES * 2;  // 1 / 2 / 3 rounds measure the same (1.558 / 1.559 / 1.559 ms), 6: +1.2 %
     long long fpw = (total + waves - 1) / waves;
-    if (fpw < 16) fpw = 16;
+    // long runs per wave (register re-use of the overlapping frames) once a round of workgroups is full; a call that
+    // cannot fill one round -- the one-clip legacy entry points: 1000 frames -- is spread over all CUs instead
+    // (16 frames in sequence per wave were 75 us of a 1000-frame call's 190, profiles/r05_legacy_phases.txt)
+    if (fpw < 16) {
+        const long long oneRound = (total + (long long)cus * WAVES - 1) / ((long long)cus * WAVES);
+        fpw = oneRound < 16 ? oneRound : 16;
+    }
     const long long usedWaves = (total + fpw - 1) / fpw;
     const long long blocks = (usedWaves + WAVES - 1) / WAVES;
 

@@ -526,7 +526,13 @@ int launch_variant(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     long long waves = (long long)cus * WAVES * 2;  // two rounds of workgroups (afx_melfused2.hip)
     long long fpw = (total + waves - 1) / waves;
-    if (fpw < 16) fpw = 16;
+    // long runs per wave (register re-use of the overlapping frames) once a round of workgroups is full; a call that
+    // cannot fill one round -- the one-clip legacy entry points: 1000 frames -- is spread over all CUs instead
+    // (16 frames in sequence per wave were 75 us of a 1000-frame call's 190, profiles/r05_legacy_phases.txt)
+    if (fpw < 16) {
+        const long long oneRound = (total + (long long)cus * WAVES - 1) / ((long long)cus * WAVES);
+        fpw = oneRound < 16 ? oneRound : 16;
+    }
     const long long usedWaves = (total + fpw - 1) / fpw;
     const long long blocks = (usedWaves + WAVES - 1) / WAVES;
 

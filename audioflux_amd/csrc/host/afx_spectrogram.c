@@ -1,3 +1,6 @@
+#ifdef AFX_EXPERIMENTS
+#define _POSIX_C_SOURCE 199309L /* clock_gettime of the measurement build */
+#endif
 /* afx_spectrogram.c -- the spectrogram object (C host side) behind
  * include/spectrogram_algorithm.h.
  *
@@ -473,6 +476,31 @@ int spectrogramObj_spectrogramBatchDevice(SpectrogramObj o, const float *dData, 
     return st;
 }
 
+#ifdef AFX_EXPERIMENTS /* measurement builds only: where a one-clip call spends its time (printed every 200 calls) */
+#include <stdio.h>
+#include <time.h>
+static double g_phase[5], g_phaseLast;
+static int g_phaseCalls;
+static double phase_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+}
+#define AFX_PHASE_T(i)                                                                                          \
+    do {                                                                                                        \
+        const double now_ = phase_now();                                                                        \
+        if ((i) > 0) g_phase[i] += now_ - g_phaseLast;                                                          \
+        g_phaseLast = now_;                                                                                     \
+        if ((i) == 4 && ++g_phaseCalls % 200 == 0) {                                                            \
+            fprintf(stderr, "[afx phases, us per call] h2d %.1f launch %.1f d2h %.1f sync %.1f\n", g_phase[1] / 200, \
+                    g_phase[2] / 200, g_phase[3] / 200, g_phase[4] / 200);                                      \
+            g_phase[1] = g_phase[2] = g_phase[3] = g_phase[4] = 0;                                              \
+        }                                                                                                       \
+    } while (0)
+#else
+#define AFX_PHASE_T(i) ((void)0)
+#endif
+
 void spectrogramObj_spectrogram(SpectrogramObj o, float *dataArr, int dataLength, float *mSpectArr,
                                 float *mPhaseArr) {
     AFX_ENTER(o ? o->core : NULL);
@@ -494,13 +522,17 @@ void spectrogramObj_spectrogram(SpectrogramObj o, float *dataArr, int dataLength
     const int upData = dataLength - skip, total = headTail + upData;
     void *stream = o->core->stream;
     const size_t outB = sizeof(float) * (size_t)T * o->num;
+    AFX_PHASE_T(0);
     int st = afxdev_reserve((void **)&o->dX, &o->capX, sizeof(float) * (size_t)total);
     if (st == AFX_OK) st = afxdev_reserve((void **)&o->dOut, &o->capOut, 2 * outB);
     if (st == AFX_OK && headTail > 0)
         st = afxdev_h2d(o->dX, o->tail.tailDataArr, sizeof(float) * (size_t)headTail, stream);
     if (st == AFX_OK) st = afxdev_h2d(o->dX + headTail, dataArr + skip, sizeof(float) * (size_t)upData, stream);
+    AFX_PHASE_T(1);
     if (st == AFX_OK) st = spectrogramObj_spectrogramBatchDevice(o, o->dX, 1, total, total, o->dOut, stream);
+    AFX_PHASE_T(2);
     if (st == AFX_OK) st = afxdev_d2h(mSpectArr, o->dOut, outB, stream);
+    AFX_PHASE_T(3);
     if (st == AFX_OK && mPhaseArr && o->scale == SpectralFilterBankScale_Linear) {
         /* phase of the sliced bins, real part clamped at 1e-16 (:1037-1053) */
         AfxStftArgs a;
@@ -522,6 +554,7 @@ void spectrogramObj_spectrogram(SpectrogramObj o, float *dataArr, int dataLength
         if (st == AFX_OK) st = afxdev_d2h(mPhaseArr, a.outRe, outB, stream);
     }
     if (st == AFX_OK) st = afxdev_stream_sync(stream);
+    AFX_PHASE_T(4);
     if (o->isContinue) afx_stft_keep_tail(&o->tail, dataArr + skip, upData, total);
     if (st != AFX_OK) fail(o, st, "spectrogramObj_spectrogram");
 }

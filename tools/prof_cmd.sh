@@ -18,5 +18,6 @@ for CTRS in "${ARR[@]}"; do
 done
 python tools/prof_summary.py $(find $OUT -name '*.db' | sort) > $OUT/summary.txt 2>&1
 grep -h '^{' $OUT/trace_cmd.log >> $OUT/summary.txt
+[ -n "${PROF_DB_HOOK:-}" ] && python $PROF_DB_HOOK $(find $OUT/trace -name '*.db' | head -n 1) > $OUT/hook.txt 2>&1
 find $OUT -name '*.db' -delete
 cat $OUT/summary.txt
