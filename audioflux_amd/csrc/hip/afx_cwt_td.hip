@@ -19,12 +19,8 @@
 //     xh gh + xh gl + xl gh on v_mfma_f32_32x32x16_f16 with float32 accumulation: measured against the reference
 //     (tests) 3-6e-7 of the peak -- and 1e-6 of every 512-sample block's OWN peak after a level step, where the
 //     reference's float32 transform of 2^17 points carries 4e-4 (tools/proto_cwt_td.py);
-//   * a persistent workgroup keeps the HIGH words of ONE pair's image (1 KB per K step of 16 taps, <= 64 KB) in LDS and
-//     walks tiles of 512 outputs (two row tiles share every B fragment): per K step 6 MFMAs on 4 accumulators,
-//     5 ds_read_b128 and one 16-byte buffer load -- the LOW words of the image (one of the six products) come from
-//     memory (L2-resident, 64 KB per pair), two K steps ahead like the LDS operands: the longest class then holds
-//     91 KB of LDS instead of 155 and shares its CU with a workgroup of the narrow-band inverse transforms, whose
-//     work is vector / LDS arithmetic while this kernel's is matrix instructions (round 5);
+//   * a persistent workgroup keeps ONE pair's image (2 KB per K step of 16 taps, <= 128 KB) in LDS and walks tiles of
+//     512 outputs (two row tiles share every B fragment): per K step 6 MFMAs on 4 accumulators, 6 ds_read_b128;
 //   * the window comes in by 16-byte loads (chunk edges: per-sample loads through the reflect / wrap index map,
 //     cwt_algorithm.c:404-414), is scaled by 2^e from its own peak, split and stored as two f16 planes; results are
 //     transposed through LDS and leave as 1 KB runs per (scale, plane).
@@ -52,9 +48,9 @@ constexpr int TILE = 512;            // outputs per wave iteration: two row tile
 constexpr int SLAB = 8192;           // outputs per work unit (a workgroup's share of one chunk at a time)
 constexpr int EPI_PITCH = 264;       // floats per (scale, plane) row of the epilogue buffer: banks 8 q + p distinct
 // Two classes of pairs, one instantiation each: MAXK = the taps of the longest kernel of the class.  The long class
-// (<= 1024 taps: up to 64 KB of image high words in LDS); the short class (<= SHORTK taps: <= 24 KB, 3.7 KB of window
-// planes per wave) fits several workgroups per CU, so that one wave's conversion / epilogue runs under another's
-// K loop -- with 8 .. 24 K steps per tile those phases are as long as the loop itself.
+// (<= 1024 taps: up to 128 KB of image) leaves room for one workgroup per CU; the short class (<= SHORTK taps: <= 48 KB
+// of image, 3.7 KB of window planes per wave) fits TWO workgroups per CU, so that one wave's conversion / epilogue
+// runs under the other's K loop -- with 8 .. 24 K steps per tile those phases are as long as the loop itself.
 constexpr int SHORTK = 384;
 template <int MAXK>
 struct TdGeom {
@@ -99,19 +95,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
     const int wgCount = a.wgBase[p + 1] - a.wgBase[p];
     const int local = (int)blockIdx.x - a.wgBase[p];
     const int KS = pr->ks, kh = pr->kh, Kt = 16 * KS;
-    const int hiBytes = KS * 1024;  // the image: KS K steps of high words, then KS of low words
+    const int imgBytes = 2 * KS * 1024;
     unsigned char *Bl = smem_raw;
-    unsigned char *sig = smem_raw + hiBytes + 2048 + wave * WAVE_BYTES;  // (+ 2 KB: the K loop requests two steps ahead)
-    {   // high words of the image -> LDS
+    unsigned char *sig = smem_raw + imgBytes + 2048 + wave * WAVE_BYTES;  // (+ 2 KB: the K loop requests two steps ahead)
+    {   // image -> LDS
         const float4 *src = reinterpret_cast<const float4 *>(a.image + pr->img);
         float4 *dst = reinterpret_cast<float4 *>(Bl);
-        for (int e = tid; e < hiBytes / 16; e += WAVES * 64) dst[e] = src[e];
+        for (int e = tid; e < imgBytes / 16; e += WAVES * 64) dst[e] = src[e];
     }
     __syncthreads();
-    // low words: a raw buffer over the pair's second half (requests past its end -- the K loop runs two steps ahead --
-    // return zeros and are never used)
-    const __amdgpu_buffer_rsrc_t rLo =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.image + pr->img + hiBytes), 0, hiBytes, RSRC_RAW);
 
     const int D = a.dataLength;
     const int slabs = D / SLAB;                       // D is a power of two >= SLAB
@@ -166,6 +158,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
     // A fragments: row i of row tile rt, half g, K step ks = the 16 bytes at 16 (32 rt + i + g + 2 ks)
     const unsigned char *aHi0 = sig + 16 * (i + g);
     const unsigned char *bHi0 = Bl + 16 * lane;
+    const int bLoOff = KS * 1024;
     // epilogue: column c = lane & 31 -> q = c >> 3 in (scale, plane) order, phase c & 7
     float *epi = reinterpret_cast<float *>(sig);
     float *epiW = epi + (i >> 3) * EPI_PITCH + (i & 7) + 32 * g;
@@ -233,6 +226,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
             }
         }
         wave_lds_order();
+        if (tau + 1 < tiles) fetch(tau + 1);
 
         // ---- K loop: per step of 16 taps 6 MFMAs (two row tiles x {xh gh, xh gl, xl gh}), operands two steps ahead.
         //      The first step takes a zero C operand (an inline constant): no pass over the 64 accumulator registers.
@@ -240,14 +234,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
         const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         h8 ah0[4], al0[4], ah1[4], al1[4], bh[4], bl[4];
         const unsigned char *pa = aHi0, *pb = bHi0;
-        int kLo = 0;  // byte offset of the current block in the low-word half (wave-uniform)
         auto load = [&](int slot, int off) {  // off: K step relative to the current base (compile-time immediates)
             ah0[slot] = *reinterpret_cast<const h8 *>(pa + 32 * off);
             al0[slot] = *reinterpret_cast<const h8 *>(pa + PLANE + 32 * off);
             ah1[slot] = *reinterpret_cast<const h8 *>(pa + 512 + 32 * off);
             al1[slot] = *reinterpret_cast<const h8 *>(pa + PLANE + 512 + 32 * off);
             bh[slot] = *reinterpret_cast<const h8 *>(pb + 1024 * off);
-            bl[slot] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rLo, 16u * lane, kLo + 1024 * off, 0));
+            bl[slot] = *reinterpret_cast<const h8 *>(pb + bLoOff + 1024 * off);
         };
         auto block = [&](auto first) {  // four K steps; first: the accumulators start here
 #pragma unroll
@@ -261,17 +254,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
                 x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[s], bl[s], init ? Z : x1, 0, 0, 0);
                 x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[s], bh[s], x0, 0, 0, 0);
                 x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[s], bh[s], x1, 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (the low words)
 #pragma unroll
-                for (int q = 0; q < 5; ++q) {
+                for (int q = 0; q < 6; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
                 }
             }
             pa += 128;
             pb += 4096;
-            kLo += 4096;
         };
         load(0, 0);
         load(1, 1);
@@ -290,9 +280,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // the next tile's window: in flight under the epilogue and its eight stores (issued here, not before the K loop:
-        // the loop's own buffer loads return in order behind anything older)
-        if (tau + 1 < tiles) fetch(tau + 1);
 
         // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 g -> output n0 + 256 rt + 8 row + phase
         const float mul = down * colMul;
@@ -326,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cwt_td(TdArgs a) {
 template <int MAXK>
 static int launch_td(const AfxCwtTdPlan *p, int first, int count, int maxKs, double wgTarget, TdArgs a, void *stream) {
     if (count <= 0) return AFX_OK;
-    const size_t lds = (size_t)maxKs * 1024 + 2048 + (size_t)WAVES * TdGeom<MAXK>::WAVE_BYTES;  // high words of the image only
+    const size_t lds = (size_t)2 * maxKs * 1024 + 2048 + (size_t)WAVES * TdGeom<MAXK>::WAVE_BYTES;
     if (lds > 160 * 1024) return AFX_ERR_UNSUPPORTED;
     static bool attrSet[AFX_MAX_DEVICES] = {};
     const int dev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
@@ -368,8 +355,8 @@ extern "C" int afxk_cwt_td_fits(const AfxCwtTdPlan *p, int dataLength, int num) 
     int nLong = 0;  // pairs are sorted longest first; each class is one launch of <= MAXPAIRS pairs
     while (nLong < p->nPairs && 16 * p->hostKs[nLong] > SHORTK) ++nLong;
     if (nLong > MAXPAIRS || p->nPairs - nLong > MAXPAIRS) return AFX_ERR_UNSUPPORTED;
-    if (nLong > 0 && (size_t)p->maxKs * 1024 + 2048 + (size_t)WAVES * TdGeom<AFX_CWT_TD_MAXK>::WAVE_BYTES > 160 * 1024) return AFX_ERR_UNSUPPORTED;
-    if (nLong < p->nPairs && (size_t)p->hostKs[nLong] * 1024 + 2048 + (size_t)WAVES * TdGeom<SHORTK>::WAVE_BYTES > 160 * 1024)
+    if (nLong > 0 && (size_t)2 * p->maxKs * 1024 + 2048 + (size_t)WAVES * TdGeom<AFX_CWT_TD_MAXK>::WAVE_BYTES > 160 * 1024) return AFX_ERR_UNSUPPORTED;
+    if (nLong < p->nPairs && (size_t)2 * p->hostKs[nLong] * 1024 + 2048 + (size_t)WAVES * TdGeom<SHORTK>::WAVE_BYTES > 160 * 1024)
         return AFX_ERR_UNSUPPORTED;
     return AFX_OK;
 }

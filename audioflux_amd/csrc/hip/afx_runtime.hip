@@ -201,8 +201,8 @@ extern "C" int afxdev_memset(void *dptr, int value, size_t bytes, void *stream) 
 // ---- small host-pointer copies through pinned staging --------------------------------------------------------
 // The legacy entry points (one clip per call: bftObj_bft, spectrogramObj_spectrogram, cqtObj_cqt, ...) hand over
 // pageable host arrays, usually ones the runtime has never seen: hipMemcpyAsync then has the operating system pin
-// the pages first (227 us per 1.9 MB against 44 us on the wire, profiles/r04_hostabi.txt).  Copies of at most
-// AFX_STAGE_MAX bytes therefore go through a pinned slab that belongs to the stream: up = host memcpy in growing
+// the pages first (227 us per 1.9 MB against 44 us on the wire, profiles/r04_hostabi.txt).  With AFX_STAGING=1 copies of
+// at most AFX_STAGE_MAX bytes go through a pinned slab that belongs to the stream: up = host memcpy in growing
 // pieces, each piece's DMA running under the memcpy of the next; down = DMA into the slab, the memcpy to the
 // caller's array deferred to afxdev_stream_sync (the ONLY synchronisation point of the host code -- every
 // afxdev_d2h is followed by one before its function returns).  Slab space is handed out by a bump pointer that the
@@ -226,8 +226,11 @@ struct Stage {
 constexpr int AFX_STAGE_SLOTS = 64;
 std::mutex g_stageMu;
 Stage g_stage[AFX_STAGE_SLOTS];  // (a stream's slabs go back to this table's free entries when the stream is destroyed)
+// OFF unless AFX_STAGING is set (read once): in the reference's published protocol the caller's arrays keep their
+// addresses, the runtime's pin cache serves them, and the staged path measured 0.233 ms per call against 0.205
+// (profiles/r05_legacy_phases.txt); it pays for callers that bring new pages every call.
 bool stage_off() {
-    static const bool off = getenv("AFX_NO_STAGING") != nullptr;
+    static const bool off = getenv("AFX_STAGING") == nullptr;
     return off;
 }
 // the stage of `stream` (created on first use); nullptr: table full or no pinned memory -> plain copies

@@ -406,11 +406,15 @@ def test_concurrent_objects_are_race_free_through_the_real_launchers(tmp_path):
     launchers under clang's ThreadSanitizer: the launcher-level statics (per-device attribute flags, lazily built
     tables) as well as the host objects"""
     exes, _ = _build_with_fake_hip(str(tmp_path), ["-g", "-O1", "-fsanitize=thread", "-fno-omit-frame-pointer"], ("driver_threads",))
-    e = dict(os.environ, AFX_QUIET="1")
-    r = subprocess.run([exes["driver_threads"]], capture_output=True, text=True, env=e, timeout=600)
-    out = r.stdout + r.stderr
-    assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
-    assert "ThreadSanitizer" not in out, out[-3000:]
+    for staging in ("", "1"):  # AFX_STAGING=1: host-pointer copies through the per-stream pinned slabs (afx_runtime.hip: a table shared by the threads)
+        e = dict(os.environ, AFX_QUIET="1")
+        e.pop("AFX_STAGING", None)
+        if staging:
+            e["AFX_STAGING"] = staging
+        r = subprocess.run([exes["driver_threads"]], capture_output=True, text=True, env=e, timeout=600)
+        out = r.stdout + r.stderr
+        assert r.returncode == 0 and "OK" in r.stdout, out[-3000:]
+        assert "ThreadSanitizer" not in out, out[-3000:]
 
 
 def _tsan_runtime():
