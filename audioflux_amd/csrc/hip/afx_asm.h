@@ -131,6 +131,11 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 // ---- global memory
 #define VM_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")             // own stores -> L2 (vmcnt counts stores on gfx9)
 #define VM_LGKM_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+// 16-byte load from a wave-uniform base (SGPR pair) + per-lane byte offset + immediate: constant tables read through the
+// vector cache (L1-resident) instead of the LDS; waited for by hand (vmcnt returns in order: n = loads issued behind it)
+#define GLD128_S(dst, voff, sbase, off) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off) : "memory")
+#define VM_WAIT_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // 16-byte load served by the L2, never by this CU's L1 (rows another lane of the wave stored a moment ago)
 #define LOAD_SC1_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
 

@@ -36,6 +36,24 @@
 #include "afx_hipcheck.h"
 #include "afx_pkmath.h"
 
+// Knock-out measurement builds (make EXTRA=-DAFX_KO=<mask>; results are WRONG, timing only): bit s drops the LDS traffic of
+// site class s -- 0 exchange writes, 1 exchange / image reads, 2 table reads (window, twiddles), 3 band-stage reads, 4 power-row
+// writes -- and leaves the arithmetic on whatever the registers hold; bit 5 drops the second radix-16 layer's arithmetic,
+// bit 6 the band-stage multiply-adds.  What the step time does NOT lose says what does not bind it (profiles/r05_ab_headline.txt (c)).
+#ifdef AFX_KO
+#define KO_ON(s) (((AFX_KO) >> (s)) & 1)
+#define RD128_S(s, dst, addr, off) do { if (KO_ON(s)) asm volatile("" : "=v"(dst)); else RD128(dst, addr, off); } while (0)
+#define RD64_S(s, dst, addr, off) do { if (KO_ON(s)) asm volatile("" : "=v"(dst)); else RD64(dst, addr, off); } while (0)
+#define WR2_64_S(s, addr, d0, d1, o0, o1) do { if (KO_ON(s)) asm volatile("" ::"v"(d0), "v"(d1)); else WR2_64(addr, d0, d1, o0, o1); } while (0)
+#define WR2ST_32_S(s, addr, d0, d1, o0, o1) do { if (KO_ON(s)) asm volatile("" ::"v"(d0), "v"(d1)); else WR2ST_32(addr, d0, d1, o0, o1); } while (0)
+#else
+#define KO_ON(s) 0
+#define RD128_S(s, dst, addr, off) RD128(dst, addr, off)
+#define RD64_S(s, dst, addr, off) RD64(dst, addr, off)
+#define WR2_64_S(s, addr, d0, d1, o0, o1) WR2_64(addr, d0, d1, o0, o1)
+#define WR2ST_32_S(s, addr, d0, d1, o0, o1) WR2ST_32(addr, d0, d1, o0, o1)
+#endif
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         {
             v4f wv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) RD128(wv[j], aWin, T_WIN + 1024 * j);
+            for (int j = 0; j < 8; ++j) RD128_S(2, wv[j], aWin, T_WIN + 1024 * j);
             LDS_WAIT_N(4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         {
             v4f tq[8];  // requested after the butterflies: held across them they would spill
 #pragma unroll
-            for (int j = 0; j < 8; ++j) RD128(tq[j], aWin, T_TW1 + 1024 * j);
+            for (int j = 0; j < 8; ++j) RD128_S(2, tq[j], aWin, T_TW1 + 1024 * j);
             LDS_WAIT_N(0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) PIN(tq[j]);
@@ -353,8 +371,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const unsigned b = aE1w + 2304 * g;  // rows 4g .. 4g+3, 576 bytes = 72 units apart
-                WR2_64(b, o[4 * g], o[4 * g + 1], 0, 72);
-                WR2_64(b, o[4 * g + 2], o[4 * g + 3], 144, 216);
+                WR2_64_S(0, b, o[4 * g], o[4 * g + 1], 0, 72);
+                WR2_64_S(0, b, o[4 * g + 2], o[4 * g + 3], 144, 216);
             }
         }
         wave_lds_sync();
@@ -362,7 +380,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         {
             v4f rq[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) RD128(rq[jj], aE1r, 64 * jj);
+            for (int jj = 0; jj < 8; ++jj) RD128_S(1, rq[jj], aE1r, 64 * jj);
             wave_lds_sync();
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
@@ -374,23 +392,23 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
 
         // ---- 2b. radix-16 over m1, twiddle W_64^(m2 j1) -> image V[q = k1 + 16 j1][m2] --------
         MEL_PHASE(3);
-        dft16(v);
+        if (!KO_ON(5)) dft16(v);
         {
             v4f tq[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) RD128(tq[j], aTw2, 16 * j);
+            for (int j = 0; j < 8; ++j) RD128_S(2, tq[j], aTw2, 16 * j);
             LDS_WAIT_N(0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) PIN(tq[j]);
             v2 o[16];
             o[0] = v[0];
 #pragma unroll
-            for (int j1 = 1; j1 < 16; ++j1) o[j1] = cmul(v[rev4(j1)], (j1 & 1) ? hi2(tq[j1 >> 1]) : lo2(tq[j1 >> 1]));
+            for (int j1 = 1; j1 < 16; ++j1) o[j1] = KO_ON(5) ? v[rev4(j1)] : cmul(v[rev4(j1)], (j1 & 1) ? hi2(tq[j1 >> 1]) : lo2(tq[j1 >> 1]));
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const unsigned b = aE2w + 2048 * g;  // j1 = 4g .. 4g+3, 512 bytes = 64 units apart
-                WR2_64(b, o[4 * g], o[4 * g + 1], 0, 64);
-                WR2_64(b, o[4 * g + 2], o[4 * g + 3], 128, 192);
+                WR2_64_S(0, b, o[4 * g], o[4 * g + 1], 0, 64);
+                WR2_64_S(0, b, o[4 * g + 2], o[4 * g + 3], 128, 192);
             }
         }
         wave_lds_sync();
@@ -400,18 +418,18 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         float pk[2][4], pq[2][4], p512;
         {
             v4f zalo[2], zahi[2], zblo[2], zbhi[2], wlo[2], whi[2];
-            RD128(zalo[0], aAlo, 0);
-            RD128(zahi[0], aAhi, 0);
-            RD128(zblo[0], aB0lo, 0);
-            RD128(zbhi[0], aB0hi, 0);
-            RD128(wlo[0], aT3lo, 0);
-            RD128(whi[0], aT3hi, 0);
-            RD128(zalo[1], aAlo, 2048);
-            RD128(zahi[1], aAhi, 2048);
-            RD128(zblo[1], aB1lo, 0);
-            RD128(zbhi[1], aB1hi, 0);
-            RD128(wlo[1], aT3lo, 2048);
-            RD128(whi[1], aT3hi, 2048);
+            RD128_S(1, zalo[0], aAlo, 0);
+            RD128_S(1, zahi[0], aAhi, 0);
+            RD128_S(1, zblo[0], aB0lo, 0);
+            RD128_S(1, zbhi[0], aB0hi, 0);
+            RD128_S(2, wlo[0], aT3lo, 0);
+            RD128_S(2, whi[0], aT3hi, 0);
+            RD128_S(1, zalo[1], aAlo, 2048);
+            RD128_S(1, zahi[1], aAhi, 2048);
+            RD128_S(1, zblo[1], aB1lo, 0);
+            RD128_S(1, zbhi[1], aB1hi, 0);
+            RD128_S(2, wlo[1], aT3lo, 2048);
+            RD128_S(2, whi[1], aT3hi, 2048);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (s == 0) LDS_WAIT_N(6);
@@ -456,14 +474,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
             p512 = powf(p512, a.normValue);
         }
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
-        WR2ST_32(aP01, pk[0][0], pk[0][1], 0, 4);
-        WR2ST_32(aP23, pk[0][2], pk[0][3], 0, 4);
-        WR2ST_32(aP01, pk[1][0], pk[1][1], 1, 5);
-        WR2ST_32(aP01, pk[1][2], pk[1][3], 9, 13);
-        WR2ST_32(aQs1, pq[0][1], pq[0][0], 9, 13);
-        WR2ST_32(aQ23, pq[0][3], pq[0][2], 0, 4);
-        WR2ST_32(aQs1, pq[1][3], pq[1][2], 0, 4);
-        WR2ST_32(aQs1, pq[1][1], pq[1][0], 8, 12);
+        WR2ST_32_S(4, aP01, pk[0][0], pk[0][1], 0, 4);
+        WR2ST_32_S(4, aP23, pk[0][2], pk[0][3], 0, 4);
+        WR2ST_32_S(4, aP01, pk[1][0], pk[1][1], 1, 5);
+        WR2ST_32_S(4, aP01, pk[1][2], pk[1][3], 9, 13);
+        WR2ST_32_S(4, aQs1, pq[0][1], pq[0][0], 9, 13);
+        WR2ST_32_S(4, aQ23, pq[0][3], pq[0][2], 0, 4);
+        WR2ST_32_S(4, aQs1, pq[1][3], pq[1][2], 0, 4);
+        WR2ST_32_S(4, aQs1, pq[1][1], pq[1][0], 8, 12);
         if (lane0) prow[512] = p512;
         wave_lds_sync();
 
@@ -482,13 +500,13 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
                 for (int i = 0; i < BLK; ++i) {
                     const int q = blk * BLK + i;
                     if (q >= QT) continue;
-                    RD128(wq[i], awr, 16 * q);
+                    RD128_S(3, wq[i], awr, 16 * q);
                     if (q < QA) {
-                        RD64(q0v[i], apa, 16 * q);
-                        RD64(q1v[i], apa, 16 * q + 8);
+                        RD64_S(3, q0v[i], apa, 16 * q);
+                        RD64_S(3, q1v[i], apa, 16 * q + 8);
                     } else {
-                        RD64(q0v[i], apb, 16 * (q - QA));
-                        RD64(q1v[i], apb, 16 * (q - QA) + 8);
+                        RD64_S(3, q0v[i], apb, 16 * (q - QA));
+                        RD64_S(3, q1v[i], apb, 16 * (q - QA) + 8);
                     }
                 }
             };
@@ -510,7 +528,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
                     PIN(p0[cur][i]);
                     PIN(p1[cur][i]);
                     const int q = blk * BLK + i;
-                    if (q < QA) {
+                    if (KO_ON(6)) {
+                        asm volatile("" ::"v"(w[cur][i]), "v"(p0[cur][i]), "v"(p1[cur][i]));
+                    } else if (q < QA) {
                         sA += lo2(w[cur][i]) * p0[cur][i];
                         sA += hi2(w[cur][i]) * p1[cur][i];
                     } else {
