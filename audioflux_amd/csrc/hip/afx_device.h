@@ -396,7 +396,7 @@ typedef struct {
 } AfxCepstrogramArgs;
 int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream);
 /* host: fills tab[AFX_CEPSTROGRAM_FASTTAB_FLOATS] for AfxCepstrogramArgs.fastTab (fftLength 2048 or 4096) */
-#define AFX_CEPSTROGRAM_FASTTAB_FLOATS (2 * (16 * 64 + 64 + 1024 + 1025))
+#define AFX_CEPSTROGRAM_FASTTAB_FLOATS (2 * (16 * 64 + 72 + 1024 + 1025))
 void afxk_cepstrogram_fast_tables(float *tab, int fftLength);
 
 /* specialised rectify + DCT for cepstra (afx_cepstrum.hip): out[rows, ccNum] =

@@ -69,9 +69,11 @@ static_assert(16 * P1 * 8 <= PROW_OFF + 1025 * 4, "exchange image must end befor
 // table blob, byte offsets (built on the host by afxk_mel2_create, copied to LDS per workgroup)
 constexpr int T_WIN = 0;                     // [8][64] float4: (w[2n], w[2n+1]) of rows n1 = 2j, 2j + 1
 constexpr int T_TW1 = 8192;                  // [8][64] float4: W_1024^(lane k1), k1 = 2j, 2j + 1
-constexpr int T_TW2 = 16384;                 // [4][16] float2: W_64^(m2 j1)
-constexpr int T_TW3 = 16896;                 // [2][64][4] float2: 0.5 W_2048^bin of slot (s, lane, m)
-constexpr int T_BAND = 20992;                // [64][WP] floats: lane-major band weights, A then B taps
+constexpr int T_TW2 = 16384;                 // [4] rows of 16 float2, TW2_PITCH bytes apart: W_64^(m2 j1)
+constexpr int TW2_PITCH = 144;               // (128 put rows m2 and m2 + 2 on the same banks: every read of this table two-way
+                                             //  conflicted -- the 6.4 % of the kernel's LDS cycles SQ_LDS_BANK_CONFLICT showed)
+constexpr int T_TW3 = 16960;                 // [2][64][4] float2: 0.5 W_2048^bin of slot (s, lane, m)
+constexpr int T_BAND = 21056;                // [64][WP] floats: lane-major band weights, A then B taps
 __host__ __device__ constexpr int wpitch(int ta, int tb) { return ta + tb + 4; }
 __host__ __device__ constexpr int tab_bytes(int ta, int tb) { return T_BAND + 64 * wpitch(ta, tb) * 4; }
 constexpr int DCT_PITCH = 36;                // floats per lane of the DCT operand table (9 x 16 B: conflict-free b128)
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
     const int k1 = lane >> 2, m2 = lane & 3;
     const unsigned T0 = lds_addr(smem), W0 = lds_addr(wreg);
     const unsigned aWin = T0 + T_WIN + 16 * lane;                      // + 1024 j; W_1024 at + T_TW1
-    const unsigned aTw2 = T0 + T_TW2 + 128 * m2;                       // + 16 j
+    const unsigned aTw2 = T0 + T_TW2 + TW2_PITCH * m2;                       // + 16 j
     const unsigned aE1w = W0 + 8 * (8 * (k1 >> 1) + 2 * m2 + (k1 & 1));  // writer m1 = lane >> 2; row k: + 576 k
     const unsigned aE1r = W0 + 576 * k1 + 16 * m2;                     // pair jj: + 64 jj
     const unsigned aE2w = W0 + 32 * k1 + 16 * ((m2 >> 1) ^ ((k1 >> 3) & 1)) + 8 * (m2 & 1);  // j1: + 512 j1
@@ -730,8 +732,8 @@ extern "C" int afxk_mel2_create(void **plan, int variant, const float *hWindow, 
     for (int m = 0; m < 4; ++m)
         for (int j = 0; j < 16; ++j) {
             const double ang = -2.0 * PI * (double)(m * j) / 64.0;
-            tw2[2 * (m * 16 + j)] = (float)cos(ang);
-            tw2[2 * (m * 16 + j) + 1] = (float)sin(ang);
+            tw2[(TW2_PITCH / 4) * m + 2 * j] = (float)cos(ang);
+            tw2[(TW2_PITCH / 4) * m + 2 * j + 1] = (float)sin(ang);
         }
     // 0.5 W_2048^bin of the P-bin of slot (s, lane, m); 16-byte halves swapped when bit 3 of lane is set
     for (int s = 0; s < 2; ++s)

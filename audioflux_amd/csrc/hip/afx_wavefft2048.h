@@ -21,7 +21,9 @@ namespace afxw {
 constexpr int EX_PITCH = 68;            // float2 per k1 row of the first exchange image
 constexpr int EX_F2 = 16 * EX_PITCH;    // 1088 float2 per wave; the second image needs 3*260 + 256
 constexpr int TAB_TW1_F2 = 16 * 64;     // W_1024^(lane k1)   at [k1][lane]
-constexpr int TAB_TW2_F2 = 64;          // W_64^(m2 j1)       at [m2][j1]
+constexpr int TW2_ROW = 18;             // float2 per row: 16 + 2 (144 bytes, 16-byte aligned: rows m2 and m2 + 2 on different banks;
+                                        // 128 bytes is a two-way conflict on every read of the table)
+constexpr int TAB_TW2_F2 = 4 * TW2_ROW; // W_64^(m2 j1)       at [m2][j1]
 constexpr int TAB_TW3_F2 = 1024;        // 0.5 W_2048^k
 constexpr int TAB_F2 = TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
 
@@ -66,7 +68,7 @@ __device__ __forceinline__ void rfft2048(v2 (&v)[16], v2 *ex, const Tables &t, i
     dft16(v);
     ex[m2 * 260 + k1] = v[0];
 #pragma unroll
-    for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], t.tw2[m2 * 16 + j1]);
+    for (int j1 = 1; j1 < 16; ++j1) ex[m2 * 260 + k1 + 16 * j1] = cmul(v[rev4(j1)], t.tw2[m2 * TW2_ROW + j1]);
     wave_lds_order();
     const int qm = (256 - lane) & 255;  // mirror base of q = lane (lane 0 mirrors itself)
 #pragma unroll
@@ -150,8 +152,8 @@ inline void fill_tables(float *tab) {
     for (int m = 0; m < 4; ++m)
         for (int j = 0; j < 16; ++j) {
             const double ang = -2.0 * PI * (double)(m * j) / 64.0;
-            tw2[2 * (m * 16 + j)] = (float)cos(ang);
-            tw2[2 * (m * 16 + j) + 1] = (float)sin(ang);
+            tw2[2 * (m * TW2_ROW + j)] = (float)cos(ang);
+            tw2[2 * (m * TW2_ROW + j) + 1] = (float)sin(ang);
         }
     for (int k = 0; k < 1024; ++k) {
         const double ang = -2.0 * PI * (double)k / 2048.0;

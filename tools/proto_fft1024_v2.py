@@ -105,6 +105,14 @@ def read_row(qv):
     return [ex2[lo], ex2[lo + 1], ex2[hi], ex2[hi + 1]]
 
 
+# constant tables (round 5): the W_64 rows -- lane (k1, m2) reads row m2 at 16 j, four distinct addresses per lane group -- are
+# conflict-free at a row pitch of 144 bytes; the natural 128 puts rows m2 and m2 + 2 on the same banks (every read two-way:
+# the 6.4 % of the kernel's LDS cycles SQ_LDS_BANK_CONFLICT reported through round 4).  Window / W_1024 rows: 16 bytes per lane.
+for j in range(8):
+    assert conflicts(144 * (lane & 3) + 16 * j, 16, G128, 64) == 1, "W_64 rows at pitch 144"
+    assert conflicts(128 * (lane & 3) + 16 * j, 16, G128, 64) == 2, "W_64 rows at pitch 128 (the round-2 layout)"
+    assert conflicts(16 * lane + 1024 * j, 16, G128, 64) == 1, "window / W_1024 rows"
+
 tw3L = np.zeros((2, 64, 4), complex)  # 0.5 W_2048^k of the slot's P-bin
 pbin = np.zeros((2, 64, 4), int)
 for s in range(2):
