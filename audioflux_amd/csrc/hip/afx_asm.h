@@ -96,6 +96,48 @@ __device__ __forceinline__ v2 mul_mi(v2 a) {
 }
 
 
+// ---- the register image of overlapping frames, moved down IN PLACE: r[n] = r[n + S] for n + S < 16 as ONE asm statement that
+// owns all sixteen register pairs.  Written as plain assignments the compiler keeps two images of the frame and copies one
+// onto the other at the top of every iteration (32 more moves per frame in the headline kernel), and in the n_fft 4096
+// kernel it landed the new loads in temporaries that it then waited for right behind their issue to copy them into place.
+template <int S>
+__device__ __forceinline__ void shift_rows_inplace(v2 (&r)[16]) {
+    static_assert(S == 2 || S == 4 || S == 8, "hop = N/8, N/4, N/2");
+#define AFX_SHIFT_OPS                                                                                                     \
+    "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), \
+        "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+    if constexpr (S == 2) {
+        asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\tv_mov_b64 %2, %4\n\tv_mov_b64 %3, %5\n\tv_mov_b64 %4, %6\n\tv_mov_b64 %5, %7\n\tv_mov_b64 %6, %8\n\tv_mov_b64 %7, %9\n\tv_mov_b64 %8, %10\n\tv_mov_b64 %9, %11\n\tv_mov_b64 %10, %12\n\tv_mov_b64 %11, %13\n\tv_mov_b64 %12, %14\n\tv_mov_b64 %13, %15" : AFX_SHIFT_OPS);
+    } else if constexpr (S == 4) {
+        asm volatile("v_mov_b64 %0, %4\n\tv_mov_b64 %1, %5\n\tv_mov_b64 %2, %6\n\tv_mov_b64 %3, %7\n\tv_mov_b64 %4, %8\n\tv_mov_b64 %5, %9\n\tv_mov_b64 %6, %10\n\tv_mov_b64 %7, %11\n\tv_mov_b64 %8, %12\n\tv_mov_b64 %9, %13\n\tv_mov_b64 %10, %14\n\tv_mov_b64 %11, %15" : AFX_SHIFT_OPS);
+    } else {
+        asm volatile("v_mov_b64 %0, %8\n\tv_mov_b64 %1, %9\n\tv_mov_b64 %2, %10\n\tv_mov_b64 %3, %11\n\tv_mov_b64 %4, %12\n\tv_mov_b64 %5, %13\n\tv_mov_b64 %6, %14\n\tv_mov_b64 %7, %15" : AFX_SHIFT_OPS);
+    }
+#undef AFX_SHIFT_OPS
+}
+
+
+// ---- the same for frames whose rows are 1024 bytes apart in memory (n_fft 4096: a stream of 8-byte pairs every 16 bytes), with the
+// refill in the SAME statement: rows move down by S and the S new rows are requested from `p` (row 16 - S of the next frame) -- the
+// compiler never sees a load it could land in a temporary.  The loads are waited for by hand (s_waitcnt vmcnt(0) + PIN before
+// the first use).  rows_fetch_all: the whole image, `p` = row 0 (p1 .. p3 = p + 4096, 8192, 12288 bytes).
+template <int S>
+__device__ __forceinline__ void rows_shift_fetch(v2 (&r)[16], const float *p) {
+    static_assert(S == 4, "hop = N/4");
+    asm volatile("v_mov_b64 %0, %4\n\tv_mov_b64 %1, %5\n\tv_mov_b64 %2, %6\n\tv_mov_b64 %3, %7\n\tv_mov_b64 %4, %8\n\tv_mov_b64 %5, %9\n\tv_mov_b64 %6, %10\n\tv_mov_b64 %7, %11\n\tv_mov_b64 %8, %12\n\tv_mov_b64 %9, %13\n\tv_mov_b64 %10, %14\n\tv_mov_b64 %11, %15\n\tglobal_load_dwordx2 %12, %16, off offset:0\n\tglobal_load_dwordx2 %13, %16, off offset:1024\n\tglobal_load_dwordx2 %14, %16, off offset:2048\n\tglobal_load_dwordx2 %15, %16, off offset:3072"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                   "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+                 : "v"(p));
+}
+__device__ __forceinline__ void rows_fetch_all(v2 (&r)[16], const float *p) {
+    const float *p1 = p + 1024, *p2 = p + 2048, *p3 = p + 3072;
+    asm volatile("global_load_dwordx2 %0, %16, off offset:0\n\tglobal_load_dwordx2 %1, %16, off offset:1024\n\tglobal_load_dwordx2 %2, %16, off offset:2048\n\tglobal_load_dwordx2 %3, %16, off offset:3072\n\tglobal_load_dwordx2 %4, %17, off offset:0\n\tglobal_load_dwordx2 %5, %17, off offset:1024\n\tglobal_load_dwordx2 %6, %17, off offset:2048\n\tglobal_load_dwordx2 %7, %17, off offset:3072\n\tglobal_load_dwordx2 %8, %18, off offset:0\n\tglobal_load_dwordx2 %9, %18, off offset:1024\n\tglobal_load_dwordx2 %10, %18, off offset:2048\n\tglobal_load_dwordx2 %11, %18, off offset:3072\n\tglobal_load_dwordx2 %12, %19, off offset:0\n\tglobal_load_dwordx2 %13, %19, off offset:1024\n\tglobal_load_dwordx2 %14, %19, off offset:2048\n\tglobal_load_dwordx2 %15, %19, off offset:3072"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]),
+                   "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+                 : "v"(p), "v"(p1), "v"(p2), "v"(p3));
+}
+
+
 // ---- float32 -> (hi, lo) binary16 words --------------------------------------------------
 // (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
 // fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).

@@ -322,13 +322,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
                 ++cn;
             }
             const float *pn = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
-            if (SHIFT > 0 && tn != 0) {
-#pragma unroll
-                for (int n1 = 0; n1 + SHIFT < 16; ++n1) raw[n1] = raw[n1 + SHIFT];
-                fetch(pn, 16 - SHIFT);
-            } else {
-                fetch(pn, 0);
+            bool whole = true;
+            if constexpr (SHIFT > 0) {
+                if (tn != 0) {
+                    shift_rows_inplace<SHIFT>(raw);  // (in place: afx_asm.h)
+                    fetch(pn, 16 - SHIFT);
+                    whole = false;
+                }
             }
+            if (whole) fetch(pn, 0);
         }
         // ---- 1c. temporal features of the windowed frame (temporal_algorithm.c:138-144) -------
         if constexpr (TEMPORAL) {

@@ -15,7 +15,7 @@
 // everything above is lane-local.  The first half's 16 values wait in registers while the second is transformed.
 // Lane 0 carries the self-mirrored base q = 128 in place of its duplicate slots (as in afx_melfused2.hip) and the
 // pair (512, 1536).  8 waves per workgroup (2 per SIMD): the frame's float4 image stays in registers and moves down by
-// hop / 256 registers per frame (hop 1024: four new float4 per lane and frame).
+// hop / 256 register pairs per frame (hop 1024: four new float4 per lane and frame).
 //
 // Replaces k_stft_band_4k (afx_melfused4k.hip, which keeps the complex-result modes) for specMap 0 / 1 / 2;
 // per frame the same reference code: stft_algorithm.c:696-803 (frame, window, FFT), bft_algorithm.c:360-455
@@ -167,24 +167,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
     int clip = (int)(f / a.timeLength);
     int t = (int)(f - (long long)clip * a.timeLength);
 
-    // raw[n1] = x[4m .. 4m+3], m = 64 n1 + lane: (.x, .y) = ze[m], (.z, .w) = zo[m]
-    v4f raw[16];
-    auto fetch = [&](const float *px, int first) {
-        if (a.aligned) {
-            const v4f *p4 = reinterpret_cast<const v4f *>(px);
+    // rlo[n1] = ze[m] = (x[4m], x[4m+1]), rhi[n1] = zo[m] = (x[4m+2], x[4m+3]), m = 64 n1 + lane: two register images, each
+    // moved down in place and refilled right behind its own window multiply by ONE asm statement (rows_shift_fetch /
+    // rows_fetch_all, afx_asm.h: 8-byte loads, dword alignment is enough); the loads are waited for by hand at the end of
+    // the frame, BEFORE its row stores are issued (so the wait never meets a store that was issued a moment ago)
+    v2 rlo[16], rhi[16];
+    {
+        const float *px = a.x + (long long)clip * a.clipStride + (long long)t * a.hop + 4 * lane;
+        rows_fetch_all(rlo, px);
+        rows_fetch_all(rhi, px + 2);
+        VM_WAIT_ALL();
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1)
-                if (n1 >= first) raw[n1] = p4[64 * n1 + lane];
-        } else {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1)
-                if (n1 >= first) {
-                    const int m = 64 * n1 + lane;
-                    raw[n1] = v4f{px[4 * m], px[4 * m + 1], px[4 * m + 2], px[4 * m + 3]};
-                }
+        for (int n1 = 0; n1 < 16; ++n1) {
+            PIN(rlo[n1]);
+            PIN(rhi[n1]);
         }
-    };
-    fetch(a.x + (long long)clip * a.clipStride + (long long)t * a.hop, 0);
+    }
 
     for (; f < fEnd; ++f) {
         // first half's values at the lane's slots: EA[4 s + j] = Ze[k], EB[4 s + j] = Ze[1024 - k], k = lane + 64 s + 256 j
@@ -205,32 +203,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     PIN(wv[j]);
-                    v[2 * j] = (half ? hi2(raw[2 * j]) : lo2(raw[2 * j])) * lo2(wv[j]);
-                    v[2 * j + 1] = (half ? hi2(raw[2 * j + 1]) : lo2(raw[2 * j + 1])) * hi2(wv[j]);
+                    v[2 * j] = (half ? rhi[2 * j] : rlo[2 * j]) * lo2(wv[j]);
+                    v[2 * j + 1] = (half ? rhi[2 * j + 1] : rlo[2 * j + 1]) * hi2(wv[j]);
                 }
                 LDS_WAIT_N(0);
 #pragma unroll
                 for (int j = 4; j < 8; ++j) {
                     PIN(wv[j]);
-                    v[2 * j] = (half ? hi2(raw[2 * j]) : lo2(raw[2 * j])) * lo2(wv[j]);
-                    v[2 * j + 1] = (half ? hi2(raw[2 * j + 1]) : lo2(raw[2 * j + 1])) * hi2(wv[j]);
+                    v[2 * j] = (half ? rhi[2 * j] : rlo[2 * j]) * lo2(wv[j]);
+                    v[2 * j + 1] = (half ? rhi[2 * j + 1] : rlo[2 * j + 1]) * hi2(wv[j]);
                 }
             }
-            // ---- 1b. the frame's samples are consumed: start fetching the next frame -------------
-            if (half == 1 && f + 1 < fEnd) {
+            // ---- 1b. this half's samples are consumed (pinned: the products must not sink below the statement that
+            //      overwrites their operands -- the compiler would copy the whole image aside for them): move its image
+            //      down and request the next frame's rows ----
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) PIN(v[n1]);
+            if (f + 1 < fEnd) {
                 int tn = t + 1, cn = clip;
                 if (tn == a.timeLength) {
                     tn = 0;
                     ++cn;
                 }
-                const float *pnx = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
-                if (SHIFT > 0 && tn != 0) {
-#pragma unroll
-                    for (int n1 = 0; n1 + SHIFT < 16; ++n1) raw[n1] = raw[n1 + SHIFT];
-                    fetch(pnx, 16 - SHIFT);
-                } else {
-                    fetch(pnx, 0);
+                const float *pnx = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop + 4 * lane + 2 * half;
+                bool whole = true;
+                if constexpr (SHIFT > 0) {
+                    if (tn != 0) {
+                        rows_shift_fetch<SHIFT>(half ? rhi : rlo, pnx + 256 * (16 - SHIFT));
+                        whole = false;
+                    }
                 }
+                if (whole) rows_fetch_all(half ? rhi : rlo, pnx);
             }
 
             // ---- 2a. radix-16 over n1, twiddle W_1024^(lane k1), transpose through LDS -----------
@@ -475,7 +478,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
             accB = powf(accB, a.normValue);
         }
         MEL4K_PHASE(6);
-        // ---- 5. store ----
+        // ---- 5. the next frame's samples have landed (requested half a frame and a frame ago); store ----
+        VM_WAIT_ALL();
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            PIN(rlo[n1]);
+            PIN(rhi[n1]);
+        }
         float *orow = a.out + f * a.num;
         if constexpr (SPLIT) {
             // slot results -> LDS (start of the wave's region: the image there is dead since stage 3, the power row

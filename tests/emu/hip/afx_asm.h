@@ -73,6 +73,24 @@ __device__ __forceinline__ v2 mul_mi(v2 a) {
 }
 
 
+// r[n] = r[n + S] for n + S < 16 (the product's version is one asm statement that moves the registers in place)
+template <int S>
+__device__ __forceinline__ void shift_rows_inplace(v2 (&r)[16]) {
+    for (int n = 0; n + S < 16; ++n) r[n] = r[n + S];
+}
+
+
+// rows 1024 bytes apart in memory (n_fft 4096): move down by S and refill the last S from p / the whole image from p
+template <int S>
+__device__ __forceinline__ void rows_shift_fetch(v2 (&r)[16], const float *p) {
+    for (int n = 0; n + S < 16; ++n) r[n] = r[n + S];
+    for (int i = 0; i < S; ++i) r[16 - S + i] = v2{p[256 * i], p[256 * i + 1]};
+}
+__device__ __forceinline__ void rows_fetch_all(v2 (&r)[16], const float *p) {
+    for (int n = 0; n < 16; ++n) r[n] = v2{p[256 * n], p[256 * n + 1]};
+}
+
+
 // (x0 up, x1 up) -> f16 pair `hi` (round to nearest even) and f16 pair `lo` = f16(x up - hi): four mixed-precision
 // fmas (x up is exact: up is a power of two; the subtraction of the f16 word happens inside the fma, one rounding).
 // One asm statement: VALU->VALU dependences are interlocked, and hipcc's own form of this costs 7 instructions.
