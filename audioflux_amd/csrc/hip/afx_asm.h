@@ -117,6 +117,14 @@ __device__ __forceinline__ void shift_rows_inplace(v2 (&r)[16]) {
 }
 
 
+// the eight-row image of the n_fft 1024 kernel (hop 256: S = 2)
+template <int S>
+__device__ __forceinline__ void shift_rows8_inplace(v2 (&r)[8]) {
+    static_assert(S == 2, "hop = N/4");
+    asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\tv_mov_b64 %2, %4\n\tv_mov_b64 %3, %5\n\tv_mov_b64 %4, %6\n\tv_mov_b64 %5, %7"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+}
+
 // ---- the same for frames whose rows are 1024 bytes apart in memory (n_fft 4096: a stream of 8-byte pairs every 16 bytes), with the
 // refill in the SAME statement: rows move down by S and the S new rows are requested from `p` (row 16 - S of the next frame) -- the
 // compiler never sees a load it could land in a temporary.  The loads are waited for by hand (s_waitcnt vmcnt(0) + PIN before

@@ -187,13 +187,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_cplx(KArgs a) {
                 ++cn;
             }
             const float *pn = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
-            if (SHIFT > 0 && tn != 0) {
-#pragma unroll
-                for (int n1 = 0; n1 + SHIFT < 16; ++n1) raw[n1] = raw[n1 + SHIFT];
-                fetch(pn, 16 - SHIFT);
-            } else {
-                fetch(pn, 0);
+            bool whole = true;
+            if constexpr (SHIFT > 0) {
+                if (tn != 0) {
+                    shift_rows_inplace<SHIFT>(raw);  // in place (afx_asm.h: the compiler's own form keeps two images of the frame)
+                    fetch(pn, 16 - SHIFT);
+                    whole = false;
+                }
             }
+            if (whole) fetch(pn, 0);
         }
 
         AFX_TRANSFORM_PRIO(1);  // (afx_melfused2.hip: the transform's phases above the window / band / store phases of the SIMD's other waves)

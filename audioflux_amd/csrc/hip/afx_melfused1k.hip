@@ -149,13 +149,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 ++cn;
             }
             const float *pn = a.x + (long long)cn * a.clipStride + (long long)tn * a.hop;
-            if (SHIFT > 0 && tn != 0) {  // hop = 128 SHIFT samples = SHIFT registers
-#pragma unroll
-                for (int r = 0; r + SHIFT < 8; ++r) raw[r] = raw[r + SHIFT];
-                fetch(pn, 8 - SHIFT);
-            } else {
-                fetch(pn, 0);
+            bool whole = true;
+            if constexpr (SHIFT > 0) {  // hop = 128 SHIFT samples = SHIFT registers, moved in place (afx_asm.h)
+                if (tn != 0) {
+                    shift_rows8_inplace<SHIFT>(raw);
+                    fetch(pn, 8 - SHIFT);
+                    whole = false;
+                }
             }
+            if (whole) fetch(pn, 0);
         }
         // ---- 2. 512-point complex FFT, 8 x 8 x 8 ------------------------------------------
         {

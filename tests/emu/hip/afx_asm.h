@@ -80,6 +80,11 @@ __device__ __forceinline__ void shift_rows_inplace(v2 (&r)[16]) {
 }
 
 
+template <int S>
+__device__ __forceinline__ void shift_rows8_inplace(v2 (&r)[8]) {
+    for (int n = 0; n + S < 8; ++n) r[n] = r[n + S];
+}
+
 // rows 1024 bytes apart in memory (n_fft 4096): move down by S and refill the last S from p / the whole image from p
 template <int S>
 __device__ __forceinline__ void rows_shift_fetch(v2 (&r)[16], const float *p) {
