@@ -462,21 +462,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
                 split_pair(A3, B3, hi2(whi[s]), pk[s][3], pq[s][3]);
             }
         }
-        if (a.specMap == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                pk[i >> 2][i & 3] = sqrtf(pk[i >> 2][i & 3]);
-                pq[i >> 2][i & 3] = sqrtf(pq[i >> 2][i & 3]);
-            }
-            p512 = sqrtf(p512);
-        } else if (a.specMap == 2) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                pk[i >> 2][i & 3] = powf(pk[i >> 2][i & 3], a.normValue);
-                pq[i >> 2][i & 3] = powf(pq[i >> 2][i & 3], a.normValue);
-            }
-            p512 = powf(p512, a.normValue);
-        }
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
         WR2ST_32_S(4, aP01, pk[0][0], pk[0][1], 0, 4);
         WR2ST_32_S(4, aP23, pk[0][2], pk[0][3], 0, 4);
@@ -488,6 +473,16 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         WR2ST_32_S(4, aQs1, pq[1][1], pq[1][0], 8, 12);
         if (lane0) prow[512] = p512;
         wave_lds_sync();
+        if (a.specMap) {
+            // magnitude / norm exponent (rare modes): one pass over the row in LDS.  (Applied to the 17 register values
+            // before the stores, the two branches' results met the plain path's in different registers and the plain
+            // path paid 17 moves per frame for it.)
+            for (int k = lane; k < 1025; k += 64) {
+                const float p = prow[k];
+                prow[k] = a.specMap == 1 ? sqrtf(p) : powf(p, a.normValue);
+            }
+            wave_lds_sync();
+        }
 
         MEL_PHASE(5);
         // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset

@@ -373,27 +373,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
                 }
             }
         }
-        if (a.specMap == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                pk[i] = sqrtf(pk[i]);
-                pn[i] = sqrtf(pn[i]);
-                pm[i] = sqrtf(pm[i]);
-                pq[i] = sqrtf(pq[i]);
-            }
-            p512 = sqrtf(p512);
-            p1536 = sqrtf(p1536);
-        } else if (a.specMap == 2) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                pk[i] = powf(pk[i], a.normValue);
-                pn[i] = powf(pn[i], a.normValue);
-                pm[i] = powf(pm[i], a.normValue);
-                pq[i] = powf(pq[i], a.normValue);
-            }
-            p512 = powf(p512, a.normValue);
-            p1536 = powf(p1536, a.normValue);
-        }
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
         // bins k (s = 0: j 0, 1 | 2, 3; s = 1: j 0, 1 | 2, 3) and 1024 + k
         WR2ST_32(aP01, pk[0], pk[1], 0, 4);
@@ -418,6 +397,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
             prow[1536] = p1536;
         }
         wave_lds_sync();
+        if (a.specMap) {  // magnitude / norm exponent (rare modes): one pass over the row in LDS (afx_melfused2.hip)
+            for (int k = lane; k < 2049; k += 64) {
+                const float p = prow[k];
+                prow[k] = a.specMap == 1 ? sqrtf(p) : powf(p, a.normValue);
+            }
+            wave_lds_sync();
+        }
 
         MEL4K_PHASE(5);
         // ---- 4. banded filter bank (afx_melfused2.hip): weights by ds_read_b128, power row by immediate-offset
