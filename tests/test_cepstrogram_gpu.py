@@ -87,7 +87,10 @@ def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_n
     rr = ref.RefCepstrogram(r, wt, hop)
     from oracle import restate
     want0, bar0 = None, {}
-    K = {"cep": 2.0, "env": 4.0, "det": 5.0}
+    # bars in units of the reference's own distance from float64 (below): 3 for the envelope and the details -- measured over these
+    # shapes wherever the error exceeds TOL at all: envelope <= 1.2, details <= 2.8 (round 5, gpurun_out parity log) -- except the two
+    # shapes whose details are decided by one bin next to a spectral null (4.3 and 3.3 of the reference's distance): 5 there
+    K = {"cep": 2.0, "env": 3.0, "det": 5.0 if (r, hop, cep_num) in ((11, 512, 17), (12, 1024, 16)) else 3.0}
     for i in range(clips):
         want = rr.cepstrogram(x[i, :length], cep_num)
         want0 = want if i == 0 else want0
@@ -98,10 +101,9 @@ def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_n
         # order, with a factor that depends on how deep the frame's deepest spectral null is.
         # The bar is therefore the larger of TOL and K x the reference's own distance from float64
         # (peak- and L2-relative separately), for the comparison with the reference AND with float64:
-        # K = 2 for the cepstrum, 4 for the envelope, 5 for the details (round 3: 6 for all; measured
-        # at worst 1.5 / 3.9 (below TOL) / 4.3 over these 33 shapes -- the maximum of a heavy-tailed
-        # error, one bin decides it; tests/test_realaudio_gpu.py pins the well-conditioned part of
-        # real clips at plain 1e-5).
+        # K = 2 for the cepstrum, 3 for the envelope and the details, 5 for the details of two shapes (round 4: 2 / 4 / 5 for all;
+        # round 3: 6) -- the maximum of a heavy-tailed error, one bin decides it; tests/test_realaudio_gpu.py pins the
+        # well-conditioned part of real clips at plain 1e-5).
         f64 = restate.cepstrogram(x[i, :length].astype(np.float64), 1 << r, hop, cep_num, window_type=wt)
         for k, name in enumerate(("cep", "env", "det")):
             got = outs[k][i].cpu().numpy().astype(np.float64)
