@@ -169,7 +169,7 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
     constexpr int N = 2048, F = 1025;
     v2 *tabWin = reinterpret_cast<v2 *>(smem_raw);
     v2 *tabTw = tabWin + 1024;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: frame counters and row pointers stay scalar)
     v2 *ex = tabTw + afxw::TAB_F2 + wave * afxw::EX_F2;
     float *row = reinterpret_cast<float *>(ex);  // natural-order row between transforms (1025 floats)
     {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(CW4 * 64) void k_cepstrogram_w4096(CepWArgs a) {
     v4 *tabWin = reinterpret_cast<v4 *>(smem_raw);                // [1024] window quads
     v2 *tabTw = reinterpret_cast<v2 *>(tabWin + 1024);
     v2 *tabW4 = tabTw + afxw::TAB_F2;                             // W_4096^k, k <= 1024 (1032 slots)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: frame counters and row pointers stay scalar)
     v2 *ex = tabW4 + 1032 + wave * afxw::EX_F2;
     float *row = reinterpret_cast<float *>(ex);  // natural-order row between transforms (2049 floats)
     {
