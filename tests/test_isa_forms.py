@@ -58,3 +58,39 @@ def test_no_packed_f32_instruction_breaks_the_operand_select_rule(tmp_path):
                     bad.append((f, sym[:80], line.strip()[:120]))
     assert packed > 20000, packed  # the FFT kernels are made of these
     assert not bad, f"{len(bad)} instructions break the rule, e.g. {bad[:5]}"
+
+
+# kernels whose frame loops must not touch scratch memory (demangled-name fragment -> the instantiations meant)
+NO_SCRATCH = {
+    "k_stft_band_4k2": "n_fft 4096 real results, every instantiation (round 5: replaces k_stft_band_4k's 68 B per lane)",
+    "k_cepstrogram_w4096": "cepstrogram n_fft 4096 (round 5: 52 B per lane before the wave index became scalar)",
+    "k_cepstrogram_w2048": "cepstrogram n_fft 2048",
+    "k_cqt_pyramid": None,  # (reported, not asserted: 160 B of loop invariants by design)
+}
+
+
+def test_hot_kernels_do_not_spill(tmp_path):
+    """no scratch_* instruction in the n_fft 4096 kernels (and the headline instantiation the bench
+    times: k_stft_mel_v2<48, 16, 4, false, true, false>)"""
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([OBJDUMP, "--offloading", lib], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = sorted(f for f in os.listdir(tmp_path) if "amdgcn" in f and "gfx950" in f)
+    seen, bad = {}, []
+    for f in objs:
+        dis = subprocess.run([OBJDUMP, "-d", "--demangle", str(tmp_path / f)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        sym = "?"
+        for line in dis.splitlines():
+            if line.endswith(">:"):
+                sym = line.split("<", 1)[-1][:-2]
+            if "scratch_" in line:
+                seen[sym] = seen.get(sym, 0) + 1
+    headline = [s for s in seen if "k_stft_mel_v2<48, 16, 4, false, true, false>" in s]
+    assert not headline, headline
+    for frag, why in NO_SCRATCH.items():
+        if why is None:
+            continue
+        hit = {s: n for s, n in seen.items() if frag + "<" in s or frag + "(" in s}
+        if hit:
+            bad.append((frag, why, sorted(hit.items())[:3]))
+    assert not bad, bad
