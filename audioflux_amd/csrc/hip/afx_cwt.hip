@@ -382,6 +382,25 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2
                    outIm + ((long long)blockIdx.z * g.num + j) * D);
 }
 
+// Four-step twiddles W_L^(m1 (16 a + g)), a = 0 .. 15, from the two LDS tables (W_L^m = tlo[m & 255] thi[m >> 8]) in two
+// levels: A[a >> 2] = W_L^(m1 (g + 64 (a >> 2))) and B[a & 3] = W_L^(16 m1 (a & 3)) -- 14 gathered reads and 19 products
+// instead of 32 and 16 (these kernels keep the LDS pipe 86 % busy, profiles/r05_ab_cwt.txt); one more rounding per value.
+__device__ __forceinline__ void nb_fourstep_twiddles(const v2 *tlo, const v2 *thi, int m1, int gq, v2 (&wl)[16]) {
+    v2 A[4], B[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m1 * (gq + 64 * q);  // < 2^17
+        A[q] = cmul(tlo[m & 255], thi[m >> 8]);
+    }
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const int m = 16 * m1 * r;
+        B[r] = cmul(tlo[m & 255], thi[m >> 8]);
+    }
+#pragma unroll
+    for (int a = 0; a < 16; ++a) wl[a] = (a & 3) ? cmul(A[a >> 2], B[a & 3]) : A[a >> 2];
+}
+
 // Narrow-band scales: every non-zero of the wavelet lies in R rows k2 in [lo, lo + R) of the
 // transposed spectrum (frequencies k = k1 + 256 k2), so the 512-point row transform of the first
 // pass is an R-term sum,
@@ -436,11 +455,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
     v2 w5[R], wl[16];
 #pragma unroll
     for (int k2 = 0; k2 < R; ++k2) w5[k2] = thi[((lo + k2) * m1) & (L2 - 1)];  // W_512^((lo + k2) m1)
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {  // four-step twiddle W_L^(m1 k1), m1 k1 < L
-        const int m = m1 * (16 * a + gq);
-        wl[a] = cmul(tlo[m & 255], thi[m >> 8]);
-    }
+    nb_fourstep_twiddles(tlo, thi, m1, gq, wl);  // W_L^(m1 k1), m1 k1 < L
     v2 r[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
@@ -526,16 +541,16 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
     __syncthreads();
     v2 r[16];
     {
-        v2 w5[R2];
+        v2 w5[R2], wl[16];
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) w5[k2] = thi[((lo + R + k2) * m1) & (L2 - 1)];
+        nb_fourstep_twiddles(tlo, thi, m1, gq, wl);  // W_L^(m1 k1), m1 k1 < L
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             const v2 *z = zs + (16 * a + gq) * R2;
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) acc[a] = cfma(z[k2], w5[k2], acc[a]);
-            const int m = m1 * (16 * a + gq);  // four-step twiddle W_L^(m1 k1), m1 k1 < L
-            r[a] = cmul(acc[a], cmul(tlo[m & 255], thi[m >> 8]));
+            r[a] = cmul(acc[a], wl[a]);
         }
     }
     __syncthreads();  // every thread is done with zs before the exchange buffer is written
