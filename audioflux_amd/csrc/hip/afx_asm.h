@@ -169,9 +169,13 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 // (the same read through a pointer into a static __shared__ array)
 #define RD128_P(dst, ptr, off) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((unsigned)(size_t)(ptr)), "n"(off) : "memory")
-// two rows with one instruction; offsets in units of 8 bytes (<= 255)
-#define WR2_64(addr, d0, d1, o0, o1) \
-    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
+// two rows (16 bytes per lane); offsets in units of 8 bytes
+// (as TWO ds_write_b64: the LDS takes 6 cycles for each against 13 for one ds_write2_b64 of the same 16 bytes per lane --
+//  headline kernel 1.3861 / 1.3938 -> 1.3714 / 1.3745 ms per step, profiles/r05_ab_headline.txt (j); instruction issue does not bind)
+#define WR2_64(addr, d0, d1, o0, o1)                                                                           \
+    asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4" ::"v"(addr), "v"(d0), "v"(d1), \
+                 "n"(8 * (o0)), "n"(8 * (o1))                                                                  \
+                 : "memory")
 // two dwords 64-dword units apart; offsets in units of 256 bytes (<= 255)
 #define WR2ST_32(addr, d0, d1, o0, o1) \
     asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(d0), "v"(d1), "n"(o0), "n"(o1) : "memory")
