@@ -459,7 +459,7 @@ extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBan
 extern "C" int afxk_mel1k_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 extern "C" void afxk_mel1k_destroy(void *plan);
 
-// n_fft = 4096 lives in afx_melfused4k.hip (variant numbers >= 200)
+// n_fft = 4096 lives in afx_melfused4k2.hip (variant numbers >= 200)
 extern "C" int afxk_mel4k_variant(int tapsA, int tapsB);
 extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream);
 extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream);

@@ -17,8 +17,9 @@
 // pair (512, 1536).  8 waves per workgroup (2 per SIMD): the frame's float4 image stays in registers and moves down by
 // hop / 256 register pairs per frame (hop 1024: four new float4 per lane and frame).
 //
-// Replaces k_stft_band_4k (afx_melfused4k.hip, which keeps the complex-result modes) for specMap 0 / 1 / 2;
-// per frame the same reference code: stft_algorithm.c:696-803 (frame, window, FFT), bft_algorithm.c:360-455
+// Real results (specMap 0 / 1 / 2) and complex results (3: S, 4: S^2 -- bftObj_setResultType(0), the wrapper's default for
+// bft(): the imaginary parts wait in registers for a second pass of the bank; 246 VGPRs).  Round 1's k_stft_band_4k is gone.
+// Per frame the same reference code: stft_algorithm.c:696-803 (frame, window, FFT), bft_algorithm.c:360-455
 // (spectrum value, bank product).
 #include <hip/hip_runtime.h>
 
@@ -67,6 +68,7 @@ struct KArgs4 {
     int specMap, postPow;
     float normValue;
     float *out;            // [totalFrames, num]
+    float *outIm;          // complex results (specMap 3 / 4): imaginary parts, same shape
     int num;
 };
 
@@ -109,10 +111,32 @@ __device__ __forceinline__ void split_pair_q(v2 A, v2 B, v2 w, float &pa, float 
     pb = y.x * y.x + y.y * y.y;
 }
 
+// complex results: the spectrum values themselves (x = X[a], y = conj(X[2048-a]); q variant: x = X[1024-k], y = conj(X[1024+k]))
+__device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, v2 &x, v2 &y) {
+    const v2 e2 = pk_add_conj(A, B);
+    const v2 d = pk_sub_conj(A, B);
+    const v2 wo = cmul_mi(d, w);
+    x = e2 * 0.5f + wo;
+    y = e2 * 0.5f - wo;
+}
+__device__ __forceinline__ void split_pair_qc(v2 A, v2 B, v2 w, v2 &x, v2 &y) {
+    const v2 e2 = pk_add_conj(A, B);
+    const v2 d = pk_sub_conj(A, B);
+    const v2 vv = cmul_conj(d, w);
+    x = e2 * 0.5f - vv;
+    y = e2 * 0.5f + vv;
+}
+// (re, im) of the requested complex result from a spectrum value c: S (sq = false) or S^2 (bft_algorithm.c:457-485)
+__device__ __forceinline__ void cplx_map(v2 c, bool sq, float &re, float &im) {
+    re = sq ? c.x * c.x - c.y * c.y : c.x;
+    im = sq ? 2.f * (c.x * c.y) : c.y;
+}
+
 // SHIFT: hop = 256 * SHIFT samples -> the next frame's register image is this one moved down by SHIFT float4,
 //   only SHIFT new float4 per lane are fetched (0: every frame fetched whole)
 // SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split)
-template <int TA, int TB, int SHIFT, bool SPLIT>
+// CPLX: complex results (specMap 3: S, 4: S^2): the imaginary parts wait in registers for a second pass of the bank
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -188,8 +212,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
         // first half's values at the lane's slots: EA[4 s + j] = Ze[k], EB[4 s + j] = Ze[1024 - k], k = lane + 64 s + 256 j
         // (lane 0, s = 0: k = 0, 256, 128, 384); ec = Ze[512] (lane 0)
         v2 EA[8], EB[8], ec;
-        float pk[8], pn[8], pm[8], pq[8];  // |X|^2 at bins k, 2048 - k, 1024 - k, 1024 + k
+        float pk[8], pn[8], pm[8], pq[8];  // |X|^2 (CPLX: real parts) at bins k, 2048 - k, 1024 - k, 1024 + k
         float p512, p1536;
+        float ik[CPLX ? 8 : 1], in_[CPLX ? 8 : 1], im_[CPLX ? 8 : 1], iq[CPLX ? 8 : 1], i512 = 0.f, i1536 = 0.f;  // CPLX: imaginary parts
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             v2 v[16];
@@ -360,20 +385,52 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
                             const v2 u = cmul_conj(B[j], wc[j]);   // conj(W_2048^k) Zo[1024-k]
                             const v2 zk = EA[i] + to, zk1 = EA[i] - to;  // Z[k], Z[k + 1024]
                             const v2 zm = EB[i] - u, zn = EB[i] + u;     // Z[1024 - k], Z[2048 - k]
-                            split_pair(zk, zn, ws[j], pk[i], pn[i]);
-                            split_pair_q(zm, zk1, ws[j], pm[i], pq[i]);
+                            if constexpr (CPLX) {
+                                const bool sq = a.specMap == 4;
+                                v2 x, y;
+                                split_pair_c(zk, zn, ws[j], x, y);
+                                cplx_map(x, sq, pk[i], ik[CPLX ? i : 0]);
+                                cplx_map(v2{y.x, -y.y}, sq, pn[i], in_[CPLX ? i : 0]);
+                                split_pair_qc(zm, zk1, ws[j], x, y);
+                                cplx_map(x, sq, pm[i], im_[CPLX ? i : 0]);
+                                cplx_map(v2{y.x, -y.y}, sq, pq[i], iq[CPLX ? i : 0]);
+                            } else {
+                                split_pair(zk, zn, ws[j], pk[i], pn[i]);
+                                split_pair_q(zm, zk1, ws[j], pm[i], pq[i]);
+                            }
                         }
                         if (s == 0) {
                             // bins 512, 1536 (lane 0's values): Z[512] = Ze[512] - i Zo[512], Z[1536] = Ze[512] + i Zo[512]
                             constexpr float HH = 0.35355339059327376f;  // 0.5 W_4096^512 = 0.5 exp(-i pi / 4)
                             const v2 z5 = pk_add_mi(ec, zc), z15 = pk_add_pi(ec, zc);
-                            split_pair(z5, z15, v2{HH, -HH}, p512, p1536);
+                            if constexpr (CPLX) {
+                                v2 x, y;
+                                split_pair_c(z5, z15, v2{HH, -HH}, x, y);
+                                cplx_map(x, a.specMap == 4, p512, i512);
+                                cplx_map(v2{y.x, -y.y}, a.specMap == 4, p1536, i1536);
+                            } else {
+                                split_pair(z5, z15, v2{HH, -HH}, p512, p1536);
+                            }
                         }
                     }
                 }
             }
         }
+#pragma unroll
+        for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
+        // (CPLX: the second pass writes the imaginary parts over the row the first pass has read)
+        if (CPLX && pass == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pk[i] = ik[CPLX ? i : 0];
+                pn[i] = in_[CPLX ? i : 0];
+                pm[i] = im_[CPLX ? i : 0];
+                pq[i] = iq[CPLX ? i : 0];
+            }
+            p512 = i512;
+            p1536 = i1536;
+        }
         // bins k (s = 0: j 0, 1 | 2, 3; s = 1: j 0, 1 | 2, 3) and 1024 + k
         WR2ST_32(aP01, pk[0], pk[1], 0, 4);
         WR2ST_32(aP23, pk[2], pk[3], 0, 4);
@@ -397,7 +454,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
             prow[1536] = p1536;
         }
         wave_lds_sync();
-        if (a.specMap) {  // magnitude / norm exponent (rare modes): one pass over the row in LDS (afx_melfused2.hip)
+        if (!CPLX && a.specMap) {  // magnitude / norm exponent (rare modes): one pass over the row in LDS (afx_melfused2.hip)
             for (int k = lane; k < 2049; k += 64) {
                 const float p = prow[k];
                 prow[k] = a.specMap == 1 ? sqrtf(p) : powf(p, a.normValue);
@@ -459,19 +516,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
             accA = hsum(sA);
             accB = hsum(sB);
         }
-        if (!SPLIT && a.postPow) {
+        if (!CPLX && !SPLIT && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
         }
         MEL4K_PHASE(6);
         // ---- 5. the next frame's samples have landed (requested half a frame and a frame ago); store ----
-        VM_WAIT_ALL();
+        if (pass == 0) {
+            VM_WAIT_ALL();
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            PIN(rlo[n1]);
-            PIN(rhi[n1]);
+            for (int n1 = 0; n1 < 16; ++n1) {
+                PIN(rlo[n1]);
+                PIN(rhi[n1]);
+            }
         }
-        float *orow = a.out + f * a.num;
+        float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
         if constexpr (SPLIT) {
             // slot results -> LDS (start of the wave's region: the image there is dead since stage 3, the power row
             // starts behind it), then every row is the sum of its segments in ascending bins
@@ -486,7 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
                 float sum = part[u & 255u] + part[(u >> 8) & 255u];
                 sum += part[(u >> 16) & 255u];
                 sum += part[u >> 24];
-                if (a.postPow) sum = powf(sum, a.normValue);
+                if (!CPLX && a.postPow) sum = powf(sum, a.normValue);
                 if (lane + 64 * h < a.num) orow[lane + 64 * h] = sum;
             }
         } else {
@@ -494,6 +553,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
             if (rowB >= 0) orow[rowB] = accB;
         }
         wave_lds_sync();  // the next frame overwrites the images / the power row
+
+        }  // pass
 
         if (++t == a.timeLength) {
             t = 0;
@@ -503,18 +564,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
 }
 
 struct Plan4 {
-    int variant, num, split;
+    int variant;  // 200 + index into kVariants: FIRST field (afx_melfused.hip: variant >= 200 -> this file)
+    int num, split;
     float4 *dTab;
     int *dMeta;
 };
 struct Variant {
     int tapsA, tapsB;
 };
-constexpr Variant kVariants[] = {{96, 32}, {128, 64}, {176, 8}};  // (afx_melfused4k.hip: the same three)
+constexpr Variant kVariants[] = {{96, 32}, {128, 64}, {176, 8}};
 static_assert(block_lds_bytes(96, 32) <= 163840 && block_lds_bytes(128, 64) <= 163840 && block_lds_bytes(176, 8) <= 163840,
               "tables + weights + 8 wave regions must fit the 160 KB LDS");
 
-template <int TA, int TB, int SHIFT, bool SPLIT>
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX>
 int launch_variant(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -547,32 +609,54 @@ int launch_variant(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     k.postPow = a->postPow;
     k.normValue = a->normValue;
     k.out = a->out;
+    k.outIm = a->outIm;
     k.num = p->num;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k2<TA, TB, SHIFT, SPLIT>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet[attrDev] = true;
     }
-    hipLaunchKernelGGL((k_stft_band_4k2<TA, TB, SHIFT, SPLIT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_band_4k2");
     return AFX_OK;
 }
 
-template <int TA, int TB>
-int launch(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
+template <int TA, int TB, bool CPLX>
+int launch_mode(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     // register re-use of the overlapping frames at the wrapper's default hop = N/4; other hops fetch every frame whole
     if (a->hop == 1024)
-        return p->split ? launch_variant<TA, TB, 4, true>(p, a, stream) : launch_variant<TA, TB, 4, false>(p, a, stream);
-    return p->split ? launch_variant<TA, TB, 0, true>(p, a, stream) : launch_variant<TA, TB, 0, false>(p, a, stream);
+        return p->split ? launch_variant<TA, TB, 4, true, CPLX>(p, a, stream) : launch_variant<TA, TB, 4, false, CPLX>(p, a, stream);
+    return p->split ? launch_variant<TA, TB, 0, true, CPLX>(p, a, stream) : launch_variant<TA, TB, 0, false, CPLX>(p, a, stream);
+}
+
+template <int TA, int TB>
+int launch(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
+    if (a->specMap >= 3) {  // complex results: S (3) or S^2 (4)
+        if (!a->outIm) return AFX_ERR_ARG;
+        return launch_mode<TA, TB, true>(p, a, stream);
+    }
+    return launch_mode<TA, TB, false>(p, a, stream);
 }
 
 }  // namespace
 
-extern "C" void afxk_mel4k2_destroy(void *plan) {
+// ---- the n_fft 4096 entry points of the fused dispatcher (afx_melfused.hip reads Plan4.variant >= 200 as "this file") ----
+extern "C" int afxk_mel4k_variant(int tapsA, int tapsB) {
+    for (int i = 0; i < 3; ++i)
+        if (tapsA <= kVariants[i].tapsA && tapsB <= kVariants[i].tapsB) return 200 + i;
+    return -1;
+}
+
+extern "C" int afxk_mel4k_kind(const void *plan) {
+    const Plan4 *p = static_cast<const Plan4 *>(plan);
+    return !p ? 0 : (p->split ? 202 : 201);
+}
+
+extern "C" void afxk_mel4k_destroy(void *plan) {
     Plan4 *p = static_cast<Plan4 *>(plan);
     if (!p) return;
     afxdev_free(p->dTab);
@@ -580,9 +664,9 @@ extern "C" void afxk_mel4k2_destroy(void *plan) {
     free(p);
 }
 
-// variant: index into {96+32, 128+64, 176+8} taps (afxk_mel4k_variant - 200)
-extern "C" int afxk_mel4k2_create(void **plan, int variant, const float *hWindow, const AfxBandPlan *band, void *stream) {
+extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream) {
     *plan = nullptr;
+    const int variant = afxk_mel4k_variant(band->tapsA, band->tapsB) - 200;  // index into {96+32, 128+64, 176+8} taps
     if (variant < 0 || variant > 2) return AFX_ERR_UNSUPPORTED;
     const int TA = kVariants[variant].tapsA, TB = kVariants[variant].tapsB;
     const int WP = wpitch(TA, TB);
@@ -594,7 +678,7 @@ extern "C" int afxk_mel4k2_create(void **plan, int variant, const float *hWindow
         free(tab);
         return AFX_ERR_NOMEM;
     }
-    p->variant = variant;
+    p->variant = 200 + variant;  // (first field: the dispatcher's tag)
     p->num = band->num;
     p->split = band->split;
     const double PI = 3.14159265358979323846;
@@ -652,21 +736,22 @@ extern "C" int afxk_mel4k2_create(void **plan, int variant, const float *hWindow
     if (st == AFX_OK) st = afxdev_stream_sync(stream);  // host staging buffers are freed below
     free(tab);
     if (st != AFX_OK) {
-        afxk_mel4k2_destroy(p);
+        afxk_mel4k_destroy(p);
         return st;
     }
     *plan = p;
     return AFX_OK;
 }
 
-// real-result modes only (specMap 0, 1, 2)
-extern "C" int afxk_mel4k2_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
+// specMap 0 / 1 / 2: real results; 3 / 4: complex results (out + outIm)
+extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
+    if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;  // fusions exist at n_fft 2048 only
     const Plan4 *p = static_cast<const Plan4 *>(plan);
-    if (!p || a->specMap >= 3) return AFX_ERR_ARG;
+    if (!p || a->specMap > 4) return AFX_ERR_ARG;
     switch (p->variant) {
-        case 0: return launch<96, 32>(p, a, stream);
-        case 1: return launch<128, 64>(p, a, stream);
-        case 2: return launch<176, 8>(p, a, stream);
+        case 200: return launch<96, 32>(p, a, stream);
+        case 201: return launch<128, 64>(p, a, stream);
+        case 202: return launch<176, 8>(p, a, stream);
         default: return AFX_ERR_UNSUPPORTED;
     }
 }

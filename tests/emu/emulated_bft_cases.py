@@ -18,7 +18,7 @@ vp, fp = C.c_void_p, C.POINTER(C.c_float)
 lib.bftObj_calTimeLength.restype = C.c_int
 lib.afx_emulated_launches.restype = C.c_int
 lib.afx_emulated_launches.argtypes = [C.c_char_p]
-KERNELS = (b"k_stft_mel_v2", b"k_stft_mel_cplx", b"k_stft_band_1k", b"k_stft_band_4k2", b"k_stft_band_4k")
+KERNELS = (b"k_stft_mel_v2", b"k_stft_mel_cplx", b"k_stft_band_1k", b"k_stft_band_4k2")
 
 
 def rel(got, want):

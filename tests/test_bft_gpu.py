@@ -164,9 +164,9 @@ def test_bft_nfft1024_fused_kernel_matches_compiled_reference(scale):
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("scale", [2, 3])   # mel, bark
 def test_bft_nfft4096_fused_kernel_matches_compiled_reference(scale):
-    """n_fft 4096 (the reference wrapper's default) runs k_stft_band_4k: the 2048-point real
-    transforms of the even and odd samples through the 16 x 16 x 4 pipeline, then a radix-2
-    combine.  hop 1024 (register re-use) and 900 (plain), power / magnitude / norm exponent,
+    """n_fft 4096 (the reference wrapper's default) runs k_stft_band_4k2: two 1024-point
+    halves of the packed frame through the 16 x 16 x 4 pipeline, lane-local combine + real-input
+    split.  hop 1024 (register re-use) and 900 (plain), power / magnitude / norm exponent,
     real and complex results."""
     x = cases.noise(70 + scale, 16000 * 3 + 55)
     for hop in (1024, 900):

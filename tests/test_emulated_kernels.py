@@ -32,7 +32,7 @@ STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cwt_td_fits", "afxk_cwt_
                                                      "afxk_melfused_destroy", "afxk_melfused_kind")]
 
 EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "cwt_emulated_td", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
-             "mel_emulated_melfused1k", "mel_emulated_melfused4k", "mel_emulated_4k2")
+             "mel_emulated_melfused1k", "mel_emulated_4k2")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
 
@@ -144,7 +144,7 @@ def test_headline_kernel_emulated_meets_the_golden_vectors(emulated):
 def test_fused_stft_kernels_emulated_meet_the_golden_vectors(emulated):
     """the other fused STFT -> filter-bank kernels, through the product's own dispatcher: n_fft 2048 complex results
     (k_stft_mel_cplx), n_fft 1024 (k_stft_band_1k: mel-80 magnitudes with area normalisation, mel-64 with temporal
-    features), n_fft 4096 (k_stft_band_4k: 60 octave bands), and the ragged-tail clip on the headline kernel"""
+    features), n_fft 4096 (k_stft_band_4k2: 60 octave bands), and the ragged-tail clip on the headline kernel"""
     out = _run(emulated, "emulated_bft_cases.py", ["cfg1_mel_complex", "tones_mel_mag_area", "mel_temporal", "octave_hann_style", "ragged_tail"])
     for k in ("k_stft_mel_cplx", "k_stft_band_1k", "k_stft_band_4k2", "k_stft_mel_v2"):
         assert k in out, out
