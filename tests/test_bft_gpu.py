@@ -169,7 +169,7 @@ def test_bft_nfft4096_fused_kernel_matches_compiled_reference(scale):
     split.  hop 1024 (register re-use) and 900 (plain), power / magnitude / norm exponent,
     real and complex results."""
     x = cases.noise(70 + scale, 16000 * 3 + 55)
-    for hop in (1024, 900):
+    for hop in (1024, 900, 1001):  # 1001: frames start on odd samples (8-byte loads at 4-byte alignment)
         for rt, dt, norm in ((1, 0, None), (1, 1, None), (1, 0, 0.5), (1, 1, 2.0), (0, 0, None), (0, 1, None)):
             r = ref.RefBFT(128, 12, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1,
                            slide_length=hop, scale_type=scale, style_type=0, normal_type=0, data_type=dt)
