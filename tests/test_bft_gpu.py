@@ -184,6 +184,26 @@ def test_bft_nfft4096_fused_kernel_matches_compiled_reference(scale):
                 o.set_data_norm_value(norm)
             got = o.bft(x, result_type=rt).T
             assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"scale{scale} hop{hop} rt{rt} dt{dt} norm{norm}")
+    # the device batch call on clips an ODD number of samples apart (row pitch n + 1: every second clip starts at 4-byte
+    # alignment), real and complex results, three clips across the wave's clip boundaries
+    import torch
+    n = 16000 * 2 + 4
+    xs = np.stack([cases.noise(170 + scale + i, n + 1) for i in range(3)])
+    xd = torch.from_numpy(xs).cuda()[:, :n]
+    for rt in (1, 0):
+        o = af.BFT(128, radix2_exp=12, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=1024,
+                   scale_type=af.SpectralFilterBankScaleType(scale), data_type=af.SpectralDataType.POWER)
+        o.set_result_type(rt)
+        out = o.bft_device(xd)
+        torch.cuda.synchronize()
+        r = ref.RefBFT(128, 12, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1, slide_length=1024,
+                       scale_type=scale, style_type=0, normal_type=0, data_type=0)
+        r.set_result_type(rt)
+        for i in range(3):
+            re, im = r.bft(np.ascontiguousarray(xs[i, :n]))
+            got = out[i].cpu().numpy() if rt == 1 else out[0][i].cpu().numpy() + 1j * out[1][i].cpu().numpy()
+            want = re if rt == 1 else re + 1j * im
+            assert_parity(got, want.reshape(got.shape) if want.shape != got.shape else want, TOL, f"batch scale{scale} rt{rt} clip{i} (odd row pitch)")
 
 
 def _bank32(num, n, sr, scale):
