@@ -184,8 +184,9 @@ class Cfg2:
               "one launch per step)")
     gather_choices = ("mfcc", "mel")
     # what binds the kernel (roofline.compute): the vector unit + LDS of every SIMD, not the memory system
-    bound = "issue/VALU"
-    bound_note = "vector unit 68 % + LDS 62 % busy on every SIMD; frac prices the kernel against HBM, which is not what limits it"
+    bound = "VALU+LDS"
+    bound_note = ("vector unit and LDS pipe each about 61 % busy and only partly overlapped; knock-out builds price LDS work like vector work "
+                  "and instruction issue at nothing (profiles/r05_ab_headline.txt); frac prices the kernel against HBM, which is not what limits it")
 
     def __init__(self, torch, af, dev, rank, clips):
         self.torch, self.af, self.clips = torch, af, clips
@@ -233,8 +234,9 @@ class Cfg4:
               "k_cwt_fwd_*, k_cwt_inv_cols256_nb<R> (44 narrow-band scales) + k_cwt_inv_cols256_nb2<4> (4 scales of 17-20 rows)")
     dtype = "f32 (36 of 84 scales: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ()
-    bound = "issue/VALU+LDS capacity"
-    bound_note = "the step is the sum of its launches: the LDS-resident f16 matrix kernel and the VALU/LDS-bound inverse transforms"
+    bound = "matrix+LDS"
+    bound_note = ("the step is the sum of its launches' work: the f16 matrix kernels (time-domain scales) and the LDS-bound narrow-band inverse "
+                  "transforms (LDS pipe 86 % busy) run at the same time and slow each other (profiles/r05_ab_cwt.txt)")
     GROUP = 32  # chunks per device call: the [84, 2^16] complex outputs (44 MB per chunk) are ring-buffered
 
     def __init__(self, torch, af, dev, rank, clips):
