@@ -586,6 +586,8 @@ extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *str
     if (p->variant >= 200) return afxk_mel4k_run(plan, a, stream);
     if (p->variant >= 100) return afxk_mel1k_run(plan, a, stream);
     if (a->specMap < 3) return afxk_mel2_run(p->v2, a, stream);  // real results: afx_melfused2.hip
+    // complex results: afx_melfused2.hip too (round 5), except the whole-row plan of the wide variant, whose instantiation spills there
+    if (!(a->cc || a->energy) && (p->variant == 0 || p->split)) return afxk_mel2_run(p->v2, a, stream);
     if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;
     switch (p->variant) {
         case 0:

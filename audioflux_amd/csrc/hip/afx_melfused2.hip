@@ -61,6 +61,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int NFFT = 2048;
 constexpr int MC = 1024;
 constexpr int WAVES = 12;                    // one workgroup per CU, 3 waves per SIMD (8: - 5 %, profiles/r02_ab_headline.txt)
+constexpr int WAVES_CPLX = 8;                // complex results: 17 more live values -- two waves per SIMD, 256 registers
+__host__ __device__ constexpr int waves_of(bool cplx) { return cplx ? WAVES_CPLX : WAVES; }
 constexpr int P1 = 72;                       // float2 per row of the exchange-1 image
 constexpr int PROW_OFF = 5120;               // byte offset of the power row in a wave's region
 constexpr int PROW_F = 1104;                 // 1025 bins + zero pad for the fixed-length band loops
@@ -78,7 +80,7 @@ __host__ __device__ constexpr int wpitch(int ta, int tb) { return ta + tb + 4; }
 __host__ __device__ constexpr int tab_bytes(int ta, int tb) { return T_BAND + 64 * wpitch(ta, tb) * 4; }
 constexpr int DCT_PITCH = 36;                // floats per lane of the DCT operand table (9 x 16 B: conflict-free b128)
 __host__ __device__ constexpr int block_lds_bytes(int ta, int tb, bool cc) {
-    return tab_bytes(ta, tb) + (cc ? 64 * DCT_PITCH * 4 : 0) + WAVES * WAVE_LDS;
+    return tab_bytes(ta, tb) + (cc ? 64 * DCT_PITCH * 4 : 0) + WAVES * WAVE_LDS;  // (complex results: fewer waves, less)
 }
 
 struct KArgs2 {
@@ -93,6 +95,7 @@ struct KArgs2 {
     int specMap, postPow;
     float normValue;
     float *out;            // [totalFrames, num]
+    float *outIm;          // CPLX: imaginary parts, same shape
     int num;
     // CC
     const float *dct;      // device [num, num] orthonormal DCT-II (row = coefficient)
@@ -143,6 +146,20 @@ __device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w, float &pk, float &p
     pq = y.x * y.x + y.y * y.y;
 }
 
+// complex results: the spectrum values themselves, x = X[k], y = conj(X[1024-k])
+__device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, v2 &x, v2 &y) {
+    const v2 e2 = pk_add_conj(A, B);
+    const v2 d = pk_sub_conj(A, B);
+    const v2 wo = cmul_mi(d, w);
+    x = e2 * 0.5f + wo;
+    y = e2 * 0.5f - wo;
+}
+// (re, im) of the requested complex result from a spectrum value c: S (sq = false) or S^2 (bft_algorithm.c:457-485)
+__device__ __forceinline__ void cplx_map(v2 c, bool sq, float &re, float &im) {
+    re = sq ? c.x * c.x - c.y * c.y : c.x;
+    im = sq ? 2.f * (c.x * c.y) : c.y;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -154,8 +171,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 // SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split)
 // CC: cepstra of the rows in the same launch (num = 128, ccNum <= 16, log10 rectification)
 // TEMPORAL: energy / rms / zcr of the windowed frame
-template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL>
-__global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
+// CPLX: complex results (specMap 3: S, 4: S^2): the imaginary parts wait in registers for a second pass of the bank
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL, bool CPLX = false>
+__global__ __launch_bounds__(waves_of(CPLX) * 64, CPLX ? 2 : 3) void k_stft_mel_v2(KArgs2 a) {
+    constexpr int NWV = waves_of(CPLX);
+    static_assert(!(CPLX && (CC || TEMPORAL)), "complex results: the bank only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -168,12 +188,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
     // ---- workgroup-shared tables -> LDS (once) -------------------------------------------
     {
         float4 *s4 = reinterpret_cast<float4 *>(smem);
-        for (int i = threadIdx.x; i < TABB / 16; i += WAVES * 64) s4[i] = a.tab[i];
+        for (int i = threadIdx.x; i < TABB / 16; i += NWV * 64) s4[i] = a.tab[i];
         if constexpr (CC) {
             // B operand of the cepstrum MFMAs: lane (coefficient fi = lane & 15, k-slot g = lane >> 4)
             // holds dct[fi][16 u + 4 g + c] at [lane][4 u + c]
             float *tabD = reinterpret_cast<float *>(smem + TABB);
-            for (int i = threadIdx.x; i < 64 * 32; i += WAVES * 64) {
+            for (int i = threadIdx.x; i < 64 * 32; i += NWV * 64) {
                 const int l = i >> 5, e = i & 31;
                 const int fi = l & 15, g = l >> 4;
                 tabD[l * DCT_PITCH + e] =
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
     const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
     const unsigned awr = T0 + T_BAND + 4 * WP * lane;
 
-    const long long gw = (long long)blockIdx.x * WAVES + wave;
+    const long long gw = (long long)blockIdx.x * NWV + wave;
     long long f = gw * a.framesPerWave;
     long long fEnd = f + a.framesPerWave;
     if (fEnd > a.totalFrames) fEnd = a.totalFrames;
@@ -419,7 +439,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
 
         // ---- 3. last radix-4 + real-input split -> spectrum values in registers --------------
         MEL_PHASE(4);
-        float pk[2][4], pq[2][4], p512;
+        float pk[2][4], pq[2][4], p512;  // |X|^2 (CPLX: real parts)
+        float ik[CPLX ? 2 : 1][4], iq[CPLX ? 2 : 1][4], i512 = 0.f;  // CPLX: imaginary parts
         {
             v4f zalo[2], zahi[2], zblo[2], zbhi[2], wlo[2], whi[2];
             RD128_S(1, zalo[0], aAlo, 0);
@@ -448,7 +469,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
                 if (s == 0) {
                     // lane 0: q = 0 mirrors itself and q' = 128 mirrors itself:
                     // (Z0, Z0) -> bins 0, 1024; (Z256, Z768); (Z128, Z896); (Z384, Z640); bin 512 below
-                    p512 = za2.x * za2.x + za2.y * za2.y;
+                    if constexpr (CPLX) cplx_map(v2{za2.x, -za2.y}, a.specMap == 4, p512, i512);  // X[512] = conj(Z[512])
+                    else p512 = za2.x * za2.x + za2.y * za2.y;
                     A2 = lane0 ? zb0 : za2;
                     A3 = lane0 ? zb1 : za3;
                     B0 = lane0 ? za0 : zb3;
@@ -456,13 +478,37 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
                     B2 = lane0 ? zb3 : zb1;
                     B3 = lane0 ? zb2 : zb0;
                 }
-                split_pair(A0, B0, lo2(wlo[s]), pk[s][0], pq[s][0]);
-                split_pair(A1, B1, hi2(wlo[s]), pk[s][1], pq[s][1]);
-                split_pair(A2, B2, lo2(whi[s]), pk[s][2], pq[s][2]);
-                split_pair(A3, B3, hi2(whi[s]), pk[s][3], pq[s][3]);
+                if constexpr (CPLX) {
+                    const bool sq = a.specMap == 4;
+                    const v2 AA[4] = {A0, A1, A2, A3}, BB[4] = {B0, B1, B2, B3};
+                    const v2 ww[4] = {lo2(wlo[s]), hi2(wlo[s]), lo2(whi[s]), hi2(whi[s])};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v2 x, y;
+                        split_pair_c(AA[j], BB[j], ww[j], x, y);
+                        cplx_map(x, sq, pk[s][j], ik[CPLX ? s : 0][j]);
+                        cplx_map(v2{y.x, -y.y}, sq, pq[s][j], iq[CPLX ? s : 0][j]);
+                    }
+                } else {
+                    split_pair(A0, B0, lo2(wlo[s]), pk[s][0], pq[s][0]);
+                    split_pair(A1, B1, hi2(wlo[s]), pk[s][1], pq[s][1]);
+                    split_pair(A2, B2, lo2(whi[s]), pk[s][2], pq[s][2]);
+                    split_pair(A3, B3, hi2(whi[s]), pk[s][3], pq[s][3]);
+                }
             }
         }
+#pragma unroll
+        for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
+        // (CPLX: the second pass writes the imaginary parts over the row the first pass has read)
+        if (CPLX && pass == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pk[i >> 2][i & 3] = ik[CPLX ? i >> 2 : 0][i & 3];
+                pq[i >> 2][i & 3] = iq[CPLX ? i >> 2 : 0][i & 3];
+            }
+            p512 = i512;
+        }
         WR2ST_32_S(4, aP01, pk[0][0], pk[0][1], 0, 4);
         WR2ST_32_S(4, aP23, pk[0][2], pk[0][3], 0, 4);
         WR2ST_32_S(4, aP01, pk[1][0], pk[1][1], 1, 5);
@@ -473,7 +519,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         WR2ST_32_S(4, aQs1, pq[1][1], pq[1][0], 8, 12);
         if (lane0) prow[512] = p512;
         wave_lds_sync();
-        if (a.specMap) {
+        if (!CPLX && a.specMap) {
             // magnitude / norm exponent (rare modes): one pass over the row in LDS.  (Applied to the 17 register values
             // before the stores, the two branches' results met the plain path's in different registers and the plain
             // path paid 17 moves per frame for it.)
@@ -541,7 +587,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
         }
-        if (!SPLIT && a.postPow) {
+        if (!CPLX && !SPLIT && a.postPow) {
             accA = powf(accA, a.normValue);
             accB = powf(accB, a.normValue);
         }
@@ -550,7 +596,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
         if constexpr (CC) {
             if (ccN == 16) cc_block(f - 16, 16);
         }
-        float *orow = a.out + f * a.num;
+        float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
         if constexpr (SPLIT) {
             // slot results -> LDS (start of the wave's region: the image there is dead since stage 3),
             // then every row is the sum of its segments in ascending bins
@@ -565,7 +611,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
                 float sum = part[u & 255u] + part[(u >> 8) & 255u];
                 sum += part[(u >> 16) & 255u];
                 sum += part[u >> 24];
-                if (a.postPow) sum = powf(sum, a.normValue);
+                if (!CPLX && a.postPow) sum = powf(sum, a.normValue);
                 if (lane + 64 * h < a.num) orow[lane + 64 * h] = sum;
             }
         } else {
@@ -577,6 +623,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void k_stft_mel_v2(KArgs2 a) {
             if (f + 1 == fEnd) cc_block(f + 1 - ccN, ccN);  // the wave's last rows (drains its last stores)
         }
         wave_lds_sync();  // the next frame overwrites the images / the power row
+
+        }  // pass
 
         if (++t == a.timeLength) {
             t = 0;
@@ -595,7 +643,7 @@ struct Variant {
 };
 constexpr Variant kVariants[] = {{48, 16}, {72, 32}};
 
-template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL>
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL, bool CPLX = false>
 int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -603,17 +651,18 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // one 12-wave workgroup is resident per CU; two rounds of workgroups keep the tail short while each
     // wave still streams a long contiguous run of frames (and re-uses 3/4 of every frame from registers)
-    long long waves = (long long)cus * WAVES * 2;  // 1 / 2 / 3 rounds measure the same (1.558 / 1.559 / 1.559 ms), 6: +1.2 %
+    constexpr int NWV = waves_of(CPLX);
+    long long waves = (long long)cus * NWV * 2;  // 1 / 2 / 3 rounds measure the same (1.558 / 1.559 / 1.559 ms), 6: +1.2 %
     long long fpw = (total + waves - 1) / waves;
     // long runs per wave (register re-use of the overlapping frames) once a round of workgroups is full; a call that
     // cannot fill one round -- the one-clip legacy entry points: 1000 frames -- is spread over all CUs instead
     // (16 frames in sequence per wave were 75 us of a 1000-frame call's 190, profiles/r05_legacy_phases.txt)
     if (fpw < 16) {
-        const long long oneRound = (total + (long long)cus * WAVES - 1) / ((long long)cus * WAVES);
+        const long long oneRound = (total + (long long)cus * NWV - 1) / ((long long)cus * NWV);
         fpw = oneRound < 16 ? oneRound : 16;
     }
     const long long usedWaves = (total + fpw - 1) / fpw;
-    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+    const long long blocks = (usedWaves + NWV - 1) / NWV;
 
     KArgs2 k;
     memset(&k, 0, sizeof(k));
@@ -630,6 +679,7 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     k.postPow = a->postPow;
     k.normValue = a->normValue;
     k.out = a->out;
+    k.outIm = a->outIm;
     k.num = p->num;
     k.dct = a->dct;
     k.ccNum = a->ccNum;
@@ -642,11 +692,11 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL, CPLX>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet[attrDev] = true;
     }
-    hipLaunchKernelGGL((k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL, CPLX>), dim3((unsigned)blocks), dim3(NWV * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_mel_v2");
     return AFX_OK;
@@ -670,6 +720,15 @@ int launch_hop(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
 template <int TA, int TB>
 int launch(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     const bool cc = a->cc != nullptr, tmp = a->energy != nullptr;
+    if (a->specMap >= 3) {  // complex results: S (3) or S^2 (4); hop N/4 with register re-use, any other hop plain
+        if (cc || tmp) return AFX_ERR_UNSUPPORTED;
+        if (!a->outIm) return AFX_ERR_ARG;
+        if (a->hop == 512)
+            return p->split ? launch_variant<TA, TB, 4, true, false, false, true>(p, a, stream)
+                            : launch_variant<TA, TB, 4, false, false, false, true>(p, a, stream);
+        return p->split ? launch_variant<TA, TB, 0, true, false, false, true>(p, a, stream)
+                        : launch_variant<TA, TB, 0, false, false, false, true>(p, a, stream);
+    }
     if (cc && tmp) return AFX_ERR_UNSUPPORTED;  // callers run the cepstra separately for temporal objects
     if (cc) {
         if (p->split || p->num != 128 || a->ccNum < 1 || a->ccNum > 16 || !a->dct || !a->out) return AFX_ERR_UNSUPPORTED;
@@ -771,10 +830,10 @@ extern "C" int afxk_mel2_create(void **plan, int variant, const float *hWindow, 
     return AFX_OK;
 }
 
-// real-result modes only (specMap 0, 1, 2); AFX_ERR_UNSUPPORTED when the requested fusion
+// specMap 0 / 1 / 2: real results, 3 / 4: complex results (out + outIm); AFX_ERR_UNSUPPORTED when the requested fusion
 // (cepstra / temporal features) does not apply to this plan
 extern "C" int afxk_mel2_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
     const Plan2 *p = static_cast<const Plan2 *>(plan);
-    if (!p || a->specMap >= 3) return AFX_ERR_ARG;
+    if (!p || a->specMap > 4) return AFX_ERR_ARG;
     return p->variant == 0 ? launch<48, 16>(p, a, stream) : launch<72, 32>(p, a, stream);
 }
