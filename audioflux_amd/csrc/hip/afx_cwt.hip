@@ -324,6 +324,71 @@ __global__ __launch_bounds__(256) void k_cwt_inv_rows512(CwtGeom g, const float2
     }
 }
 
+// forward pass 2 at L = 2^17 (rows of 512): the same wave-level 8 x 8 x 8 transform as k_cwt_inv_rows512 in place of the
+// size-generic radix-2 passes through LDS (k_cwt_fwd_rows: a workgroup barrier per stage, 48 % of its LDS cycles bank
+// conflicts -- profiles/r05_ab_cwt.txt).  One wave per row, four rows per wave; X[k2 = lane + 64 d2] leaves lane-contiguous.
+__global__ __launch_bounds__(256) void k_cwt_fwd_rows512(CwtGeom g, const float2 *__restrict__ A, float2 *__restrict__ Xt) {
+    __shared__ v2 ex[4][64 * RP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
+    const int k1base = blockIdx.x * (4 * ROWS_PER_WAVE) + wave;
+    const float2 *ac = A + (long long)blockIdx.y * L;
+    float2 *xo = Xt + (long long)blockIdx.y * L;
+    v2 *e = ex[wave];
+    float2 t1[8], t2[8];
+#pragma unroll
+    for (int d = 1; d < 8; ++d) {
+        t1[d] = g.fastTw[64 * d + lane];                 // W_512^(lane d)
+        t2[d] = g.fastTw[8 * 64 + 8 * d + (lane & 7)];   // W_64^(c d)
+    }
+    float2 xv[8], xvN[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) xvN[a] = ac[(long long)k1base * L2 + 64 * a + lane];
+#pragma unroll
+    for (int it = 0; it < ROWS_PER_WAVE; ++it) {
+        const int k1 = k1base + 4 * it;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) xv[a] = xvN[a];
+        if (it + 1 < ROWS_PER_WAVE) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) xvN[a] = ac[(long long)(k1 + 4) * L2 + 64 * a + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v2 r[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) r[a] = v2{xv[a].x, xv[a].y};
+        dft8(r);
+#pragma unroll
+        for (int d0 = 1; d0 < 8; ++d0) r[rev8(d0)] = cmul(r[rev8(d0)], v2{t1[d0].x, t1[d0].y});
+        {
+            const int b = lane >> 3, c = lane & 7;
+            wave_lds_order();
+#pragma unroll
+            for (int d0 = 0; d0 < 8; ++d0) e[(8 * d0 + c) * RP + b] = r[rev8(d0)];
+            wave_lds_order();
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) r[bb] = e[lane * RP + bb];
+        }
+        dft8(r);
+#pragma unroll
+        for (int d1 = 1; d1 < 8; ++d1) r[rev8(d1)] = cmul(r[rev8(d1)], v2{t2[d1].x, t2[d1].y});
+        {
+            const int d0 = lane >> 3, c = lane & 7;
+            wave_lds_order();
+#pragma unroll
+            for (int d1 = 0; d1 < 8; ++d1) e[(d0 + 8 * d1) * RP + c] = r[rev8(d1)];
+            wave_lds_order();
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) r[cc] = e[lane * RP + cc];
+        }
+        dft8(r);  // r[rev8(d2)] = X[k2 = lane + 64 d2]
+        float2 *out = xo + (long long)k1 * L2;
+#pragma unroll
+        for (int d2 = 0; d2 < 8; ++d2) out[64 * d2 + lane] = make_float2(r[rev8(d2)].x, r[rev8(d2)].y);
+    }
+}
+
 // second half of the 256-point column transform, shared by the two column kernels: r[a] holds
 // B[16 a + g][c] of thread (c, g); radix-16, twiddle, exchange, radix-16, conj, 1/L, crop, store
 __device__ __forceinline__ void cols256_twiddles(const CwtGeom &g, int gq, float2 (&t3)[16]) {
@@ -380,6 +445,50 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2
     const long long D = g.dataLength;
     cols256_finish(g, r, t3, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
                    outIm + ((long long)blockIdx.z * g.num + j) * D);
+}
+
+// forward pass 1 at L = 2^17 (columns of 256): thread (c = tid & 15, g = tid >> 4) holds the reflect-padded samples
+// n1 = 16 a + g of column c0 + c; 256 = 16 x 16 in registers with one exchange (the forward half of cols256_finish), then
+// the four-step twiddle W_L^(k1 n2).  Replaces the size-generic k_cwt_fwd_cols (eight radix-2 passes through LDS).
+__global__ __launch_bounds__(256) void k_cwt_fwd_cols256(CwtGeom g, const float *__restrict__ x, long long xStride,
+                                                         float2 *__restrict__ A) {
+    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]
+    constexpr int L2 = 512;
+    constexpr long long L = 1LL << 17;
+    const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
+    const int c0 = blockIdx.x * 16, m = c0 + c;
+    x += (long long)blockIdx.y * xStride;
+    A += (long long)blockIdx.y * L;
+    const int D = g.dataLength, P = g.pad;
+    float2 t3[16];
+    cols256_twiddles(g, gq, t3);
+    v2 r[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const long long n = (long long)(16 * a + gq) * L2 + m;
+        float v;  // cwt_algorithm.c:404-414
+        if (n < P) v = x[P - 1 - n];
+        else if (n < P + D) v = x[n - P];
+        else v = x[D - 1 - (n - P - D)];
+        r[a] = v2{v, 0.f};
+    }
+    dft16(r);  // r[rev4(p)] = sum_a s[16 a + g] W_16^(a p)
+#pragma unroll
+    for (int p = 1; p < 16; ++p) r[rev4(p)] = cmul(r[rev4(p)], v2{t3[p].x, t3[p].y});
+#pragma unroll
+    for (int p = 0; p < 16; ++p) ex[(p * 16 + gq) * 16 + c] = r[rev4(p)];
+    __syncthreads();
+    const int p = gq;  // this thread now owns k1 = p + 16 q of column c
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) r[gg] = ex[(p * 16 + gg) * 16 + c];
+    dft16(r);  // r[rev4(q)] = S[k1 = p + 16 q]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k1 = p + 16 * q;
+        const float2 w = twl(g.tw, (long long)k1 * m, L >> 1);
+        const v2 o = cmul(r[rev4(q)], v2{w.x, w.y});
+        A[(long long)k1 * L2 + m] = make_float2(o.x, o.y);
+    }
 }
 
 // Four-step twiddles W_L^(m1 (16 a + g)), a = 0 .. 15, from the two LDS tables (W_L^m = tlo[m & 255] thi[m >> 8]) in two
@@ -672,9 +781,21 @@ extern "C" int afxk_cwt_forward(const AfxCwtPlanDims *d, const float *tw, const 
     int st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_fwd_cols), ldsC);
     if (st == AFX_OK) st = lds_opt_in(reinterpret_cast<const void *>(k_cwt_fwd_rows), ldsR);
     if (st != AFX_OK) return st;
-    hipLaunchKernelGGL(k_cwt_fwd_cols, dim3(L2 / d->tileCols, chunks), dim3(256), ldsC,
-                       (hipStream_t)stream, g, x, xStride, reinterpret_cast<float2 *>(scratchA));
-    AFX_LAUNCH_CHECK("k_cwt_fwd_cols");
+    if (d->fastTw && d->r1 == 8 && d->r2 == 9 && !afxdev_no_fused()) {
+        hipLaunchKernelGGL(k_cwt_fwd_cols256, dim3(L2 / 16, chunks), dim3(256), 0, (hipStream_t)stream, g, x, xStride,
+                           reinterpret_cast<float2 *>(scratchA));
+        AFX_LAUNCH_CHECK("k_cwt_fwd_cols256");
+    } else {
+        hipLaunchKernelGGL(k_cwt_fwd_cols, dim3(L2 / d->tileCols, chunks), dim3(256), ldsC,
+                           (hipStream_t)stream, g, x, xStride, reinterpret_cast<float2 *>(scratchA));
+        AFX_LAUNCH_CHECK("k_cwt_fwd_cols");
+    }
+    if (d->fastTw && d->r1 == 8 && d->r2 == 9 && !afxdev_no_fused()) {
+        hipLaunchKernelGGL(k_cwt_fwd_rows512, dim3(L1 / (4 * ROWS_PER_WAVE), chunks), dim3(256), 0, (hipStream_t)stream, g,
+                           reinterpret_cast<const float2 *>(scratchA), reinterpret_cast<float2 *>(Xt));
+        AFX_LAUNCH_CHECK("k_cwt_fwd_rows512");
+        return AFX_OK;
+    }
     hipLaunchKernelGGL(k_cwt_fwd_rows, dim3(L1, chunks), dim3(256), ldsR, (hipStream_t)stream, g,
                        reinterpret_cast<const float2 *>(scratchA), reinterpret_cast<float2 *>(Xt));
     AFX_LAUNCH_CHECK("k_cwt_fwd_rows");
