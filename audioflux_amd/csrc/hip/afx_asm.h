@@ -166,7 +166,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigne
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
 #define RD64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #define RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-// (the same read through a pointer into a static __shared__ array)
+// (the same reads through a pointer into a static __shared__ array)
+#define RD64_P(dst, ptr, off) \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"((unsigned)(size_t)(ptr)), "n"(off) : "memory")
 #define RD128_P(dst, ptr, off) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((unsigned)(size_t)(ptr)), "n"(off) : "memory")
 // two rows (16 bytes per lane); offsets in units of 8 bytes

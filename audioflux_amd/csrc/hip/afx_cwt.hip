@@ -510,6 +510,21 @@ __device__ __forceinline__ void nb_fourstep_twiddles(const v2 *tlo, const v2 *th
     for (int a = 0; a < 16; ++a) wl[a] = (a & 3) ? cmul(A[a >> 2], B[a & 3]) : A[a >> 2];
 }
 
+// staged products z[0 .. R) of one row, read two at a time as 16 bytes (ds_read_b128: the rows start 16-byte aligned; read as
+// float2 the compiler pairs them into ds_read2_b64, which the LDS serves at HALF the rate -- these kernels are LDS-bound)
+typedef float nb_v4 __attribute__((ext_vector_type(4)));
+template <int RR>
+__device__ __forceinline__ void nb_row(const v2 *z, v2 (&out)[RR]) {
+    static_assert(RR % 2 == 0, "pairs");
+    const nb_v4 *z4 = reinterpret_cast<const nb_v4 *>(__builtin_assume_aligned(z, 16));
+#pragma unroll
+    for (int i = 0; i < RR / 2; ++i) {
+        const nb_v4 q = z4[i];
+        out[2 * i] = v2{q.x, q.y};
+        out[2 * i + 1] = v2{q.z, q.w};
+    }
+}
+
 // Narrow-band scales: every non-zero of the wavelet lies in R rows k2 in [lo, lo + R) of the
 // transposed spectrum (frequencies k = k1 + 256 k2), so the 512-point row transform of the first
 // pass is an R-term sum,
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
                                                             const float *__restrict__ bankT, int isDet,
                                                             int listBase, float *__restrict__ outRe,
                                                             float *__restrict__ outIm) {
-    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]
+    __shared__ __attribute__((aligned(16))) v2 ex[16 * 16 * 16];  // [p][g][c]
     static_assert(256 * R <= 16 * 16 * 16, "the staged products share the exchange buffer");
     v2 *zs = ex;                       // [k1][k2 - lo], consumed before the exchange starts
     __shared__ v2 tlo[256], thi[512];  // W_L^m (m < 256), W_L^(256 q) (q < 512)
@@ -568,7 +583,8 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
     v2 r[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        const v2 *z = zs + (16 * a + gq) * R;
+        v2 z[R];
+        nb_row<R>(zs + (16 * a + gq) * R, z);
         v2 acc = cmul(z[0], w5[0]);
 #pragma unroll
         for (int k2 = 1; k2 < R; ++k2) acc = cfma(z[k2], w5[k2], acc);
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
                                                              int listBase, float *__restrict__ outRe,
                                                              float *__restrict__ outIm) {
     constexpr int R = 16;
-    __shared__ v2 ex[16 * 16 * 16];  // [p][g][c]; before that the staged products of one block of rows
+    __shared__ __attribute__((aligned(16))) v2 ex[16 * 16 * 16];  // [p][g][c]; before that the staged products of one block of rows
     v2 *zs = ex;
     __shared__ v2 tlo[256], thi[512];  // W_L^m (m < 256), W_L^(256 q) (q < 512)
     constexpr int L2 = 512;
@@ -637,7 +653,8 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
         for (int k2 = 0; k2 < R; ++k2) w5[k2] = thi[((lo + k2) * m1) & (L2 - 1)];  // W_512^((lo + k2) m1)
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const v2 *z = zs + (16 * a + gq) * R;
+            v2 z[R];
+            nb_row<R>(zs + (16 * a + gq) * R, z);
             acc[a] = cmul(z[0], w5[0]);
 #pragma unroll
             for (int k2 = 1; k2 < R; ++k2) acc[a] = cfma(z[k2], w5[k2], acc[a]);
@@ -656,7 +673,8 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
         nb_fourstep_twiddles(tlo, thi, m1, gq, wl);  // W_L^(m1 k1), m1 k1 < L
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const v2 *z = zs + (16 * a + gq) * R2;
+            v2 z[R2];
+            nb_row<R2>(zs + (16 * a + gq) * R2, z);
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) acc[a] = cfma(z[k2], w5[k2], acc[a]);
             r[a] = cmul(acc[a], wl[a]);

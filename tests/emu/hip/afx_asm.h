@@ -116,6 +116,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigne
 #define RD64(dst, addr, off) (afx_emu_ds(), __builtin_memcpy(&(dst), afx_emu_lds + (addr) + (off), 8), afx_emu_ds())
 #define RD128(dst, addr, off) (afx_emu_ds(), __builtin_memcpy(&(dst), afx_emu_lds + (addr) + (off), 16), afx_emu_ds())
 #define RD128_P(dst, ptr, off) __builtin_memcpy(&(dst), reinterpret_cast<const char *>(ptr) + (off), 16)
+#define RD64_P(dst, ptr, off) __builtin_memcpy(&(dst), reinterpret_cast<const char *>(ptr) + (off), 8)
 #define WR2_64(addr, d0, d1, o0, o1) \
     (__builtin_memcpy(afx_emu_lds + (addr) + 8 * (o0), &(d0), 8), __builtin_memcpy(afx_emu_lds + (addr) + 8 * (o1), &(d1), 8))
 #define WR2ST_32(addr, d0, d1, o0, o1) \
