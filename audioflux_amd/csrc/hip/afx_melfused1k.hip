@@ -21,12 +21,20 @@
 
 namespace {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2 lo2(v4f q) { return v2{q.x, q.y}; }
+__device__ __forceinline__ v2 hi2(v4f q) { return v2{q.z, q.w}; }
+
 constexpr int NFFT = 1024;
 constexpr int MC = 512;            // complex FFT length
-constexpr int RP = 9;              // exchange pitch (float2) of the 64 x 8 images
-constexpr int EX_F2 = 64 * RP;     // 576 float2; also holds the 512-float2 natural image
-constexpr int PROW_F = 640;        // 513 bins + zero pad for the fixed-length band loops
-constexpr int WAVE_LDS_BYTES = EX_F2 * 8;  // 4608; the power row (2560 B) aliases the image
+constexpr int RP = 10;             // exchange pitch (float2) of the 64 x 8 images: 80-byte rows are read as four ds_read_b128 free
+                                   // of conflicts (pitch 9: eight half-rate ds_read2_b64) and the first exchange's stores lose
+                                   // their two-way conflict (tools/proto_fft1024_v2.py: conflicts())
+constexpr int EX_F2 = 64 * RP;     // 640 float2; also holds the 512-float2 natural image
+constexpr int PROW_OFF = 3072;     // byte offset of the power row in a wave's region: bins 0..512 alias the images' tail,
+constexpr int PROW_F = 640;        // the zero pad of the fixed-length band loops (bins 513..639) lies behind them
+constexpr int WAVE_LDS_BYTES = PROW_OFF + PROW_F * 4;  // 5632
+static_assert(EX_F2 * 8 <= PROW_OFF + 513 * 4, "the images must end before the zero pad");
 constexpr int WAVES = 16;          // one workgroup per CU: 4 waves per SIMD
 constexpr int TAB_WIN_F2 = 512;    // (w[2n], w[2n+1])
 constexpr int TAB_TW1_F2 = 8 * 64; // W_512^(lane d0)
@@ -34,6 +42,7 @@ constexpr int TAB_TW2_F2 = 8 * 8;  // W_64^(c d1)
 constexpr int TAB_TW3_F2 = 320;    // 0.5 * W_1024^k, k <= 256
 constexpr int TAB_F2 = TAB_WIN_F2 + TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
 constexpr int TAB_BYTES = TAB_F2 * 8;
+constexpr int T_WIN = 0, T_TW1 = T_WIN + 8 * TAB_WIN_F2, T_TW2 = T_TW1 + 8 * TAB_TW1_F2, T_TW3 = T_TW2 + 8 * TAB_TW2_F2;  // byte offsets
 __host__ __device__ constexpr int wpitch(int ta, int tb) { return ta + tb + 4; }
 __host__ __device__ constexpr int block_lds_bytes(int ta, int tb) {
     return TAB_BYTES + 64 * wpitch(ta, tb) * 4 + WAVES * WAVE_LDS_BYTES;
@@ -91,24 +100,46 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     constexpr int WP = wpitch(TA, TB);
-    v2 *tabWin = reinterpret_cast<v2 *>(smem);
-    v2 *tabTw1 = tabWin + TAB_WIN_F2;
-    v2 *tabTw2 = tabTw1 + TAB_TW1_F2;
-    v2 *tabTw3 = tabTw2 + TAB_TW2_F2;
-    float *tabW = reinterpret_cast<float *>(smem + TAB_BYTES);
-    v2 *ex = reinterpret_cast<v2 *>(smem + TAB_BYTES + 64 * WP * 4 + wave * WAVE_LDS_BYTES);
-    float *prow = reinterpret_cast<float *>(ex);
-
-    for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = reinterpret_cast<const v2 *>(a.win2)[i];
-    for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = reinterpret_cast<const v2 *>(a.tw1)[i];
-    for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = reinterpret_cast<const v2 *>(a.tw3)[i];
-    for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
-    if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = reinterpret_cast<const v2 *>(a.tw2)[threadIdx.x];
+    unsigned char *wreg = smem + TAB_BYTES + 64 * WP * 4 + wave * WAVE_LDS_BYTES;
+    float *prow = reinterpret_cast<float *>(wreg + PROW_OFF);
+    {
+        v2 *tabWin = reinterpret_cast<v2 *>(smem + T_WIN);
+        v2 *tabTw1 = reinterpret_cast<v2 *>(smem + T_TW1);
+        v2 *tabTw2 = reinterpret_cast<v2 *>(smem + T_TW2);
+        v2 *tabTw3 = reinterpret_cast<v2 *>(smem + T_TW3);
+        float *tabW = reinterpret_cast<float *>(smem + TAB_BYTES);
+        for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = reinterpret_cast<const v2 *>(a.win2)[i];
+        for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = reinterpret_cast<const v2 *>(a.tw1)[i];
+        for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = reinterpret_cast<const v2 *>(a.tw3)[i];
+        for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
+        if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = reinterpret_cast<const v2 *>(a.tw2)[threadIdx.x];
+        // zero pad behind bin 512 (the fixed-length band loops read it with zero weights): behind the images, written once
+        for (int i = 513 + lane; i < PROW_F; i += 64) prow[i] = 0.f;
+    }
     __syncthreads();
+
+    // ---- per-lane constants: loop-invariant LDS byte addresses of the hand-issued reads and writes (afx_asm.h) ----
+    const int b = lane >> 3, c = lane & 7;
+    const bool lane0 = (lane == 0);
+    const unsigned T0 = lds_addr(smem), W0 = lds_addr(wreg);
+    const unsigned aWin = T0 + T_WIN + 8 * lane;       // window row r: + 512 r;  W_512^(lane d0): + T_TW1 + 512 d0
+    const unsigned aTw2 = T0 + T_TW2 + 8 * c;          // W_64^(c d1): + 64 d1
+    const unsigned aT3 = T0 + T_TW3 + 8 * lane;        // 0.5 W_1024^(lane + 64 j): + 512 j
+    const unsigned aE1w = W0 + 8 * (c * RP + b);       // first exchange, row 8 d0 + c: + 64 RP d0
+    const unsigned aE2w = W0 + 8 * (b * RP + c);       // second exchange (d0 = lane >> 3), row d0 + 8 d1: + 64 RP d1
+    const unsigned aEr = W0 + 8 * RP * lane;           // a lane's row of either image: 4 x 16 bytes
+    const unsigned aN = W0 + 8 * lane;                 // natural image Z[lane + 64 d2]: + 512 d2
+    const unsigned aNm = W0 + 8 * (320 - lane);        // Z[512 - lane - 64 j]: + 512 (3 - j)   (lane 0, j = 0: see below)
+    const unsigned aMid = W0 + 2048;                   // Z[256]
+    const unsigned aT3m = T0 + T_TW3 + 2048;           // 0.5 W_1024^256
+    const unsigned R = W0 + PROW_OFF;
+    const unsigned aP = R + 4 * lane;                  // bins lane + 64 j: + 256 j
+    const unsigned aQ = R + 4 * (320 - lane);          // bins 512 - lane - 64 j: + 256 (3 - j)
 
     const int startA = a.meta[lane], startB = a.meta[64 + lane];
     const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
-    const float4 *wrow = reinterpret_cast<const float4 *>(tabW + lane * WP);
+    const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
+    const unsigned awr = T0 + TAB_BYTES + 4 * WP * lane;
 
     const long long gw = (long long)blockIdx.x * WAVES + wave;
     long long f = gw * a.framesPerWave;
@@ -139,9 +170,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
 
     for (; f < fEnd; ++f) {
         v2 v[8];
-        // ---- 1. window; start fetching the next frame ------------------------------------
+        // ---- 1. window (the first half is used while the second lands); start fetching the next frame ----------
+        {
+            v2 wv[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = raw[r] * tabWin[64 * r + lane];
+            for (int r = 0; r < 8; ++r) RD64(wv[r], aWin, T_WIN + 512 * r);
+            LDS_WAIT_N(4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                PIN(wv[r]);
+                v[r] = raw[r] * wv[r];
+            }
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int r = 4; r < 8; ++r) {
+                PIN(wv[r]);
+                v[r] = raw[r] * wv[r];
+            }
+        }
         if (f + 1 < fEnd) {
             int tn = t + 1, cn = clip;
             if (tn == a.timeLength) {
@@ -159,57 +205,96 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
             }
             if (whole) fetch(pn, 0);
         }
-        // ---- 2. 512-point complex FFT, 8 x 8 x 8 ------------------------------------------
+        // ---- 2. 512-point complex FFT, 8 x 8 x 8: twiddles requested ahead of the butterflies that hide them ----
         {
-            v2 t1[8];
+            v2 tw[8];
 #pragma unroll
-            for (int d = 1; d < 8; ++d) t1[d] = tabTw1[64 * d + lane];
+            for (int d = 1; d < 8; ++d) RD64(tw[d], aWin, T_TW1 + 512 * d);
             dft8(v);  // v[rev8(d0)]
-            const int b = lane >> 3, c = lane & 7;
-            ex[c * RP + b] = v[0];
 #pragma unroll
-            for (int d0 = 1; d0 < 8; ++d0) ex[(8 * d0 + c) * RP + b] = cmul(v[rev8(d0)], t1[d0]);
-            wave_lds_order();
+            for (int i = 0; i < 8; ++i) PIN(v[i]);
+            LDS_WAIT_N(0);
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) v[bb] = ex[lane * RP + bb];
-            wave_lds_order();
+            for (int d = 1; d < 8; ++d) PIN(tw[d]);
+            v2 o[8];
+            o[0] = v[0];
+#pragma unroll
+            for (int d0 = 1; d0 < 8; ++d0) o[d0] = cmul(v[rev8(d0)], tw[d0]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) WR2_64(aE1w, o[2 * g], o[2 * g + 1], 8 * RP * (2 * g), 8 * RP * (2 * g + 1));
         }
+        wave_lds_order();
         {
-            v2 t2[8];
-            const int d0 = lane >> 3, c = lane & 7;
+            v4f rq[4];
+            v2 tw[8];
 #pragma unroll
-            for (int d = 1; d < 8; ++d) t2[d] = tabTw2[8 * d + c];
+            for (int i = 0; i < 4; ++i) RD128(rq[i], aEr, 16 * i);
+#pragma unroll
+            for (int d = 1; d < 8; ++d) RD64(tw[d], aTw2, 64 * d);
+            LDS_WAIT_N(7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                PIN(rq[i]);
+                v[2 * i] = lo2(rq[i]);
+                v[2 * i + 1] = hi2(rq[i]);
+            }
             dft8(v);  // v[rev8(d1)], lane = 8 d0 + c
-            ex[d0 * RP + c] = v[0];
 #pragma unroll
-            for (int d1 = 1; d1 < 8; ++d1) ex[(d0 + 8 * d1) * RP + c] = cmul(v[rev8(d1)], t2[d1]);
-            wave_lds_order();
+            for (int i = 0; i < 8; ++i) PIN(v[i]);
+            LDS_WAIT_N(0);
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) v[cc] = ex[lane * RP + cc];
-            wave_lds_order();
+            for (int d = 1; d < 8; ++d) PIN(tw[d]);
+            v2 o[8];
+            o[0] = v[0];
+#pragma unroll
+            for (int d1 = 1; d1 < 8; ++d1) o[d1] = cmul(v[rev8(d1)], tw[d1]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) WR2_64(aE2w, o[2 * g], o[2 * g + 1], 8 * RP * (2 * g), 8 * RP * (2 * g + 1));
+        }
+        wave_lds_order();
+        {
+            v4f rq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) RD128(rq[i], aEr, 16 * i);
+            LDS_WAIT_N(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                PIN(rq[i]);
+                v[2 * i] = lo2(rq[i]);
+                v[2 * i + 1] = hi2(rq[i]);
+            }
         }
         dft8(v);  // v[rev8(d2)] = Z[lane + 64 d2]
         // ---- 3. natural-order image, conjugate pairs (k, 512-k), spectrum values ---------
 #pragma unroll
-        for (int d2 = 0; d2 < 8; ++d2) ex[lane + 64 * d2] = v[rev8(d2)];
+        for (int g = 0; g < 4; ++g) WR2_64(aN, v[rev8(2 * g)], v[rev8(2 * g + 1)], 64 * (2 * g), 64 * (2 * g + 1));
         wave_lds_order();
         float pk[5], pq[5];
         float pkI[CPLX ? 5 : 1], pqI[CPLX ? 5 : 1];
         {
-            v2 za[4], zb[4], w3[4];
+            v2 za[4], zb[4], w3[4], zm, wm;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = lane + 64 * j;
-                za[j] = ex[k];
-                zb[j] = ex[(MC - k) & (MC - 1)];  // k = 0 pairs with itself: X[0] and X[512]
-                w3[j] = tabTw3[k];
+                RD64(za[j], aN, 512 * j);
+                RD64(zb[j], aNm, 512 * (3 - j));  // Z[512 - k], k = lane + 64 j
+                RD64(w3[j], aT3, 512 * j);
             }
-            const v2 zm = ex[256], wm = tabTw3[256];  // bin 256 pairs with itself
+            RD64(zm, aMid, 0);  // bin 256 pairs with itself
+            RD64(wm, aT3m, 0);
+            LDS_WAIT_N(8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (CPLX) split_pair_c(za[j], zb[j], w3[j], a.specMap == 4, pk[j], pkI[CPLX ? j : 0], pq[j], pqI[CPLX ? j : 0]);
-                else split_pair(za[j], zb[j], w3[j], pk[j], pq[j]);
+                if (j == 2) LDS_WAIT_N(0);
+                PIN(za[j]);
+                PIN(zb[j]);
+                PIN(w3[j]);
+                // k = 0 pairs with itself (X[0] and X[512]); lane 0's read of slot 512 is past the image and discarded
+                const v2 zbj = (j == 0) ? (lane0 ? za[0] : zb[0]) : zb[j];
+                if (CPLX) split_pair_c(za[j], zbj, w3[j], a.specMap == 4, pk[j], pkI[CPLX ? j : 0], pq[j], pqI[CPLX ? j : 0]);
+                else split_pair(za[j], zbj, w3[j], pk[j], pq[j]);
             }
+            PIN(zm);
+            PIN(wm);
             if (CPLX) split_pair_c(zm, zm, wm, a.specMap == 4, pk[4], pkI[CPLX ? 4 : 0], pq[4], pqI[CPLX ? 4 : 0]);
             else split_pair(zm, zm, wm, pk[4], pq[4]);
         }
@@ -227,56 +312,75 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 pq[i] = powf(pq[i], a.normValue);
             }
         }
-        wave_lds_order();  // every lane has its bins in registers; ex becomes the power row
+        // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite its tail
 #pragma unroll
         for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
-            if (pass == 1) wave_lds_order();
+            if (CPLX && pass == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = lane + 64 * j;
-                prow[k] = (CPLX && pass) ? pkI[CPLX ? j : 0] : pk[j];
-                prow[MC - k] = (CPLX && pass) ? pqI[CPLX ? j : 0] : pq[j];
+                for (int i = 0; i < 5; ++i) {
+                    pk[i] = pkI[CPLX ? i : 0];
+                    pq[i] = pqI[CPLX ? i : 0];
+                }
             }
-            if (lane == 0) prow[256] = (CPLX && pass) ? pkI[CPLX ? 4 : 0] : pk[4];
-            // zero pad behind bin 512: the fixed-length band loops read it with zero weights
-            prow[513 + lane] = 0.f;
-            if (lane < PROW_F - 513 - 64) prow[513 + 64 + lane] = 0.f;
+            WR2ST_32(aP, pk[0], pk[1], 0, 1);
+            WR2ST_32(aP, pk[2], pk[3], 2, 3);
+            WR2ST_32(aQ, pq[3], pq[2], 0, 1);
+            WR2ST_32(aQ, pq[1], pq[0], 2, 3);
+            if (lane0) prow[256] = pk[4];
             wave_lds_order();
 
-            // ---- 4. banded filter bank (see afx_melfused.hip) ----------------------------
+            // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset ds_read_b64; the NEXT
+            //         block of four quads is requested before this block's values are waited for (see afx_melfused2.hip)
             float accA, accB;
             {
-                const v2 *pa = reinterpret_cast<const v2 *>(prow + startA);
-                const v2 *pb = reinterpret_cast<const v2 *>(prow + startB);
+                constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 4, NB = (QT + BLK - 1) / BLK;
                 v2 sA = {0.f, 0.f}, sB = {0.f, 0.f};
-                constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 4;
-#pragma unroll
-                for (int q0 = 0; q0 < QT; q0 += BLK) {
-                    float4 w[BLK];
-                    v2 p0[BLK], p1[BLK];
+                v4f w[2][BLK];
+                v2 p0[2][BLK], p1[2][BLK];
+                auto request = [&](int blk, v4f (&wq)[BLK], v2 (&q0v)[BLK], v2 (&q1v)[BLK]) {
 #pragma unroll
                     for (int i = 0; i < BLK; ++i) {
-                        const int q = q0 + i;
-                        if (q < QT) {
-                            w[i] = wrow[q];
-                            const v2 *src = q < QA ? pa + 2 * q : pb + 2 * (q - QA);
-                            p0[i] = src[0];
-                            p1[i] = src[1];
+                        const int q = blk * BLK + i;
+                        if (q >= QT) continue;
+                        RD128(wq[i], awr, 16 * q);
+                        if (q < QA) {
+                            RD64(q0v[i], apa, 16 * q);
+                            RD64(q1v[i], apa, 16 * q + 8);
+                        } else {
+                            RD64(q0v[i], apb, 16 * (q - QA));
+                            RD64(q1v[i], apb, 16 * (q - QA) + 8);
                         }
                     }
+                };
+                request(0, w[0], p0[0], p1[0]);
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    const int cur = blk & 1;
+                    const int nextQuads = (blk + 1 < NB) ? ((QT - (blk + 1) * BLK) < BLK ? (QT - (blk + 1) * BLK) : BLK) : 0;
+                    if (blk + 1 < NB) request(blk + 1, w[cur ^ 1], p0[cur ^ 1], p1[cur ^ 1]);
+                    if (nextQuads == 4) LDS_WAIT_N(12);
+                    else if (nextQuads == 3) LDS_WAIT_N(9);
+                    else if (nextQuads == 2) LDS_WAIT_N(6);
+                    else if (nextQuads == 1) LDS_WAIT_N(3);
+                    else LDS_WAIT_N(0);
 #pragma unroll
                     for (int i = 0; i < BLK; ++i) {
-                        const int q = q0 + i;
-                        if (q < QT) {
-                            if (q < QA) {
-                                sA += v2{w[i].x, w[i].y} * p0[i];
-                                sA += v2{w[i].z, w[i].w} * p1[i];
-                            } else {
-                                sB += v2{w[i].x, w[i].y} * p0[i];
-                                sB += v2{w[i].z, w[i].w} * p1[i];
-                            }
+                        if (blk * BLK + i >= QT) continue;
+                        PIN(w[cur][i]);
+                        PIN(p0[cur][i]);
+                        PIN(p1[cur][i]);
+                        if (blk * BLK + i < QA) {
+                            sA += lo2(w[cur][i]) * p0[cur][i];
+                            sA += hi2(w[cur][i]) * p1[cur][i];
+                        } else {
+                            sB += lo2(w[cur][i]) * p0[cur][i];
+                            sB += hi2(w[cur][i]) * p1[cur][i];
                         }
                     }
+                    // the sums of this block before the next block's requests: left free, the scheduler sinks every
+                    // multiply-add behind the last request and keeps all the operands alive (212-532 bytes of scratch per lane)
+                    PIN(sA);
+                    PIN(sB);
                 }
                 accA = sA.x + sA.y;
                 accB = sB.x + sB.y;
@@ -290,7 +394,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
             if (rowA >= 0) orow[rowA] = accA;
             if (rowB >= 0) orow[rowB] = accB;
         }
-        wave_lds_order();  // the next frame overwrites ex / prow
+        // (the band stage's reads have returned -- its last wait is lgkmcnt(0) -- before the next frame's images overwrite the row)
 
         if (++t == a.timeLength) {
             t = 0;

@@ -61,7 +61,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int NFFT = 2048;
 constexpr int MC = 1024;
 constexpr int WAVES = 12;                    // one workgroup per CU, 3 waves per SIMD (8: - 5 %, profiles/r02_ab_headline.txt)
-constexpr int WAVES_CPLX = 8;                // complex results: 17 more live values -- two waves per SIMD, 256 registers
+constexpr int WAVES_CPLX = 12;               // complex results (8 while the imaginary parts waited in registers for their pass)
 __host__ __device__ constexpr int waves_of(bool cplx) { return cplx ? WAVES_CPLX : WAVES; }
 constexpr int P1 = 72;                       // float2 per row of the exchange-1 image
 constexpr int PROW_OFF = 5120;               // byte offset of the power row in a wave's region
@@ -171,9 +171,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split)
 // CC: cepstra of the rows in the same launch (num = 128, ccNum <= 16, log10 rectification)
 // TEMPORAL: energy / rms / zcr of the windowed frame
-// CPLX: complex results (specMap 3: S, 4: S^2): the imaginary parts wait in registers for a second pass of the bank
+// CPLX: complex results (specMap 3: S, 4: S^2): a second row in LDS holds the imaginary parts for a second pass of the bank
 template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL, bool CPLX = false>
-__global__ __launch_bounds__(waves_of(CPLX) * 64, CPLX ? 2 : 3) void k_stft_mel_v2(KArgs2 a) {
+__global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a) {
     constexpr int NWV = waves_of(CPLX);
     static_assert(!(CPLX && (CC || TEMPORAL)), "complex results: the bank only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -497,17 +497,23 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, CPLX ? 2 : 3) void k_stft_mel_
                 }
             }
         }
-#pragma unroll
-        for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
-        // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
-        // (CPLX: the second pass writes the imaginary parts over the row the first pass has read)
-        if (CPLX && pass == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                pk[i >> 2][i & 3] = ik[CPLX ? i >> 2 : 0][i & 3];
-                pq[i >> 2][i & 3] = iq[CPLX ? i >> 2 : 0][i & 3];
-            }
-            p512 = i512;
+        // every read of the images has returned (lgkmcnt(0) above): the power row may overwrite their tail.
+        // CPLX: the imaginary parts' row goes to the START of the wave's region, dead until the next frame's first exchange
+        // (held in registers for a second pass over one row they cost 17 registers across the first pass: two waves per
+        // SIMD); its zero pad lies inside the images and is rewritten with it
+        if constexpr (CPLX) {
+            WR2ST_32(aP01 - PROW_OFF, ik[0][0], ik[0][1], 0, 4);
+            WR2ST_32(aP23 - PROW_OFF, ik[0][2], ik[0][3], 0, 4);
+            WR2ST_32(aP01 - PROW_OFF, ik[1][0], ik[1][1], 1, 5);
+            WR2ST_32(aP01 - PROW_OFF, ik[1][2], ik[1][3], 9, 13);
+            WR2ST_32(aQs1 - PROW_OFF, iq[0][1], iq[0][0], 9, 13);
+            WR2ST_32(aQ23 - PROW_OFF, iq[0][3], iq[0][2], 0, 4);
+            WR2ST_32(aQs1 - PROW_OFF, iq[1][3], iq[1][2], 0, 4);
+            WR2ST_32(aQs1 - PROW_OFF, iq[1][1], iq[1][0], 8, 12);
+            float *prowI = reinterpret_cast<float *>(wreg);
+            if (lane0) prowI[512] = i512;
+            prowI[1025 + lane] = 0.f;
+            if (lane < PROW_F - 1025 - 64) prowI[1025 + 64 + lane] = 0.f;
         }
         WR2ST_32_S(4, aP01, pk[0][0], pk[0][1], 0, 4);
         WR2ST_32_S(4, aP23, pk[0][2], pk[0][3], 0, 4);
@@ -519,6 +525,9 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, CPLX ? 2 : 3) void k_stft_mel_
         WR2ST_32_S(4, aQs1, pq[1][1], pq[1][0], 8, 12);
         if (lane0) prow[512] = p512;
         wave_lds_sync();
+#pragma unroll
+        for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
+        const unsigned bpa = (CPLX && pass) ? apa - PROW_OFF : apa, bpb = (CPLX && pass) ? apb - PROW_OFF : apb;
         if (!CPLX && a.specMap) {
             // magnitude / norm exponent (rare modes): one pass over the row in LDS.  (Applied to the 17 register values
             // before the stores, the two branches' results met the plain path's in different registers and the plain
@@ -547,11 +556,11 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, CPLX ? 2 : 3) void k_stft_mel_
                     if (q >= QT) continue;
                     RD128_S(3, wq[i], awr, 16 * q);
                     if (q < QA) {
-                        RD64_S(3, q0v[i], apa, 16 * q);
-                        RD64_S(3, q1v[i], apa, 16 * q + 8);
+                        RD64_S(3, q0v[i], bpa, 16 * q);
+                        RD64_S(3, q1v[i], bpa, 16 * q + 8);
                     } else {
-                        RD64_S(3, q0v[i], apb, 16 * (q - QA));
-                        RD64_S(3, q1v[i], apb, 16 * (q - QA) + 8);
+                        RD64_S(3, q0v[i], bpb, 16 * (q - QA));
+                        RD64_S(3, q1v[i], bpb, 16 * (q - QA) + 8);
                     }
                 }
             };
@@ -583,6 +592,10 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, CPLX ? 2 : 3) void k_stft_mel_
                         sB += hi2(w[cur][i]) * p1[cur][i];
                     }
                 }
+                if constexpr (CPLX) {  // this block's sums before the next block's requests: left free, the multiply-adds of the
+                    PIN(sA);           // complex instantiations sink behind the last request with every operand alive (240-256
+                    PIN(sB);           // registers + 264 bytes of scratch -> 182)
+                }
             }
             accA = sA.x + sA.y;
             accB = sB.x + sB.y;
@@ -600,7 +613,8 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, CPLX ? 2 : 3) void k_stft_mel_
         if constexpr (SPLIT) {
             // slot results -> LDS (start of the wave's region: the image there is dead since stage 3),
             // then every row is the sum of its segments in ascending bins
-            float *part = reinterpret_cast<float *>(wreg);
+            float *part = reinterpret_cast<float *>(wreg + (CPLX ? PROW_F * 4 : 0));  // (CPLX: behind the imaginary parts' row)
+            static_assert(PROW_F * 4 + 129 * 4 <= PROW_OFF, "segment sums must fit between the two rows");
             part[lane] = accA;
             part[64 + lane] = accB;
             if (lane0) part[128] = 0.f;

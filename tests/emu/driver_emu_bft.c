@@ -1,8 +1,8 @@
 /* The fused STFT -> filter-bank kernels on the emulated library for ThreadSanitizer: n_fft 1024 (k_stft_band_1k), n_fft 4096
- * (k_stft_band_4k), n_fft 2048 complex (k_stft_mel_cplx) and real + MFCC (k_stft_mel_v2), a few frames each.  The 1k / 4k /
- * complex kernels exchange data through LDS with plain loads and stores between explicit ordering points, so an exchange
- * without such a point is a reported race.  (k_stft_mel_v2 issues its DS instructions by hand and relies on their issue
- * order; the emulation makes each a rendezvous, so it cannot race here by construction.)  Exit 0 and no report = pass. */
+ * (k_stft_band_4k2), n_fft 2048 complex and real + MFCC (k_stft_mel_v2), a few frames each.  All three issue their DS
+ * instructions by hand and rely on their issue order; the emulation makes each a rendezvous, so those cannot race here by
+ * construction -- what ThreadSanitizer watches are the plain loads and stores around them (table fills, zero pads, segment
+ * sums, staging) between explicit ordering points.  Exit 0 and no report = pass. */
 #include <stdio.h>
 #include <stdlib.h>
 

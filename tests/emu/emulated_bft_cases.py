@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden BFT cases through the fused STFT -> filter-bank kernels as emulated device code (tests/emu): n_fft 2048 real
-(k_stft_mel_v2) and complex (k_stft_mel_cplx), n_fft 1024 (k_stft_band_1k), n_fft 4096 (k_stft_band_4k), with the
+and complex (k_stft_mel_v2), n_fft 1024 (k_stft_band_1k), n_fft 4096 (k_stft_band_4k2), with the
 product's own dispatcher and launchers.  Usage: emulated_bft_cases.py <case> ...; a case the dispatcher sends to the
 size-generic kernels (not emulated) is reported and fails.  AFX_LIB = the library tests/test_emulated_kernels.py builds."""
 import ctypes as C
@@ -18,7 +18,7 @@ vp, fp = C.c_void_p, C.POINTER(C.c_float)
 lib.bftObj_calTimeLength.restype = C.c_int
 lib.afx_emulated_launches.restype = C.c_int
 lib.afx_emulated_launches.argtypes = [C.c_char_p]
-KERNELS = (b"k_stft_mel_v2", b"k_stft_mel_cplx", b"k_stft_band_1k", b"k_stft_band_4k2")
+KERNELS = (b"k_stft_mel_v2", b"k_stft_band_1k", b"k_stft_band_4k2")
 
 
 def rel(got, want):

@@ -4,4 +4,6 @@
 namespace {
 alignas(16) unsigned char smem[160 * 1024];
 }
+static unsigned char *const afx_emu_lds = smem;
+static inline void afx_emu_ds() { emu::wave_barrier(); }
 #include "../../audioflux_amd/csrc/hip/afx_melfused1k.hip"
