@@ -192,6 +192,15 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 #define GLD128_S(dst, voff, sbase, off) \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off) : "memory")
 #define VM_WAIT_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// dword stores to wave-uniform bases (SGPR pairs) + per-lane byte offset: no 64-bit address registers.  The s_nop covers
+// "VALU writes SGPR -> VMEM reads that SGPR: 5 wait states" (v_readfirstlane / v_readlane of a restored SGPR right before the
+// statement: the compiler's hazard recogniser does not look inside inline assembly -- found as a write fault at address 0)
+#define GST32_S(voff, data, sbase) \
+    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(data), "s"(sbase) : "memory")
+#define GST32X2_S(voff, d0, sbase0, d1, sbase1)                                                                          \
+    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2\n\tglobal_store_dword %0, %3, %4" ::"v"(voff), "v"(d0), "s"(sbase0), \
+                 "v"(d1), "s"(sbase1)                                                                                     \
+                 : "memory")
 // 16-byte load served by the L2, never by this CU's L1 (rows another lane of the wave stored a moment ago)
 #define LOAD_SC1_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
 

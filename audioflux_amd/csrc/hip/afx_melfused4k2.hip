@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
@@ -70,6 +71,11 @@ struct KArgs4 {
     float *out;            // [totalFrames, num]
     float *outIm;          // complex results (specMap 3 / 4): imaginary parts, same shape
     int num;
+    // STFT instantiations (afxk_stft4k): bins instead of bank rows
+    const float *window;   // device [4096], natural order
+    int mode;              // AFX_SPEC_*
+    int binLo, binCount;   // bins binLo .. binLo + binCount - 1 are stored; above 2048: conjugate mirrors
+    long long outPitch;    // floats between output rows
 };
 
 // orders this wave's LDS stores before its later LDS loads of other lanes' data (afx_melfused2.hip)
@@ -132,12 +138,30 @@ __device__ __forceinline__ void cplx_map(v2 c, bool sq, float &re, float &im) {
     im = sq ? 2.f * (c.x * c.y) : c.y;
 }
 
+// what an STFT instantiation stores for a spectrum value (the maps of afx_stft.hip)
+__device__ __forceinline__ void stft_map(float re, float im, int mode, float normValue, float &v0, float &v1) {
+    v1 = 0.f;
+    switch (mode) {
+        case AFX_SPEC_COMPLEX: v0 = re; v1 = im; break;
+        case AFX_SPEC_POWER: v0 = re * re + im * im; break;
+        case AFX_SPEC_MAG: v0 = sqrtf(re * re + im * im); break;
+        case AFX_SPEC_SQUARE: v0 = re * re - im * im; v1 = 2.f * re * im; break;
+        case AFX_SPEC_MAG_NORM: v0 = powf(sqrtf(re * re + im * im), normValue); break;
+        case AFX_SPEC_PHASE: v0 = atan2f(im, re < 1e-16f ? 1e-16f : re); break;
+        default: v0 = powf(re * re + im * im, normValue); break;  // AFX_SPEC_POWER_NORM
+    }
+}
+
 // SHIFT: hop = 256 * SHIFT samples -> the next frame's register image is this one moved down by SHIFT float4,
 //   only SHIFT new float4 per lane are fetched (0: every frame fetched whole)
 // SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split)
 // CPLX: complex results (specMap 3: S, 4: S^2): the imaginary parts wait in registers for a second pass of the bank
-template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX>
+// STFT: no bank -- the spectrum values themselves (CPLX form, specMap 3) go to memory through stft_map: the STFT object's
+//   full complex spectrum, the linear-scale bin slices, the reassignment object's transforms (afxk_stft4k; frames inside the clip);
+//   MAPPED: any AFX_SPEC_* map, otherwise the complex values as they are; FULL: all 4096 bins are stored (no range checks)
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
+    static_assert(!STFT || (CPLX && !SPLIT && TA == 0 && TB == 0), "STFT instantiations: complex values, no bank");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -149,7 +173,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
     // ---- workgroup-shared tables -> LDS (once) -------------------------------------------
     {
         float4 *s4 = reinterpret_cast<float4 *>(smem);
-        for (int i = threadIdx.x; i < TABB / 16; i += WAVES * 64) s4[i] = a.tab[i];
+        for (int i = threadIdx.x + (STFT ? T_TW1 / 16 : 0); i < TABB / 16; i += WAVES * 64) s4[i] = a.tab[i];
+        if constexpr (STFT) {
+            // the window of each half in pair layout from the object's natural-order window (afxk_mel4k_create builds the same)
+            v2 *winT = reinterpret_cast<v2 *>(smem + T_WIN);
+            for (int i = threadIdx.x; i < 2048; i += WAVES * 64) {
+                const int h = i >> 10, n1 = (i >> 6) & 15, l = i & 63;
+                const int m = 64 * n1 + l;
+                winT[1024 * h + 128 * (n1 >> 1) + 2 * l + (n1 & 1)] = v2{a.window[4 * m + 2 * h], a.window[4 * m + 2 * h + 1]};
+            }
+        }
         for (int i = 2049 + lane; i < PROW_F; i += 64) prow[i] = 0.f;  // zero pad, never overwritten
     }
     __syncthreads();
@@ -177,8 +210,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
     const unsigned aQ23 = R + 4 * (lane == 0 ? 640 : 256 - lane);      // s = 0 slots 3, 2 | lane 0: (640, 896)
     const bool lane0 = (lane == 0);
 
-    const int startA = a.meta[lane], startB = a.meta[64 + lane];
-    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const int startA = STFT ? 0 : a.meta[lane], startB = STFT ? 0 : a.meta[64 + lane];
+    const int rowA = STFT ? -1 : a.meta[128 + lane], rowB = STFT ? -1 : a.meta[192 + lane];
     const unsigned seg0 = SPLIT ? (unsigned)a.meta[256 + lane] : 0u, seg1 = SPLIT ? (unsigned)a.meta[320 + lane] : 0u;
     const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
     const unsigned awr = T0 + T_BAND + 4 * WP * lane;
@@ -386,7 +419,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
                             const v2 zk = EA[i] + to, zk1 = EA[i] - to;  // Z[k], Z[k + 1024]
                             const v2 zm = EB[i] - u, zn = EB[i] + u;     // Z[1024 - k], Z[2048 - k]
                             if constexpr (CPLX) {
-                                const bool sq = a.specMap == 4;
+                                const bool sq = !STFT && a.specMap == 4;
                                 v2 x, y;
                                 split_pair_c(zk, zn, ws[j], x, y);
                                 cplx_map(x, sq, pk[i], ik[CPLX ? i : 0]);
@@ -406,8 +439,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
                             if constexpr (CPLX) {
                                 v2 x, y;
                                 split_pair_c(z5, z15, v2{HH, -HH}, x, y);
-                                cplx_map(x, a.specMap == 4, p512, i512);
-                                cplx_map(v2{y.x, -y.y}, a.specMap == 4, p1536, i1536);
+                                cplx_map(x, !STFT && a.specMap == 4, p512, i512);
+                                cplx_map(v2{y.x, -y.y}, !STFT && a.specMap == 4, p1536, i1536);
                             } else {
                                 split_pair(z5, z15, v2{HH, -HH}, p512, p1536);
                             }
@@ -416,6 +449,67 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
                 }
             }
         }
+        if constexpr (STFT) {
+            // ---- 4'. the spectrum itself: lanes hold consecutive bins, every store instruction covers 256 contiguous bytes.
+            //      The next frame's samples have landed (requested half a frame and a frame ago): waited for before the first store
+            VM_WAIT_ALL();
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                PIN(rlo[n1]);
+                PIN(rhi[n1]);
+            }
+            MEL4K_PHASE(6);
+            // the frame's rows through wave-uniform base pointers (the frame number is the same in every lane, which the compiler
+            // cannot see) + ONE byte-offset register per family of bins: 128 sixty-four-bit addresses per lane otherwise, and
+            // 300 - 440 B of scratch.  ore / oim point at bin 0 of the row.
+            const long long row = f * a.outPitch - a.binLo;
+            auto uniform = [](const float *p) {
+                const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+            };
+            const float *const ore = uniform(a.out + row), *const oim = uniform(a.outIm ? a.outIm + row : a.out + row);
+            const bool two = !MAPPED || a.mode == AFX_SPEC_SQUARE;
+            const int lo = a.binLo, hi = a.binLo + a.binCount;
+            // bin = cb + (byte offset of the lane) / 4; the value, or for mirrors its conjugate (stftObj_stft keeps all 4096 bins)
+            auto put = [&](bool pred, int bin, unsigned voff, int cb, float re, float im) {
+                if (!FULL) pred = pred && bin >= lo && bin < hi;
+                if (pred) {
+                    float v0 = re, v1 = im;
+                    if constexpr (MAPPED) stft_map(re, im, a.mode, a.normValue, v0, v1);
+                    if (two) GST32X2_S(voff, v0, ore + cb, v1, oim + cb);
+                    else GST32_S(voff, v0, ore + cb);
+                }
+            };
+            const unsigned vUp = 4u * lane, vDn = 4u * (64 - lane);          // bins c + lane / c + 64 - lane
+            const unsigned vUp23 = lane0 ? 4u * 128 : 4u * (lane + 512);      // slots 2, 3 of s = 0: lane 0 carries base 128 (bins 128, 384)
+            const unsigned vDn23 = lane0 ? 4u * 448 : 4u * (64 - lane);       //   ... mirrored: c + 64 - 512 - lane | lane 0: c + 64 - 128
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool sp = (i == 2 || i == 3);                          // the slots lane 0 uses for base 128
+                const int c = 64 * (i >> 2) + 256 * (i & 3);                 // k = c + lane (sp, lane 0: c - 384)
+                const int k = sp ? (lane0 ? c - 384 : c + lane) : c + lane;
+                const unsigned up = sp ? vUp23 : vUp, dn = sp ? vDn23 : vDn;
+                const int cu = sp ? c - 512 : c;                             // k = cu + up / 4
+                const int cd = -64 - c;                                      // -k = cd + dn / 4   (sp, lane 0: 448 - 64 - c = -(c - 384))
+                const bool kpos = !(i == 0) || !lane0;                       // k > 0
+                const float re0 = pk[i], im0 = ik[CPLX ? i : 0], re1 = pn[i], im1 = in_[CPLX ? i : 0];
+                const float re2 = pq[i], im2 = iq[CPLX ? i : 0], re3 = pm[i], im3 = im_[CPLX ? i : 0];
+                put(true, k, up, cu, re0, im0);                     // X[k]
+                put(kpos, 4096 - k, dn, 4096 + cd, re0, -im0);      //   mirror 4096 - k
+                put(true, 2048 - k, dn, 2048 + cd, re1, im1);       // X[2048 - k]
+                put(kpos, 2048 + k, up, 2048 + cu, re1, -im1);      //   mirror 2048 + k
+                put(true, 1024 + k, up, 1024 + cu, re2, im2);       // X[1024 + k]
+                put(true, 3072 - k, dn, 3072 + cd, re2, -im2);      //   mirror 3072 - k
+                put(true, 1024 - k, dn, 1024 + cd, re3, im3);       // X[1024 - k]  (k = 0: bin 1024 twice, this one last -- as the power row has it)
+                put(true, 3072 + k, up, 3072 + cu, re3, -im3);      //   mirror 3072 + k
+            }
+            put(lane0, 512, vUp, 512, p512, i512);
+            put(lane0, 3584, vUp, 3584, p512, -i512);
+            put(lane0, 1536, vUp, 1536, p1536, i1536);
+            put(lane0, 2560, vUp, 2560, p1536, -i1536);
+            wave_lds_sync();  // the next frame overwrites the images
+        } else {
 #pragma unroll
         for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite it
@@ -555,12 +649,123 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
         wave_lds_sync();  // the next frame overwrites the images / the power row
 
         }  // pass
+        }  // !STFT
 
         if (++t == a.timeLength) {
             t = 0;
             ++clip;
         }
     }
+}
+
+// host: the transform's tables at their byte offsets in the blob (twiddles in double, rounded once); window == nullptr leaves
+// the window part alone (STFT instantiations build it in the kernel from the object's device window)
+void fill_transform_tables(float *tab, const float *hWindow) {
+    const double PI = 3.14159265358979323846;
+    // window of each half and W_1024^(lane k1) in pair layout: entry (n1, lane) at float2 index 128 (n1 >> 1) + 2 lane + (n1 & 1)
+    float *win = tab + T_WIN / 4, *tw1 = tab + T_TW1 / 4, *tw2 = tab + T_TW2 / 4, *twc = tab + T_TWC / 4, *tws = tab + T_TWS / 4;
+    for (int n1 = 0; n1 < 16; ++n1)
+        for (int l = 0; l < 64; ++l) {
+            const int at = 2 * (128 * (n1 >> 1) + 2 * l + (n1 & 1));
+            const int m = 64 * n1 + l;
+            for (int h = 0; h < 2 && hWindow; ++h) {
+                win[2048 * h + at] = hWindow[4 * m + 2 * h];
+                win[2048 * h + at + 1] = hWindow[4 * m + 2 * h + 1];
+            }
+            const double ang = -2.0 * PI * (double)(n1 * l) / MC;
+            tw1[at] = (float)cos(ang);
+            tw1[at + 1] = (float)sin(ang);
+        }
+    for (int m = 0; m < 4; ++m)
+        for (int j = 0; j < 16; ++j) {
+            const double ang = -2.0 * PI * (double)(m * j) / 64.0;
+            tw2[(TW2_PITCH / 4) * m + 2 * j] = (float)cos(ang);
+            tw2[(TW2_PITCH / 4) * m + 2 * j + 1] = (float)sin(ang);
+        }
+    // W_2048^bin and 0.5 W_4096^bin of slot (s, lane, m); 16-byte halves swapped when bit 3 of lane is set
+    for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < 64; ++l)
+            for (int m = 0; m < 4; ++m) {
+                int bin = l + 64 * s + 256 * m;
+                if (s == 0 && l == 0 && m >= 2) bin = m == 2 ? 128 : 384;  // lane 0 carries the self-mirrored base
+                const int at = 2 * (4 * (64 * s + l) + 2 * ((m >> 1) ^ ((l >> 3) & 1)) + (m & 1));
+                const double ac = -2.0 * PI * (double)bin / 2048.0, as = -2.0 * PI * (double)bin / NFFT;
+                twc[at] = (float)cos(ac);
+                twc[at + 1] = (float)sin(ac);
+                tws[at] = (float)(0.5 * cos(as));
+                tws[at + 1] = (float)(0.5 * sin(as));
+            }
+}
+
+// the STFT instantiations' twiddle blob (bytes [T_TW1, tab_bytes(0, 0)) are read), one device copy per device, never freed
+const float4 *stft_tables(void *stream) {
+    static std::mutex mu;
+    static float4 *dTab[AFX_MAX_DEVICES] = {};
+    const int dev = afxdev_current_device();
+    if (dev < 0 || dev >= AFX_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dTab[dev]) {
+        const size_t bytes = (size_t)tab_bytes(0, 0);
+        float *h = static_cast<float *>(calloc(bytes, 1));
+        float4 *d = nullptr;
+        if (!h) return nullptr;
+        fill_transform_tables(h, nullptr);
+        int st = afxdev_malloc(reinterpret_cast<void **>(&d), bytes);
+        if (st == AFX_OK) st = afxdev_h2d(d, h, bytes, stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(stream);
+        free(h);
+        if (st != AFX_OK) {
+            afxdev_free(d);
+            return nullptr;
+        }
+        dTab[dev] = d;
+    }
+    return dTab[dev];
+}
+
+template <int SHIFT, bool MAPPED, bool FULL>
+int launch_stft(const AfxStftArgs *a, const float4 *tab, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long waves = (long long)cus * WAVES * 2;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 16) {  // (launch_variant: a call that cannot fill one round of workgroups is spread over all CUs)
+        const long long oneRound = (total + (long long)cus * WAVES - 1) / ((long long)cus * WAVES);
+        fpw = oneRound < 16 ? oneRound : 16;
+    }
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+    KArgs4 k;
+    memset(&k, 0, sizeof(k));
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.tab = tab;
+    k.specMap = 3;
+    k.normValue = a->normValue;
+    k.out = a->outRe;
+    k.outIm = a->outIm;
+    k.window = a->window;
+    k.mode = a->mode;
+    k.binLo = a->binLo;
+    k.binCount = a->binCount;
+    k.outPitch = a->outPitch ? a->outPitch : (long long)a->binCount;
+    constexpr size_t lds = (size_t)block_lds_bytes(0, 0);
+    static bool attrSet[AFX_MAX_DEVICES] = {};
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev]) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k2<0, 0, SHIFT, false, true, true, MAPPED, FULL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet[attrDev] = true;
+    }
+    hipLaunchKernelGGL((k_stft_band_4k2<0, 0, SHIFT, false, true, true, MAPPED, FULL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_band_4k2<stft>");
+    return AFX_OK;
 }
 
 struct Plan4 {
@@ -681,40 +886,7 @@ extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBan
     p->variant = 200 + variant;  // (first field: the dispatcher's tag)
     p->num = band->num;
     p->split = band->split;
-    const double PI = 3.14159265358979323846;
-    // window of each half and W_1024^(lane k1) in pair layout: entry (n1, lane) at float2 index 128 (n1 >> 1) + 2 lane + (n1 & 1)
-    float *win = tab + T_WIN / 4, *tw1 = tab + T_TW1 / 4, *tw2 = tab + T_TW2 / 4, *twc = tab + T_TWC / 4, *tws = tab + T_TWS / 4;
-    for (int n1 = 0; n1 < 16; ++n1)
-        for (int l = 0; l < 64; ++l) {
-            const int at = 2 * (128 * (n1 >> 1) + 2 * l + (n1 & 1));
-            const int m = 64 * n1 + l;
-            for (int h = 0; h < 2; ++h) {
-                win[2048 * h + at] = hWindow[4 * m + 2 * h];
-                win[2048 * h + at + 1] = hWindow[4 * m + 2 * h + 1];
-            }
-            const double ang = -2.0 * PI * (double)(n1 * l) / MC;  // twiddles in double, rounded once
-            tw1[at] = (float)cos(ang);
-            tw1[at + 1] = (float)sin(ang);
-        }
-    for (int m = 0; m < 4; ++m)
-        for (int j = 0; j < 16; ++j) {
-            const double ang = -2.0 * PI * (double)(m * j) / 64.0;
-            tw2[(TW2_PITCH / 4) * m + 2 * j] = (float)cos(ang);
-            tw2[(TW2_PITCH / 4) * m + 2 * j + 1] = (float)sin(ang);
-        }
-    // W_2048^bin and 0.5 W_4096^bin of slot (s, lane, m); 16-byte halves swapped when bit 3 of lane is set
-    for (int s = 0; s < 2; ++s)
-        for (int l = 0; l < 64; ++l)
-            for (int m = 0; m < 4; ++m) {
-                int bin = l + 64 * s + 256 * m;
-                if (s == 0 && l == 0 && m >= 2) bin = m == 2 ? 128 : 384;  // lane 0 carries the self-mirrored base
-                const int at = 2 * (4 * (64 * s + l) + 2 * ((m >> 1) ^ ((l >> 3) & 1)) + (m & 1));
-                const double ac = -2.0 * PI * (double)bin / 2048.0, as = -2.0 * PI * (double)bin / NFFT;
-                twc[at] = (float)cos(ac);
-                twc[at + 1] = (float)sin(ac);
-                tws[at] = (float)(0.5 * cos(as));
-                tws[at + 1] = (float)(0.5 * sin(as));
-            }
+    fill_transform_tables(tab, hWindow);
     float *wL = tab + T_BAND / 4;
     for (int l = 0; l < 64; ++l) {
         for (int t = 0; t < band->tapsA; ++t) wL[(size_t)l * WP + t] = band->wA[(size_t)t * 64 + l];
@@ -754,4 +926,23 @@ extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream
         case 202: return launch<176, 8>(p, a, stream);
         default: return AFX_ERR_UNSUPPORTED;
     }
+}
+
+// n_fft 4096 without a bank (afxk_stft, afx_stft.hip): every frame inside its clip (no padding), no temporal features.
+// AFX_ERR_UNSUPPORTED: the caller runs the size-generic kernel.
+extern "C" int afxk_stft4k(const AfxStftArgs *a, void *stream) {
+    if (a->radix2Exp != 12 || a->bandStart || a->energy || a->binLo < 0 || a->binCount < 1 || a->binLo + a->binCount > NFFT ||
+        a->padLeft != 0 || a->hop < 1 || (long long)(a->timeLength - 1) * a->hop + NFFT > a->dataLength)
+        return AFX_ERR_UNSUPPORTED;
+    const bool two = (a->mode == AFX_SPEC_COMPLEX || a->mode == AFX_SPEC_SQUARE);
+    if (!a->outRe || (two && !a->outIm)) return AFX_ERR_ARG;
+    if ((long long)a->batch * a->timeLength <= 0) return AFX_OK;
+    const float4 *tab = stft_tables(stream);
+    if (!tab) return AFX_ERR_UNSUPPORTED;
+    const bool s4 = a->hop == 1024;  // register re-use of the overlapping frames at the wrapper's default hop
+    if (a->mode == AFX_SPEC_COMPLEX) {
+        if (a->binLo == 0 && a->binCount == NFFT) return s4 ? launch_stft<4, false, true>(a, tab, stream) : launch_stft<0, false, true>(a, tab, stream);
+        return s4 ? launch_stft<4, false, false>(a, tab, stream) : launch_stft<0, false, false>(a, tab, stream);
+    }
+    return s4 ? launch_stft<4, true, false>(a, tab, stream) : launch_stft<0, true, false>(a, tab, stream);
 }

@@ -175,7 +175,7 @@ __global__ void k_stft_generic(AfxStftArgs a) {
 // and stores its bins straight from registers -- lanes hold consecutive bins, so every store
 // instruction covers 256 contiguous bytes.  Frames that touch the clip's ends (padding modes) or
 // start unaligned are gathered sample by sample through the same index map as the generic kernel.
-constexpr int SW = 8;  // waves per workgroup
+constexpr int SW = 12;  // waves per workgroup: 148 - 162 registers keep three waves per SIMD (8: 198 -> 12: 208 M frames/s, profiles/r05_ab_other.txt)
 
 // CPLX: mode AFX_SPEC_COMPLEX only (the stores are the spectrum itself); the general maps are
 // compiled for n_fft 2048 only (at 4096 their 40 unrolled bin slots exceed the unroller's budget
@@ -359,6 +359,8 @@ int launch_stft_wave(const AfxStftArgs *a, const float2 *tab, long long frames, 
 
 }  // namespace
 
+extern "C" int afxk_stft4k(const AfxStftArgs *a, void *stream);  // afx_melfused4k2.hip
+
 extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     if (a->radix2Exp < 1 || a->radix2Exp > 14) {
         afxdev_set_error("stft: fftLength 2^%d is outside the supported 2..16384", a->radix2Exp);
@@ -370,15 +372,21 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
         afxdev_set_error("stft: %lld frames in one launch", frames);
         return AFX_ERR_UNSUPPORTED;
     }
-    // n_fft 2048: one wave per frame (191 vs 111 M frames/s for the full complex spectrum).  The
+    // n_fft 2048: one wave per frame (208 vs 111 M frames/s for the full complex spectrum).  The
     // n_fft 4096 instantiation (<12, true>: two transforms + combine, 40 bin slots per lane) needs
-    // 252 VGPRs + 620 B/lane of scratch and measured SLOWER than this kernel (38 vs 57 M frames/s):
-    // not dispatched.
+    // 252 VGPRs + 620 B/lane of scratch in 8-wave workgroups (38 M frames/s) or 412 registers in 4-wave
+    // workgroups (47 M) and measured SLOWER than the size-generic kernel (58 M) both ways: not dispatched.
     const bool cplx = a->mode == AFX_SPEC_COMPLEX;
     if (a->radix2Exp == 11 && !a->bandStart && !a->energy && a->binLo >= 0 && !afxdev_no_fused()) {
         if (const float2 *tab = wave_tables())
             return cplx ? launch_stft_wave<11, true>(a, tab, frames, stream)
                         : launch_stft_wave<11, false>(a, tab, frames, stream);
+    }
+    // n_fft 4096 (the wrapper's default): the transform of the n_fft 4096 bank kernel storing its spectrum (afx_melfused4k2.hip),
+    // when every frame lies inside its clip; AFX_ERR_UNSUPPORTED = not its case
+    if (a->radix2Exp == 12 && !afxdev_no_fused()) {
+        const int st = afxk_stft4k(a, stream);
+        if (st != AFX_ERR_UNSUPPORTED) return st;
     }
     const int N = 1 << a->radix2Exp;
     int threads = N / 4;

@@ -128,5 +128,8 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigne
 #define LOAD_SC1_B128(dst, ptr) ((dst) = *(ptr))
 #define GLD128_S(dst, voff, sbase, off) __builtin_memcpy(&(dst), reinterpret_cast<const char *>(sbase) + (voff) + (off), 16)
 #define VM_WAIT_N(n) ((void)0)
+#define GST32_S(voff, data, sbase) \
+    (*reinterpret_cast<float *>(const_cast<char *>(reinterpret_cast<const char *>(sbase)) + (voff)) = (data))
+#define GST32X2_S(voff, d0, sbase0, d1, sbase1) (GST32_S(voff, d0, sbase0), GST32_S(voff, d1, sbase1))
 
 #endif /* AFX_ASM_H */
