@@ -150,6 +150,15 @@ def test_fused_stft_kernels_emulated_meet_the_golden_vectors(emulated):
         assert k in out, out
 
 
+def test_n4096_spectrum_kernel_emulated_against_float64(emulated):
+    """afxk_stft4k / k_stft_band_4k2<STFT> (round 5: the STFT object, the linear-scale slices and the reassignment object's
+    transforms at n_fft 4096): every store family of the epilogue -- bins k, 2048 - k, 1024 +- k of a lane's eight slots, lane
+    0's self-mirrored base, the conjugate mirrors above 2048 -- with and without range checks, plain and mapped, against
+    numpy's float64 FFT; on the device the same kernel meets the compiled reference (tests/test_stft_gpu.py)"""
+    out = _run(emulated, "emulated_stft4k.py", [])
+    assert "emulated k_stft_band_4k2 4" in out and "mirrors are exact conjugates" in out, out[-800:]
+
+
 def test_f32_matrix_core_octave_kernels_emulated(emulated):
     """calibration of the f32 MFMA model: k_cqt_octave_mfma / _mfma_w (AFX_CQT_F32=1; measured on the device in round 1)"""
     n = _launches(_run(emulated, "emulated_cqt.py", ["c84_32k_area", "power_max"], "AFX_CQT_F32=1"))
