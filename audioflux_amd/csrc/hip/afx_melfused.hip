@@ -2,7 +2,7 @@
 // size.  n_fft 2048 runs k_stft_mel_v2 (afx_melfused2.hip) for real AND complex results (bftObj_setResultType(0), the
 // reference wrapper's default: bft_algorithm.c:457-485; round 1's separate complex-result kernel of this file is gone since
 // the complex instantiations of k_stft_mel_v2 keep three waves per SIMD); n_fft 1024 / 4096 live in afx_melfused1k.hip /
-// afx_melfused4k2.hip.
+// afx_melfused4k2.hip, n_fft 512 in afx_melfused512.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -13,7 +13,7 @@
 namespace {
 
 struct Plan {
-    int variant;  // first field of every size's plan: < 100 this file (n_fft 2048), >= 100 afx_melfused1k, >= 200 afx_melfused4k2
+    int variant;  // first field of every size's plan: < 100 this file (n_fft 2048), >= 100 afx_melfused1k, >= 200 afx_melfused4k2, >= 300 afx_melfused512
     int num;
     int split;  // slots hold row segments (AfxBandPlan.split)
     void *v2;   // plan of afx_melfused2.hip
@@ -38,7 +38,13 @@ extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBan
 extern "C" int afxk_mel1k_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 extern "C" void afxk_mel1k_destroy(void *plan);
 
-// n_fft = 4096 lives in afx_melfused4k2.hip (variant numbers >= 200)
+// n_fft = 512 lives in afx_melfused512.hip (variant numbers >= 300)
+extern "C" int afxk_mel512_variant(int tapsA, int tapsB);
+extern "C" int afxk_mel512_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream);
+extern "C" int afxk_mel512_run(void *plan, const AfxMelFusedArgs *a, void *stream);
+extern "C" void afxk_mel512_destroy(void *plan);
+
+// n_fft = 4096 lives in afx_melfused4k2.hip (variant numbers 200 .. 299)
 extern "C" int afxk_mel4k_variant(int tapsA, int tapsB);
 extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream);
 extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream);
@@ -47,6 +53,7 @@ extern "C" int afxk_mel4k_kind(const void *plan);
 
 extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
     if (afxdev_no_fused()) return -1;
+    if (radix2Exp == 9) return afxk_mel512_variant(tapsA, tapsB);
     if (radix2Exp == 10) return afxk_mel1k_variant(tapsA, tapsB);
     if (radix2Exp == 12) return afxk_mel4k_variant(tapsA, tapsB);
     if (radix2Exp != 11) return -1;
@@ -59,6 +66,7 @@ extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
 extern "C" int afxk_melfused_kind(const void *plan) {
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return 0;
+    if (p->variant >= 300) return 301;
     if (p->variant >= 200) return afxk_mel4k_kind(plan);
     if (p->variant >= 100) return 101;
     return p->split ? 2 : 1;
@@ -67,6 +75,10 @@ extern "C" int afxk_melfused_kind(const void *plan) {
 extern "C" void afxk_melfused_destroy(void *plan) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p) return;
+    if (p->variant >= 300) {
+        afxk_mel512_destroy(plan);
+        return;
+    }
     if (p->variant >= 200) {
         afxk_mel4k_destroy(plan);
         return;
@@ -84,6 +96,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
     *plan = nullptr;
     const int variant = afxk_melfused_variant(radix2Exp, band->tapsA, band->tapsB);
     if (variant < 0) return AFX_ERR_UNSUPPORTED;
+    if (variant >= 300) return afxk_mel512_create(plan, hWindow, band, stream);
     if (variant >= 200) return afxk_mel4k_create(plan, hWindow, band, stream);
     if (variant >= 100) return afxk_mel1k_create(plan, hWindow, band, stream);
     Plan *p = static_cast<Plan *>(calloc(1, sizeof(Plan)));
@@ -103,6 +116,7 @@ extern "C" int afxk_melfused_create(void **plan, int radix2Exp, const float *hWi
 extern "C" int afxk_melfused_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return AFX_ERR_ARG;
+    if (p->variant >= 300) return afxk_mel512_run(plan, a, stream);
     if (p->variant >= 200) return afxk_mel4k_run(plan, a, stream);
     if (p->variant >= 100) return afxk_mel1k_run(plan, a, stream);
     return afxk_mel2_run(p->v2, a, stream);  // real and complex results

@@ -19,7 +19,7 @@ os.makedirs(E, exist_ok=True)
 CL = "/opt/rocm/lib/llvm/bin/clang"
 INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
 hipdir = f"{ROOT}/audioflux_amd/csrc/hip"
-UNITS = ["afx_cqt", "afx_cqt_f16", "afx_gemm_bf16", "afx_melfused2", "afx_melfused", "afx_melfused1k", "afx_melfused4k2",
+UNITS = ["afx_cqt", "afx_cqt_f16", "afx_gemm_bf16", "afx_melfused2", "afx_melfused", "afx_melfused1k", "afx_melfused4k2", "afx_melfused512",
          "afx_gemm", "afx_cepstrogram", "afx_cepstrum", "afx_cwt", "afx_cwt_td", "afx_stft", "afx_istft", "afx_spectral", "afx_xxcc", "afx_wsst", "afx_reassign"]
 renames = set()
 jobs = []

@@ -162,6 +162,48 @@ def test_bft_nfft1024_fused_kernel_matches_compiled_reference(scale):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("scale,num,sr", [(2, 128, 16000), (2, 80, 16000), (2, 40, 16000), (2, 26, 44100), (3, 64, 16000), (4, 64, 16000)])
+def test_bft_nfft512_fused_kernel_matches_compiled_reference(scale, num, sr):
+    """n_fft 512 (32 ms of 16 kHz speech) runs k_stft_band_512 (256-point complex FFT as 4 x 4 x 4 x 4 in four registers
+    per lane): every tap variant (mel-128: 16 + 4 ... mel-26 at 44.1 kHz: 64 + 8), hop 128 (register re-use), 160 and 101
+    (plain; frames on odd samples), real / complex results, power / magnitude, norm exponent -- against the reference library;
+    then the device batch call on clips an odd number of floats apart."""
+    x = cases.noise(80 + scale + num, sr + 77)
+    kinds = set()
+    for hop in (128, 160, 101):
+        for rt, dt, norm in ((1, 0, None), (1, 1, None), (0, 0, None), (0, 1, None), (1, 0, 0.5), (1, 1, 2.0)):
+            r = ref.RefBFT(num, 9, samplate=sr, low_fre=0.0, high_fre=sr / 2, window_type=1, slide_length=hop,
+                           scale_type=scale, style_type=0, normal_type=0, data_type=dt)
+            assert r.status == 0
+            r.set_result_type(rt)
+            if norm:
+                r.set_norm(norm)
+            re, im = r.bft(x)
+            o = af.BFT(num, radix2_exp=9, samplate=sr, low_fre=0.0, high_fre=sr / 2, slide_length=hop,
+                       scale_type=af.SpectralFilterBankScaleType(scale), data_type=af.SpectralDataType(dt))
+            kinds.add(o.fused_plan_kind())
+            if norm:
+                o.set_data_norm_value(norm)
+            got = o.bft(x, result_type=rt).T
+            assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"scale{scale} num{num} hop{hop} rt{rt} dt{dt} norm{norm}")
+    assert kinds == {301}, kinds
+    import torch
+    n = sr + 4
+    xs = np.stack([cases.noise(180 + scale + i, n + 1) for i in range(3)])
+    xd = torch.from_numpy(xs).cuda()[:, :n]
+    for rt in (1, 0):
+        o = af.BFT(num, radix2_exp=9, samplate=sr, low_fre=0.0, high_fre=sr / 2, slide_length=128,
+                   scale_type=af.SpectralFilterBankScaleType(scale), data_type=af.SpectralDataType.POWER)
+        o.set_result_type(rt)
+        out = o.bft_device(xd)
+        torch.cuda.synchronize()
+        for i in range(3):
+            host = o.bft(xs[i, :n], result_type=rt).T
+            dev = out[i].cpu().numpy() if rt == 1 else out[0][i].cpu().numpy() + 1j * out[1][i].cpu().numpy()
+            assert np.array_equal(dev, host), (rt, i)
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("scale", [2, 3])   # mel, bark
 def test_bft_nfft4096_fused_kernel_matches_compiled_reference(scale):
     """n_fft 4096 (the reference wrapper's default) runs k_stft_band_4k2: two 1024-point
@@ -286,6 +328,7 @@ def test_fused_plan_kinds():
     assert mk(40, 11).fused_plan_kind() == 2
     assert mk(13, 11).fused_plan_kind() == 0   # rows of ~160 bins: more than four segments
     assert mk(128, 10).fused_plan_kind() == 101
+    assert mk(128, 9).fused_plan_kind() == 301 and mk(40, 9).fused_plan_kind() == 301
     assert mk(128, 12).fused_plan_kind() == 201
     assert mk(80, 12, 32000).fused_plan_kind() == 202
 

@@ -32,7 +32,7 @@ STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cwt_td_fits", "afxk_cwt_
                                                      "afxk_melfused_destroy", "afxk_melfused_kind")]
 
 EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "cwt_emulated_td", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
-             "mel_emulated_melfused1k", "mel_emulated_4k2")
+             "mel_emulated_melfused1k", "mel_emulated_4k2", "mel_emulated_melfused512")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
 
@@ -148,6 +148,15 @@ def test_fused_stft_kernels_emulated_meet_the_golden_vectors(emulated):
     out = _run(emulated, "emulated_bft_cases.py", ["cfg1_mel_complex", "tones_mel_mag_area", "mel_temporal", "octave_hann_style", "ragged_tail"])
     for k in ("k_stft_band_1k", "k_stft_band_4k2", "k_stft_mel_v2"):  # (complex results at n_fft 2048: the headline kernel's CPLX instantiation since round 5)
         assert k in out, out
+
+
+def test_n512_bank_kernel_emulated_against_the_restatement(emulated):
+    """k_stft_band_512 (round 5; n_fft 512 had run the size-generic kernels): the 4 x 4 x 4 x 4 transform in four registers
+    per lane with its three transposes, every tap variant, real / magnitude / norm-exponent / complex results, register re-use
+    and whole-frame fetches, through bftObj_new's own plan and dispatcher; on the device the same cases meet the compiled
+    reference (tests/test_bft_gpu.py)"""
+    out = _run(emulated, "emulated_bft512.py", [])
+    assert "emulated k_stft_band_512 6" in out, out[-800:]
 
 
 def test_n4096_spectrum_kernel_emulated_against_float64(emulated):
