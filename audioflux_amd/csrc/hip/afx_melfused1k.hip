@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
@@ -62,7 +63,25 @@ struct KArgs {
     float normValue;
     float *out, *outIm;
     int num;
+    // STFT instantiations (afxk_stft1k): bins instead of bank rows
+    int mode;              // AFX_SPEC_*
+    int binLo, binCount;   // bins binLo .. binLo + binCount - 1 are stored; above 512: conjugate mirrors
+    long long outPitch;    // floats between output rows
 };
+
+// what an STFT instantiation stores for a spectrum value (the maps of afx_stft.hip)
+__device__ __forceinline__ void stft_map(float re, float im, int mode, float normValue, float &v0, float &v1) {
+    v1 = 0.f;
+    switch (mode) {
+        case AFX_SPEC_COMPLEX: v0 = re; v1 = im; break;
+        case AFX_SPEC_POWER: v0 = re * re + im * im; break;
+        case AFX_SPEC_MAG: v0 = sqrtf(re * re + im * im); break;
+        case AFX_SPEC_SQUARE: v0 = re * re - im * im; v1 = 2.f * re * im; break;
+        case AFX_SPEC_MAG_NORM: v0 = powf(sqrtf(re * re + im * im), normValue); break;
+        case AFX_SPEC_PHASE: v0 = atan2f(im, re < 1e-16f ? 1e-16f : re); break;
+        default: v0 = powf(re * re + im * im, normValue); break;  // AFX_SPEC_POWER_NORM
+    }
+}
 
 // |X|^2 of the conjugate pair (k, 512-k) from A = Z[k], B = Z[512-k], w = 0.5 W_1024^k
 __device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w, float &pk, float &pq) {
@@ -94,8 +113,12 @@ __device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &k
     }
 }
 
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX>
+// STFT: no bank -- the spectrum values themselves (CPLX form) go to memory through stft_map (the STFT object's full complex
+//   spectrum, linear-scale bin slices: afxk_stft1k, afx_melfused4k2.hip has the same at n_fft 4096); MAPPED: any AFX_SPEC_* map,
+//   otherwise the complex values as they are; FULL: all 1024 bins are stored (no range checks)
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
+    static_assert(!STFT || (CPLX && TA == 0 && TB == 0), "STFT instantiations: complex values, no bank");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -111,7 +134,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
         for (int i = threadIdx.x; i < TAB_WIN_F2; i += WAVES * 64) tabWin[i] = reinterpret_cast<const v2 *>(a.win2)[i];
         for (int i = threadIdx.x; i < TAB_TW1_F2; i += WAVES * 64) tabTw1[i] = reinterpret_cast<const v2 *>(a.tw1)[i];
         for (int i = threadIdx.x; i < TAB_TW3_F2; i += WAVES * 64) tabTw3[i] = reinterpret_cast<const v2 *>(a.tw3)[i];
-        for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
+        if constexpr (!STFT)
+            for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
         if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = reinterpret_cast<const v2 *>(a.tw2)[threadIdx.x];
         // zero pad behind bin 512 (the fixed-length band loops read it with zero weights): behind the images, written once
         for (int i = 513 + lane; i < PROW_F; i += 64) prow[i] = 0.f;
@@ -136,8 +160,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
     const unsigned aP = R + 4 * lane;                  // bins lane + 64 j: + 256 j
     const unsigned aQ = R + 4 * (320 - lane);          // bins 512 - lane - 64 j: + 256 (3 - j)
 
-    const int startA = a.meta[lane], startB = a.meta[64 + lane];
-    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const int startA = STFT ? 0 : a.meta[lane], startB = STFT ? 0 : a.meta[64 + lane];
+    const int rowA = STFT ? -1 : a.meta[128 + lane], rowB = STFT ? -1 : a.meta[192 + lane];
     const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
     const unsigned awr = T0 + TAB_BYTES + 4 * WP * lane;
 
@@ -290,12 +314,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 PIN(w3[j]);
                 // k = 0 pairs with itself (X[0] and X[512]); lane 0's read of slot 512 is past the image and discarded
                 const v2 zbj = (j == 0) ? (lane0 ? za[0] : zb[0]) : zb[j];
-                if (CPLX) split_pair_c(za[j], zbj, w3[j], a.specMap == 4, pk[j], pkI[CPLX ? j : 0], pq[j], pqI[CPLX ? j : 0]);
+                if (CPLX) split_pair_c(za[j], zbj, w3[j], !STFT && a.specMap == 4, pk[j], pkI[CPLX ? j : 0], pq[j], pqI[CPLX ? j : 0]);
                 else split_pair(za[j], zbj, w3[j], pk[j], pq[j]);
             }
             PIN(zm);
             PIN(wm);
-            if (CPLX) split_pair_c(zm, zm, wm, a.specMap == 4, pk[4], pkI[CPLX ? 4 : 0], pq[4], pqI[CPLX ? 4 : 0]);
+            if (CPLX) split_pair_c(zm, zm, wm, !STFT && a.specMap == 4, pk[4], pkI[CPLX ? 4 : 0], pq[4], pqI[CPLX ? 4 : 0]);
             else split_pair(zm, zm, wm, pk[4], pq[4]);
         }
         if (CPLX) {
@@ -312,6 +336,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 pq[i] = powf(pq[i], a.normValue);
             }
         }
+        if constexpr (STFT) {
+            // ---- 4'. the spectrum itself: lanes hold consecutive bins; wave-uniform row bases in scalar registers + ONE byte-offset
+            //      register per family of bins (afx_melfused4k2.hip).  ore / oim point at bin 0 of the row.
+            const long long row = f * a.outPitch - a.binLo;
+            auto uniform = [](const float *p) {
+                const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+            };
+            const float *const ore = uniform(a.out + row), *const oim = uniform(a.outIm ? a.outIm + row : a.out + row);
+            const bool two = !MAPPED || a.mode == AFX_SPEC_SQUARE;
+            const int lo = a.binLo, hi = a.binLo + a.binCount;
+            auto put = [&](bool pred, int bin, unsigned voff, int cb, float re, float im) {
+                if (!FULL) pred = pred && bin >= lo && bin < hi;
+                if (pred) {
+                    float v0 = re, v1 = im;
+                    if constexpr (MAPPED) stft_map(re, im, a.mode, a.normValue, v0, v1);
+                    if (two) GST32X2_S(voff, v0, ore + cb, v1, oim + cb);
+                    else GST32_S(voff, v0, ore + cb);
+                }
+            };
+            const unsigned vUp = 4u * lane, vDn = 4u * (64 - lane);  // bins c + lane / c + 64 - lane
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * j;
+                const bool kpos = j > 0 || !lane0;  // k > 0: bins 0 and 512 have no mirror
+                const float re0 = pk[j], im0 = pkI[CPLX ? j : 0], re1 = pq[j], im1 = pqI[CPLX ? j : 0];
+                put(true, k, vUp, 64 * j, re0, im0);                    // X[k]
+                put(kpos, NFFT - k, vDn, NFFT - 64 - 64 * j, re0, -im0);  //   mirror 1024 - k
+                put(true, MC - k, vDn, MC - 64 - 64 * j, re1, im1);      // X[512 - k]
+                put(kpos, MC + k, vUp, MC + 64 * j, re1, -im1);          //   mirror 512 + k
+            }
+            put(lane0, 256, vUp, 256, pk[4], pkI[CPLX ? 4 : 0]);
+            put(lane0, 768, vUp, 768, pk[4], -pkI[CPLX ? 4 : 0]);
+        } else {
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite its tail
 #pragma unroll
         for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
@@ -394,12 +453,35 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
             if (rowA >= 0) orow[rowA] = accA;
             if (rowB >= 0) orow[rowB] = accB;
         }
+        }  // !STFT
         // (the band stage's reads have returned -- its last wait is lgkmcnt(0) -- before the next frame's images overwrite the row)
 
         if (++t == a.timeLength) {
             t = 0;
             ++clip;
         }
+    }
+}
+
+// host: W_512^(lane d0) | W_64^(c d1) | 0.5 W_1024^k (k <= 256), in double, rounded once
+void fill_twiddles(float *tw1, float *tw2, float *tw3) {
+    const double PI = 3.14159265358979323846;
+    for (int d = 0; d < 8; ++d)
+        for (int l = 0; l < 64; ++l) {
+            const double ang = -2.0 * PI * (double)(d * l) / MC;
+            tw1[2 * (d * 64 + l)] = (float)cos(ang);
+            tw1[2 * (d * 64 + l) + 1] = (float)sin(ang);
+        }
+    for (int d = 0; d < 8; ++d)
+        for (int c = 0; c < 8; ++c) {
+            const double ang = -2.0 * PI * (double)(d * c) / 64.0;
+            tw2[2 * (d * 8 + c)] = (float)cos(ang);
+            tw2[2 * (d * 8 + c) + 1] = (float)sin(ang);
+        }
+    for (int k = 0; k <= 256; ++k) {
+        const double ang = -2.0 * PI * (double)k / NFFT;
+        tw3[2 * k] = (float)(0.5 * cos(ang));
+        tw3[2 * k + 1] = (float)(0.5 * sin(ang));
     }
 }
 
@@ -529,24 +611,7 @@ extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBan
     int meta[256];
     int st = (tw1 && tw2 && tw3 && wL) ? AFX_OK : AFX_ERR_NOMEM;
     if (st == AFX_OK) {
-        const double PI = 3.14159265358979323846;
-        for (int d = 0; d < 8; ++d)
-            for (int l = 0; l < 64; ++l) {
-                const double ang = -2.0 * PI * (double)(d * l) / MC;
-                tw1[2 * (d * 64 + l)] = (float)cos(ang);
-                tw1[2 * (d * 64 + l) + 1] = (float)sin(ang);
-            }
-        for (int d = 0; d < 8; ++d)
-            for (int c = 0; c < 8; ++c) {
-                const double ang = -2.0 * PI * (double)(d * c) / 64.0;
-                tw2[2 * (d * 8 + c)] = (float)cos(ang);
-                tw2[2 * (d * 8 + c) + 1] = (float)sin(ang);
-            }
-        for (int k = 0; k <= 256; ++k) {
-            const double ang = -2.0 * PI * (double)k / NFFT;
-            tw3[2 * k] = (float)(0.5 * cos(ang));
-            tw3[2 * k + 1] = (float)(0.5 * sin(ang));
-        }
+        fill_twiddles(tw1, tw2, tw3);
         for (int l = 0; l < 64; ++l) {
             for (int t = 0; t < band->tapsA; ++t) wL[(size_t)l * WP + t] = band->wA[(size_t)t * 64 + l];
             for (int t = 0; t < band->tapsB; ++t) wL[(size_t)l * WP + TA + t] = band->wB[(size_t)t * 64 + l];
@@ -586,4 +651,102 @@ extern "C" int afxk_mel1k_run(void *plan, const AfxMelFusedArgs *a, void *stream
         case 103: return launch<72, 32>(p, a, stream);
         default: return AFX_ERR_UNSUPPORTED;
     }
+}
+
+// ---- n_fft 1024 without a bank (afxk_stft, afx_stft.hip): every frame inside its clip (no padding), no temporal features.
+namespace {
+
+// twiddle tables of the STFT instantiations, one device copy per device, never freed: tw1 | tw2 | tw3
+const float2 *stft_tables(void *stream) {
+    static std::mutex mu;
+    static float2 *dTab[AFX_MAX_DEVICES] = {};
+    const int dev = afxdev_current_device();
+    if (dev < 0 || dev >= AFX_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dTab[dev]) {
+        constexpr int NF2 = TAB_TW1_F2 + TAB_TW2_F2 + TAB_TW3_F2;
+        float *h = static_cast<float *>(calloc(2 * NF2, sizeof(float)));
+        if (!h) return nullptr;
+        fill_twiddles(h, h + 2 * TAB_TW1_F2, h + 2 * (TAB_TW1_F2 + TAB_TW2_F2));
+        float2 *d = nullptr;
+        int st = afxdev_malloc(reinterpret_cast<void **>(&d), sizeof(float) * 2 * NF2);
+        if (st == AFX_OK) st = afxdev_h2d(d, h, sizeof(float) * 2 * NF2, stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(stream);
+        free(h);
+        if (st != AFX_OK) {
+            afxdev_free(d);
+            return nullptr;
+        }
+        dTab[dev] = d;
+    }
+    return dTab[dev];
+}
+
+template <int SHIFT, bool MAPPED, bool FULL>
+int launch_stft(const AfxStftArgs *a, const float2 *tab, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long waves = (long long)cus * WAVES * 2;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 16) {
+        const long long oneRound = (total + (long long)cus * WAVES - 1) / ((long long)cus * WAVES);
+        fpw = oneRound < 16 ? oneRound : 16;
+    }
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+    KArgs k;
+    memset(&k, 0, sizeof(k));
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.aligned = ((a->clipStride & 1) == 0) && ((a->hop & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
+    k.win2 = reinterpret_cast<const float2 *>(a->window);  // (w[2n], w[2n+1]) at [n]: the object's window as it lies
+    k.tw1 = tab;
+    k.tw2 = tab + TAB_TW1_F2;
+    k.tw3 = tab + TAB_TW1_F2 + TAB_TW2_F2;
+    k.specMap = 3;
+    k.normValue = a->normValue;
+    k.out = a->outRe;
+    k.outIm = a->outIm;
+    k.mode = a->mode;
+    k.binLo = a->binLo;
+    k.binCount = a->binCount;
+    k.outPitch = a->outPitch ? a->outPitch : (long long)a->binCount;
+    constexpr size_t lds = (size_t)block_lds_bytes(0, 0);
+    static bool attrSet[AFX_MAX_DEVICES] = {};
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev]) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<0, 0, false, SHIFT, true, true, MAPPED, FULL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet[attrDev] = true;
+    }
+    hipLaunchKernelGGL((k_stft_band_1k<0, 0, false, SHIFT, true, true, MAPPED, FULL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_band_1k<stft>");
+    return AFX_OK;
+}
+
+}  // namespace
+
+// AFX_ERR_UNSUPPORTED: the caller runs the size-generic kernel
+extern "C" int afxk_stft1k(const AfxStftArgs *a, void *stream) {
+    if (a->radix2Exp != 10 || a->bandStart || a->energy || a->binLo < 0 || a->binCount < 1 || a->binLo + a->binCount > NFFT ||
+        a->padLeft != 0 || a->hop < 1 || (long long)(a->timeLength - 1) * a->hop + NFFT > a->dataLength ||
+        (reinterpret_cast<uintptr_t>(a->window) & 7) != 0)
+        return AFX_ERR_UNSUPPORTED;
+    const bool two = (a->mode == AFX_SPEC_COMPLEX || a->mode == AFX_SPEC_SQUARE);
+    if (!a->outRe || (two && !a->outIm)) return AFX_ERR_ARG;
+    if ((long long)a->batch * a->timeLength <= 0) return AFX_OK;
+    const float2 *tab = stft_tables(stream);
+    if (!tab) return AFX_ERR_UNSUPPORTED;
+    const bool s2 = a->hop == 256;  // register re-use of the overlapping frames
+    if (a->mode == AFX_SPEC_COMPLEX) {
+        if (a->binLo == 0 && a->binCount == NFFT) return s2 ? launch_stft<2, false, true>(a, tab, stream) : launch_stft<0, false, true>(a, tab, stream);
+        return s2 ? launch_stft<2, false, false>(a, tab, stream) : launch_stft<0, false, false>(a, tab, stream);
+    }
+    return s2 ? launch_stft<2, true, false>(a, tab, stream) : launch_stft<0, true, false>(a, tab, stream);
 }

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "afx_device.h"
 #include "afx_hipcheck.h"
@@ -59,7 +60,26 @@ struct KArgs {
     float normValue;
     float *out, *outIm;
     int num;
+    // STFT instantiations (afxk_stft512): bins instead of bank rows
+    const float *window;   // device [512], natural order = (w[2n], w[2n+1]) at [n]
+    int mode;              // AFX_SPEC_*
+    int binLo, binCount;   // bins binLo .. binLo + binCount - 1 are stored; above 256: conjugate mirrors
+    long long outPitch;    // floats between output rows
 };
+
+// what an STFT instantiation stores for a spectrum value (the maps of afx_stft.hip)
+__device__ __forceinline__ void stft_map(float re, float im, int mode, float normValue, float &v0, float &v1) {
+    v1 = 0.f;
+    switch (mode) {
+        case AFX_SPEC_COMPLEX: v0 = re; v1 = im; break;
+        case AFX_SPEC_POWER: v0 = re * re + im * im; break;
+        case AFX_SPEC_MAG: v0 = sqrtf(re * re + im * im); break;
+        case AFX_SPEC_SQUARE: v0 = re * re - im * im; v1 = 2.f * re * im; break;
+        case AFX_SPEC_MAG_NORM: v0 = powf(sqrtf(re * re + im * im), normValue); break;
+        case AFX_SPEC_PHASE: v0 = atan2f(im, re < 1e-16f ? 1e-16f : re); break;
+        default: v0 = powf(re * re + im * im, normValue); break;  // AFX_SPEC_POWER_NORM
+    }
+}
 
 // |X|^2 of the conjugate pair (k, 256-k) from A = Z[k], B = Z[256-k], w = 0.5 W_512^k
 __device__ __forceinline__ void split_pair(v2 A, v2 B, v2 w, float &pk, float &pq) {
@@ -93,8 +113,11 @@ __device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &k
 
 // GENERAL: magnitude / norm exponent / post power (real results); SHIFT: hop = 128 SHIFT samples = SHIFT registers;
 // CPLX: complex results (specMap 3: S, 4: S^2), the bank runs over the real and the imaginary parts in turn
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX>
+// STFT: no bank -- the spectrum values themselves (CPLX form) go to memory through stft_map (afxk_stft512; afx_melfused4k2.hip
+//   has the same at n_fft 4096); MAPPED: any AFX_SPEC_* map; FULL: all 512 bins are stored (no range checks)
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
+    static_assert(!STFT || (CPLX && TA == 0 && TB == 0), "STFT instantiations: complex values, no bank");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -105,7 +128,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
     {
         float4 *s4 = reinterpret_cast<float4 *>(smem);
         const float4 *g4 = reinterpret_cast<const float4 *>(a.tab);
-        for (int i = threadIdx.x; i < TABB / 16; i += WAVES * 64) s4[i] = g4[i];
+        for (int i = threadIdx.x + (STFT ? T_TW1 / 16 : 0); i < (STFT ? TAB_BYTES : TABB) / 16; i += WAVES * 64) s4[i] = g4[i];
+        if constexpr (STFT)  // the object's own window; the blob holds the twiddles only
+            for (int i = threadIdx.x; i < NFFT; i += WAVES * 64) reinterpret_cast<float *>(smem + T_WIN)[i] = a.window[i];
         for (int i = 257 + lane; i < PROW_F; i += 64) prow[i] = 0.f;  // zero pad, written once
     }
     __syncthreads();
@@ -131,8 +156,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
     const unsigned aP = R + 4 * lane;                                  // bins lane, lane + 64
     const unsigned aQ = R + 4 * (192 - lane);                          // bins 192 - lane, 256 - lane
 
-    const int startA = a.meta[lane], startB = a.meta[64 + lane];
-    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const int startA = STFT ? 0 : a.meta[lane], startB = STFT ? 0 : a.meta[64 + lane];
+    const int rowA = STFT ? -1 : a.meta[128 + lane], rowB = STFT ? -1 : a.meta[192 + lane];
     const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
     const unsigned awr = T0 + TAB_BYTES + 4 * WP * lane;
 
@@ -287,10 +312,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
             PIN(zb[0]); PIN(zb[1]); PIN(ws[0]); PIN(ws[1]); PIN(zm); PIN(wm);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (CPLX) split_pair_c(v[j], zb[j], ws[j], a.specMap == 4, pk[j], pkI[CPLX ? j : 0], pq[j], pqI[CPLX ? j : 0]);
+                if (CPLX) split_pair_c(v[j], zb[j], ws[j], !STFT && a.specMap == 4, pk[j], pkI[CPLX ? j : 0], pq[j], pqI[CPLX ? j : 0]);
                 else split_pair(v[j], zb[j], ws[j], pk[j], pq[j]);
             }
-            if (CPLX) split_pair_c(zm, zm, wm, a.specMap == 4, pk[2], pkI[CPLX ? 2 : 0], pq[2], pqI[CPLX ? 2 : 0]);
+            if (CPLX) split_pair_c(zm, zm, wm, !STFT && a.specMap == 4, pk[2], pkI[CPLX ? 2 : 0], pq[2], pqI[CPLX ? 2 : 0]);
             else split_pair(zm, zm, wm, pk[2], pq[2]);
         }
         if (CPLX) {
@@ -307,6 +332,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
                 pq[i] = powf(pq[i], a.normValue);
             }
         }
+        if constexpr (STFT) {
+            // ---- 4'. the spectrum itself: wave-uniform row bases in scalar registers + ONE byte-offset register per family of
+            //      bins (afx_melfused4k2.hip).  ore / oim point at bin 0 of the row.
+            const long long row = f * a.outPitch - a.binLo;
+            auto uniform = [](const float *p) {
+                const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+            };
+            const float *const ore = uniform(a.out + row), *const oim = uniform(a.outIm ? a.outIm + row : a.out + row);
+            const bool two = !MAPPED || a.mode == AFX_SPEC_SQUARE;
+            const int lo = a.binLo, hi = a.binLo + a.binCount;
+            auto put = [&](bool pred, int bin, unsigned voff, int cb, float re, float im) {
+                if (!FULL) pred = pred && bin >= lo && bin < hi;
+                if (pred) {
+                    float v0 = re, v1 = im;
+                    if constexpr (MAPPED) stft_map(re, im, a.mode, a.normValue, v0, v1);
+                    if (two) GST32X2_S(voff, v0, ore + cb, v1, oim + cb);
+                    else GST32_S(voff, v0, ore + cb);
+                }
+            };
+            const unsigned vUp = 4u * lane, vDn = 4u * (64 - lane);  // bins c + lane / c + 64 - lane
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = lane + 64 * j;
+                const bool kpos = j > 0 || !lane0;  // k > 0: bins 0 and 256 have no mirror
+                const float re0 = pk[j], im0 = pkI[CPLX ? j : 0], re1 = pq[j], im1 = pqI[CPLX ? j : 0];
+                put(true, k, vUp, 64 * j, re0, im0);                      // X[k]
+                put(kpos, NFFT - k, vDn, NFFT - 64 - 64 * j, re0, -im0);  //   mirror 512 - k
+                put(true, MC - k, vDn, MC - 64 - 64 * j, re1, im1);       // X[256 - k]
+                put(kpos, MC + k, vUp, MC + 64 * j, re1, -im1);           //   mirror 256 + k
+            }
+            put(lane0, 128, vUp, 128, pk[2], pkI[CPLX ? 2 : 0]);
+            put(lane0, 384, vUp, 384, pk[2], -pkI[CPLX ? 2 : 0]);
+        } else {
         // every read of the image has returned (lgkmcnt(0) above): the power row may overwrite its tail
 #pragma unroll
         for (int pass = 0; pass < (CPLX ? 2 : 1); ++pass) {
@@ -384,6 +444,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
             if (rowA >= 0) orow[rowA] = accA;
             if (rowB >= 0) orow[rowB] = accB;
         }
+        }  // !STFT
         // (the band stage's reads have returned before the next frame's images overwrite the row)
 
         if (++t == a.timeLength) {
@@ -391,6 +452,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
             ++clip;
         }
     }
+}
+
+// host: the transform's tables at their byte offsets (twiddles in double, rounded once); hWindow == nullptr leaves the window part alone
+void fill_transform_tables(float *tab, const float *hWindow) {
+    const double PI = 3.14159265358979323846;
+    auto put = [&](int byteOff, int idx, double ang, double scale) {
+        tab[byteOff / 4 + 2 * idx] = (float)(scale * cos(ang));
+        tab[byteOff / 4 + 2 * idx + 1] = (float)(scale * sin(ang));
+    };
+    if (hWindow) memcpy(tab + T_WIN / 4, hWindow, sizeof(float) * NFFT);  // (w[2n], w[2n+1]) at [n], n = 64 r + lane
+    for (int d = 0; d < 4; ++d)
+        for (int l = 0; l < 64; ++l) put(T_TW1, 64 * d + l, -2.0 * PI * (double)(d * l) / MC, 1.0);
+    for (int r = 0; r < 16; ++r)
+        for (int q = 0; q < 4; ++q) put(T_TW2, RP * r + q, -2.0 * PI * (double)(r * q) / 64.0, 1.0);
+    for (int c = 0; c < 4; ++c)
+        for (int q = 0; q < 4; ++q) put(T_TW3, RP * c + q, -2.0 * PI * (double)(c * q) / 16.0, 1.0);
+    for (int k = 0; k <= 128; ++k) put(T_TWS, k, -2.0 * PI * (double)k / NFFT, 0.5);
 }
 
 struct Plan {
@@ -498,19 +576,7 @@ extern "C" int afxk_mel512_create(void **plan, const float *hWindow, const AfxBa
     }
     p->variant = variant;
     p->num = band->num;
-    const double PI = 3.14159265358979323846;  // twiddles in double, rounded once
-    auto put = [&](int byteOff, int idx, double ang, double scale) {
-        tab[byteOff / 4 + 2 * idx] = (float)(scale * cos(ang));
-        tab[byteOff / 4 + 2 * idx + 1] = (float)(scale * sin(ang));
-    };
-    memcpy(tab + T_WIN / 4, hWindow, sizeof(float) * NFFT);  // (w[2n], w[2n+1]) at [n], n = 64 r + lane
-    for (int d = 0; d < 4; ++d)
-        for (int l = 0; l < 64; ++l) put(T_TW1, 64 * d + l, -2.0 * PI * (double)(d * l) / MC, 1.0);
-    for (int r = 0; r < 16; ++r)
-        for (int q = 0; q < 4; ++q) put(T_TW2, RP * r + q, -2.0 * PI * (double)(r * q) / 64.0, 1.0);
-    for (int c = 0; c < 4; ++c)
-        for (int q = 0; q < 4; ++q) put(T_TW3, RP * c + q, -2.0 * PI * (double)(c * q) / 16.0, 1.0);
-    for (int k = 0; k <= 128; ++k) put(T_TWS, k, -2.0 * PI * (double)k / NFFT, 0.5);
+    fill_transform_tables(tab, hWindow);
     float *wL = tab + TAB_BYTES / 4;
     int meta[256];
     for (int l = 0; l < 64; ++l) {
@@ -546,4 +612,97 @@ extern "C" int afxk_mel512_run(void *plan, const AfxMelFusedArgs *a, void *strea
         case 303: return launch<64, 8>(p, a, stream);
         default: return AFX_ERR_UNSUPPORTED;
     }
+}
+
+// ---- n_fft 512 without a bank (afxk_stft, afx_stft.hip): every frame inside its clip (no padding), no temporal features.
+namespace {
+
+const float *stft_tables(void *stream) {  // one device copy of the twiddle blob per device, never freed
+    static std::mutex mu;
+    static float *dTab[AFX_MAX_DEVICES] = {};
+    const int dev = afxdev_current_device();
+    if (dev < 0 || dev >= AFX_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dTab[dev]) {
+        float *h = static_cast<float *>(calloc(TAB_BYTES, 1));
+        if (!h) return nullptr;
+        fill_transform_tables(h, nullptr);
+        float *d = nullptr;
+        int st = afxdev_malloc(reinterpret_cast<void **>(&d), TAB_BYTES);
+        if (st == AFX_OK) st = afxdev_h2d(d, h, TAB_BYTES, stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(stream);
+        free(h);
+        if (st != AFX_OK) {
+            afxdev_free(d);
+            return nullptr;
+        }
+        dTab[dev] = d;
+    }
+    return dTab[dev];
+}
+
+template <int SHIFT, bool MAPPED, bool FULL>
+int launch_stft(const AfxStftArgs *a, const float *tab, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long waves = (long long)cus * WAVES * 2;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 16) {
+        const long long oneRound = (total + (long long)cus * WAVES - 1) / ((long long)cus * WAVES);
+        fpw = oneRound < 16 ? oneRound : 16;
+    }
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+    KArgs k;
+    memset(&k, 0, sizeof(k));
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.aligned = ((a->clipStride & 1) == 0) && ((a->hop & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
+    k.tab = tab;
+    k.specMap = 3;
+    k.normValue = a->normValue;
+    k.out = a->outRe;
+    k.outIm = a->outIm;
+    k.window = a->window;
+    k.mode = a->mode;
+    k.binLo = a->binLo;
+    k.binCount = a->binCount;
+    k.outPitch = a->outPitch ? a->outPitch : (long long)a->binCount;
+    constexpr size_t lds = (size_t)block_lds_bytes(0, 0);
+    static bool attrSet[AFX_MAX_DEVICES] = {};
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev]) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_512<0, 0, false, SHIFT, true, true, MAPPED, FULL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet[attrDev] = true;
+    }
+    hipLaunchKernelGGL((k_stft_band_512<0, 0, false, SHIFT, true, true, MAPPED, FULL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_band_512<stft>");
+    return AFX_OK;
+}
+
+}  // namespace
+
+// AFX_ERR_UNSUPPORTED: the caller runs the size-generic kernel
+extern "C" int afxk_stft512(const AfxStftArgs *a, void *stream) {
+    if (a->radix2Exp != 9 || a->bandStart || a->energy || a->binLo < 0 || a->binCount < 1 || a->binLo + a->binCount > NFFT ||
+        a->padLeft != 0 || a->hop < 1 || (long long)(a->timeLength - 1) * a->hop + NFFT > a->dataLength)
+        return AFX_ERR_UNSUPPORTED;
+    const bool two = (a->mode == AFX_SPEC_COMPLEX || a->mode == AFX_SPEC_SQUARE);
+    if (!a->outRe || (two && !a->outIm)) return AFX_ERR_ARG;
+    if ((long long)a->batch * a->timeLength <= 0) return AFX_OK;
+    const float *tab = stft_tables(stream);
+    if (!tab) return AFX_ERR_UNSUPPORTED;
+    const bool s1 = a->hop == 128;  // register re-use of the overlapping frames
+    if (a->mode == AFX_SPEC_COMPLEX) {
+        if (a->binLo == 0 && a->binCount == NFFT) return s1 ? launch_stft<1, false, true>(a, tab, stream) : launch_stft<0, false, true>(a, tab, stream);
+        return s1 ? launch_stft<1, false, false>(a, tab, stream) : launch_stft<0, false, false>(a, tab, stream);
+    }
+    return s1 ? launch_stft<1, true, false>(a, tab, stream) : launch_stft<0, true, false>(a, tab, stream);
 }

@@ -359,7 +359,9 @@ int launch_stft_wave(const AfxStftArgs *a, const float2 *tab, long long frames, 
 
 }  // namespace
 
-extern "C" int afxk_stft4k(const AfxStftArgs *a, void *stream);  // afx_melfused4k2.hip
+extern "C" int afxk_stft4k(const AfxStftArgs *a, void *stream);   // afx_melfused4k2.hip
+extern "C" int afxk_stft1k(const AfxStftArgs *a, void *stream);   // afx_melfused1k.hip
+extern "C" int afxk_stft512(const AfxStftArgs *a, void *stream);  // afx_melfused512.hip
 
 extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     if (a->radix2Exp < 1 || a->radix2Exp > 14) {
@@ -382,10 +384,10 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
             return cplx ? launch_stft_wave<11, true>(a, tab, frames, stream)
                         : launch_stft_wave<11, false>(a, tab, frames, stream);
     }
-    // n_fft 4096 (the wrapper's default): the transform of the n_fft 4096 bank kernel storing its spectrum (afx_melfused4k2.hip),
-    // when every frame lies inside its clip; AFX_ERR_UNSUPPORTED = not its case
-    if (a->radix2Exp == 12 && !afxdev_no_fused()) {
-        const int st = afxk_stft4k(a, stream);
+    // n_fft 4096 (the wrapper's default), 1024, 512: the transform of that size's bank kernel storing its spectrum
+    // (afx_melfused4k2 / 1k / 512.hip), when every frame lies inside its clip; AFX_ERR_UNSUPPORTED = not its case
+    if ((a->radix2Exp == 12 || a->radix2Exp == 10 || a->radix2Exp == 9) && !afxdev_no_fused()) {
+        const int st = a->radix2Exp == 12 ? afxk_stft4k(a, stream) : a->radix2Exp == 10 ? afxk_stft1k(a, stream) : afxk_stft512(a, stream);
         if (st != AFX_ERR_UNSUPPORTED) return st;
     }
     const int N = 1 << a->radix2Exp;

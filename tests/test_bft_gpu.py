@@ -355,23 +355,25 @@ def test_bft_linear_scale_n2048_every_result_mode(hop):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("hop", [1024, 600])
-def test_bft_linear_scale_n4096_every_result_mode(hop):
-    """linear scale at n_fft 4096 = a bin slice from k_stft_band_4k2<STFT> (range-checked stores, every AFX_SPEC_* map)"""
-    x = cases.noise(43, 16000 * 3 + 5)
+@pytest.mark.parametrize("r2,hop", [(12, 1024), (12, 600), (10, 256), (10, 150), (9, 128), (9, 75)])
+def test_bft_linear_scale_on_the_spectrum_kernels_every_result_mode(r2, hop):
+    """linear scale at n_fft 4096 / 1024 / 512 = a bin slice from k_stft_band_4k2 / _1k / _512 <STFT> (range-checked stores,
+    every AFX_SPEC_* map)"""
+    x = cases.noise(43 + r2, 16000 * 3 + 5)
+    num = (1 << r2) * 300 // 4096
     for rt, dt, norm in ((1, 0, 1.0), (1, 1, 1.0), (1, 0, 0.5), (1, 1, 2.0), (0, 0, 1.0), (0, 1, 1.0)):
-        r = ref.RefBFT(300, 12, samplate=16000, low_fre=500.0, high_fre=8000.0, window_type=1, slide_length=hop,
+        r = ref.RefBFT(num, r2, samplate=16000, low_fre=500.0, high_fre=8000.0, window_type=1, slide_length=hop,
                        scale_type=0, style_type=0, normal_type=0, data_type=dt)
         r.set_result_type(rt)
         if norm != 1.0:
             r.set_norm(norm)
         re, im = r.bft(x)
-        o = af.BFT(300, radix2_exp=12, samplate=16000, low_fre=500.0, high_fre=8000.0, slide_length=hop,
+        o = af.BFT(num, radix2_exp=r2, samplate=16000, low_fre=500.0, high_fre=8000.0, slide_length=hop,
                    scale_type=af.SpectralFilterBankScaleType.LINEAR, data_type=af.SpectralDataType(dt))
         if norm != 1.0:
             o.set_data_norm_value(norm)
         got = o.bft(x, result_type=rt).T
-        assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"linear 4096 hop{hop} rt{rt} dt{dt} norm{norm}")
+        assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"linear r{r2} hop{hop} rt{rt} dt{dt} norm{norm}")
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")

@@ -159,13 +159,15 @@ def test_n512_bank_kernel_emulated_against_the_restatement(emulated):
     assert "emulated k_stft_band_512 6" in out, out[-800:]
 
 
-def test_n4096_spectrum_kernel_emulated_against_float64(emulated):
-    """afxk_stft4k / k_stft_band_4k2<STFT> (round 5: the STFT object, the linear-scale slices and the reassignment object's
-    transforms at n_fft 4096): every store family of the epilogue -- bins k, 2048 - k, 1024 +- k of a lane's eight slots, lane
-    0's self-mirrored base, the conjugate mirrors above 2048 -- with and without range checks, plain and mapped, against
-    numpy's float64 FFT; on the device the same kernel meets the compiled reference (tests/test_stft_gpu.py)"""
+def test_spectrum_kernels_emulated_against_float64(emulated):
+    """afxk_stft4k / afxk_stft1k / afxk_stft512 = k_stft_band_4k2 / _1k / _512 <STFT> (round 5: the STFT object, the linear-scale
+    slices and the reassignment object's transforms at n_fft 4096 / 1024 / 512): every store family of the epilogues -- a lane's
+    bins and their partners, lane 0's special slots, the conjugate mirrors above N / 2 -- with and without range checks, plain
+    and mapped, against numpy's float64 FFT; on the device the same kernels meet the compiled reference (tests/test_stft_gpu.py)"""
     out = _run(emulated, "emulated_stft4k.py", [])
-    assert "emulated k_stft_band_4k2 4" in out and "mirrors are exact conjugates" in out, out[-800:]
+    for k in ("k_stft_band_4k2", "k_stft_band_1k", "k_stft_band_512"):
+        assert f"emulated {k} 4" in out, out[-1200:]
+    assert out.count("mirrors are exact conjugates") == 3, out[-1200:]
 
 
 def test_f32_matrix_core_octave_kernels_emulated(emulated):

@@ -195,36 +195,39 @@ def test_wave_kernel_every_padding_mode_and_the_generic_kernel(r, hop):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("hop", [1024, 700, 1001, 4096])
-def test_n4096_spectrum_from_the_bank_kernels_transform(hop):
-    """n_fft 4096 without padding (every frame inside the clip) runs the even / odd-half transform of the n_fft 4096 bank
-    kernel with its spectrum stored from registers (k_stft_band_4k2<STFT>, afxk_stft4k): all 4096 bins of stftObj_stft --
-    conjugate mirrors above 2048 -- against the compiled reference; hop 1024 re-uses 3/4 of a frame from registers, the
-    other hops fetch every frame whole (1001: frame starts on odd samples)."""
-    x = cases.noise(900 + hop, 9 * 4096 + 77)
-    rr = ref.RefSTFT(12, 1, hop)
-    o = af.STFT(radix2_exp=12, window_type=af.WindowType.HANN, slide_length=hop)
+@pytest.mark.parametrize("r,hop", [(12, 1024), (12, 700), (12, 1001), (12, 4096), (10, 256), (10, 175), (10, 1024), (9, 128), (9, 89), (9, 160)])
+def test_spectrum_from_the_bank_kernels_transforms(r, hop):
+    """n_fft 4096 / 1024 / 512 without padding (every frame inside the clip) run the transform of that size's bank kernel with
+    its spectrum stored from registers (k_stft_band_4k2 / _1k / _512 <STFT>, afxk_stft4k / 1k / 512): all N bins of stftObj_stft
+    -- conjugate mirrors above N / 2 -- against the compiled reference; hop N / 4 re-uses 3/4 of a frame from registers, the
+    other hops fetch every frame whole (odd hops: frame starts on odd samples)."""
+    n = 1 << r
+    x = cases.noise(900 + hop + r, 9 * n + 77)
+    rr = ref.RefSTFT(r, 1, hop)
+    o = af.STFT(radix2_exp=r, window_type=af.WindowType.HANN, slide_length=hop)
     re, im = rr.stft(x)
     gre, gim = o.stft_full(x)
     assert gre.shape == re.shape and re.shape[0] >= 2
-    assert_parity(gre + 1j * gim, re + 1j * im, TOL, f"n4096 hop{hop}")
-    # mirrors are exact conjugates of what the lower half stores, bin 0 / 2048 have none
-    assert np.array_equal(gre[:, 1:2048], gre[:, :2048:-1]) and np.array_equal(gim[:, 1:2048], -gim[:, :2048:-1])
+    assert_parity(gre + 1j * gim, re + 1j * im, TOL, f"n{n} hop{hop}")
+    # mirrors are exact conjugates of what the lower half stores, bin 0 / N / 2 have none
+    h = n // 2
+    assert np.array_equal(gre[:, 1:h], gre[:, :h:-1]) and np.array_equal(gim[:, 1:h], -gim[:, :h:-1])
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-def test_n4096_device_batch_with_an_odd_clip_pitch():
+@pytest.mark.parametrize("r", [12, 10, 9])
+def test_spectrum_kernels_device_batch_with_an_odd_clip_pitch(r):
     """three clips 48 001 floats apart through the device call = each clip through the legacy call, bit for bit;
     more frames per clip than one wave's run, so runs cross clip boundaries"""
     import torch
-    o = af.STFT(radix2_exp=12, window_type=af.WindowType.HAMM, slide_length=1024)
+    o = af.STFT(radix2_exp=r, window_type=af.WindowType.HAMM, slide_length=(1 << r) // 4)
     n = 48000
     base = torch.from_numpy(np.stack([cases.noise(950 + i, n + 1) for i in range(3)])).cuda()
     x = base[:, :n]
     assert x.stride(0) == n + 1
     re, im = o.stft_device(x)
     torch.cuda.synchronize()
-    rr = ref.RefSTFT(12, 2, 1024)
+    rr = ref.RefSTFT(r, 2, (1 << r) // 4)
     for i in range(3):
         xi = x[i].cpu().numpy()
         g1, g2 = o.stft_full(xi)
