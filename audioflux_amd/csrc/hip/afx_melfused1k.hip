@@ -392,7 +392,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
             //         block of four quads is requested before this block's values are waited for (see afx_melfused2.hip)
             float accA, accB;
             {
-                constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = 4, NB = (QT + BLK - 1) / BLK;
+                constexpr int QA = TA / 4, QB = TB / 4, QT = QA + QB, BLK = CPLX ? 2 : 4, NB = (QT + BLK - 1) / BLK;  // (complex: ten values wait for the second pass)
                 v2 sA = {0.f, 0.f}, sB = {0.f, 0.f};
                 v4f w[2][BLK];
                 v2 p0[2][BLK], p1[2][BLK];
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                     const int cur = blk & 1;
                     const int nextQuads = (blk + 1 < NB) ? ((QT - (blk + 1) * BLK) < BLK ? (QT - (blk + 1) * BLK) : BLK) : 0;
                     if (blk + 1 < NB) request(blk + 1, w[cur ^ 1], p0[cur ^ 1], p1[cur ^ 1]);
-                    if (nextQuads == 4) LDS_WAIT_N(12);
+                    if (nextQuads >= 4) LDS_WAIT_N(12);
                     else if (nextQuads == 3) LDS_WAIT_N(9);
                     else if (nextQuads == 2) LDS_WAIT_N(6);
                     else if (nextQuads == 1) LDS_WAIT_N(3);

@@ -1,4 +1,4 @@
-/* The fused STFT -> filter-bank kernels on the emulated library for ThreadSanitizer: n_fft 1024 (k_stft_band_1k), n_fft 4096
+/* The fused STFT -> filter-bank kernels on the emulated library for ThreadSanitizer: n_fft 512 (k_stft_band_512), n_fft 1024 (k_stft_band_1k), n_fft 4096
  * (k_stft_band_4k2), n_fft 2048 complex and real + MFCC (k_stft_mel_v2), a few frames each.  All three issue their DS
  * instructions by hand and rely on their issue order; the emulation makes each a rendezvous, so those cannot race here by
  * construction -- what ThreadSanitizer watches are the plain loads and stores around them (table fills, zero pads, segment
@@ -36,6 +36,8 @@ static int run(int r2, int num, int hop, int resultType, int withCc) {
 }
 
 int main(void) {
+    if (run(9, 40, 128, 1, 0)) return 1;
+    if (run(9, 128, 100, 0, 0)) return 1;
     if (run(10, 80, 160, 1, 0)) return 1;
     if (run(12, 128, 1024, 1, 0)) return 1;
     if (run(11, 128, 512, 0, 0)) return 1;
