@@ -37,12 +37,14 @@ extern "C" int afxk_mel1k_variant(int tapsA, int tapsB);
 extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream);
 extern "C" int afxk_mel1k_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 extern "C" void afxk_mel1k_destroy(void *plan);
+extern "C" int afxk_mel1k_kind(const void *plan);
 
 // n_fft = 512 lives in afx_melfused512.hip (variant numbers >= 300)
 extern "C" int afxk_mel512_variant(int tapsA, int tapsB);
 extern "C" int afxk_mel512_create(void **plan, const float *hWindow, const AfxBandPlan *band, void *stream);
 extern "C" int afxk_mel512_run(void *plan, const AfxMelFusedArgs *a, void *stream);
 extern "C" void afxk_mel512_destroy(void *plan);
+extern "C" int afxk_mel512_kind(const void *plan);
 
 // n_fft = 4096 lives in afx_melfused4k2.hip (variant numbers 200 .. 299)
 extern "C" int afxk_mel4k_variant(int tapsA, int tapsB);
@@ -66,9 +68,9 @@ extern "C" int afxk_melfused_variant(int radix2Exp, int tapsA, int tapsB) {
 extern "C" int afxk_melfused_kind(const void *plan) {
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return 0;
-    if (p->variant >= 300) return 301;
+    if (p->variant >= 300) return afxk_mel512_kind(plan);
     if (p->variant >= 200) return afxk_mel4k_kind(plan);
-    if (p->variant >= 100) return 101;
+    if (p->variant >= 100) return afxk_mel1k_kind(plan);
     return p->split ? 2 : 1;
 }
 

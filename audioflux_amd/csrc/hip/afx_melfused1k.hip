@@ -116,9 +116,10 @@ __device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &k
 // STFT: no bank -- the spectrum values themselves (CPLX form) go to memory through stft_map (the STFT object's full complex
 //   spectrum, linear-scale bin slices: afxk_stft1k, afx_melfused4k2.hip has the same at n_fft 4096); MAPPED: any AFX_SPEC_* map,
 //   otherwise the complex values as they are; FULL: all 1024 bins are stored (no range checks)
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false>
+// SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split): banks whose rows are longer than the tap variants
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
-    static_assert(!STFT || (CPLX && TA == 0 && TB == 0), "STFT instantiations: complex values, no bank");
+    static_assert(!STFT || (CPLX && TA == 0 && TB == 0 && !SPLIT), "STFT instantiations: complex values, no bank");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
 
     const int startA = STFT ? 0 : a.meta[lane], startB = STFT ? 0 : a.meta[64 + lane];
     const int rowA = STFT ? -1 : a.meta[128 + lane], rowB = STFT ? -1 : a.meta[192 + lane];
+    const unsigned seg0 = SPLIT ? (unsigned)a.meta[256 + lane] : 0u, seg1 = SPLIT ? (unsigned)a.meta[320 + lane] : 0u;
     const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
     const unsigned awr = T0 + TAB_BYTES + 4 * WP * lane;
 
@@ -444,14 +446,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 accA = sA.x + sA.y;
                 accB = sB.x + sB.y;
             }
-            if (GENERAL && !CPLX && a.postPow) {
+            if (GENERAL && !CPLX && !SPLIT && a.postPow) {
                 accA = powf(accA, a.normValue);
                 accB = powf(accB, a.normValue);
             }
             // ---- 5. store --------------------------------------------------------------
             float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
-            if (rowA >= 0) orow[rowA] = accA;
-            if (rowB >= 0) orow[rowB] = accB;
+            if constexpr (SPLIT) {
+                // slot results -> LDS (start of the wave's region: the images there are dead, the power row starts behind), then every
+                // row is the sum of its segments in ascending bins (afx_melfused2.hip)
+                float *part = reinterpret_cast<float *>(wreg);
+                part[lane] = accA;
+                part[64 + lane] = accB;
+                if (lane0) part[128] = 0.f;
+                wave_lds_order();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned u = h ? seg1 : seg0;
+                    float sum = part[u & 255u] + part[(u >> 8) & 255u];
+                    sum += part[(u >> 16) & 255u];
+                    sum += part[u >> 24];
+                    if (GENERAL && !CPLX && a.postPow) sum = powf(sum, a.normValue);
+                    if (lane + 64 * h < a.num) orow[lane + 64 * h] = sum;
+                }
+                wave_lds_order();  // before the next pass / frame writes there
+            } else {
+                if (rowA >= 0) orow[rowA] = accA;
+                if (rowB >= 0) orow[rowB] = accB;
+            }
         }
         }  // !STFT
         // (the band stage's reads have returned -- its last wait is lgkmcnt(0) -- before the next frame's images overwrite the row)
@@ -487,7 +509,7 @@ void fill_twiddles(float *tw1, float *tw2, float *tw3) {
 
 struct Plan {
     int variant;  // >= 100: this file (afxk_melfused_* dispatches on it)
-    int num;
+    int num, split;
     float2 *dWin2, *dTw1, *dTw2, *dTw3;
     float *dWLane;
     int *dMeta;
@@ -500,7 +522,7 @@ struct Variant {
 constexpr Variant kVariants[] = {{24, 8}, {32, 32}, {48, 16}, {72, 32}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX>
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool SPLIT = false>
 int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -541,11 +563,11 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet[attrDev] = true;
     }
-    hipLaunchKernelGGL((k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_band_1k");
     return AFX_OK;
@@ -555,6 +577,13 @@ template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const bool general = (a->specMap != 0) || a->postPow;
     const bool shift2 = (a->hop == 256);  // hop = 128 * SHIFT
+    if (p->split) {  // segment plans: the general instantiations only (they take the plain modes too)
+        if (a->specMap >= 3) {
+            if (!a->outIm) return AFX_ERR_ARG;
+            return shift2 ? launch_variant<TA, TB, true, 2, true, true>(p, a, stream) : launch_variant<TA, TB, true, 0, true, true>(p, a, stream);
+        }
+        return shift2 ? launch_variant<TA, TB, true, 2, false, true>(p, a, stream) : launch_variant<TA, TB, true, 0, false, true>(p, a, stream);
+    }
     if (a->specMap >= 3) {
         if (!a->outIm) return AFX_ERR_ARG;
         return shift2 ? launch_variant<TA, TB, true, 2, true>(p, a, stream)
@@ -582,6 +611,11 @@ extern "C" int afxk_mel1k_variant(int tapsA, int tapsB) {
     return -1;
 }
 
+extern "C" int afxk_mel1k_kind(const void *plan) {
+    const Plan *p = static_cast<const Plan *>(plan);
+    return !p ? 0 : (p->split ? 102 : 101);
+}
+
 extern "C" void afxk_mel1k_destroy(void *plan) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p) return;
@@ -603,12 +637,13 @@ extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBan
     if (!p) return AFX_ERR_NOMEM;
     p->variant = variant;
     p->num = band->num;
+    p->split = band->split;
     const int WP = TA + TB + 4;
     float *tw1 = static_cast<float *>(malloc(sizeof(float) * 2 * TAB_TW1_F2));
     float *tw2 = static_cast<float *>(malloc(sizeof(float) * 2 * TAB_TW2_F2));
     float *tw3 = static_cast<float *>(calloc(2 * TAB_TW3_F2, sizeof(float)));
     float *wL = static_cast<float *>(calloc((size_t)64 * WP, sizeof(float)));
-    int meta[256];
+    int meta[384];  // startA | startB | rowA | rowB | segIdx[0..63] | segIdx[64..127]
     int st = (tw1 && tw2 && tw3 && wL) ? AFX_OK : AFX_ERR_NOMEM;
     if (st == AFX_OK) {
         fill_twiddles(tw1, tw2, tw3);
@@ -619,6 +654,8 @@ extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBan
             meta[64 + l] = band->startB[l];
             meta[128 + l] = band->rowA[l];
             meta[192 + l] = band->rowB[l];
+            meta[256 + l] = (int)band->segIdx[l];
+            meta[320 + l] = (int)band->segIdx[64 + l];
         }
         st = upload(&p->dWin2, hWindow, sizeof(float) * NFFT, stream);
     }

@@ -23,14 +23,16 @@ int afx_bft_plan_fast(struct OpaqueBFT *o, const float *hWindow, const float *hB
     if (afx_bandplan_build(hBank, o->num, o->F, &band) != 0) return AFX_OK;
     int st = AFX_OK;
     int fits = afxk_melfused_variant(o->radix2Exp, band.tapsA, band.tapsB) >= 0;
-    if (!fits && (o->radix2Exp == 11 || o->radix2Exp == 12)) {
+    if (!fits && o->radix2Exp >= 9 && o->radix2Exp <= 12) {
         /* rows longer than the compiled tap variants (mel-40 / -64 / -80, bark, erb, higher sample
          * rates): cut them into segments, smallest variant first (afx_bandplan.c); the last number
-         * is the length of the kernel's zero-padded power row (PROW_F of afx_melfused{,4k}.hip) */
+         * is the length of the kernel's zero-padded power row (PROW_F of afx_melfused{512,1k,2,4k2}.hip) */
+        static const int v512[4][3] = {{16, 4, 384}, {32, 4, 384}, {48, 4, 384}, {64, 8, 384}};
+        static const int v1k[4][3] = {{24, 8, 640}, {32, 32, 640}, {48, 16, 640}, {72, 32, 640}};
         static const int v2k[2][3] = {{48, 16, 1104}, {72, 32, 1104}};
         static const int v4k[3][3] = {{96, 32, 2176}, {128, 64, 2176}, {176, 8, 2176}};
-        const int (*v)[3] = o->radix2Exp == 11 ? v2k : v4k;
-        const int nv = o->radix2Exp == 11 ? 2 : 3;
+        const int (*v)[3] = o->radix2Exp == 9 ? v512 : o->radix2Exp == 10 ? v1k : o->radix2Exp == 11 ? v2k : v4k;
+        const int nv = o->radix2Exp == 11 ? 2 : o->radix2Exp == 12 ? 3 : 4;
         afx_bandplan_free(&band);
         for (int i = 0; i < nv && !fits; i++)
             fits = afx_bandplan_build_split(hBank, o->num, o->F, v[i][0], v[i][1], v[i][2], &band) == 0;

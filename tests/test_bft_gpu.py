@@ -267,13 +267,16 @@ SPLIT_CASES = [  # (radix2_exp, scale, num, samplate): banks whose rows exceed t
     (11, "BARK", 80, 44100), (11, "ERB", 64, 22050), (11, "ERB", 40, 44100),
     (12, "MEL", 80, 32000), (12, "MEL", 40, 16000), (12, "BARK", 40, 32000), (12, "BARK", 64, 44100),
     (12, "ERB", 64, 22050),
+    # n_fft 1024 / 512 (round 5): rows longer than those kernels' tap variants
+    (10, "MEL", 13, 16000), (10, "MEL", 26, 22050), (10, "BARK", 24, 16000), (9, "MEL", 13, 16000), (9, "MEL", 20, 44100),
+    (9, "BARK", 24, 16000),
 ]
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("r2,scale,num,sr", SPLIT_CASES)
 def test_bft_split_plan_matches_compiled_reference(r2, scale, num, sr, monkeypatch):
-    """n_fft 2048 / 4096 with long-row banks: the fused kernel runs a split plan (row segments per lane slot,
+    """n_fft 512 ... 4096 with long-row banks: the fused kernel runs a split plan (row segments per lane slot,
     summed in ascending bin order) instead of falling back to the size-generic kernel -- real and
     complex results, power / magnitude / norm exponent, the register-reuse (hop 512) and plain (hop 300)
     instantiations (the size-generic kernel is held to the same reference by the other transform sizes)"""
@@ -297,7 +300,7 @@ def test_bft_split_plan_matches_compiled_reference(r2, scale, num, sr, monkeypat
                 r.set_norm(norm)
             re, im = r.bft(x)
             o = af.BFT(num, slide_length=hop, data_type=af.SpectralDataType(dt), **kw)
-            assert o.fused_plan_kind() == (2 if r2 == 11 else 202), (scale, num, sr)
+            assert o.fused_plan_kind() == {9: 302, 10: 102, 11: 2, 12: 202}[r2], (scale, num, sr)
             if norm != 1.0:
                 o.set_data_norm_value(norm)
             got = o.bft(x, result_type=rt).T

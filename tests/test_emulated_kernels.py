@@ -153,10 +153,10 @@ def test_fused_stft_kernels_emulated_meet_the_golden_vectors(emulated):
 def test_n512_bank_kernel_emulated_against_the_restatement(emulated):
     """k_stft_band_512 (round 5; n_fft 512 had run the size-generic kernels): the 4 x 4 x 4 x 4 transform in four registers
     per lane with its three transposes, every tap variant, real / magnitude / norm-exponent / complex results, register re-use
-    and whole-frame fetches, through bftObj_new's own plan and dispatcher; on the device the same cases meet the compiled
-    reference (tests/test_bft_gpu.py)"""
+    and whole-frame fetches, through bftObj_new's own plan and dispatcher -- and the row-segment plans (SPLIT instantiations) of
+    the n_fft 512 and n_fft 1024 kernels; on the device the same cases meet the compiled reference (tests/test_bft_gpu.py)"""
     out = _run(emulated, "emulated_bft512.py", [])
-    assert "emulated k_stft_band_512 6" in out, out[-800:]
+    assert "emulated k_stft_band_512 9, k_stft_band_1k 3" in out, out[-800:]
 
 
 def test_spectrum_kernels_emulated_against_float64(emulated):
