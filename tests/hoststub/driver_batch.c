@@ -31,8 +31,8 @@ static float *buf(size_t n) {
     return p;
 }
 
-static int bft_paths(void *stream) {
-    const int clips = 5, n = 16000, hop = 512, r2 = 11;
+static int bft_paths_at(void *stream, int r2) {
+    const int clips = 5, n = 16000, hop = (1 << r2) / 4;
     const long long stride = n + 24;
     int sr = 16000, slide = hop;
     float lo = 0.f, hi = 8000.f;
@@ -44,7 +44,7 @@ static int bft_paths(void *stream) {
         SpectralFilterBankStyleType style = variant == 1 ? SpectralFilterBankStyle_Gammatone : SpectralFilterBankStyle_Slaney;
         SpectralDataType dt = SpectralData_Power;
         int temporal = variant == 3;
-        const int num = variant == 2 ? 40 : 128;
+        const int num = variant == 2 ? (r2 <= 10 ? 13 : 40) : 128;  /* rows longer than the size's tap variants */
         CHECK(bftObj_new(&o, num, r2, &sr, &lo, &hi, NULL, NULL, &slide, &scale, &style, NULL, &dt, NULL, &temporal));
         const int T = bftObj_calTimeLength(o, n);
         float *re = buf((size_t)clips * T * num), *im = buf((size_t)clips * T * num);
@@ -72,8 +72,15 @@ static int bft_paths(void *stream) {
     return 0;
 }
 
-static int stft_paths(void *stream) {
-    const int clips = 4, n = 9000, r2 = 10, hop = 256, N = 1 << r2;
+/* the fused kernels of every transform size: n_fft 512 (k_stft_band_512), 1024, 2048, 4096 */
+static int bft_paths(void *stream) {
+    for (int r2 = 9; r2 <= 12; r2++)
+        if (bft_paths_at(stream, r2)) return 1;
+    return 0;
+}
+
+static int stft_paths_at(void *stream, int r2) {
+    const int clips = 4, n = 3 * (1 << r2) + 808, hop = (1 << r2) / 4, N = 1 << r2;
     int slide = hop;
     float *x = buf((size_t)clips * n);
     STFTObj s = NULL;
@@ -95,7 +102,7 @@ static int stft_paths(void *stream) {
     CHECK(spectrogramObj_spectrogramBatchDevice(sp, x, clips, n, n, m, stream));
     spectrogramObj_free(sp);
     free(m);
-    for (int cr2 = 10; cr2 <= 11; cr2++) {
+    for (int cr2 = 10; cr2 <= 11 && r2 == 10; cr2++) {
         CepstrogramObj ce = NULL;
         int cslide = (1 << cr2) / 4;
         CHECK(cepstrogramObj_new(&ce, cr2, NULL, &cslide));
@@ -125,6 +132,13 @@ static int stft_paths(void *stream) {
     free(re);
     free(im);
     free(x);
+    return 0;
+}
+
+/* the STFT object / spectrogram / reassignment at the sizes whose spectrum comes from the bank kernels' transforms (512, 1024, 4096) and at 2048 */
+static int stft_paths(void *stream) {
+    for (int r2 = 9; r2 <= 12; r2++)
+        if (stft_paths_at(stream, r2)) return 1;
     return 0;
 }
 

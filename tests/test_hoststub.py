@@ -301,8 +301,9 @@ def test_launch_audit(launch_audit, env, expect):
                                         ("driver_batch", "AFX_CWT_NARROW_MAX=0"), ("driver_cqt", ""), ("driver_cqt", "AFX_CQT_F32=1"),
                                         ("driver_cqt", "AFX_NO_FUSED=1"), ("driver_cqt", "AFX_CQT_CHUNK=2")])
 def test_launch_audit_of_the_small_configurations(launch_audit, driver, env):
-    """the configurations of tests/hoststub/driver_batch.c / driver_cqt.c (mel / gammatone / 40-band / temporal banks,
-    STFT and inverse, spectrogram, cepstrogram at two sizes, reassignment, CWT at 2^12 and 2^16 padded and not, PWT,
+    """the configurations of tests/hoststub/driver_batch.c / driver_cqt.c (mel / gammatone / segment-plan / temporal banks
+    at n_fft 512 ... 4096 -- every fused kernel family, real and complex results, with and without cepstra; STFT and inverse,
+    spectrogram, reassignment at the same four sizes; cepstrogram at two sizes, CWT at 2^12 and 2^16 padded and not, PWT,
     WSST; CQT plans of 84 and 48 bins, short clips, odd strides, 12 and 6 chroma classes) through the real launchers
     and the checking HIP stand-in.  For the CQT kernels the stand-in also decodes the argument lists and keeps the
     happens-before relation of the streams: a launch that reads or writes a range another stream's launch writes,
