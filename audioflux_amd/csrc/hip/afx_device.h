@@ -139,6 +139,9 @@ AFX_HD static inline long long afx_pad_index(long long q, int n, int mode) {
 
 /* generic framed FFT, any radix2Exp in 1..14 */
 int afxk_stft(const AfxStftArgs *a, void *stream);
+/* energy / rms / zcr of the windowed frames alone (x, clipStride, batch, dataLength, timeLength, radix2Exp, hop, window,
+ * padLeft / padMode, energy, rms, zcr are read): for bank rows that come from a fused kernel without them */
+int afxk_temporal(const AfxStftArgs *a, void *stream);
 
 /* inverse STFT (afx_istft.hip): re/im [batch*timeLength, N] -> out[b*outStride + j],
  * j < (timeLength-1)*hop + N: out = (out + sum_frames ifft*win1) / clamp(sum_frames win2) */

@@ -310,6 +310,47 @@ __global__ __launch_bounds__(SW * 64) void k_stft_wave(AfxStftArgs a, const floa
     }
 }
 
+// ---- temporal features alone (temporal_algorithm.c:138-144): energy, rms and zero-crossing rate of the windowed frames for the
+// objects whose bank rows come from a fused kernel without them (every transform size but 2048, and the complex results): one
+// wave per frame reads the frame again (its samples are in L2: the bank kernel has just read them) in the sample order of the
+// fused kernels' own temporal code -- lane l, step i holds samples 2 (64 i + l), + 1.
+__global__ __launch_bounds__(256) void k_temporal(AfxStftArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long frame = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= (long long)a.batch * a.timeLength) return;
+    const int N = 1 << a.radix2Exp, M = N >> 1;
+    const int b = (int)(frame / a.timeLength);
+    const int t = (int)(frame - (long long)b * a.timeLength);
+    const float *x = a.x + (long long)b * a.clipStride;
+    const long long start = (long long)t * a.hop - a.padLeft;
+    float e = 0.f, z = 0.f, prevTop = 0.f;  // prevTop: the second sample of lane 63 one step earlier, wave-uniform
+    for (int i0 = 0; i0 < M; i0 += 64) {
+        const int i = i0 + lane;
+        float vx = 0.f, vy = 0.f;
+        if (i < M) {
+            vx = fetch(x, start + 2 * i, a) * a.window[2 * i];
+            vy = fetch(x, start + 2 * i + 1, a) * a.window[2 * i + 1];
+        }
+        e = fmaf(vx, vx, e);
+        e = fmaf(vy, vy, e);
+        float py = __shfl_up(vy, 1, 64);
+        if (lane == 0) py = prevTop;
+        if (i > 0 && i < M && vx * py < 0.f) z += 1.f;  // sample 0 has no predecessor
+        if (i < M && vy * vx < 0.f) z += 1.f;
+        prevTop = __shfl(vy, 63, 64);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        e += __shfl_xor(e, o, 64);
+        z += __shfl_xor(z, o, 64);
+    }
+    if (lane == 0) {
+        a.energy[frame] = e;
+        a.rms[frame] = sqrtf(e / (float)N);
+        a.zcr[frame] = (float)((double)z / (double)N);
+    }
+}
+
 // twiddle tables of the wave kernels, one device copy per device (never freed)
 const float2 *wave_tables() {
     static std::mutex mu;
@@ -432,5 +473,18 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     hipLaunchKernelGGL(k_stft_generic, dim3((unsigned)frames), dim3(threads), lds,
                        (hipStream_t)stream, *a);
     AFX_LAUNCH_CHECK("k_stft_generic");
+    return AFX_OK;
+}
+
+extern "C" int afxk_temporal(const AfxStftArgs *a, void *stream) {
+    if (!a->x || !a->window || !a->energy || !a->rms || !a->zcr || a->radix2Exp < 1 || a->radix2Exp > 14) return AFX_ERR_ARG;
+    const long long frames = (long long)a->batch * a->timeLength;
+    if (frames <= 0) return AFX_OK;
+    if (frames > 0x7fffffffLL) {
+        afxdev_set_error("temporal: %lld frames in one launch", frames);
+        return AFX_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_temporal, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+    AFX_LAUNCH_CHECK("k_temporal");
     return AFX_OK;
 }

@@ -72,8 +72,7 @@ static void fast_args(struct OpaqueBFT *o, const float *dData, int batch, int da
     }
 }
 
-/* dTemporal: 3 planes of batch*T floats (energy | rms | zcr) or NULL.  Temporal features ride
- * along in the n_fft 2048 real-result kernel; anything else reports "not used" for them. */
+/* dTemporal: 3 planes of batch*T floats (energy | rms | zcr) or NULL. */
 int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dataLength,
                      long long clipStride, float *dRe, float *dIm, float *dTemporal, void *stream,
                      int *used) {
@@ -82,15 +81,43 @@ int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dat
     if (!o->resultType && !dIm) return AFX_OK;
     AfxMelFusedArgs a;
     fast_args(o, dData, batch, dataLength, clipStride, dRe, dIm, &a);
+    const long long frames = (long long)batch * a.timeLength;
+    /* temporal features ride along in the n_fft 2048 real-result kernel; every other fused kernel runs without them and
+     * k_temporal (afx_stft.hip) reads the frames a second time -- from L2 -- instead of the whole call falling back to
+     * the size-generic kernels */
+    int separate = 0;
     if (dTemporal) {
-        const long long frames = (long long)batch * a.timeLength;
-        if (!o->resultType) return AFX_OK;
-        a.energy = dTemporal;
-        a.rms = dTemporal + frames;
-        a.zcr = dTemporal + 2 * frames;
+        if (o->resultType && o->radix2Exp == 11) {
+            a.energy = dTemporal;
+            a.rms = dTemporal + frames;
+            a.zcr = dTemporal + 2 * frames;
+        } else {
+            separate = 1;
+        }
     }
     int st = afxk_melfused_run(o->fast, &a, stream);
-    if (st == AFX_ERR_UNSUPPORTED) return AFX_OK; /* e.g. complex results at n_fft 4096: generic kernels */
+    if (st == AFX_ERR_UNSUPPORTED && a.energy) { /* a plan whose kernel has no temporal instantiation */
+        a.energy = a.rms = a.zcr = NULL;
+        separate = 1;
+        st = afxk_melfused_run(o->fast, &a, stream);
+    }
+    if (st == AFX_ERR_UNSUPPORTED) return AFX_OK; /* size-generic kernels */
+    if (st == AFX_OK && separate) {
+        AfxStftArgs t;
+        memset(&t, 0, sizeof(t));
+        t.x = dData;
+        t.clipStride = clipStride;
+        t.batch = batch;
+        t.dataLength = dataLength;
+        t.timeLength = a.timeLength;
+        t.radix2Exp = o->radix2Exp;
+        t.hop = o->slideLength;
+        t.window = o->dWindow;
+        t.energy = dTemporal;
+        t.rms = dTemporal + frames;
+        t.zcr = dTemporal + 2 * frames;
+        st = afxk_temporal(&t, stream);
+    }
     if (st == AFX_OK) *used = 1;
     return st;
 }

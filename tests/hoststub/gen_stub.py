@@ -115,6 +115,16 @@ static void touch_rows_r(const float *p, long long rows, long long width, long l
     if (DRY) return;
     for (long long r = 0; r < rows; r++) touch_read(p + r * pitch, width);
 }
+int afxk_temporal(const AfxStftArgs *a, void *stream) {
+    (void)stream;
+    const long long rows = (long long)a->batch * a->timeLength;
+    if (!a->energy || !a->rms || !a->zcr) return AFX_ERR_ARG;
+    touch_read(a->window, 1LL << a->radix2Exp);
+    touch_write(a->energy, rows, 1.f);
+    touch_write(a->rms, rows, 1.f);
+    touch_write(a->zcr, rows, 0.f);
+    return AFX_OK;
+}
 int afxk_stft(const AfxStftArgs *a, void *stream) {
     (void)stream;
     const long long N = 1LL << a->radix2Exp, rows = (long long)a->batch * a->timeLength;
@@ -340,7 +350,7 @@ int afxk_melfused_kind(const void *plan) { return plan ? 1 : 0; }
 DONE = {"afxdev_ensure", "afxdev_last_error", "afxdev_set_error", "afxdev_error_count", "afxdev_report_failure", "afxdev_no_fused", "afxdev_cqt_f32", "afxdev_malloc", "afxdev_free",
         "afxdev_memset", "afxdev_h2d", "afxdev_d2h", "afxdev_d2d", "afxdev_stream_create", "afxdev_stream_destroy",
         "afxdev_reserve", "afxk_cqt_decimate", "afxk_cqt_octave", "afxk_cqt_octave_f16",
-        "afxk_cqt_chroma", "afxk_stft", "afxk_istft", "afxk_spec_map", "afxk_row_post", "afxk_gemm_nt",
+        "afxk_cqt_chroma", "afxk_stft", "afxk_temporal", "afxk_istft", "afxk_spec_map", "afxk_row_post", "afxk_gemm_nt",
         "afxk_xxcc_standard", "afxk_cwt_forward", "afxk_cwt_inverse", "afxk_cwt_small", "afxk_wsst_squeeze",
         "afxk_synsq_phase", "afxk_reassign", "afxk_cqt_deconv", "afxk_cepstrogram", "afxk_cepstrum_supported",
         "afxk_cepstrum", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run", "afxk_melfused_destroy",

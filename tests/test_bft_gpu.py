@@ -405,6 +405,31 @@ def test_temporal_features_ride_in_the_fused_kernel(hop):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("r2,rt", [(9, 1), (10, 1), (12, 1), (11, 0), (12, 0)])
+def test_temporal_features_beside_the_other_fused_kernels(r2, rt):
+    """isTemporal objects at n_fft 512 / 1024 / 4096 (and complex results at any size) keep their fused bank kernel: the
+    energy / rms / zcr come from k_temporal, one wave per frame over the frames the bank kernel has just read (round 5;
+    such objects ran the size-generic kernels for everything before) -- bank rows and features against the reference"""
+    n, hop = 1 << r2, (1 << r2) // 4
+    x = cases.tones(12, 16000 * 2 + 301, 16000) + 0.05 * cases.noise(71 + r2, 16000 * 2 + 301)
+    r = ref.RefBFT(128, r2, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1, slide_length=hop, scale_type=2,
+                   style_type=0, normal_type=0, data_type=0, is_temporal=1)
+    r.set_result_type(rt)
+    re, im = r.bft(x)
+    we, wr, wz = r.temporal(re.shape[0])
+    o = af.BFT(128, radix2_exp=r2, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+               scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER, is_temporal=True)
+    assert o.fused_plan_kind() != 0
+    got = o.bft(x, result_type=rt).T
+    e, rms, z = o.get_temporal_data()
+    assert_parity(got, re if rt == 1 else re + 1j * im, TOL, f"temporal spec r{r2} rt{rt}")
+    assert_parity(e, we, TOL, "energy")
+    assert_parity(rms, wr, TOL, "rms")
+    # a sign change decided by a product at float32 rounding may differ: at most one count per frame
+    assert np.abs(z - wz).max() <= 1.0 / n + 1e-9 and (z != wz).mean() <= 0.02, np.abs(z - wz).max()
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("rt,dt", [(1, 0), (1, 1), (0, 0)])
 def test_dense_bank_at_the_headline_shape(rt, dt):
     """Dense (gammatone) bank at n_fft 2048 / 128 bands: STFT wave kernel -> pitched [T,F] scratch ->
