@@ -404,6 +404,8 @@ extern "C" int afxk_stft4k(const AfxStftArgs *a, void *stream);   // afx_melfuse
 extern "C" int afxk_stft1k(const AfxStftArgs *a, void *stream);   // afx_melfused1k.hip
 extern "C" int afxk_stft512(const AfxStftArgs *a, void *stream);  // afx_melfused512.hip
 
+extern "C" int afxk_temporal(const AfxStftArgs *a, void *stream);
+
 extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     if (a->radix2Exp < 1 || a->radix2Exp > 14) {
         afxdev_set_error("stft: fftLength 2^%d is outside the supported 2..16384", a->radix2Exp);
@@ -420,16 +422,21 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     // 252 VGPRs + 620 B/lane of scratch in 8-wave workgroups (38 M frames/s) or 412 registers in 4-wave
     // workgroups (47 M) and measured SLOWER than the size-generic kernel (58 M) both ways: not dispatched.
     const bool cplx = a->mode == AFX_SPEC_COMPLEX;
-    if (a->radix2Exp == 11 && !a->bandStart && !a->energy && a->binLo >= 0 && !afxdev_no_fused()) {
-        if (const float2 *tab = wave_tables())
-            return cplx ? launch_stft_wave<11, true>(a, tab, frames, stream)
-                        : launch_stft_wave<11, false>(a, tab, frames, stream);
+    // (temporal features asked for beside the bins -- the linear-scale objects with isTemporal: the wave kernels run without
+    //  them and k_temporal follows, instead of the whole call running the size-generic kernel)
+    AfxStftArgs bins = *a;
+    bins.energy = bins.rms = bins.zcr = nullptr;
+    if (a->radix2Exp == 11 && !a->bandStart && a->binLo >= 0 && !afxdev_no_fused()) {
+        if (const float2 *tab = wave_tables()) {
+            const int st = cplx ? launch_stft_wave<11, true>(&bins, tab, frames, stream) : launch_stft_wave<11, false>(&bins, tab, frames, stream);
+            return (st == AFX_OK && a->energy) ? afxk_temporal(a, stream) : st;
+        }
     }
     // n_fft 4096 (the wrapper's default), 1024, 512: the transform of that size's bank kernel storing its spectrum
     // (afx_melfused4k2 / 1k / 512.hip), when every frame lies inside its clip; AFX_ERR_UNSUPPORTED = not its case
-    if ((a->radix2Exp == 12 || a->radix2Exp == 10 || a->radix2Exp == 9) && !afxdev_no_fused()) {
-        const int st = a->radix2Exp == 12 ? afxk_stft4k(a, stream) : a->radix2Exp == 10 ? afxk_stft1k(a, stream) : afxk_stft512(a, stream);
-        if (st != AFX_ERR_UNSUPPORTED) return st;
+    if ((a->radix2Exp == 12 || a->radix2Exp == 10 || a->radix2Exp == 9) && !a->bandStart && !afxdev_no_fused()) {
+        const int st = a->radix2Exp == 12 ? afxk_stft4k(&bins, stream) : a->radix2Exp == 10 ? afxk_stft1k(&bins, stream) : afxk_stft512(&bins, stream);
+        if (st != AFX_ERR_UNSUPPORTED) return (st == AFX_OK && a->energy) ? afxk_temporal(a, stream) : st;
     }
     const int N = 1 << a->radix2Exp;
     int threads = N / 4;

@@ -405,6 +405,30 @@ def test_temporal_features_ride_in_the_fused_kernel(hop):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("r2", [9, 11, 12])
+def test_temporal_features_beside_a_linear_bin_slice(r2):
+    """linear-scale objects with isTemporal: the bins from the wave / spectrum kernels, the features from k_temporal"""
+    n, hop = 1 << r2, (1 << r2) // 4
+    num = n * 100 // 2048
+    # (noise: single power bins of a strong tone sit 1-3e-5 from the reference, whose float32 radix-2 transform carries that
+    #  error -- the mel rows of the test below average it away)
+    x = cases.noise(75 + r2, 16000 * 2 + 301)
+    r = ref.RefBFT(num, r2, samplate=16000, low_fre=1000.0, high_fre=8000.0, window_type=1, slide_length=hop, scale_type=0,
+                   style_type=0, normal_type=0, data_type=0, is_temporal=1)
+    r.set_result_type(1)
+    re, _ = r.bft(x)
+    we, wr, wz = r.temporal(re.shape[0])
+    o = af.BFT(num, radix2_exp=r2, samplate=16000, low_fre=1000.0, high_fre=8000.0, slide_length=hop,
+               scale_type=af.SpectralFilterBankScaleType.LINEAR, data_type=af.SpectralDataType.POWER, is_temporal=True)
+    got = o.bft(x, result_type=1).T
+    e, rms, z = o.get_temporal_data()
+    assert_parity(got, re, TOL, f"linear temporal r{r2}")
+    assert_parity(e, we, TOL, "energy")
+    assert_parity(rms, wr, TOL, "rms")
+    assert np.abs(z - wz).max() <= 1.0 / n + 1e-9 and (z != wz).mean() <= 0.02, np.abs(z - wz).max()
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("r2,rt", [(9, 1), (10, 1), (12, 1), (11, 0), (12, 0)])
 def test_temporal_features_beside_the_other_fused_kernels(r2, rt):
     """isTemporal objects at n_fft 512 / 1024 / 4096 (and complex results at any size) keep their fused bank kernel: the
