@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("script", ["proto_fft1024.py", "proto_fft1024_v2.py", "proto_fft512.py", "proto_cepstrogram_wave.py",
-                                    "proto_cqt_f16.py", "proto_gemm_bf16.py", "proto_cqt_pyramid.py"])
+                                    "proto_cqt_f16.py", "proto_gemm_bf16.py", "proto_cqt_pyramid.py", "proto_fft256.py"])
 def test_prototype_script(script):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], cwd=ROOT, capture_output=True,
                          text=True, timeout=300)
