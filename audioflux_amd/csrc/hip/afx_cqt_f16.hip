@@ -38,6 +38,18 @@
 #include "afx_pkmath.h"
 #include "afx_f16split.h"
 
+// Knock-out measurement builds (make EXTRA=-DAFX_KO_CQT=<mask>; results are WRONG, timing only; tools/gpu_ko_cqt.sh,
+// profiles/r06_ko_cqt.txt): bit 0 row stores, 1 chroma loads + stores, 2 ring stores, 3 A-operand LDS reads, 4 B-operand (image / tap)
+// LDS reads, 5 window conversion, 6 resampler products, 7 the two correction products of the K loop, 8 clip loads, 9 ring loads,
+// 11 row pieces as aligned 64-byte writes.  "Price" bits ADD work on the real data (knocking a class out changes the operands, and
+// the clock of this kernel depends on them): 12 every ring store twice (second copy into the chroma plane), 13 the K loop's first
+// product twice (+ 224 MFMAs per step), 14 the K loop's A-operand reads twice
+#ifdef AFX_KO_CQT
+#define CQ_KO(s) (((AFX_KO_CQT) >> (s)) & 1)
+#else
+#define CQ_KO(s) 0
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -129,6 +141,14 @@ __device__ __forceinline__ void cq_convert_window(const u32x4 (&wnd)[CqF16<H>::N
     }
 }
 
+// (knock-out builds: an operand the compiler cannot fold)
+__device__ __forceinline__ h8 cq_ko_operand(int salt) {
+    u32x4 v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v.x) : "s"(salt));
+    v.y = v.z = v.w = v.x;
+    return __builtin_bit_cast(h8, v);
+}
+
 // K loop: 32 steps x (xh gh, xh gl, xl gh), operands two steps ahead; nothing but MFMAs and DS reads at
 // immediate offsets between the two scheduling barriers
 template <int H>
@@ -139,10 +159,18 @@ __device__ __forceinline__ void cq_kloop(const unsigned char *aHi, const unsigne
     for (int r = 0; r < 16; ++r) hh[r] = hl[r] = lh[r] = 0.f;
     h8 ah[3], al[3], bh[3], bl[3];
     auto load = [&](int ks, int slot) {
-        ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
-        al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
-        bh[slot] = *reinterpret_cast<const h8 *>(bHi + 1024 * ks);
-        bl[slot] = *reinterpret_cast<const h8 *>(bLo + 1024 * ks);
+        if (CQ_KO(3)) {
+            ah[slot] = al[slot] = cq_ko_operand(0x3c003c00);
+        } else {
+            ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
+            al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
+        }
+        if (CQ_KO(4)) {
+            bh[slot] = bl[slot] = cq_ko_operand(0x38003800);
+        } else {
+            bh[slot] = *reinterpret_cast<const h8 *>(bHi + 1024 * ks);
+            bl[slot] = *reinterpret_cast<const h8 *>(bLo + 1024 * ks);
+        }
     };
     load(0, 0);
     load(1, 1);
@@ -152,9 +180,16 @@ __device__ __forceinline__ void cq_kloop(const unsigned char *aHi, const unsigne
         if (ks + 2 < C::KS) load(ks + 2, (ks + 2) % 3);
         const int sl = ks % 3;
         hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bh[sl], hh, 0, 0, 0);
-        hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bl[sl], hl, 0, 0, 0);
-        lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl], bh[sl], lh, 0, 0, 0);
-        if (ks + 2 < C::KS) {
+        if (CQ_KO(13)) lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bh[sl], lh, 0, 0, 0);
+        if (CQ_KO(14) && ks + 2 < C::KS) {
+            h8 d0 = *reinterpret_cast<const volatile h8 *>(aHi + C::step(ks + 2)), d1 = *reinterpret_cast<const volatile h8 *>(aLo + C::step(ks + 2));
+            asm volatile("" ::"v"(d0), "v"(d1));
+        }
+        if (!CQ_KO(7)) {
+            hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl], bl[sl], hl, 0, 0, 0);
+            lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl], bh[sl], lh, 0, 0, 0);
+        }
+        if (ks + 2 < C::KS && !CQ_KO(3) && !CQ_KO(4) && !CQ_KO(7) && !CQ_KO(13) && !CQ_KO(14)) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -219,7 +254,11 @@ __device__ __forceinline__ void cq_store_tile(const f32x16 &hh, const f32x16 &hl
             const u32x4 v = *reinterpret_cast<const u32x4 *>(L.epiR + (q >> 1) * 2048 + (q & 1) * 64);
             const u32x3 v3 = {v.x, v.y, v.z};
             if (pieces) pieces[q] = v3;  // (the pyramid's chroma: bins 3 (lane & 3) .. + 2 of frame 16 (q >> 1) + (lane >> 2), plane q & 1)
-            __builtin_amdgcn_raw_buffer_store_b96(v3, (q & 1) ? rIm : rRe, L.voff12 + tileOff + (unsigned)(q >> 1) * 16u * L.rowBytes, 0, AUX);
+#if defined(AFX_KO_CQT) && (AFX_KO_CQT & 2048)  // bit 11 (timing only): every row piece as an ALIGNED 64-byte write (4 lanes x 16 bytes) instead of 48 bytes
+            __builtin_amdgcn_raw_buffer_store_b128(v, (q & 1) ? rIm : rRe, ((L.voff12 + tileOff + (unsigned)(q >> 1) * 16u * L.rowBytes) & ~63u) + 16u * (threadIdx.x & 3), 0, AUX);
+#else
+            __builtin_amdgcn_raw_buffer_store_b96(v3, (q & 1) ? rIm : rRe, CQ_KO(0) ? 0x80000000u + 16u * q : L.voff12 + tileOff + (unsigned)(q >> 1) * 16u * L.rowBytes, 0, AUX);
+#endif
         }
     } else {
 #pragma unroll
@@ -376,6 +415,16 @@ constexpr int LDS_BYTES = CqF16<128>::B_BYTES + plane_off(7) + TAB_BYTES + ALT_B
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr int AUX_L2 = 17;                           // sc0 sc1: served by the L2, never by this CU's L1
 constexpr int AUX_STREAM = 2;                        // nt: the clip and the rows pass through once -- they must not push the rings out of the L2
+// (measurement builds: cache policy of the row stores / the ring stores / the chroma stores)
+#ifndef AFX_CQ_ROW_AUX
+#define AFX_CQ_ROW_AUX 2
+#endif
+#ifndef AFX_CQ_RING_AUX
+#define AFX_CQ_RING_AUX 0
+#endif
+#ifndef AFX_CQ_CHROMA_AUX
+#define AFX_CQ_CHROMA_AUX 0
+#endif
 // tiles of level k whose resampler output (block of level k+1) a run [t0, t1) needs: [t0 - need_back(k), t1 + need_ahead(k)]
 __host__ __device__ constexpr int need_back(int k) { return 9 - k; }
 __host__ __device__ constexpr int need_ahead(int k) { return 8 - k; }
@@ -425,10 +474,18 @@ __device__ __forceinline__ void pyr_dec_loop(const unsigned char *aHi, const uns
     for (int r = 0; r < 16; ++r) hh[r] = hl[r] = lh[r] = 0.f;
     h8 ah[3], al[3], th[3], tl[3];
     auto load = [&](int ks, int slot) {
-        ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
-        al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
-        th[slot] = *reinterpret_cast<const h8 *>(tHi + 32 * ks);
-        tl[slot] = *reinterpret_cast<const h8 *>(tLo + 32 * ks);
+        if (CQ_KO(3)) {
+            ah[slot] = al[slot] = cq_ko_operand(0x3c003c00);
+        } else {
+            ah[slot] = *reinterpret_cast<const h8 *>(aHi + C::step(ks));
+            al[slot] = *reinterpret_cast<const h8 *>(aLo + C::step(ks));
+        }
+        if (CQ_KO(4)) {
+            th[slot] = tl[slot] = cq_ko_operand(0x38003800);
+        } else {
+            th[slot] = *reinterpret_cast<const h8 *>(tHi + 32 * ks);
+            tl[slot] = *reinterpret_cast<const h8 *>(tLo + 32 * ks);
+        }
     };
     load(KS0, 0);
     load(KS0 + 1, 1);
@@ -442,7 +499,7 @@ __device__ __forceinline__ void pyr_dec_loop(const unsigned char *aHi, const uns
         hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[sl], ah[sl], hh, 0, 0, 0);
         hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[sl], ah[sl], hl, 0, 0, 0);
         lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[sl], al[sl], lh, 0, 0, 0);
-        if (ks + 2 <= KS1) {
+        if (ks + 2 <= KS1 && !CQ_KO(3) && !CQ_KO(4)) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -476,13 +533,14 @@ __device__ __forceinline__ void cq_zero_samples(unsigned char *sig, int first, i
 // signal (only the first and the last blocks of a clip take the masked path).
 template <int H, int CT>
 __device__ __forceinline__ void pyr_dec_store(const f32x16 &hh, const f32x16 &hl, const f32x16 &lh, float mul, int t, int lane,
-                                              const __amdgpu_buffer_rsrc_t &ring, unsigned ringMask, int dstLen) {
+                                              const __amdgpu_buffer_rsrc_t &ring, unsigned ringMask, int dstLen,
+                                              const __amdgpu_buffer_rsrc_t &ringDup) {
     constexpr int W = H / 2;                      // outputs per frame
     constexpr int NQ = W - 32 * CT >= 32 ? 4 : W >= 8 ? W / 8 : 1;  // 16-byte pieces per lane that hold valid outputs
     const int tf = lane & 31, g = lane >> 5;
     const int i0 = (32 * t + tf) * W + 32 * CT + 4 * g;
     const bool laneOk = W >= 8 || g == 0;         // W = 4, 2: outputs 0 ... W-1 sit in the g = 0 half only
-    const unsigned base = laneOk ? ((unsigned)i0 & ringMask) * 4u : 0x80000000u;
+    const unsigned base = (laneOk && !CQ_KO(2)) ? ((unsigned)i0 & ringMask) * 4u : 0x80000000u;
     const int blockLo = 32 * t * W, blockHi = blockLo + 32 * W;
     const bool inside = blockLo >= 0 && blockHi <= dstLen;  // wave-uniform
 #pragma unroll
@@ -498,7 +556,8 @@ __device__ __forceinline__ void pyr_dec_store(const f32x16 &hh, const f32x16 &hl
         }
         if (W >= 4) {
             const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(o, ring, (int)(base + 32u * q), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, ring, (int)(base + 32u * q), 0, AFX_CQ_RING_AUX);
+            if (CQ_KO(12)) __builtin_amdgcn_raw_buffer_store_b128(o, ringDup, (int)(base + 32u * q), 0, AFX_CQ_RING_AUX);
         } else {  // hop 4: two outputs per frame
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), ring, (int)base, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), ring, (int)(base + 4u), 0, 0);
@@ -527,7 +586,7 @@ __device__ __forceinline__ void pyr_chroma_request(PyrChroma &ch, int t, int lan
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             ch.part[h][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                ch.rows, (int)((unsigned)(32 * t + 16 * h + (lane >> 2)) * 48u + ch.off[j]), 0, pyr::AUX_L2));
+                ch.rows, CQ_KO(1) ? (int)(0x80000000u + 4u * (3 * h + j)) : (int)((unsigned)(32 * t + 16 * h + (lane >> 2)) * 48u + ch.off[j]), 0, pyr::AUX_L2));
 }
 
 template <int K>
@@ -566,7 +625,7 @@ __device__ __forceinline__ void pyr_chroma_add(PyrChroma &ch, const u32x3 (&piec
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), ch.rows,
-                                                  (int)((unsigned)(32 * t + 16 * h + (lane >> 2)) * 48u + ch.off[j]), 0, 0);
+                                                  CQ_KO(1) ? (int)(0x80000000u + 4u * (3 * h + j)) : (int)((unsigned)(32 * t + 16 * h + (lane >> 2)) * 48u + ch.off[j]), 0, AFX_CQ_CHROMA_AUX);
     }
 }
 
@@ -613,6 +672,10 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
     const __amdgpu_buffer_rsrc_t ringNext =
         __builtin_amdgcn_make_buffer_rsrc(wgRing + pyr::ring_off(KN), 0, pyr::ring_size(KN) * 4, RSRC_RAW);
     constexpr unsigned NMASK = (unsigned)pyr::ring_size(KN) - 1u;
+    // (price build, bit 12: a second copy of every ring store, into this workgroup's slice of the chroma plane)
+    const __amdgpu_buffer_rsrc_t ringDup = __builtin_amdgcn_make_buffer_rsrc(
+        (CQ_KO(12) && a.chroma) ? a.chroma + (size_t)blockIdx.x * AFX_CQT_PYR_RING_FLOATS + pyr::ring_off(KN) : wgRing, 0,
+        (CQ_KO(12) && a.chroma) ? pyr::ring_size(KN) * 4 : 0, RSRC_RAW);
     float *outRe = a.outRe + (long long)clip * a.outStride, *outIm = a.outIm + (long long)clip * a.outStride;
     constexpr int NW = PREP ? C::NV : 1;
     u32x4 wnd[NW];
@@ -627,7 +690,7 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
 #pragma unroll
         for (int u = 0; u < (PREP ? C::NV : 0); ++u) {
             const int pos = p0 + 4 * (lane + 64 * u);
-            wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)pos & RMASK) * 4u), 0, K == 0 ? pyr::AUX_STREAM : pyr::AUX_L2);
+            wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, CQ_KO(K == 0 ? 8 : 9) ? (int)(0x80000000u + 16u * u) : (int)(((unsigned)pos & RMASK) * 4u), 0, K == 0 ? pyr::AUX_STREAM : pyr::AUX_L2);
         }
     };
     // the wave works on tile s - LAG: the octave's rows for the tiles of the run, the resampler also for the tiles
@@ -659,7 +722,7 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         const int e = cq_window_exponent<H>(reinterpret_cast<const u32x4(&)[C::NV]>(wnd), lane);
         const float up = __uint_as_float((unsigned)(e + 127) << 23);
         wave_lds_order();
-        cq_convert_window<H>(reinterpret_cast<const u32x4(&)[C::NV]>(wnd), up, sig, lane);
+        if (!CQ_KO(5)) cq_convert_window<H>(reinterpret_cast<const u32x4(&)[C::NV]>(wnd), up, sig, lane);
         wave_lds_order();
         return __uint_as_float((unsigned)(127 - e) << 23);
     };
@@ -679,7 +742,7 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         L.epiW += bf * ALT;
         L.epiR += bf * ALT;
         u32x3 pieces[4];
-        cq_store_tile<true, pyr::AUX_STREAM>(hh, hl, lh, dn, L, outRe, outIm, tt * 32, pieces);
+        cq_store_tile<true, AFX_CQ_ROW_AUX>(hh, hl, lh, dn, L, outRe, outIm, tt * 32, pieces);
         if (chromaOn) pyr_chroma_add<K>(ch, pieces, tt, lane, a.chromaMag, a.chromaNorm);
     };
     // a convert-first wave finds the window of step s in registers requested during step s - 1; the run's first step has
@@ -718,16 +781,16 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         // wait at the barrier), and the octave's epilogue transposes through the planes
         if (WORK && DEC && dec) {
             f32x16 dh, dl, dm;
-            if (empty) {
+            if (empty || CQ_KO(6)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dh[r] = dl[r] = dm[r] = 0.f;
             } else {
                 pyr_dec_loop<H, 0>(aHi, aHi + C::PART, tHi, tLo, dh, dl, dm);
             }
-            pyr_dec_store<H, 0>(dh, dl, dm, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
+            pyr_dec_store<H, 0>(dh, dl, dm, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN], ringDup);
             if (H / 2 > 32) {
-                if (!empty) pyr_dec_loop<H, 1>(aHi, aHi + C::PART, tHi - 128, tLo - 128, dh, dl, dm);  // outputs 32 ... 63: 64 table entries down
-                pyr_dec_store<H, 1>(dh, dl, dm, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN]);
+                if (!empty && !CQ_KO(6)) pyr_dec_loop<H, 1>(aHi, aHi + C::PART, tHi - 128, tLo - 128, dh, dl, dm);  // outputs 32 ... 63: 64 table entries down
+                pyr_dec_store<H, 1>(dh, dl, dm, down * a.decMul, t, lane, ringNext, NMASK, a.len[KN], ringDup);
             }
         }
         clk.lap(5);
@@ -762,6 +825,11 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
         }
         pyr_barrier();
         clk.lap(6);
+        if (TIMING && K == 0 && PART == 1 && blockIdx.x == 0 && tim && lane == 0) {
+            // the step's end as an absolute stamp: entry i of the series lives in the spare rows 9, 10 of block i / 16
+            const int i = s - s0;
+            if (i < 4096) (tim - (size_t)(threadIdx.x >> 6) * 8)[((size_t)(i >> 4) * 11 + 9 + ((i >> 3) & 1)) * 8 + (i & 7)] = __builtin_amdgcn_s_memtime();
+        }
     }
     if (LATE && pend) rows_out(pendDown, pendT, 0);  // (not reached: a run ends with DRAIN steps without rows)
     clk.flush(tim, lane);
@@ -786,6 +854,7 @@ __global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidAr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long tKernel0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
     cq_image_to_lds(a.timeKernelH, smem_raw, tid, 64 * pyr::WAVES);
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(a.decTab);
@@ -807,6 +876,13 @@ __global__ __launch_bounds__(64 * pyr::WAVES) void k_cqt_pyramid(AfxCqtPyramidAr
         case 6: pyr_role<5, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
         case 3: pyr_role<3, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
         default: pyr_role<4, 0, TIMING>(a, smem_raw, lane, wgRing, items); break;
+    }
+    if (TIMING && a.timing && tid == 0) {  // row 8 of the block: kernel cycles (summed over launches), start / end stamps of the last one
+        unsigned long long *r8 = a.timing + ((size_t)blockIdx.x * 11 + 8) * 8;
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        r8[0] += t1 - tKernel0;
+        r8[1] = tKernel0;
+        r8[2] = t1;
     }
 }
 

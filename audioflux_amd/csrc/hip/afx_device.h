@@ -442,10 +442,11 @@ typedef struct {
     float normValue;
     float *out;     /* device [batch*timeLength, num]                       */
     float *outIm;   /* device, same shape; complex result modes only        */
-    /* optional fusions of the n_fft 2048 real-result kernel (afx_melfused2.hip); a run that cannot
+    /* optional fusions: cepstra (every fused kernel, real results) and temporal features (n_fft 2048); a run that cannot
      * honour them returns AFX_ERR_UNSUPPORTED and the caller takes the separate kernels */
     const float *dct; /* device [num, num] orthonormal DCT-II: cepstra of the rows in the same launch */
-    int ccNum;        /*   first ccNum coefficients of log10(max(row, 1e-8)); needs `out`              */
+    int ccNum;        /*   first ccNum (<= 16) coefficients of the rectified rows; needs `out`           */
+    int ccRectify;    /*   0: log10f(max(row, 1e-8)), 1: powf(row, 1/3) (xxcc_algorithm.c:124-137)        */
     float *cc;        /*   device [batch*timeLength, ccNum]                                          */
     float *energy, *rms, *zcr; /* device [batch*timeLength]: temporal features of the windowed frame */
 } AfxMelFusedArgs;

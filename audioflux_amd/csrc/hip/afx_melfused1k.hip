@@ -19,6 +19,7 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_pkmath.h"
+#include "afx_ccblock.h"
 
 namespace {
 
@@ -67,6 +68,10 @@ struct KArgs {
     int mode;              // AFX_SPEC_*
     int binLo, binCount;   // bins binLo .. binLo + binCount - 1 are stored; above 512: conjugate mirrors
     long long outPitch;    // floats between output rows
+    // CC instantiations: cepstra of the rows in the same launch (afx_ccblock.h)
+    const float *dct;      // device [num, num] orthonormal DCT-II
+    int ccNum, ccCbrt;
+    float *cc;             // [totalFrames, ccNum]
 };
 
 // what an STFT instantiation stores for a spectrum value (the maps of afx_stft.hip)
@@ -117,9 +122,11 @@ __device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &k
 //   spectrum, linear-scale bin slices: afxk_stft1k, afx_melfused4k2.hip has the same at n_fft 4096); MAPPED: any AFX_SPEC_* map,
 //   otherwise the complex values as they are; FULL: all 1024 bins are stored (no range checks)
 // SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split): banks whose rows are longer than the tap variants
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false, bool SPLIT = false>
+// CC: cepstra of the rows in the same launch (real results; afx_ccblock.h: every 16 frames the wave re-reads its rows from L2)
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false, bool SPLIT = false, bool CC = false>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
     static_assert(!STFT || (CPLX && TA == 0 && TB == 0 && !SPLIT), "STFT instantiations: complex values, no bank");
+    static_assert(!CC || (!CPLX && !STFT), "cepstra: real bank rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -163,7 +170,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
 
     const int startA = STFT ? 0 : a.meta[lane], startB = STFT ? 0 : a.meta[64 + lane];
     const int rowA = STFT ? -1 : a.meta[128 + lane], rowB = STFT ? -1 : a.meta[192 + lane];
-    const unsigned seg0 = SPLIT ? (unsigned)a.meta[256 + lane] : 0u, seg1 = SPLIT ? (unsigned)a.meta[320 + lane] : 0u;
+    // (split plans with cepstra sit at the 128-register cap: they re-read their two segment words per frame -- vector cache --
+    // instead of carrying them through the loop)
+    const unsigned seg0 = (SPLIT && !CC) ? (unsigned)a.meta[256 + lane] : 0u, seg1 = (SPLIT && !CC) ? (unsigned)a.meta[320 + lane] : 0u;
     const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
     const unsigned awr = T0 + TAB_BYTES + 4 * WP * lane;
 
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
     if (f >= fEnd) return;
     int clip = (int)(f / a.timeLength);
     int t = (int)(f - (long long)clip * a.timeLength);
+    int ccN = 0;  // CC: rows of this wave whose cepstra are still to be formed
 
     // raw[r] = (x[2n], x[2n+1]), n = 64 r + lane
     v2 raw[8];
@@ -451,6 +461,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 accB = powf(accB, a.normValue);
             }
             // ---- 5. store --------------------------------------------------------------
+            if constexpr (CC && !SPLIT) {
+                // the cepstra of the 16 rows stored BEFORE this one: their stores are a frame old, the block's wait finds them complete
+                if (ccN == 16) {
+                    ccb_rows<4>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane);
+                    ccN = 0;
+                }
+            }
             float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
             if constexpr (SPLIT) {
                 // slot results -> LDS (start of the wave's region: the images there are dead, the power row starts behind), then every
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 wave_lds_order();
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const unsigned u = h ? seg1 : seg0;
+                    const unsigned u = CC ? (unsigned)a.meta[256 + 64 * h + lane] : (h ? seg1 : seg0);
                     float sum = part[u & 255u] + part[(u >> 8) & 255u];
                     sum += part[(u >> 16) & 255u];
                     sum += part[u >> 24];
@@ -473,6 +490,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
             } else {
                 if (rowA >= 0) orow[rowA] = accA;
                 if (rowB >= 0) orow[rowB] = accB;
+            }
+            if constexpr (CC) {
+                // split plans: ONE call site, behind the row's stores where the band stage's values are dead (its wait then covers the
+                // 16th row's stores); whole-row plans: only the wave's last rows here
+                ++ccN;
+                if ((SPLIT && ccN == 16) || f + 1 == fEnd) {
+                    ccb_rows<2, 1>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane);
+                    ccN = 0;
+                }
             }
         }
         }  // !STFT
@@ -522,7 +548,7 @@ struct Variant {
 constexpr Variant kVariants[] = {{24, 8}, {32, 32}, {48, 16}, {72, 32}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool SPLIT = false>
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool SPLIT = false, bool CC = false>
 int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -559,15 +585,19 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.out = a->out;
     k.outIm = a->outIm;
     k.num = p->num;
+    k.dct = a->dct;
+    k.ccNum = a->ccNum;
+    k.ccCbrt = a->ccRectify == 1;
+    k.cc = a->cc;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet[attrDev] = true;
     }
-    hipLaunchKernelGGL((k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_band_1k");
     return AFX_OK;
@@ -577,6 +607,15 @@ template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const bool general = (a->specMap != 0) || a->postPow;
     const bool shift2 = (a->hop == 256);  // hop = 128 * SHIFT
+    if (a->cc) {  // cepstra in the same launch: real results, plain power rows on whole-row plans, every real mode on split plans
+        if (a->specMap >= 3 || a->ccNum < 1 || a->ccNum > 16 || !a->dct || !a->out || p->num > 128 || (p->num & 3) ||
+            (a->ccRectify != 0 && a->ccRectify != 1) || a->energy)
+            return AFX_ERR_UNSUPPORTED;
+        if (p->split)
+            return shift2 ? launch_variant<TA, TB, true, 2, false, true, true>(p, a, stream) : launch_variant<TA, TB, true, 0, false, true, true>(p, a, stream);
+        if (general) return AFX_ERR_UNSUPPORTED;
+        return shift2 ? launch_variant<TA, TB, false, 2, false, false, true>(p, a, stream) : launch_variant<TA, TB, false, 0, false, false, true>(p, a, stream);
+    }
     if (p->split) {  // segment plans: the general instantiations only (they take the plain modes too)
         if (a->specMap >= 3) {
             if (!a->outIm) return AFX_ERR_ARG;
@@ -678,7 +717,7 @@ extern "C" int afxk_mel1k_create(void **plan, const float *hWindow, const AfxBan
 }
 
 extern "C" int afxk_mel1k_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
-    if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;  // fusions exist at n_fft 2048 only
+    if (a->energy) return AFX_ERR_UNSUPPORTED;  // temporal features ride along at n_fft 2048 only (cepstra: every size, launch())
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p) return AFX_ERR_ARG;
     switch (p->variant) {

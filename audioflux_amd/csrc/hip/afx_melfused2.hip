@@ -21,7 +21,9 @@
 //   * cepstra in the same launch (CC): every 16 frames the wave re-reads its own 16 mel rows
 //     (L2-resident), takes log10 and runs 32 v_mfma_f32_16x16x4_f32 against the DCT rows held
 //     in LDS -- the matrix pipe is otherwise idle in this kernel, the second launch and its
-//     478 MB re-read of mel from HBM disappear (xxcc_algorithm.c:124-155)
+//     478 MB re-read of mel from HBM disappear (xxcc_algorithm.c:124-155).  CC = 1: the headline
+//     form (num = 128, log10, whole-row plan); CC = 2: afx_ccblock.h's general form (any num <= 128
+//     that is a multiple of 4, split plans, cube-root rectification; DCT operand from memory)
 //   * temporal features (TEMPORAL): energy / rms / zero-crossing rate of the windowed frame
 //     as wave reductions (temporal_algorithm.c:138-144), so isTemporal objects stay on this kernel
 //
@@ -35,6 +37,7 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_pkmath.h"
+#include "afx_ccblock.h"
 
 // Knock-out measurement builds (make EXTRA=-DAFX_KO=<mask>; results are WRONG, timing only): bit s drops the LDS traffic of
 // site class s -- 0 exchange writes, 1 exchange / image reads, 2 table reads (window, twiddles), 3 band-stage reads, 4 power-row
@@ -99,7 +102,7 @@ struct KArgs2 {
     int num;
     // CC
     const float *dct;      // device [num, num] orthonormal DCT-II (row = coefficient)
-    int ccNum;
+    int ccNum, ccCbrt;     // (ccCbrt: powf(x, 1/3) instead of log10, CC = 2 only)
     float *cc;             // [totalFrames, ccNum]
     // TEMPORAL
     float *energy, *rms, *zcr;  // [totalFrames]
@@ -169,10 +172,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // SHIFT: hop = 128 * SHIFT samples -> the next frame's register image is this one moved down by
 //   SHIFT registers, only SHIFT new float2 per lane are fetched (0: every frame fetched whole)
 // SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split)
-// CC: cepstra of the rows in the same launch (num = 128, ccNum <= 16, log10 rectification)
+// CC: cepstra of the rows in the same launch, ccNum <= 16 (1: num = 128, log10 rectification, DCT operand in LDS; 2: afx_ccblock.h)
 // TEMPORAL: energy / rms / zcr of the windowed frame
 // CPLX: complex results (specMap 3: S, 4: S^2): a second row in LDS holds the imaginary parts for a second pass of the bank
-template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL, bool CPLX = false>
+template <int TA, int TB, int SHIFT, bool SPLIT, int CC, bool TEMPORAL, bool CPLX = false>
 __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a) {
     constexpr int NWV = waves_of(CPLX);
     static_assert(!(CPLX && (CC || TEMPORAL)), "complex results: the bank only");
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
     const int wave = threadIdx.x >> 6;
     constexpr int WP = wpitch(TA, TB);
     constexpr int TABB = tab_bytes(TA, TB);
-    constexpr int DCTB = CC ? 64 * DCT_PITCH * 4 : 0;
+    constexpr int DCTB = CC == 1 ? 64 * DCT_PITCH * 4 : 0;
     unsigned char *wreg = smem + TABB + DCTB + wave * WAVE_LDS;
     float *prow = reinterpret_cast<float *>(wreg + PROW_OFF);
 
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
     {
         float4 *s4 = reinterpret_cast<float4 *>(smem);
         for (int i = threadIdx.x; i < TABB / 16; i += NWV * 64) s4[i] = a.tab[i];
-        if constexpr (CC) {
+        if constexpr (CC == 1) {
             // B operand of the cepstrum MFMAs: lane (coefficient fi = lane & 15, k-slot g = lane >> 4)
             // holds dct[fi][16 u + 4 g + c] at [lane][4 u + c]
             float *tabD = reinterpret_cast<float *>(smem + TABB);
@@ -265,6 +268,9 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
     //      the matching DCT elements come from the LDS table.  Called one frame AFTER the 16th row was
     //      stored, so the s_waitcnt finds those stores long complete; reads bypass the CU's L1.
     auto cc_block = [&](long long fb, int cnt) {
+        if constexpr (CC == 2) {  // the general form: runtime num / rectification, DCT operand from memory
+            ccb_rows<SPLIT ? 2 : 4>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, fb, cnt, lane);
+        } else {
         VM_WAIT_ALL();  // own stores -> L2 (vmcnt counts stores on gfx9)
         int ln = lane;
         PIN(ln);  // keep this block's per-lane values out of the frame loop's registers
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
                 if (rr < cnt) a.cc[(fb + rr) * a.ccNum + fi] = sum[reg];
             }
         }
+        }  // CC == 1
         ccN -= cnt;
     };
 
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
         }
         MEL_PHASE(6);
         // ---- 5. store (first the cepstra of the 16 rows stored before this one, if that many wait) ----
-        if constexpr (CC) {
+        if constexpr (CC != 0 && !SPLIT) {
             if (ccN == 16) cc_block(f - 16, 16);
         }
         float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
@@ -632,9 +639,12 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
             if (rowA >= 0) orow[rowA] = accA;
             if (rowB >= 0) orow[rowB] = accB;
         }
-        if constexpr (CC) {
+        if constexpr (CC != 0) {
             ++ccN;
-            if (f + 1 == fEnd) cc_block(f + 1 - ccN, ccN);  // the wave's last rows (drains its last stores)
+            // the wave's last rows (drains its last stores).  Split plans: ONE call site, behind the row's stores where the
+            // band stage's values are dead (beside them the block spilled 336-656 bytes per lane); its wait then covers the
+            // stores of the 16th row as well, once per 16 frames
+            if (f + 1 == fEnd || (SPLIT && ccN == 16)) cc_block(f + 1 - ccN, ccN);
         }
         wave_lds_sync();  // the next frame overwrites the images / the power row
 
@@ -657,7 +667,7 @@ struct Variant {
 };
 constexpr Variant kVariants[] = {{48, 16}, {72, 32}};
 
-template <int TA, int TB, int SHIFT, bool SPLIT, bool CC, bool TEMPORAL, bool CPLX = false>
+template <int TA, int TB, int SHIFT, bool SPLIT, int CC, bool TEMPORAL, bool CPLX = false>
 int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -697,11 +707,12 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     k.num = p->num;
     k.dct = a->dct;
     k.ccNum = a->ccNum;
+    k.ccCbrt = a->ccRectify == 1;
     k.cc = a->cc;
     k.energy = a->energy;
     k.rms = a->rms;
     k.zcr = a->zcr;
-    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB, CC);
+    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB, CC == 1);
     static_assert(lds <= 163840, "workgroup LDS budget");
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
@@ -716,7 +727,7 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     return AFX_OK;
 }
 
-template <int TA, int TB, bool SPLIT, bool CC, bool TEMPORAL>
+template <int TA, int TB, bool SPLIT, int CC, bool TEMPORAL>
 int launch_hop(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     // register re-use of the overlapping frames for hop = 128 * SHIFT: N/8, N/4, N/2
 #ifdef AFX_EXPERIMENTS  // measurement builds only (make EXTRA=-DAFX_EXPERIMENTS): AFX_EXP_MEL=noshift fetches every frame whole
@@ -738,25 +749,29 @@ int launch(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
         if (cc || tmp) return AFX_ERR_UNSUPPORTED;
         if (!a->outIm) return AFX_ERR_ARG;
         if (a->hop == 512)
-            return p->split ? launch_variant<TA, TB, 4, true, false, false, true>(p, a, stream)
-                            : launch_variant<TA, TB, 4, false, false, false, true>(p, a, stream);
-        return p->split ? launch_variant<TA, TB, 0, true, false, false, true>(p, a, stream)
-                        : launch_variant<TA, TB, 0, false, false, false, true>(p, a, stream);
+            return p->split ? launch_variant<TA, TB, 4, true, 0, false, true>(p, a, stream)
+                            : launch_variant<TA, TB, 4, false, 0, false, true>(p, a, stream);
+        return p->split ? launch_variant<TA, TB, 0, true, 0, false, true>(p, a, stream)
+                        : launch_variant<TA, TB, 0, false, 0, false, true>(p, a, stream);
     }
     if (cc && tmp) return AFX_ERR_UNSUPPORTED;  // callers run the cepstra separately for temporal objects
     if (cc) {
-        if (p->split || p->num != 128 || a->ccNum < 1 || a->ccNum > 16 || !a->dct || !a->out) return AFX_ERR_UNSUPPORTED;
-        if (block_lds_bytes(TA, TB, true) > 163840) return AFX_ERR_UNSUPPORTED;
-        if constexpr (block_lds_bytes(TA, TB, true) <= 163840) return launch_hop<TA, TB, false, true, false>(p, a, stream);
-        return AFX_ERR_UNSUPPORTED;
+        if (a->ccNum < 1 || a->ccNum > 16 || !a->dct || !a->out || p->num > 128 || (p->num & 3)) return AFX_ERR_UNSUPPORTED;
+        if (a->ccRectify != 0 && a->ccRectify != 1) return AFX_ERR_UNSUPPORTED;
+        if constexpr (block_lds_bytes(TA, TB, true) <= 163840)  // the headline form: DCT operand in LDS
+            if (!p->split && p->num == 128 && a->ccRectify == 0) return launch_hop<TA, TB, false, 1, false>(p, a, stream);
+        // the general form (afx_ccblock.h): hop N/4 with the register re-use of the overlapping frames, any other hop plain
+        if (a->hop == 512)
+            return p->split ? launch_variant<TA, TB, 4, true, 2, false>(p, a, stream) : launch_variant<TA, TB, 4, false, 2, false>(p, a, stream);
+        return p->split ? launch_variant<TA, TB, 0, true, 2, false>(p, a, stream) : launch_variant<TA, TB, 0, false, 2, false>(p, a, stream);
     }
     if (tmp) {
         if (!a->rms || !a->zcr) return AFX_ERR_ARG;
-        return p->split ? launch_hop<TA, TB, true, false, true>(p, a, stream)
-                        : launch_hop<TA, TB, false, false, true>(p, a, stream);
+        return p->split ? launch_hop<TA, TB, true, 0, true>(p, a, stream)
+                        : launch_hop<TA, TB, false, 0, true>(p, a, stream);
     }
-    return p->split ? launch_hop<TA, TB, true, false, false>(p, a, stream)
-                    : launch_hop<TA, TB, false, false, false>(p, a, stream);
+    return p->split ? launch_hop<TA, TB, true, 0, false>(p, a, stream)
+                    : launch_hop<TA, TB, false, 0, false>(p, a, stream);
 }
 
 }  // namespace

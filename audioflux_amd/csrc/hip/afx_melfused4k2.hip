@@ -32,6 +32,7 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_pkmath.h"
+#include "afx_ccblock.h"
 
 namespace {
 
@@ -76,6 +77,10 @@ struct KArgs4 {
     int mode;              // AFX_SPEC_*
     int binLo, binCount;   // bins binLo .. binLo + binCount - 1 are stored; above 2048: conjugate mirrors
     long long outPitch;    // floats between output rows
+    // CC instantiations: cepstra of the rows in the same launch (afx_ccblock.h)
+    const float *dct;      // device [num, num] orthonormal DCT-II
+    int ccNum, ccCbrt;
+    float *cc;             // [totalFrames, ccNum]
 };
 
 // orders this wave's LDS stores before its later LDS loads of other lanes' data (afx_melfused2.hip)
@@ -159,8 +164,10 @@ __device__ __forceinline__ void stft_map(float re, float im, int mode, float nor
 // STFT: no bank -- the spectrum values themselves (CPLX form, specMap 3) go to memory through stft_map: the STFT object's
 //   full complex spectrum, the linear-scale bin slices, the reassignment object's transforms (afxk_stft4k; frames inside the clip);
 //   MAPPED: any AFX_SPEC_* map, otherwise the complex values as they are; FULL: all 4096 bins are stored (no range checks)
-template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false>
+// CC: cepstra of the rows in the same launch (real results; afx_ccblock.h: every 16 frames the wave re-reads its rows from L2)
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false, bool CC = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
+    static_assert(!CC || (!CPLX && !STFT), "cepstra: real bank rows");
     static_assert(!STFT || (CPLX && !SPLIT && TA == 0 && TB == 0), "STFT instantiations: complex values, no bank");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
     if (f >= fEnd) return;
     int clip = (int)(f / a.timeLength);
     int t = (int)(f - (long long)clip * a.timeLength);
+    int ccN = 0;  // CC: rows of this wave whose cepstra are still to be formed
 
     // rlo[n1] = ze[m] = (x[4m], x[4m+1]), rhi[n1] = zo[m] = (x[4m+2], x[4m+3]), m = 64 n1 + lane: two register images, each
     // moved down in place and refilled right behind its own window multiply by ONE asm statement (rows_shift_fetch /
@@ -647,6 +655,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
             if (rowB >= 0) orow[rowB] = accB;
         }
         wave_lds_sync();  // the next frame overwrites the images / the power row
+        if constexpr (CC) {
+            // behind the row's stores, where the band stage's values are dead; the block's wait covers the 16th row's stores
+            ++ccN;
+            if (ccN == 16 || f + 1 == fEnd) {
+                ccb_rows<2>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane);
+                ccN = 0;
+            }
+        }
 
         }  // pass
         }  // !STFT
@@ -781,7 +797,7 @@ constexpr Variant kVariants[] = {{96, 32}, {128, 64}, {176, 8}};
 static_assert(block_lds_bytes(96, 32) <= 163840 && block_lds_bytes(128, 64) <= 163840 && block_lds_bytes(176, 8) <= 163840,
               "tables + weights + 8 wave regions must fit the 160 KB LDS");
 
-template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX>
+template <int TA, int TB, int SHIFT, bool SPLIT, bool CPLX, bool CC = false>
 int launch_variant(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -816,15 +832,19 @@ int launch_variant(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     k.out = a->out;
     k.outIm = a->outIm;
     k.num = p->num;
+    k.dct = a->dct;
+    k.ccNum = a->ccNum;
+    k.ccCbrt = a->ccRectify == 1;
+    k.cc = a->cc;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX, false, false, false, CC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet[attrDev] = true;
     }
-    hipLaunchKernelGGL((k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX, false, false, false, CC>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_band_4k2");
     return AFX_OK;
@@ -841,8 +861,16 @@ int launch_mode(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
 template <int TA, int TB>
 int launch(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     if (a->specMap >= 3) {  // complex results: S (3) or S^2 (4)
+        if (a->cc) return AFX_ERR_UNSUPPORTED;
         if (!a->outIm) return AFX_ERR_ARG;
         return launch_mode<TA, TB, true>(p, a, stream);
+    }
+    if (a->cc) {  // cepstra in the same launch (real results, every real mode)
+        if (a->ccNum < 1 || a->ccNum > 16 || !a->dct || !a->out || p->num > 128 || (p->num & 3) || (a->ccRectify != 0 && a->ccRectify != 1) || a->energy)
+            return AFX_ERR_UNSUPPORTED;
+        if (a->hop == 1024)
+            return p->split ? launch_variant<TA, TB, 4, true, false, true>(p, a, stream) : launch_variant<TA, TB, 4, false, false, true>(p, a, stream);
+        return p->split ? launch_variant<TA, TB, 0, true, false, true>(p, a, stream) : launch_variant<TA, TB, 0, false, false, true>(p, a, stream);
     }
     return launch_mode<TA, TB, false>(p, a, stream);
 }
@@ -917,7 +945,7 @@ extern "C" int afxk_mel4k_create(void **plan, const float *hWindow, const AfxBan
 
 // specMap 0 / 1 / 2: real results; 3 / 4: complex results (out + outIm)
 extern "C" int afxk_mel4k_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
-    if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;  // fusions exist at n_fft 2048 only
+    if (a->energy) return AFX_ERR_UNSUPPORTED;  // temporal features ride along at n_fft 2048 only (cepstra: every size, launch())
     const Plan4 *p = static_cast<const Plan4 *>(plan);
     if (!p || a->specMap > 4) return AFX_ERR_ARG;
     switch (p->variant) {

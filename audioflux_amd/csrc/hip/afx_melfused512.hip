@@ -18,6 +18,7 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_pkmath.h"
+#include "afx_ccblock.h"
 
 namespace {
 
@@ -65,6 +66,10 @@ struct KArgs {
     int mode;              // AFX_SPEC_*
     int binLo, binCount;   // bins binLo .. binLo + binCount - 1 are stored; above 256: conjugate mirrors
     long long outPitch;    // floats between output rows
+    // CC instantiations: cepstra of the rows in the same launch (afx_ccblock.h)
+    const float *dct;      // device [num, num] orthonormal DCT-II
+    int ccNum, ccCbrt;
+    float *cc;             // [totalFrames, ccNum]
 };
 
 // what an STFT instantiation stores for a spectrum value (the maps of afx_stft.hip)
@@ -116,8 +121,10 @@ __device__ __forceinline__ void split_pair_c(v2 A, v2 B, v2 w, bool sq, float &k
 // STFT: no bank -- the spectrum values themselves (CPLX form) go to memory through stft_map (afxk_stft512; afx_melfused4k2.hip
 //   has the same at n_fft 4096); MAPPED: any AFX_SPEC_* map; FULL: all 512 bins are stored (no range checks)
 // SPLIT: the plan's slots hold row SEGMENTS (afx_bandplan_build_split): banks whose rows are longer than the tap variants
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false, bool SPLIT = false>
+// CC: cepstra of the rows in the same launch (real results; afx_ccblock.h: every 16 frames the wave re-reads its rows from L2)
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool STFT = false, bool MAPPED = false, bool FULL = false, bool SPLIT = false, bool CC = false>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
+    static_assert(!CC || (!CPLX && !STFT), "cepstra: real bank rows");
     static_assert(!STFT || (CPLX && TA == 0 && TB == 0 && !SPLIT), "STFT instantiations: complex values, no bank");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
     if (f >= fEnd) return;
     int clip = (int)(f / a.timeLength);
     int t = (int)(f - (long long)clip * a.timeLength);
+    int ccN = 0;  // CC: rows of this wave whose cepstra are still to be formed
 
     // raw[r] = (x[2n], x[2n+1]), n = 64 r + lane
     v2 raw[4];
@@ -442,6 +450,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
                 accB = powf(accB, a.normValue);
             }
             // ---- 5. store ----
+            if constexpr (CC && !SPLIT) {
+                // the cepstra of the 16 rows stored BEFORE this one: their stores are a frame old, the block's wait finds them complete
+                if (ccN == 16) {
+                    ccb_rows<4>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane);
+                    ccN = 0;
+                }
+            }
             float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
             if constexpr (SPLIT) {
                 // slot results -> LDS (start of the wave's region: the images there are dead, the power row starts behind), then every
@@ -464,6 +479,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
             } else {
                 if (rowA >= 0) orow[rowA] = accA;
                 if (rowB >= 0) orow[rowB] = accB;
+            }
+            if constexpr (CC) {
+                // split plans: ONE call site, behind the row's stores where the band stage's values are dead (its wait then covers the
+                // 16th row's stores); whole-row plans: only the wave's last rows here
+                ++ccN;
+                if ((SPLIT && ccN == 16) || f + 1 == fEnd) {
+                    ccb_rows<2>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane);
+                    ccN = 0;
+                }
             }
         }
         }  // !STFT
@@ -506,7 +530,7 @@ struct Variant {
 constexpr Variant kVariants[] = {{16, 4}, {32, 4}, {48, 4}, {64, 8}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool SPLIT = false>
+template <int TA, int TB, bool GENERAL, int SHIFT, bool CPLX, bool SPLIT = false, bool CC = false>
 int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const long long total = (long long)a->batch * a->timeLength;
     if (total <= 0) return AFX_OK;
@@ -536,15 +560,19 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.out = a->out;
     k.outIm = a->outIm;
     k.num = p->num;
+    k.dct = a->dct;
+    k.ccNum = a->ccNum;
+    k.ccCbrt = a->ccRectify == 1;
+    k.cc = a->cc;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {
-        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_512<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT>),
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_512<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attrSet[attrDev] = true;
     }
-    hipLaunchKernelGGL((k_stft_band_512<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+    hipLaunchKernelGGL((k_stft_band_512<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
     AFX_LAUNCH_CHECK("k_stft_band_512");
     return AFX_OK;
@@ -554,6 +582,15 @@ template <int TA, int TB>
 int launch(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     const bool general = (a->specMap != 0) || a->postPow;
     const bool shift1 = (a->hop == 128);  // hop = 128 * SHIFT
+    if (a->cc) {  // cepstra in the same launch: real results, plain power rows on whole-row plans, every real mode on split plans
+        if (a->specMap >= 3 || a->ccNum < 1 || a->ccNum > 16 || !a->dct || !a->out || p->num > 128 || (p->num & 3) ||
+            (a->ccRectify != 0 && a->ccRectify != 1) || a->energy)
+            return AFX_ERR_UNSUPPORTED;
+        if (p->split)
+            return shift1 ? launch_variant<TA, TB, true, 1, false, true, true>(p, a, stream) : launch_variant<TA, TB, true, 0, false, true, true>(p, a, stream);
+        if (general) return AFX_ERR_UNSUPPORTED;
+        return shift1 ? launch_variant<TA, TB, false, 1, false, false, true>(p, a, stream) : launch_variant<TA, TB, false, 0, false, false, true>(p, a, stream);
+    }
     if (p->split) {  // segment plans: the general instantiations only (they take the plain modes too)
         if (a->specMap >= 3) {
             if (!a->outIm) return AFX_ERR_ARG;
@@ -639,7 +676,7 @@ extern "C" int afxk_mel512_create(void **plan, const float *hWindow, const AfxBa
 }
 
 extern "C" int afxk_mel512_run(void *plan, const AfxMelFusedArgs *a, void *stream) {
-    if (a->cc || a->energy) return AFX_ERR_UNSUPPORTED;  // fusions exist at n_fft 2048 only
+    if (a->energy) return AFX_ERR_UNSUPPORTED;  // temporal features ride along at n_fft 2048 only (cepstra: every size, launch())
     const Plan *p = static_cast<const Plan *>(plan);
     if (!p || a->specMap > 4) return AFX_ERR_ARG;
     switch (p->variant) {

@@ -393,3 +393,38 @@ extern "C" int afxdev_stream_sync(void *stream) {
     AFX_HIP(e);
     return AFX_OK;
 }
+
+// ---- clock probe (include/afx_batch.h: afx_clock_probe_start / _stop) ----------------------------------------
+// One wave that sleeps and, every few microseconds, writes (shader cycles, wall ticks) since its start to memory:
+// s_memtime counts shader-clock cycles, wall_clock64 the constant reference clock, so their ratio over a stretch in
+// which the OTHER 255 CUs run the measured kernels is the clock the chip held under that load.  It ends when the
+// caller's stop word becomes non-zero (or after maxWallTicks: it can never outlive a forgotten stop by more).
+namespace {
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out, const volatile unsigned *stop, unsigned long long maxWallTicks) {
+    const unsigned long long s0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        const unsigned long long s1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+        const unsigned st = __hip_atomic_load(const_cast<const unsigned *>(stop), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            out[0] = s1 - s0;
+            out[1] = w1 - w0;
+        }
+        if (st != 0u || w1 - w0 >= maxWallTicks) break;
+    }
+}
+}  // namespace
+
+extern "C" int afx_clock_probe_start(void *stream, unsigned long long *dOut2, const unsigned *dStop, double maxSeconds, int *wallClockKHz) {
+    if (!dOut2 || !dStop || maxSeconds <= 0.0 || maxSeconds > 60.0) return AFX_ERR_ARG;
+    if (afxdev_ensure() != AFX_OK) return AFX_ERR_NODEVICE;
+    int dev = 0, khz = 0;
+    AFX_HIP(hipGetDevice(&dev));
+    AFX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    if (khz <= 0) return AFX_ERR_UNSUPPORTED;
+    if (wallClockKHz) *wallClockKHz = khz;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, dOut2, dStop, (unsigned long long)(maxSeconds * 1e3 * khz));
+    AFX_LAUNCH_CHECK("k_clock_probe");
+    return AFX_OK;
+}

@@ -15,6 +15,10 @@ const char *afx_version(void) { return "audioflux_mi355x 0.1.0 gfx950"; }
 
 int bftObj_fusedPlanKind(BFTObj bft) { return bft ? afxk_melfused_kind(bft->fast) : 0; }
 
+/* calls of afx_bftXxccBatchDevice on this thread that ran as ONE launch (diagnostic: tests assert the route) */
+static __thread long long t_oneLaunchCalls = 0;
+long long afx_bftXxccOneLaunchCount(void) { return t_oneLaunchCalls; }
+
 int afx_bftXxccBatchDevice(BFTObj bft, XXCCObj xxcc, const float *dData, int batch,
                            int dataLength, long long clipStride, int ccNum,
                            CepstralRectifyType *rectifyType, float *dMel, float *dCc,
@@ -30,10 +34,11 @@ int afx_bftXxccBatchDevice(BFTObj bft, XXCCObj xxcc, const float *dData, int bat
     if (T <= 0 || batch <= 0) return AFX_OK;
     const long long frames = (long long)batch * T;
 
-    /* one launch (STFT -> bank -> log10 -> DCT-II, afx_melfused2.hip) when the plan supports it */
+    /* one launch (STFT -> bank -> rectify -> DCT-II inside the size's fused kernel) when the plan supports it */
     int used = 0;
     int st = afx_bft_try_fast_cc(bft, xxcc, dData, batch, dataLength, clipStride, ccNum,
                                  rectifyType, dMel, dCc, stream, &used);
+    if (st == AFX_OK && used) t_oneLaunchCalls++;
     if (st != AFX_OK || used) return st;
 
     /* otherwise: bank output (kept in scratch when the caller does not want it) + DCT GEMM */

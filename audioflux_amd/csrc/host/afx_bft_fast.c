@@ -122,18 +122,21 @@ int afx_bft_try_fast(struct OpaqueBFT *o, const float *dData, int batch, int dat
     return st;
 }
 
-/* STFT -> bank -> log10 -> DCT-II in ONE launch (afx_melfused2.hip): applies to real-result
- * objects on the n_fft 2048 whole-row plan with num = 128, ccNum <= 16 and the log rectification
- * (xxcc_algorithm.c:124-155).  dMel may be NULL: the rows then go to the object's scratch (the
- * kernel re-reads every 16 of them from L2 to form the cepstra). */
+/* STFT -> bank -> rectify -> DCT-II in ONE launch (xxcc_algorithm.c:95-156 behind bftObj_bft): real-result objects on
+ * any fused plan -- n_fft 512 / 1024 / 2048 / 4096, whole-row or split band plans -- with num <= 128 a multiple of 4,
+ * ccNum <= 16, log or cube-root rectification.  The headline shape (n_fft 2048, num 128, log) keeps its own form with the
+ * DCT operand in LDS; everything else runs afx_ccblock.h inside the size's kernel.  dMel may be NULL: the rows then go to
+ * the object's scratch (the kernel re-reads every 16 of them from L2 to form the cepstra).  A plan / mode without a fused
+ * form reports *used = 0 and the caller runs the two kernels. */
 int afx_bft_try_fast_cc(struct OpaqueBFT *o, struct OpaqueXXCC *x, const float *dData, int batch,
                         int dataLength, long long clipStride, int ccNum,
                         CepstralRectifyType *rectifyType, float *dMel, float *dCc, void *stream,
                         int *used) {
     *used = 0;
     if (!o->fast || !o->resultType || o->isTemporal) return AFX_OK;
-    if (rectifyType && *rectifyType != CepstralRectify_Log) return AFX_OK;
-    if (x->num != o->num || ccNum < 1 || ccNum > 16) return AFX_OK;
+    const CepstralRectifyType rect = rectifyType ? *rectifyType : CepstralRectify_Log;
+    if (rect != CepstralRectify_Log && rect != CepstralRectify_CubicRoot) return AFX_OK;
+    if (x->num != o->num || ccNum < 1 || ccNum > 16 || o->num > 128 || (o->num & 3)) return AFX_OK;
     AfxMelFusedArgs a;
     fast_args(o, dData, batch, dataLength, clipStride, dMel, NULL, &a);
     if (!a.out) {
@@ -144,6 +147,7 @@ int afx_bft_try_fast_cc(struct OpaqueBFT *o, struct OpaqueXXCC *x, const float *
     }
     a.dct = x->dDct;
     a.ccNum = ccNum;
+    a.ccRectify = rect == CepstralRectify_CubicRoot ? 1 : 0;
     a.cc = dCc;
     int st = afxk_melfused_run(o->fast, &a, stream);
     if (st == AFX_ERR_UNSUPPORTED) return AFX_OK;

@@ -385,7 +385,7 @@ def pmc_traffic(config, clips):
     """HBM bytes per step from the round's rocprofv3 --pmc passes of this command
     (tools/prof_traffic.py): 2 x FETCH_SIZE (gfx950 tallies wide coalesced reads at half,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB, scaled to this run's clip count"""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_bench_cfg{config}_pmc.json")
         try:
             rec = json.load(open(path))
@@ -476,10 +476,21 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
     res = {"elapsed": elapsed, "last": max(steps - 1, 0),
            "kern_ms": float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if ev else None,
            "gather_ms": float(np.mean([g0.elapsed_time(g1) for g0, g1 in gev])) if gev else None,
-           "sustained_ms": None}
+           "sustained_ms": None, "clock": None}
+    # ---- outside the timed region: the shader clock THIS device holds under THIS workload (a sleeping wave on a side stream
+    # samples s_memtime against the constant reference clock while the steps below run on the other CUs: afx_clock_probe_start)
+    probe = None
+    if not dry:
+        try:
+            from audioflux_amd.batch import ClockProbe
+            probe = ClockProbe(torch, dev)
+        except Exception:
+            probe = None
     if sustained_s > 0 and world == 1 and not dry:  # outside the timed region
         n, s0, s1 = 0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t1 = time.perf_counter()
+        if probe is not None:
+            probe.start()
         s0.record()
         while True:
             w.step(n)
@@ -489,9 +500,18 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
                 if time.perf_counter() - t1 >= sustained_s:
                     break
         s1.record()
+        if probe is not None:
+            res["clock"] = dict(probe.stop(), over="sustained loop", steps=n)
         torch.cuda.synchronize()
         res["sustained_ms"] = s0.elapsed_time(s1) / n
         res["last"] = n - 1
+    elif probe is not None and steps > 0:  # no sustained loop (N > 1, --no-sustained): K more steps, untimed, under the probe
+        probe.start()
+        for i in range(steps):
+            w.step(res["last"] + 1 + i)
+        res["clock"] = dict(probe.stop(), over="untimed repeat of the K steps", steps=steps)
+        sync()
+        res["last"] += steps
     return res
 
 
@@ -506,7 +526,7 @@ def pmc_compute(config, units=None, kern_ms=None):
     kernel that is nowhere near the HBM roofline; replayed from profiles/, like `traffic`.  `frac_of_peak` relates THIS
     run's rate to the unit that binds: cfg 2 vector instructions per second / (1024 SIMDs x 2.4 GHz / 4); cfg 5 matrix
     flop/s (tiles x 807 MFMAs x 32768 flop) / the 2.5 PF dense f16 peak."""
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_bench_cfg{config}_compute.json")
         try:
             rec = json.load(open(path))
@@ -543,7 +563,35 @@ def roofline(W, w, clips, m):
             "algorithmic_bytes_per_unit": W.bytes_per_unit, "units_per_launch": w.units,
             "sustained_ms": sus, "sustained_value": (w.units / (sus * 1e-3)) if sus else None,
             "sustained_frac": (alg / (sus * 1e-3) / 1e9 / HBM_PEAK_GBS) if sus else None,
+            # the shader clock of THIS run on THIS device (box-to-box spread of the step time is clock spread: power-limited kernels)
+            "clock_mhz_this_run": (m.get("clock") or {}).get("clock_mhz"), "clock_probe": m.get("clock"),
             "compute": pmc_compute(W.config, w.units, kern_ms) if hasattr(W, "config") else None}
+
+
+def device_info(torch, dev):
+    """what ran the numbers: name / arch / CU count / PCI bus id from the runtime, power cap and temperature from rocm-smi
+    when it answers within a few seconds (never a reason to lose the line)"""
+    p = torch.cuda.get_device_properties(dev)
+    info = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+            "hbm_gib": round(p.total_memory / 2**30, 1),
+            "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+            "hip": getattr(torch.version, "hip", None)}
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showmaxpower", "--showpower", "--showtemp", "--json"],
+                           capture_output=True, text=True, timeout=8)
+        card = next(iter(json.loads(r.stdout).values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if "max graphics package power" in kl:
+                info["power_cap_w"] = float(v)
+            elif "package power" in kl and "max" not in kl:
+                info["power_w_idle_sample"] = float(v)
+            elif "temperature" in kl and "junction" in kl:
+                info["junction_c"] = float(v)
+    except Exception:
+        pass
+    return info
 
 
 def self_launch(n):
@@ -581,6 +629,8 @@ def main():
                     "after the headline (outside its timed region) and reports them under `secondary`")
     ap.add_argument("--no-legacy", action="store_true", help="skip the reference's published benchmark through its own wrapper "
                     "(tools/legacy_bench.py; --config 2 at one GPU)")
+    ap.add_argument("--n1-value", type=float, default=0.0, help="the N = 1 value of the same configuration (BENCH line): with N > 1 the "
+                    "line then carries efficiency_vs_n1 = value / (N x n1-value), the weak-scaling efficiency north_star asks for")
     ap.add_argument("--clock-warmup", type=float, default=0.5, help="seconds of untimed steps before the W warm-up "
                     "steps: the device ramps its clocks over tens of ms after idling, and W steps of ~1.5 ms end "
                     "long before that (0 disables; reported as config.clock_warmup_s)")
@@ -663,7 +713,8 @@ def main():
             "scaling": "strong" if a.total_clips > 0 else "weak", "vs_baseline": None,
             "dtype": getattr(w, "dtype", "f32"), "data": "synthetic",
             "config": {"workload": w.workload, "clips_per_gpu": clips, "units_per_step_per_gpu": w.units,
-                       "outputs": w.outputs, "parallelism": par, "clock_warmup_s": a.clock_warmup},
+                       "outputs": w.outputs, "parallelism": par, "clock_warmup_s": a.clock_warmup,
+                       "device": None if dry else device_info(torch, dev)},
             "roofline": roofline(W, w, clips, m),
             "oracle_check": {"clip0_max_rel_err": err, "bar": 1e-5},
         }
@@ -679,6 +730,10 @@ def main():
                              "exposed_ms": exposed if gathers else 0.0,
                              "overlap_hidden_ms": max(0.0, gm - exposed) if (gathers and gm is not None) else None}
             assert not gathers or out["gather"]["gather_ms"] is not None, "N > 1 with a gather must report gather_ms"
+            out["config"]["clips_per_rank"] = counts
+            if a.n1_value > 0:  # weak scaling: N ranks x the one-GPU rate is 1.0
+                out["efficiency_vs_n1"] = value / (world * a.n1_value) if a.total_clips <= 0 else value / a.n1_value / world
+                out["n1_value"] = a.n1_value
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = w.cpu()

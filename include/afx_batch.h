@@ -50,6 +50,13 @@ int afx_set_device(int ordinal);
 /* "audioflux_mi355x <version> gfx950" */
 const char *afx_version(void);
 
+/* Measurement aid (bench.py: roofline.clock_mhz_this_run): launches ONE sleeping wave on `hipStream` that keeps writing
+ * dOut2[0] = shader-clock cycles and dOut2[1] = reference-clock ticks (rate returned in *wallClockKHz) since its start,
+ * until the device word *dStop becomes non-zero (write it from another stream) or maxSeconds (<= 60) have passed.
+ * dOut2[0] / dOut2[1] * wallClockKHz = the shader clock in kHz the device held while the kernels launched in between
+ * ran on its other compute units.  No reference counterpart. */
+int afx_clock_probe_start(void *hipStream, unsigned long long *dOut2, const unsigned *dStop, double maxSeconds, int *wallClockKHz);
+
 /* which execution plan a BFT object (bftObj_new, or the one inside a spectrogram object) got:
  * 0 = size-generic kernels, 1 = fused STFT -> filter-bank kernel (n_fft 2048) with whole rows per
  * lane slot, 2 = the same kernel with rows cut into segments (banks whose rows exceed the compiled
@@ -78,6 +85,9 @@ int afx_bftXxccBatchDevice(BFTObj bftObj, XXCCObj xxccObj, const float *dData, i
                            int dataLength, long long clipStride, int ccNum,
                            CepstralRectifyType *rectifyType, float *dMel, float *dCc,
                            void *hipStream);
+/* how many afx_bftXxccBatchDevice calls of the calling thread ran as ONE kernel launch so far (the others took the bank
+ * kernel + the cepstrum kernel).  Diagnostic only. */
+long long afx_bftXxccOneLaunchCount(void);
 
 /* xxccObj_xxcc (feature/xxcc_algorithm.h) with the row count passed explicitly instead of
  * through xxccObj_setTimeLength: mDataArr1[rows*num] -> mDataArr2[rows*ccNum], host pointers */

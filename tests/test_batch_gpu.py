@@ -216,6 +216,51 @@ def test_one_launch_mel_mfcc_variants_against_reference():
                 assert_parity(mel.cpu().numpy(), rmel, what=f"mel hop{hop}")
 
 
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("r2", [9, 10, 11, 12])
+def test_one_launch_mel_mfcc_at_every_fused_size(r2):
+    """mel + MFCC in ONE launch at the shapes the reference defaults to -- n_fft 512 / 1024 / 2048 / 4096
+    (python/audioflux/core.py:511-512: radix2_exp 12), mel banks of any num <= 128 that is a multiple of 4 incl. the split band
+    plans (mel-40 / 64 / 80), log and cube-root rectification (xxcc_algorithm.c:124-137), hop N/4 and an odd hop; against
+    the compiled reference at plain 1e-5, and the route is asserted (afx_bftXxccOneLaunchCount)."""
+    torch = _torch()
+    import ctypes
+    lib = af.get_lib()
+    lib.afx_bftXxccOneLaunchCount.restype = ctypes.c_longlong
+    rng = np.random.default_rng(600 + r2)
+    n_fft = 1 << r2
+    for num, hop, clips, rects in ((128, n_fft // 4, 3, (0, 1)), (64, n_fft // 4, 2, (0,)), (40, n_fft // 4, 2, (0, 1)), (80, 3 * n_fft // 8 + 4, 2, (0,)),
+                                   (20, n_fft // 4, 2, (0,))):
+        n = n_fft + hop * 37 + 3
+        x = (0.1 * rng.standard_normal((clips, n))).astype(np.float32)
+        x[0, : n // 2] = 0.0  # silent frames: the 1e-8 floor of the log, 0^(1/3)
+        xd = torch.from_numpy(x).cuda()
+        bft = af.BFT(num, radix2_exp=r2, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+                     scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+        bft.set_result_type(1)
+        xx = af.XXCC(num)
+        rb = ref.RefBFT(num, r2, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1, slide_length=hop,
+                        scale_type=2, style_type=0, normal_type=0, data_type=0)
+        rb.set_result_type(1)
+        rc = ref.RefXXCC(num)
+        rmel = np.stack([rb.bft(x[i])[0] for i in range(clips)])
+        kind = lib.bftObj_fusedPlanKind(bft._obj)
+        for rect in rects:
+            for cc_num, want_mel in ((13, True), (16, False), (5, True)):
+                if cc_num > num:
+                    continue
+                before = lib.afx_bftXxccOneLaunchCount()
+                mel, cc = af.mel_mfcc_device(bft, xx, xd, cc_num, rectify_type=af.CepstralRectifyType(rect), want_mel=want_mel)
+                torch.cuda.synchronize()
+                if kind:  # every fused plan carries the cepstra
+                    assert lib.afx_bftXxccOneLaunchCount() == before + 1, f"n_fft {n_fft} num {num}: plan kind {kind} took two launches"
+                want = np.stack([rc.xxcc(rmel[i], cc_num, rect) for i in range(clips)])
+                assert_parity(cc.cpu().numpy(), want, what=f"mfcc n_fft{n_fft} num{num} hop{hop} cc{cc_num} rect{rect} kind{kind}")
+                if want_mel:
+                    assert_parity(mel.cpu().numpy(), rmel, what=f"mel n_fft{n_fft} num{num} hop{hop}")
+        assert kind, f"mel-{num} at n_fft {n_fft}: no fused plan"
+
+
 def test_objects_are_usable_from_other_threads():
     """HIP's current device is per thread: an object built on one thread computes on another, and a
     thread that never touched the library builds its own (device binding per entry point)"""

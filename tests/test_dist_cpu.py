@@ -161,3 +161,34 @@ def test_bench_launcher_passes_failures_on():
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
     assert res.returncode != 0
     assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("config", [2, 4, 5])
+def test_bench_world8_line_is_complete(config):
+    """the launch the driver's SCALE run makes at N = 8 -- `python bench.py --gpus 8 --config C` -- dry
+    (AFX_BENCH_DRYRUN=1, gloo, 8 processes on this box's CPUs): ONE JSON line with n_gpus / rccl_ranks 8, every rank's clip
+    span, the gather block (gather_ms, exposed_ms; none for cfg 4: replicas only) and, with --n1-value, the weak-scaling
+    efficiency north_star asks for (value / (8 x the one-GPU value))."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AFX_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--config", str(config),
+           "--n1-value", "1000.0"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["clips_per_rank"] == [d["config"]["clips_per_gpu"]] * 8
+    assert d["value"] > 0 and abs(d["efficiency_vs_n1"] - d["value"] / 8000.0) < 1e-9 and d["n1_value"] == 1000.0
+    g = d["gather"]
+    if config == 4:
+        assert not g["slabs"] and g["exposed_ms"] == 0.0 and "replicas only" in d["config"]["parallelism"]
+    else:
+        assert g["slabs"] and g["gather_ms"] is not None and g["exposed_ms"] is not None and g["overlap_hidden_ms"] is not None
+        assert "RCCL gather" in d["config"]["parallelism"]
+    # the rank's units are summed over the ranks: 8 x one rank's
+    assert d["config"]["units_per_step_per_gpu"] * 8 * d["steps"] == pytest.approx(d["value"] * d["ms_per_step"] * d["steps"] / 1e3, rel=1e-6)

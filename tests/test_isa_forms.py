@@ -75,7 +75,7 @@ NO_SCRATCH = {
 
 def test_hot_kernels_do_not_spill(tmp_path):
     """no scratch_* instruction in the fused STFT kernels of any size (the headline instantiation the
-    bench times, k_stft_mel_v2<48, 16, 4, false, true, false>, named apart) and the cepstrogram wave kernels"""
+    bench times, k_stft_mel_v2<48, 16, 4, false, 1, false>, named apart) and the cepstrogram wave kernels"""
     lib = str(tmp_path / "lib.so")
     shutil.copy(_lib.LIB_PATH, lib)
     subprocess.run([OBJDUMP, "--offloading", lib], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -89,7 +89,7 @@ def test_hot_kernels_do_not_spill(tmp_path):
                 sym = line.split("<", 1)[-1][:-2]
             if "scratch_" in line:
                 seen[sym] = seen.get(sym, 0) + 1
-    headline = [s for s in seen if "k_stft_mel_v2<48, 16, 4, false, true, false>" in s]
+    headline = [s for s in seen if "k_stft_mel_v2<48, 16, 4, false, 1, false" in s]
     assert not headline, headline
     for frag, why in NO_SCRATCH.items():
         if why is None:

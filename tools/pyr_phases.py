@@ -43,3 +43,13 @@ for w in range(8):
           "  ".join(f"{names_c[i]} {m[i]:.0f}" for i in range(8)))
 tot = used.sum(axis=2).mean() / steps
 print(f"cycles per step ~{tot:.0f}; at {ms*1e-3/ (steps/reps) * 1e9:.0f} ns per step -> clock ~{tot / (ms*1e-3/(steps/reps)) / 1e6:.0f} MHz")
+# ---- round 6: the launch as a whole -- kernel cycles per workgroup against the cycles inside the step loop, and the step series of workgroup 0
+kc = buf[:wgs, 8, 0].astype(np.float64) / reps
+inloop = used[:, 0, :].sum(axis=1) / reps
+print(f"kernel cycles per workgroup and launch: mean {kc.mean():.0f} min {kc.min():.0f} max {kc.max():.0f}; inside the step loop (wave 0): mean {inloop.mean():.0f}")
+t0k, t1k = buf[:wgs, 8, 1].astype(np.float64), buf[:wgs, 8, 2].astype(np.float64)
+print(f"last launch: workgroup starts spread over {t0k.max() - t0k.min():.0f} cycles, ends over {t1k.max() - t1k.min():.0f}; first start -> last end {t1k.max() - t0k.min():.0f}")
+ser = np.array([buf[i >> 4, 9 + ((i >> 3) & 1), i & 7] for i in range(tpc + 31)], dtype=np.float64)
+d = np.diff(ser)
+print("step durations of workgroup 0 (cycles): first 12", d[:12].astype(int).tolist(), "| middle (median)", int(np.median(d[20:-30])), "| last 24", d[-24:].astype(int).tolist())
+print(f"prologue (kernel start -> end of step 0): {ser[0] - t0k[0]:.0f} cycles; last step end -> kernel end: {t1k[0] - ser[-1]:.0f}")
