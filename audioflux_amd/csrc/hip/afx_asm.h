@@ -203,5 +203,14 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
                  : "memory")
 // 16-byte load served by the L2, never by this CU's L1 (rows another lane of the wave stored a moment ago)
 #define LOAD_SC1_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+// the same through the vector cache (read-only tables); waited for by hand like the one above
+#define LOAD_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+
+// a wave-uniform 64-bit value the compiler computed on the vector unit (64-bit multiplies are VALU on gfx9) back in scalar registers
+__device__ __forceinline__ long long uniform64(long long x) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)x);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)x >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
 
 #endif /* AFX_ASM_H */

@@ -28,50 +28,83 @@ __device__ __forceinline__ float ccb_rect(float x, int cbrt) {
     return cbrt ? __builtin_amdgcn_exp2f(lg * (float)(1.0 / 3)) : lg * LOG10_2;
 }
 
+// DCT operand table in LDS (optional): lane (coefficient fi = lane & 15, k-slot g = lane >> 4) holds dct[fi][16 u + 4 g + c] at
+// [lane][4 u + c], CCB_PITCH floats per lane (9 x 16 bytes: conflict-free ds_read_b128); zeros for fi >= ccNum and bands >= num.
+constexpr int CCB_PITCH = 36;
+constexpr int CCB_BYTES = 64 * CCB_PITCH * 4;  // 9216
+__device__ __forceinline__ void ccb_table_fill(float *tabD, const float *dct, int num, int ccNum, int tid, int nthreads) {
+    for (int i = tid; i < 64 * 32; i += nthreads) {
+        const int l = i >> 5, e = i & 31;
+        const int fi = l & 15, g = l >> 4;
+        const int band = 16 * (e >> 2) + 4 * g + (e & 3);
+        tabD[l * CCB_PITCH + e] = (fi < ccNum && band < num) ? dct[(long long)fi * num + band] : 0.f;
+    }
+}
+
 // cepstra of `cnt` (<= 16) consecutive rows fb .. of this wave: C[16 frames, 16 coefficients] = rect(rows) . D^T.
 // Lane (fi = lane & 15, g = lane >> 4) loads row[fb + fi][16 u + 4 g .. + 3] (k-slot g of MFMA (u, c) stands for band
-// 16 u + 4 g + c) and the matching elements of DCT row fi.  Bands >= num: the lane re-reads the row's first piece (no
-// access past the last row) against zeros of the operand.  Call it one frame AFTER the last of the rows was stored.
+// 16 u + 4 g + c) and the matching elements of DCT row fi -- from the LDS table `ldsTab` (LDSD) or from memory.  The rows come
+// through a raw buffer over exactly these `cnt` rows with the L2-scope cache policy (served by the L2, never by this CU's
+// L1: another lane of the wave stored them a moment ago): compiler-tracked loads -- no hand-placed waits, so the pieces of
+// the next trip can be requested before this trip's arithmetic -- and out-of-range pieces (bands >= num of the last row,
+// rows past cnt) read as zeros against zeros of the operand.  Call it with the rows' stores issued: the wait in front
+// covers them.
 // CHAINS: independent accumulator chains (4: a dependent f32 MFMA never waits; 2: eight registers less, for the split-plan
-// instantiations that sit at their register cap).
-// GROUPS: 16-band groups requested per trip (2: 8 + 8 live registers; 1: 4 + 4).
-template <int CHAINS = 4, int GROUPS = 2>
+// instantiations that sit at their register cap).  GROUPS: 16-band groups per trip.  AHEAD: the next trip's pieces are requested
+// before this trip's arithmetic (4 GROUPS registers more).
+template <int CHAINS = 4, int GROUPS = 2, bool LDSD = false, bool AHEAD = true>
 __device__ __forceinline__ void ccb_rows(const float *out, float *cc, const float *dct, int num, int ccNum, int cbrt,
-                                         long long fb, int cnt, int lane) {
+                                         long long fb, int cnt, int lane, const float *ldsTab = nullptr) {
+    static_assert(CHAINS == 2 || CHAINS == 4, "accumulator chains");
+    static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "groups per trip");
     VM_WAIT_ALL();  // own stores -> L2 (vmcnt counts stores on gfx9)
     int ln = lane;
     PIN(ln);  // keep this block's per-lane values out of the frame loop's registers
     const int fi = ln & 15, g = ln >> 4;
-    const long long r = fb + (fi < cnt ? fi : cnt - 1);  // tail: duplicate the last row, not stored
-    const float *src = out + r * num;
+    // (the block is wave-uniform: say so, or the resource is built in vector registers and every load becomes a waterfall loop)
+    const unsigned long long base = reinterpret_cast<unsigned long long>(out + fb * num);
+    float *const ubase = reinterpret_cast<float *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                                                   (unsigned)__builtin_amdgcn_readfirstlane((int)base));
+    const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, __builtin_amdgcn_readfirstlane(cnt * num * 4), 0x00020000);
+    const unsigned rowOff = (unsigned)((fi < cnt ? fi : cnt - 1) * num + 4 * g) * 4u;  // tail: duplicate the last row, not stored
     const bool dOn = fi < ccNum;
-    const float *drow = dct + (long long)(dOn ? fi : 0) * num;
-    static_assert(CHAINS == 2 || CHAINS == 4, "accumulator chains");
+    const float *drow = dct + (long long)(dOn ? fi : 0) * num + 4 * g;
+    const ccb_v4 *dl = reinterpret_cast<const ccb_v4 *>(ldsTab + CCB_PITCH * ln);
     ccb_v4 acc[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) acc[c] = ccb_v4{0.f, 0.f, 0.f, 0.f};
     const int nu = (num + 15) >> 4;
+    typedef unsigned ccb_u4 __attribute__((ext_vector_type(4)));
+    auto row_piece = [&](int u) {  // bands 16 u + 4 g .. + 3 of the lane's row (zeros past the row's end when the row is the last)
+        const bool in = 16 * u + 4 * g < num;
+        return __builtin_bit_cast(ccb_v4, (ccb_u4)__builtin_amdgcn_raw_buffer_load_b128(rows, in ? (int)(rowOff + 64u * (unsigned)u) : (int)0x80000000, 0, 17));
+    };
+    ccb_v4 nxt[GROUPS];
+    if constexpr (AHEAD) {
+#pragma unroll
+        for (int j = 0; j < GROUPS; ++j) nxt[j] = row_piece(j);
+    }
 #pragma unroll 1
     for (int u0 = 0; u0 < nu; u0 += GROUPS) {
         ccb_v4 av[GROUPS], dv[GROUPS];
 #pragma unroll
         for (int j = 0; j < GROUPS; ++j) {
-            const int band = 16 * (u0 + j) + 4 * g;
-            const bool on = band < num;
-            LOAD_SC1_B128(av[j], src + (on ? band : 0));  // served by the L2, never by this CU's L1
-            const float *dp = drow + (on ? band : 0);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dv[j]) : "v"(dp) : "memory");
+            const int u = u0 + j;
+            if constexpr (AHEAD) av[j] = nxt[j];
+            else av[j] = row_piece(u);
+            if constexpr (LDSD) dv[j] = dl[u];
+            else dv[j] = (dOn && 16 * u + 4 * g < num) ? *reinterpret_cast<const ccb_v4 *>(drow + 16 * u) : ccb_v4{0.f, 0.f, 0.f, 0.f};
         }
-        VM_WAIT_ALL();
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int j = 0; j < GROUPS; ++j) nxt[j] = row_piece(u0 + GROUPS + j);  // (past the last group: out of range, zeros)
+        }
 #pragma unroll
         for (int j = 0; j < GROUPS; ++j) {
-            PIN(av[j]);
-            PIN(dv[j]);
-            const bool on = dOn && (16 * (u0 + j) + 4 * g) < num;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float lg = ccb_rect(av[j][c], cbrt);
-                acc[c % CHAINS] = __builtin_amdgcn_mfma_f32_16x16x4f32(lg, on ? dv[j][c] : 0.f, acc[c % CHAINS], 0, 0, 0);
+                acc[c % CHAINS] = __builtin_amdgcn_mfma_f32_16x16x4f32(lg, dv[j][c], acc[c % CHAINS], 0, 0, 0);
             }
         }
     }

@@ -17,6 +17,7 @@
 #include "afx_hipcheck.h"
 #include "afx_ldsfft.h"
 #include "afx_wavefft2048.h"
+#include "afx_wavefft_small.h"
 
 namespace {
 
@@ -344,6 +345,131 @@ __global__ __launch_bounds__(CW * 64) void k_cepstrogram_w2048(CepWArgs a) {
     }
 }
 
+// ---- N = 1024 and N = 512: the same chain on the wave transforms of the fused STFT kernels at those sizes (afx_wavefft_small.h;
+// round 6 -- the size-generic kernel ran these at 0.08-0.09 of the HBM roofline).  Closed-form lifters only (cepNum <= DIRECT_Q;
+// larger cepNum takes the size-generic kernel).  Bin layout: k = lane + 64 j and its partner N/2 - k, j < NJ, + bin N/4 in every lane.
+constexpr int CWS = 8;  // waves per workgroup
+
+template <class X>
+__global__ __launch_bounds__(CWS * 64) void k_cepstrogram_wsmall(CepWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = X::N, M = X::M, F = M + 1, NR = X::NR, NJ = X::NJ, NB = 2 * NJ + 1;
+    v2 *tabWin = reinterpret_cast<v2 *>(smem_raw);
+    v2 *tabTw = tabWin + M;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v2 *ex = tabTw + X::TAB_F2 + wave * X::EX_F2;
+    float *row = reinterpret_cast<float *>(ex);  // natural-order row between transforms (F floats)
+    {
+        const float2 *win2 = reinterpret_cast<const float2 *>(a.win);
+        for (int i = threadIdx.x; i < M; i += CWS * 64) tabWin[i] = v2{win2[i].x, win2[i].y};
+        for (int i = threadIdx.x; i < X::TAB_F2; i += CWS * 64) tabTw[i] = v2{a.tab[i].x, a.tab[i].y};
+    }
+    __syncthreads();
+    const v2 *tw3 = X::tw3_of(tabTw);  // 0.5 W_N^k, k <= N/4
+
+    const long long gw = (long long)blockIdx.x * CWS + wave;
+    long long f = gw * a.framesPerWave, fEnd = f + a.framesPerWave;
+    if (fEnd > a.totalFrames) fEnd = a.totalFrames;
+    if (f >= fEnd) return;
+    auto frame_ptr = [&](long long fr) {
+        return a.framesPerClip > 0
+                   ? a.x + (fr / a.framesPerClip) * a.clipStride + (fr % a.framesPerClip) * (long long)a.hop
+                   : a.x + fr * (long long)a.hop;
+    };
+    v2 raw[NR];
+    auto fetch = [&](const float *px) {
+        if (a.aligned) {
+            const v2 *p2 = reinterpret_cast<const v2 *>(px);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) raw[r] = p2[64 * r + lane];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) raw[r] = v2{px[2 * (64 * r + lane)], px[2 * (64 * r + lane) + 1]};
+        }
+    };
+    const int q = a.cepNum;
+    const float invN = 1.f / (float)N;
+    fetch(frame_ptr(f));
+    for (; f < fEnd; ++f) {
+        v2 v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[r] = raw[r] * tabWin[64 * r + lane];
+        if (f + 1 < fEnd) fetch(frame_ptr(f + 1));  // in flight under the transforms
+        typename X::B b;
+        // 1. spectrum -> log power row.  Slots: j -> bin k = lane + 64 j, NJ + j -> bin M - k, 2 NJ -> bin N/4
+        X::rfft(v, ex, tabTw, lane, b);
+        float Lk[NB];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            Lk[j] = log_power(b.x[j]);
+            Lk[NJ + j] = log_power(b.y[j]);
+        }
+        Lk[2 * NJ] = log_power(b.xm);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            row[lane + 64 * j] = Lk[j];
+            row[M - lane - 64 * j] = Lk[NJ + j];
+        }
+        if (lane == 0) row[N / 4] = Lk[2 * NJ];
+        wave_lds_order();
+        // 2. real cepstrum: rfft of the even extension L[m] = L[N - m]
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int m = 2 * (64 * r + lane);
+            v[r] = v2{row[m <= M ? m : N - m], row[m + 1 <= M ? m + 1 : N - m - 1]};
+        }
+        wave_lds_order();
+        X::rfft(v, ex, tabTw, lane, b);
+        if (a.out1) {
+            float *o1 = a.out1 + f * F;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                o1[lane + 64 * j] = b.x[j].x * invN;
+                o1[M - lane - 64 * j] = b.y[j].x * invN;
+            }
+            if (lane == 0) o1[N / 4] = b.xm.x * invN;
+        }
+        if (!a.out2 && !a.out3) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            row[lane + 64 * j] = b.x[j].x * invN;
+            row[M - lane - 64 * j] = b.y[j].x * invN;
+        }
+        if (lane == 0) row[N / 4] = b.xm.x * invN;
+        wave_lds_order();
+        // 3'. closed-form lifters; W_N^k = 2 tw3[k], W_N^(M - k) = -conj(W_N^k)
+        {
+            v2 w[NB];
+            float env[NB], det[NB];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const v2 t = tw3[lane + 64 * j] * 2.f;
+                w[j] = t;
+                w[NJ + j] = v2{-t.x, t.y};
+            }
+            w[2 * NJ] = tw3[N / 4] * 2.f;
+            lifters_direct<NB>(row, q, w, Lk, env, det);
+            float *o2 = a.out2 ? a.out2 + f * F : nullptr, *o3 = a.out3 ? a.out3 + f * F : nullptr;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (o2) {
+                    o2[lane + 64 * j] = env[j];
+                    o2[M - lane - 64 * j] = env[NJ + j];
+                }
+                if (o3) {
+                    o3[lane + 64 * j] = det[j];
+                    o3[M - lane - 64 * j] = det[NJ + j];
+                }
+            }
+            if (lane == 0) {
+                if (o2) o2[N / 4] = env[2 * NJ];
+                if (o3) o3[N / 4] = det[2 * NJ];
+            }
+        }
+        wave_lds_order();  // the row is read; the next frame's transform may overwrite it
+    }
+}
+
 // ---- N = 4096 (combine4096 / bin4096: afx_wavefft2048.h) ---------------------------------------
 using afxw::bin4096;
 using afxw::combine4096;
@@ -469,6 +595,14 @@ __global__ __launch_bounds__(CW4 * 64) void k_cepstrogram_w4096(CepWArgs a) {
 // host: twiddle tables of the wave kernels, tab[AFX_CEPSTROGRAM_FASTTAB_FLOATS]; N = 4096 appends
 // W_4096^k, k <= 1024 (in double, rounded once)
 extern "C" void afxk_cepstrogram_fast_tables(float *tab, int fftLength) {
+    if (fftLength == 1024) {
+        afxws::Fft1k::fill_tables(tab);
+        return;
+    }
+    if (fftLength == 512) {
+        afxws::Fft512::fill_tables(tab);
+        return;
+    }
     afxw::fill_tables(tab);
     if (fftLength == 4096) {
         const double PI = 3.14159265358979323846;
@@ -488,7 +622,8 @@ extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
     if (a->timeLength <= 0) return AFX_OK;
     const int N = 1 << a->radix2Exp;
     const bool wave2k = N == 2048 && 2 * a->cepNum + 2 < N, wave4k = N == 4096 && a->cepNum <= DIRECT_Q;
-    if ((wave2k || wave4k) && a->x && !a->specRe && a->fastTab && !afxdev_no_fused()) {
+    const bool waveS = (N == 1024 || N == 512) && a->cepNum <= DIRECT_Q;
+    if ((wave2k || wave4k || waveS) && a->x && !a->specRe && a->fastTab && !afxdev_no_fused()) {
         CepWArgs w;
         w.x = a->x;
         w.clipStride = a->clipStride;
@@ -496,7 +631,7 @@ extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
         w.framesPerClip = a->framesPerClip;
         w.hop = a->hop;
         // vector loads (float2 / float4 per lane) need every frame start aligned to them
-        const int am = wave2k ? 1 : 3;
+        const int am = (wave2k || waveS) ? 1 : 3;
         w.aligned = ((reinterpret_cast<size_t>(a->x) & (size_t)(4 * am + 3)) == 0 && (a->hop & am) == 0 &&
                      (a->framesPerClip <= 0 || (a->clipStride & am) == 0))
                         ? 1
@@ -507,13 +642,26 @@ extern "C" int afxk_cepstrogram(const AfxCepstrogramArgs *a, void *stream) {
         w.out1 = a->out1;
         w.out2 = a->out2;
         w.out3 = a->out3;
-        const int cw = wave2k ? CW : CW4;
+        const int cw = waveS ? CWS : wave2k ? CW : CW4;
         // enough waves for ~4 workgroups per CU, at most 16 frames per wave
         long long fpw = w.totalFrames / (256LL * cw * 4);
         w.framesPerWave = fpw < 1 ? 1 : (fpw > 16 ? 16 : (int)fpw);
         const long long waves = (w.totalFrames + w.framesPerWave - 1) / w.framesPerWave;
         const long long blocks = (waves + cw - 1) / cw;
-        if (wave2k) {
+        if (waveS) {
+            if (N == 1024) {
+                using X = afxws::Fft1k;
+                const size_t lds = sizeof(float2) * (size_t)(X::M + X::TAB_F2 + CWS * X::EX_F2);
+                AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram_wsmall<X>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_cepstrogram_wsmall<X>, dim3((unsigned)blocks), dim3(CWS * 64), lds, (hipStream_t)stream, w);
+            } else {
+                using X = afxws::Fft512;
+                const size_t lds = sizeof(float2) * (size_t)(X::M + X::TAB_F2 + CWS * X::EX_F2);
+                AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram_wsmall<X>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_cepstrogram_wsmall<X>, dim3((unsigned)blocks), dim3(CWS * 64), lds, (hipStream_t)stream, w);
+            }
+            AFX_LAUNCH_CHECK("k_cepstrogram_wsmall");
+        } else if (wave2k) {
             const size_t lds = sizeof(float2) * (size_t)(1024 + afxw::TAB_F2 + CW * afxw::EX_F2);
             AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cepstrogram_w2048),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

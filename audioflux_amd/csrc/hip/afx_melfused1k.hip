@@ -145,6 +145,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
         if constexpr (!STFT)
             for (int i = threadIdx.x; i < 64 * WP; i += WAVES * 64) tabW[i] = a.wLane[i];
         if (threadIdx.x < TAB_TW2_F2) tabTw2[threadIdx.x] = reinterpret_cast<const v2 *>(a.tw2)[threadIdx.x];
+        if constexpr (CC)  // the DCT operand of the cepstrum block, behind the wave regions (afx_ccblock.h)
+            ccb_table_fill(reinterpret_cast<float *>(smem + block_lds_bytes(TA, TB)), a.dct, a.num, a.ccNum, threadIdx.x, WAVES * 64);
         // zero pad behind bin 512 (the fixed-length band loops read it with zero weights): behind the images, written once
         for (int i = 513 + lane; i < PROW_F; i += 64) prow[i] = 0.f;
     }
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
     int clip = (int)(f / a.timeLength);
     int t = (int)(f - (long long)clip * a.timeLength);
     int ccN = 0;  // CC: rows of this wave whose cepstra are still to be formed
+    const float *const ccTab = reinterpret_cast<const float *>(smem + block_lds_bytes(TA, TB));
 
     // raw[r] = (x[2n], x[2n+1]), n = 64 r + lane
     v2 raw[8];
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
             if constexpr (CC && !SPLIT) {
                 // the cepstra of the 16 rows stored BEFORE this one: their stores are a frame old, the block's wait finds them complete
                 if (ccN == 16) {
-                    ccb_rows<4>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane);
+                    ccb_rows<4, 2, true>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane, ccTab);
                     ccN = 0;
                 }
             }
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_1k(KArgs a) {
                 // 16th row's stores); whole-row plans: only the wave's last rows here
                 ++ccN;
                 if ((SPLIT && ccN == 16) || f + 1 == fEnd) {
-                    ccb_rows<2, 1>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane);
+                    ccb_rows<2, 1, true, false>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane, ccTab);
                     ccN = 0;
                 }
             }
@@ -589,7 +592,8 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.ccNum = a->ccNum;
     k.ccCbrt = a->ccRectify == 1;
     k.cc = a->cc;
-    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
+    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB) + (CC ? CCB_BYTES : 0);  // (CC: the DCT operand table behind the wave regions)
+    static_assert(lds <= 163840, "workgroup LDS budget");
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {

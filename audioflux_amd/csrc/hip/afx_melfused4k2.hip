@@ -632,6 +632,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
                 PIN(rhi[n1]);
             }
         }
+        if constexpr (CC && !SPLIT) {
+            // the cepstra of the 16 rows stored BEFORE this one: their stores are a frame old, the block's wait finds them complete
+            if (ccN == 16) {
+                ccb_rows<2>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane);
+                ccN = 0;
+            }
+        }
         float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
         if constexpr (SPLIT) {
             // slot results -> LDS (start of the wave's region: the image there is dead since stage 3, the power row
@@ -656,9 +663,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_stft_band_4k2(KArgs4 a) {
         }
         wave_lds_sync();  // the next frame overwrites the images / the power row
         if constexpr (CC) {
-            // behind the row's stores, where the band stage's values are dead; the block's wait covers the 16th row's stores
+            // split plans: ONE call site, behind the row's stores where the band stage's values are dead (its wait then covers the
+            // 16th row's stores); whole-row plans: only the wave's last rows here
             ++ccN;
-            if (ccN == 16 || f + 1 == fEnd) {
+            if ((SPLIT && ccN == 16) || f + 1 == fEnd) {
                 ccb_rows<2>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane);
                 ccN = 0;
             }

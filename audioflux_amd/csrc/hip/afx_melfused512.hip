@@ -140,6 +140,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
         if constexpr (STFT)  // the object's own window; the blob holds the twiddles only
             for (int i = threadIdx.x; i < NFFT; i += WAVES * 64) reinterpret_cast<float *>(smem + T_WIN)[i] = a.window[i];
         for (int i = 257 + lane; i < PROW_F; i += 64) prow[i] = 0.f;  // zero pad, written once
+        if constexpr (CC)  // the DCT operand of the cepstrum block, behind the wave regions (afx_ccblock.h)
+            ccb_table_fill(reinterpret_cast<float *>(smem + block_lds_bytes(TA, TB)), a.dct, a.num, a.ccNum, threadIdx.x, WAVES * 64);
     }
     __syncthreads();
 
@@ -171,13 +173,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
     const unsigned awr = T0 + TAB_BYTES + 4 * WP * lane;
 
     const long long gw = (long long)blockIdx.x * WAVES + wave;
-    long long f = gw * a.framesPerWave;
+    long long f = uniform64(gw * a.framesPerWave);  // (scalar registers: the frame counters are compared and advanced on the scalar unit)
     long long fEnd = f + a.framesPerWave;
     if (fEnd > a.totalFrames) fEnd = a.totalFrames;
     if (f >= fEnd) return;
     int clip = (int)(f / a.timeLength);
     int t = (int)(f - (long long)clip * a.timeLength);
     int ccN = 0;  // CC: rows of this wave whose cepstra are still to be formed
+    const float *const ccTab = reinterpret_cast<const float *>(smem + block_lds_bytes(TA, TB));
 
     // raw[r] = (x[2n], x[2n+1]), n = 64 r + lane
     v2 raw[4];
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
             if constexpr (CC && !SPLIT) {
                 // the cepstra of the 16 rows stored BEFORE this one: their stores are a frame old, the block's wait finds them complete
                 if (ccN == 16) {
-                    ccb_rows<4>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane);
+                    ccb_rows<4, 2, true>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane, ccTab);
                     ccN = 0;
                 }
             }
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
                 // 16th row's stores); whole-row plans: only the wave's last rows here
                 ++ccN;
                 if ((SPLIT && ccN == 16) || f + 1 == fEnd) {
-                    ccb_rows<2>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane);
+                    ccb_rows<2, 1, true, false>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f + 1 - ccN, ccN, lane, ccTab);
                     ccN = 0;
                 }
             }
@@ -564,7 +567,8 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.ccNum = a->ccNum;
     k.ccCbrt = a->ccRectify == 1;
     k.cc = a->cc;
-    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
+    constexpr size_t lds = (size_t)block_lds_bytes(TA, TB) + (CC ? CCB_BYTES : 0);  // (CC: the DCT operand table behind the wave regions)
+    static_assert(lds <= 163840, "workgroup LDS budget");
     static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
     if (!attrSet[attrDev]) {

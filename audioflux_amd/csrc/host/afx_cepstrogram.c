@@ -14,7 +14,7 @@ struct OpaqueCepstrogram {
     WindowType windowType;
     void *stream;
     float *dWindow, *dTwiddle;
-    float *dFastTab; /* twiddle tables of the N = 2048 / 4096 wave kernels (NULL for other sizes) */
+    float *dFastTab; /* twiddle tables of the N = 512 / 1024 / 2048 / 4096 wave kernels (NULL for other sizes) */
     float *dX, *dOut, *dSpec; /* grow-only scratch */
     size_t capX, capOut, capSpec;
     int cachedTime; /* frames of the spectrum kept in dSpec (for cepstrogram2) */
@@ -52,7 +52,7 @@ int cepstrogramObj_new(CepstrogramObj *cepstrogramObj, int radix2Exp, WindowType
     if (st == AFX_OK) st = afxdev_malloc((void **)&o->dTwiddle, nb < 8 ? 8 : nb);
     if (st == AFX_OK) st = afxdev_h2d(o->dWindow, w, nb, o->stream);
     if (st == AFX_OK) st = afxdev_h2d(o->dTwiddle, tw, nb < 8 ? 8 : nb, o->stream);
-    if (st == AFX_OK && (o->fftLength == 2048 || o->fftLength == 4096)) {
+    if (st == AFX_OK && (o->fftLength == 512 || o->fftLength == 1024 || o->fftLength == 2048 || o->fftLength == 4096)) {
         float *ft = (float *)calloc(AFX_CEPSTROGRAM_FASTTAB_FLOATS, sizeof(float));
         if (!ft) st = AFX_ERR_NOMEM;
         if (st == AFX_OK) {

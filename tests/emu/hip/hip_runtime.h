@@ -80,7 +80,11 @@ static inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { *p = 
 static inline hipError_t hipFreeAsync(void *p, hipStream_t) { free(p); return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
-static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }  // few "CUs": few workgroups
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) {  // few "CUs": few workgroups (AFX_EMU_CUS: long runs of frames per wave)
+    const char *e = getenv("AFX_EMU_CUS");
+    *v = e && atoi(e) > 0 ? atoi(e) : 4;
+    return hipSuccess;
+}
 
 // ---- launch: workgroups one after the other, one thread per lane
 namespace emu {
@@ -303,6 +307,7 @@ static inline T __shfl_down(T v, int delta, int = 64) { return emu_shfl_from(v, 
 template <class T>
 static inline T __shfl_up(T v, int delta, int = 64) { return emu_shfl_from(v, emu::lane() >= delta ? emu::lane() - delta : emu::lane()); }
 #define __log2f(x) log2f(x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 
 // v_mfma_f32_16x16x4_f32: A operand lane l = row l & 15, k = l >> 4; B operand lane l = column l & 15, k = l >> 4;
 // D register r of lane l = row 4 (l >> 4) + r, column l & 15

@@ -131,13 +131,20 @@ def test_cepstrogram_batch_device_equals_loop():
     torch = _torch()
     rng = np.random.default_rng(35)
     x = (0.1 * rng.standard_normal((3, 12000))).astype(np.float32)
-    o = af.Cepstrogram(radix2_exp=10, samplate=16000, window_type=af.WindowType.HANN, slide_length=256)
-    outs = o.cepstrogram_device(torch.from_numpy(x).cuda(), cep_num=6)
-    torch.cuda.synchronize()
-    for i in range(3):
-        loop = o.cepstrogram(x[i], cep_num=6)
-        for k in range(3):
-            assert np.array_equal(outs[k][i].cpu().numpy().T, loop[k]), f"clip {i} output {k}"
+    # n_fft 256: both entry points run the size-generic kernel -- the same bits; n_fft 1024: the batched call runs the wave kernel
+    # (round 6), the one-clip call the size-generic one -- two float32 evaluations of one chain
+    for r2, hop in ((8, 64), (10, 256)):
+        o = af.Cepstrogram(radix2_exp=r2, samplate=16000, window_type=af.WindowType.HANN, slide_length=hop)
+        outs = o.cepstrogram_device(torch.from_numpy(x).cuda(), cep_num=6)
+        torch.cuda.synchronize()
+        for i in range(3):
+            loop = o.cepstrogram(x[i], cep_num=6)
+            for k in range(3):
+                got = outs[k][i].cpu().numpy().T
+                if r2 == 8:
+                    assert np.array_equal(got, loop[k]), f"clip {i} output {k}"
+                else:
+                    assert_parity(got, loop[k], tol=2e-5, what=f"n_fft 1024 clip {i} output {k}: wave kernel vs size-generic kernel")
 
 
 def test_xxcc_batch_host():
@@ -259,6 +266,32 @@ def test_one_launch_mel_mfcc_at_every_fused_size(r2):
                 if want_mel:
                     assert_parity(mel.cpu().numpy(), rmel, what=f"mel n_fft{n_fft} num{num} hop{hop}")
         assert kind, f"mel-{num} at n_fft {n_fft}: no fused plan"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("r2,clips", [(9, 64), (10, 64), (12, 48)])
+def test_one_launch_mel_mfcc_long_runs_per_wave(r2, clips):
+    """the same at a size where every wave walks 30-40 frames (332 000 frames at n_fft 512): whole 16-row blocks behind each other
+    (afx_ccblock.h).  Every frame against the two-launch route (k_cepstrum_mfma over the same mel rows), two clips against the compiled reference."""
+    torch = _torch()
+    n_fft, hop = 1 << r2, (1 << r2) // 4
+    n = n_fft + hop * 5196
+    gen = torch.Generator(device="cuda").manual_seed(900 + r2)
+    xd = 0.1 * torch.randn((clips, n), generator=gen, device="cuda", dtype=torch.float32)
+    bft = af.BFT(128, radix2_exp=r2, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+                 scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+    bft.set_result_type(1)
+    xx = af.XXCC(128)
+    mel, cc = af.mel_mfcc_device(bft, xx, xd, 13)
+    two = xx.xxcc_device(mel.reshape(-1, 128), 13)
+    torch.cuda.synchronize()
+    got, want = cc.reshape(-1, 13), two.reshape(-1, 13)
+    peak = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-6 * peak, "one launch vs bank kernel + cepstrum kernel"
+    for i in (0, clips - 1):
+        rmel, rcc = ref.mel_mfcc(xd[i:i + 1].cpu().numpy(), radix2_exp=r2, hop=hop)
+        assert_parity(mel[i].cpu().numpy(), rmel[0], what=f"mel n_fft{n_fft} clip {i}")
+        assert_parity(cc[i].cpu().numpy(), rcc[0], what=f"mfcc n_fft{n_fft} clip {i}")
 
 
 def test_objects_are_usable_from_other_threads():

@@ -69,6 +69,14 @@ def test_wave_kernel_2048_matches_golden_through_device_call(golden_dir):
     (12, 1024, 40000, 1, 16, "hamm"),    # odd row pitch: dword loads
     (12, 700, 30000, 0, 0, "rect"),
     (12, 1001, 20000, 0, 7, "hann"),     # odd hop
+    (10, 256, 20000, 0, 4, "hann"),      # round 6: n_fft 1024 / 512 on the wave transforms of the fused STFT kernels at those sizes
+    (10, 256, 20000, 1, 16, "hamm"),     # odd row pitch: dword loads; the largest closed-form cep_num
+    (10, 333, 9000, 0, 0, "rect"),       # odd hop, cep_num 0
+    (10, 1024, 16384, 0, 7, "hann"),     # no overlap
+    (9, 128, 12000, 0, 4, "hann"),
+    (9, 128, 12000, 1, 16, "hamm"),
+    (9, 77, 6000, 0, 1, "rect"),
+    (9, 512, 8192, 0, 9, "hann"),
 ])
 def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_num, window):
     import torch
@@ -90,7 +98,8 @@ def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_n
     # bars in units of the reference's own distance from float64 (below): 3 for the envelope and the details -- measured over these
     # shapes wherever the error exceeds TOL at all: envelope <= 1.2, details <= 2.8 (round 5, gpurun_out parity log) -- except the two
     # shapes whose details are decided by one bin next to a spectral null (4.3 and 3.3 of the reference's distance): 5 there
-    K = {"cep": 2.0, "env": 3.0, "det": 5.0 if (r, hop, cep_num) in ((11, 512, 17), (12, 1024, 16)) else 3.0}
+    # (round 6, n_fft 512: the tonal clip's details at hop 128 / q 4 sit at 3.5 x -- one bin again, the L2 statistic below is at 1.8 x)
+    K = {"cep": 2.0, "env": 3.0, "det": 5.0 if (r, hop, cep_num) in ((11, 512, 17), (12, 1024, 16), (9, 128, 4)) else 3.0}
     for i in range(clips):
         want = rr.cepstrogram(x[i, :length], cep_num)
         want0 = want if i == 0 else want0

@@ -159,6 +159,17 @@ def test_n512_bank_kernel_emulated_against_the_restatement(emulated):
     assert "emulated k_stft_band_512 9, k_stft_band_1k 3" in out, out[-800:]
 
 
+def test_one_launch_mel_mfcc_emulated_at_every_fused_size(emulated):
+    """round 6: the cepstrum block of afx_ccblock.h inside k_stft_band_512 / _1k / _4k2 and the general form of k_stft_mel_v2 --
+    mel + MFCC from ONE emulated launch per call at n_fft 512 / 1024 / 2048 / 4096: whole-row and segment plans, num 128 / 64 /
+    40 / 20, log and cube-root rectification, partial 16-row blocks -- against the float64 restatement, route asserted"""
+    out = _run(emulated, "emulated_mfcc_sizes.py", [])
+    assert "one-launch mel + MFCC cases: 11" in out, out[-800:]
+    # long runs of frames per wave: whole 16-row blocks behind each other
+    out = _run(emulated, "emulated_mfcc_sizes.py", [], env="AFX_EMU_CUS=1")
+    assert "one-launch mel + MFCC cases: 4" in out, out[-800:]
+
+
 def test_spectrum_kernels_emulated_against_float64(emulated):
     """afxk_stft4k / afxk_stft1k / afxk_stft512 = k_stft_band_4k2 / _1k / _512 <STFT> (round 5: the STFT object, the linear-scale
     slices and the reassignment object's transforms at n_fft 4096 / 1024 / 512): every store family of the epilogues -- a lane's

@@ -26,6 +26,7 @@ for STEP in "$@"; do
     tests:*) timeout -k 10 900 python -m pytest -q -m gpu -x ${STEP#tests:} > $OUT/pytest_sel.log 2>&1; tail -n 15 $OUT/pytest_sel.log | cut -c1-400 ;;
     bench) timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; line $OUT/bench_default.json ;;
     cfg2|cfg4|cfg5) c=${STEP#cfg}; timeout -k 10 300 python bench.py --config $c --steps $([ $c = 4 ] && echo 3 || echo 50) --warmup 3 --no-cpu-baseline --no-secondary --no-legacy > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; line $OUT/bench_cfg$c.json ;;
+    ceps) timeout -k 10 300 python tools/bench_cepstrogram.py 2>&1 | tee $OUT/cepstrogram.txt ;;
     mfcc) AFX_BENCH_NUMS=${AFX_BENCH_NUMS:-128,80,40} timeout -k 10 400 python tools/bench_mfcc_sizes.py 2>&1 | tee $OUT/mfcc_sizes.txt ;;
     phases) AFX_LIB=$V/libafx_exp.so timeout -k 10 200 python tools/pyr_phases.py 125 10 2>&1 | tail -n 16 | tee $OUT/pyr_phases.txt ;;
     *) echo "unknown step $STEP" ;;
