@@ -57,6 +57,18 @@
 #define WR2ST_32_S(s, addr, d0, d1, o0, o1) WR2ST_32(addr, d0, d1, o0, o1)
 #endif
 
+// measurement switches of round 6 (profiles/r06_ab_headline.txt): AFX_V2_NTIN -- the samples are read with the streaming (nt) policy, so
+// that the bank rows a wave re-reads for its cepstra 16 frames later are not pushed out of the L2 by them; AFX_V2_CCEVERY -- frames per
+// cepstrum block (16: one full MFMA tile; 8: the rows are half as old when they are re-read)
+#ifdef AFX_V2_NTIN
+#define AFX_V2_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define AFX_V2_LOAD(p) (*(p))
+#endif
+#ifndef AFX_V2_CCEVERY
+#define AFX_V2_CCEVERY 16
+#endif
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
             const v2 *p2 = reinterpret_cast<const v2 *>(px);
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1)
-                if (n1 >= first) raw[n1] = p2[64 * n1 + lane];
+                if (n1 >= first) raw[n1] = AFX_V2_LOAD(&p2[64 * n1 + lane]);
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1)
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
         MEL_PHASE(6);
         // ---- 5. store (first the cepstra of the 16 rows stored before this one, if that many wait) ----
         if constexpr (CC != 0 && !SPLIT) {
-            if (ccN == 16) cc_block(f - 16, 16);
+            if (ccN == AFX_V2_CCEVERY) cc_block(f - AFX_V2_CCEVERY, AFX_V2_CCEVERY);
         }
         float *orow = ((CPLX && pass) ? a.outIm : a.out) + f * a.num;
         if constexpr (SPLIT) {
