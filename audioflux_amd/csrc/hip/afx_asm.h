@@ -202,7 +202,11 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
                  "v"(d1), "s"(sbase1)                                                                                     \
                  : "memory")
 // 16-byte load served by the L2, never by this CU's L1 (rows another lane of the wave stored a moment ago)
+#ifdef AFX_CC_PLAINLOAD  // (measurement, profiles/r06_ab_headline.txt (b))
+#define LOAD_SC1_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#else
 #define LOAD_SC1_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+#endif
 // the same through the vector cache (read-only tables); waited for by hand like the one above
 #define LOAD_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 

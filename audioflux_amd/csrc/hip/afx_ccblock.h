@@ -30,6 +30,11 @@ __device__ __forceinline__ float ccb_rect(float x, int cbrt) {
 
 // DCT operand table in LDS (optional): lane (coefficient fi = lane & 15, k-slot g = lane >> 4) holds dct[fi][16 u + 4 g + c] at
 // [lane][4 u + c], CCB_PITCH floats per lane (9 x 16 bytes: conflict-free ds_read_b128); zeros for fi >= ccNum and bands >= num.
+#ifdef AFX_CC_PLAINLOAD  // (measurement, profiles/r06_ab_headline.txt (b))
+constexpr int CCB_ROW_AUX = 0;
+#else
+constexpr int CCB_ROW_AUX = 17;  // sc0 sc1
+#endif
 constexpr int CCB_PITCH = 36;
 constexpr int CCB_BYTES = 64 * CCB_PITCH * 4;  // 9216
 __device__ __forceinline__ void ccb_table_fill(float *tabD, const float *dct, int num, int ccNum, int tid, int nthreads) {
@@ -77,7 +82,7 @@ __device__ __forceinline__ void ccb_rows(const float *out, float *cc, const floa
     typedef unsigned ccb_u4 __attribute__((ext_vector_type(4)));
     auto row_piece = [&](int u) {  // bands 16 u + 4 g .. + 3 of the lane's row (zeros past the row's end when the row is the last)
         const bool in = 16 * u + 4 * g < num;
-        return __builtin_bit_cast(ccb_v4, (ccb_u4)__builtin_amdgcn_raw_buffer_load_b128(rows, in ? (int)(rowOff + 64u * (unsigned)u) : (int)0x80000000, 0, 17));
+        return __builtin_bit_cast(ccb_v4, (ccb_u4)__builtin_amdgcn_raw_buffer_load_b128(rows, in ? (int)(rowOff + 64u * (unsigned)u) : (int)0x80000000, 0, CCB_ROW_AUX));
     };
     ccb_v4 nxt[GROUPS];
     if constexpr (AHEAD) {

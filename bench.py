@@ -505,7 +505,8 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
         torch.cuda.synchronize()
         res["sustained_ms"] = s0.elapsed_time(s1) / n
         res["last"] = n - 1
-    elif probe is not None and steps > 0:  # no sustained loop (N > 1, --no-sustained): K more steps, untimed, under the probe
+    elif probe is not None and steps > 0 and world > 1:  # N > 1 (no sustained loop): K more steps, untimed, under the probe
+        # (N = 1 with --no-sustained is a profiling run: tools/prof_*.py count on warm-up + K launches exactly)
         probe.start()
         for i in range(steps):
             w.step(res["last"] + 1 + i)
