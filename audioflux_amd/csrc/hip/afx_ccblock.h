@@ -61,7 +61,7 @@ template <int CHAINS = 4, int GROUPS = 2, bool LDSD = false, bool AHEAD = true>
 __device__ __forceinline__ void ccb_rows(const float *out, float *cc, const float *dct, int num, int ccNum, int cbrt,
                                          long long fb, int cnt, int lane, const float *ldsTab = nullptr) {
     static_assert(CHAINS == 2 || CHAINS == 4, "accumulator chains");
-    static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "groups per trip");
+    static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4 || GROUPS == 8, "groups per trip");
     VM_WAIT_ALL();  // own stores -> L2 (vmcnt counts stores on gfx9)
     int ln = lane;
     PIN(ln);  // keep this block's per-lane values out of the frame loop's registers

@@ -396,6 +396,19 @@ __device__ __forceinline__ void cols256_twiddles(const CwtGeom &g, int gq, float
     for (int p = 1; p < 16; ++p) t3[p] = g.fastTw[8 * 64 + 8 * 8 + 16 * p + gq];  // W_256^(g p)
 }
 
+// Column block of a 256-thread column-pass workgroup (grid.x = 512 / 16 = 32).  Workgroups go to the eight XCDs round-robin in
+// launch order, x fastest: blocks x and x + 1 -- the two 64-byte halves of every 128-byte line of an output row -- would be
+// written through two different L2s, each evicting a partial line.  XCD k (x = k, k + 8, k + 16, k + 24) takes the four ADJACENT
+// blocks 4 k .. 4 k + 3 instead: 256 contiguous bytes of every row pass through one L2 (+ 1.3 % on cfg 4, profiles/r06_cwt_phases.txt).
+__device__ __forceinline__ int col_block16() {
+#ifdef AFX_CWT_NO_XCDMAP
+    return (int)blockIdx.x;
+#else
+    const int x = (int)blockIdx.x;
+    return 4 * (x & 7) + (x >> 3);
+#endif
+}
+
 __device__ __forceinline__ void cols256_finish(const CwtGeom &g, v2 (&r)[16], const float2 (&t3)[16], v2 *ex,
                                                int c, int gq, int c0, float *__restrict__ oRe,
                                                float *__restrict__ oIm) {
@@ -418,7 +431,11 @@ __device__ __forceinline__ void cols256_finish(const CwtGeom &g, v2 (&r)[16], co
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int n = n0 + q * (16 * L2);
+#ifdef AFX_KO_CWT_STORES  // knock-out measurement build (results wrong): no row is stored (the compiler cannot know: pad >= 0)
+        if ((unsigned)n < (unsigned)(g.pad < 0 ? g.dataLength : 0)) {
+#else
         if ((unsigned)n < (unsigned)g.dataLength) {  // conj, 1/L, crop (cwt_algorithm.c:449-458)
+#endif
             const v2 a = r[rev4(q)];
             oRe[n] = a.x * invL;
             oIm[n] = -a.y * invL;
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256(CwtGeom g, const float2
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
     const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
-    const int c0 = blockIdx.x * 16;
+    const int c0 = col_block16() * 16;
     const int j = g.order ? g.order[blockIdx.y] : (int)blockIdx.y;
     const float2 *in = B + ((long long)blockIdx.z * g.num + j) * L + c0 + c;
     v2 r[16];
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(256) void k_cwt_fwd_cols256(CwtGeom g, const float 
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
     const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
-    const int c0 = blockIdx.x * 16, m = c0 + c;
+    const int c0 = col_block16() * 16, m = c0 + c;
     x += (long long)blockIdx.y * xStride;
     A += (long long)blockIdx.y * L;
     const int D = g.dataLength, P = g.pad;
@@ -525,6 +542,30 @@ __device__ __forceinline__ void nb_row(const v2 *z, v2 (&out)[RR]) {
     }
 }
 
+// Phase clocks of the narrow-band kernels (measurement builds, make EXTRA=-DAFX_EXPERIMENTS; tools/cwt_phases.py): thread 0 of every
+// workgroup stamps s_memtime at the phase boundaries and adds the differences to g_nbPhase[log2 R][phase]; [..][7] counts workgroups.
+#ifdef AFX_EXPERIMENTS
+__device__ unsigned long long g_nbPhase[5][8];
+#define NB_CLOCK_DECL unsigned long long nbT[8]; int nbI = 0
+#define NB_STAMP()                                                         \
+    do {                                                                   \
+        if (threadIdx.x == 0) nbT[nbI] = __builtin_amdgcn_s_memtime();     \
+        ++nbI;                                                             \
+    } while (0)
+#define NB_CLOCK_END(R)                                                                                             \
+    do {                                                                                                            \
+        if (threadIdx.x == 0) {                                                                                     \
+            constexpr int lr = (R) == 2 ? 1 : (R) == 4 ? 2 : (R) == 8 ? 3 : 4;                                      \
+            for (int i = 0; i + 1 < nbI; ++i) atomicAdd(&g_nbPhase[lr][i], nbT[i + 1] - nbT[i]);                    \
+            atomicAdd(&g_nbPhase[lr][7], 1ull);                                                                     \
+        }                                                                                                           \
+    } while (0)
+#else
+#define NB_CLOCK_DECL
+#define NB_STAMP() ((void)0)
+#define NB_CLOCK_END(R) ((void)0)
+#endif
+
 // Narrow-band scales: every non-zero of the wavelet lies in R rows k2 in [lo, lo + R) of the
 // transposed spectrum (frequencies k = k1 + 256 k2), so the 512-point row transform of the first
 // pass is an R-term sum,
@@ -546,7 +587,9 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
     const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
-    const int c0 = blockIdx.x * 16, m1 = c0 + c;
+    NB_CLOCK_DECL;
+    NB_STAMP();  // 0 -> 1: operand and twiddle loads issued and ARRIVED (the LDS stores below wait for them)
+    const int c0 = col_block16() * 16, m1 = c0 + c;
     // (scale, first row of its support): one dependent read ahead of the operand loads
     const int2 jl = reinterpret_cast<const int2 *>(g.orderLo)[listBase + blockIdx.y];
     const int j = jl.x;
@@ -567,6 +610,10 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
     const float2 ta = g.tw[256 * tid], tb = g.tw[tid];  // W_L^(256 i) = W_512^i; i >= 256: -W_512^(i - 256)
     cols256_twiddles(g, gq, t3);
     __builtin_amdgcn_sched_barrier(0);  // every global read of the workgroup is in flight from here
+#ifdef AFX_EXPERIMENTS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    NB_STAMP();  // 1 -> 2: products staged in LDS, barrier
     thi[tid] = v2{ta.x, ta.y};
     thi[tid + 256] = v2{-ta.x, -ta.y};
     tlo[tid] = v2{tb.x, tb.y};
@@ -576,6 +623,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
         zs[tid + 256 * i] = isDet ? v2{-bw[i] * xv[i].y, -(bw[i] * xv[i].x)} : v2{bw[i] * xv[i].x, -(bw[i] * xv[i].y)};
     }
     __syncthreads();
+    NB_STAMP();  // 2 -> 3: gathered twiddles + the R-term sums of 16 rows
     v2 w5[R], wl[16];
 #pragma unroll
     for (int k2 = 0; k2 < R; ++k2) w5[k2] = thi[((lo + k2) * m1) & (L2 - 1)];  // W_512^((lo + k2) m1)
@@ -590,10 +638,18 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
         for (int k2 = 1; k2 < R; ++k2) acc = cfma(z[k2], w5[k2], acc);
         r[a] = cmul(acc, wl[a]);
     }
+    NB_STAMP();  // 3 -> 4: barrier
     __syncthreads();  // every thread is done with zs before the exchange buffer is written
+    NB_STAMP();  // 4 -> 5: column transform (exchange through LDS) and the row stores issued
     const long long D = g.dataLength;
     cols256_finish(g, r, t3, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
                    outIm + ((long long)blockIdx.z * g.num + j) * D);
+    NB_STAMP();
+#ifdef AFX_EXPERIMENTS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    NB_STAMP();  // 5 -> 6: the stores acknowledged
+    NB_CLOCK_END(R);
 }
 
 // Scales whose support spans 17 ... 32 rows: the same kernel with the R-term sum taken in two blocks of rows
@@ -612,7 +668,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
     constexpr int L2 = 512;
     constexpr long long L = 1LL << 17;
     const int tid = threadIdx.x, c = tid & 15, gq = tid >> 4;
-    const int c0 = blockIdx.x * 16, m1 = c0 + c;
+    const int c0 = col_block16() * 16, m1 = c0 + c;
     const int2 jl = reinterpret_cast<const int2 *>(g.orderLo)[listBase + blockIdx.y];
     const int j = jl.x;
     int lo = jl.y;
@@ -909,3 +965,14 @@ extern "C" int afxk_cwt_inverse(const AfxCwtPlanDims *d, const float *tw, const 
     AFX_LAUNCH_CHECK("k_cwt_inv_cols");
     return AFX_OK;
 }
+
+#ifdef AFX_EXPERIMENTS
+// measurement builds: read and clear the phase clocks of the narrow-band kernels (tools/cwt_phases.py); out[5][8]
+extern "C" int afx_cwt_nb_phases(unsigned long long *out) {
+    unsigned long long zero[5][8] = {};
+    AFX_HIP(hipDeviceSynchronize());
+    AFX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nbPhase), sizeof(zero)));
+    AFX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_nbPhase), zero, sizeof(zero)));
+    return AFX_OK;
+}
+#endif

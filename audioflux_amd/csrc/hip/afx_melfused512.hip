@@ -20,6 +20,11 @@
 #include "afx_pkmath.h"
 #include "afx_ccblock.h"
 
+#ifndef AFX_CC_GROUPS  // whole-row plans: 16-band groups of the rows requested per trip to the L2, and whether the next trip is requested ahead
+#define AFX_CC_GROUPS 2
+#define AFX_CC_AHEAD true
+#endif
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_band_512(KArgs a) {
             if constexpr (CC && !SPLIT) {
                 // the cepstra of the 16 rows stored BEFORE this one: their stores are a frame old, the block's wait finds them complete
                 if (ccN == 16) {
-                    ccb_rows<4, 2, true>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane, ccTab);
+                    ccb_rows<4, AFX_CC_GROUPS, true, AFX_CC_AHEAD>(a.out, a.cc, a.dct, a.num, a.ccNum, a.ccCbrt, f - 16, 16, lane, ccTab);
                     ccN = 0;
                 }
             }

@@ -237,7 +237,7 @@ class Cfg4:
     bound = "matrix+LDS"
     bound_note = ("the step is the sum of its launches' work: the f16 matrix kernels (time-domain scales) and the LDS-bound narrow-band inverse "
                   "transforms (LDS pipe 86 % busy) run at the same time and slow each other (profiles/r05_ab_cwt.txt)")
-    GROUP = 32  # chunks per device call: the [84, 2^16] complex outputs (44 MB per chunk) are ring-buffered
+    GROUP = int(os.environ.get("AFX_CFG4_GROUP", "32"))  # chunks per device call: the [84, 2^16] complex outputs (44 MB per chunk) are ring-buffered
 
     def __init__(self, torch, af, dev, rank, clips):
         self.torch, self.af, self.clips = torch, af, clips
@@ -544,6 +544,9 @@ def pmc_compute(config, units=None, kern_ms=None):
                     out["valu_wave_insts_per_s"], out["frac_of_peak"] = rate, rate / VALU_PEAK_WAVE_INSTS
                     out["peak_of"] = "vector issue: 1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction"
             out["kernel"] = rec.get("kernel")
+            for k in ("classes", "share_of_summed_kernel_time", "occupancy"):  # (cfg 4: per kernel class + the step's union / sum of busy intervals)
+                if rec.get(k) is not None:
+                    out[k] = rec[k]
             out["source"] = os.path.relpath(path, ROOT)
             return out
         except (OSError, KeyError, ValueError):

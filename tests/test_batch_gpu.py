@@ -317,3 +317,19 @@ def test_objects_are_usable_from_other_threads():
     th.join()
     assert np.array_equal(out["shared"], want) and np.array_equal(out["own"], want)
     assert np.array_equal(out["cqt"], af.CQT(num=84, samplate=32000).cqt(x))
+
+
+@pytest.mark.parametrize("ordinal", ["0", "99"])
+def test_afx_device_environment_switch(ordinal):
+    """AFX_DEVICE selects the default device of a process (read once, at the library's first call); an ordinal the box does
+    not have falls back to device 0 instead of failing.  A fresh process each: the switch is latched."""
+    import subprocess, sys
+    code = ("import numpy as np, audioflux_amd as af\n"
+            "x = (0.1 * np.random.default_rng(1).standard_normal(4096)).astype(np.float32)\n"
+            "o = af.BFT(32, radix2_exp=10, samplate=16000, slide_length=256)\n"
+            "y = o.bft(x)\n"
+            "assert y.shape[0] == 32 and np.all(np.isfinite(y)) and float(np.abs(y).max()) > 0\n"
+            "print('ok', y.shape)\n")
+    env = dict(os.environ, AFX_DEVICE=ordinal)
+    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:]

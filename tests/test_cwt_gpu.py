@@ -100,11 +100,14 @@ def test_more_short_kernel_scales_than_the_time_domain_launch_takes():
     assert np.array_equal(got, got2)
 
 
-def test_derivative_transform_time_domain_scales_against_reference():
+@pytest.mark.parametrize("td_det", ["1", "0"])
+def test_derivative_transform_time_domain_scales_against_reference(td_det, monkeypatch):
     """BASELINE cfg 4's object with cwtObj_enableDet: the 36 short-kernel scales of the DERIVATIVE transform run in
     the time domain too (kernels IFFT(j w psi), cwt_algorithm.c:485-528) -- every scale against the compiled reference
-    at 1e-5 of the scale's own peak, from the batched device entry and from the one-chunk host entry."""
+    at 1e-5 of the scale's own peak, from the batched device entry and from the one-chunk host entry.  AFX_CWT_TD_DET=0
+    (read by cwtObj_enableDet) keeps those scales on the two-pass path: the same bar."""
     import torch
+    monkeypatch.setenv("AFX_CWT_TD_DET", td_det)
     from oracle import ref
     if not ref.available():
         pytest.skip("compiled reference not built")
@@ -128,5 +131,5 @@ def test_derivative_transform_time_domain_scales_against_reference():
         worst = max(worst, float(err.max()))
         assert err.max() <= 1e-5, (c, np.argmax(err), err.max())
     from tests.conftest import parity_log
-    parity_log("cwt/derivative transform, per scale (36 time-domain scales)", worst, 1e-5, kind="per-scale peak")
+    parity_log("cwt/derivative transform, per scale (36 short-kernel scales, AFX_CWT_TD_DET=%s)" % td_det, worst, 1e-5, kind="per-scale peak")
     assert_parity(o.cwt_det(x[1])[::-1], (lambda a, b: a + 1j * b)(*r.cwt(x[1], det=True)), TOL, "host entry, derivative")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPU: where the steps of k_cqt_pyramid go -- AFX_CQT_PYR_TIMING=1 runs the instrumented instantiation; shader cycles
-per wave role and phase, averaged over the workgroups and divided by the steps of a run.
-usage: tools/pyr_phases.py [clips] [steps]"""
+per wave role and phase, averaged over the workgroups and divided by the steps of a run.  The switch exists in measurement
+builds only: tools/build_variant.sh exp -DAFX_EXPERIMENTS afx_cqt afx_cqt_f16 afx_melfused2, then
+AFX_LIB=audioflux_amd/lib/variants/libafx_exp.so python tools/pyr_phases.py [clips] [steps]   (gpu_call6.sh phases does both)"""
 import ctypes as C, os, sys, time
 os.environ["AFX_CQT_PYR_TIMING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +28,9 @@ for _ in range(reps):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / reps
 got = lib.afx_cqt_pyramid_timing(C.c_void_p(o._obj.value if hasattr(o._obj, "value") else o._obj), buf.ctypes.data_as(C.c_void_p))
-assert got, "no timing recorded (AFX_CQT_PYR_TIMING)"
+if not got:
+    sys.exit("no timing recorded: this library was built without -DAFX_EXPERIMENTS (see the header of this file); "
+             "the shipped build has no instrumented ladder")
 nT = (T + 31) // 32
 wgs = min(256, clips * max(1, min(256 // clips, nT // 48)))
 used = buf[:wgs].astype(np.float64)
