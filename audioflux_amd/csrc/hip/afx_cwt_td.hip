@@ -26,6 +26,8 @@
 //     transposed through LDS and leave as 1 KB runs per (scale, plane).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -315,12 +317,12 @@ static int launch_td(const AfxCwtTdPlan *p, int first, int count, int maxKs, dou
     if (count <= 0) return AFX_OK;
     const size_t lds = (size_t)2 * maxKs * 1024 + 2048 + (size_t)WAVES * TdGeom<MAXK>::WAVE_BYTES;
     if (lds > 160 * 1024) return AFX_ERR_UNSUPPORTED;
-    static bool attrSet[AFX_MAX_DEVICES] = {};
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];
     const int dev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[dev]) {
+    if (!attrSet[dev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cwt_td<MAXK>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
-        attrSet[dev] = true;
+        attrSet[dev].store(true, std::memory_order_release);
     }
     a.pairs = p->pairs + first;
     a.nPairs = count;

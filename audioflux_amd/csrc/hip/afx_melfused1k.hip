@@ -10,6 +10,8 @@
 // flux_vector.c:55-86).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -599,12 +601,12 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.cc = a->cc;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB) + (CC ? CCB_BYTES : 0);  // (CC: the DCT operand table behind the wave regions)
     static_assert(lds <= 163840, "workgroup LDS budget");
-    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[attrDev]) {
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet[attrDev] = true;
+        attrSet[attrDev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_stft_band_1k<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
@@ -755,8 +757,8 @@ const float2 *stft_tables(void *stream) {
         fill_twiddles(h, h + 2 * TAB_TW1_F2, h + 2 * (TAB_TW1_F2 + TAB_TW2_F2));
         float2 *d = nullptr;
         int st = afxdev_malloc(reinterpret_cast<void **>(&d), sizeof(float) * 2 * NF2);
-        if (st == AFX_OK) st = afxdev_h2d(d, h, sizeof(float) * 2 * NF2, stream);
-        if (st == AFX_OK) st = afxdev_stream_sync(stream);
+        // (a synchronous copy, like wave_tables() of afx_stft.hip: the caller's stream is not waited for under this lock)
+        if (st == AFX_OK && hipMemcpy(d, h, sizeof(float) * 2 * NF2, hipMemcpyHostToDevice) != hipSuccess) st = AFX_ERR_HIP;
         free(h);
         if (st != AFX_OK) {
             afxdev_free(d);
@@ -802,12 +804,12 @@ int launch_stft(const AfxStftArgs *a, const float2 *tab, void *stream) {
     k.binCount = a->binCount;
     k.outPitch = a->outPitch ? a->outPitch : (long long)a->binCount;
     constexpr size_t lds = (size_t)block_lds_bytes(0, 0);
-    static bool attrSet[AFX_MAX_DEVICES] = {};
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[attrDev]) {
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_1k<0, 0, false, SHIFT, true, true, MAPPED, FULL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet[attrDev] = true;
+        attrSet[attrDev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_stft_band_1k<0, 0, false, SHIFT, true, true, MAPPED, FULL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);

@@ -30,6 +30,8 @@
 // Index algebra and LDS bank behaviour of every access class: tools/proto_fft1024_v2.py.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -726,12 +728,12 @@ int launch_variant(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
     k.zcr = a->zcr;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB, CC == 1);
     static_assert(lds <= 163840, "workgroup LDS budget");
-    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[attrDev]) {
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL, CPLX>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet[attrDev] = true;
+        attrSet[attrDev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_stft_mel_v2<TA, TB, SHIFT, SPLIT, CC, TEMPORAL, CPLX>), dim3((unsigned)blocks), dim3(NWV * 64), lds,
                        (hipStream_t)stream, k);

@@ -23,6 +23,8 @@
 // (spectrum value, bank product).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -735,8 +737,8 @@ const float4 *stft_tables(void *stream) {
         if (!h) return nullptr;
         fill_transform_tables(h, nullptr);
         int st = afxdev_malloc(reinterpret_cast<void **>(&d), bytes);
-        if (st == AFX_OK) st = afxdev_h2d(d, h, bytes, stream);
-        if (st == AFX_OK) st = afxdev_stream_sync(stream);
+        // (a synchronous copy, like wave_tables() of afx_stft.hip: the caller's stream is not waited for under this lock)
+        if (st == AFX_OK && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) st = AFX_ERR_HIP;
         free(h);
         if (st != AFX_OK) {
             afxdev_free(d);
@@ -779,12 +781,12 @@ int launch_stft(const AfxStftArgs *a, const float4 *tab, void *stream) {
     k.binCount = a->binCount;
     k.outPitch = a->outPitch ? a->outPitch : (long long)a->binCount;
     constexpr size_t lds = (size_t)block_lds_bytes(0, 0);
-    static bool attrSet[AFX_MAX_DEVICES] = {};
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[attrDev]) {
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k2<0, 0, SHIFT, false, true, true, MAPPED, FULL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet[attrDev] = true;
+        attrSet[attrDev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_stft_band_4k2<0, 0, SHIFT, false, true, true, MAPPED, FULL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
@@ -845,12 +847,12 @@ int launch_variant(const Plan4 *p, const AfxMelFusedArgs *a, void *stream) {
     k.ccCbrt = a->ccRectify == 1;
     k.cc = a->cc;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB);
-    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[attrDev]) {
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX, false, false, false, CC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet[attrDev] = true;
+        attrSet[attrDev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_stft_band_4k2<TA, TB, SHIFT, SPLIT, CPLX, false, false, false, CC>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);

@@ -9,6 +9,8 @@
 // flux_complex.c:254-286,469-503, bft_algorithm.c:457-529, flux_vector.c:55-86).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -574,12 +576,12 @@ int launch_variant(const Plan *p, const AfxMelFusedArgs *a, void *stream) {
     k.cc = a->cc;
     constexpr size_t lds = (size_t)block_lds_bytes(TA, TB) + (CC ? CCB_BYTES : 0);  // (CC: the DCT operand table behind the wave regions)
     static_assert(lds <= 163840, "workgroup LDS budget");
-    static bool attrSet[AFX_MAX_DEVICES] = {};  // per device: the attribute lives in the device's code object
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];  // per device: the attribute lives in the device's code object
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[attrDev]) {
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_512<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet[attrDev] = true;
+        attrSet[attrDev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_stft_band_512<TA, TB, GENERAL, SHIFT, CPLX, false, false, false, SPLIT, CC>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);
@@ -712,8 +714,8 @@ const float *stft_tables(void *stream) {  // one device copy of the twiddle blob
         fill_transform_tables(h, nullptr);
         float *d = nullptr;
         int st = afxdev_malloc(reinterpret_cast<void **>(&d), TAB_BYTES);
-        if (st == AFX_OK) st = afxdev_h2d(d, h, TAB_BYTES, stream);
-        if (st == AFX_OK) st = afxdev_stream_sync(stream);
+        // (a synchronous copy, like wave_tables() of afx_stft.hip: the caller's stream is not waited for under this lock)
+        if (st == AFX_OK && hipMemcpy(d, h, TAB_BYTES, hipMemcpyHostToDevice) != hipSuccess) st = AFX_ERR_HIP;
         free(h);
         if (st != AFX_OK) {
             afxdev_free(d);
@@ -757,12 +759,12 @@ int launch_stft(const AfxStftArgs *a, const float *tab, void *stream) {
     k.binCount = a->binCount;
     k.outPitch = a->outPitch ? a->outPitch : (long long)a->binCount;
     constexpr size_t lds = (size_t)block_lds_bytes(0, 0);
-    static bool attrSet[AFX_MAX_DEVICES] = {};
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];
     const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
-    if (!attrSet[attrDev]) {
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {  // (two threads may both set it: idempotent)
         AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_band_512<0, 0, false, SHIFT, true, true, MAPPED, FULL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet[attrDev] = true;
+        attrSet[attrDev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_stft_band_512<0, 0, false, SHIFT, true, true, MAPPED, FULL>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, k);

@@ -235,7 +235,27 @@ bool stage_off() {
 }
 // the stage of `stream` (created on first use); nullptr: table full or no pinned memory -> plain copies
 thread_local Stage *t_lastStage = nullptr;  // the stage this thread used last
-Stage *stage_of(void *stream, bool create) {
+// every stage this thread has staged transfers on (an object with several streams, a nested object): a failing call drops the
+// pending downloads of ALL of them, not only of the last one (a later sync would copy into caller arrays that may be gone).
+// A stream -- and so its stage -- belongs to ONE thread at a time, like the object that owns it (include/afx_batch.h).
+constexpr int AFX_STAGE_TOUCHED = 8;
+thread_local Stage *t_touched[AFX_STAGE_TOUCHED] = {};
+Stage *stage_note(Stage *s) {
+    if (s) {
+        for (Stage *&t : t_touched) {
+            if (t == s) return s;
+            if (!t) {
+                t = s;
+                return s;
+            }
+        }
+        t_touched[0] = s;  // (more than eight streams per thread: the oldest note is given up)
+    }
+    return s;
+}
+Stage *stage_find(void *stream, bool create);
+Stage *stage_of(void *stream, bool create) { return stage_note(stage_find(stream, create)); }
+Stage *stage_find(void *stream, bool create) {
     Stage *&last = t_lastStage;
     if (last && last->stream.load(std::memory_order_relaxed) == stream) return last;
     std::lock_guard<std::mutex> g(g_stageMu);
@@ -271,6 +291,10 @@ Stage *stage_of(void *stream, bool create) {
 }  // namespace
 
 static void stage_drop_pending(void) {
+    for (Stage *&t : t_touched) {
+        if (t) t->nPend = 0;
+        t = nullptr;
+    }
     if (t_lastStage) t_lastStage->nPend = 0;
 }
 

@@ -522,7 +522,7 @@ MFMA_F16_PEAK_FLOPS = 2.5e15   # dense f16 / bf16 matrix peak
 
 
 def pmc_compute(config, units=None, kern_ms=None):
-    """the compute side of the roofline from the round's PMC passes (tools/gpu_call5.sh + tools/prof_compute.py): how busy
+    """the compute side of the roofline from the round's PMC passes (tools/gpu_call6.sh evidence + tools/prof_compute.py): how busy
     the vector unit, the LDS, the SIMDs' issue ports and the matrix pipe were under the dominant kernel -- what bounds a
     kernel that is nowhere near the HBM roofline; replayed from profiles/, like `traffic`.  `frac_of_peak` relates THIS
     run's rate to the unit that binds: cfg 2 vector instructions per second / (1024 SIMDs x 2.4 GHz / 4); cfg 5 matrix

@@ -98,3 +98,89 @@ def test_hot_kernels_do_not_spill(tmp_path):
         if hit:
             bad.append((frag, why, sorted(hit.items())[:3]))
     assert not bad, bad
+
+
+# ---- loads issued by hand inside asm statements (afx_asm.h rows_shift_fetch / rows_fetch_all, the LOAD_*_B128 macros): the compiler
+# believes their destinations are defined AT the statement, the hand-written s_waitcnt vmcnt comes statements later.  Nothing may touch
+# a destination register while its load is in flight (a copy, spill or coalesce there would read stale registers).
+REG = re.compile(r"\bv(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def _regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def inflight_hazards(lines):
+    """linear scan of one kernel's disassembly with gfx9's in-order vmcnt: (instruction, registers) pairs that read or write the
+    destination of a vector-memory load that no s_waitcnt has covered yet.  Branch targets are not followed (conservative for
+    the straight-line frame loops this is meant for: a back edge re-enters with whatever is outstanding, as the hardware does)."""
+    fifo, bad = [], []  # outstanding VM operations in issue order: set of destination registers (empty for stores)
+    for raw in lines:
+        ins = raw.split("//")[0].strip()
+        if not ins or ins.endswith(":"):
+            continue
+        op = ins.split()[0]
+        if op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", ins)
+            if m:
+                n = int(m.group(1))
+                while len(fifo) > n:
+                    fifo.pop(0)
+            continue
+        if op.startswith(("s_endpgm", "s_branch", "s_setpc")):  # the next line is not this one's successor
+            fifo = []
+            continue
+        is_load = op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load"))
+        # (a load's own destination is exempt: loads return in order, so a second load into a register in flight -- the other
+        #  arm of an if / else in this linear scan, or a real overwrite -- is served after the first; its ADDRESS operands count)
+        used = _regs(ins.split(None, 1)[1].split(",", 1)[1]) if is_load and "," in ins else _regs(ins)
+        busy = set().union(*fifo) if fifo else set()
+        if used & busy:
+            bad.append((ins[:100], sorted(used & busy)))
+        if is_load:
+            dst = ins.split(None, 1)[1].split(",")[0]
+            fifo.append(_regs(dst))
+        elif op.startswith(("global_store", "buffer_store", "flat_store", "scratch_store", "global_atomic", "buffer_atomic")):
+            fifo.append(set())
+    return bad
+
+
+def test_the_inflight_scanner():
+    ok = ["global_load_dwordx2 v[12:13], v[40:41], off", "v_mov_b64 v[0:1], v[2:3]", "s_waitcnt vmcnt(0)", "v_pk_mul_f32 v[4:5], v[12:13], v[6:7]"]
+    assert not inflight_hazards(ok)
+    assert inflight_hazards(["global_load_dwordx2 v[12:13], v[40:41], off", "v_mov_b32 v3, v13", "s_waitcnt vmcnt(0)"])
+    # in-order counter: vmcnt(1) covers the first of two loads only
+    two = ["global_load_dword v1, v[8:9], off", "global_load_dword v2, v[8:9], off offset:4", "s_waitcnt vmcnt(1)", "v_add_f32 v3, v1, v1", "v_add_f32 v3, v2, v2"]
+    assert [b[1] for b in inflight_hazards(two)] == [[2]]
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="no llvm-objdump in this image")
+def test_no_instruction_touches_a_register_whose_hand_issued_load_is_in_flight(tmp_path):
+    """the n_fft 4096 kernels (rows_shift_fetch / rows_fetch_all: 4 + 16 loads in one asm statement, waited for by hand before the row
+    stores) and the kernels with the cepstrum block's hand-waited loads (k_stft_mel_v2): every instantiation in the shipped library"""
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([OBJDUMP, "--offloading", lib], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = sorted(f for f in os.listdir(tmp_path) if "amdgcn" in f and "gfx950" in f)
+    checked, bad = 0, []
+    for f in objs:
+        dis = subprocess.run([OBJDUMP, "-d", "--demangle", str(tmp_path / f)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        sym, body = None, []
+        for line in dis.splitlines() + ["<end>:"]:
+            if line.endswith(">:"):
+                if sym and ("k_stft_band_4k2<" in sym or "k_stft_mel_v2<" in sym):
+                    checked += 1
+                    h = inflight_hazards(body)
+                    if h:
+                        bad.append((sym[:90], h[:3]))
+                sym, body = line.split("<", 1)[-1][:-2], []
+            elif sym:
+                body.append(re.sub(r"^\s*[0-9a-fA-F]+:\s+", "", line) if re.match(r"^\s*[0-9a-fA-F]+:\s", line) else line)
+    assert checked >= 20, checked
+    assert not bad, bad[:5]
