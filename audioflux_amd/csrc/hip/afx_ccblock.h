@@ -15,6 +15,14 @@
 
 #include <afx_asm.h>
 
+// knock-out measurement builds of the block (make EXTRA=-DAFX_KO_CC=<mask>; results WRONG, timing only; profiles/r06_ab_mfcc.txt):
+// bit 0 the row loads (registers as they are), 1 the MFMAs (one v_add per product), 2 the rectification, 3 the wait for the stores
+#ifdef AFX_KO_CC
+#define CCB_KO(b) (((AFX_KO_CC) >> (b)) & 1)
+#else
+#define CCB_KO(b) 0
+#endif
+
 namespace {
 
 typedef float ccb_v4 __attribute__((ext_vector_type(4)));
@@ -62,7 +70,7 @@ __device__ __forceinline__ void ccb_rows(const float *out, float *cc, const floa
                                          long long fb, int cnt, int lane, const float *ldsTab = nullptr) {
     static_assert(CHAINS == 2 || CHAINS == 4, "accumulator chains");
     static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4 || GROUPS == 8, "groups per trip");
-    VM_WAIT_ALL();  // own stores -> L2 (vmcnt counts stores on gfx9)
+    if (!CCB_KO(3)) VM_WAIT_ALL();  // own stores -> L2 (vmcnt counts stores on gfx9)
     int ln = lane;
     PIN(ln);  // keep this block's per-lane values out of the frame loop's registers
     const int fi = ln & 15, g = ln >> 4;
@@ -82,6 +90,11 @@ __device__ __forceinline__ void ccb_rows(const float *out, float *cc, const floa
     typedef unsigned ccb_u4 __attribute__((ext_vector_type(4)));
     auto row_piece = [&](int u) {  // bands 16 u + 4 g .. + 3 of the lane's row (zeros past the row's end when the row is the last)
         const bool in = 16 * u + 4 * g < num;
+        if (CCB_KO(0)) {
+            ccb_v4 q;
+            asm volatile("" : "=v"(q));
+            return q;
+        }
         return __builtin_bit_cast(ccb_v4, (ccb_u4)__builtin_amdgcn_raw_buffer_load_b128(rows, in ? (int)(rowOff + 64u * (unsigned)u) : (int)0x80000000, 0, CCB_ROW_AUX));
     };
     ccb_v4 nxt[GROUPS];
@@ -108,8 +121,9 @@ __device__ __forceinline__ void ccb_rows(const float *out, float *cc, const floa
         for (int j = 0; j < GROUPS; ++j) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float lg = ccb_rect(av[j][c], cbrt);
-                acc[c % CHAINS] = __builtin_amdgcn_mfma_f32_16x16x4f32(lg, dv[j][c], acc[c % CHAINS], 0, 0, 0);
+                const float lg = CCB_KO(2) ? av[j][c] : ccb_rect(av[j][c], cbrt);
+                if (CCB_KO(1)) acc[c % CHAINS][0] += lg * dv[j][c];
+                else acc[c % CHAINS] = __builtin_amdgcn_mfma_f32_16x16x4f32(lg, dv[j][c], acc[c % CHAINS], 0, 0, 0);
             }
         }
     }
