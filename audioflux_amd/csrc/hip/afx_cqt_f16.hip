@@ -690,7 +690,11 @@ __device__ __forceinline__ void pyr_wave(const AfxCqtPyramidArgs &a, unsigned ch
 #pragma unroll
         for (int u = 0; u < (PREP ? C::NV : 0); ++u) {
             const int pos = p0 + 4 * (lane + 64 * u);
-            wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, CQ_KO(K == 0 ? 8 : 9) ? (int)(0x80000000u + 16u * u) : (int)(((unsigned)pos & RMASK) * 4u), 0, K == 0 ? pyr::AUX_STREAM : pyr::AUX_L2);
+            // (the last register reaches past the window: those 16-byte pieces are not requested -- zeros, like every use of them
+            //  already assumes; in a ring they would be the block the level above is writing in this very step: a read nobody uses,
+            //  but a race in the lane emulation under ThreadSanitizer, tests/test_emulated_kernels.py)
+            const bool past = 4 * (lane + 64 * u) >= C::S;
+            wnd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (CQ_KO(K == 0 ? 8 : 9) || past) ? (int)(0x80000000u + 16u * u) : (int)(((unsigned)pos & RMASK) * 4u), 0, K == 0 ? pyr::AUX_STREAM : pyr::AUX_L2);
         }
     };
     // the wave works on tile s - LAG: the octave's rows for the tiles of the run, the resampler also for the tiles

@@ -269,6 +269,37 @@ def test_one_launch_mel_mfcc_at_every_fused_size(r2):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("r2", [9, 10, 11, 12])
+def test_one_launch_mel_mfcc_edge_shapes(r2):
+    """the same call at the edges of its shapes: ONE frame per clip over 70 clips (every wave's block is a partial block of one row,
+    a clip boundary behind every frame), two frames, the smallest bank the block takes (num = 4) and a bank it does not take
+    (num = 30: not a multiple of 4 -- the cepstra come from the second kernel, same results); ccNum = num."""
+    torch = _torch()
+    rng = np.random.default_rng(700 + r2)
+    n_fft, hop = 1 << r2, (1 << r2) // 4
+    for num, frames, clips, cc_num in ((128, 1, 70, 13), (128, 2, 5, 16), (4, 19, 3, 4), (30, 18, 2, 13), (64, 1, 1, 1)):
+        n = n_fft + hop * (frames - 1)
+        x = (0.1 * rng.standard_normal((clips, n))).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        bft = af.BFT(num, radix2_exp=r2, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=hop,
+                     scale_type=af.SpectralFilterBankScaleType.MEL, data_type=af.SpectralDataType.POWER)
+        bft.set_result_type(1)
+        xx = af.XXCC(num)
+        rb = ref.RefBFT(num, r2, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1, slide_length=hop,
+                        scale_type=2, style_type=0, normal_type=0, data_type=0)
+        rb.set_result_type(1)
+        rc = ref.RefXXCC(num)
+        rmel = np.stack([rb.bft(x[i])[0] for i in range(clips)])
+        assert rmel.shape[1] == frames
+        for rect in (0, 1):
+            mel, cc = af.mel_mfcc_device(bft, xx, xd, cc_num, rectify_type=af.CepstralRectifyType(rect))
+            torch.cuda.synchronize()
+            want = np.stack([rc.xxcc(rmel[i], cc_num, rect) for i in range(clips)])
+            assert_parity(cc.cpu().numpy(), want, what=f"mfcc n_fft{n_fft} num{num} frames{frames} clips{clips} cc{cc_num} rect{rect}")
+            assert_parity(mel.cpu().numpy(), rmel, what=f"mel n_fft{n_fft} num{num} frames{frames}")
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("r2,clips", [(9, 64), (10, 64), (12, 48)])
 def test_one_launch_mel_mfcc_long_runs_per_wave(r2, clips):
     """the same at a size where every wave walks 30-40 frames (332 000 frames at n_fft 512): whole 16-row blocks behind each other

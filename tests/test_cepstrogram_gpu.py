@@ -77,6 +77,8 @@ def test_wave_kernel_2048_matches_golden_through_device_call(golden_dir):
     (9, 128, 12000, 1, 16, "hamm"),
     (9, 77, 6000, 0, 1, "rect"),
     (9, 512, 8192, 0, 9, "hann"),
+    (10, 256, 1024, 0, 4, "hann"),       # one frame
+    (9, 128, 640, 1, 16, "rect"),        # two frames, odd row pitch
 ])
 def test_wave_kernels_match_compiled_reference(r, hop, length, stride_pad, cep_num, window):
     import torch
