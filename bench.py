@@ -496,7 +496,9 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
             w.step(n)
             n += 1
             if n % 8 == 0 or sustained_s < 1.0:
-                torch.cuda.synchronize()
+                # (the launch stream only: a device-wide synchronize would wait for the probe's sleeping wave on its side stream,
+                #  which ends when the flag behind this loop is written -- i.e. at its 20 s limit)
+                torch.cuda.current_stream(dev).synchronize()
                 if time.perf_counter() - t1 >= sustained_s:
                     break
         s1.record()
