@@ -409,8 +409,8 @@ class CpuEvent:
 
 
 def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s, gathers=(), which=(), dry=False):
-    """W untimed steps, then exactly `steps` steps between barrier + synchronize fences; per-step device time from
-    events on the launch stream; optionally a back-to-back loop of >= sustained_s seconds.  With `gathers` the slabs
+    """W untimed steps, then exactly `steps` steps between barrier + synchronize fences; the steps' average device time from
+    ONE pair of events on the launch stream around them; optionally a back-to-back loop of >= sustained_s seconds.  With `gathers` the slabs
     of step i travel to rank 0 on a side stream while step i + 1 computes (double-buffered sources)."""
     Event = CpuEvent if dry else torch.cuda.Event
     sync = (lambda: None) if dry else torch.cuda.synchronize
@@ -418,12 +418,9 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
     ev, gev = [], []
 
     def step(i, timed):
-        e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
-        e0.record()
+        # (no events between the steps: an event record on the launch stream drains it -- 2.5 % of a 1.4 ms step; ONE pair
+        #  brackets the K timed steps, the average launch duration is their difference / K)
         w.step(i)
-        e1.record()
-        if timed:
-            ev.append((e0, e1))
         if gathers:
             # the slabs of this step go to rank 0 while the next step computes (double-buffered
             # sources; the previous gather has had a whole step to finish)
@@ -465,8 +462,13 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
         step(i, False)
     fence()
     t0 = time.perf_counter()
+    if steps > 0:
+        ev.append((Event(enable_timing=True), Event(enable_timing=True)))
+        ev[0][0].record()
     for i in range(steps):
         step(i, True)
+    if steps > 0:
+        ev[0][1].record()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -474,7 +476,7 @@ def measure(w, torch, dist, dev, world, steps, warmup, clock_warmup, sustained_s
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     res = {"elapsed": elapsed, "last": max(steps - 1, 0),
-           "kern_ms": float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if ev else None,
+           "kern_ms": float(ev[0][0].elapsed_time(ev[0][1]) / steps) if ev else None,
            "gather_ms": float(np.mean([g0.elapsed_time(g1) for g0, g1 in gev])) if gev else None,
            "sustained_ms": None, "clock": None}
     # ---- outside the timed region: the shader clock THIS device holds under THIS workload (a sleeping wave on a side stream
