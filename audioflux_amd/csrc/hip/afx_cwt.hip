@@ -566,6 +566,80 @@ __device__ unsigned long long g_nbPhase[5][8];
 #define NB_CLOCK_END(R) ((void)0)
 #endif
 
+// ---- the R-term sums on the f32 matrix pipe (round 6).  Counters of the narrow-band launches: vector unit 55-74 % busy on the CUs
+// they own, LDS 35-59 %, matrix pipe idle -- and the sums are 17 (R = 2) ... 60 % (R = 16) of a thread's vector instructions.  As a real
+// product per wave: D[row][col] = sum_kk A[row][kk] B[kk][col], A = the staged products (2 R floats per row: re, im interleaved), B =
+// the twiddles W_512^((lo + k2) m1) of the 16 columns as [wr, -wi] / [wi, wr] (a "re" and an "im" column tile), v_mfma_f32_16x16x4_f32:
+// true float32 products, float32 accumulation (no conversions: the f16 (hi, lo) form of round 4 paid for them on the vector unit).
+// Tile T of wave w holds rows k1 = 16 (4 T + (i & 3)) + 4 w + (i >> 2), i = 0 .. 15: the D layout (row 4 (lane >> 4) + reg, column
+// lane & 15) then leaves thread (c = lane & 15, g = 4 w + (lane >> 4)) with its own rows 16 a + g, a = 4 T + reg -- no exchange.
+// K slot q = lane >> 4 of step s stands for float kk = F q + s of the row (F = R / 2: a lane's A operands are F consecutive floats of
+// its row -- one or two 16-byte reads for R = 8 / 16 -- and its B operands need only F / 2 gathered twiddles instead of R).
+// LDS layout of the staged rows for R >= 8: the row's 16-byte pieces rotated by rot(k1), so that the 16 lanes of a read group (four
+// rows 16 apart x four adjacent rows) hit 16 distinct bank quads without padding.
+template <int R>
+__device__ __forceinline__ int nb_rot(int k1) {
+    return R == 16 ? (((k1 >> 4) & 3) + 4 * ((k1 >> 1) & 1)) : R == 8 ? ((k1 >> 4) & 3) : 0;
+}
+// float2 index of element (k1, k2) in the staging buffer
+template <int R>
+__device__ __forceinline__ int nb_slot(int k1, int k2) {
+    if (R < 8) return k1 * R + k2;
+    constexpr int P = R / 2;  // 16-byte pieces per row
+    return k1 * R + 2 * (((k2 >> 1) + nb_rot<R>(k1)) & (P - 1)) + (k2 & 1);
+}
+typedef float nb_f4 __attribute__((ext_vector_type(4)));
+template <int R>
+__device__ __forceinline__ void nb_sums_mfma(const v2 *zs, const v2 *thi, int lo, int m1, int lane, int wave, v2 (&out)[16]) {
+    constexpr int F = R / 2;  // floats of a row per lane = MFMA steps
+    const int i = lane & 15, q = lane >> 4;
+    // B operands: step s <-> float kk = F q + s of a row <-> (k2 = kk >> 1, re / im)
+    float bRe[F], bIm[F];
+#pragma unroll
+    for (int s = 0; s < F; ++s) {
+        const int kk = F * q + s, k2 = kk >> 1;
+        const v2 w = thi[((lo + k2) * m1) & 511];  // W_512^((lo + k2) m1)
+        bRe[s] = (kk & 1) ? -w.y : w.x;
+        bIm[s] = (kk & 1) ? w.x : w.y;
+    }
+    float A[4][F];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const int k1 = 16 * (4 * T + (i & 3)) + 4 * wave + (i >> 2);
+        const float *row = reinterpret_cast<const float *>(zs + k1 * R);
+        if constexpr (R == 16) {
+            const int rot = nb_rot<R>(k1);
+            const nb_f4 p0 = *reinterpret_cast<const nb_f4 *>(row + 4 * ((2 * q + rot) & 7));
+            const nb_f4 p1 = *reinterpret_cast<const nb_f4 *>(row + 4 * ((2 * q + 1 + rot) & 7));
+            A[T][0] = p0.x; A[T][1] = p0.y; A[T][2] = p0.z; A[T][3] = p0.w;
+            A[T][4] = p1.x; A[T][5] = p1.y; A[T][6] = p1.z; A[T][7] = p1.w;
+        } else if constexpr (R == 8) {
+            const nb_f4 p0 = *reinterpret_cast<const nb_f4 *>(row + 4 * ((q + nb_rot<R>(k1)) & 3));
+            A[T][0] = p0.x; A[T][1] = p0.y; A[T][2] = p0.z; A[T][3] = p0.w;
+        } else if constexpr (R == 4) {
+            const v2 p0 = *reinterpret_cast<const v2 *>(row + 2 * q);
+            A[T][0] = p0.x; A[T][1] = p0.y;
+        } else {
+            A[T][0] = row[q];
+        }
+    }
+    nb_f4 accRe[4], accIm[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) accRe[T] = accIm[T] = nb_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < F; ++s) {  // eight independent accumulator chains per step
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            accRe[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[T][s], bRe[s], accRe[T], 0, 0, 0);
+            accIm[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[T][s], bIm[s], accIm[T], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) out[4 * T + reg] = v2{accRe[T][reg], accIm[T][reg]};
+}
+
 // Narrow-band scales: every non-zero of the wavelet lies in R rows k2 in [lo, lo + R) of the
 // transposed spectrum (frequencies k = k1 + 256 k2), so the 512-point row transform of the first
 // pass is an R-term sum,
@@ -576,7 +650,7 @@ __device__ unsigned long long g_nbPhase[5][8];
 // staged in LDS with row-contiguous loads; they are the same for the 32 workgroups of a scale and
 // are served by L2.  The terms outside a wavelet's support that R rounds up to are exact zeros.
 template <int R>
-__global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const float2 *__restrict__ Xt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cwt_inv_cols256_nb(CwtGeom g, const float2 *__restrict__ Xt,
                                                             const float *__restrict__ bankT, int isDet,
                                                             int listBase, float *__restrict__ outRe,
                                                             float *__restrict__ outIm) {
@@ -620,15 +694,22 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         // conj(X * wavelet) (cwt_algorithm.c:428-435): IFFT through a forward FFT
-        zs[tid + 256 * i] = isDet ? v2{-bw[i] * xv[i].y, -(bw[i] * xv[i].x)} : v2{bw[i] * xv[i].x, -(bw[i] * xv[i].y)};
+#ifdef AFX_CWT_NB_VALU
+        const int slot = tid + 256 * i;
+#else
+        const int slot = nb_slot<R>((tid + 256 * i) / R, (tid + 256 * i) & (R - 1));
+#endif
+        zs[slot] = isDet ? v2{-bw[i] * xv[i].y, -(bw[i] * xv[i].x)} : v2{bw[i] * xv[i].x, -(bw[i] * xv[i].y)};
     }
     __syncthreads();
     NB_STAMP();  // 2 -> 3: gathered twiddles + the R-term sums of 16 rows
-    v2 w5[R], wl[16];
+    v2 wl[16];
+    v2 r[16];
+#ifdef AFX_CWT_NB_VALU  // (round 5's form, kept for A/B: every thread sums its 16 rows on the vector unit)
+    v2 w5[R];
 #pragma unroll
     for (int k2 = 0; k2 < R; ++k2) w5[k2] = thi[((lo + k2) * m1) & (L2 - 1)];  // W_512^((lo + k2) m1)
     nb_fourstep_twiddles(tlo, thi, m1, gq, wl);  // W_L^(m1 k1), m1 k1 < L
-    v2 r[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         v2 z[R];
@@ -638,6 +719,12 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb(CwtGeom g, const flo
         for (int k2 = 1; k2 < R; ++k2) acc = cfma(z[k2], w5[k2], acc);
         r[a] = cmul(acc, wl[a]);
     }
+#else
+    nb_sums_mfma<R>(zs, thi, lo, m1, tid & 63, __builtin_amdgcn_readfirstlane(tid >> 6), r);
+    nb_fourstep_twiddles(tlo, thi, m1, gq, wl);  // W_L^(m1 k1), m1 k1 < L
+#pragma unroll
+    for (int a = 0; a < 16; ++a) r[a] = cmul(r[a], wl[a]);
+#endif
     NB_STAMP();  // 3 -> 4: barrier
     __syncthreads();  // every thread is done with zs before the exchange buffer is written
     NB_STAMP();  // 4 -> 5: column transform (exchange through LDS) and the row stores issued
