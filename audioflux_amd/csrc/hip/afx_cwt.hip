@@ -590,7 +590,7 @@ __device__ __forceinline__ int nb_slot(int k1, int k2) {
 }
 typedef float nb_f4 __attribute__((ext_vector_type(4)));
 template <int R>
-__device__ __forceinline__ void nb_sums_mfma(const v2 *zs, const v2 *thi, int lo, int m1, int lane, int wave, v2 (&out)[16]) {
+__device__ __forceinline__ void nb_mfma_acc(const v2 *zs, const v2 *thi, int lo, int m1, int lane, int wave, nb_f4 (&accRe)[4], nb_f4 (&accIm)[4]) {
     constexpr int F = R / 2;  // floats of a row per lane = MFMA steps
     const int i = lane & 15, q = lane >> 4;
     // B operands: step s <-> float kk = F q + s of a row <-> (k2 = kk >> 1, re / im)
@@ -623,9 +623,6 @@ __device__ __forceinline__ void nb_sums_mfma(const v2 *zs, const v2 *thi, int lo
             A[T][0] = row[q];
         }
     }
-    nb_f4 accRe[4], accIm[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) accRe[T] = accIm[T] = nb_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < F; ++s) {  // eight independent accumulator chains per step
 #pragma unroll
@@ -634,10 +631,24 @@ __device__ __forceinline__ void nb_sums_mfma(const v2 *zs, const v2 *thi, int lo
             accIm[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[T][s], bIm[s], accIm[T], 0, 0, 0);
         }
     }
+}
+__device__ __forceinline__ void nb_mfma_zero(nb_f4 (&accRe)[4], nb_f4 (&accIm)[4]) {
+#pragma unroll
+    for (int T = 0; T < 4; ++T) accRe[T] = accIm[T] = nb_f4{0.f, 0.f, 0.f, 0.f};
+}
+// accumulators -> the thread's own rows 16 a + g, a = 4 T + reg
+__device__ __forceinline__ void nb_mfma_rows(const nb_f4 (&accRe)[4], const nb_f4 (&accIm)[4], v2 (&out)[16]) {
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) out[4 * T + reg] = v2{accRe[T][reg], accIm[T][reg]};
+}
+template <int R>
+__device__ __forceinline__ void nb_sums_mfma(const v2 *zs, const v2 *thi, int lo, int m1, int lane, int wave, v2 (&out)[16]) {
+    nb_f4 accRe[4], accIm[4];
+    nb_mfma_zero(accRe, accIm);
+    nb_mfma_acc<R>(zs, thi, lo, m1, lane, wave, accRe, accIm);
+    nb_mfma_rows(accRe, accIm, out);
 }
 
 // Narrow-band scales: every non-zero of the wavelet lies in R rows k2 in [lo, lo + R) of the
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // not a candidate of afx_cwt_td.hip) nor a band narrow enough for the single-block kernel, and its row pass +
 // 1 MB intermediate + column pass cost 2.7 x what the R-term sums cost here (profiles/r03_cwt_nb2.txt).
 template <int R2>
-__global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const float2 *__restrict__ Xt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R2 >= 8 ? 3 : 4, 4))) void k_cwt_inv_cols256_nb2(CwtGeom g, const float2 *__restrict__ Xt,
                                                              const float *__restrict__ bankT, int isDet,
                                                              int listBase, float *__restrict__ outRe,
                                                              float *__restrict__ outIm) {
@@ -777,8 +788,14 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
     thi[tid + 256] = v2{-ta.x, -ta.y};
     tlo[tid] = v2{tb.x, tb.y};
 #pragma unroll
-    for (int i = 0; i < R; ++i)
-        zs[tid + 256 * i] = isDet ? v2{-bw[i] * xv[i].y, -(bw[i] * xv[i].x)} : v2{bw[i] * xv[i].x, -(bw[i] * xv[i].y)};
+    for (int i = 0; i < R; ++i) {
+#ifdef AFX_CWT_NB_VALU
+        const int slot = tid + 256 * i;
+#else
+        const int slot = nb_slot<R>((tid + 256 * i) / R, (tid + 256 * i) & (R - 1));
+#endif
+        zs[slot] = isDet ? v2{-bw[i] * xv[i].y, -(bw[i] * xv[i].x)} : v2{bw[i] * xv[i].x, -(bw[i] * xv[i].y)};
+    }
     // second block of rows: requested now, staged once the first block's sums are taken
     float2 xw[R2];
     float bv[R2];
@@ -789,6 +806,27 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
         bv[i] = bankj[k1 * L2 + R + k2];
     }
     __syncthreads();
+#ifndef AFX_CWT_NB_VALU  // both blocks of rows into the same accumulators of the f32 matrix pipe (nb_mfma_acc above)
+    nb_f4 accRe[4], accIm[4];
+    nb_mfma_zero(accRe, accIm);
+    nb_mfma_acc<R>(zs, thi, lo, m1, tid & 63, __builtin_amdgcn_readfirstlane(tid >> 6), accRe, accIm);
+    __syncthreads();  // every thread is done with the first block
+#pragma unroll
+    for (int i = 0; i < R2; ++i) {
+        const int slot = nb_slot<R2>((tid + 256 * i) / R2, (tid + 256 * i) & (R2 - 1));
+        zs[slot] = isDet ? v2{-bv[i] * xw[i].y, -(bv[i] * xw[i].x)} : v2{bv[i] * xw[i].x, -(bv[i] * xw[i].y)};
+    }
+    __syncthreads();
+    v2 r[16];
+    {
+        v2 wl[16];
+        nb_mfma_acc<R2>(zs, thi, lo + R, m1, tid & 63, __builtin_amdgcn_readfirstlane(tid >> 6), accRe, accIm);
+        nb_mfma_rows(accRe, accIm, r);
+        nb_fourstep_twiddles(tlo, thi, m1, gq, wl);  // W_L^(m1 k1), m1 k1 < L
+#pragma unroll
+        for (int a = 0; a < 16; ++a) r[a] = cmul(r[a], wl[a]);
+    }
+#else
     v2 acc[16];
     {
         v2 w5[R];
@@ -823,6 +861,7 @@ __global__ __launch_bounds__(256) void k_cwt_inv_cols256_nb2(CwtGeom g, const fl
             r[a] = cmul(acc[a], wl[a]);
         }
     }
+#endif
     __syncthreads();  // every thread is done with zs before the exchange buffer is written
     const long long D = g.dataLength;
     cols256_finish(g, r, t3, ex, c, gq, c0, outRe + ((long long)blockIdx.z * g.num + j) * D,
