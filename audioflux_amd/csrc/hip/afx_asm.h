@@ -209,6 +209,10 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 #endif
 // the same through the vector cache (read-only tables); waited for by hand like the one above
 #define LOAD_B128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+// the same into a register tuple that is carried around a loop (a ring of loads in flight, afx_gemm_bf16.hip): the tuple is
+// an in-out operand, so the slot's previous value dies here and the loop-carried copy of it coalesces with the destination --
+// no v_mov of a tuple whose load is still in flight (tests/test_isa_forms.py looks for one)
+#define LOAD_B128_SLOT(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory")
 
 // a wave-uniform 64-bit value the compiler computed on the vector unit (64-bit multiplies are VALU on gfx9) back in scalar registers
 __device__ __forceinline__ long long uniform64(long long x) {

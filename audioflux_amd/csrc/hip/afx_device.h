@@ -181,6 +181,16 @@ int afxk_gemm_nt(const float *A, long long lda, const float *B, int ldb,
 int afxk_gemm_nt128_bf16(const float *A, long long lda, const float *B, int ldb, float *C, long long ldc,
                          long long M, int N, int K, int post, float postArg, void *stream);
 
+/* the dense FILTER-BANK product with the bank prepared once per object (afx_gemm_bf16.hip, k_gemm_bank_bf16x3):
+ * afxk_gemm_bank_prepare splits bank[N, K] (device, row pitch ldb floats) into its three bf16 word planes in the order the
+ * kernel stages them ("bank image", device memory owned by the caller: afxdev_free); afxk_gemm_nt_bank computes
+ * C[M, N] = post(A[M, K] . bank^T) with the float32 rows of A split while they are staged.  A: 16-byte aligned, lda a
+ * multiple of 4 floats; AFX_ERR_UNSUPPORTED otherwise (callers then run afxk_gemm_nt on the float bank).
+ * The reference's product: __mdot1, src/vector/flux_vector.c:55-86 */
+int afxk_gemm_bank_prepare(const float *B, int ldb, int N, int K, void **bankImage, void *stream);
+int afxk_gemm_nt_bank(const float *A, long long lda, const void *bankImage, int N, int K, float *C, long long ldc,
+                      long long M, int post, float postArg, void *stream);
+
 /* "standard" cepstra post-pass (xxcc_algorithm.c:244-292): per frame, put
  * ln(max(energy,1e-8)) in front of / in place of coefficient 0 and take the
  * causal smoothing-derivative FIR (util_delta, util/flux_util.c:803-815) along

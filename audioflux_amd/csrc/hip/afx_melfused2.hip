@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 
 #include <cmath>
 #include <cstdlib>
@@ -120,6 +121,11 @@ struct KArgs2 {
     float *cc;             // [totalFrames, ccNum]
     // TEMPORAL
     float *energy, *rms, *zcr;  // [totalFrames]
+    // STFT: the mapped spectrum rows themselves (afxk_stft2k): bins binLo .. binLo + binCount - 1 of every frame to out + f * outPitch
+    const float *win;      // device window [2048], natural order, 8-byte aligned (the blob's window table is not used)
+    int binLo, binCount;
+    long long outPitch;
+    int vecOut;            // binLo == 0, all 1025 bins, 16-byte aligned rows of >= 1028 floats: 16-byte stores (the pad gets zeros)
 };
 
 // (lds_addr, RD64 / RD128, WR2_64, WR2ST_32, PIN, LDS_WAIT_N and the L1-bypassing load: afx_asm.h)
@@ -189,10 +195,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 // CC: cepstra of the rows in the same launch, ccNum <= 16 (1: num = 128, log10 rectification, DCT operand in LDS; 2: afx_ccblock.h)
 // TEMPORAL: energy / rms / zcr of the windowed frame
 // CPLX: complex results (specMap 3: S, 4: S^2): a second row in LDS holds the imaginary parts for a second pass of the bank
-template <int TA, int TB, int SHIFT, bool SPLIT, int CC, bool TEMPORAL, bool CPLX = false>
+// STFT: no bank -- the frame's mapped spectrum row (|S|^2, |S|, |S|^2p) goes to memory as it stands in the LDS (afxk_stft2k: the
+//   producer of the dense-bank route's [T, F] rows and the STFT object's real results at n_fft 2048)
+template <int TA, int TB, int SHIFT, bool SPLIT, int CC, bool TEMPORAL, bool CPLX = false, bool STFT = false>
 __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a) {
     constexpr int NWV = waves_of(CPLX);
     static_assert(!(CPLX && (CC || TEMPORAL)), "complex results: the bank only");
+    static_assert(!STFT || (TA == 0 && TB == 0 && !SPLIT && CC == 0 && !TEMPORAL && !CPLX), "STFT instantiations: real rows, no bank");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -205,7 +214,17 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
     // ---- workgroup-shared tables -> LDS (once) -------------------------------------------
     {
         float4 *s4 = reinterpret_cast<float4 *>(smem);
-        for (int i = threadIdx.x; i < TABB / 16; i += NWV * 64) s4[i] = a.tab[i];
+        for (int i = threadIdx.x + (STFT ? T_TW1 / 16 : 0); i < TABB / 16; i += NWV * 64) s4[i] = a.tab[i];
+        if constexpr (STFT) {
+            // the caller's window in the pair layout of afxk_mel2_create: entry (n1, lane) = (w[2n], w[2n+1]), n = 64 n1 + lane,
+            // at float2 index 128 (n1 >> 1) + 2 lane + (n1 & 1)
+            v2 *tw = reinterpret_cast<v2 *>(smem + T_WIN);
+            const v2 *w2 = reinterpret_cast<const v2 *>(a.win);
+            for (int at = threadIdx.x; at < 1024; at += NWV * 64) {
+                const int n1 = 2 * (at >> 7) + (at & 1), l = (at & 127) >> 1;
+                tw[at] = w2[64 * n1 + l];
+            }
+        }
         if constexpr (CC == 1) {
             // B operand of the cepstrum MFMAs: lane (coefficient fi = lane & 15, k-slot g = lane >> 4)
             // holds dct[fi][16 u + 4 g + c] at [lane][4 u + c]
@@ -242,8 +261,8 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
     const unsigned aQ23 = R + 4 * (lane == 0 ? 640 : 256 - lane);      // s = 0 slots 3, 2 | lane 0: (640, 896)
     const bool lane0 = (lane == 0);
 
-    const int startA = a.meta[lane], startB = a.meta[64 + lane];
-    const int rowA = a.meta[128 + lane], rowB = a.meta[192 + lane];
+    const int startA = STFT ? 0 : a.meta[lane], startB = STFT ? 0 : a.meta[64 + lane];
+    const int rowA = STFT ? -1 : a.meta[128 + lane], rowB = STFT ? -1 : a.meta[192 + lane];
     const unsigned seg0 = SPLIT ? (unsigned)a.meta[256 + lane] : 0u, seg1 = SPLIT ? (unsigned)a.meta[320 + lane] : 0u;
     const unsigned apa = R + 4 * startA, apb = R + 4 * startB;
     const unsigned awr = T0 + T_BAND + 4 * WP * lane;
@@ -560,6 +579,23 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
             wave_lds_sync();
         }
 
+        if constexpr (STFT) {
+            // ---- 4'. the row itself: 16-byte reads of the natural-order row, 1 KB per store instruction of the wave ----
+            MEL_PHASE(6);
+            float *orow = a.out + f * a.outPitch;
+            if (a.vecOut) {
+                const float4 *p4 = reinterpret_cast<const float4 *>(prow);
+                float4 *o4 = reinterpret_cast<float4 *>(orow);
+                float4 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = p4[lane + 64 * i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[lane + 64 * i] = q[i];
+                if (lane0) o4[256] = p4[256];  // bin 1024 and three words of the zero pad
+            } else {
+                for (int k = lane; k < a.binCount; k += 64) orow[k] = prow[a.binLo + k];
+            }
+        } else {
         MEL_PHASE(5);
         // ---- 4. banded filter bank: weights by ds_read_b128, power row by immediate-offset
         //         ds_read_b64 (conflict-free by the plan's bank-aware lane assignment); the NEXT
@@ -660,6 +696,7 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
             // stores of the 16th row as well, once per 16 frames
             if (f + 1 == fEnd || (SPLIT && ccN == 16)) cc_block(f + 1 - ccN, ccN);
         }
+        }  // !STFT
         wave_lds_sync();  // the next frame overwrites the images / the power row
 
         }  // pass
@@ -669,6 +706,42 @@ __global__ __launch_bounds__(waves_of(CPLX) * 64, 3) void k_stft_mel_v2(KArgs2 a
             ++clip;
         }
     }
+}
+
+// window (hWindow != nullptr) and twiddle tables of the blob, byte offsets T_WIN / T_TW1 / T_TW2 / T_TW3
+void fill_tables(float *tab, const float *hWindow) {
+    const double PI = 3.14159265358979323846;
+    // window and W_1024^(lane k1) in pair layout: entry (n1, lane) at float2 index 128 (n1 >> 1) + 2 lane + (n1 & 1)
+    float *win = tab + T_WIN / 4, *tw1 = tab + T_TW1 / 4, *tw2 = tab + T_TW2 / 4, *tw3 = tab + T_TW3 / 4;
+    for (int n1 = 0; n1 < 16; ++n1)
+        for (int l = 0; l < 64; ++l) {
+            const int at = 2 * (128 * (n1 >> 1) + 2 * l + (n1 & 1));
+            const int n = 64 * n1 + l;
+            if (hWindow) {
+                win[at] = hWindow[2 * n];
+                win[at + 1] = hWindow[2 * n + 1];
+            }
+            const double ang = -2.0 * PI * (double)(n1 * l) / MC;  // twiddles in double, rounded once
+            tw1[at] = (float)cos(ang);
+            tw1[at + 1] = (float)sin(ang);
+        }
+    for (int m = 0; m < 4; ++m)
+        for (int j = 0; j < 16; ++j) {
+            const double ang = -2.0 * PI * (double)(m * j) / 64.0;
+            tw2[(TW2_PITCH / 4) * m + 2 * j] = (float)cos(ang);
+            tw2[(TW2_PITCH / 4) * m + 2 * j + 1] = (float)sin(ang);
+        }
+    // 0.5 W_2048^bin of the P-bin of slot (s, lane, m); 16-byte halves swapped when bit 3 of lane is set
+    for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < 64; ++l)
+            for (int m = 0; m < 4; ++m) {
+                int bin = l + 64 * s + 256 * m;
+                if (s == 0 && l == 0 && m >= 2) bin = m == 2 ? 128 : 384;  // lane 0 carries the self-mirrored base
+                const double ang = -2.0 * PI * (double)bin / NFFT;
+                const int at = 2 * (4 * (64 * s + l) + 2 * ((m >> 1) ^ ((l >> 3) & 1)) + (m & 1));
+                tw3[at] = (float)(0.5 * cos(ang));
+                tw3[at + 1] = (float)(0.5 * sin(ang));
+            }
 }
 
 struct Plan2 {
@@ -788,7 +861,103 @@ int launch(const Plan2 *p, const AfxMelFusedArgs *a, void *stream) {
                     : launch_hop<TA, TB, false, 0, false>(p, a, stream);
 }
 
+// twiddle tables of the STFT instantiations (the blob without window and bank), one device copy per device, never freed
+const float4 *stft2k_tables() {
+    static std::mutex mu;
+    static float4 *dTab[AFX_MAX_DEVICES] = {};
+    const int dev = afxdev_current_device();
+    if (dev < 0 || dev >= AFX_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dTab[dev]) {
+        const size_t bytes = (size_t)tab_bytes(0, 0);
+        float *h = static_cast<float *>(calloc(bytes, 1));
+        if (!h) return nullptr;
+        fill_tables(h, nullptr);
+        float4 *d = nullptr;
+        int st = afxdev_malloc(reinterpret_cast<void **>(&d), bytes);
+        // (a synchronous copy: the caller's stream is not waited for under this lock)
+        if (st == AFX_OK && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) st = AFX_ERR_HIP;
+        free(h);
+        if (st != AFX_OK) {
+            afxdev_free(d);
+            return nullptr;
+        }
+        dTab[dev] = d;
+    }
+    return dTab[dev];
+}
+
+template <int SHIFT>
+int launch_stft2k(const AfxStftArgs *a, const float4 *tab, void *stream) {
+    const long long total = (long long)a->batch * a->timeLength;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // the frame distribution of launch_variant: two rounds of 12-wave workgroups, short calls spread over every CU
+    long long waves = (long long)cus * WAVES * 2;
+    long long fpw = (total + waves - 1) / waves;
+    if (fpw < 16) {
+        const long long oneRound = (total + (long long)cus * WAVES - 1) / ((long long)cus * WAVES);
+        fpw = oneRound < 16 ? oneRound : 16;
+    }
+    const long long usedWaves = (total + fpw - 1) / fpw;
+    const long long blocks = (usedWaves + WAVES - 1) / WAVES;
+    KArgs2 k;
+    memset(&k, 0, sizeof(k));
+    k.x = a->x;
+    k.clipStride = a->clipStride;
+    k.totalFrames = total;
+    k.timeLength = a->timeLength;
+    k.hop = a->hop;
+    k.framesPerWave = (int)fpw;
+    k.aligned = ((a->clipStride & 1) == 0) && ((a->hop & 1) == 0) && ((reinterpret_cast<uintptr_t>(a->x) & 7) == 0);
+    k.tab = tab;
+    k.specMap = a->mode == AFX_SPEC_POWER ? 0 : a->mode == AFX_SPEC_MAG ? 1 : 2;
+    k.normValue = a->normValue;
+    k.out = a->outRe;
+    k.win = a->window;
+    k.binLo = a->binLo;
+    k.binCount = a->binCount;
+    k.outPitch = a->outPitch ? a->outPitch : (long long)a->binCount;
+    k.vecOut = a->binLo == 0 && a->binCount == NFFT / 2 + 1 && k.outPitch >= 1028 && (k.outPitch & 3) == 0 &&
+               (reinterpret_cast<uintptr_t>(a->outRe) & 15) == 0;
+    constexpr size_t lds = (size_t)block_lds_bytes(0, 0, false);
+    static std::atomic<bool> attrSet[AFX_MAX_DEVICES];
+    const int attrDev = afxdev_current_device() & (AFX_MAX_DEVICES - 1);
+    if (!attrSet[attrDev].load(std::memory_order_acquire)) {
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stft_mel_v2<0, 0, SHIFT, false, 0, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attrSet[attrDev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_stft_mel_v2<0, 0, SHIFT, false, 0, false, false, true>), dim3((unsigned)blocks), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, k);
+    AFX_LAUNCH_CHECK("k_stft_mel_v2 (stft)");
+    return AFX_OK;
+}
+
 }  // namespace
+
+// The n_fft 2048 wave transform storing its mapped spectrum rows (real results: |S|^2, |S|, |S|^2p) -- the [T, F] rows of the
+// dense-bank route and of the STFT / linear-scale objects (stft_algorithm.c:717-803, bft_algorithm.c:489-504); every frame inside
+// its clip.  AFX_ERR_UNSUPPORTED: not this kernel's case (afxk_stft then runs k_stft_wave / the size-generic kernel)
+extern "C" int afxk_stft2k(const AfxStftArgs *a, void *stream) {
+    if (a->radix2Exp != 11 || a->bandStart || a->energy || a->padLeft != 0 || a->hop < 1 || a->binLo < 0 || a->binCount < 1 ||
+        a->binLo + a->binCount > NFFT / 2 + 1 || (long long)(a->timeLength - 1) * a->hop + NFFT > a->dataLength ||
+        (reinterpret_cast<uintptr_t>(a->window) & 7) != 0)
+        return AFX_ERR_UNSUPPORTED;
+    if (a->mode != AFX_SPEC_POWER && a->mode != AFX_SPEC_MAG && a->mode != AFX_SPEC_POWER_NORM) return AFX_ERR_UNSUPPORTED;
+    if (!a->outRe) return AFX_ERR_ARG;
+    const long long total = (long long)a->batch * a->timeLength;
+    if (total <= 0) return AFX_OK;
+    if (total > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+    const float4 *tab = stft2k_tables();
+    if (!tab) return AFX_ERR_UNSUPPORTED;
+    switch (a->hop) {
+        case 256: return launch_stft2k<2>(a, tab, stream);
+        case 512: return launch_stft2k<4>(a, tab, stream);
+        case 1024: return launch_stft2k<8>(a, tab, stream);
+        default: return launch_stft2k<0>(a, tab, stream);
+    }
+}
 
 extern "C" void afxk_mel2_destroy(void *plan) {
     Plan2 *p = static_cast<Plan2 *>(plan);
@@ -815,36 +984,7 @@ extern "C" int afxk_mel2_create(void **plan, int variant, const float *hWindow, 
     p->variant = variant;
     p->num = band->num;
     p->split = band->split;
-    const double PI = 3.14159265358979323846;
-    // window and W_1024^(lane k1) in pair layout: entry (n1, lane) at float2 index 128 (n1 >> 1) + 2 lane + (n1 & 1)
-    float *win = tab + T_WIN / 4, *tw1 = tab + T_TW1 / 4, *tw2 = tab + T_TW2 / 4, *tw3 = tab + T_TW3 / 4;
-    for (int n1 = 0; n1 < 16; ++n1)
-        for (int l = 0; l < 64; ++l) {
-            const int at = 2 * (128 * (n1 >> 1) + 2 * l + (n1 & 1));
-            const int n = 64 * n1 + l;
-            win[at] = hWindow[2 * n];
-            win[at + 1] = hWindow[2 * n + 1];
-            const double ang = -2.0 * PI * (double)(n1 * l) / MC;  // twiddles in double, rounded once
-            tw1[at] = (float)cos(ang);
-            tw1[at + 1] = (float)sin(ang);
-        }
-    for (int m = 0; m < 4; ++m)
-        for (int j = 0; j < 16; ++j) {
-            const double ang = -2.0 * PI * (double)(m * j) / 64.0;
-            tw2[(TW2_PITCH / 4) * m + 2 * j] = (float)cos(ang);
-            tw2[(TW2_PITCH / 4) * m + 2 * j + 1] = (float)sin(ang);
-        }
-    // 0.5 W_2048^bin of the P-bin of slot (s, lane, m); 16-byte halves swapped when bit 3 of lane is set
-    for (int s = 0; s < 2; ++s)
-        for (int l = 0; l < 64; ++l)
-            for (int m = 0; m < 4; ++m) {
-                int bin = l + 64 * s + 256 * m;
-                if (s == 0 && l == 0 && m >= 2) bin = m == 2 ? 128 : 384;  // lane 0 carries the self-mirrored base
-                const double ang = -2.0 * PI * (double)bin / NFFT;
-                const int at = 2 * (4 * (64 * s + l) + 2 * ((m >> 1) ^ ((l >> 3) & 1)) + (m & 1));
-                tw3[at] = (float)(0.5 * cos(ang));
-                tw3[at + 1] = (float)(0.5 * sin(ang));
-            }
+    fill_tables(tab, hWindow);
     float *wL = tab + T_BAND / 4;
     for (int l = 0; l < 64; ++l) {
         for (int t = 0; t < band->tapsA; ++t) wL[(size_t)l * WP + t] = band->wA[(size_t)t * 64 + l];

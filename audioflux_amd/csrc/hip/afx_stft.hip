@@ -400,6 +400,7 @@ int launch_stft_wave(const AfxStftArgs *a, const float2 *tab, long long frames, 
 
 }  // namespace
 
+extern "C" int afxk_stft2k(const AfxStftArgs *a, void *stream);   // afx_melfused2.hip
 extern "C" int afxk_stft4k(const AfxStftArgs *a, void *stream);   // afx_melfused4k2.hip
 extern "C" int afxk_stft1k(const AfxStftArgs *a, void *stream);   // afx_melfused1k.hip
 extern "C" int afxk_stft512(const AfxStftArgs *a, void *stream);  // afx_melfused512.hip
@@ -427,6 +428,12 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
     AfxStftArgs bins = *a;
     bins.energy = bins.rms = bins.zcr = nullptr;
     if (a->radix2Exp == 11 && !a->bandStart && a->binLo >= 0 && !afxdev_no_fused()) {
+        // real results of frames that lie inside their clips: the headline kernel's transform storing its row (afxk_stft2k:
+        // 2.4 x k_stft_wave<11, false> on the dense route's rows); AFX_ERR_UNSUPPORTED = not its case
+        if (!cplx) {
+            const int st = afxk_stft2k(&bins, stream);
+            if (st != AFX_ERR_UNSUPPORTED) return (st == AFX_OK && a->energy) ? afxk_temporal(a, stream) : st;
+        }
         if (const float2 *tab = wave_tables()) {
             const int st = cplx ? launch_stft_wave<11, true>(&bins, tab, frames, stream) : launch_stft_wave<11, false>(&bins, tab, frames, stream);
             return (st == AFX_OK && a->energy) ? afxk_temporal(a, stream) : st;

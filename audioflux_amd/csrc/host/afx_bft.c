@@ -33,6 +33,28 @@ static size_t dense_chunk_bytes(void) {
     return mb << 20;
 }
 
+/* rows[frames, F] (pitched) . bank^T -> out[frames, num]: the prepared-bank kernel (the bank split into its bf16 word planes
+ * once per object, afx_gemm_bf16.hip), else the generic product on the float bank (__mdot1, flux_vector.c:55-86) */
+static int dense_product(BFTObj o, const float *rows, int pitch, float *out, long long frames, int post, float postArg,
+                         void *stream) {
+    if (!o->bankImageTried) {
+        o->bankImageTried = 1;
+        o->dBankImage = NULL;
+        int st = afxk_gemm_bank_prepare(o->dBank, o->bankPitch, o->num, o->F, &o->dBankImage, stream);
+        if (st == AFX_OK) st = afxdev_stream_sync(stream); /* once per object: later calls may come on another stream */
+        if (st != AFX_OK) {
+            afxdev_free(o->dBankImage);
+            o->dBankImage = NULL;
+        }
+    }
+    if (o->dBankImage) {
+        const int st = afxk_gemm_nt_bank(rows, pitch, o->dBankImage, o->num, o->F, out, o->num, frames, post, postArg, stream);
+        if (st != AFX_ERR_UNSUPPORTED) return st;
+    }
+    return afxk_gemm_nt(rows, pitch, o->dBank, o->bankPitch, out, o->num, frames, o->num, o->F, AFX_MAP_NONE, post, postArg,
+                        stream);
+}
+
 int bftObj_new(BFTObj *bftObj, int num, int radix2Exp, int *samplate, float *lowFre,
                float *highFre, int *binPerOctave, WindowType *windowType, int *slideLength,
                SpectralFilterBankScaleType *filterScaleType,
@@ -514,12 +536,10 @@ int afx_bft_run_device(BFTObj o, const float *dData, int batch, int dataLength,
         }
         st = afxk_stft(&a, stream);
         if (st != AFX_OK) return st;
-        st = afxk_gemm_nt(a.outRe, pitch, o->dBank, pitch, dRe + b0 * T * o->num, o->num, frames,
-                          o->num, o->F, AFX_MAP_NONE, post, o->normValue, stream);
+        st = dense_product(o, a.outRe, pitch, dRe + b0 * T * o->num, frames, post, o->normValue, stream);
         if (st != AFX_OK) return st;
         if (complexOut) {
-            st = afxk_gemm_nt(a.outIm, pitch, o->dBank, pitch, dIm + b0 * T * o->num, o->num, frames,
-                              o->num, o->F, AFX_MAP_NONE, AFX_MAP_NONE, 1.f, stream);
+            st = dense_product(o, a.outIm, pitch, dIm + b0 * T * o->num, frames, AFX_MAP_NONE, 1.f, stream);
             if (st != AFX_OK) return st;
         }
     }
@@ -611,6 +631,7 @@ void bftObj_free(BFTObj o) {
     afxdev_free(o->dWindow);
     afxdev_free(o->dTwiddle);
     afxdev_free(o->dBank);
+    afxdev_free(o->dBankImage);
     afxdev_free(o->dBandMeta);
     afxdev_free(o->dBandW);
     afxdev_free(o->dX);

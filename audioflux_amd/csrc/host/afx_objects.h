@@ -43,6 +43,9 @@ struct OpaqueBFT {
     struct AfxMelFusedPlan *fast; /* NULL when the fused kernel does not apply */
     struct OpaqueReassign *reassign; /* isReassign = 1: the reassigned spectrum replaces the STFT */
     /* grow-only device scratch of the legacy host-pointer calls */
+    void *dBankImage; /* dense banks: dBank as three bf16 word planes in the GEMM's staging order (afxk_gemm_bank_prepare),
+                       * built on the first dense call; bankImageTried: the stand-in / a failure left none -- float bank then */
+    int bankImageTried;
     float *dX, *dSpec, *dOut, *dTemporal;
     size_t capX, capSpec, capOut, capTemporal;
     /* host copies for bftObj_getTemporalData */

@@ -10,19 +10,9 @@ import sys
 
 import numpy as np
 
+from emulated_stft4k_args import AfxStftArgs, fp
+
 lib = C.CDLL(os.environ["AFX_LIB"])
-fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
-
-
-class AfxStftArgs(C.Structure):  # audioflux_amd/csrc/hip/afx_device.h
-    _fields_ = [("x", fp), ("clipStride", C.c_longlong), ("batch", C.c_int), ("dataLength", C.c_int), ("timeLength", C.c_int),
-                ("radix2Exp", C.c_int), ("hop", C.c_int), ("window", fp), ("twiddle", fp), ("mode", C.c_int),
-                ("normValue", C.c_float), ("binLo", C.c_int), ("binCount", C.c_int), ("outPitch", C.c_longlong),
-                ("outRe", fp), ("outIm", fp), ("energy", fp), ("rms", fp), ("zcr", fp), ("padLeft", C.c_int),
-                ("bandStart", ip), ("bandLen", ip), ("bandOff", ip), ("bandW", fp), ("bandNum", C.c_int),
-                ("bandPost", C.c_int), ("bandPostArg", C.c_float), ("fullSpectrum", C.c_int), ("padMode", C.c_int),
-                ("padValueL", C.c_float), ("padValueR", C.c_float)]
-
 
 for fn in ("afxk_stft4k", "afxk_stft1k", "afxk_stft512"):
     getattr(lib, fn).restype = C.c_int

@@ -33,6 +33,7 @@
 #define __shared__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define AFX_WAVES_PER_EU(lo, hi)  // (a register-allocation hint of the device build)
 
 struct dim3 {
     unsigned x, y, z;

@@ -46,7 +46,7 @@ def emulated(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp("emu"))
     stub = os.path.join(tmp, "stub.c")
     subprocess.run([sys.executable, os.path.join(STUB, "gen_stub.py"), os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"),
-                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16", "--omit=afxk_cqt_pyramid", "--omit=afxk_cqt_pyramid_plan"], check=True)
+                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16", "--omit=afxk_gemm_bank_prepare", "--omit=afxk_gemm_nt_bank", "--omit=afxk_cqt_pyramid", "--omit=afxk_cqt_pyramid_plan"], check=True)
     # afx_cqt.hip keeps two arrays in static LDS: on the host, storage shared by the lanes' threads
     src = open(os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_cqt.hip")).read()
     patched, n = re.subn(r"(?m)^(\s*)__shared__ ", r"\1static ", src)
@@ -201,7 +201,17 @@ def test_bf16x3_gemm_emulated_matches_float64(emulated):
     """k_gemm_nt128_bf16x3: loader / three-word split / 24 MFMAs per k-step / epilogue with every
     tail, elementwise against float64 on operands spanning ten decades"""
     out = _run(emulated, "emulated_gemm.py", [])
-    assert out.count("elementwise relative error") == 3
+    assert out.count("elementwise relative error") == 8 and out.count("bank form") == 5
+
+
+def test_dense_route_producer_emulated_against_float64(emulated):
+    """afxk_stft2k = k_stft_mel_v2 <STFT> (round 6): the headline kernel's transform storing its mapped spectrum row -- the [T, F]
+    rows of the dense-bank route (16-byte stores on rows of 1028 floats, zero pad), bin slices, magnitude / power-law maps, hops
+    with and without the register re-use -- against numpy's float64 FFT.  With k_gemm_bank_bf16x3 (the prepared-bank product,
+    test above) these are the two launches of bftObj_bft for dense (gammatone) banks; on the device they meet the compiled
+    reference (tests/test_bft_gpu.py::test_dense_bank_at_the_headline_shape)"""
+    out = _run(emulated, "emulated_stft2k.py", [])
+    assert "pad words are zeros" in out and "power law 0.3" in out, out[-800:]
 
 
 @pytest.fixture(scope="module")
@@ -214,7 +224,7 @@ def emulated_tsan(tmp_path_factory):
     san = ["-O1", "-gline-tables-only", "-fsanitize=thread", "-fno-omit-frame-pointer"]
     stub = os.path.join(tmp, "stub.c")
     subprocess.run([sys.executable, os.path.join(STUB, "gen_stub.py"), os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_device.h"),
-                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16", "--omit=afxk_cqt_pyramid", "--omit=afxk_cqt_pyramid_plan"], check=True)
+                    stub, "--functional-cqt", "--omit=afxk_gemm_nt128_bf16", "--omit=afxk_gemm_bank_prepare", "--omit=afxk_gemm_nt_bank", "--omit=afxk_cqt_pyramid", "--omit=afxk_cqt_pyramid_plan"], check=True)
     src = open(os.path.join(ROOT, "audioflux_amd", "csrc", "hip", "afx_cqt.hip")).read()
     with open(os.path.join(tmp, "afx_cqt_host.hip"), "w") as f:
         f.write(re.sub(r"(?m)^(\s*)__shared__ ", r"\1static ", src))
