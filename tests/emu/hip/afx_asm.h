@@ -127,7 +127,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float up, unsigne
 #define VM_LGKM_WAIT_ALL() ((void)0)
 #define LOAD_SC1_B128(dst, ptr) ((dst) = *(ptr))
 #define LOAD_B128(dst, ptr) ((dst) = *(ptr))
-#define LOAD_B128_SLOT(dst, ptr) ((dst) = *(ptr))
+#define LOAD_B128_SLOT(dst, ptr) __builtin_memcpy(&(dst), (ptr), 16)
 static inline long long uniform64(long long x) { return x; }
 #define GLD128_S(dst, voff, sbase, off) __builtin_memcpy(&(dst), reinterpret_cast<const char *>(sbase) + (voff) + (off), 16)
 #define VM_WAIT_N(n) ((void)0)

@@ -1,8 +1,8 @@
 """Dense filter-bank route at the headline shape: gammatone-128 (ERB scale) at n_fft 2048 / hop 512,
-1000 x 30 s @ 16 kHz (934 000 frames): k_stft_wave -> pitched [T,F] scratch (chunks sized for the
-Infinity Cache) -> k_gemm_nt128 (128 x 128 tiles of v_mfma_f32_32x32x2_f32).  Prints frames/s and the
-GEMM's FLOP rate against the 157.3 TF f32 matrix peak; run under rocprofv3 (tools/prof_cmd.sh) for
-SQ_INSTS_VALU_MFMA_F32 / SQ_VALU_MFMA_BUSY_CYCLES.   python tools/bench_dense.py [clips] [steps]"""
+1000 x 30 s @ 16 kHz (934 000 frames): afxk_stft2k (the headline kernel's transform storing its spectrum rows) -> pitched [T,F]
+scratch -> k_gemm_bank_bf16x3 (128 x 128 tiles of v_mfma_f32_32x32x16_bf16, three bf16 words per operand, bank prepared once).
+Prints frames/s; run under rocprofv3 (tools/gpu_dense.sh) for the kernel split and SQ_VALU_MFMA_BUSY_CYCLES.
+   python tools/bench_dense.py [clips] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
