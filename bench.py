@@ -28,6 +28,9 @@ benchmarked outputs is checked against the oracle (1e-5 peak / L2).
 headline -- value, ms_per_step, frac, PMC traffic, oracle check each.  With N > 1 `gather` says whether the
 exchange hides behind the compute: gather_ms (device time of the collective on rank 0's side stream),
 exposed_ms (step time beyond the step's own compute) and overlap_hidden_ms.
+`dense_bank` (same line): the dense filter-bank route north_star names as the MFMA path -- gammatone-128 at the headline shape as
+frames/s with its own oracle check, and the route's product alone (k_gemm_bank_bf16x3, one chunk's shape) as bf16 matrix FLOP/s
+against the 2.5 PF/s dense peak (`roofline.bound` "mfma"); mfma_busy is replayed from profiles/r06_rocprofv3_dense.txt.
 `cpu_baseline` times the reference's own C path (oracle/_ref, built-in FFT + naive
 double-accumulating matmul: no FFTW/MKL in this image) on the host cores for a bounded sample.
 """
@@ -576,6 +579,90 @@ def roofline(W, w, clips, m):
             "compute": pmc_compute(W.config, w.units, kern_ms) if hasattr(W, "config") else None}
 
 
+def dense_bank_block(torch, af, dev, check=True):
+    """north_star's MFMA evidence on the driver's line: the dense filter-bank route (gammatone-128 at the headline shape: spectrum rows
+    from the headline transform, afxk_stft2k -> k_gemm_bank_bf16x3, three bf16 words per operand on the bf16 matrix cores) as frames/s,
+    and its product alone (one chunk's shape through the library's C entry points) as matrix FLOP/s against the dense bf16 peak.
+    Reference: __mdot1, src/vector/flux_vector.c:55-86, on the rows of src/stft_algorithm.c:717-803."""
+    import ctypes as C
+    clips, n = 1000, 16000 * 30
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = 0.1 * torch.randn((clips, n), generator=gen, device=dev, dtype=torch.float32)
+    o = af.BFT(128, radix2_exp=11, samplate=16000, low_fre=0.0, high_fre=8000.0, slide_length=512,
+               scale_type=af.SpectralFilterBankScaleType.ERB, style_type=af.SpectralFilterBankStyleType.GAMMATONE,
+               data_type=af.SpectralDataType.POWER)
+    o.set_result_type(1)
+    T = o.cal_time_length(n)
+    out = torch.empty((clips, T, 128), device=dev, dtype=torch.float32)
+    t_end = time.time() + 0.3
+    while time.time() < t_end:  # clock warm-up
+        o.bft_device(x, out_real=out)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k = 10
+    e0.record()
+    for _ in range(k):
+        o.bft_device(x, out_real=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / k
+    err = None
+    if check:
+        from oracle import ref
+        if ref.available():
+            r = ref.RefBFT(128, 11, samplate=16000, low_fre=0.0, high_fre=8000.0, window_type=1, slide_length=512, scale_type=4,
+                           style_type=2, normal_type=0, data_type=0)
+            r.set_result_type(1)
+            want, _ = r.bft(x[0].cpu().numpy())
+            err = _parity(out[0].cpu().numpy(), want)
+            assert err <= 1e-5, f"dense bank: benchmarked output differs from the oracle: {err:.3e}"
+    # the product alone: one chunk of the route (250 clips: 233 500 rows x 1025 bins, pitch 1028) x the 128 x 1025 bank
+    lib = af.get_lib()
+    vp, ll = C.c_void_p, C.c_longlong
+    lib.afxk_gemm_bank_prepare.restype = C.c_int
+    lib.afxk_gemm_bank_prepare.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), vp]
+    lib.afxk_gemm_nt_bank.restype = C.c_int
+    lib.afxk_gemm_nt_bank.argtypes = [vp, ll, vp, C.c_int, C.c_int, vp, ll, ll, C.c_int, C.c_float, vp]
+    lib.afxdev_free.argtypes = [vp]
+    M, N, K, P = 250 * T, 128, 1025, 1028
+    del x
+    A = torch.zeros((M, P), device=dev)
+    A[:, :K] = torch.randn((M, K), device=dev, generator=gen) ** 2 * 10.0 ** (10 * torch.rand((M, K), device=dev, generator=gen) - 5)
+    B = torch.zeros((N, P), device=dev)
+    B[:, :K] = torch.rand((N, K), device=dev, generator=gen)
+    Cm = out.view(-1)[:M * N].view(M, N)
+    img, stream = vp(), torch.cuda.current_stream().cuda_stream
+    assert lib.afxk_gemm_bank_prepare(B.data_ptr(), P, N, K, C.byref(img), stream) == 0
+    run = lambda: lib.afxk_gemm_nt_bank(A.data_ptr(), P, img, N, K, Cm.data_ptr(), N, M, 0, 0.0, stream)
+    for _ in range(40):
+        assert run() == 0, af.last_error()
+    torch.cuda.synchronize()
+    kk = 40
+    e0.record()
+    for _ in range(kk):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / kk
+    rows = torch.arange(0, M, M // 256, device=dev)
+    want = A[rows, :K].double() @ B[:, :K].double().T
+    gerr = ((Cm[rows].double() - want).abs() / want.abs().clamp_min(1e-300)).max().item()
+    lib.afxdev_free(img)
+    flop = 2.0 * M * N * K
+    blk = {"metric": "audio frames/sec (gammatone-128 dense bank, n_fft=2048 hop=512)", "value": clips * T / ms * 1e3, "unit": "frames/s",
+           "steps": k, "ms_per_step": ms, "dtype": "f32 (operands as three bf16 words each on the bf16 matrix cores, f32 accumulation)",
+           "workload": f"batched STFT -> dense gammatone-128 bank, {clips} x 30 s @16 kHz, n_fft=2048 hop=512 (the MFMA route north_star names)",
+           "kernels": "k_stft_mel_v2<STFT> (afxk_stft2k: spectrum rows) -> k_gemm_bank_bf16x3 (128 x 128 tiles, v_mfma_f32_32x32x16_bf16)",
+           "oracle_check": {"clip0_max_rel_err": err, "bar": 1e-5},
+           "roofline": {"bound": "mfma", "kernel": "k_gemm_bank_bf16x3", "kernel_us": us, "shape": [M, N, K],
+                        "achieved": 6.0 * flop / us / 1e6, "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * flop / us / 1e6 / 2500.0,
+                        "f32_equivalent_tflops": flop / us / 1e6, "products_per_f32_product": 6,
+                        "elementwise_err_vs_f64": gerr,
+                        "mfma_busy": 0.495, "mfma_busy_source": "profiles/r06_rocprofv3_dense.txt (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))",
+                        "note": "bound by the registers' operand fill rate at a 64 x 64 wave tile (profiles/r06_dense.txt (c)), not by the matrix pipe"}}
+    return blk
+
+
 def device_info(torch, dev):
     """what ran the numbers: name / arch / CU count / PCI bus id from the runtime, power cap and temperature from rocm-smi
     when it answers within a few seconds (never a reason to lose the line)"""
@@ -776,6 +863,12 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:  # never lose the headline line to a secondary configuration
                     out["secondary"][f"cfg{cfg}"] = {"error": repr(e)}
+        if world == 1 and a.config == 2 and not dry and not a.no_secondary:
+            try:  # the dense filter-bank route and its MFMA product (a few seconds; never a reason to lose the line)
+                out["dense_bank"] = dense_bank_block(torch, af, dev, check=not a.no_check)
+            except Exception as e:
+                out["dense_bank"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
         if world == 1 and a.config == 2 and not dry and not a.no_legacy:
             # the reference's own published benchmark through its unmodified wrapper + this library (host pointers, one
             # clip per call, PCIe inside the clock) -- a fresh interpreter, after everything else

@@ -484,3 +484,34 @@ def test_dense_bank_at_the_headline_shape(rt, dt):
             os.environ.pop("AFX_SCRATCH_MB", None)
         else:
             os.environ["AFX_SCRATCH_MB"] = old
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("hop,dt,num,extra", [(256, 0, 128, 51), (1024, 1, 128, 50), (300, 0, 40, 7), (512, 0, 12, 1)])
+def test_dense_bank_rows_from_the_headline_transform(hop, dt, num, extra):
+    """round 6: the dense route's two launches at the shapes around the headline one -- afxk_stft2k (k_stft_mel_v2 <STFT>) with the
+    register re-use of overlapping frames at hop N / 8 and N / 2 and whole-frame fetches from any sample (hop 300, clips an odd
+    number of floats apart), power and magnitude rows; k_gemm_bank_bf16x3 on banks of 128, 40 and 12 rows (column padding of the
+    tile, the k tail: 1025 = 64 x 16 + 1), more than one chunk (AFX_SCRATCH_MB=1) -- against the reference's double-accumulating
+    __mdot1 (flux_vector.c:55-86) on the reference's own spectrum (stft_algorithm.c:717-803)"""
+    xs = np.stack([cases.noise(90 + i, 16000 + extra) for i in range(3)])
+    r = ref.RefBFT(num, 11, samplate=16000, low_fre=50.0, high_fre=7000.0, window_type=1, slide_length=hop,
+                   scale_type=4, style_type=2, normal_type=0, data_type=dt)
+    r.set_result_type(1)
+    o = af.BFT(num, radix2_exp=11, samplate=16000, low_fre=50.0, high_fre=7000.0, slide_length=hop,
+               scale_type=af.SpectralFilterBankScaleType.ERB, style_type=af.SpectralFilterBankStyleType.GAMMATONE,
+               data_type=af.SpectralDataType(dt))
+    assert o.fused_plan_kind() == 0
+    old = os.environ.get("AFX_SCRATCH_MB")
+    try:
+        os.environ["AFX_SCRATCH_MB"] = "1"
+        got = o.bft_batch(xs, result_type=1)
+    finally:
+        if old is None:
+            os.environ.pop("AFX_SCRATCH_MB", None)
+        else:
+            os.environ["AFX_SCRATCH_MB"] = old
+    for i in range(3):
+        re, _ = r.bft(xs[i])
+        assert_parity(got[i], re, TOL, f"gammatone-{num} hop {hop} dt{dt} clip{i}")
+
