@@ -156,6 +156,9 @@ typedef struct {
     long long outStride;
 } AfxIstftArgs;
 int afxk_istft(const AfxIstftArgs *a, void *stream);
+/* n_fft 2048: one wave per frame (the inverse as ONE forward real transform of re + im of the Hermitian part), overlap-add in an
+ * LDS ring, no frame scratch (a->frames / a->twiddle are not read); AFX_ERR_UNSUPPORTED: not its case -- run afxk_istft */
+int afxk_istft_fused(const AfxIstftArgs *a, void *stream);
 
 /* afx_spectral.hip: per-bin value (AFX_SPEC_*) of the bins [binLo, binLo+binCount) of a complex
  * spectrum re/im [rows, rowPitch] -> out [rows, binCount] (+ out2 for COMPLEX / SQUARE) */

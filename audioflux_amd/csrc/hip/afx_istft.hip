@@ -17,6 +17,7 @@
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_ldsfft.h"
+#include "afx_wavefft2048.h"
 
 namespace {
 
@@ -62,7 +63,219 @@ __global__ void k_istft_ola(AfxIstftArgs a) {
 
 }  // namespace
 
+// ---- n_fft 2048: one wave per frame, overlap-add in the LDS, no frame scratch (round 6) -----------------------------------
+//
+// The inverse transform of a frame is ONE forward real transform (afx_wavefft2048.h, the function the forward kernels run): with
+// Xs = the Hermitian part of the given bins (what the real part of the reference's complex inverse keeps, stft_algorithm.c:304-409),
+//     u[k] = Re Xs[k] + Im Xs[k] = (re[k] + re[N-k] + im[k] - im[N-k]) / 2      (a real sequence),   U = FFT(u):
+//     x[n] = (Re U[n] + Im U[n]) / N,   x[N-n] = (Re U[n] - Im U[n]) / N,   0 <= n <= N/2
+// (the cosine sums of the even part and the sine sums of the odd part, each once).  A lane holds u[2n], u[2n+1], n = 64 n1 + lane;
+// the mirrored bins N - 2n - 1 are element .y of register 15 - n1 in lane 63 - lane, N - 2n element .x of register 15 - n1 in lane
+// 64 - lane (lane 0: its own register 16 - n1): two cross-lane reads per plane instead of reversed loads.
+// Overlap-add: a wave walks a run of consecutive frames of one clip (the ceil(N / hop) - 1 frames before its run first: their tails
+// reach into it) with a ring of N floats in the LDS: a sample enters the ring with the caller's value of out[] (the reference adds
+// to what is there), takes the frames in ascending order -- the order of the reference's scatter loop (:378-386) and of k_istft_ola,
+// so the float32 sums round the same way -- and leaves it, divided by the window-power sum (:389-396), when frame i has been
+// added to [i hop, (i + 1) hop).  Per frame 8 N bytes in and 4 hop out (+ 4 hop of out[] read): the [frames, N] scratch round trip
+// (8 N bytes) and the second launch are gone.
+namespace {
+
+constexpr int IW = 7;  // waves per workgroup: 25 KB of tables (window w^e, twiddles) + <= 8 KB of window-power sums + 7 x 16.5 KB (exchange image + ring)
+
+__global__ __launch_bounds__(IW * 64) void k_istft_w2048(AfxIstftArgs a, const float2 *__restrict__ tab, int framesPerRun, int runsPerClip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = 2048;
+    float *win1 = reinterpret_cast<float *>(smem_raw);  // [N] synthesis window w^e
+    const float *__restrict__ win2 = a.win2;             // w^(e+1): read at the clip's ends only
+    v2 *tabTw = reinterpret_cast<v2 *>(win1 + N);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2 *ex = tabTw + afxw::TAB_F2 + wave * afxw::EX_F2;
+    float *ring = reinterpret_cast<float *>(tabTw + afxw::TAB_F2 + IW * afxw::EX_F2) + wave * N;
+    // window-power sum of a sample every covering frame of which exists (N <= j, j / hop <= T - 1): a function of j mod hop, added
+    // in the order of k_istft_ola's loop (ascending frames = descending window positions)
+    float *nrmTab = ring + (IW - wave) * N;              // [hop], behind the last wave's ring
+    for (int i = threadIdx.x; i < N; i += IW * 64) win1[i] = a.win1[i];
+    for (int i = threadIdx.x; i < afxw::TAB_F2; i += IW * 64) tabTw[i] = v2{tab[i].x, tab[i].y};
+    for (int t = threadIdx.x; t < a.hop; t += IW * 64) {
+        float sum = 0.f;
+        for (int k = t + ((N - 1 - t) / a.hop) * a.hop; k >= 0; k -= a.hop) sum += win2[k];
+        nrmTab[t] = sum;
+    }
+    __syncthreads();
+    const afxw::Tables tb = {tabTw, tabTw + afxw::TAB_TW1_F2, tabTw + afxw::TAB_TW1_F2 + afxw::TAB_TW2_F2};
+
+    const long long run = (long long)blockIdx.x * IW + wave;
+    if (run >= (long long)a.batch * runsPerClip) return;
+    const int b = (int)(run / runsPerClip), T = a.timeLength, H = a.hop;
+    const int f0 = (int)(run - (long long)b * runsPerClip) * framesPerRun;
+    const int f1 = f0 + framesPerRun < T ? f0 + framesPerRun : T;
+    const int halo = (N - 1) / H;
+    const int fs = f0 > halo ? f0 - halo : 0;
+    const long long outLen = (long long)(T - 1) * H + N;
+    const long long ownLo = (long long)f0 * H, ownHi = f1 == T ? outLen : (long long)f1 * H;
+    float *out = a.out + (long long)b * a.outStride;
+    const float scale = 0.5f / (float)N;
+    const bool lane0 = lane == 0;
+
+    // samples that enter the ring with a frame: the caller's values where this wave will store, zeros elsewhere
+    auto entering = [&](long long j) { return (j >= ownLo && j < ownHi) ? out[j] : 0.f; };
+    for (int t = lane; t < N; t += 64) ring[((long long)fs * H + t) & (N - 1)] = entering((long long)fs * H + t);
+    // the bins of the frame about to be transformed; the next frame's are requested behind the transform, under the overlap-add
+    v2 r[16], m[16];
+    auto fetch = [&](int i) {
+        const v2 *re2 = reinterpret_cast<const v2 *>(a.re + ((long long)b * T + i) * N);
+        const v2 *im2 = reinterpret_cast<const v2 *>(a.im + ((long long)b * T + i) * N);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            r[n1] = re2[64 * n1 + lane];
+            m[n1] = im2[64 * n1 + lane];
+        }
+    };
+    fetch(fs);
+    const bool shortHop = H <= 512;  // the samples entering with the next frame fit eight registers per lane: requested a frame ahead
+
+    for (int i = fs; i < f1; ++i) {
+        const long long j0 = (long long)i * H;
+        float nxt[8];
+        if (shortHop && i + 1 < f1) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) nxt[t] = lane + 64 * t < H ? entering(j0 + N + lane + 64 * t) : 0.f;
+        }
+        // 2. the frame's bins -> u
+        v2 v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            // mirrors: .y from lane 63 - lane, .x from lane 64 - lane (lane 0: own register 16 - n1, bin N = bin 0 for n1 = 0)
+            const float ry = __shfl(r[15 - n1].y, 63 - lane, 64), my = __shfl(m[15 - n1].y, 63 - lane, 64);
+            float rx = __shfl(r[15 - n1].x, (64 - lane) & 63, 64), mx = __shfl(m[15 - n1].x, (64 - lane) & 63, 64);
+            if (lane0) {
+                rx = r[n1 == 0 ? 0 : 16 - n1].x;
+                mx = m[n1 == 0 ? 0 : 16 - n1].x;
+            }
+            v[n1] = v2{(r[n1].x + rx) + (m[n1].x - mx), (r[n1].y + ry) + (m[n1].y - my)};
+        }
+        afxw::Bins bn;
+        afxw::rfft2048(v, ex, tb, lane, bn);
+        if (i + 1 < f1) fetch(i + 1);  // (behind the transform: in flight across it the 64 registers spill)
+        // 3. x[n] = (Re U[n] + Im U[n]) / N and its mirror, windowed, into the ring.  (The 0.5 of the Hermitian part rides in scale.)
+        // (every output index occurs once per frame, so the slots of a batch of contributions are distinct: its reads, then its
+        //  writes -- written one by one the compiler must order each read behind the previous write)
+        int at[16];
+        float val[16];
+        bool ok[16];
+        auto put = [&](int e, bool valid, int n, float x) {
+            ok[e] = valid;
+            at[e] = (int)((j0 + n) & (N - 1));
+            val[e] = valid ? (x * scale) * win1[n] : 0.f;
+        };
+        auto flush = [&](int cnt) {
+            float cur[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (e < cnt) cur[e] = ok[e] ? ring[at[e]] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (e < cnt && ok[e]) ring[at[e]] = cur[e] + val[e];
+        };
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * s + 256 * j, e = 4 * j;
+                const v2 X = bn.x[s][j], Y = bn.y[s][j];  // U[k], conj(U[1024 - k])
+                // lane 0, s = 0 holds k = 0, 256, 512, 768: the partners 768, 512, 256 are its own x slots -- only 1024 is new
+                const bool partner = !(lane0 && s == 0 && j > 0);
+                put(e, true, k, X.x + X.y);
+                put(e + 1, k > 0, (N - k) & (N - 1), X.x - X.y);
+                put(e + 2, partner, 1024 - k, Y.x - Y.y);
+                put(e + 3, partner && k > 0, (1024 + k) & (N - 1), Y.x + Y.y);
+            }
+            flush(16);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {  // bins 128 + 256 i and their partners 896 - 256 i (every lane computed them: lane 0 adds)
+            const int k = 128 + 256 * q, e = 4 * q;
+            put(e, lane0, k, bn.xc[q].x + bn.xc[q].y);
+            put(e + 1, lane0, N - k, bn.xc[q].x - bn.xc[q].y);
+            put(e + 2, lane0, 1024 - k, bn.yc[q].x - bn.yc[q].y);
+            put(e + 3, lane0, 1024 + k, bn.yc[q].x + bn.yc[q].y);
+        }
+        flush(8);
+        wave_lds_order();
+        // 4. samples no later frame reaches: [i hop, (i + 1) hop), everything to the clip's end behind its last frame
+        if (i >= f0) {
+            const int cnt = i == T - 1 ? N : H;
+            auto power = [&](long long j) {  // the window-power sum of sample j (k_istft_ola's loop; interior samples: the table)
+                if (j >= N && j / H <= T - 1) return nrmTab[(int)(j % H)];
+                long long iLo = j >= N ? (j - N) / H + 1 : 0, iHi = j / H;
+                if (iHi > T - 1) iHi = T - 1;
+                float nrm = 0.f;
+                for (long long q = iLo; q <= iHi; ++q) nrm += win2[(int)(j - q * H)];
+                return nrm;
+            };
+            for (int t0 = 0; t0 < cnt; t0 += 512) {  // eight samples per lane at a time: their reads first, then the stores
+                float acc[8], nrm[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + lane + 64 * u;
+                    acc[u] = t < cnt ? ring[(j0 + t) & (N - 1)] : 0.f;
+                    nrm[u] = t < cnt ? power(j0 + t) : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + lane + 64 * u;
+                    if (t < cnt) out[j0 + t] = acc[u] / (nrm[u] < 1e-6f ? 1.f : nrm[u]);
+                }
+            }
+        }
+        wave_lds_order();
+        // 1'. the next frame's new samples take the slots just stored
+        if (i + 1 < f1) {
+            if (shortHop) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (lane + 64 * t < H) ring[(j0 + N + lane + 64 * t) & (N - 1)] = nxt[t];
+            } else {
+                for (int t = lane; t < H; t += 64) ring[(j0 + N + t) & (N - 1)] = entering(j0 + N + t);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" const void *afxk_wave_tables(void);  // afx_stft.hip
+
+// AFX_ERR_UNSUPPORTED: not this kernel's case (afxk_istft then runs the two size-generic launches, which need a->frames)
+extern "C" int afxk_istft_fused(const AfxIstftArgs *a, void *stream) {
+    if (a->radix2Exp != 11 || a->hop < 1 || a->hop > 2048 || a->timeLength < 1 || (reinterpret_cast<uintptr_t>(a->re) & 7) ||
+        (reinterpret_cast<uintptr_t>(a->im) & 7))
+        return AFX_ERR_UNSUPPORTED;
+    const float2 *tab = static_cast<const float2 *>(afxk_wave_tables());
+    if (!tab) return AFX_ERR_UNSUPPORTED;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // runs of >= 32 frames (the frames before a run are transformed again for their tails: 3 at hop N / 4), two rounds of waves
+    const long long total = (long long)a->batch * a->timeLength;
+    long long fpr = (total + 2LL * cus * IW - 1) / (2LL * cus * IW);
+    if (fpr < 32) fpr = 32;
+    if (fpr > a->timeLength) fpr = a->timeLength;
+    const long long runsPerClip = (a->timeLength + fpr - 1) / fpr, runs = runsPerClip * a->batch;
+    const long long blocks = (runs + IW - 1) / IW;
+    if (blocks > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * 2048 + sizeof(float2) * (size_t)(afxw::TAB_F2 + IW * afxw::EX_F2) + sizeof(float) * 2048 * IW +
+                       sizeof(float) * (size_t)a->hop;
+    AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft_w2048), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_istft_w2048, dim3((unsigned)blocks), dim3(IW * 64), lds, (hipStream_t)stream, *a, tab, (int)fpr, (int)runsPerClip);
+    AFX_LAUNCH_CHECK("k_istft_w2048");
+    return AFX_OK;
+}
+
 extern "C" int afxk_istft(const AfxIstftArgs *a, void *stream) {
+    if (!a->frames) {
+        afxdev_set_error("istft: the size-generic kernels need the frame scratch");
+        return AFX_ERR_ARG;
+    }
     if (a->radix2Exp < 1 || a->radix2Exp > 14) {
         afxdev_set_error("istft: fftLength 2^%d is outside the supported 2..16384", a->radix2Exp);
         return AFX_ERR_UNSUPPORTED;

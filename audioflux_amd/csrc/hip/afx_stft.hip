@@ -378,6 +378,13 @@ const float2 *wave_tables() {
     return dTab[dev];
 }
 
+}  // namespace
+
+// the wave kernels' twiddle tables (afxw::TAB_F2 float2 + 1025 of W_4096) for the other translation units (afx_istft.hip)
+extern "C" const void *afxk_wave_tables(void) { return wave_tables(); }
+
+namespace {
+
 template <int R2, bool CPLX>
 int launch_stft_wave(const AfxStftArgs *a, const float2 *tab, long long frames, void *stream) {
     constexpr int N = 1 << R2;

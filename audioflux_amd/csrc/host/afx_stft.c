@@ -331,9 +331,6 @@ int stftObj_istftBatchDevice(STFTObj o, const float *dReal, const float *dImag, 
     o->lastStream = hipStream;
     o->lastStreamSet = 1;
     int st = sync_synthesis(o, type, hipStream);
-    if (st == AFX_OK)
-        st = afxdev_reserve((void **)&o->dFrames, &o->capFrames,
-                            sizeof(float) * (size_t)batch * nLength * o->fftLength);
     if (st != AFX_OK) return st;
     AfxIstftArgs a;
     memset(&a, 0, sizeof(a));
@@ -346,9 +343,16 @@ int stftObj_istftBatchDevice(STFTObj o, const float *dReal, const float *dImag, 
     a.twiddle = o->dTwiddle;
     a.win1 = o->dWin12;
     a.win2 = o->dWin12 + o->fftLength;
-    a.frames = o->dFrames;
     a.out = dData;
     a.outStride = dataStride;
+    /* n_fft 2048: one launch, overlap-add on the chip, no [frames, N] scratch */
+    if (!afxdev_no_fused()) {
+        st = afxk_istft_fused(&a, hipStream);
+        if (st != AFX_ERR_UNSUPPORTED) return st;
+    }
+    st = afxdev_reserve((void **)&o->dFrames, &o->capFrames, sizeof(float) * (size_t)batch * nLength * o->fftLength);
+    if (st != AFX_OK) return st;
+    a.frames = o->dFrames;
     return afxk_istft(&a, hipStream);
 }
 

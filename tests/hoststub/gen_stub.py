@@ -140,6 +140,8 @@ int afxk_stft(const AfxStftArgs *a, void *stream) {
     if (a->zcr) touch_write(a->zcr, rows, 1.f);
     return AFX_OK;
 }
+/* the one-launch form: not on this stand-in, so that the two-launch path (scratch sizes, footprints) stays under the sanitizers */
+int afxk_istft_fused(const AfxIstftArgs *a, void *stream) { (void)a; (void)stream; return AFX_ERR_UNSUPPORTED; }
 int afxk_istft(const AfxIstftArgs *a, void *stream) {
     (void)stream;
     const long long N = 1LL << a->radix2Exp, rows = (long long)a->batch * a->timeLength;
@@ -350,7 +352,7 @@ int afxk_melfused_kind(const void *plan) { return plan ? 1 : 0; }
 DONE = {"afxdev_ensure", "afxdev_last_error", "afxdev_set_error", "afxdev_error_count", "afxdev_report_failure", "afxdev_no_fused", "afxdev_cqt_f32", "afxdev_malloc", "afxdev_free",
         "afxdev_memset", "afxdev_h2d", "afxdev_d2h", "afxdev_d2d", "afxdev_stream_create", "afxdev_stream_destroy",
         "afxdev_reserve", "afxk_cqt_decimate", "afxk_cqt_octave", "afxk_cqt_octave_f16",
-        "afxk_cqt_chroma", "afxk_stft", "afxk_temporal", "afxk_istft", "afxk_spec_map", "afxk_row_post", "afxk_gemm_nt",
+        "afxk_cqt_chroma", "afxk_stft", "afxk_temporal", "afxk_istft", "afxk_istft_fused", "afxk_spec_map", "afxk_row_post", "afxk_gemm_nt",
         "afxk_xxcc_standard", "afxk_cwt_forward", "afxk_cwt_inverse", "afxk_cwt_small", "afxk_wsst_squeeze",
         "afxk_synsq_phase", "afxk_reassign", "afxk_cqt_deconv", "afxk_cepstrogram", "afxk_cepstrum_supported",
         "afxk_cepstrum", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run", "afxk_melfused_destroy",
