@@ -14,10 +14,15 @@
 // Both are HBM streaming kernels: per frame 8 N bytes in, 4 N out, then 4 N in and 4 hop out.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <cstdlib>
+#include <mutex>
+
 #include "afx_device.h"
 #include "afx_hipcheck.h"
 #include "afx_ldsfft.h"
 #include "afx_wavefft2048.h"
+#include "afx_wavefft_small.h"
 
 namespace {
 
@@ -242,15 +247,186 @@ __global__ __launch_bounds__(IW * 64) void k_istft_w2048(AfxIstftArgs a, const f
     }
 }
 
+// ---- n_fft 1024 / 512: the same scheme on the wave transforms of afx_wavefft_small.h (8 x 8 x 8 in eight registers, 4 x 4 x 4 x 4
+// in four).  Their bins come out once each: k = lane + 64 j < N / 4 with its partner N / 2 - k, N / 4 in every lane.
+constexpr int ISW = 12;  // waves per workgroup (1024: 12 x 9 KB of exchange image + ring, 11 KB of tables)
+
+template <class F>
+__global__ __launch_bounds__(ISW * 64) void k_istft_wsmall(AfxIstftArgs a, const float2 *__restrict__ tab, int framesPerRun, int runsPerClip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = F::N, NR = F::NR, NJ = F::NJ;
+    float *win1 = reinterpret_cast<float *>(smem_raw);
+    const float *__restrict__ win2 = a.win2;
+    v2 *tabTw = reinterpret_cast<v2 *>(win1 + N);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2 *ex = tabTw + F::TAB_F2 + wave * F::EX_F2;
+    float *ring = reinterpret_cast<float *>(tabTw + F::TAB_F2 + ISW * F::EX_F2) + wave * N;
+    float *nrmTab = ring + (ISW - wave) * N;
+    for (int i = threadIdx.x; i < N; i += ISW * 64) win1[i] = a.win1[i];
+    for (int i = threadIdx.x; i < F::TAB_F2; i += ISW * 64) tabTw[i] = v2{tab[i].x, tab[i].y};
+    for (int t = threadIdx.x; t < a.hop; t += ISW * 64) {
+        float sum = 0.f;
+        for (int k = t + ((N - 1 - t) / a.hop) * a.hop; k >= 0; k -= a.hop) sum += win2[k];
+        nrmTab[t] = sum;
+    }
+    __syncthreads();
+
+    const long long run = (long long)blockIdx.x * ISW + wave;
+    if (run >= (long long)a.batch * runsPerClip) return;
+    const int b = (int)(run / runsPerClip), T = a.timeLength, H = a.hop;
+    const int f0 = (int)(run - (long long)b * runsPerClip) * framesPerRun;
+    const int f1 = f0 + framesPerRun < T ? f0 + framesPerRun : T;
+    const int halo = (N - 1) / H;
+    const int fs = f0 > halo ? f0 - halo : 0;
+    const long long outLen = (long long)(T - 1) * H + N;
+    const long long ownLo = (long long)f0 * H, ownHi = f1 == T ? outLen : (long long)f1 * H;
+    float *out = a.out + (long long)b * a.outStride;
+    const float scale = 0.5f / (float)N;
+    const bool lane0 = lane == 0;
+    auto entering = [&](long long j) { return (j >= ownLo && j < ownHi) ? out[j] : 0.f; };
+    for (int t = lane; t < N; t += 64) ring[((long long)fs * H + t) & (N - 1)] = entering((long long)fs * H + t);
+    v2 r[NR], m[NR];
+    auto fetch = [&](int i) {
+        const v2 *re2 = reinterpret_cast<const v2 *>(a.re + ((long long)b * T + i) * N);
+        const v2 *im2 = reinterpret_cast<const v2 *>(a.im + ((long long)b * T + i) * N);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            r[q] = re2[64 * q + lane];
+            m[q] = im2[64 * q + lane];
+        }
+    };
+    fetch(fs);
+    for (int i = fs; i < f1; ++i) {
+        const long long j0 = (long long)i * H;
+        v2 v[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const float ry = __shfl(r[NR - 1 - q].y, 63 - lane, 64), my = __shfl(m[NR - 1 - q].y, 63 - lane, 64);
+            float rx = __shfl(r[NR - 1 - q].x, (64 - lane) & 63, 64), mx = __shfl(m[NR - 1 - q].x, (64 - lane) & 63, 64);
+            if (lane0) {
+                rx = r[q == 0 ? 0 : NR - q].x;
+                mx = m[q == 0 ? 0 : NR - q].x;
+            }
+            v[q] = v2{(r[q].x + rx) + (m[q].x - mx), (r[q].y + ry) + (m[q].y - my)};
+        }
+        if (i + 1 < f1) fetch(i + 1);
+        typename F::B bn;
+        F::rfft(v, ex, tabTw, lane, bn);
+        int at[4 * NJ + 2];
+        float val[4 * NJ + 2];
+        bool ok[4 * NJ + 2];
+        auto put = [&](int e, bool valid, int n, float x) {
+            ok[e] = valid;
+            at[e] = (int)((j0 + n) & (N - 1));
+            val[e] = valid ? (x * scale) * win1[n] : 0.f;
+        };
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = lane + 64 * j;
+            const v2 X = bn.x[j], Y = bn.y[j];  // U[k], conj(U[N / 2 - k])
+            put(4 * j, true, k, X.x + X.y);
+            put(4 * j + 1, k > 0, (N - k) & (N - 1), X.x - X.y);
+            put(4 * j + 2, true, N / 2 - k, Y.x - Y.y);
+            put(4 * j + 3, k > 0, (N / 2 + k) & (N - 1), Y.x + Y.y);
+        }
+        put(4 * NJ, lane0, N / 4, bn.xm.x + bn.xm.y);
+        put(4 * NJ + 1, lane0, 3 * N / 4, bn.xm.x - bn.xm.y);
+        float cur[4 * NJ + 2];
+#pragma unroll
+        for (int e = 0; e < 4 * NJ + 2; ++e) cur[e] = ok[e] ? ring[at[e]] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4 * NJ + 2; ++e)
+            if (ok[e]) ring[at[e]] = cur[e] + val[e];
+        wave_lds_order();
+        if (i >= f0) {
+            const int cnt = i == T - 1 ? N : H;
+            auto power = [&](long long j) {
+                if (j >= N && j / H <= T - 1) return nrmTab[(int)(j % H)];
+                long long iLo = j >= N ? (j - N) / H + 1 : 0, iHi = j / H;
+                if (iHi > T - 1) iHi = T - 1;
+                float nrm = 0.f;
+                for (long long q = iLo; q <= iHi; ++q) nrm += win2[(int)(j - q * H)];
+                return nrm;
+            };
+            for (int t0 = 0; t0 < cnt; t0 += 256) {
+                float acc[4], nrm[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + lane + 64 * u;
+                    acc[u] = t < cnt ? ring[(j0 + t) & (N - 1)] : 0.f;
+                    nrm[u] = t < cnt ? power(j0 + t) : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + lane + 64 * u;
+                    if (t < cnt) out[j0 + t] = acc[u] / (nrm[u] < 1e-6f ? 1.f : nrm[u]);
+                }
+            }
+        }
+        wave_lds_order();
+        if (i + 1 < f1)
+            for (int t = lane; t < H; t += 64) ring[(j0 + N + t) & (N - 1)] = entering(j0 + N + t);
+    }
+}
+
+// twiddle tables of the small wave transforms, one device copy per device and size (never freed)
+template <class F>
+const float2 *small_tables() {
+    static std::mutex mu;
+    static float2 *dTab[AFX_MAX_DEVICES] = {};
+    const int dev = afxdev_current_device();
+    if (dev < 0 || dev >= AFX_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dTab[dev]) {
+        float *h = static_cast<float *>(calloc(2 * F::TAB_F2, sizeof(float)));
+        if (!h) return nullptr;
+        F::fill_tables(h);
+        float2 *d = nullptr;
+        int st = afxdev_malloc(reinterpret_cast<void **>(&d), sizeof(float) * 2 * F::TAB_F2);
+        if (st == AFX_OK && hipMemcpy(d, h, sizeof(float) * 2 * F::TAB_F2, hipMemcpyHostToDevice) != hipSuccess) st = AFX_ERR_HIP;
+        free(h);
+        if (st != AFX_OK) {
+            afxdev_free(d);
+            return nullptr;
+        }
+        dTab[dev] = d;
+    }
+    return dTab[dev];
+}
+
+template <class F>
+int launch_istft_small(const AfxIstftArgs *a, void *stream) {
+    const float2 *tab = small_tables<F>();
+    if (!tab) return AFX_ERR_UNSUPPORTED;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long total = (long long)a->batch * a->timeLength;
+    long long fpr = (total + 2LL * cus * ISW - 1) / (2LL * cus * ISW);
+    if (fpr < 32) fpr = 32;
+    if (fpr > a->timeLength) fpr = a->timeLength;
+    const long long runsPerClip = (a->timeLength + fpr - 1) / fpr, runs = runsPerClip * a->batch;
+    const long long blocks = (runs + ISW - 1) / ISW;
+    if (blocks > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * F::N + sizeof(float2) * (size_t)(F::TAB_F2 + ISW * F::EX_F2) + sizeof(float) * F::N * ISW +
+                       sizeof(float) * (size_t)a->hop;
+    AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft_wsmall<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_istft_wsmall<F>, dim3((unsigned)blocks), dim3(ISW * 64), lds, (hipStream_t)stream, *a, tab, (int)fpr, (int)runsPerClip);
+    AFX_LAUNCH_CHECK("k_istft_wsmall");
+    return AFX_OK;
+}
+
 }  // namespace
 
 extern "C" const void *afxk_wave_tables(void);  // afx_stft.hip
 
 // AFX_ERR_UNSUPPORTED: not this kernel's case (afxk_istft then runs the two size-generic launches, which need a->frames)
 extern "C" int afxk_istft_fused(const AfxIstftArgs *a, void *stream) {
-    if (a->radix2Exp != 11 || a->hop < 1 || a->hop > 2048 || a->timeLength < 1 || (reinterpret_cast<uintptr_t>(a->re) & 7) ||
+    if (a->hop < 1 || a->hop > (1 << a->radix2Exp) || a->timeLength < 1 || (reinterpret_cast<uintptr_t>(a->re) & 7) ||
         (reinterpret_cast<uintptr_t>(a->im) & 7))
         return AFX_ERR_UNSUPPORTED;
+    if (a->radix2Exp == 10) return launch_istft_small<afxws::Fft1k>(a, stream);
+    if (a->radix2Exp == 9) return launch_istft_small<afxws::Fft512>(a, stream);
+    if (a->radix2Exp != 11) return AFX_ERR_UNSUPPORTED;
     const float2 *tab = static_cast<const float2 *>(afxk_wave_tables());
     if (!tab) return AFX_ERR_UNSUPPORTED;
     int dev = 0, cus = 256;

@@ -117,7 +117,8 @@ def test_custom_window_and_slide_length_switches():
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("r,hop", [(11, 512), (12, 1024), (11, 300), (12, 999), (13, 3000), (5, 8), (1, 1), (2, 1)])
+@pytest.mark.parametrize("r,hop", [(11, 512), (12, 1024), (11, 300), (12, 999), (13, 3000), (5, 8), (1, 1), (2, 1), (10, 256), (10, 300), (9, 128), (9, 77),
+                                   (11, 1024), (10, 512)])
 def test_stft_istft_match_compiled_reference_fresh_inputs(r, hop):
     n = 1 << r
     x = cases.noise(100 + r, max(6 * n + 17, 50))
@@ -157,6 +158,28 @@ def test_device_batch_calls_match_host_calls():
     torch.cuda.synchronize()
     S = (host[2][0] + 1j * host[2][1])[:, :513].T.astype(np.complex64)
     assert np.array_equal(y[2].cpu().numpy(), o.istft(S))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("r,hop", [(11, 512), (11, 300), (11, 1024), (10, 256), (10, 300), (9, 128), (9, 77)])
+def test_one_launch_istft_over_several_runs_matches_the_reference(r, hop):
+    """round 6: k_istft_w2048 / k_istft_wsmall cut a clip into runs of >= 32 frames, one wave each, and transform the frames before a
+    run again for their tails: clips of ~150 frames (five runs), a batch of two, both synthesis methods, against the compiled
+    reference clip by clip; hop N / 4, N / 2, hops that do not divide N"""
+    import torch
+    n = 1 << r
+    xs = np.stack([cases.noise(300 + 7 * r + i, 150 * hop + n) for i in range(2)])
+    rr = ref.RefSTFT(r, 1, hop)
+    o = af.STFT(radix2_exp=r, window_type=af.WindowType.HANN, slide_length=hop)
+    spec = [rr.stft(x) for x in xs]
+    re = torch.from_numpy(np.stack([s[0] for s in spec])).cuda()
+    im = torch.from_numpy(np.stack([s[1] for s in spec])).cuda()
+    for method in (0, 1):
+        y = o.istft_device(re, im, method_type=method).cpu().numpy()
+        for i in range(2):
+            want = rr.istft(spec[i][0], spec[i][1], method)
+            gn = restate.istft_norm(spec[i][0].shape[0], n, hop, rr.window(), method)
+            assert_istft_parity(y[i, :want.size], want, gn, f"one-launch istft r{r} hop{hop} m{method} clip{i}")
 
 
 def test_degenerate_inputs():
