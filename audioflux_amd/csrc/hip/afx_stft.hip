@@ -411,6 +411,7 @@ extern "C" int afxk_stft2k(const AfxStftArgs *a, void *stream);   // afx_melfuse
 extern "C" int afxk_stft4k(const AfxStftArgs *a, void *stream);   // afx_melfused4k2.hip
 extern "C" int afxk_stft1k(const AfxStftArgs *a, void *stream);   // afx_melfused1k.hip
 extern "C" int afxk_stft512(const AfxStftArgs *a, void *stream);  // afx_melfused512.hip
+extern "C" int afxk_stft256(const AfxStftArgs *a, void *stream);  // afx_stft256.hip
 
 extern "C" int afxk_temporal(const AfxStftArgs *a, void *stream);
 
@@ -447,9 +448,11 @@ extern "C" int afxk_stft(const AfxStftArgs *a, void *stream) {
         }
     }
     // n_fft 4096 (the wrapper's default), 1024, 512: the transform of that size's bank kernel storing its spectrum
-    // (afx_melfused4k2 / 1k / 512.hip), when every frame lies inside its clip; AFX_ERR_UNSUPPORTED = not its case
-    if ((a->radix2Exp == 12 || a->radix2Exp == 10 || a->radix2Exp == 9) && !a->bandStart && !afxdev_no_fused()) {
-        const int st = a->radix2Exp == 12 ? afxk_stft4k(&bins, stream) : a->radix2Exp == 10 ? afxk_stft1k(&bins, stream) : afxk_stft512(&bins, stream);
+    // (afx_melfused4k2 / 1k / 512.hip), 256: two frames per 256-point complex wave transform (afx_stft256.hip) -- when every frame
+    // lies inside its clip; AFX_ERR_UNSUPPORTED = not its case
+    if ((a->radix2Exp == 12 || a->radix2Exp == 10 || a->radix2Exp == 9 || a->radix2Exp == 8) && !a->bandStart && !afxdev_no_fused()) {
+        const int st = a->radix2Exp == 12 ? afxk_stft4k(&bins, stream) : a->radix2Exp == 10 ? afxk_stft1k(&bins, stream)
+                       : a->radix2Exp == 9 ? afxk_stft512(&bins, stream) : afxk_stft256(&bins, stream);
         if (st != AFX_ERR_UNSUPPORTED) return (st == AFX_OK && a->energy) ? afxk_temporal(a, stream) : st;
     }
     const int N = 1 << a->radix2Exp;

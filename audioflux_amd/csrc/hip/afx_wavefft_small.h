@@ -121,8 +121,11 @@ struct Fft512 {
 
     static __device__ __forceinline__ const v2 *tw3_of(const v2 *tab) { return tab + TW1_F2 + TW2_F2 + TW3_F2; }
 
-    static __device__ __forceinline__ void rfft(v2 (&v)[4], v2 *ex, const v2 *tab, int lane, B &o) {
-        const v2 *tw1 = tab, *tw2 = tab + TW1_F2, *tw3 = tw2 + TW2_F2, *tws = tw3 + TW3_F2;
+    // the 256-point complex transform alone: v[r] = z[64 r + lane] -> v[q] = Z[lane + 64 q], and the natural-order image Z[k] in
+    // ex[0 .. 255] (still needed by the caller: wave_lds_order() before `ex` is written again).  rfft = cfft + the real-input split;
+    // afx_stft256.hip packs TWO real frames into z (re = frame a, im = frame b) and separates their spectra from Z[k], Z[256 - k]
+    static __device__ __forceinline__ void cfft(v2 (&v)[4], v2 *ex, const v2 *tab, int lane) {
+        const v2 *tw1 = tab, *tw2 = tab + TW1_F2, *tw3 = tw2 + TW2_F2;
         const int hi4 = lane >> 4, mid = (lane >> 2) & 3, low = lane & 3;
         __builtin_amdgcn_s_setprio(1);
         // stage 1: over r, twiddle W_256^(lane d0); lane (a, b, c) -> row 16 d0 + 4 b + c, column a
@@ -161,6 +164,11 @@ struct Fft512 {
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) ex[lane + 64 * q2] = v[q2];
         wave_lds_order();
+    }
+
+    static __device__ __forceinline__ void rfft(v2 (&v)[4], v2 *ex, const v2 *tab, int lane, B &o) {
+        const v2 *tws = tab + TW1_F2 + TW2_F2 + TW3_F2;
+        cfft(v, ex, tab, lane);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const v2 zb = ex[(256 - lane - 64 * j) & 255];  // (lane 0, j = 0: Z[0] pairs with itself)

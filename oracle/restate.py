@@ -740,13 +740,16 @@ def reassign_scatter(Sh, vt, vf, amplitude=False, order=1):
     return out
 
 
-def reassign_allowance(Sh, vt, vf, thresh, c_rel=1e-5):
+def reassign_allowance(Sh, vt, vf, thresh, c_rel=1e-5, order=1):
     """per target cell: total magnitude of the coefficients whose target cell is not determined at
     float32 accuracy -- a coordinate within dv of a rounding boundary (dv = the coordinate shift a
     relative error c_rel * max|S| / |S| of the ratios S_dh/S_h, S_th/S_h produces: they scale the
     OFFSET from the coefficient's own cell), or |S|^2 within c_rel of the threshold (the
     coefficient then falls back to its own cell).  Each may land anywhere in the 3 x 3
-    neighbourhood of its nominal target or in its own cell; nothing else may differ."""
+    neighbourhood of its nominal target or in its own cell; nothing else may differ.
+    order > 1 (the bin index map iterated inside each frame, reassign_scatter): a coefficient whose FIRST target bin is the cell of an
+    undetermined coefficient of the same frame follows that coefficient's coin flip -- it is undetermined too, around the iterated
+    target (found on the device at n_fft 256: one coefficient with vf = 23.500000 moved the two that map onto bin 23 with it)."""
     Sh = np.asarray(Sh, np.complex128)
     t_len, f_len = Sh.shape
     mag = np.abs(Sh)
@@ -761,6 +764,14 @@ def reassign_allowance(Sh, vt, vf, thresh, c_rel=1e-5):
     amb = (near | edge) & np.isfinite(vt) & np.isfinite(vf)
     allow = np.zeros((t_len, f_len))
     it, jf = np.floor(vt + 0.5), np.floor(vf + 0.5)
+    if order > 1:
+        rows = np.arange(t_len)[:, None]
+        for _ in range(order - 1):
+            k = np.where(np.isfinite(jf), jf, -1).astype(np.int64)
+            ok = (k >= 0) & (k < f_len)
+            kc = np.clip(k, 0, f_len - 1)
+            amb = amb | (ok & amb[rows, kc])
+            jf = np.where(ok, jf[rows, kc], jf)
     for a in (-1, 0, 1):
         for b in (-1, 0, 1):
             r, c = it + a, jf + b

@@ -50,7 +50,7 @@ def test_reassign_matches_golden(name, gold):
     Sh, vt, vf = restated(c, x)
     assert_parity(a[2] + 1j * a[3], Sh, 1e-5, name + " stft output")
     got = a[0] if amp else a[0] + 1j * a[1]
-    n_diff = explained(got, want, Sh, vt, vf, c.get("thresh", 0.001), name)
+    n_diff = explained(got, want, Sh, vt, vf, c.get("thresh", 0.001), name, order=c.get("order", 1))
     assert n_diff < 0.005 * want.size
     # coefficients are moved, not created: total (signed) mass is that of the accepted sources
     if not amp and c.get("order", 1) == 1:

@@ -32,8 +32,8 @@ def restated(c, x):
     return S[0], vt, vf
 
 
-def explained(got, want, Sh, vt, vf, thresh, what):
-    allow, amb = restate.reassign_allowance(Sh, vt, vf, thresh)
+def explained(got, want, Sh, vt, vf, thresh, what, order=1):
+    allow, amb = restate.reassign_allowance(Sh, vt, vf, thresh, order=order)
     scale = np.abs(want).max()
     d = np.abs(np.asarray(got, np.complex128) - want)
     bad = d > allow + 1e-5 * scale
@@ -95,7 +95,7 @@ def test_restatement_explains_golden(name, gold):
     amp = c.get("result_type", 0) == 1
     out = restate.reassign_scatter(Sh, vt, vf, amp, c.get("order", 1))
     want = gold[f"{name}/re"] if amp else gold[f"{name}/re"] + 1j * gold[f"{name}/im"]
-    n_diff = explained(out, want, Sh, vt, vf, c.get("thresh", 0.001), name)
+    n_diff = explained(out, want, Sh, vt, vf, c.get("thresh", 0.001), name, order=c.get("order", 1))
     assert n_diff < 0.005 * want.size
 
 

@@ -118,7 +118,7 @@ def test_custom_window_and_slide_length_switches():
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("r,hop", [(11, 512), (12, 1024), (11, 300), (12, 999), (13, 3000), (5, 8), (1, 1), (2, 1), (10, 256), (10, 300), (9, 128), (9, 77),
-                                   (11, 1024), (10, 512)])
+                                   (11, 1024), (10, 512), (8, 64), (8, 100), (8, 256)])
 def test_stft_istft_match_compiled_reference_fresh_inputs(r, hop):
     n = 1 << r
     x = cases.noise(100 + r, max(6 * n + 17, 50))
