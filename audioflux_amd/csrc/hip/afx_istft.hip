@@ -85,7 +85,10 @@ __global__ void k_istft_ola(AfxIstftArgs a) {
 // (8 N bytes) and the second launch are gone.
 namespace {
 
-constexpr int IW = 7;  // waves per workgroup: 25 KB of tables (window w^e, twiddles) + <= 8 KB of window-power sums + 7 x 16.5 KB (exchange image + ring)
+#ifndef AFX_ISTFT_WAVES
+#define AFX_ISTFT_WAVES 7
+#endif
+constexpr int IW = AFX_ISTFT_WAVES;  // waves per workgroup: 25 KB of tables (window w^e, twiddles) + <= 8 KB of window-power sums + 7 x 16.5 KB (exchange image + ring)
 
 __global__ __launch_bounds__(IW * 64) void k_istft_w2048(AfxIstftArgs a, const float2 *__restrict__ tab, int framesPerRun, int runsPerClip) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
