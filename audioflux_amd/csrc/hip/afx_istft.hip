@@ -250,6 +250,146 @@ __global__ __launch_bounds__(IW * 64) void k_istft_w2048(AfxIstftArgs a, const f
     }
 }
 
+// ---- n_fft 4096 (the reference wrapper's default): the same scheme; U = the real transform of the 4096 values u[k] from the wave
+// transforms of its even and odd samples (afxw::combine4096, as the forward kernels do).  A lane holds u[4n .. 4n + 3], n = 64 n1 + lane:
+// the mirrors 4096 - 4n - c are element 0 of quad 1024 - n (lane 64 - lane; lane 0: its own register 16 - n1) for c = 0 and
+// elements 3, 2, 1 of quad 1023 - n (lane 63 - lane, register 15 - n1) for c = 1, 2, 3.
+constexpr int IW4 = 4;  // waves per workgroup: 16 KB window + 25 KB twiddles + <= 16 KB window-power sums + 4 x 24.5 KB (exchange image + ring)
+
+__global__ __launch_bounds__(IW4 * 64) void k_istft_w4096(AfxIstftArgs a, const float2 *__restrict__ tab, int framesPerRun, int runsPerClip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    constexpr int N = 4096, NT = afxw::TAB_F2 + 1032;  // the wave tables + W_4096^k, k <= 1024 (padded to a 16-byte multiple)
+    float *win1 = reinterpret_cast<float *>(smem_raw);
+    const float *__restrict__ win2 = a.win2;
+    v2 *tabTw = reinterpret_cast<v2 *>(win1 + N);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2 *ex = tabTw + NT + wave * afxw::EX_F2;
+    float *ring = reinterpret_cast<float *>(tabTw + NT + IW4 * afxw::EX_F2) + wave * N;
+    float *nrmTab = ring + (IW4 - wave) * N;
+    for (int i = threadIdx.x; i < N; i += IW4 * 64) win1[i] = a.win1[i];
+    for (int i = threadIdx.x; i < afxw::TAB_F2 + 1025; i += IW4 * 64) tabTw[i] = v2{tab[i].x, tab[i].y};
+    for (int t = threadIdx.x; t < a.hop; t += IW4 * 64) {
+        float sum = 0.f;
+        for (int k = t + ((N - 1 - t) / a.hop) * a.hop; k >= 0; k -= a.hop) sum += win2[k];
+        nrmTab[t] = sum;
+    }
+    __syncthreads();
+    const afxw::Tables tb = {tabTw, tabTw + afxw::TAB_TW1_F2, tabTw + afxw::TAB_TW1_F2 + afxw::TAB_TW2_F2};
+    const v2 *tabW4 = tabTw + afxw::TAB_F2;
+
+    const long long run = (long long)blockIdx.x * IW4 + wave;
+    if (run >= (long long)a.batch * runsPerClip) return;
+    const int b = (int)(run / runsPerClip), T = a.timeLength, H = a.hop;
+    const int f0 = (int)(run - (long long)b * runsPerClip) * framesPerRun;
+    const int f1 = f0 + framesPerRun < T ? f0 + framesPerRun : T;
+    const int halo = (N - 1) / H;
+    const int fs = f0 > halo ? f0 - halo : 0;
+    const long long outLen = (long long)(T - 1) * H + N;
+    const long long ownLo = (long long)f0 * H, ownHi = f1 == T ? outLen : (long long)f1 * H;
+    float *out = a.out + (long long)b * a.outStride;
+    const float scale = 0.5f / (float)N;
+    const bool lane0 = lane == 0;
+    auto entering = [&](long long j) { return (j >= ownLo && j < ownHi) ? out[j] : 0.f; };
+    for (int t = lane; t < N; t += 64) ring[((long long)fs * H + t) & (N - 1)] = entering((long long)fs * H + t);
+
+    for (int i = fs; i < f1; ++i) {
+        const long long j0 = (long long)i * H;
+        afxw::Bins be, bo;
+        {
+            // the frame's bins -> u: even samples (u[4n], u[4n + 2]) and odd samples (u[4n + 1], u[4n + 3]) of every quad
+            const v4 *re4 = reinterpret_cast<const v4 *>(a.re + ((long long)b * T + i) * N);
+            const v4 *im4 = reinterpret_cast<const v4 *>(a.im + ((long long)b * T + i) * N);
+            v4 r[16], m[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                r[n1] = re4[64 * n1 + lane];
+                m[n1] = im4[64 * n1 + lane];
+            }
+            v2 ve[16], vo[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const v4 rq = r[15 - n1], mq = m[15 - n1];
+                float r0 = __shfl(rq.x, (64 - lane) & 63, 64), m0 = __shfl(mq.x, (64 - lane) & 63, 64);
+                if (lane0) {
+                    r0 = r[n1 == 0 ? 0 : 16 - n1].x;
+                    m0 = m[n1 == 0 ? 0 : 16 - n1].x;
+                }
+                const float r1 = __shfl(rq.w, 63 - lane, 64), m1 = __shfl(mq.w, 63 - lane, 64);
+                const float r2 = __shfl(rq.z, 63 - lane, 64), m2 = __shfl(mq.z, 63 - lane, 64);
+                const float r3 = __shfl(rq.y, 63 - lane, 64), m3 = __shfl(mq.y, 63 - lane, 64);
+                ve[n1] = v2{(r[n1].x + r0) + (m[n1].x - m0), (r[n1].z + r2) + (m[n1].z - m2)};
+                vo[n1] = v2{(r[n1].y + r1) + (m[n1].y - m1), (r[n1].w + r3) + (m[n1].w - m3)};
+            }
+            afxw::rfft2048(ve, ex, tb, lane, be);
+            afxw::rfft2048(vo, ex, tb, lane, bo);
+        }
+        // x[n] = (Re U[n] + Im U[n]) / N and its mirror N - n, windowed, into the ring: 16 contributions at a time (distinct slots:
+        // their reads, then their writes)
+        int at[16];
+        float val[16];
+        bool ok[16];
+        int fill = 0;
+        auto flush = [&]() {
+            float cur[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cur[e] = ok[e] ? ring[at[e]] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (ok[e]) ring[at[e]] = cur[e] + val[e];
+        };
+        afxw::combine4096(be, bo, tabW4, lane, [&](int slot, v2 X) {
+            const int p = slot >> 2, rr = slot & 3;
+            const int kp = p < 8 ? lane + 64 * (p >> 2) + 256 * (p & 3) : 128 + 256 * (p - 8);
+            const int bin = afxw::bin4096(slot, lane);
+            // lane 0 at p < 4 holds kp = 0, 256, 512, 768: their partners 1024 -+ kp are its own slots of 4 - j (kp = 0: 1024 once);
+            // the positions 128 + 256 i are lane 0's alone
+            bool valid = p < 8 || lane0;
+            if (lane0 && p < 4 && p > 0 && rr >= 2) valid = false;
+            if (p < 8 && kp == 0 && rr == 3) valid = false;
+            const int e = 2 * (slot & 7);
+            ok[e] = valid;
+            at[e] = (int)((j0 + bin) & (N - 1));
+            val[e] = valid ? ((X.x + X.y) * scale) * win1[bin & (N - 1)] : 0.f;
+            const bool mirror = valid && bin > 0 && bin < 2048;
+            ok[e + 1] = mirror;
+            at[e + 1] = (int)((j0 + N - bin) & (N - 1));
+            val[e + 1] = mirror ? ((X.x - X.y) * scale) * win1[(N - bin) & (N - 1)] : 0.f;
+            if ((slot & 7) == 7) flush();
+            (void)fill;
+        });
+        wave_lds_order();
+        if (i >= f0) {
+            const int cnt = i == T - 1 ? N : H;
+            auto power = [&](long long j) {
+                if (j >= N && j / H <= T - 1) return nrmTab[(int)(j % H)];
+                long long iLo = j >= N ? (j - N) / H + 1 : 0, iHi = j / H;
+                if (iHi > T - 1) iHi = T - 1;
+                float nrm = 0.f;
+                for (long long q = iLo; q <= iHi; ++q) nrm += win2[(int)(j - q * H)];
+                return nrm;
+            };
+            for (int t0 = 0; t0 < cnt; t0 += 512) {
+                float acc[8], nrm[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + lane + 64 * u;
+                    acc[u] = t < cnt ? ring[(j0 + t) & (N - 1)] : 0.f;
+                    nrm[u] = t < cnt ? power(j0 + t) : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + lane + 64 * u;
+                    if (t < cnt) out[j0 + t] = acc[u] / (nrm[u] < 1e-6f ? 1.f : nrm[u]);
+                }
+            }
+        }
+        wave_lds_order();
+        if (i + 1 < f1)
+            for (int t = lane; t < H; t += 64) ring[(j0 + N + t) & (N - 1)] = entering(j0 + N + t);
+    }
+}
+
 // ---- n_fft 1024 / 512: the same scheme on the wave transforms of afx_wavefft_small.h (8 x 8 x 8 in eight registers, 4 x 4 x 4 x 4
 // in four).  Their bins come out once each: k = lane + 64 j < N / 4 with its partner N / 2 - k, N / 4 in every lane.
 constexpr int ISW = 12;  // waves per workgroup (1024: 12 x 9 KB of exchange image + ring, 11 KB of tables)
@@ -427,6 +567,25 @@ extern "C" int afxk_istft_fused(const AfxIstftArgs *a, void *stream) {
     if (a->hop < 1 || a->hop > (1 << a->radix2Exp) || a->timeLength < 1 || (reinterpret_cast<uintptr_t>(a->re) & 7) ||
         (reinterpret_cast<uintptr_t>(a->im) & 7))
         return AFX_ERR_UNSUPPORTED;
+    if (a->radix2Exp == 12) {
+        const float2 *tab4 = static_cast<const float2 *>(afxk_wave_tables());
+        if (!tab4 || (reinterpret_cast<uintptr_t>(a->re) & 15) || (reinterpret_cast<uintptr_t>(a->im) & 15)) return AFX_ERR_UNSUPPORTED;
+        int dev4 = 0, cus4 = 256;
+        if (hipGetDevice(&dev4) == hipSuccess) (void)hipDeviceGetAttribute(&cus4, hipDeviceAttributeMultiprocessorCount, dev4);
+        const long long total4 = (long long)a->batch * a->timeLength;
+        long long fpr4 = (total4 + 2LL * cus4 * IW4 - 1) / (2LL * cus4 * IW4);
+        if (fpr4 < 32) fpr4 = 32;
+        if (fpr4 > a->timeLength) fpr4 = a->timeLength;
+        const long long rpc4 = (a->timeLength + fpr4 - 1) / fpr4, blocks4 = (rpc4 * a->batch + IW4 - 1) / IW4;
+        if (blocks4 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+        const size_t lds4 = sizeof(float) * 4096 + sizeof(float2) * (size_t)(afxw::TAB_F2 + 1032 + IW4 * afxw::EX_F2) + sizeof(float) * 4096 * IW4 +
+                            sizeof(float) * (size_t)a->hop;
+        if (lds4 > 160 * 1024) return AFX_ERR_UNSUPPORTED;  // (hops beyond ~3000: the size-generic launches)
+        AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft_w4096), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        hipLaunchKernelGGL(k_istft_w4096, dim3((unsigned)blocks4), dim3(IW4 * 64), lds4, (hipStream_t)stream, *a, tab4, (int)fpr4, (int)rpc4);
+        AFX_LAUNCH_CHECK("k_istft_w4096");
+        return AFX_OK;
+    }
     if (a->radix2Exp == 10) return launch_istft_small<afxws::Fft1k>(a, stream);
     if (a->radix2Exp == 9) return launch_istft_small<afxws::Fft512>(a, stream);
     if (a->radix2Exp != 11) return AFX_ERR_UNSUPPORTED;
