@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) AFX_WAVES_PER_EU(2, 2) void k_gemm_bank_bf16x3
     const int wr = wave >> 1, wc = wave & 1;
     const long long m0 = (long long)blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
+    __builtin_assume(K >= 1);          // (the launcher's contract: the stage loop runs at least once)
     const int nk = (K + TK - 1) / TK;  // k-steps of the image
     const int ns = (nk + 1) / 2;       // stages: two k-steps of A between barriers
     // A loader: a thread takes quad `pq` (k = 32 s + 4 pq .. + 3) of rows lr + 32 j, j < 4 -- eight lanes cover one 128-byte line
@@ -433,7 +434,20 @@ __global__ __launch_bounds__(256) AFX_WAVES_PER_EU(2, 2) void k_gemm_bank_bf16x3
             if (!(AFX_KO_GEMM & 4)) __syncthreads();
         }
     }
-    VM_WAIT_N(0);  // the rings' last loads land in registers the epilogue may use
+    // The rings' last loads (behind the last k-step: clamped, never used) are still in flight, and nothing the compiler can see keeps
+    // it from handing their registers to the epilogue's address arithmetic AHEAD of this hand-written wait -- met on the device: an
+    // epilogue variant whose first instructions were scheduled before the wait returned errors of 0.3-0.6.  The pins behind the wait
+    // keep every ring register alive up to it.
+    VM_WAIT_N(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PIN(ra[s][j]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int w = 0; w < 3; ++w) PIN(rb[s][t][w]);
+    }
 
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)

@@ -185,3 +185,49 @@ def test_no_instruction_touches_a_register_whose_hand_issued_load_is_in_flight(t
                 body.append(re.sub(r"^\s*[0-9a-fA-F]+:\s+", "", line) if re.match(r"^\s*[0-9a-fA-F]+:\s", line) else line)
     assert checked >= 21, checked
     assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="no llvm-objdump in this image")
+def test_the_gemm_rings_stay_untouched_until_their_final_wait(tmp_path):
+    """k_gemm_bank_bf16x3 leaves its loop with loads in flight whose values nobody uses (behind the last k-step): to the compiler
+    their destination registers are free, and an epilogue whose first instructions it scheduled ahead of the hand-written
+    `s_waitcnt vmcnt(0)` returned wrong values on the device (the linear scanner above starts afresh behind a branch and cannot see
+    it).  The pins behind that wait keep the rings alive: between the epilogue's label and the wait no instruction may write a
+    register any global load of the kernel targets."""
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([OBJDUMP, "--offloading", lib], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = sorted(f for f in os.listdir(tmp_path) if "amdgcn" in f and "gfx950" in f)
+    found = 0
+    for f in objs:
+        dis = subprocess.run([OBJDUMP, "-d", "--demangle", str(tmp_path / f)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        sym, body = None, []
+        for line in dis.splitlines() + ["<end>:"]:
+            if line.endswith(">:"):
+                if sym and "k_gemm_bank_bf16x3" in sym:
+                    found += 1
+                    ins = [re.sub(r"^\s*[0-9a-fA-F]+:\s+", "", l).split("//")[0].strip() for l in body]
+                    ring = set()
+                    for i in ins:
+                        if i.startswith("global_load_dwordx4"):
+                            ring |= _regs(i.split(None, 1)[1].split(",")[0])
+                    assert len(ring) >= 80, len(ring)  # 2 x 4 A quads + 2 x 6 bank fragments of four registers
+                    waits = [n for n, i in enumerate(ins) if i.startswith("s_waitcnt") and "vmcnt(0)" in i]
+                    assert waits, "no final drain of the rings"
+                    last = waits[-1]
+                    start = last
+                    while start > 0 and not ins[start - 1].startswith(("s_cbranch", "s_branch", "s_barrier")):
+                        start -= 1
+                    early = []
+                    for i in ins[start:last]:
+                        if not i or i.startswith("s_"):
+                            continue
+                        dst = i.split(None, 1)[1].split(",")[0] if " " in i else ""
+                        if _regs(dst) & ring:
+                            early.append(i[:90])
+                    assert not early, early[:5]
+                sym, body = line.split("<", 1)[-1][:-2], []
+            elif sym:
+                body.append(line)
+    assert found == 1, found
+
