@@ -487,12 +487,14 @@ def test_dense_bank_at_the_headline_shape(rt, dt):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("hop,dt,num,extra", [(256, 0, 128, 51), (1024, 1, 128, 50), (300, 0, 40, 7), (512, 0, 12, 1)])
-def test_dense_bank_rows_from_the_headline_transform(hop, dt, num, extra):
+@pytest.mark.parametrize("hop,dt,num,extra,norm", [(256, 0, 128, 51, None), (1024, 1, 128, 50, None), (300, 0, 40, 7, None), (512, 0, 12, 1, None),
+                                                    (512, 0, 128, 3, 0.6), (256, 1, 40, 2, 0.7)])
+def test_dense_bank_rows_from_the_headline_transform(hop, dt, num, extra, norm):
     """round 6: the dense route's two launches at the shapes around the headline one -- afxk_stft2k (k_stft_mel_v2 <STFT>) with the
     register re-use of overlapping frames at hop N / 8 and N / 2 and whole-frame fetches from any sample (hop 300, clips an odd
     number of floats apart), power and magnitude rows; k_gemm_bank_bf16x3 on banks of 128, 40 and 12 rows (column padding of the
-    tile, the k tail: 1025 = 64 x 16 + 1), more than one chunk (AFX_SCRATCH_MB=1) -- against the reference's double-accumulating
+    tile, the k tail: 1025 = 64 x 16 + 1), more than one chunk (AFX_SCRATCH_MB=1), the norm exponent on the power rows (the kernel's
+    |S|^2p map) and on magnitude banks (the product's power-law epilogue) -- against the reference's double-accumulating
     __mdot1 (flux_vector.c:55-86) on the reference's own spectrum (stft_algorithm.c:717-803)"""
     xs = np.stack([cases.noise(90 + i, 16000 + extra) for i in range(3)])
     r = ref.RefBFT(num, 11, samplate=16000, low_fre=50.0, high_fre=7000.0, window_type=1, slide_length=hop,
@@ -502,6 +504,9 @@ def test_dense_bank_rows_from_the_headline_transform(hop, dt, num, extra):
                scale_type=af.SpectralFilterBankScaleType.ERB, style_type=af.SpectralFilterBankStyleType.GAMMATONE,
                data_type=af.SpectralDataType(dt))
     assert o.fused_plan_kind() == 0
+    if norm is not None:
+        r.set_norm(norm)
+        o.set_data_norm_value(norm)
     old = os.environ.get("AFX_SCRATCH_MB")
     try:
         os.environ["AFX_SCRATCH_MB"] = "1"
