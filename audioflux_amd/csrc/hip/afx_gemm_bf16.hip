@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt128_bf16x3(const float *__res
 // knock-out table prices the A loads at 35 % and the fragment loads at 30 % of the launch (neither alone: 203 us = the MFMAs'
 // own 190), LDS stores and the split at 9-11 % each, the barrier at nothing.  A 64 x 64 wave tile takes 12 KB of operands into
 // registers per 24 MFMAs -- 62 bytes per cycle and CU against 64 from the vector memory pipe and 128 from the LDS, whichever
-// mix serves them (fragments through the LDS measured the same: 417 us).  Past this: 64 x 128 wave tiles (128 accumulators, one
-// wave per SIMD) with loader waves beside them.
+// mix serves them (fragments through the LDS measured the same: 417 us).  Two further forms measured slower and reverted
+// (profiles/r06_dense.txt (c'), (c'')): 128 x 64 wave tiles at one wave per SIMD (474 us), loader waves beside multiplying waves (463 us).
 // Knock-out measurement builds (tools/build_variant.sh kog<mask> -DAFX_KO_GEMM=<mask> afx_gemm_bf16; results WRONG, timing only):
 // 1 A quads not loaded, 2 bank fragments not loaded, 4 no barrier, 8 A words not stored to the LDS, 16 split arithmetic dropped,
 // 32 A fragments not read from the LDS, 64 no MFMAs, 128 every workgroup reads the rows of tile 0 (cache hits) (profiles/r06_dense.txt)
