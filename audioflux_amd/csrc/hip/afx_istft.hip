@@ -512,6 +512,124 @@ __global__ __launch_bounds__(ISW * 64) void k_istft_wsmall(AfxIstftArgs a, const
     }
 }
 
+// ---- n_fft 256: TWO frames per 256-point complex wave transform (the inverse of afx_stft256.hip's trick).  With As, Bs the Hermitian
+// parts of the bins of two consecutive frames a, b:  x_a + i x_b = IFFT(As + i Bs) = conj(FFT(conj(As + i Bs))) / N, and
+// conj(As + i Bs)[k] = (Re As - Im Bs, -Im As - Re Bs).  The transform's natural-order output gives sample n = lane + 64 q of both frames
+// in one lane: frame a is added to the ring, then frame b one hop further -- ascending frames, as everywhere.
+__global__ __launch_bounds__(ISW * 64) void k_istft_w256(AfxIstftArgs a, const float2 *__restrict__ tab, int framesPerRun, int runsPerClip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    typedef afxws::Fft512 F;
+    constexpr int N = 256;
+    float *win1 = reinterpret_cast<float *>(smem_raw);
+    const float *__restrict__ win2 = a.win2;
+    v2 *tabTw = reinterpret_cast<v2 *>(win1 + N);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2 *ex = tabTw + F::TAB_F2 + wave * F::EX_F2;
+    float *ring = reinterpret_cast<float *>(tabTw + F::TAB_F2 + ISW * F::EX_F2) + wave * N;
+    float *nrmTab = ring + (ISW - wave) * N;
+    for (int i = threadIdx.x; i < N; i += ISW * 64) win1[i] = a.win1[i];
+    for (int i = threadIdx.x; i < F::TAB_F2; i += ISW * 64) tabTw[i] = v2{tab[i].x, tab[i].y};
+    for (int t = threadIdx.x; t < a.hop; t += ISW * 64) {
+        float sum = 0.f;
+        for (int k = t + ((N - 1 - t) / a.hop) * a.hop; k >= 0; k -= a.hop) sum += win2[k];
+        nrmTab[t] = sum;
+    }
+    __syncthreads();
+
+    const long long run = (long long)blockIdx.x * ISW + wave;
+    if (run >= (long long)a.batch * runsPerClip) return;
+    const int b = (int)(run / runsPerClip), T = a.timeLength, H = a.hop;
+    const int f0 = (int)(run - (long long)b * runsPerClip) * framesPerRun;
+    const int f1 = f0 + framesPerRun < T ? f0 + framesPerRun : T;
+    const int halo = (N - 1) / H;
+    const int fs = f0 > halo ? f0 - halo : 0;
+    const long long outLen = (long long)(T - 1) * H + N;
+    const long long ownLo = (long long)f0 * H, ownHi = f1 == T ? outLen : (long long)f1 * H;
+    float *out = a.out + (long long)b * a.outStride;
+    const float scale = 0.5f / (float)N;
+    const bool lane0 = lane == 0;
+    auto entering = [&](long long j) { return (j >= ownLo && j < ownHi) ? out[j] : 0.f; };
+    for (int t = lane; t < N; t += 64) ring[((long long)fs * H + t) & (N - 1)] = entering((long long)fs * H + t);
+    auto power = [&](long long j) {
+        if (j >= N && j / H <= T - 1) return nrmTab[(int)(j % H)];
+        long long iLo = j >= N ? (j - N) / H + 1 : 0, iHi = j / H;
+        if (iHi > T - 1) iHi = T - 1;
+        float nrm = 0.f;
+        for (long long q = iLo; q <= iHi; ++q) nrm += win2[(int)(j - q * H)];
+        return nrm;
+    };
+    // one frame's samples (x[q] = sample lane + 64 q) into the ring, its finished samples out, the next frame's new samples in
+    auto overlap_add = [&](int i, const float (&x)[4]) {
+        const long long j0 = (long long)i * H;
+        float cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = ring[(j0 + lane + 64 * q) & (N - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[(j0 + lane + 64 * q) & (N - 1)] = cur[q] + (x[q] * scale) * win1[lane + 64 * q];
+        wave_lds_order();
+        if (i >= f0) {
+            const int cnt = i == T - 1 ? N : H;
+            float acc[4], nrm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = lane + 64 * u;
+                acc[u] = t < cnt ? ring[(j0 + t) & (N - 1)] : 0.f;
+                nrm[u] = t < cnt ? power(j0 + t) : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = lane + 64 * u;
+                if (t < cnt) out[j0 + t] = acc[u] / (nrm[u] < 1e-6f ? 1.f : nrm[u]);
+            }
+        }
+        wave_lds_order();
+        if (i + 1 < f1)
+            for (int t = lane; t < H; t += 64) ring[(j0 + N + t) & (N - 1)] = entering(j0 + N + t);
+        wave_lds_order();
+    };
+
+    for (int i = fs; i < f1; i += 2) {
+        const int ib = i + 1 < f1 ? i + 1 : i;  // an odd run: the last frame rides twice, added once
+        const float *ra = a.re + ((long long)b * T + i) * N, *ia = a.im + ((long long)b * T + i) * N;
+        const float *rb = a.re + ((long long)b * T + ib) * N, *ib_ = a.im + ((long long)b * T + ib) * N;
+        float are[4], aim[4], bre[4], bim[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            are[r] = ra[64 * r + lane];
+            aim[r] = ia[64 * r + lane];
+            bre[r] = rb[64 * r + lane];
+            bim[r] = ib_[64 * r + lane];
+        }
+        v2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // bin N - k, k = 64 r + lane: register 3 - r of lane 64 - lane (lane 0: its own register 4 - r; r = 0: bin 0 itself)
+            const int src = (64 - lane) & 63;
+            float mar = __shfl(are[3 - r], src, 64), mai = __shfl(aim[3 - r], src, 64);
+            float mbr = __shfl(bre[3 - r], src, 64), mbi = __shfl(bim[3 - r], src, 64);
+            if (lane0) {
+                mar = are[r == 0 ? 0 : 4 - r];
+                mai = aim[r == 0 ? 0 : 4 - r];
+                mbr = bre[r == 0 ? 0 : 4 - r];
+                mbi = bim[r == 0 ? 0 : 4 - r];
+            }
+            const float asr = are[r] + mar, asi = aim[r] - mai, bsr = bre[r] + mbr, bsi = bim[r] - mbi;  // 2 x the Hermitian parts
+            v[r] = v2{asr - bsi, -asi - bsr};
+        }
+        F::cfft(v, ex, tabTw, lane);
+        __builtin_amdgcn_s_setprio(0);
+        wave_lds_order();  // (the natural-order image in `ex` is not needed: the lanes' registers hold their samples)
+        float xa[4], xb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xa[q] = v[q].x;
+            xb[q] = -v[q].y;
+        }
+        overlap_add(i, xa);
+        if (ib != i) overlap_add(ib, xb);
+    }
+}
+
 // twiddle tables of the small wave transforms, one device copy per device and size (never freed)
 template <class F>
 const float2 *small_tables() {
@@ -588,6 +706,24 @@ extern "C" int afxk_istft_fused(const AfxIstftArgs *a, void *stream) {
     }
     if (a->radix2Exp == 10) return launch_istft_small<afxws::Fft1k>(a, stream);
     if (a->radix2Exp == 9) return launch_istft_small<afxws::Fft512>(a, stream);
+    if (a->radix2Exp == 8) {
+        typedef afxws::Fft512 F8;
+        const float2 *tab8 = small_tables<F8>();
+        if (!tab8) return AFX_ERR_UNSUPPORTED;
+        int dev8 = 0, cus8 = 256;
+        if (hipGetDevice(&dev8) == hipSuccess) (void)hipDeviceGetAttribute(&cus8, hipDeviceAttributeMultiprocessorCount, dev8);
+        const long long total8 = (long long)a->batch * a->timeLength;
+        long long fpr8 = (total8 + 2LL * cus8 * ISW - 1) / (2LL * cus8 * ISW);
+        if (fpr8 < 64) fpr8 = 64;
+        if (fpr8 > a->timeLength) fpr8 = a->timeLength;
+        const long long rpc8 = (a->timeLength + fpr8 - 1) / fpr8, blocks8 = (rpc8 * a->batch + ISW - 1) / ISW;
+        if (blocks8 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
+        const size_t lds8 = sizeof(float) * 256 + sizeof(float2) * (size_t)(F8::TAB_F2 + ISW * F8::EX_F2) + sizeof(float) * 256 * ISW +
+                            sizeof(float) * (size_t)a->hop;
+        hipLaunchKernelGGL(k_istft_w256, dim3((unsigned)blocks8), dim3(ISW * 64), lds8, (hipStream_t)stream, *a, tab8, (int)fpr8, (int)rpc8);
+        AFX_LAUNCH_CHECK("k_istft_w256");
+        return AFX_OK;
+    }
     if (a->radix2Exp != 11) return AFX_ERR_UNSUPPORTED;
     const float2 *tab = static_cast<const float2 *>(afxk_wave_tables());
     if (!tab) return AFX_ERR_UNSUPPORTED;

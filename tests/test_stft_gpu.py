@@ -161,9 +161,9 @@ def test_device_batch_calls_match_host_calls():
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("r,hop", [(11, 512), (11, 300), (11, 1024), (10, 256), (10, 300), (9, 128), (9, 77), (12, 1024), (12, 999)])
+@pytest.mark.parametrize("r,hop", [(11, 512), (11, 300), (11, 1024), (10, 256), (10, 300), (9, 128), (9, 77), (12, 1024), (12, 999), (8, 64), (8, 100)])
 def test_one_launch_istft_over_several_runs_matches_the_reference(r, hop):
-    """round 6: k_istft_w2048 / _w4096 / k_istft_wsmall cut a clip into runs of >= 32 frames, one wave each, and transform the frames before a
+    """round 6: k_istft_w2048 / _w4096 / _w256 / k_istft_wsmall cut a clip into runs of >= 32 frames, one wave each, and transform the frames before a
     run again for their tails: clips of ~150 frames (five runs), a batch of two, both synthesis methods, against the compiled
     reference clip by clip; hop N / 4, N / 2, hops that do not divide N"""
     import torch
