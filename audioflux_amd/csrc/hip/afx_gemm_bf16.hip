@@ -196,14 +196,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt128_bf16x3(const float *__res
 //     FRAGMENT order: per column tile and k-step, for each column half wc, 32-column MFMA tile tj and word w, the 64 lanes' 16
 //     bytes in lane order.  A wave takes its B operands straight from memory into registers (six 1 KB loads per k-step,
 //     L2-resident: 787 KB for 128 x 1025) -- the bank never touches the LDS;
-//   * the float32 rows of A are requested FOUR k-steps ahead into a ring of registers, the bank fragments one k-step ahead,
-//     both by hand (afx_asm.h) and waited for by count: the compiler's own s_waitcnt placement drains every older load at the
-//     loop header (a prefetch distance of one k-step whatever the source says);
+//   * the float32 rows of A are requested a whole stage (two k-steps) ahead of their split -- three ahead of their MFMAs -- into a
+//     ring of registers, the bank fragments one k-step ahead, both by hand (afx_asm.h) and waited for by count: the compiler's own
+//     s_waitcnt placement drains every older load at the loop header (a prefetch distance of one k-step whatever the source says);
 //   * A is split with integer arithmetic on the bit patterns (add / mask / subtract per word, half-word packs): exact,
 //     8 + 8 + 8 bits cover float32's 24, so the six-term product below is the same expansion as the converting split's;
 //   * the 24 MFMAs of a k-step keep their source order (the four tiles take turns: no accumulator is reused before its
-//     fourth successor) and the split of the NEXT k-step's rows is cut into 20 pieces of 3-5 vector instructions, one behind
-//     each MFMA: the scheduler is held to that order (sched_barrier), left alone it gathers the MFMAs into chains on one
+//     fourth successor) and the split of the NEXT stage's rows is cut into 20 pieces of 3-5 vector instructions per k-step, one
+//     behind each MFMA: the scheduler is held to that order (sched_barrier), left alone it gathers the MFMAs into chains on one
 //     accumulator and the vector work behind them;
 //   * tile, A fragments and epilogue as in k_gemm_nt128_bf16x3.
 // Measured (profiles/r06_dense.txt, 233 500 x 128 x 1025 per launch): 384-404 us by box = 152-160 TF/s float32-equivalent,
