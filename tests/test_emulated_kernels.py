@@ -29,10 +29,10 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
 INC = [f"-I{ROOT}/include", f"-I{ROOT}/audioflux_amd/csrc/hip", f"-I{ROOT}/audioflux_amd/csrc/host"]
 
 STANDIN_RENAMES = [f"-D{n}=standin_{n}" for n in ("afxk_cwt_td_fits", "afxk_cwt_td", "afxk_cqt_deconv", "afxk_melfused_variant", "afxk_melfused_create", "afxk_melfused_run",
-                                                     "afxk_melfused_destroy", "afxk_melfused_kind")]
+                                                     "afxk_melfused_destroy", "afxk_melfused_kind", "afxk_istft", "afxk_istft_fused")]
 
 EMU_UNITS = ("emu_engine", "cqt_emulated_f16", "cwt_emulated_td", "gemm_emulated_bf16", "mel_emulated_v2", "mel_emulated_melfused",
-             "mel_emulated_melfused1k", "mel_emulated_4k2", "mel_emulated_melfused512")
+             "mel_emulated_melfused1k", "mel_emulated_4k2", "mel_emulated_melfused512", "istft_emulated", "stft256_emulated")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang (x86 _Float16 / __bf16 vectors)")
 
@@ -179,6 +179,17 @@ def test_spectrum_kernels_emulated_against_float64(emulated):
     for k in ("k_stft_band_4k2", "k_stft_band_1k", "k_stft_band_512"):
         assert f"emulated {k} 4" in out, out[-1200:]
     assert out.count("mirrors are exact conjugates") == 3, out[-1200:]
+
+
+def test_one_launch_inverse_stft_and_stft256_emulated_against_float64(emulated):
+    """round 6: k_istft_w256 / _wsmall / _w2048 / _w4096 (the inverse of a frame as ONE forward real wave transform of re + im of the
+    Hermitian part; overlap-add in an LDS ring over runs of frames, the frames before a run transformed again for their tails; an
+    output buffer that is not zero; a non-Hermitian part in the input that must not reach the output) and k_stft_256 (two real frames
+    per 256-point complex transform, odd and even frame counts, a mapped bin slice) against numpy in float64; on the device the same
+    kernels meet the compiled reference (tests/test_stft_gpu.py)"""
+    out = _run(emulated, "emulated_istft.py", [])
+    lines = out.splitlines()
+    assert sum(l.startswith("istft n_fft") for l in lines) == 6 and sum(l.startswith("stft n_fft 256") for l in lines) == 3, out[-1500:]
 
 
 def test_f32_matrix_core_octave_kernels_emulated(emulated):
