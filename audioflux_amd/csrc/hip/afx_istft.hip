@@ -630,6 +630,34 @@ __global__ __launch_bounds__(ISW * 64) void k_istft_w256(AfxIstftArgs a, const f
     }
 }
 
+// Frames per run.  A wave walks one run (+ `halo` frames before it) and every wave slot of the device takes one run per round, so a launch
+// costs rounds x (frames per run + halo) frame times: the cheapest (rounds, run length) pair with all runs placed -- 64 clips of 938 frames
+// on 1792 slots as 1920 runs of 32 is two rounds of 35 frame times, as 1792 runs of 34 one round of 37.  Runs never shorter than `least`.
+int frames_per_run(int batch, int T, long long slots, int halo, int least) {
+    long long best = T, bestCost = -1;
+    for (int rounds = 1; rounds <= 8; ++rounds) {
+        const long long perClip = slots * rounds / batch;  // runs a clip may take
+        if (perClip < 1) continue;
+        long long fpr = (T + perClip - 1) / perClip;
+        if (fpr < least) fpr = least;
+        if (fpr > T) fpr = T;
+        const long long runs = (long long)batch * ((T + fpr - 1) / fpr);
+        const long long cost = ((runs + slots - 1) / slots) * (fpr + halo);
+        if (bestCost < 0 || cost < bestCost) {
+            bestCost = cost;
+            best = fpr;
+        }
+    }
+    return (int)best;
+}
+
+// workgroups of `waves` waves and `lds` bytes a CU holds at a time (160 KB of LDS, 32 waves)
+int resident_groups(size_t lds, int waves) {
+    long long g = lds ? (long long)(163840 / lds) : 1;
+    if (g > 32 / waves) g = 32 / waves;
+    return g < 1 ? 1 : (int)g;
+}
+
 // twiddle tables of the small wave transforms, one device copy per device and size (never freed)
 template <class F>
 const float2 *small_tables() {
@@ -661,15 +689,12 @@ int launch_istft_small(const AfxIstftArgs *a, void *stream) {
     if (!tab) return AFX_ERR_UNSUPPORTED;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const long long total = (long long)a->batch * a->timeLength;
-    long long fpr = (total + 2LL * cus * ISW - 1) / (2LL * cus * ISW);
-    if (fpr < 32) fpr = 32;
-    if (fpr > a->timeLength) fpr = a->timeLength;
+    const size_t lds = sizeof(float) * F::N + sizeof(float2) * (size_t)(F::TAB_F2 + ISW * F::EX_F2) + sizeof(float) * F::N * ISW +
+                       sizeof(float) * (size_t)a->hop;
+    const long long fpr = frames_per_run(a->batch, a->timeLength, (long long)cus * ISW * resident_groups(lds, ISW), (F::N - 1) / a->hop, 16);
     const long long runsPerClip = (a->timeLength + fpr - 1) / fpr, runs = runsPerClip * a->batch;
     const long long blocks = (runs + ISW - 1) / ISW;
     if (blocks > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
-    const size_t lds = sizeof(float) * F::N + sizeof(float2) * (size_t)(F::TAB_F2 + ISW * F::EX_F2) + sizeof(float) * F::N * ISW +
-                       sizeof(float) * (size_t)a->hop;
     AFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_istft_wsmall<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_istft_wsmall<F>, dim3((unsigned)blocks), dim3(ISW * 64), lds, (hipStream_t)stream, *a, tab, (int)fpr, (int)runsPerClip);
     AFX_LAUNCH_CHECK("k_istft_wsmall");
@@ -690,10 +715,7 @@ extern "C" int afxk_istft_fused(const AfxIstftArgs *a, void *stream) {
         if (!tab4 || (reinterpret_cast<uintptr_t>(a->re) & 15) || (reinterpret_cast<uintptr_t>(a->im) & 15)) return AFX_ERR_UNSUPPORTED;
         int dev4 = 0, cus4 = 256;
         if (hipGetDevice(&dev4) == hipSuccess) (void)hipDeviceGetAttribute(&cus4, hipDeviceAttributeMultiprocessorCount, dev4);
-        const long long total4 = (long long)a->batch * a->timeLength;
-        long long fpr4 = (total4 + 2LL * cus4 * IW4 - 1) / (2LL * cus4 * IW4);
-        if (fpr4 < 32) fpr4 = 32;
-        if (fpr4 > a->timeLength) fpr4 = a->timeLength;
+        const long long fpr4 = frames_per_run(a->batch, a->timeLength, (long long)cus4 * IW4, 4095 / a->hop, 16);
         const long long rpc4 = (a->timeLength + fpr4 - 1) / fpr4, blocks4 = (rpc4 * a->batch + IW4 - 1) / IW4;
         if (blocks4 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
         const size_t lds4 = sizeof(float) * 4096 + sizeof(float2) * (size_t)(afxw::TAB_F2 + 1032 + IW4 * afxw::EX_F2) + sizeof(float) * 4096 * IW4 +
@@ -712,14 +734,11 @@ extern "C" int afxk_istft_fused(const AfxIstftArgs *a, void *stream) {
         if (!tab8) return AFX_ERR_UNSUPPORTED;
         int dev8 = 0, cus8 = 256;
         if (hipGetDevice(&dev8) == hipSuccess) (void)hipDeviceGetAttribute(&cus8, hipDeviceAttributeMultiprocessorCount, dev8);
-        const long long total8 = (long long)a->batch * a->timeLength;
-        long long fpr8 = (total8 + 2LL * cus8 * ISW - 1) / (2LL * cus8 * ISW);
-        if (fpr8 < 64) fpr8 = 64;
-        if (fpr8 > a->timeLength) fpr8 = a->timeLength;
-        const long long rpc8 = (a->timeLength + fpr8 - 1) / fpr8, blocks8 = (rpc8 * a->batch + ISW - 1) / ISW;
-        if (blocks8 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
         const size_t lds8 = sizeof(float) * 256 + sizeof(float2) * (size_t)(F8::TAB_F2 + ISW * F8::EX_F2) + sizeof(float) * 256 * ISW +
                             sizeof(float) * (size_t)a->hop;
+        const long long fpr8 = frames_per_run(a->batch, a->timeLength, (long long)cus8 * ISW * resident_groups(lds8, ISW), 255 / a->hop, 32);
+        const long long rpc8 = (a->timeLength + fpr8 - 1) / fpr8, blocks8 = (rpc8 * a->batch + ISW - 1) / ISW;
+        if (blocks8 > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k_istft_w256, dim3((unsigned)blocks8), dim3(ISW * 64), lds8, (hipStream_t)stream, *a, tab8, (int)fpr8, (int)rpc8);
         AFX_LAUNCH_CHECK("k_istft_w256");
         return AFX_OK;
@@ -730,10 +749,7 @@ extern "C" int afxk_istft_fused(const AfxIstftArgs *a, void *stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // runs of >= 32 frames (the frames before a run are transformed again for their tails: 3 at hop N / 4), two rounds of waves
-    const long long total = (long long)a->batch * a->timeLength;
-    long long fpr = (total + 2LL * cus * IW - 1) / (2LL * cus * IW);
-    if (fpr < 32) fpr = 32;
-    if (fpr > a->timeLength) fpr = a->timeLength;
+    const long long fpr = frames_per_run(a->batch, a->timeLength, (long long)cus * IW, 2047 / a->hop, 16);
     const long long runsPerClip = (a->timeLength + fpr - 1) / fpr, runs = runsPerClip * a->batch;
     const long long blocks = (runs + IW - 1) / IW;
     if (blocks > 0x7fffffffLL) return AFX_ERR_UNSUPPORTED;
