@@ -21,7 +21,7 @@ DCT-II); it is timed live with HIP events on the stream it is launched on (torch
 handed to the library).  `achieved` = SURVEY 8d's algorithmic bytes per unit x units per launch /
 that duration; `sustained_ms` repeats the step back to back for >= 1 s (sustained clocks, where the
 K-step region of a short run sees boost clocks); `traffic` = HBM bytes per launch from the round's
-own rocprofv3 --pmc passes of this command (profiles/r05_bench_cfg<N>_pmc.json, written by
+own rocprofv3 --pmc passes of this command (profiles/r06_bench_cfg<N>_pmc.json, written by
 tools/prof_traffic.py), null when that file is absent.  After the timed region clip 0 of the
 benchmarked outputs is checked against the oracle (1e-5 peak / L2).
 `secondary` (--config 2 at one GPU, the driver's line): cfg 4 and cfg 5 measured in the same process after the
@@ -238,8 +238,9 @@ class Cfg4:
     dtype = "f32 (36 of 84 scales: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ()
     bound = "matrix+LDS"
-    bound_note = ("the step is the sum of its launches' work: the f16 matrix kernels (time-domain scales) and the LDS-bound narrow-band inverse "
-                  "transforms (LDS pipe 86 % busy) run at the same time and slow each other (profiles/r05_ab_cwt.txt)")
+    bound_note = ("the step is the sum of its launches' work: the f16 matrix kernels (time-domain scales, 44 % of the summed kernel time, matrix pipe "
+                  "45 % busy) and the narrow-band inverse transforms (45 %; their R-term sums on the f32 matrix pipe since round 6: vector unit 47-53 %, "
+                  "no unit saturated) run at the same time on two streams and slow each other (profiles/r06_cwt_phases.txt, r06_cfg4_occupancy.json)")
     GROUP = int(os.environ.get("AFX_CFG4_GROUP", "32"))  # chunks per device call: the [84, 2^16] complex outputs (44 MB per chunk) are ring-buffered
 
     def __init__(self, torch, af, dev, rank, clips):
@@ -298,9 +299,10 @@ class Cfg5:
     dtype = "f32 (octave products: f32 operands as (hi, lo) f16 words on the f16 matrix cores, f32 accumulation)"
     gather_choices = ("chroma", "cqt")
     bound = "matrix+power"
-    bound_note = ("f16 matrix pipe 44 % busy at 1.77 GHz -- the clock a loop of nothing but MFMAs holds on this part (1.78 GHz, "
-                  "profiles/r04_mfma_busy_calibration.txt): the power budget sets the clock, the per-wave chains (planes -> "
-                  "MFMA -> rows) the idle share (profiles/r05_bench_cfg5_compute.json, 557 warm dispatches)")
+    bound_note = ("f16 matrix pipe 44-47 % busy at 1.6-1.8 GHz: on real data the launch is held by its data-dependent power (the same code on zeros / "
+                  "constants holds 2.3-2.4 GHz) and, at full clock, by 3.3 GB per step of poorly shaped traffic (48-byte row pieces, ring write-backs, "
+                  "chroma read-modify-writes) -- both limits within 4 % of each other; the one class worth more than 8 % is the requested output "
+                  "itself (knock-out and price builds, profiles/r06_ko_cqt.txt)")
 
     def __init__(self, torch, af, dev, rank, clips):
         self.torch, self.af, self.clips = torch, af, clips
